@@ -1,0 +1,387 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by IMPORTING the reference (read-only) in this container.
+
+Run here only:   python tools/gen_golden.py            (needs /root/reference)
+The reference's Python never travels to the GPU box; only the vectors written by this
+script do.  Fixtures hold data (seeded inputs, the random draws, expected outputs), never
+reference source text.
+
+Stub modules placed in sys.modules so that the pure-NumPy parts of the reference import:
+  mpi4py (single-rank COMM_WORLD), tensorflow (permissive object; nothing TF is executed),
+  gym / gym.spaces.Box, mujoco_py.MujocoException, pandas.ewma attribute.
+The duck-typed environment handed to the reference RolloutWorker is oracle.env's
+synthetic arm (the reference's own environment, gym_flowers, is not vendored).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('CURIOUS_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+# ----------------------------------------------------------------------------- stubs
+class _Comm:
+    def Get_rank(self): return 0
+    def Get_size(self): return 1
+    def Allreduce(self, src, dst, op=None): dst[...] = src
+    def Bcast(self, buf, root=0): pass
+    def bcast(self, obj, root=0): return obj
+    def scatter(self, objs, root=0): return objs[0]
+    def gather(self, obj, root=0): return [obj]
+    def Abort(self): raise SystemExit(1)
+
+
+class _Permissive(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        m = _Permissive(self.__name__ + '.' + name)
+        setattr(self, name, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return _Permissive('call')
+
+
+def install_stubs():
+    mpi4py = types.ModuleType('mpi4py')
+    MPI = types.ModuleType('mpi4py.MPI')
+    MPI.COMM_WORLD = _Comm()
+    MPI.SUM = 'SUM'
+    mpi4py.MPI = MPI
+    sys.modules['mpi4py'] = mpi4py
+    sys.modules['mpi4py.MPI'] = MPI
+    tf = _Permissive('tensorflow')
+    sys.modules['tensorflow'] = tf
+    for sub in ['contrib', 'contrib.staging', 'python', 'python.client']:
+        sys.modules['tensorflow.' + sub] = getattr(tf, sub.split('.')[0]) if '.' not in sub else _Permissive(sub)
+    gym = types.ModuleType('gym')
+    spaces = types.ModuleType('gym.spaces')
+
+    class Box:
+        def __init__(self, low, high, dtype=np.float32):
+            self.low, self.high = np.asarray(low), np.asarray(high)
+    spaces.Box = Box
+    gym.spaces = spaces
+    gym.make = lambda name: None
+    sys.modules['gym'] = gym
+    sys.modules['gym.spaces'] = spaces
+    mj = types.ModuleType('mujoco_py')
+
+    class MujocoException(Exception):
+        pass
+    mj.MujocoException = MujocoException
+    sys.modules['mujoco_py'] = mj
+    import pandas
+    if not hasattr(pandas, 'ewma'):
+        pandas.ewma = lambda *a, **k: None
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def synth_episodes(rng, E, T, dimo, nb_tasks, dimu=4):
+    """float32-valued synthetic episodes in the reference's buffer layout (SURVEY 8d cfg 2)."""
+    G = AG = 3 * nb_tasks
+    o = np.empty([E, T + 1, dimo], np.float32)
+    o[:, 0] = rng.randn(E, dimo).astype(np.float32)
+    steps = (0.01 * rng.randn(E, T, dimo)).astype(np.float32)
+    # some coordinates stay frozen so that `change` is not all-True
+    frozen = rng.rand(E, 1, dimo) < 0.4
+    steps = np.where(frozen, np.float32(0), steps)
+    for t in range(T):
+        o[:, t + 1] = o[:, t] + steps[:, t]
+    ag = o[:, :, :AG].copy()
+    task = rng.randint(nb_tasks, size=E)
+    td = np.zeros([E, T, nb_tasks], np.float32)
+    td[np.arange(E), :, task] = 1
+    g = np.zeros([E, T, G], np.float32)
+    for e in range(E):
+        sl = slice(3 * task[e], 3 * task[e] + 3)
+        # goals close to the trajectory so that both rewards 0 and -1 occur
+        g[e, :, sl] = ag[e, rng.randint(T + 1), sl] + (0.03 * rng.randn(3)).astype(np.float32)
+    u = rng.uniform(-1, 1, [E, T, dimu]).astype(np.float32)
+    change = (np.abs(ag[:, :1] - ag[:, 1:]) > 1e-3)
+    succ = rng.randint(2, size=[E, T, 1]).astype(np.float32)
+    return dict(o=o, u=u, g=g, ag=ag, task_descr=td, change=change, info_is_success=succ)
+
+
+def to_f64_buffers(ep):
+    """What ReplayBuffer holds: float64 arrays (replay_buffer.py:23) with float32 values."""
+    return {k: v.astype(np.float64) for k, v in ep.items()}
+
+
+def tables(nb_tasks):
+    ids = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(nb_tasks)]
+    return ids, [list(x) for x in ids]
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def flat_dict(prefix, d):
+    return {prefix + k: np.asarray(v) for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_her():
+    from baselines.her import her as ref_her
+    from oracle.reward import make_reward_fun
+    cases = []
+    rng = np.random.RandomState(1234)
+    cfgs = [
+        # name, nb_tasks, dimo, E, T, B, task_replay, goal_replay, task_to_replay, flat
+        ('arm4_buffer_none', 4, 40, 23, 50, 256, 'replay_task_cp_buffer', 'her', None, False),
+        ('arm4_buffer_t2', 4, 40, 23, 50, 256, 'replay_task_cp_buffer', 'her', 2, False),
+        ('arm4_buffer_t0_E1', 4, 40, 1, 50, 64, 'replay_task_random_buffer', 'her', 0, False),
+        ('arm8_buffer_t5', 8, 52, 17, 50, 256, 'replay_task_cp_buffer', 'her', 5, False),
+        ('arm4_current', 4, 40, 11, 50, 128, 'replay_current_task_transition', 'her', None, False),
+        ('arm4_random', 4, 40, 11, 50, 128, 'replay_random_task_transition', 'her', None, False),
+        ('arm4_cp', 4, 40, 11, 50, 128, 'replay_cp_task_transition', 'her', None, False),
+        ('arm4_noher', 4, 40, 9, 50, 96, 'replay_task_cp_buffer', 'none', 1, False),
+        ('arm4_T7_ragged', 4, 19, 5, 7, 33, 'replay_task_cp_buffer', 'her', 3, False),
+        ('arm4_flat', 4, 40, 13, 50, 128, '', 'her', None, True),
+    ]
+    out = {}
+    names = []
+    for i, (name, nb, dimo, E, T, B, task_replay, goal_replay, ttr, flat) in enumerate(cfgs):
+        ag_ids, g_ids = tables(nb)
+        ep = synth_episodes(rng, E, T, dimo, nb)
+        buf = to_f64_buffers(ep)
+        buf['o_2'] = buf['o'][:, 1:, :]
+        buf['ag_2'] = buf['ag'][:, 1:, :]
+        reward = make_reward_fun(ag_ids, g_ids)
+        seed = 100 + i
+        cp_proba = None
+        if task_replay == 'replay_cp_task_transition':
+            cp_proba = np.array([0.5, 0.2, 0.2, 0.1])
+        if flat:
+            fn = ref_her.make_sample_her_transitions(goal_replay, 4, reward, tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+            def reward_flat(ag_2, g, task_descr, info, _r=reward):
+                return _r(ag_2, g, None, info)
+            fn = ref_her.make_sample_her_transitions(goal_replay, 4, reward_flat, tasks_ag_id=ag_ids,
+                                                     tasks_g_id=g_ids)
+        else:
+            fn = ref_her.make_sample_multi_task_her_transitions(goal_replay, 4, task_replay, reward,
+                                                                tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+        np.random.seed(seed)
+        tr = fn(buf, B, task_to_replay=ttr, cp_proba=cp_proba)
+        # the raw draws (same legacy stream, re-drawn) for kernel-level tests
+        rs = np.random.RandomState(seed)
+        d_ep = rs.randint(0, E, B)
+        d_t = rs.randint(T, size=B)
+        d_uher = rs.uniform(size=B)
+        d_uoff = rs.uniform(size=B)
+        names.append(name)
+        out.update(flat_dict(name + '/in/', ep))
+        out.update(flat_dict(name + '/out/', tr))
+        out[name + '/draw/ep'] = d_ep
+        out[name + '/draw/t'] = d_t
+        out[name + '/draw/u_her'] = d_uher
+        out[name + '/draw/u_off'] = d_uoff
+        out[name + '/cfg'] = np.array([nb, dimo, E, T, B, seed, -1 if ttr is None else ttr, int(flat)])
+        out[name + '/task_replay'] = np.array(task_replay)
+        out[name + '/goal_replay'] = np.array(goal_replay)
+        if cp_proba is not None:
+            out[name + '/cp_proba'] = cp_proba
+    out['names'] = np.array(names)
+    save('her', **out)
+
+
+def gen_replay_buffer():
+    from baselines.her import her as ref_her
+    from baselines.her.replay_buffer import ReplayBuffer
+    from oracle.reward import make_reward_fun
+    nb, dimo, T = 4, 40, 10
+    ag_ids, g_ids = tables(nb)
+    reward = make_reward_fun(ag_ids, g_ids)
+    fn = ref_her.make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer', reward,
+                                                        tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, 12), ag=(T + 1, 12), task_descr=(T, nb),
+                  change=(T, 12), info_is_success=(T, 1))
+    rb = ReplayBuffer(shapes, T * 7, T, fn)           # capacity 7 episodes
+    rng = np.random.RandomState(77)
+    incs = [1, 1, 3, 1, 4, 2, 1, 3]                   # crosses the "append -> random" boundary
+    np.random.seed(4242)
+    out = {'incs': np.array(incs)}
+    for step, inc in enumerate(incs):
+        ep = synth_episodes(rng, inc, T, dimo, nb)
+        ep64 = {k: v.astype(np.float64) for k, v in ep.items()}
+        rb.store_episode(ep64)
+        out.update(flat_dict('step%d/in/' % step, ep))
+        out['step%d/current_size' % step] = np.array(rb.get_current_episode_size())
+        out['step%d/n_stored' % step] = np.array(rb.get_transitions_stored())
+        # buffer contents are fully defined only below current_size
+        out['step%d/o_rows' % step] = rb.buffers['o'][:rb.current_size, 0, :3].copy()
+    tr = rb.sample(64, task_to_replay=1)
+    out.update(flat_dict('sample/', tr))
+    for k in rb.buffers:
+        out['final/' + k] = rb.buffers[k][:rb.current_size].copy()
+    out['cfg'] = np.array([nb, dimo, T, 7, 4242])
+    save('replay_buffer', **out)
+
+
+def gen_queues():
+    from baselines.her.queues import CompetenceQueue
+    rng = np.random.RandomState(5)
+    q = CompetenceQueue(window=10)
+    chunks, Cs, CPs, sizes = [], [], [], []
+    for i in range(40):
+        n = rng.randint(0, 4)
+        p = 0.2 + 0.6 * (i / 40.0)
+        ch = (rng.rand(n) < p).astype(np.float64)
+        q.update(ch.tolist())
+        chunks.append(np.concatenate([ch, -np.ones(4 - n)]))
+        Cs.append(q.C)
+        CPs.append(q.CP)
+        sizes.append(q.size)
+    save('queues', chunks=np.array(chunks), C=np.array(Cs, dtype=np.float64), CP=np.array(CPs, dtype=np.float64),
+         size=np.array(sizes), window=np.array(10))
+
+
+class FakePolicy:
+    """Deterministic linear policy + the reference's action post-processing (ddpg.py:147-156),
+    written with np.random so it consumes the global stream like DDPG.get_actions."""
+
+    def __init__(self, A, max_u=1.0):
+        self.A = A
+        self.max_u = max_u
+
+    def get_actions(self, o, ag, g, task_descr=None, noise_eps=0., random_eps=0., use_target_net=False,
+                    compute_Q=False):
+        x = np.concatenate([o.reshape(len(o), -1), g.reshape(len(g), -1), task_descr.reshape(len(o), -1)], axis=1)
+        u = 0.1 * np.tanh(x.astype(np.float64) @ self.A)
+        # goal-directed on the gripper slots so that the Reach task succeeds now and then
+        gg = g.reshape(len(g), -1)
+        u[:, :3] += 4.0 * (gg[:, :3] - o.reshape(len(o), -1)[:, :3]) * (gg[:, :1] > 0)   # fails for half the goals
+        Q = u.sum(axis=1, keepdims=True)
+        noise = noise_eps * self.max_u * np.random.randn(*u.shape)
+        u = u + noise
+        u = np.clip(u, -self.max_u, self.max_u)
+        u += np.random.binomial(1, random_eps, u.shape[0]).reshape(-1, 1) * (
+            np.random.uniform(low=-self.max_u, high=self.max_u, size=u.shape) - u)
+        if u.shape[0] == 1:
+            u = u[0]
+        return [u.copy(), Q] if compute_Q else u.copy()
+
+
+def gen_rollout():
+    from baselines.her.rollout import RolloutWorker
+    from baselines import logger
+    from oracle.env import SyntheticMultiTaskArm
+    nb, dimo, T, B = 4, 40, 25, 3
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    rngA = np.random.RandomState(9)
+    A = (0.5 * rngA.randn(dimo + 12 + nb, 4))
+    out = {'A': A, 'cfg': np.array([nb, dimo, T, B])}
+    for mode, (eval_, task_sel) in {'train': (False, 'active_competence_progress'),
+                                    'eval': (True, 'active_competence_progress')}.items():
+        counter = [0]
+
+        def make_env():
+            e = SyntheticMultiTaskArm(nb, dimo, T, seed=0, env_id=counter[0])
+            counter[0] += 1
+            return e
+        np.random.seed(31337)
+        w = RolloutWorker(make_env, FakePolicy(A), dims, logger, T=T, rollout_batch_size=B,
+                          exploit=eval_, use_target_net=False, compute_Q=eval_, noise_eps=0.2,
+                          random_eps=0.3, structure='curious', task_selection=task_sel,
+                          goal_selection='random', queue_length=4, eval=eval_)
+        w.seed(555)
+        n_cycles = 80
+        for c in range(n_cycles):
+            ep, CP, n_ep = w.generate_rollouts()
+            if c in (0, 1, n_cycles - 1):
+                out.update(flat_dict('%s/cycle%d/' % (mode, c), ep))
+            out['%s/CP%d' % (mode, c)] = np.asarray(CP, dtype=np.float64)
+            out['%s/p%d' % (mode, c)] = np.asarray(w.p, dtype=np.float64)
+            out['%s/C%d' % (mode, c)] = np.asarray(w.C, dtype=np.float64)
+            out['%s/exploit%d' % (mode, c)] = np.array(bool(w.exploit))
+            out['%s/n_ep%d' % (mode, c)] = np.array(n_ep)
+        out['%s/success_rate' % mode] = np.array(w.current_success_rate())
+        if eval_:
+            out['%s/mean_Q' % mode] = np.array(w.current_mean_Q())
+        out['%s/n_cycles' % mode] = np.array(n_cycles)
+    save('rollout', **out)
+
+
+def gen_adam():
+    from baselines.common.mpi_adam import MpiAdam
+    rng = np.random.RandomState(3)
+    P = 1000
+    theta0 = rng.randn(P).astype(np.float32)
+    ad = object.__new__(MpiAdam)
+    ad.beta1, ad.beta2, ad.epsilon, ad.scale_grad_by_procs = 0.9, 0.999, 1e-08, False
+    ad.m = np.zeros(P, 'float32')
+    ad.v = np.zeros(P, 'float32')
+    ad.t = 0
+    store = {'theta': theta0.copy()}
+    ad.getflat = lambda: store['theta']
+    ad.setfromflat = lambda x: store.__setitem__('theta', np.asarray(x).astype(np.float32))   # TF var is float32
+    from mpi4py import MPI
+    ad.comm = MPI.COMM_WORLD
+    grads, thetas, ms, vs = [], [], [], []
+    for k in range(12):
+        g = (rng.randn(P) * (10.0 ** rng.randint(-6, 2))).astype(np.float32)
+        ad.update(g, 1e-3)
+        grads.append(g)
+        thetas.append(store['theta'].copy())
+        ms.append(ad.m.copy())
+        vs.append(ad.v.copy())
+    save('adam', theta0=theta0, grads=np.array(grads), thetas=np.array(thetas), ms=np.array(ms), vs=np.array(vs),
+         numpy_version=np.array(np.__version__))
+
+
+def gen_normalizer():
+    from baselines.her.normalizer import Normalizer
+    rng = np.random.RandomState(8)
+    size = 12
+    nz = object.__new__(Normalizer)
+    nz.size = size
+    nz.local_sum = np.zeros(size, np.float32)
+    nz.local_sumsq = np.zeros(size, np.float32)
+    nz.local_count = np.zeros(1, np.float32)
+    import threading
+    nz.lock = threading.Lock()
+    vs, sums, sumsqs, counts = [], [], [], []
+    for k in range(5):
+        v = (rng.randn(37, size) * 3).astype(np.float32).astype(np.float64)
+        nz.update(v)
+        vs.append(v)
+        s, ss, c = nz.synchronize(nz.local_sum.copy(), nz.local_sumsq.copy(), nz.local_count.copy())
+        sums.append(s)
+        sumsqs.append(ss)
+        counts.append(c)
+    save('normalizer', vs=np.array(vs), sums=np.array(sums), sumsqs=np.array(sumsqs), counts=np.array(counts))
+
+
+def gen_mpi_moments():
+    from baselines.common.mpi_moments import mpi_moments
+    rng = np.random.RandomState(2)
+    xs, means, stds = [], [], []
+    for k in range(4):
+        x = rng.randn(7)
+        mean, std, count = mpi_moments(x)
+        xs.append(x)
+        means.append(mean)
+        stds.append(std)
+    save('mpi_moments', xs=np.array(xs), means=np.array(means), stds=np.array(stds))
+
+
+if __name__ == '__main__':
+    install_stubs()
+    gen_her()
+    gen_replay_buffer()
+    gen_queues()
+    gen_rollout()
+    gen_adam()
+    gen_normalizer()
+    gen_mpi_moments()
