@@ -1,0 +1,158 @@
+"""ctypes binding of libcurious_hip.so (the C ABI declared in include/curious_hip.h).
+
+The product path has no CPU fallback: `lib()` raises if the shared library has not been built
+(`python -m curious_amd.build`) and every wrapper raises `CuriousHipError` on a non-zero status.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
+
+MAX_TASKS = 16
+MAX_TASK_DIMS = 8
+
+RELABEL_BUFFER_TASK, RELABEL_GIVEN_TASK, RELABEL_CURRENT_TASK, RELABEL_FLAT = 0, 1, 2, 3
+
+
+class CuriousHipError(RuntimeError):
+    pass
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ['T', 'dimo', 'dimag', 'dimg', 'dimu', 'dimtd', 'dimextra',
+                 'off_o', 'off_ag', 'off_g', 'off_u', 'off_td', 'off_extra', 'row_stride']]
+
+
+class BatchLayout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ['off_o', 'off_td', 'off_u', 'off_g', 'off_o2', 'off_g2', 'off_r', 'off_ag', 'off_ag2',
+                 'off_extra', 'stride']]
+
+
+class Tasks(C.Structure):
+    _fields_ = [('ntasks', C.c_int32), ('len', C.c_int32 * MAX_TASKS),
+                ('g_id', (C.c_int32 * MAX_TASK_DIMS) * MAX_TASKS),
+                ('ag_id', (C.c_int32 * MAX_TASK_DIMS) * MAX_TASKS)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [('future_p', C.c_double), ('reward_eps', C.c_double), ('clip_obs', C.c_float),
+                ('relative_goals', C.c_int32), ('relabel_mode', C.c_int32), ('flat_reward', C.c_int32)]
+
+
+class SamplePlan(C.Structure):
+    _fields_ = [('buf', C.c_void_p), ('ep', C.c_void_p), ('t', C.c_void_p), ('u_her', C.c_void_p),
+                ('u_off', C.c_void_p), ('task_to_replay', C.c_void_p), ('out_row', C.c_void_p)]
+
+
+class SampleRng(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('step_ctr', C.c_void_p), ('step_host', C.c_int64),
+                ('prop_prefix', C.c_void_p), ('cur_size', C.c_void_p), ('buf_alias', C.c_void_p),
+                ('buf_task', C.c_void_p), ('nbuf', C.c_int32)]
+
+
+class NetCfg(C.Structure):
+    _fields_ = [('dimo', C.c_int32), ('dimg', C.c_int32), ('dimu', C.c_int32), ('dimtd', C.c_int32),
+                ('hidden', C.c_int32), ('layers', C.c_int32), ('modular', C.c_int32),
+                ('max_u', C.c_float), ('gamma', C.c_float), ('clip_return', C.c_float), ('action_l2', C.c_float),
+                ('clip_pos_returns', C.c_int32), ('normalize_obs', C.c_int32), ('norm_clip', C.c_float)]
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [('ntasks', C.c_int32), ('dimo', C.c_int32), ('T', C.c_int32), ('seed', C.c_uint64)]
+
+
+_P = C.c_void_p
+_I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); every symbol include/curious_hip.h declares
+PROTOTYPES = {
+    'curious_last_error': (C.c_char_p, []),
+    'curious_abi_version': (C.c_int, []),
+    'curious_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
+                                     C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
+                                     _P]),
+    'curious_store_episodes': (C.c_int, [_P, _P, C.POINTER(Layout), _P, _P, _I32, _P]),
+    'curious_episode_activity': (C.c_int, [_P, C.POINTER(Layout), C.POINTER(Tasks), _I32, _I32, _P, _P]),
+    'curious_norm_update': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'curious_norm_scratch_doubles': (_I64, [_I32, _I32]),
+    'curious_norm_recompute': (C.c_int, [_P, _P, _I32, _F, _F, _P]),
+    'curious_param_count_Q': (_I64, [C.POINTER(NetCfg)]),
+    'curious_param_count_pi': (_I64, [C.POINTER(NetCfg)]),
+    'curious_param_offset_pi': (_I64, [C.POINTER(NetCfg)]),
+    'curious_param_total': (_I64, [C.POINTER(NetCfg)]),
+    'curious_workspace_floats': (_I64, [C.POINTER(NetCfg), _I32]),
+    'curious_ddpg_grads': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
+                                     _P, _P, _P, _P]),
+    'curious_policy_forward': (C.c_int, [C.POINTER(NetCfg), _P, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _F,
+                                         _I32, _P, _P, _P, _P, _P, _P]),
+    'curious_action_noise': (C.c_int, [_P, _I32, _I32, _I32, _D, _D, _D, _P, _P, _P, _U64, _U64, _P]),
+    'curious_adam_update': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, C.POINTER(C.c_float), _F, _F,
+                                      _F, _F, _F, _P]),
+    'curious_polyak_update': (C.c_int, [_P, _P, _I64, _F, _F, _P]),
+    'curious_param_checksum': (C.c_int, [_P, _I64, _P, _P]),
+    'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,
+                                    _P, _P]),
+    'curious_env_step': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _I32, _I32, _P,
+                                   _P, _P, _P, _P, _I32, _I32, _D, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises (loudly) when it is missing -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CuriousHipError(
+                'libcurious_hip.so is not built (%s). Run `python -m curious_amd.build` '
+                '(hipcc --offload-arch=gfx950); curious_amd has no CPU fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)            # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.curious_abi_version() != 1:
+            raise CuriousHipError('libcurious_hip ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().curious_last_error()
+        raise CuriousHipError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None as c_void_p value."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_tasks(tasks_ag_id, tasks_g_id):
+    nb = len(tasks_g_id)
+    if nb > MAX_TASKS:
+        raise CuriousHipError('at most %d tasks are supported' % MAX_TASKS)
+    t = Tasks()
+    t.ntasks = nb
+    for j in range(nb):
+        g_ids = list(tasks_g_id[j])
+        ag_ids = list(tasks_ag_id[j])[:len(g_ids)]      # her.py:148-149
+        if len(g_ids) > MAX_TASK_DIMS:
+            raise CuriousHipError('at most %d goal dims per task are supported' % MAX_TASK_DIMS)
+        t.len[j] = len(g_ids)
+        for k, (a, b) in enumerate(zip(ag_ids, g_ids)):
+            t.ag_id[j][k] = int(a)
+            t.g_id[j][k] = int(b)
+    return t

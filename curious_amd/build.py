@@ -1,0 +1,55 @@
+"""Build libcurious_hip.so (gfx950) in-tree with hipcc.  `python -m curious_amd.build [--force]`."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libcurious_hip.so')
+SOURCES = ['api.cpp', 'her_sample.hip', 'store.hip', 'normalizer.hip', 'optim.hip', 'actor.hip', 'env.hip', 'mlp.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(os.path.dirname(HERE), 'include', 'curious_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+         '-x', 'hip']
+
+
+def _digest():
+    h = hashlib.sha256()
+    for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, 'build.sha256')
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(LIBDIR, s.rsplit('.', 1)[0] + '.o')
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s' % s)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,70 @@
+// Shared device/host helpers for libcurious_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/curious_hip.h"
+
+#define CURIOUS_WAVE 64
+
+void curious_set_error(const char* fmt, ...);
+
+#define CURIOUS_CHECK(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      curious_set_error(__VA_ARGS__);     \
+      return -1;                          \
+    }                                     \
+  } while (0)
+
+#define CURIOUS_LAUNCH_CHECK(name)                                                   \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      curious_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return -2;                                                                     \
+    }                                                                                \
+  } while (0)
+
+// ---------------------------------------------------------------- Philox4x32-10 (matches oracle/env.py)
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o = {c0, c1, c2, c3};
+  return o;
+}
+
+// uint32 -> float32 uniform in [0,1): top 24 bits * 2^-24 (exact)
+__host__ __device__ inline float u01_f32(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }
+// two uint32 -> float64 uniform in [0,1) with 53 bits (NumPy's random_sample recipe)
+__host__ __device__ inline double u01_f64(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// non-contracted float32 arithmetic (bit parity with NumPy: one rounding per operation)
+__device__ inline float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ inline float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ inline float fsub(float a, float b) { return __fsub_rn(a, b); }
+// IEEE division / sqrt: hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt makes `/` and sqrtf correctly
+// rounded; the __fdiv_rn / __fsqrt_rn intrinsics lower to native (approximate) instructions on AMD.
+__device__ inline float fdiv(float a, float b) { return a / b; }
+__device__ inline float fclip(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+static inline hipStream_t as_stream(curious_stream_t s) { return (hipStream_t)s; }

@@ -1,0 +1,141 @@
+// K12: batched synthetic MultiTaskFetchArm stand-in (reset + step) writing the episode record in place.
+//
+// Replaces (reference): the per-env Python loop around env.reset/reset_task_goal/env.step and the list
+// appends + `change` flag of RolloutWorker rollout.py:107-143,244-303, for the synthetic environment
+// specified in oracle/env.py (the reference's MuJoCo envs live in the un-vendored gym_flowers package).
+// float32 arithmetic with single-rounding ops and Philox4x32-10 streams: bit-exact with oracle/env.py.
+#include "common.h"
+
+#define STREAM_RESET 1u
+#define STREAM_DISTRACT 2u
+
+__global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_t env_id0,
+                                 const int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
+                                 const float* __restrict__ goals_raw, int32_t n, float* __restrict__ o,
+                                 float* __restrict__ ag, float* __restrict__ g, float* __restrict__ td,
+                                 float* __restrict__ staging) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int AG = 3 * E.ntasks;
+  float* oe = o + (int64_t)e * E.dimo;
+  float* row0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
+  for (int i = 0; i < E.dimo; ++i) oe[i] = 0.0f;
+  for (int s = 0; s < (AG + 3) / 4; ++s) {
+    Philox4 r = philox4x32((uint32_t)(env_id0 + e), (uint32_t)episode[e], (uint32_t)s, STREAM_RESET,
+                           (uint32_t)E.seed, (uint32_t)(E.seed >> 32));
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    for (int k = 0; k < 4; ++k) {
+      int i = 4 * s + k;
+      if (i < AG) {
+        float lo = (i < 3) ? -0.1f : -0.6f, wid = (i < 3) ? 0.2f : 1.2f;
+        oe[i] = __fadd_rn(lo, __fmul_rn(wid, u01_f32(w[k])));
+      }
+    }
+  }
+  const int task = tasks[e];
+  for (int i = 0; i < AG; ++i) {
+    ag[(int64_t)e * AG + i] = oe[i];
+    g[(int64_t)e * AG + i] = 0.0f;
+  }
+  for (int k = 0; k < 3; ++k) g[(int64_t)e * AG + 3 * task + k] = __fmul_rn(0.5f, goals_raw[e * 3 + k]);
+  for (int j = 0; j < E.ntasks; ++j) td[(int64_t)e * E.ntasks + j] = (j == task) ? 1.0f : 0.0f;
+  for (int i = 0; i < E.dimo; ++i) row0[L.off_o + i] = oe[i];
+  for (int i = 0; i < AG; ++i) row0[L.off_ag + i] = oe[i];
+}
+
+extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                 const int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                                 float* o, float* ag, float* g, float* td, float* staging,
+                                 curious_stream_t stream) {
+  CURIOUS_CHECK(E && L && episode && tasks && goals_raw && o && ag && g && td && staging,
+                "curious_env_reset: NULL argument");
+  CURIOUS_CHECK(L->dimo == E->dimo && L->dimag == 3 * E->ntasks && L->dimg == 3 * E->ntasks &&
+                    L->dimtd == E->ntasks && L->dimu == 4 && E->dimo >= 3 * E->ntasks + 4,
+                "curious_env_reset: layout does not match the synthetic env");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(env_reset_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
+                     tasks, goals_raw, n, o, ag, g, td, staging);
+  CURIOUS_LAUNCH_CHECK("env_reset_kernel");
+  return 0;
+}
+
+__global__ void env_step_kernel(curious_env_cfg_t E, curious_layout_t L, int32_t env_id0,
+                                const int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
+                                const float* __restrict__ u, int32_t ldu, int32_t t, int32_t n,
+                                float* __restrict__ o, float* __restrict__ ag, const float* __restrict__ g,
+                                const float* __restrict__ td, float* __restrict__ staging, int32_t off_change,
+                                int32_t off_success, double reward_eps) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int AG = 3 * E.ntasks;
+  float* oe = o + (int64_t)e * E.dimo;
+  const float* ue = u + (int64_t)e * ldu;
+  float* ep0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
+  float* row = ep0 + (int64_t)t * L.row_stride;
+  float* nxt = row + L.row_stride;
+  float uc[4];
+  for (int k = 0; k < 4; ++k) uc[k] = fclip(ue[k], -1.0f, 1.0f);
+  float grip[3], ng[3], delta[3];
+  for (int k = 0; k < 3; ++k) {
+    grip[k] = oe[k];
+    ng[k] = fclip(__fadd_rn(grip[k], __fmul_rn(0.05f, uc[k])), -1.0f, 1.0f);
+    delta[k] = __fsub_rn(ng[k], grip[k]);
+  }
+  for (int j = 1; j < E.ntasks; ++j) {
+    float* obj = oe + 3 * j;
+    if (j < 4) {
+      float d = fmaxf(fmaxf(fabsf(__fsub_rn(grip[0], obj[0])), fabsf(__fsub_rn(grip[1], obj[1]))),
+                      fabsf(__fsub_rn(grip[2], obj[2])));
+      if (d < 0.1f && uc[3] < 0.0f)
+        for (int k = 0; k < 3; ++k) obj[k] = fclip(__fadd_rn(obj[k], delta[k]), -1.0f, 1.0f);
+    } else {
+      Philox4 r = philox4x32((uint32_t)(env_id0 + e), (uint32_t)(episode[e] - 1), (uint32_t)(t * E.ntasks + j),
+                             STREAM_DISTRACT, (uint32_t)E.seed, (uint32_t)(E.seed >> 32));
+      uint32_t w[3] = {r.x, r.y, r.z};
+      for (int k = 0; k < 3; ++k) {
+        float st = __fmul_rn(0.01f, __fsub_rn(__fmul_rn(2.0f, u01_f32(w[k])), 1.0f));
+        obj[k] = fclip(__fadd_rn(obj[k], st), -1.0f, 1.0f);
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    oe[k] = ng[k];
+    oe[AG + k] = delta[k];
+  }
+  oe[AG + 3] = uc[3];
+  // record row t: u, g, td, change, is_success (rollout.py:273-284,290-303); row t+1: o, ag
+  const float* ge = g + (int64_t)e * AG;
+  const float* tde = td + (int64_t)e * E.ntasks;
+  for (int k = 0; k < L.dimu; ++k) row[L.off_u + k] = ue[k];
+  for (int i = 0; i < AG; ++i) row[L.off_g + i] = ge[i];
+  for (int j = 0; j < E.ntasks; ++j) row[L.off_td + j] = tde[j];
+  for (int i = 0; i < AG; ++i) {
+    float a = oe[i];
+    ag[(int64_t)e * AG + i] = a;
+    nxt[L.off_ag + i] = a;
+    row[off_change + i] = (fabsf(__fsub_rn(ep0[L.off_ag + i], a)) > 1e-3f) ? 1.0f : 0.0f;   // rollout.py:284
+  }
+  for (int i = 0; i < E.dimo; ++i) nxt[L.off_o + i] = oe[i];
+  // is_success = (reward == 0) for the env's own task and goal (oracle/env.py step)
+  const int task = tasks[e];
+  double d2 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double d = __dsub_rn((double)oe[3 * task + k], (double)ge[3 * task + k]);
+    d2 = __dadd_rn(d2, __dmul_rn(d, d));
+  }
+  row[off_success] = (sqrt(d2) > reward_eps) ? 0.0f : 1.0f;
+}
+
+extern "C" int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                const int32_t* episode, const int32_t* tasks, const float* u, int32_t ldu, int32_t t,
+                                int32_t n, float* o, float* ag, const float* g, const float* td, float* staging,
+                                int32_t off_change, int32_t off_success, double reward_eps,
+                                curious_stream_t stream) {
+  CURIOUS_CHECK(E && L && episode && tasks && u && o && ag && g && td && staging, "curious_env_step: NULL argument");
+  CURIOUS_CHECK(t >= 0 && t < L->T, "curious_env_step: t out of range");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(env_step_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
+                     tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps);
+  CURIOUS_LAUNCH_CHECK("env_step_kernel");
+  return 0;
+}

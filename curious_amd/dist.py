@@ -1,0 +1,95 @@
+"""One process per GPU over RCCL/xGMI: the collectives that replace the reference's mpi4py calls.
+
+Reference call sites: C1/C2 MpiAdam Allreduce(SUM) mpi_adam.py:26; C3 Bcast mpi_adam.py:39; C4
+check_synced mpi_adam.py:42-50; C5 Normalizer._mpi_average normalizer.py:84-94; C9 competence gathers
+rollout.py:332-336; C11 mpi_moments.py:16.  `torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used for
+the CPU tests of this layer.  With a single process every function is the identity.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+
+def is_distributed():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def rank():
+    return td.get_rank() if (td.is_available() and td.is_initialized()) else 0
+
+
+def world_size():
+    return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for 1 rank."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or (td.is_available() and td.is_initialized()):
+        return
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    td.init_process_group(backend=backend)
+
+
+def allreduce_sum_(t):
+    """In-place SUM over ranks of a tensor (GPU: RCCL all-reduce on the current stream)."""
+    if is_distributed():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def broadcast_(t, root=0):
+    if is_distributed():
+        td.broadcast(t, src=root)
+    return t
+
+
+def allgather(t):
+    """[n, ...] per rank -> [world*n, ...] in rank order."""
+    if not is_distributed():
+        return t
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    td.all_gather(out, t.contiguous())
+    return torch.cat(out, dim=0)
+
+
+def _comm_device():
+    if is_distributed() and td.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def allreduce_sum_numpy(x):
+    """Small host arrays (log scalars, C11)."""
+    if not is_distributed():
+        return x
+    t = torch.as_tensor(np.asarray(x, dtype=np.float64)).to(_comm_device())
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def allgather_numpy(x):
+    """[n, ...] host array per rank -> [world*n, ...] (C9)."""
+    if not is_distributed():
+        return np.asarray(x)
+    t = torch.as_tensor(np.ascontiguousarray(x)).to(_comm_device())
+    return allgather(t).cpu().numpy()
+
+
+def broadcast_object(obj, root=0):
+    if not is_distributed():
+        return obj
+    box = [obj]
+    td.broadcast_object_list(box, src=root)
+    return box[0]
+
+
+def barrier():
+    if is_distributed():
+        td.barrier()

@@ -1,0 +1,201 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of include/curious_hip.h).
+
+Tensors must live on the GPU (`cuda` device of PyTorch-ROCm); PyTorch is only the allocator / stream
+provider here.  All calls enqueue on torch's current stream and never synchronise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from curious_amd import _lib
+from curious_amd._lib import check, current_stream, lib, ptr
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.CuriousHipError('%s must be a GPU tensor (curious_amd has no CPU path)' % name)
+    return t
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int(0)
+    check(lib().curious_device_info(name, 256, C.byref(cu)), 'curious_device_info')
+    return name.value.decode(), cu.value
+
+
+def her_sample(storage, buf_stride, layout, tasks, params, n, batch, plan=None, rng=None):
+    """storage: float32 GPU tensor holding [nbuf][capacity][T+1][row_stride]; batch: [n, batch_stride]."""
+    _dev(storage, 'storage')
+    _dev(batch, 'batch')
+    L = layout.c_layout()
+    BL = layout.c_batch_layout()
+    assert batch.stride(0) == BL.stride and batch.shape[0] >= n
+    check(lib().curious_her_sample(ptr(storage), int(buf_stride), C.byref(L), C.byref(tasks), C.byref(params),
+                                   C.byref(plan) if plan is not None else None,
+                                   C.byref(rng) if rng is not None else None,
+                                   int(n), ptr(batch), C.byref(BL), current_stream()), 'curious_her_sample')
+
+
+def make_plan(ep, t, u_her, u_off, buf=None, task_to_replay=None, out_row=None):
+    """Device arrays -> SamplePlan (keeps references alive on the returned object)."""
+    p = _lib.SamplePlan()
+    p._keep = (ep, t, u_her, u_off, buf, task_to_replay, out_row)
+    assert ep.dtype == torch.int32 and t.dtype == torch.int32
+    assert u_her.dtype == torch.float64 and u_off.dtype == torch.float64
+    p.ep, p.t, p.u_her, p.u_off = ep.data_ptr(), t.data_ptr(), u_her.data_ptr(), u_off.data_ptr()
+    p.buf = buf.data_ptr() if buf is not None else None
+    p.task_to_replay = task_to_replay.data_ptr() if task_to_replay is not None else None
+    p.out_row = out_row.data_ptr() if out_row is not None else None
+    return p
+
+
+def store_episodes(storage, staging, layout, pair_src, pair_dst):
+    _dev(storage, 'storage')
+    _dev(staging, 'staging')
+    assert pair_src.dtype == torch.int32 and pair_dst.dtype == torch.int64
+    L = layout.c_layout()
+    check(lib().curious_store_episodes(ptr(storage), ptr(staging), C.byref(L), ptr(pair_src), ptr(pair_dst),
+                                       int(pair_src.numel()), current_stream()), 'curious_store_episodes')
+
+
+def episode_activity(staging, layout, tasks, n_episodes, active):
+    L = layout.c_layout()
+    check(lib().curious_episode_activity(ptr(_dev(staging, 'staging')), C.byref(L), C.byref(tasks),
+                                         int(layout.off['change']), int(n_episodes), ptr(active),
+                                         current_stream()), 'curious_episode_activity')
+
+
+def norm_scratch_doubles(n_rows, dim):
+    return int(lib().curious_norm_scratch_doubles(int(n_rows), int(dim)))
+
+
+def norm_update(rows, n_rows, stride, col_off, dim, acc, scratch):
+    check(lib().curious_norm_update(ptr(_dev(rows, 'rows')), int(n_rows), int(stride), int(col_off), int(dim),
+                                    ptr(acc), ptr(scratch), current_stream()), 'curious_norm_update')
+
+
+def norm_recompute(acc, state, dim, world_size, eps):
+    check(lib().curious_norm_recompute(ptr(_dev(acc, 'acc')), ptr(state), int(dim), float(world_size), float(eps),
+                                       current_stream()), 'curious_norm_recompute')
+
+
+def make_net_cfg(dimo, dimg, dimu, dimtd, hidden, layers, modular, max_u, gamma, clip_return, action_l2,
+                 clip_pos_returns=True, normalize_obs=False, norm_clip=5.0):
+    c = _lib.NetCfg()
+    c.dimo, c.dimg, c.dimu, c.dimtd, c.hidden, c.layers = dimo, dimg, dimu, dimtd, hidden, layers
+    c.modular = int(bool(modular))
+    c.max_u, c.gamma, c.action_l2 = float(max_u), float(gamma), float(action_l2)
+    c.clip_return = float(min(clip_return, 3.0e38))
+    c.clip_pos_returns, c.normalize_obs, c.norm_clip = int(bool(clip_pos_returns)), int(bool(normalize_obs)), \
+        float(min(norm_clip, 3.0e38))
+    return c
+
+
+def param_counts(cfg):
+    return int(lib().curious_param_count_Q(C.byref(cfg))), int(lib().curious_param_count_pi(C.byref(cfg)))
+
+
+def param_layout(cfg):
+    """(P_Q, P_pi, offset of theta_pi, total floats) of the padded parameter vector."""
+    return (int(lib().curious_param_count_Q(C.byref(cfg))), int(lib().curious_param_count_pi(C.byref(cfg))),
+            int(lib().curious_param_offset_pi(C.byref(cfg))), int(lib().curious_param_total(C.byref(cfg))))
+
+
+def pad_params(cfg, flat):
+    """Reference flat vector [theta_Q | theta_pi] (NumPy) -> padded layout (NumPy float32)."""
+    PQ, Ppi, off, total = param_layout(cfg)
+    flat = np.asarray(flat, dtype=np.float32)
+    assert flat.shape[0] == PQ + Ppi
+    out = np.zeros(total, np.float32)
+    out[:PQ] = flat[:PQ]
+    out[off:off + Ppi] = flat[PQ:]
+    return out
+
+
+def unpad_params(cfg, padded):
+    PQ, Ppi, off, total = param_layout(cfg)
+    padded = np.asarray(padded)
+    return np.concatenate([padded[:PQ], padded[off:off + Ppi]])
+
+
+def workspace_floats(cfg, B):
+    return int(lib().curious_workspace_floats(C.byref(cfg), int(B)))
+
+
+def ddpg_grads(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi,
+               o_stats=None, g_stats=None, step_ctr=None):
+    BL = layout.c_batch_layout()
+    check(lib().curious_ddpg_grads(C.byref(cfg), ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
+                                   ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
+                                   ptr(workspace), ptr(grad), ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr),
+                                   current_stream()), 'curious_ddpg_grads')
+
+
+def policy_forward(cfg, theta, o, g, td, n, clip_obs, workspace, out_pi, out_Q=None, ag=None,
+                   relative_goals=False, o_stats=None, g_stats=None):
+    _dev(o, 'o')
+    check(lib().curious_policy_forward(C.byref(cfg), ptr(_dev(theta, 'theta')), ptr(o), int(o.stride(0)),
+                                       ptr(ag), int(ag.stride(0)) if ag is not None else 0, ptr(g),
+                                       int(g.stride(0)), ptr(td), int(td.stride(0)) if td is not None else 0,
+                                       int(n), float(clip_obs), int(bool(relative_goals)), ptr(o_stats),
+                                       ptr(g_stats), ptr(workspace), ptr(out_pi), ptr(out_Q), current_stream()),
+          'curious_policy_forward')
+
+
+def action_noise(u, n, dimu, noise_scale, random_eps, max_u, randn=None, binom=None, unif=None, seed=0, counter=0):
+    check(lib().curious_action_noise(ptr(_dev(u, 'u')), int(u.stride(0)), int(n), int(dimu), float(noise_scale),
+                                     float(random_eps), float(max_u), ptr(randn), ptr(binom), ptr(unif),
+                                     int(seed), int(counter), current_stream()), 'curious_action_noise')
+
+
+def adam_alpha(stepsize, t, beta1=0.9, beta2=0.999):
+    """mpi_adam.py:30 in float64, rounded to float32 the way NumPy 1.x multiplies it into float32 arrays."""
+    return np.float32(stepsize * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t))
+
+
+def adam_update(theta, m, v, grad, n_Q, n_pi, alpha_Q=None, alpha_pi=None, beta1=0.9, beta2=0.999, epsilon=1e-08,
+                alpha_tab=None, step_ctr=None, tab_base=0):
+    f = np.float32
+    ah = None
+    if alpha_tab is None:
+        ah = (C.c_float * 2)(float(alpha_Q), float(alpha_pi if alpha_pi is not None else 0.0))
+    check(lib().curious_adam_update(ptr(_dev(theta, 'theta')), ptr(m), ptr(v), ptr(grad), int(n_Q), int(n_pi),
+                                    ptr(alpha_tab), ptr(step_ctr), int(tab_base),
+                                    int(alpha_tab.shape[0]) if alpha_tab is not None else 0, ah,
+                                    float(f(beta1)), float(f(1 - beta1)), float(f(beta2)), float(f(1 - beta2)),
+                                    float(f(epsilon)), current_stream()), 'curious_adam_update')
+
+
+def polyak_update(target, main, polyak):
+    f = np.float32
+    check(lib().curious_polyak_update(ptr(_dev(target, 'target')), ptr(main), int(target.numel()),
+                                      float(f(polyak)), float(f(1. - polyak)), current_stream()),
+          'curious_polyak_update')
+
+
+def param_checksum(theta, out):
+    check(lib().curious_param_checksum(ptr(_dev(theta, 'theta')), int(theta.numel()), ptr(out), current_stream()),
+          'curious_param_checksum')
+
+
+def make_env_cfg(ntasks, dimo, T, seed):
+    e = _lib.EnvCfg()
+    e.ntasks, e.dimo, e.T, e.seed = int(ntasks), int(dimo), int(T), int(seed) & 0xFFFFFFFFFFFFFFFF
+    return e
+
+
+def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging):
+    L = layout.c_layout()
+    check(lib().curious_env_reset(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks),
+                                  ptr(goals_raw), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
+                                  current_stream()), 'curious_env_reset')
+
+
+def env_step(ecfg, layout, env_id0, episode, tasks, u, t, n, o, ag, g, td, staging, reward_eps):
+    L = layout.c_layout()
+    check(lib().curious_env_step(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), ptr(u),
+                                 int(u.stride(0)), int(t), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
+                                 int(layout.off['change']), int(layout.off['info_is_success']), float(reward_eps),
+                                 current_stream()), 'curious_env_step')

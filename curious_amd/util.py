@@ -1,0 +1,79 @@
+"""Small helpers on the hot path.  Mirrors baselines/her/util.py:13-53,129-191 (TF-free parts)."""
+import functools
+import importlib
+import inspect
+import os
+
+import numpy as np
+
+from curious_amd import dist
+
+# The reference resolves plugin strings "pkg.module:name" (util.py:40-46).  Its own strings are mapped onto the
+# MI355X-native counterparts so that existing parameter dicts (config.py:26,50,60,84) keep working.
+_REFERENCE_ALIASES = {
+    'baselines.her.actor_critic:ActorCritic': 'curious_amd.actor_critic:ActorCritic',
+    'baselines.her.actor_critic:MultiTaskActorCritic': 'curious_amd.actor_critic:MultiTaskActorCritic',
+    'baselines.her.her:make_sample_her_transitions': 'curious_amd.her:make_sample_her_transitions',
+    'baselines.her.her:make_sample_multi_task_her_transitions':
+        'curious_amd.her:make_sample_multi_task_her_transitions',
+}
+
+
+def store_args(method):
+    """Decorator: copy the call's arguments (with defaults) onto `self` (util.py:13-37)."""
+    sig = inspect.signature(method)
+    names = [p for p in sig.parameters][1:]
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        values = {n: p.default for n, p in sig.parameters.items()
+                  if p.default is not inspect.Parameter.empty and p.kind != inspect.Parameter.VAR_KEYWORD}
+        values.update(zip(names, args))
+        values.update(kwargs)
+        self.__dict__.update(values)
+        return method(self, *args, **kwargs)
+    return wrapper
+
+
+def import_function(spec):
+    spec = _REFERENCE_ALIASES.get(spec, spec)
+    mod_name, fn_name = spec.split(':')
+    return getattr(importlib.import_module(mod_name), fn_name)
+
+
+def convert_episode_to_batch_major(episode):
+    """Lists of per-step arrays [T(+1)][B, d] -> arrays [B, T(+1), d] (util.py:174-184)."""
+    return {k: np.array(v).copy().swapaxes(0, 1) for k, v in episode.items()}
+
+
+def transitions_in_episode_batch(episode_batch):
+    shape = episode_batch['u'].shape
+    return shape[0] * shape[1]
+
+
+def mpi_average(value):
+    """Cross-rank mean of a scalar / list of scalars (util.py:141-146 -> mpi_moments.py:6-31)."""
+    if isinstance(value, list) and len(value) == 0:
+        value = [0.]
+    if not isinstance(value, list):
+        value = [value]
+    x = np.asarray(value, dtype=np.float64)
+    packed = np.array([x.sum(), float(x.size)])
+    packed = dist.allreduce_sum_numpy(packed)
+    return packed[0] / packed[1]
+
+
+def mpi_fork(n, extra_mpi_args=()):
+    """The reference re-executes itself under mpirun (util.py:148-171).  Here ranks are started by
+    `python -m torch.distributed.run` (one process per GPU), so every process is a 'child'."""
+    return 'child'
+
+
+def find_save_path(dir, trial_id):
+    i = 0
+    while True:
+        save_dir = dir + str(trial_id + i * 100) + '/'
+        if not os.path.exists(save_dir):
+            os.makedirs(save_dir)
+            return save_dir
+        i += 1

@@ -1,0 +1,233 @@
+/*
+ * curious_hip.h -- C ABI of libcurious_hip.so (MI355X / gfx950).
+ *
+ * The reference (flowersteam/curious) is 100 % Python and has no FFI; its hot path leans on
+ * NumPy / TensorFlow-1 / mpi4py.  This header is the native boundary a maintainer binds (ctypes,
+ * see INTEGRATION.md) to replace those calls.  Every entry point cites the reference lines it
+ * replaces.  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work,
+ *     they never synchronise, allocate or free (safe to capture in a hipGraph);
+ *   - return value 0 = success, negative = error; curious_last_error() returns the message;
+ *   - matrices are row-major float32 unless stated; "rows" of a batch are `stride` floats apart.
+ */
+#ifndef CURIOUS_HIP_H
+#define CURIOUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CURIOUS_ABI_VERSION 1
+#define CURIOUS_MAX_TASKS 16
+#define CURIOUS_MAX_TASK_DIMS 8
+
+typedef void* curious_stream_t;
+
+/* ---- replay storage: one record per (episode, t), t in [0, T] -------------------------------
+ * Replaces the dict of float64 arrays {key: [size, T(+1), dim]} of replay_buffer.py:23-24.  A record
+ * row holds [o | ag | g | u | task_descr | extra] where `extra` carries the keys the sampler only
+ * copies through (change[dimag], info_*), so that transition (ep,t) and its successor (o_2, ag_2 =
+ * row t+1, replay_buffer.py:47-48) are two adjacent rows.  Rows t = T hold only o and ag.
+ * Values are float32 (the rollout produces float32, rollout.py:50-52,194-195; float64 storage in the
+ * reference holds the same values). */
+typedef struct curious_layout {
+  int32_t T;
+  int32_t dimo, dimag, dimg, dimu, dimtd, dimextra;
+  int32_t off_o, off_ag, off_g, off_u, off_td, off_extra;
+  int32_t row_stride;          /* floats per record row */
+} curious_layout_t;
+
+/* ---- staged batch: one row per sampled transition -------------------------------------------
+ * Replaces the dict returned by _sample_her_transitions (her.py:110-183) and the 8 staged arrays of
+ * DDPG.sample_batch (ddpg.py:350-358).  Row: [o | td | u | g | o_2 | g_2 | r | ag | ag_2 | extra]. */
+typedef struct curious_batch_layout {
+  int32_t off_o, off_td, off_u, off_g, off_o2, off_g2, off_r, off_ag, off_ag2, off_extra;
+  int32_t stride;              /* floats per batch row */
+} curious_batch_layout_t;
+
+/* task tables (tasks_g_id / tasks_ag_id of the env; her.py:145-149 truncates ag ids to len(g ids)) */
+typedef struct curious_tasks {
+  int32_t ntasks;
+  int32_t len[CURIOUS_MAX_TASKS];
+  int32_t g_id[CURIOUS_MAX_TASKS][CURIOUS_MAX_TASK_DIMS];
+  int32_t ag_id[CURIOUS_MAX_TASKS][CURIOUS_MAX_TASK_DIMS];
+} curious_tasks_t;
+
+/* sampler behaviour (her.py:72-97) */
+enum {
+  CURIOUS_RELABEL_BUFFER_TASK = 0,   /* multi-buffer modes: replay task = buffer's task, or the sample's
+                                        own task when task_to_replay < 0 (her.py:131-136) */
+  CURIOUS_RELABEL_GIVEN_TASK = 1,    /* single-buffer random / cp modes: per-sample task supplied in
+                                        task_to_replay[] (her.py:138-142) */
+  CURIOUS_RELABEL_CURRENT_TASK = 2,  /* replay_current_task_transition: keep task_descr (her.py:158-164) */
+  CURIOUS_RELABEL_FLAT = 3           /* make_sample_her_transitions: whole goal from future ag (her.py:43-47) */
+};
+
+typedef struct curious_sample_params {
+  double future_p;          /* her.py:86-89 */
+  double reward_eps;        /* sparse L2 threshold of the reward (config.py:158-159 -> env) */
+  float clip_obs;           /* ddpg.py:125-126; +inf = ReplayBuffer.sample (no clipping) */
+  int32_t relative_goals;   /* ddpg.py:119-124 */
+  int32_t relabel_mode;     /* CURIOUS_RELABEL_* */
+  int32_t flat_reward;      /* 1: reward over all goal slots, task_descr ignored (her.py:57) */
+} curious_sample_params_t;
+
+/* Host-drawn sample plan (parity mode): the NumPy legacy stream is consumed on the host in the
+ * reference's order (her.py:108-116, ddpg.py:326-345) and handed over as arrays of length n. */
+typedef struct curious_sample_plan {
+  const int32_t* buf;             /* buffer index of each sample */
+  const int32_t* ep;              /* episode_idxs   (her.py:108) */
+  const int32_t* t;               /* t_samples      (her.py:109) */
+  const double* u_her;            /* uniform draws  (her.py:115) */
+  const double* u_off;            /* uniform draws  (her.py:116) */
+  const int32_t* task_to_replay;  /* per sample, <0 = None */
+  const int32_t* out_row;         /* destination row (inverse of ddpg.py:338-345 shuffle); NULL = identity */
+} curious_sample_plan_t;
+
+/* Device-drawn plan (throughput mode): Philox4x32-10 keyed by (seed, *step_ctr). */
+typedef struct curious_sample_rng {
+  uint64_t seed;
+  const int64_t* step_ctr;        /* device counter, advanced by curious_ddpg_grads */
+  int64_t step_host;              /* used when step_ctr == NULL */
+  const int32_t* prop_prefix;     /* [nbuf+1] exclusive prefix of DDPG.proportions (ddpg.py:282-286) */
+  const int32_t* cur_size;        /* [nbuf] episodes stored per buffer (replay_buffer.py:27) */
+  const int32_t* buf_alias;       /* [nbuf] physical buffer of each logical buffer (ddpg.py:106-110) */
+  const int32_t* buf_task;        /* [nbuf] task_to_replay of each logical buffer, <0 = None */
+  int32_t nbuf;
+} curious_sample_rng_t;
+
+const char* curious_last_error(void);
+int curious_abi_version(void);
+/* name of the device the library runs on + its CU count; fails when no gfx950 device is present */
+int curious_device_info(char* name_host, int name_len, int* cu_count_host);
+
+/* HER sample + goal/task relabel + reward + clip, written already permuted.
+ * Replaces replay_buffer.py:37-55, her.py:99-183 (or :20-66), ddpg.py:326-353.
+ * storage: [nbuf_phys][capacity][T+1][row_stride]; buf_stride = floats between buffers.
+ * Exactly one of plan / rng is non-NULL. */
+int curious_her_sample(const float* storage, int64_t buf_stride, const curious_layout_t* L,
+                       const curious_tasks_t* tasks, const curious_sample_params_t* P,
+                       const curious_sample_plan_t* plan, const curious_sample_rng_t* rng,
+                       int32_t n, float* batch, const curious_batch_layout_t* BL, curious_stream_t stream);
+
+/* Copy n_pairs episodes (T+1 rows each) from a staging block into replay slots.
+ * Replaces replay_buffer.py:57-72 + the routing loop ddpg.py:178-197.
+ * pair_src[i] = episode index in `staging`; pair_dst[i] = buffer*capacity + slot. */
+int curious_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
+                           const int32_t* pair_src, const int64_t* pair_dst, int32_t n_pairs,
+                           curious_stream_t stream);
+
+/* Per-episode task activity test any(change[b,-1,ids]) (ddpg.py:179-184).
+ * `change` lives in the extra block at float offset off_change; active[b*ntasks+j] in {0,1}. */
+int curious_episode_activity(const float* staging, const curious_layout_t* L, const curious_tasks_t* tasks,
+                             int32_t off_change, int32_t n_episodes, int32_t* active, curious_stream_t stream);
+
+/* Normalizer.update on `dim` columns of a row matrix: local_sum += sum(v), local_sumsq += sum(v*v),
+ * local_count += rows; float64 column sums folded into the float32 accumulators like NumPy does.
+ * Replaces normalizer.py:64-70.  acc = [local_sum[dim] | local_sumsq[dim] | local_count[1]]. */
+int curious_norm_update(const float* rows, int32_t n_rows, int32_t stride, int32_t col_off, int32_t dim,
+                        float* acc, double* scratch, curious_stream_t stream);
+/* scratch floats needed by curious_norm_update (in doubles) */
+int64_t curious_norm_scratch_doubles(int32_t n_rows, int32_t dim);
+
+/* recompute_stats after the cross-rank SUM of acc: synced = acc / world_size (mean over ranks);
+ * count += synced_count, sum += ..., sumsq += ...; mean = sum/count;
+ * std = sqrt(max(eps^2, sumsq/count - (sum/count)^2)); acc is zeroed.
+ * Replaces normalizer.py:50-61,84-118.  state = [sum[dim] | sumsq[dim] | count[1] | mean[dim] | std[dim]]. */
+int curious_norm_recompute(float* acc, float* state, int32_t dim, float world_size, float eps,
+                           curious_stream_t stream);
+
+/* ---- networks ---------------------------------------------------------------------------------
+ * Parameter vector of one agent = [theta_Q | pad | theta_pi | pad] (ddpg.py:456 main_vars order); theta_pi
+ * starts at curious_param_offset_pi() (P_Q rounded up to 64 floats), the vector is curious_param_total()
+ * floats long, pads are zero and stay zero under Adam / Polyak.  Gradients, Adam moments and the target
+ * vector use the same layout.  Each network is in TF creation
+ * order (util.py:79-101): _0_state/kernel[in,H], _0_state/bias[H], _0_goal/kernel[G,H], then
+ * (kernel[H,H], bias[H]) x (layers-1), _3/kernel[H,out], _3/bias[out]; kernels [in,out] row-major.
+ * modular=0 is the flat ActorCritic (util.py:56-71): _0/kernel[(O+G(+U)),H], _0/bias, ... */
+typedef struct curious_net_cfg {
+  int32_t dimo, dimg, dimu, dimtd, hidden, layers, modular;
+  float max_u, gamma, clip_return, action_l2;
+  int32_t clip_pos_returns;
+  int32_t normalize_obs;       /* actor_critic.py:76-83 (default off, train.py:351) */
+  float norm_clip;             /* normalizer.py:72-77 default_clip_range */
+} curious_net_cfg_t;
+
+int64_t curious_param_count_Q(const curious_net_cfg_t* cfg);
+int64_t curious_param_count_pi(const curious_net_cfg_t* cfg);
+int64_t curious_param_offset_pi(const curious_net_cfg_t* cfg);
+int64_t curious_param_total(const curious_net_cfg_t* cfg);
+/* workspace floats for curious_ddpg_grads / curious_policy_forward at batch size B */
+int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
+
+/* One DDPG._grads(): target/main forward, losses, flat gradients (ddpg.py:235-243,419-449).
+ * batch rows as written by curious_her_sample.  o_stats/g_stats = normaliser state vectors (may be
+ * NULL when normalize_obs = 0).  out_losses = [Q_loss, pi_loss]; out_Q_pi[B] = main.Q_pi_tf (the
+ * "actor_loss" returned by DDPG.train, ddpg.py:237-243); grad = [Q_grad | pad | pi_grad | pad] (pads untouched).
+ * If step_ctr != NULL, *step_ctr is incremented once (device-side step counter for RNG / Adam). */
+int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
+                       const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                       const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                       float* out_losses, float* out_Q_pi, int64_t* step_ctr, curious_stream_t stream);
+
+/* Actor (and optionally critic) forward for acting: pi = max_u*tanh(net(o,td,g)), Q = critic(o,td,pi,g)
+ * (ddpg.py:129-146, actor_critic.py:87-94).  Inputs are separate row matrices with their strides;
+ * o and g are clipped to +-clip_obs first (ddpg.py:118-127).  out_Q may be NULL. */
+int curious_policy_forward(const curious_net_cfg_t* cfg, const float* theta, const float* o, int32_t ldo,
+                           const float* ag, int32_t ldag, const float* g, int32_t ldg, const float* td,
+                           int32_t ldtd, int32_t n, float clip_obs, int32_t relative_goals,
+                           const float* o_stats, const float* g_stats, float* workspace, float* out_pi,
+                           float* out_Q, curious_stream_t stream);
+
+/* Action post-processing (ddpg.py:149-152), NumPy promotion kept: u = f32(f64(u) + noise_scale*randn);
+ * u = clip(u, +-max_u); u = f32(f64(u) + binom*(unif - f64(u))).  noise_scale = noise_eps*max_u (double).
+ * Parity mode: randn[n*dimu], binom[n], unif[n*dimu] (float64, drawn on the host in that order; unif is
+ * already uniform(-max_u, max_u)).  Throughput mode (all three NULL): Philox keyed by (seed, counter). */
+int curious_action_noise(float* u, int32_t ldu, int32_t n, int32_t dimu, double noise_scale, double random_eps,
+                         double max_u, const double* randn, const double* binom, const double* unif,
+                         uint64_t seed, uint64_t counter, curious_stream_t stream);
+
+/* MpiAdam.update after the all-reduce (mpi_adam.py:29-35) on the fused [theta_Q | theta_pi] vector;
+ * the two optimisers keep separate step sizes a_Q / a_pi = lr*sqrt(1-b2^t)/(1-b1^t), rounded to float32.
+ * alpha_tab (device, [tab_len][2]) indexed by (*step_ctr - 1 - tab_base) when non-NULL, else alpha_host. */
+int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
+                        const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
+                        const float* alpha_host, float beta1, float one_minus_beta1, float beta2,
+                        float one_minus_beta2, float epsilon, curious_stream_t stream);
+
+/* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
+ * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */
+int curious_polyak_update(float* target, const float* main_, int64_t n, float polyak, float one_minus_polyak,
+                          curious_stream_t stream);
+
+/* Order-independent 64-bit checksum of the parameter bit patterns, for MpiAdam.check_synced
+ * (mpi_adam.py:42-50) without broadcasting the vector.  out[2] = {sum, xor} of a per-element hash. */
+int curious_param_checksum(const float* theta, int64_t n, uint64_t* out, curious_stream_t stream);
+
+/* ---- synthetic batched environment (stand-in for gym_flowers MultiTaskFetchArm, rollout.py:107-143,
+ * 256-284).  state/ record layout: see DESIGN.md "Synthetic env". ---------------------------------- */
+typedef struct curious_env_cfg {
+  int32_t ntasks, dimo, T;
+  uint64_t seed;
+} curious_env_cfg_t;
+
+/* Reset n envs: o[n][dimo] from Philox stream (env_id0+i, episode[i]); writes record row 0 of the
+ * staging block (o, ag, g, td) and the working arrays o/ag/g/td. goals_raw[n][3] in [-1,1], tasks[n]. */
+int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                      const int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                      float* o, float* ag, float* g, float* td, float* staging, curious_stream_t stream);
+
+/* One step of n envs with actions u[n][dimu]: updates o/ag in place, writes u, g, td, change, is_success
+ * into staging row t and o, ag into row t+1 (the episode record of rollout.py:273-303). */
+int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                     const int32_t* episode, const int32_t* tasks, const float* u, int32_t ldu, int32_t t,
+                     int32_t n, float* o, float* ag, const float* g, const float* td, float* staging,
+                     int32_t off_change, int32_t off_success, double reward_eps, curious_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURIOUS_HIP_H */

@@ -1,0 +1,414 @@
+"""Kernel-level parity: every C-ABI entry point against the oracle / golden vectors, on a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+
+def tables(nb):
+    ids = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(nb)]
+    return ids, [list(x) for x in ids]
+
+
+def shapes_of(ep, T):
+    return {k: (v.shape[1], v.shape[2]) for k, v in ep.items()}
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from curious_amd import ops as _ops
+    name, cus = _ops.device_info()
+    assert cus > 0
+    return _ops
+
+
+HER = load_golden('her')
+
+
+@pytest.mark.parametrize('name', [str(n) for n in HER['names']])
+def test_her_sample_kernel_bit_exact(ops, name):
+    from curious_amd import _lib
+    from curious_amd.layout import RecordLayout, pack_episodes
+    nb, dimo, E, T, B, seed, ttr, flat = [int(x) for x in HER[name + '/cfg']]
+    task_replay = str(HER[name + '/task_replay'])
+    goal_replay = str(HER[name + '/goal_replay'])
+    ep = sub(HER, name + '/in/')
+    layout = RecordLayout(shapes_of(ep, T), T)
+    storage = dev(pack_episodes(layout, ep))
+    ag_ids, g_ids = tables(nb)
+    tasks = _lib.make_tasks(ag_ids, g_ids)
+    P = _lib.SampleParams()
+    P.future_p = (1 - 1. / (1 + 4)) if goal_replay == 'her' else 0
+    P.reward_eps = 0.05
+    P.clip_obs = float('inf')
+    P.relative_goals = 0
+    P.flat_reward = int(flat)
+    d_ep, d_t = HER[name + '/draw/ep'], HER[name + '/draw/t']
+    u_her, u_off = HER[name + '/draw/u_her'], HER[name + '/draw/u_off']
+    ttr_arr = np.full(B, ttr, np.int32)
+    if flat:
+        P.relabel_mode = _lib.RELABEL_FLAT
+    elif task_replay == 'replay_current_task_transition':
+        P.relabel_mode = _lib.RELABEL_CURRENT_TASK
+    elif 'buffer' in task_replay:
+        P.relabel_mode = _lib.RELABEL_BUFFER_TASK
+    else:
+        # single-buffer random / cp modes draw the replay task inside the loop (her.py:138-142)
+        P.relabel_mode = _lib.RELABEL_GIVEN_TASK
+        rs = np.random.RandomState(seed)
+        rs.randint(0, E, B); rs.randint(T, size=B); rs.uniform(size=B); rs.uniform(size=B)
+        her_idx = np.where(u_her < P.future_p)[0]
+        cp = HER[name + '/cp_proba'] if task_replay == 'replay_cp_task_transition' else None
+        for i in her_idx:
+            ttr_arr[i] = rs.choice(range(nb), p=cp) if cp is not None else rs.choice(range(nb))
+    plan = ops.make_plan(dev(d_ep, torch.int32), dev(d_t, torch.int32), dev(u_her), dev(u_off),
+                         task_to_replay=dev(ttr_arr))
+    batch = torch.full([B, layout.batch_stride], float('nan'), device='cuda')
+    ops.her_sample(storage, 0, layout, tasks, P, B, batch, plan=plan)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in layout.batch_views(batch).items()}
+    want = sub(HER, name + '/out/')
+    for k in want:
+        w = want[k].astype(np.float64)
+        g = got[k].astype(np.float64).reshape(w.shape)
+        np.testing.assert_array_equal(g, w, err_msg=k)
+    # g_2 equals g when goals are absolute; every row was written
+    np.testing.assert_array_equal(got['g_2'], got['g'])
+    assert not np.isnan(batch[:, :layout.boff_extra + layout.dimextra].cpu().numpy()).any()
+
+
+def test_her_sample_clip_relative_and_permutation(ops):
+    from curious_amd import _lib
+    from curious_amd.layout import RecordLayout, pack_episodes
+    from oracle import her as oher
+    from oracle.reward import make_reward_fun
+    from oracle.ddpg import preprocess_og
+    name = 'arm4_buffer_t2'
+    nb, dimo, E, T, B, seed, ttr, flat = [int(x) for x in HER[name + '/cfg']]
+    ep = {k: v.copy() for k, v in sub(HER, name + '/in/').items()}
+    ep['o'] = ep['o'] * np.float32(150.0)          # make the +-200 clip bite
+    ep['ag'] = ep['o'][:, :, :12].copy()
+    layout = RecordLayout(shapes_of(ep, T), T)
+    storage = dev(pack_episodes(layout, ep))
+    ag_ids, g_ids = tables(nb)
+    tasks = _lib.make_tasks(ag_ids, g_ids)
+    rs = np.random.RandomState(7)
+    draws = oher.draw_her(rs, E, T, B)
+    perm = rs.permutation(B)
+    inv = np.empty(B, np.int32)
+    inv[perm] = np.arange(B)                       # out[j] = tmp[perm[j]]  <=>  sample i goes to row inv[i]
+    P = _lib.SampleParams()
+    P.future_p, P.reward_eps, P.clip_obs, P.relative_goals = 0.8, 0.05, 200.0, 1
+    P.relabel_mode, P.flat_reward = _lib.RELABEL_BUFFER_TASK, 0
+    plan = ops.make_plan(dev(draws[0], torch.int32), dev(draws[1], torch.int32), dev(draws[2]), dev(draws[3]),
+                         task_to_replay=dev(np.full(B, 2, np.int32)), out_row=dev(inv))
+    batch = torch.zeros([B, layout.batch_stride], device='cuda')
+    ops.her_sample(storage, 0, layout, tasks, P, B, batch, plan=plan)
+    got = {k: v.cpu().numpy() for k, v in layout.batch_views(batch).items()}
+    ep64 = {k: v.astype(np.float64) for k, v in ep.items()}
+    ep64['o_2'] = ep64['o'][:, 1:]
+    ep64['ag_2'] = ep64['ag'][:, 1:]
+    tr = oher.apply_multi_task(ep64, draws, future_p=0.8, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
+                               task_replay='replay_task_cp_buffer', reward_fun=make_reward_fun(ag_ids, g_ids),
+                               task_to_replay=2)
+    tr = {k: v[perm] for k, v in tr.items()}
+    o, g = preprocess_og(tr['o'], tr['ag'], tr['g'], 200.0, True)
+    o2, g2 = preprocess_og(tr['o_2'], tr['ag_2'], tr['g'], 200.0, True)
+    for k, w in dict(o=o, g=g, o_2=o2, g_2=g2, r=tr['r'], u=tr['u'], task_descr=tr['task_descr'], ag=tr['ag']).items():
+        np.testing.assert_array_equal(got[k].astype(np.float64), np.asarray(w, dtype=np.float32).astype(np.float64),
+                                      err_msg=k)
+    assert np.abs(got['o']).max() == 200.0
+
+
+def test_store_and_activity(ops):
+    from curious_amd import _lib
+    from curious_amd.layout import RecordLayout, pack_episodes
+    G = load_golden('replay_buffer')
+    ep = sub(G, 'step4/in/')        # 4 episodes
+    T = ep['u'].shape[1]
+    layout = RecordLayout(shapes_of(ep, T), T)
+    staging = dev(pack_episodes(layout, ep))
+    cap = 6
+    storage = torch.zeros([2, cap, T + 1, layout.row_stride], device='cuda')
+    src = np.array([0, 1, 3, 3], np.int32)
+    dst = np.array([0 * cap + 2, 1 * cap + 5, 1 * cap + 0, 0 * cap + 4], np.int64)
+    ops.store_episodes(storage, staging, layout, dev(src), dev(dst))
+    want = torch.zeros_like(storage)
+    flat = want.view(2 * cap, T + 1, layout.row_stride)
+    for s, d in zip(src, dst):
+        flat[d] = staging[s]
+    assert torch.equal(storage, want)
+    ag_ids, g_ids = tables(4)
+    tasks = _lib.make_tasks(ag_ids, g_ids)
+    active = torch.full([4 * 4], -1, dtype=torch.int32, device='cuda')
+    ops.episode_activity(staging, layout, tasks, 4, active)
+    ch = ep['change'][:, -1, :]
+    want_a = np.array([[int(ch[b, ag_ids[j]].any()) for j in range(4)] for b in range(4)]).reshape(-1)
+    np.testing.assert_array_equal(active.cpu().numpy(), want_a)
+
+
+def test_adam_bit_exact_vs_oracle_and_close_to_reference(ops):
+    from oracle.optim import adam_update
+    G = load_golden('adam')
+    theta0 = G['theta0']
+    P = theta0.shape[0]
+    nQ = 600
+    th, m, v = dev(theta0), torch.zeros(P, device='cuda'), torch.zeros(P, device='cuda')
+    o_th, o_m, o_v, t = theta0.copy(), np.zeros(P, np.float32), np.zeros(P, np.float32), 0
+    for k in range(G['grads'].shape[0]):
+        g = G['grads'][k]
+        a = ops.adam_alpha(1e-3, k + 1)
+        ops.adam_update(th, m, v, dev(g), nQ, P - nQ, a, a)
+        o_th, o_m, o_v, t = adam_update(o_th, o_m, o_v, t, g, 1e-3, nep50=False)
+        np.testing.assert_array_equal(m.cpu().numpy(), o_m)
+        np.testing.assert_array_equal(v.cpu().numpy(), o_v)
+        np.testing.assert_array_equal(th.cpu().numpy(), o_th)
+        np.testing.assert_array_equal(m.cpu().numpy(), G['ms'][k])      # reference, bit for bit
+        np.testing.assert_array_equal(v.cpu().numpy(), G['vs'][k])
+    np.testing.assert_allclose(th.cpu().numpy(), G['thetas'][-1], rtol=2e-6, atol=1e-7)
+
+
+def test_adam_table_mode_and_polyak(ops):
+    from oracle.optim import adam_update, polyak_update
+    rng = np.random.RandomState(0)
+    P, nQ = 5000, 3000
+    theta = rng.randn(P).astype(np.float32)
+    th, m, v = dev(theta), torch.zeros(P, device='cuda'), torch.zeros(P, device='cuda')
+    tab = np.array([[ops.adam_alpha(1e-3, t), ops.adam_alpha(5e-4, t)] for t in range(1, 9)], np.float32)
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+    oQ = (theta[:nQ].copy(), np.zeros(nQ, np.float32), np.zeros(nQ, np.float32), 0)
+    oP = (theta[nQ:].copy(), np.zeros(P - nQ, np.float32), np.zeros(P - nQ, np.float32), 0)
+    for k in range(8):
+        g = rng.randn(P).astype(np.float32)
+        ctr += 1                                  # what curious_ddpg_grads does
+        ops.adam_update(th, m, v, dev(g), nQ, P - nQ, alpha_tab=dev(tab), step_ctr=ctr, tab_base=0)
+        oQ = adam_update(*oQ, g[:nQ], 1e-3)
+        oP = adam_update(*oP, g[nQ:], 5e-4)
+    np.testing.assert_array_equal(th.cpu().numpy(), np.concatenate([oQ[0], oP[0]]))
+    target = rng.randn(P).astype(np.float32)
+    tg = dev(target)
+    ops.polyak_update(tg, th, 0.95)
+    np.testing.assert_array_equal(tg.cpu().numpy(), polyak_update(target, th.cpu().numpy(), 0.95))
+    ops.polyak_update(tg, th, 0.0)
+    assert torch.equal(tg, th)
+    out = torch.zeros(2, dtype=torch.int64, device='cuda')
+    out2 = torch.zeros(2, dtype=torch.int64, device='cuda')
+    ops.param_checksum(th, out)
+    ops.param_checksum(tg, out2)
+    assert torch.equal(out, out2)
+    tg[17] += 1e-3
+    ops.param_checksum(tg, out2)
+    assert not torch.equal(out, out2)
+
+
+def test_normalizer_update_and_recompute(ops):
+    from oracle.normalizer import Normalizer
+    rng = np.random.RandomState(4)
+    dim, stride, off = 40, 152, 0
+    nz = Normalizer(dim, eps=0.01)
+    acc = torch.zeros(2 * dim + 1, device='cuda')
+    state = torch.zeros(4 * dim + 1, device='cuda')
+    state[2 * dim] = 1.0
+    state[3 * dim + 1:] = 1.0
+    for it, n in enumerate([12800, 37, 1]):
+        rows = (rng.randn(n, stride) * 3 + 0.5).astype(np.float32)
+        scratch = torch.zeros(ops.norm_scratch_doubles(n, dim), dtype=torch.float64, device='cuda')
+        ops.norm_update(dev(rows), n, stride, off, dim, acc, scratch)
+        nz.update(rows[:, off:off + dim].astype(np.float64))
+        a = acc.cpu().numpy()
+        np.testing.assert_allclose(a[:dim], nz.local_sum, rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(a[dim:2 * dim], nz.local_sumsq, rtol=1e-6)
+        assert a[2 * dim] == nz.local_count[0]
+        # recompute: identical arithmetic given identical accumulators
+        nz.local_sum[:] = a[:dim]
+        nz.local_sumsq[:] = a[dim:2 * dim]
+        nz._comm_size = 3                               # exercises the divide-by-world rounding
+        ops.norm_recompute(acc, state, dim, 3, 0.01)
+        nz.recompute_stats()
+        s = state.cpu().numpy()
+        np.testing.assert_array_equal(s[:dim], nz.sum)
+        np.testing.assert_array_equal(s[dim:2 * dim], nz.sumsq)
+        assert s[2 * dim] == nz.count[0]
+        np.testing.assert_array_equal(s[2 * dim + 1:3 * dim + 1], nz.mean)
+        np.testing.assert_array_equal(s[3 * dim + 1:], nz.std)
+        assert float(acc.abs().sum()) == 0.0
+
+
+def _rand_batch(rng, layout, B, nb):
+    batch = np.zeros([B, layout.batch_stride], np.float32)
+    c = layout.batch_cols
+    def put(k, v):
+        batch[:, c[k][0]:c[k][0] + c[k][1]] = v
+    put('o', rng.randn(B, c['o'][1]))
+    put('o_2', rng.randn(B, c['o'][1]))
+    put('g', rng.randn(B, c['g'][1]) * 0.5)
+    put('g_2', batch[:, c['g'][0]:c['g'][0] + c['g'][1]])
+    put('u', rng.uniform(-1, 1, (B, c['u'][1])))
+    put('task_descr', np.eye(nb)[rng.randint(nb, size=B)])
+    put('r', -(rng.rand(B, 1) > 0.3).astype(np.float32))
+    return batch
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(nb=4, dimo=40, B=256, hidden=256, layers=3, max_u=1.0),
+    dict(nb=8, dimo=52, B=256, hidden=256, layers=3, max_u=1.0),
+    dict(nb=4, dimo=40, B=37, hidden=64, layers=2, max_u=1.5),       # ragged rows / other depth
+    dict(nb=3, dimo=10, B=5, hidden=24, layers=1, max_u=2.0),        # tiny, nothing multiple of 16
+])
+def test_ddpg_grads_vs_oracle(ops, cfg):
+    from curious_amd.layout import RecordLayout
+    from oracle.networks import DDPGMath
+    nb, dimo, B = cfg['nb'], cfg['dimo'], cfg['B']
+    G = 3 * nb
+    T = 50
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), task_descr=(T, nb), change=(T, G),
+                  info_is_success=(T, 1))
+    layout = RecordLayout(shapes, T)
+    rng = np.random.RandomState(11)
+    batch = _rand_batch(rng, layout, B, nb)
+    gamma = 0.98
+    m64 = DDPGMath(dimo, G, 4, nb, cfg['hidden'], cfg['layers'], cfg['max_u'], gamma, 50., True, 1.0, True,
+                   np.float64)
+    m32 = DDPGMath(dimo, G, 4, nb, cfg['hidden'], cfg['layers'], cfg['max_u'], gamma, 50., True, 1.0, True,
+                   np.float32)
+    theta = m32.init(rng)
+    theta_t = m32.init(rng)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, cfg['hidden'], cfg['layers'], True, cfg['max_u'], gamma, 50., 1.0)
+    PQ, Ppi, off_pi, total = ops.param_layout(ncfg)
+    assert (PQ, Ppi) == (m32.P_Q, m32.P_pi) and off_pi % 64 == 0 and off_pi >= PQ
+    ws = torch.zeros(ops.workspace_floats(ncfg, B), device='cuda')
+    grad = torch.full([total], float('nan'), device='cuda')
+    losses = torch.zeros(2, device='cuda')
+    Qpi = torch.zeros(B, device='cuda')
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+    ops.ddpg_grads(ncfg, dev(ops.pad_params(ncfg, theta)), dev(ops.pad_params(ncfg, theta_t)), dev(batch), layout,
+                   B, ws, grad, losses, Qpi, step_ctr=ctr)
+    torch.cuda.synchronize()
+    assert int(ctr) == 1
+    bd = {k: batch[:, o:o + d] for k, (o, d) in layout.batch_cols.items()}
+    ref = m64.losses_and_grads(theta.astype(np.float64), theta_t.astype(np.float64), bd)
+    ref32 = m32.losses_and_grads(theta, theta_t, bd)
+    got_l = losses.cpu().numpy()
+    # tolerance of the north star: losses within 1e-5 relative of the CPU reference
+    assert abs(got_l[0] - ref['Q_loss']) <= 1e-5 * abs(ref['Q_loss'])
+    assert abs(got_l[1] - ref['pi_loss']) <= 1e-5 * abs(ref['pi_loss'])
+    np.testing.assert_allclose(Qpi.cpu().numpy(), ref['Q_pi'][:, 0], rtol=1e-5, atol=1e-6)
+    g = grad.cpu().numpy()
+    assert np.isnan(g[PQ:off_pi]).all()          # pads are never written
+    g = ops.unpad_params(ncfg, g)
+    assert not np.isnan(g).any()
+    for name, sl in (('Q_grad', slice(0, PQ)), ('pi_grad', slice(PQ, PQ + Ppi))):
+        want = ref[name]
+        err = np.abs(g[sl] - want).max()
+        assert err <= 1e-5 * np.abs(want).max(), (name, err, np.abs(want).max())
+        # and no worse than the float32 CPU path is against float64
+        err32 = np.abs(ref32[name] - want).max()
+        assert err <= max(4 * err32, 1e-6 * np.abs(want).max())
+
+
+def test_policy_forward_and_noise(ops):
+    from oracle.networks import DDPGMath
+    from oracle.ddpg import action_postprocess, preprocess_og
+    rng = np.random.RandomState(5)
+    nb, dimo, G = 4, 40, 12
+    m32 = DDPGMath(dimo, G, 4, nb, 256, 3, 1.0, 0.98, 50., True, 1.0, True, np.float32)
+    m64 = DDPGMath(dimo, G, 4, nb, 256, 3, 1.0, 0.98, 50., True, 1.0, True, np.float64)
+    theta = m32.init(rng)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, 256, 3, True, 1.0, 0.98, 50., 1.0)
+    for n in (2, 256, 1000):
+        o = (rng.randn(n, dimo) * 3).astype(np.float32)
+        g = rng.randn(n, G).astype(np.float32)
+        ag = rng.randn(n, G).astype(np.float32)
+        td = np.eye(nb, dtype=np.float32)[rng.randint(nb, size=n)]
+        ws = torch.zeros(ops.workspace_floats(ncfg, n), device='cuda')
+        pi = torch.zeros([n, 4], device='cuda')
+        Q = torch.zeros([n, 1], device='cuda')
+        ops.policy_forward(ncfg, dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), n, 5.0, ws, pi, Q,
+                           ag=dev(ag))
+        oc, gc = preprocess_og(o, ag, g, 5.0)
+        assert np.abs(oc).max() == 5.0
+        Qp, pip = m64.split(theta.astype(np.float64))
+        want_pi, _, _ = m64.actor(pip, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64))
+        want_Q, _ = m64.critic(Qp, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64), want_pi)
+        np.testing.assert_allclose(pi.cpu().numpy(), want_pi, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Q.cpu().numpy(), want_Q, rtol=1e-5, atol=2e-6)
+        # noise epilogue, parity mode: bit-exact with the NumPy promotion rules
+        rs = np.random.RandomState(n)
+        randn = rs.randn(n, 4)
+        binom = rs.binomial(1, 0.3, n).astype(np.float64)
+        unif = rs.uniform(low=-1.0, high=1.0, size=(n, 4))
+        u0 = pi.clone()
+        ops.action_noise(pi, n, 4, 0.2 * 1.0, 0.3, 1.0, dev(randn), dev(binom), dev(unif))
+        want_u = action_postprocess(u0.cpu().numpy().copy(), np.random.RandomState(n), 0.2, 0.3, 1.0)
+        np.testing.assert_array_equal(pi.cpu().numpy(), want_u.astype(np.float32))
+    # throughput mode: statistics only
+    n = 4096
+    u = torch.zeros([n, 4], device='cuda')
+    ops.action_noise(u, n, 4, 0.2, 0.3, 1.0, seed=3, counter=9)
+    x = u.cpu().numpy()
+    frac_rand = np.mean(np.abs(x).max(axis=1) > 0.9)       # |N(0,0.2)| > 0.9 is ~0: these are the uniform rows
+    assert 0.07 < frac_rand < 0.14          # 0.3 * (1 - 0.9**4) = 0.103
+    assert np.abs(x).max() <= 1.0
+
+
+@pytest.mark.parametrize('name', ['MultiTaskFetchArm4-v5', 'MultiTaskFetchArm8-v5'])
+def test_env_bit_exact_vs_oracle(ops, name):
+    from curious_amd.layout import RecordLayout
+    from oracle.env import ENV_CONFIGS, SyntheticMultiTaskArm
+    nb, dimo, T = ENV_CONFIGS[name]
+    T = 9
+    G = 3 * nb
+    n = 70
+    seed = 123456789012
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), task_descr=(T, nb), change=(T, G),
+                  info_is_success=(T, 1))
+    layout = RecordLayout(shapes, T)
+    ecfg = ops.make_env_cfg(nb, dimo, T, seed)
+    rng = np.random.RandomState(0)
+    envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=seed, env_id=5 + i) for i in range(n)]
+    o = torch.zeros([n, dimo], device='cuda'); ag = torch.zeros([n, G], device='cuda')
+    g = torch.zeros([n, G], device='cuda'); td = torch.zeros([n, nb], device='cuda')
+    staging = torch.zeros([n, T + 1, layout.row_stride], device='cuda')
+    for episode in range(2):
+        tasks = rng.randint(nb, size=n).astype(np.int32)
+        goals = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        epi = np.full(n, episode, np.int32)
+        ops.env_reset(ecfg, layout, 5, dev(epi), dev(tasks), dev(goals), n, o, ag, g, td, staging)
+        obs = []
+        for i, e in enumerate(envs):
+            e.reset()
+            obs.append(e.reset_task_goal(goals[i], tasks[i]))
+        np.testing.assert_array_equal(o.cpu().numpy(), np.stack([x['observation'] for x in obs]))
+        np.testing.assert_array_equal(g.cpu().numpy(), np.stack([x['desired_goal'] for x in obs]))
+        np.testing.assert_array_equal(td.cpu().numpy(), np.stack([x['mask'] for x in obs]))
+        ag0 = np.stack([x['achieved_goal'] for x in obs])
+        epi1 = dev(np.full(n, episode + 1, np.int32))         # the oracle's episode counter after reset
+        for t in range(T):
+            u = rng.uniform(-1.3, 1.3, (n, 4)).astype(np.float32)
+            # steer some grippers onto object 1 and close the gripper so that carrying happens
+            cur = o.cpu().numpy()
+            u[::3, :3] = np.clip((cur[::3, 3:6] - cur[::3, 0:3]) * 20, -1, 1)
+            u[::3, 3] = -1
+            ops.env_step(ecfg, layout, 5, epi1, dev(tasks), dev(u), t, n, o, ag, g, td, staging, 0.05)
+            res = [e.step(u[i]) for i, e in enumerate(envs)]
+            want_o = np.stack([r[0]['observation'] for r in res])
+            np.testing.assert_array_equal(o.cpu().numpy(), want_o)
+            rec = layout.record_views(staging)
+            np.testing.assert_array_equal(rec['o'][:, t + 1].cpu().numpy(), want_o)
+            np.testing.assert_array_equal(rec['u'][:, t].cpu().numpy(), u)
+            np.testing.assert_array_equal(rec['info_is_success'][:, t, 0].cpu().numpy(),
+                                          np.array([r[3]['is_success'] for r in res], np.float32))
+            want_change = (np.abs(ag0 - want_o[:, :G]) > 1e-3).astype(np.float32)
+            np.testing.assert_array_equal(rec['change'][:, t].cpu().numpy(), want_change)
+        moved = np.abs(o.cpu().numpy()[:, 3:6] - np.stack([x['observation'] for x in obs])[:, 3:6]).max()
+        assert moved > 0      # at least one object was carried

@@ -1,0 +1,45 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, and exports every declared symbol."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from curious_amd.build import build
+    from curious_amd import _lib
+    path = build(verbose=False)
+    assert os.path.exists(path)
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'curious_hip.h')).read()
+    declared = set(re.findall(r'\b(curious_[a-z_A-Z0-9]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.PROTOTYPES.keys())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.curious_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate arguments before touching the device, so this runs on CPU."""
+    import ctypes as C
+    from curious_amd import _lib
+    L = _lib.lib()
+    rc = L.curious_her_sample(None, 0, None, None, None, None, None, 4, None, None, None)
+    assert rc != 0
+    assert b'NULL' in L.curious_last_error()
+    cfg = _lib.NetCfg()
+    cfg.dimo, cfg.dimg, cfg.dimu, cfg.dimtd, cfg.hidden, cfg.layers, cfg.modular = 40, 12, 4, 4, 256, 3, 1
+    assert L.curious_param_count_Q(C.byref(cfg)) == 147457
+    assert L.curious_param_count_pi(C.byref(cfg)) == 147204
+    cfg.dimo, cfg.dimg, cfg.dimtd = 52, 24, 8
+    assert L.curious_param_count_pi(C.byref(cfg)) == (52 + 8) * 256 + 256 + 24 * 256 + 2 * (256 * 256 + 256) + 256 * 4 + 4
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from curious_amd import ops, _lib
+    with pytest.raises(_lib.CuriousHipError):
+        ops.polyak_update(torch.zeros(4), torch.zeros(4), 0.95)
