@@ -1,0 +1,651 @@
+"""DDPG + HER agent on the GPU.  Mirrors DDPG baselines/her/ddpg.py:18-537 (constructor kwargs, methods, attributes).
+
+What replaces what (details in DESIGN.md):
+  TF graph + session            -> curious_ddpg_grads / curious_policy_forward (fp32 MFMA kernels), no session
+  StagingArea feed (stage_op)   -> the packed batch tensor written by curious_her_sample
+  per-buffer sample + concat + shuffle + clip (ddpg.py:326-353) -> ONE curious_her_sample launch
+  2 x MpiAdam (Allreduce + NumPy Adam + getflat/setfromflat) -> one RCCL all-reduce + one fused Adam kernel
+  18 tf.assign ops for Polyak   -> curious_polyak_update
+Reference quirks are kept on purpose: gradients summed over ranks, train() returns main.Q_pi as
+"actor_loss", buffer 0 is never written, only tasks j < 5 are routed when nb_tasks >= 5, buffers 6.. alias buffer 5.
+
+rng_mode='numpy' (default): every random draw comes from the NumPy global stream in the reference's order (parity
+with a seeded reference run).  rng_mode='device': Philox streams on the GPU, nothing crosses PCIe per update and the
+whole train() step can be replayed from a hipGraph (use_graph=True).
+"""
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from curious_amd import _lib, dist, ops
+from curious_amd.her import TransitionBatch, upload_plan
+from curious_amd.mpi_adam import MpiAdam
+from curious_amd.normalizer import Normalizer, recompute_many
+from curious_amd.replay_buffer import EpisodeViews, ReplayBuffer, as_records
+from curious_amd.util import import_function, store_args, transitions_in_episode_batch
+
+ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
+
+
+def dims_to_shapes(input_dims):
+    return {key: tuple([val]) if val > 0 else tuple() for key, val in input_dims.items()}
+
+
+class DDPG(object):
+    @store_args
+    def __init__(self, input_dims, hidden, layers, network_class, polyak, batch_size,
+                 Q_lr, pi_lr, norm_eps, norm_clip, max_u, action_l2, clip_obs, scope, T,
+                 rollout_batch_size, subtract_goals, relative_goals, clip_pos_returns, clip_return,
+                 normalize_obs, sample_transitions, gamma, buffers=None, reuse=False, tasks_ag_id=None,
+                 tasks_g_id=None, task_replay='', t_id=None, eps_task=None, structure='curious',
+                 rng_mode='numpy', seed=0, use_graph=False, **kwargs):
+        """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph."""
+        if self.clip_return is None:
+            self.clip_return = np.inf
+        self.create_actor_critic = import_function(self.network_class)
+        self.dimo, self.dimg = self.input_dims['o'], self.input_dims['g']
+        self.dimag, self.dimu = self.input_dims['ag'], self.input_dims['u']
+        self.dimtd = self.input_dims['task_descr'] if structure in ('curious', 'task_experts') else 0
+        self.modular = bool(getattr(self.create_actor_critic, 'modular', True))
+        if not self.modular:
+            self.dimtd = 0
+        assert rng_mode in ('numpy', 'device')
+        self.device = torch.device('cuda', torch.cuda.current_device())
+
+        # stage order of the reference: sorted non-info keys, then o_2, g_2, r (ddpg.py:75-83)
+        stage_shapes = OrderedDict()
+        input_shapes = dims_to_shapes(self.input_dims)
+        for key in sorted(self.input_dims.keys()):
+            if key.startswith('info_'):
+                continue
+            stage_shapes[key] = (None, *input_shapes[key])
+        for key in ['o', 'g']:
+            stage_shapes[key + '_2'] = stage_shapes[key]
+        stage_shapes['r'] = (None, 1)
+        self.stage_shapes = stage_shapes
+        if t_id is not None:
+            self.scope += str(t_id)
+
+        self._create_network(reuse=reuse)
+
+        if structure in ('curious', 'task_experts'):
+            self.nb_tasks = len(tasks_g_id)
+        if buffers is not None:
+            self.buffer = buffers
+            if type(self.buffer) is list and len(self.buffer) > 5:
+                for i in range(6, len(self.buffer)):                 # distractor buffers are equal (ddpg.py:106-110)
+                    self.buffer[i] = self.buffer[5]
+            self._adopt_buffers()
+        self.first = True
+        self.cp = np.zeros(self.nb_tasks) if hasattr(self, 'nb_tasks') else None
+        self.proportions = None
+        self._staged = None
+        self._graph = None
+        self._tables_dirty = True
+
+    # ------------------------------------------------------------------ construction
+    def _create_network(self, reuse=False):
+        cfg = ops.make_net_cfg(self.dimo, self.dimg, self.dimu, self.dimtd, self.hidden, self.layers, self.modular,
+                               self.max_u, self.gamma, self.clip_return, self.action_l2, self.clip_pos_returns,
+                               self.normalize_obs, self.norm_clip)
+        self.net_cfg = cfg
+        self.P_Q, self.P_pi, self.off_pi, self.P_total = ops.param_layout(cfg)
+        dev = self.device
+        # running averages; both accumulators in one buffer -> one all-reduce per cycle
+        self._stats_acc = torch.zeros(2 * self.dimo + 1 + 2 * self.dimg + 1, dtype=torch.float32, device=dev)
+        self.o_stats = Normalizer(self.dimo, self.norm_eps, self.norm_clip, _acc=self._stats_acc[:2 * self.dimo + 1])
+        self.g_stats = Normalizer(self.dimg, self.norm_eps, self.norm_clip, _acc=self._stats_acc[2 * self.dimo + 1:])
+        # parameters: Xavier-uniform kernels, zero biases (util.py:81,87-88,99).  TensorFlow draws them from its own
+        # generator (not NumPy's), so a private RandomState is used and the NumPy global stream is left untouched.
+        wrng = np.random.RandomState(self.seed)
+        flat = np.concatenate([self._xavier(self._shapes(True), wrng), self._xavier(self._shapes(False), wrng)])
+        self.theta = torch.from_numpy(ops.pad_params(cfg, flat)).to(dev)
+        self.theta_target = torch.empty_like(self.theta)
+        self.grad = torch.zeros_like(self.theta)
+        self._m = torch.zeros_like(self.theta)
+        self._v = torch.zeros_like(self.theta)
+        self.Q_adam = MpiAdam(self.theta[:self.off_pi], scale_grad_by_procs=False)       # ddpg.py:452-453
+        self.pi_adam = MpiAdam(self.theta[self.off_pi:], scale_grad_by_procs=False)
+        self.Q_adam.m, self.Q_adam.v = self._m[:self.off_pi], self._v[:self.off_pi]
+        self.pi_adam.m, self.pi_adam.v = self._m[self.off_pi:], self._v[self.off_pi:]
+        self._workspace = torch.empty(ops.workspace_floats(cfg, self.batch_size), dtype=torch.float32, device=dev)
+        self._act_ws = {}
+        self._losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._Q_pi = torch.zeros([self.batch_size, 1], dtype=torch.float32, device=dev)
+        self._step_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._alpha_tab = torch.zeros([ALPHA_TAB, 2], dtype=torch.float32, device=dev)
+        self._alpha_base = 0
+        self._alpha_filled = 0
+        self._noise_counter = 0
+        self._sync_optimizers()                                      # ddpg.py:466
+        self._init_target_net()                                      # ddpg.py:467
+
+    def _shapes(self, critic):
+        S = self.dimo + (self.dimtd if self.modular else self.dimg) + (self.dimu if critic else 0)
+        out = self.dimu if not critic else 1
+        shapes = [(S, self.hidden), (self.hidden,)]
+        if self.modular:
+            shapes.append((self.dimg, self.hidden))
+        for _ in range(self.layers - 1):
+            shapes += [(self.hidden, self.hidden), (self.hidden,)]
+        shapes += [(self.hidden, out), (out,)]
+        return shapes
+
+    @staticmethod
+    def _xavier(shapes, rng):
+        parts = []
+        for s in shapes:
+            if len(s) == 2:
+                lim = np.sqrt(6.0 / (s[0] + s[1]))
+                parts.append(rng.uniform(-lim, lim, size=s).astype(np.float32).reshape(-1))
+            else:
+                parts.append(np.zeros(s, np.float32))
+        return np.concatenate(parts)
+
+    def _adopt_buffers(self):
+        """All per-task buffers must share one pool so that a mixed minibatch is a single gather launch."""
+        bufs = self.buffer if isinstance(self.buffer, list) else [self.buffer]
+        real = [b for b in bufs if b is not None]
+        pool = real[0].pool
+        for b in real:
+            if b.pool is not pool:
+                raise ValueError('the replay buffers of one agent must share a ReplayPool '
+                                 '(use curious_amd.replay_buffer.make_pooled_buffers / config.configure_buffer)')
+        self._pool = pool
+        self._layout = real[0].layout
+
+    # ------------------------------------------------------------------ acting
+    def _random_action(self, n):
+        return np.random.uniform(low=-self.max_u, high=self.max_u, size=(n, self.dimu))   # ddpg.py:114-115
+
+    def get_actions(self, o, ag, g, task_descr=None, noise_eps=0., random_eps=0., use_target_net=False,
+                    compute_Q=False):
+        """ddpg.py:129-161.  NumPy inputs -> NumPy outputs (host envs); GPU tensors -> GPU tensors (batched env)."""
+        host_io = not isinstance(o, torch.Tensor)
+        dev = self.device
+
+        def up(x, d):
+            if x is None:
+                return None
+            if isinstance(x, torch.Tensor):
+                return x.reshape(-1, d)
+            return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1, d))).to(dev)
+        o_d, g_d, ag_d = up(o, self.dimo), up(g, self.dimg), up(ag, self.dimag)
+        td_d = up(task_descr, self.dimtd) if self.dimtd > 0 else None
+        n = o_d.shape[0]
+        theta = self.theta_target if use_target_net else self.theta
+        ws = self._act_ws.get(n)
+        if ws is None:
+            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=dev)
+            self._act_ws[n] = ws
+        u = torch.empty([n, self.dimu], dtype=torch.float32, device=dev)
+        Q = torch.empty([n, 1], dtype=torch.float32, device=dev) if compute_Q else None
+        ops.policy_forward(self.net_cfg, theta, o_d, g_d, td_d, n, self.clip_obs, ws, u, Q, ag=ag_d,
+                           relative_goals=self.relative_goals,
+                           o_stats=self.o_stats.state if self.normalize_obs else None,
+                           g_stats=self.g_stats.state if self.normalize_obs else None)
+        noise_scale = noise_eps * self.max_u
+        if self.rng_mode == 'numpy':
+            # RNG draws happen even when the eps are 0 (stream consumption matters for seed parity)
+            randn = np.random.randn(n, self.dimu)                    # ddpg.py:149
+            binom = np.random.binomial(1, random_eps, n).astype(np.float64)   # ddpg.py:152
+            unif = self._random_action(n)
+            host = np.concatenate([randn.reshape(-1), binom, unif.reshape(-1)])
+            d = torch.from_numpy(host).to(dev)
+            k = n * self.dimu
+            ops.action_noise(u, n, self.dimu, noise_scale, random_eps, self.max_u, d[:k], d[k:k + n], d[k + n:])
+        else:
+            self._noise_counter += 1
+            ops.action_noise(u, n, self.dimu, noise_scale, random_eps, self.max_u,
+                             seed=self.seed * 2654435761 + 12345 + dist.rank() * 1000003, counter=self._noise_counter)
+        if host_io:
+            u_h = u.cpu().numpy()
+            if u_h.shape[0] == 1:
+                u_h = u_h[0]
+            return [u_h, Q.cpu().numpy()] if compute_Q else u_h
+        return [u, Q] if compute_Q else u
+
+    # ------------------------------------------------------------------ storing
+    def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
+        """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
+        block produced by the batched RolloutWorker (ddpg.py:163-223)."""
+        self.cp = cp
+        self.n_episodes = n_ep
+        layout = self._layout
+        staging = as_records(episode_batch, layout)
+        batch_size = staging.shape[0]
+        if self.structure in ('curious', 'task_experts'):
+            if 'buffer' in self.task_replay or self.task_replay == 'hand_designed':
+                active = torch.empty(batch_size * self.nb_tasks, dtype=torch.int32, device=self.device)
+                ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, active)
+                active = active.cpu().numpy().reshape(batch_size, self.nb_tasks)   # one D2H sync per cycle
+                per_buffer = {}
+                for b in range(batch_size):                          # ddpg.py:178-195, order of the RNG draws kept
+                    for j in range(self.nb_tasks):
+                        if active[b, j] and (self.nb_tasks < 5 or j < 5):
+                            buf = self.buffer[j + 1]
+                            slot = buf._get_storage_idx(1)
+                            buf.n_transitions_stored += self.T
+                            per_buffer.setdefault(id(buf), (buf, [], []))
+                            per_buffer[id(buf)][1].append(b)
+                            per_buffer[id(buf)][2].append(slot)
+                # sequential semantics of the reference: when two episodes of this batch draw the same (random)
+                # slot the later one wins -> keep only the last writer of every destination
+                last = {}
+                for buf, eps, slots in per_buffer.values():
+                    for b, s in zip(eps, slots):
+                        last[int(s) + buf.pool_index * buf.pool.capacity] = b
+                dst, src = list(last.keys()), list(last.values())
+                if src:
+                    ops.store_episodes(self._pool.storage, staging, layout,
+                                       torch.as_tensor(np.asarray(src, np.int32)).to(self.device),
+                                       torch.as_tensor(np.asarray(dst, np.int64)).to(self.device))
+            else:
+                for b in range(batch_size):
+                    slot = self.buffer._get_storage_idx(1)
+                    self.buffer.n_transitions_stored += self.T
+                    self.buffer.store_records(staging, [b], [slot])
+        else:                                                        # flat (ddpg.py:199-204)
+            for b in range(batch_size):
+                slot = self.buffer._get_storage_idx(1)
+                self.buffer.n_transitions_stored += self.T
+                self.buffer.store_records(staging, [b], [slot])
+        self._tables_dirty = True
+
+        if update_stats:                                             # ddpg.py:207-223
+            views = EpisodeViews(staging, layout)
+            n = batch_size * self.T
+            if self.rng_mode == 'numpy':
+                ep, t, u_her, u_off, given = self.sample_transitions.draw(batch_size, self.T, n)
+                plan = upload_plan(n, ep, t, u_her, u_off, ttr=given)
+                rng = None
+            else:
+                plan, rng = None, self._stats_rng(batch_size, n)
+            batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
+            P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
+            ops.her_sample(views.records, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
+            cols = layout.batch_cols
+            self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
+            self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
+            recompute_many([self.o_stats, self.g_stats])
+
+    def _stats_rng(self, n_episodes, n):
+        r = _lib.SampleRng()
+        self._stats_tables = (torch.tensor([0, n], dtype=torch.int32, device=self.device),
+                              torch.tensor([n_episodes], dtype=torch.int32, device=self.device),
+                              torch.tensor([0], dtype=torch.int32, device=self.device),
+                              torch.tensor([-1], dtype=torch.int32, device=self.device))
+        r.seed = (self.seed * 7919 + 17 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+        r.step_ctr = None
+        self._stats_calls = getattr(self, '_stats_calls', 0) + 1
+        r.step_host = self._stats_calls
+        r.prop_prefix, r.cur_size, r.buf_alias, r.buf_task = [x.data_ptr() for x in self._stats_tables]
+        r.nbuf = 1
+        return r
+
+    def get_current_buffer_size(self):
+        return sum([self.buffer[i].get_current_size() for i in range(self.nb_tasks)])
+
+    # ------------------------------------------------------------------ optimiser plumbing
+    def _sync_optimizers(self):
+        dist.broadcast_(self.theta, 0)                               # C3: one broadcast for both networks
+
+    def _grads(self):
+        b = self._staged
+        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, b, self._layout_for_batch, self.batch_size,
+                       self._workspace, self.grad, self._losses, self._Q_pi,
+                       o_stats=self.o_stats.state if self.normalize_obs else None,
+                       g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr)
+        return self._losses[0], self._Q_pi, self.grad[:self.P_Q], self.grad[self.off_pi:self.off_pi + self.P_pi]
+
+    def _update(self, Q_grad=None, pi_grad=None, use_table=False):
+        """Both MpiAdam.update calls of ddpg.py:246-248 as one all-reduce + one kernel over [theta_Q | theta_pi]."""
+        if self.Q_adam.t % 100 == 0:
+            self.Q_adam.theta = self.theta                           # checksum over the fused vector (C4)
+            MpiAdam.check_synced(self.Q_adam)
+            self.Q_adam.theta = self.theta[:self.off_pi]
+        dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
+        self.Q_adam.t += 1
+        self.pi_adam.t += 1
+        if use_table:
+            ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
+                            alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base)
+        else:
+            ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
+                            self.Q_adam.alpha(self.Q_lr), self.pi_adam.alpha(self.pi_lr))
+
+    # ------------------------------------------------------------------ sampling
+    def _proportions(self):
+        """ddpg.py:255-286 (curious, multi-buffer) and ddpg.py:303-318 (task_experts)."""
+        nb1 = self.nb_tasks + 1
+        sizes = np.array([self.buffer[i].current_size * self.T for i in range(nb1)])
+        prop = np.zeros([nb1])
+        if self.structure == 'curious':
+            if sizes[1:].sum() < self.T:
+                valid = np.array([0])
+                n_valid = 1
+                prop = sizes / sizes.sum() * self.batch_size
+            else:
+                valid = np.argwhere(sizes[1:] > 0).reshape(-1)
+                n_valid = len(valid)
+                if self.task_replay == 'replay_task_random_buffer':
+                    proba = 1 / valid.size * np.ones([n_valid])
+                elif self.task_replay == 'replay_task_cp_buffer':
+                    CP = np.asarray(self.cp)[valid]
+                    if CP.sum() == 0:
+                        proba = (1 / n_valid) * np.ones([n_valid])
+                    else:
+                        proba = self.eps_task * (1 / n_valid) * np.ones([n_valid]) + \
+                            (1 - self.eps_task) * CP / CP.sum()
+                    proba[-1] = 1 - proba[:-1].sum()
+                else:
+                    raise NotImplementedError(self.task_replay)
+                prop[valid + 1] = proba * self.batch_size
+            prop = prop.astype(int)
+            for i in range(self.batch_size - prop.sum()):
+                prop[valid[i % n_valid] + 1] += 1
+        else:
+            valid = np.argwhere(sizes > 0).reshape(-1)
+            n_valid = len(valid)
+            if sizes[self.t_id + 1] > 0:
+                prop[self.t_id + 1] = 1
+            else:
+                prop[valid] = 1 / len(valid)
+            prop *= self.batch_size
+            prop = prop.astype(int)
+            for i in range(self.batch_size - prop.sum()):
+                prop[valid[i % n_valid]] += 1
+        return prop.astype(int)
+
+    def _task_of_buffer(self, i):
+        if self.structure == 'curious':
+            return i - 1 if i > 0 else None                          # ddpg.py:329-333
+        return self.t_id                                             # ddpg.py:335
+
+    def _refresh_device_tables(self):
+        nb1 = self.nb_tasks + 1
+        self.proportions = self._proportions()
+        assert self.proportions.sum() == self.batch_size             # ddpg.py:323
+        prefix = np.concatenate([[0], np.cumsum(self.proportions)]).astype(np.int32)
+        alias = np.array([self.buffer[i].pool_index for i in range(nb1)], np.int32)
+        cur = np.zeros(self._pool.n_buffers, np.int32)
+        for i in range(nb1):
+            cur[self.buffer[i].pool_index] = self.buffer[i].current_size
+        for i in range(nb1):
+            assert self.proportions[i] == 0 or self.buffer[i].current_size > 0   # replay_buffer.py:43
+        task = np.array([-1 if self._task_of_buffer(i) is None else self._task_of_buffer(i) for i in range(nb1)],
+                        np.int32)
+        host = np.concatenate([prefix, alias, task, cur])
+        if getattr(self, '_tables', None) is None or self._tables.numel() != host.size:
+            self._tables = torch.zeros(host.size, dtype=torch.int32, device=self.device)
+        self._tables.copy_(torch.from_numpy(host), non_blocking=False)
+        n0 = nb1 + 1
+        r = _lib.SampleRng()
+        r.seed = (self.seed * 104729 + 7 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+        r.step_ctr = self._step_ctr.data_ptr()
+        r.step_host = 0
+        r.prop_prefix = self._tables[:n0].data_ptr()
+        r.buf_alias = self._tables[n0:n0 + nb1].data_ptr()
+        r.buf_task = self._tables[n0 + nb1:n0 + 2 * nb1].data_ptr()
+        r.cur_size = self._tables[n0 + 2 * nb1:].data_ptr()
+        r.nbuf = nb1
+        self._rng_desc = r
+        self._tables_dirty = False
+
+    def _multi_buffer(self):
+        return self.structure in ('curious', 'task_experts') and \
+            ('buffer' in self.task_replay or self.task_replay == 'hand_designed')
+
+    def _sample_packed(self):
+        """One packed, clipped, permuted minibatch [batch_size, stride] on the GPU."""
+        S = self.sample_transitions
+        P = S.params(self.clip_obs, self.relative_goals)
+        B = self.batch_size
+        if self._multi_buffer():
+            layout = self._layout
+            if self._staged is None or self._staged.shape != (B, layout.batch_stride):
+                self._staged = torch.empty([B, layout.batch_stride], dtype=torch.float32, device=self.device)
+            if self.rng_mode == 'device':
+                if self._tables_dirty:
+                    self._refresh_device_tables()
+                ops.her_sample(self._pool.storage, self._pool.buf_stride, layout, S.tasks, P, B, self._staged,
+                               rng=self._rng_desc)
+            else:
+                self.proportions = self._proportions()
+                assert self.proportions.sum() == B                   # ddpg.py:323
+                ep, t, uh, uo, bufi, ttr = [], [], [], [], [], []
+                for i in range(self.nb_tasks + 1):                   # ddpg.py:327-336
+                    n_i = int(self.proportions[i])
+                    if n_i > 0:
+                        buf = self.buffer[i]
+                        assert buf.current_size > 0                  # replay_buffer.py:43
+                        d = S.draw(buf.current_size, self.T, n_i)
+                        ep.append(d[0]); t.append(d[1]); uh.append(d[2]); uo.append(d[3])
+                        bufi.append(np.full(n_i, buf.pool_index, np.int32))
+                        task = self._task_of_buffer(i)
+                        ttr.append(np.full(n_i, -1 if task is None else task, np.int32))
+                shuffle_inds = np.arange(B)
+                np.random.shuffle(shuffle_inds)                      # ddpg.py:338-339
+                out_row = np.empty(B, np.int32)
+                out_row[shuffle_inds] = np.arange(B)                 # out[j] = tmp[shuffle_inds[j]] (ddpg.py:345)
+                plan = upload_plan(B, np.concatenate(ep), np.concatenate(t), np.concatenate(uh), np.concatenate(uo),
+                                   buf=np.concatenate(bufi), ttr=np.concatenate(ttr), out_row=out_row)
+                ops.her_sample(self._pool.storage, self._pool.buf_stride, layout, S.tasks, P, B, self._staged,
+                               plan=plan)
+            self._layout_for_batch = layout
+            return self._staged
+        # single buffer (flat, or the *_task_transition replay modes): ddpg.py:288-299,320,348
+        buf = self.buffer
+        layout = buf.layout
+        cp_proba = None
+        if self.structure == 'curious' and self.task_replay == 'replay_cp_task_transition':
+            CP = np.asarray(self.cp, dtype=np.float64).copy()
+            if CP.sum() == 0:
+                cp_proba = (1 / self.nb_tasks) * np.ones([self.nb_tasks])
+            else:
+                cp_proba = self.eps_task * (1 / self.nb_tasks) * np.ones([self.nb_tasks]) + \
+                    (1 - self.eps_task) * CP / CP.sum()
+            cp_proba[-1] = 1 - cp_proba[:-1].sum()
+        assert buf.current_size > 0
+        ep, t, uh, uo, given = S.draw(buf.current_size, self.T, B, cp_proba)
+        plan = upload_plan(B, ep, t, uh, uo, buf=np.full(B, buf.pool_index, np.int32), ttr=given)
+        if self._staged is None or self._staged.shape != (B, layout.batch_stride):
+            self._staged = torch.empty([B, layout.batch_stride], dtype=torch.float32, device=self.device)
+        ops.her_sample(buf.pool.storage, buf.pool.buf_stride, layout, S.tasks, P, B, self._staged, plan=plan)
+        self._layout_for_batch = layout
+        return self._staged
+
+    def sample_batch(self):
+        """Returns the staged arrays in the reference's order (ddpg.py:251-360) as GPU views:
+        ag, g, o, task_descr, u, o_2, g_2, r for the multi-task structures."""
+        packed = self._sample_packed()
+        views = self._layout_for_batch.batch_views(packed)
+        return [views[key] for key in self.stage_shapes.keys()]
+
+    def stage_batch(self, batch=None):
+        """ddpg.py:362-366.  With batch=None a fresh minibatch is sampled straight into the staging tensor."""
+        if batch is None:
+            self._sample_packed()
+            return
+        assert len(self.stage_shapes) == len(batch)
+        layout = self._layout
+        host = np.zeros([self.batch_size, layout.batch_stride], np.float32)
+        for key, arr in zip(self.stage_shapes.keys(), batch):
+            off, dim = layout.batch_cols[key]
+            a = arr.detach().cpu().numpy() if isinstance(arr, torch.Tensor) else np.asarray(arr)
+            host[:, off:off + dim] = a.reshape(self.batch_size, dim)
+        self._staged = torch.from_numpy(host).to(self.device)
+        self._layout_for_batch = layout
+
+    # ------------------------------------------------------------------ training
+    def _fill_alpha_table(self):
+        t0 = self.Q_adam.t
+        n = ALPHA_TAB
+        tab = np.empty([n, 2], np.float32)
+        ts = np.arange(t0 + 1, t0 + n + 1)
+        tab[:, 0] = [self.Q_adam.alpha(self.Q_lr, int(t)) for t in ts]
+        tab[:, 1] = [self.pi_adam.alpha(self.pi_lr, int(t)) for t in ts]
+        self._alpha_tab.copy_(torch.from_numpy(tab))
+        self._alpha_base = t0
+        self._alpha_filled = t0 + n
+        self._step_ctr.fill_(t0)
+
+    def _train_body(self):
+        self._sample_packed()
+        self._grads()
+        self._update(use_table=True)
+
+    def train(self, stage=True):
+        """One update (ddpg.py:368-373).  Returns (critic_loss, actor_loss) as GPU tensors (no host sync);
+        actor_loss is main.Q_pi like in the reference (ddpg.py:237-243)."""
+        if self.use_graph and self.rng_mode == 'device' and stage and self._multi_buffer():
+            return self._train_graph()
+        if stage:
+            self.stage_batch()
+        critic_loss, actor_loss, Q_grad, pi_grad = self._grads()
+        self._update(Q_grad, pi_grad)
+        return critic_loss, actor_loss
+
+    def _train_graph(self):
+        if self._tables_dirty:
+            self._refresh_device_tables()
+        if self.Q_adam.t + 1 > self._alpha_filled or self._alpha_filled == 0:
+            self._fill_alpha_table()
+        if self._graph is None:
+            if dist.is_distributed():
+                # the all-reduce stays outside: graph A = sample + grads, graph B = Adam
+                self._graph = self._capture(lambda: (self._sample_packed(), self._grads()))
+                self._graph_b = self._capture(lambda: self._adam_only())
+            else:
+                self._graph = self._capture(self._train_body_nocheck)
+                self._graph_b = None
+        if self.Q_adam.t % 100 == 0 and dist.is_distributed():
+            self.Q_adam.theta = self.theta
+            MpiAdam.check_synced(self.Q_adam)
+            self.Q_adam.theta = self.theta[:self.off_pi]
+        self._graph.replay()
+        if self._graph_b is not None:
+            dist.allreduce_sum_(self.grad)
+            self._graph_b.replay()
+        self.Q_adam.t += 1
+        self.pi_adam.t += 1
+        return self._losses[0], self._Q_pi
+
+    def _adam_only(self):
+        ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
+                        alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base)
+
+    def _train_body_nocheck(self):
+        self._sample_packed()
+        self._grads()
+        self._adam_only()
+
+    def _capture(self, fn):
+        """Capture `fn`'s kernel launches into a hipGraph (after one eager warm-up on a side stream)."""
+        ctr = self._step_ctr.clone()
+        state = (self.theta.clone(), self._m.clone(), self._v.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        # undo the side effects of the warm-up / capture runs
+        self._step_ctr.copy_(ctr)
+        self.theta.copy_(state[0]); self._m.copy_(state[1]); self._v.copy_(state[2])
+        return g
+
+    def _init_target_net(self):
+        ops.polyak_update(self.theta_target, self.theta, 0.0)        # ddpg.py:459-460
+
+    def update_target_net(self):
+        ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
+
+    def clear_buffer(self):
+        for i in range(self.nb_tasks):
+            self.buffer[i].clear_buffer()
+        self._tables_dirty = True
+
+    # ------------------------------------------------------------------ logging / persistence
+    def logs(self, prefix=''):
+        logs = []
+        logs += [('stats_o/mean', float(self.o_stats.mean.mean()))]
+        logs += [('stats_o/std', float(self.o_stats.std.mean()))]
+        logs += [('stats_g/mean', float(self.g_stats.mean.mean()))]
+        logs += [('stats_g/std', float(self.g_stats.std.mean()))]
+        if prefix != '' and not prefix.endswith('/'):
+            return [(prefix + '/' + key, val) for key, val in logs]
+        return logs
+
+    def _net_arrays(self, vec, critic):
+        off = 0 if critic else self.off_pi
+        flat = vec[off:off + (self.P_Q if critic else self.P_pi)].cpu().numpy()
+        out, o = [], 0
+        for s in self._shapes(critic):
+            n = int(np.prod(s))
+            out.append(flat[o:o + n].reshape(s).copy())
+            o += n
+        return out
+
+    def _load_net_arrays(self, vec, critic, arrays):
+        off = 0 if critic else self.off_pi
+        flat = np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrays])
+        assert flat.size == (self.P_Q if critic else self.P_pi)
+        vec[off:off + flat.size].copy_(torch.from_numpy(flat))
+
+    def _stats_arrays(self, nz):
+        d, s = nz.size, nz.state.cpu().numpy()
+        # TF global-variable creation order of Normalizer (normalizer.py:31-45): sum, sumsq, count, mean, std
+        return [s[:d].copy(), s[d:2 * d].copy(), s[2 * d:2 * d + 1].copy(), s[2 * d + 1:3 * d + 1].copy(),
+                s[3 * d + 1:].copy()]
+
+    def save_weights(self, path):
+        """Pickled list of lists in the reference's order: main/Q, main/pi, target/Q, target/pi, o_stats, g_stats
+        (ddpg.py:481-497)."""
+        to_save = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),
+                   self._net_arrays(self.theta_target, True), self._net_arrays(self.theta_target, False),
+                   self._stats_arrays(self.o_stats), self._stats_arrays(self.g_stats)]
+        with open(path + '_weights.pkl', 'wb') as f:
+            pickle.dump(to_save, f)
+
+    def load_weights(self, path):
+        with open(path + '_weights.pkl', 'rb') as f:
+            weights = pickle.load(f)                                 # ddpg.py:499-509
+        self._load_net_arrays(self.theta, True, weights[0])
+        self._load_net_arrays(self.theta, False, weights[1])
+        self._load_net_arrays(self.theta_target, True, weights[2])
+        self._load_net_arrays(self.theta_target, False, weights[3])
+        for nz, arrs in ((self.o_stats, weights[4]), (self.g_stats, weights[5])):
+            nz.state.copy_(torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs])))
+
+    def __getstate__(self):
+        """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521)."""
+        excluded = ['_tf', '_op', '_vars', '_adam', 'buffer', 'sess', '_stats', 'main', 'target', 'lock', 'env',
+                    'sample_transitions', 'stage_shapes', 'create_actor_critic', 'theta', 'grad', 'net_cfg',
+                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_workspace',
+                    '_act_ws', '_losses', '_Q_pi', '_step_ctr', '_alpha_tab', '_m', '_v', 'kwargs']
+        state = {k: v for k, v in self.__dict__.items() if all(sub not in k for sub in excluded)}
+        state['weights'] = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),
+                            self._net_arrays(self.theta_target, True), self._net_arrays(self.theta_target, False),
+                            self._stats_arrays(self.o_stats), self._stats_arrays(self.g_stats)]
+        return state
+
+    def __setstate__(self, state):
+        weights = state.pop('weights')
+        if 'sample_transitions' not in state:
+            state['sample_transitions'] = None
+        for k in ('dimo', 'dimg', 'dimag', 'dimu', 'dimtd', 'modular', 'P_Q', 'P_pi', 'off_pi', 'P_total', 'first',
+                  'cp', 'proportions', 'nb_tasks', 'n_episodes'):
+            state.pop(k, None)
+        self.__init__(**state)
+        self._load_net_arrays(self.theta, True, weights[0])
+        self._load_net_arrays(self.theta, False, weights[1])
+        self._load_net_arrays(self.theta_target, True, weights[2])
+        self._load_net_arrays(self.theta_target, False, weights[3])
+        for nz, arrs in ((self.o_stats, weights[4]), (self.g_stats, weights[5])):
+            nz.state.copy_(torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs])))

@@ -1,0 +1,204 @@
+"""Synthetic MultiTaskFetchArm stand-ins resident on the GPU.
+
+The reference trains on MuJoCo environments from the un-vendored `gym_flowers` package (config.py:2-3,112-122);
+neither MuJoCo nor gym_flowers exists here, so the rollout half of the hot path is exercised on a small
+deterministic point-mass arm with the same interface, dimensions and task/goal tables (specification:
+oracle/env.py; kernels: curious_amd/csrc/env.hip).  Two front-ends share those kernels:
+
+  BatchedSyntheticArm   n environments stepped by ONE kernel launch, episode records written in place in the
+                        staging block the replay store reads (used by RolloutWorker's batched path);
+  SyntheticArmEnv       a single environment answering the gym-style protocol the reference consumes
+                        (SURVEY 8b "Env protocol consumed"), for code that insists on a Python list of envs.
+"""
+import numpy as np
+import torch
+
+from curious_amd import ops
+from curious_amd.layout import RecordLayout
+from curious_amd.replay_buffer import EpisodeViews
+
+ENV_CONFIGS = {
+    # name: (nb_tasks, dimo, T)  -- dimo / T are assumptions, the real values come from gym_flowers
+    'MultiTaskFetchArm4-v5': (4, 40, 50),
+    'MultiTaskFetchArm8-v5': (8, 52, 50),
+}
+REWARD_EPS = 0.05
+
+
+class _Space:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class _DictSpace:
+    def __init__(self, spaces):
+        self.spaces = spaces
+
+
+class ArmSpec:
+    """Static description shared by both front-ends."""
+
+    def __init__(self, name):
+        if name not in ENV_CONFIGS:
+            raise KeyError('unknown synthetic env %r (have %s)' % (name, sorted(ENV_CONFIGS)))
+        self.name = name
+        self.nb_tasks, self.dimo, self.T = ENV_CONFIGS[name]
+        self.dimg = self.dimag = 3 * self.nb_tasks
+        self.dimu = 4
+        self.tasks_g_id = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(self.nb_tasks)]
+        self.tasks_ag_id = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(self.nb_tasks)]
+        self.info = {'is_success': 0.0}
+        self._max_episode_steps = self.T
+        self.observation_space = _DictSpace(dict(observation=_Space([self.dimo]), achieved_goal=_Space([self.dimag]),
+                                                 desired_goal=_Space([self.dimg])))
+        self.action_space = _Space([self.dimu])
+        self.reward_spec = dict(kind='sparse_l2', eps=REWARD_EPS)
+
+    def dims(self):
+        return dict(o=self.dimo, u=self.dimu, g=self.dimg, ag=self.dimag, task_descr=self.nb_tasks,
+                    info_is_success=1)
+
+    def buffer_shapes(self):
+        T = self.T                                                   # config.py:198-206
+        return dict(o=(T + 1, self.dimo), u=(T, self.dimu), g=(T, self.dimg), ag=(T + 1, self.dimag),
+                    info_is_success=(T, 1), task_descr=(T, self.nb_tasks), change=(T, self.dimag))
+
+
+def sparse_reward_fun(spec):
+    """reward_fun(ag_2, g, task_descr, info) placeholder carrying the kernel-side reward description.  The HER
+    kernel evaluates the reward on the GPU; this callable exists so that the reference's plumbing
+    (config.py:158-167) has something to pass around, and refuses to be evaluated on the host."""
+    def reward_fun(ag_2=None, g=None, task_descr=None, info=None):
+        raise NotImplementedError('the sparse reward is evaluated inside curious_her_sample on the GPU')
+    reward_fun.spec = dict(spec)
+    return reward_fun
+
+
+class BatchedSyntheticArm(ArmSpec):
+    def __init__(self, name, n, seed=0, env_id0=0, T=None):
+        super().__init__(name)
+        if T is not None:
+            self.T = self._max_episode_steps = int(T)
+        self.n, self.env_id0 = int(n), int(env_id0)
+        self._seed = int(seed)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        self.device = dev
+        self.layout = RecordLayout(self.buffer_shapes(), self.T)
+        self.o = torch.zeros([n, self.dimo], device=dev)
+        self.ag = torch.zeros([n, self.dimag], device=dev)
+        self.g = torch.zeros([n, self.dimg], device=dev)
+        self.td = torch.zeros([n, self.nb_tasks], device=dev)
+        self.staging = torch.zeros([n, self.T + 1, self.layout.row_stride], device=dev)
+        self.episode = torch.zeros(n, dtype=torch.int32, device=dev)     # episodes started so far, per env
+        self.tasks = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.tasks_host = np.zeros(n, np.int32)
+        self.goals_host = np.zeros([n, 3], np.float32)
+        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed):
+        self._seed = int(seed)
+        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
+        self.episode.zero_()
+
+    def reset_all(self, tasks, goals_raw):
+        """tasks[n] int, goals_raw[n,3] in [-1,1] (rollout.py:120-143 for every env at once)."""
+        self.tasks_host[:] = tasks
+        self.goals_host[:] = goals_raw
+        self.tasks.copy_(torch.from_numpy(self.tasks_host))
+        goals = torch.from_numpy(self.goals_host).to(self.device)
+        ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, goals, self.n, self.o, self.ag,
+                      self.g, self.td, self.staging)
+        self.episode += 1
+
+    def step_all(self, u, t):
+        ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,
+                     self.g, self.td, self.staging, REWARD_EPS)
+
+    def episode_views(self):
+        return EpisodeViews(self.staging, self.layout, with_next=False)
+
+    def last_success(self):
+        """is_success of the final step, [n] float32 on the GPU."""
+        return self.staging[:, self.T - 1, self.layout.off['info_is_success']]
+
+
+class SyntheticArmEnv(ArmSpec):
+    """Single environment with the protocol of the reference's gym_flowers envs (one-env batched arm inside)."""
+
+    def __init__(self, name, seed=0, env_id=0):
+        super().__init__(name)
+        self._b = BatchedSyntheticArm(name, 1, seed=seed, env_id0=env_id)
+        self.task = 0
+        self.goal = np.zeros(self.dimg, np.float32)
+        self._t = 0
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed=None):
+        self._b.seed(seed)
+
+    def _obs(self):
+        return dict(observation=self._b.o[0].cpu().numpy(), achieved_goal=self._b.ag[0].cpu().numpy(),
+                    desired_goal=self._b.g[0].cpu().numpy(), mask=self._b.td[0].cpu().numpy())
+
+    def reset(self):
+        self._b.reset_all(np.array([self.task]), np.zeros([1, 3], np.float32))
+        self._t = 0
+        return self._obs()
+
+    def _compute_goal(self, g, task, eval=False):
+        goal = np.zeros(self.dimg, np.float32)
+        goal[self.tasks_g_id[task]] = np.float32(0.5) * np.asarray(g, dtype=np.float32)
+        mask = np.zeros(self.nb_tasks, np.float32)
+        mask[task] = 1
+        return goal, mask
+
+    def reset_task_goal(self, goal, task=0, directly=False, eval=False):
+        """Sets task and goal of the CURRENT episode (the state drawn by reset() is kept)."""
+        self.task = int(task)
+        raw = np.asarray(goal, dtype=np.float32) * (np.float32(2.0) if directly else np.float32(1.0))
+        b = self._b
+        b.tasks_host[0] = self.task
+        b.tasks.copy_(torch.from_numpy(b.tasks_host))
+        full, mask = self._compute_goal(raw, self.task)
+        self.goal = full
+        b.g[0].copy_(torch.from_numpy(full))
+        b.td[0].copy_(torch.from_numpy(mask))
+        return self._obs()
+
+    def step(self, u):
+        u_d = torch.as_tensor(np.asarray(u, dtype=np.float32).reshape(1, -1)).to(self._b.device)
+        t = min(self._t, self.T - 1)
+        self._b.step_all(u_d, t)
+        self._t += 1
+        succ = float(self._b.staging[0, t, self._b.layout.off['info_is_success']])
+        return self._obs(), succ - 1.0, False, {'is_success': succ}
+
+    def compute_reward(self, achieved_goal, goal, task_descr=None, info=None):
+        raise NotImplementedError('the sparse reward is evaluated inside curious_her_sample on the GPU '
+                                  '(reward_spec = %r)' % (self.reward_spec,))
+
+    def render(self):
+        pass
+
+
+class EnvFactory:
+    """`make_env` of config.prepare_params (config.py:112-115): callable -> single env; .make_batched(n) -> batched."""
+
+    def __init__(self, name):
+        self.name = name
+        self._count = 0
+
+    def __call__(self):
+        e = SyntheticArmEnv(self.name, env_id=self._count)
+        self._count += 1
+        return e
+
+    def make_batched(self, n, env_id0=0):
+        return BatchedSyntheticArm(self.name, n, env_id0=env_id0)

@@ -1,0 +1,255 @@
+"""Training entry point.  Mirrors baselines/her/experiment/train.py (train(), logs(), launch(), CLI flags).
+
+Launch one process per GPU:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N -m curious_amd.experiment.train --env ... --num_cpu N
+(the reference re-executes itself under `mpirun -np N`, util.py:148-171; here the ranks are created by
+torch.distributed.run and `--num_cpu` only has to match WORLD_SIZE).
+"""
+import argparse
+import datetime
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from curious_amd import dist, logger
+from curious_amd.experiment import config
+from curious_amd.rollout import RolloutWorker
+from curious_amd.util import find_save_path, mpi_average
+
+ENV = 'MultiTaskFetchArm4-v5'
+NUM_CPU = 1
+STRUCTURE = 'curious'                       # 'curious' | 'flat' | 'task_experts'
+TASK_SELECTION = 'active_competence_progress'
+GOAL_SELECTION = 'random'
+GOAL_REPLAY = 'her'
+TASK_REPLAY = 'replay_task_cp_buffer'
+t0 = time.time()
+
+
+def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
+          save_policies, structure, task_selection, params, perturbation_study=False, **kwargs):
+    """train.py:49-166."""
+    rank = dist.rank()
+    if rank == 0 and logger.get_dir() is not None:
+        latest_policy_path = os.path.join(logger.get_dir(), 'policy_latest.pkl')
+        best_policy_path = os.path.join(logger.get_dir(), 'policy_best.pkl')
+        periodic_policy_path = os.path.join(logger.get_dir(), 'policy_{}.pkl')
+        logger.info("Training...")
+    else:
+        latest_policy_path = best_policy_path = periodic_policy_path = None
+    best_success_rate = -1
+    nb_tasks = params['nb_tasks']
+
+    if structure == 'task_experts':
+        p = 1 / nb_tasks * np.ones([nb_tasks])
+        epoch, i_policy = -1, -1
+        evaluator.clear_history()
+        evaluator.clear_competence_queue()
+        for _ in range(n_test_rollouts):
+            evaluator.generate_rollouts()
+        best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate, best_policy_path,
+                                 periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
+                                 policy[i_policy], rank, structure, i_policy=i_policy, task_experts_cp=p)
+        for epoch in range(n_epochs):
+            if task_selection == 'random':
+                i_policy = epoch % nb_tasks                           # train.py:79-81
+            else:
+                # train.py:82-104: the reference computes `proba` from CP but draws from the stale uniform `p`
+                # (SURVEY 7 quirk list); rank 0 draws, everyone follows (C12)
+                i_policy = int(np.random.choice(range(nb_tasks), p=p)) if rank == 0 else 0
+                i_policy = dist.broadcast_object(i_policy, 0)
+            rollout_worker[i_policy].clear_history()
+            for _ in range(n_cycles):
+                episode, cp, n_ep = rollout_worker[i_policy].generate_rollouts()
+                policy[i_policy].store_episode(episode, cp, n_ep)
+                for _ in range(n_batches):
+                    policy[i_policy].train()
+                policy[i_policy].update_target_net()
+            evaluator.clear_history()
+            for _ in range(n_test_rollouts):
+                evaluator.generate_rollouts()
+            best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate,
+                                     best_policy_path, periodic_policy_path, policy_save_interval, save_policies,
+                                     latest_policy_path, policy[i_policy], rank, structure, i_policy=i_policy,
+                                     task_experts_cp=p)
+    else:
+        epoch = -1
+        evaluator.clear_history()
+        for _ in range(n_test_rollouts):
+            evaluator.generate_rollouts()
+        best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
+                                 periodic_policy_path, policy_save_interval, save_policies, latest_policy_path, policy,
+                                 rank, structure)
+        for epoch in range(n_epochs):
+            logger.info('Starting new epoch ', epoch, 'at time', time.time() - t0)
+            t_ep = time.time()
+            rollout_worker.clear_history()
+            for cyc in range(n_cycles):                               # train.py:148-155 -- the hot loop
+                episode, cp, n_ep = rollout_worker.generate_rollouts()
+                policy.store_episode(episode, cp, n_ep)
+                for j in range(n_batches):
+                    policy.train()
+                policy.update_target_net()
+            evaluator.clear_history()
+            for _ in range(n_test_rollouts):
+                evaluator.generate_rollouts()
+            torch.cuda.synchronize()
+            logger.info('Epoch', epoch, 'over in ', time.time() - t_ep, 's.')
+            best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
+                                     periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
+                                     policy, rank, structure)
+    return best_success_rate
+
+
+def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, periodic_policy_path,
+         policy_save_interval, save_policies, latest_policy_path, policy, rank, structure, i_policy=None,
+         task_experts_cp=None):
+    """train.py:170-214: same keys in progress.csv."""
+    logger.record_tabular('epoch', epoch)
+    for key, val in evaluator.logs('test'):
+        logger.record_tabular(key, "%.3g" % mpi_average(val))
+    for key, val in rollout_worker.logs('train'):
+        logger.record_tabular(key, "%.3g" % mpi_average(val))
+    for key, val in policy.logs():
+        logger.record_tabular(key, "%.3g" % mpi_average(val))
+    if rank == 0:
+        if i_policy is not None:
+            logger.record_tabular('IND_TASK_rollout', i_policy)
+        for key, val in rollout_worker.additional_logs('train'):
+            logger.record_tabular(key, val)
+        for key, val in evaluator.additional_logs('test'):
+            logger.record_tabular(key, val)
+        logger.record_tabular('Time', time.time() - t0)
+        logger.dump_tabular()
+    else:
+        logger._state['kv'].clear()
+    success_rate = mpi_average(evaluator.current_success_rate())
+    if rank == 0 and success_rate >= best_success_rate and save_policies and best_policy_path:
+        best_success_rate = success_rate
+        logger.info('New best success rate: {}. Saving policy to {} ...'.format(best_success_rate, best_policy_path))
+        evaluator.save_policy(best_policy_path)
+    if rank == 0 and policy_save_interval > 0 and epoch % policy_save_interval == 0 and save_policies \
+            and periodic_policy_path:
+        policy_path = periodic_policy_path.format(epoch)
+        logger.info('Saving periodic policy to {} ...'.format(policy_path))
+        evaluator.save_policy(policy_path)
+        evaluator.save_policy(latest_policy_path)
+    # ranks must hold different RNG streams (train.py:207-212, C13)
+    local_uniform = np.random.uniform(size=(1,))
+    root_uniform = dist.broadcast_object(float(local_uniform[0]), 0)
+    if rank != 0:
+        assert local_uniform[0] != root_uniform
+    return best_success_rate
+
+
+def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_return, normalize_obs, structure,
+           task_selection, goal_selection, goal_replay, task_replay, perturb=False, save_policies=True,
+           override_params=None, save_root='./save/'):
+    """train.py:217-339."""
+    dist.init_from_env()
+    rank = dist.rank()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    if rank == 0:
+        save_dir = find_save_path(save_root + env + "/", trial_id)
+        logger.configure(dir=save_dir)
+    else:
+        save_dir = None
+    rank_seed = seed + 1000000 * rank                                 # train.py:242-243
+    np.random.seed(rank_seed)
+    import random
+    random.seed(rank_seed)
+    torch.manual_seed(rank_seed)
+
+    params = dict(config.MULTI_TASK_PARAMS if structure in ('curious', 'task_experts') else config.DEFAULT_PARAMS)
+    params.setdefault('eps_task', 0.4)
+    params['time'] = str(datetime.datetime.now())
+    params.update(env_name=env, task_selection=task_selection, goal_selection=goal_selection, task_replay=task_replay,
+                  goal_replay=goal_replay, structure=structure, normalize_obs=normalize_obs, num_cpu=num_cpu,
+                  clip_return=clip_return, trial_id=trial_id, seed=seed)
+    if override_params:
+        params.update(override_params)
+    if rank == 0:
+        with open(os.path.join(logger.get_dir(), 'params.json'), 'w') as f:
+            json.dump({k: v for k, v in params.items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
+    params = config.prepare_params(params)
+    params['ddpg_params']['normalize_obs'] = normalize_obs
+    params['ddpg_params'].setdefault('seed', seed)                    # identical initial weights on every rank
+    if rank == 0:
+        config.log_params(params, logger=logger)
+    if num_cpu != dist.world_size():
+        logger.warn('--num_cpu %d differs from WORLD_SIZE %d; ranks are created by torch.distributed.run' %
+                    (num_cpu, dist.world_size()))
+
+    dims = config.configure_dims(params)
+    buffers = config.configure_buffer(dims=dims, params=params)
+    if structure == 'task_experts':
+        policy = [config.configure_ddpg(dims=dims, params=params, buffers=buffers, clip_return=clip_return, t_id=i)
+                  for i in range(params['nb_tasks'])]
+    else:
+        policy = config.configure_ddpg(dims=dims, params=params, buffers=buffers, clip_return=clip_return)
+
+    rollout_params = {'exploit': False, 'use_target_net': False, 'use_demo_states': True, 'compute_Q': False,
+                      'T': params['T'], 'structure': structure, 'task_selection': task_selection,
+                      'goal_selection': goal_selection, 'queue_length': params['queue_length'], 'eval': False,
+                      'eps_task': params['eps_task']}
+    eval_params = {'exploit': True, 'use_target_net': params['test_with_polyak'], 'use_demo_states': False,
+                   'compute_Q': True, 'T': params['T'], 'structure': structure, 'task_selection': task_selection,
+                   'goal_selection': goal_selection, 'queue_length': params['queue_length'], 'eval': True}
+    for name in ['T', 'rollout_batch_size', 'gamma', 'noise_eps', 'random_eps']:
+        rollout_params[name] = params[name]
+        eval_params[name] = params[name]
+    if structure == 'task_experts':
+        rollout_worker = [RolloutWorker(params['make_env'], policy[i], dims, logger, unique_task=i, **rollout_params)
+                          for i in range(params['nb_tasks'])]
+        for i in range(params['nb_tasks']):
+            rollout_worker[i].seed(rank_seed + i)
+    else:
+        rollout_worker = RolloutWorker(params['make_env'], policy, dims, logger, **rollout_params)
+        rollout_worker.seed(rank_seed)
+    evaluator = RolloutWorker(params['make_env'], policy, dims, logger, **eval_params)
+    evaluator.seed(rank_seed + 100)
+
+    return train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
+                 n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],
+                 n_batches=params['n_batches'], perturbation_study=perturb, policy_save_interval=policy_save_interval,
+                 save_policies=save_policies, structure=structure, task_selection=task_selection, params=params)
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('--env', type=str, default=ENV)
+    parser.add_argument('--trial_id', type=int, default=0)
+    parser.add_argument('--n_epochs', type=int, default=316)
+    parser.add_argument('--num_cpu', type=int, default=NUM_CPU)
+    parser.add_argument('--seed', type=int, default=int(np.random.randint(1e6)))
+    parser.add_argument('--policy_save_interval', type=int, default=20)
+    parser.add_argument('--clip_return', type=int, default=1)
+    parser.add_argument('--normalize_obs', type=lambda s: s.lower() in ('1', 'true', 'yes'), default=False)
+    parser.add_argument('--structure', type=str, default=STRUCTURE)
+    parser.add_argument('--task_selection', type=str, default=TASK_SELECTION)
+    parser.add_argument('--goal_selection', type=str, default=GOAL_SELECTION)
+    parser.add_argument('--goal_replay', type=str, default=GOAL_REPLAY)
+    parser.add_argument('--task_replay', type=str, default=TASK_REPLAY)
+    parser.add_argument('--perturb', type=lambda s: s.lower() in ('1', 'true', 'yes'), default=False)
+    # MI355X-side knobs
+    parser.add_argument('--rollout_batch_size', type=int, default=None)
+    parser.add_argument('--rng_mode', type=str, default='device', choices=['numpy', 'device'])
+    parser.add_argument('--use_graph', type=int, default=1)
+    parser.add_argument('--n_cycles', type=int, default=None)
+    parser.add_argument('--n_batches', type=int, default=None)
+    args = vars(parser.parse_args(argv))
+    over = {'rng_mode': args.pop('rng_mode'), 'use_graph': bool(args.pop('use_graph'))}
+    for k in ('rollout_batch_size', 'n_cycles', 'n_batches'):
+        v = args.pop(k)
+        if v is not None:
+            over[k] = v
+    launch(override_params=over, **args)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

@@ -1,0 +1,336 @@
+"""Rollout worker.  Mirrors RolloutWorker baselines/her/rollout.py:13-501 (constructor kwargs, methods, attributes).
+
+Two execution paths behind the same interface:
+  * batched (make_env has .make_batched): all `rollout_batch_size` environments live on the GPU; one T-step rollout
+    is T x {actor forward, noise epilogue, env step} kernel launches with no host round trip, and the episode record
+    is written in place in the staging block that DDPG.store_episode copies from (rollout.py:209-303 without the
+    Python lists, np.array(...).swapaxes of util.py:174-184, or per-env loops);
+  * generic (a Python list of gym-style envs): the reference's loop, kept for real environments.
+MPI call sites replaced: C7/C8 each rank draws its own tasks/goals from the shared p; C9 one
+all-gather of (task, success, valid) per rollout after which every rank updates identical competence queues, which
+makes the C10 broadcasts of p / CP unnecessary.
+"""
+import pickle
+from collections import deque
+
+import numpy as np
+import torch
+
+from curious_amd import dist
+from curious_amd.queues import CompetenceQueue, task_probabilities
+from curious_amd.util import convert_episode_to_batch_major, store_args
+
+
+class RolloutWorker:
+    @store_args
+    def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1, exploit=False, use_target_net=False,
+                 compute_Q=False, noise_eps=0, random_eps=0, history_len=100, render=False, structure='curious',
+                 task_selection='random', goal_selection='random', queue_length=500, eval=False, unique_task=None,
+                 temperature=None, **kwargs):
+        """Same arguments as the reference (rollout.py:16-40)."""
+        assert self.T > 0
+        if goal_selection != 'random':
+            raise NotImplementedError("only goal_selection='random' is supported (readme.md:19)")
+        self.batched = hasattr(make_env, 'make_batched')
+        self.rank = dist.rank()
+        self.nb_cpu = dist.world_size()
+        if self.batched:
+            self.benv = make_env.make_batched(rollout_batch_size, env_id0=self.rank * rollout_batch_size)
+            self.envs = [self.benv]          # attribute kept; the batch is ONE object
+            spec = self.benv
+        else:
+            self.envs = [make_env() for _ in range(rollout_batch_size)]
+            spec = self.envs[0].unwrapped
+        self.info_keys = [key.replace('info_', '') for key in dims.keys() if key.startswith('info_')]
+        self.success_history = deque(maxlen=history_len)
+        self.reward_history = deque(maxlen=history_len)
+        self.Q_history = deque(maxlen=history_len)
+        self.n_episodes = 0
+        self.g = np.empty((rollout_batch_size, dims['g']), np.float32)
+        self.initial_o = np.empty((rollout_batch_size, dims['o']), np.float32)
+        self.initial_ag = np.empty((rollout_batch_size, dims['ag']), np.float32)
+        self.nb_goals_per_rollout = self.nb_cpu * rollout_batch_size
+        self.nb_tasks = spec.nb_tasks
+        self.C = np.zeros([self.nb_tasks])
+        self.CP = np.zeros([self.nb_tasks])
+        if structure in ('curious', 'task_experts'):
+            self.tasks_ag_id = spec.tasks_ag_id
+            self.tasks_g_id = spec.tasks_g_id
+            self.task_descr = np.empty((rollout_batch_size, self.nb_tasks), np.float32)
+            self.p = 1 / self.nb_tasks * np.ones([self.nb_tasks])
+            if structure == 'task_experts' and not self.eval:
+                self.p = np.zeros([self.nb_tasks])
+                self.p[unique_task] = 1
+            self.competence_computers = [CompetenceQueue(window=queue_length) for _ in range(self.nb_tasks)]
+            self.task_history = deque()
+            self.goal_history = deque()
+        elif structure == 'flat':
+            if self.batched:
+                raise NotImplementedError('the batched synthetic env is multi-task only')
+            for i in range(rollout_batch_size):
+                self.envs[i].unwrapped.set_flat_env()
+        self.stochastic_reset = False
+        self.count = -1
+        if not self.batched:
+            self.reset_all_rollouts()
+        self.clear_history()
+
+    # ================================================================== generic path (list of host envs)
+    def reset_rollout(self, i):
+        """rollout.py:102-162; each rank samples for itself."""
+        obs = self.envs[i].reset()
+        if self.structure in ('curious', 'task_experts'):
+            task = int(np.random.choice(range(self.nb_tasks), p=self.p, size=1)[0])          # rollout.py:120
+            goal = np.random.uniform(-1, 1, len(self.tasks_g_id[task]))                       # rollout.py:129
+            self.tasks[self.rank * self.rollout_batch_size + i] = task
+            self.goals[self.rank * self.rollout_batch_size + i] = \
+                self.envs[i].unwrapped._compute_goal(goal, task, eval=self.eval)[0][self.tasks_g_id[task]]
+            self.count += 1
+            obs = self.envs[i].unwrapped.reset_task_goal(goal=goal, task=task, directly=False, eval=self.eval)
+        else:
+            goal = np.random.uniform(-1, 1, self.dims['g'])
+            obs = self.envs[i].unwrapped.reset_task_goal(goal=goal)
+        self.initial_o[i] = obs['observation']
+        self.initial_ag[i] = obs['achieved_goal']
+        self.g[i] = obs['desired_goal']
+        if self.structure in ('curious', 'task_experts'):
+            self.task_descr[i] = obs['mask']
+
+    def reset_all_rollouts(self):
+        self.goals = [[] for _ in range(self.nb_goals_per_rollout)]
+        if self.structure in ('curious', 'task_experts'):
+            self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
+        for i in range(self.rollout_batch_size):
+            self.reset_rollout(i)
+
+    def _decide_exploit(self):
+        """rollout.py:183-189."""
+        if self.structure in ('curious', 'task_experts') and not self.eval:
+            self.exploit = True if np.random.random() < 0.1 else False
+            if self.exploit and self.structure == 'curious':
+                self.p = 1 / self.nb_tasks * np.ones([self.nb_tasks])
+        elif self.eval:
+            self.exploit = True
+            self.p = 1 / self.nb_tasks * np.ones([self.nb_tasks])
+
+    def generate_rollouts(self):
+        """Returns (episode batch, CP, n_episodes) (rollout.py:177-406)."""
+        if self.batched:
+            return self._generate_rollouts_batched()
+        self._decide_exploit()
+        self.reset_all_rollouts()
+        B = self.rollout_batch_size
+        o = np.empty((B, self.dims['o']), np.float32)
+        ag = np.empty((B, self.dims['ag']), np.float32)
+        o[:] = self.initial_o
+        ag[:] = self.initial_ag
+        obs, achieved_goals, acts, goals, successes = [], [], [], [], []
+        info_values = [np.empty((self.T, B, self.dims['info_' + key]), np.float32) for key in self.info_keys]
+        Qs, task_descrs, changes = [], [], []
+        multi = self.structure in ('curious', 'task_experts')
+        for t in range(self.T):
+            if self.structure == 'task_experts' and self.eval:       # rollout.py:212-224
+                act_output = np.zeros([B, self.dims['u']])
+                q_output = np.zeros([B, 1])
+                for i in range(B):
+                    tsk = int(np.argmax(self.task_descr[i]))
+                    out = self.policy[tsk].get_actions(
+                        o[i].reshape([1, -1]), ag[i].reshape([1, -1]), self.g[i].reshape([1, -1]),
+                        task_descr=self.task_descr[i].reshape([1, -1]), compute_Q=self.compute_Q,
+                        noise_eps=self.noise_eps if not self.exploit else 0.,
+                        random_eps=self.random_eps if not self.exploit else 0., use_target_net=self.use_target_net)
+                    if self.compute_Q:
+                        act_output[i, :], q_output[i, 0] = out[0], np.asarray(out[1]).reshape(-1)[0]
+                    else:
+                        act_output[i, :] = out
+                policy_output = [act_output, q_output] if self.compute_Q else act_output
+            else:
+                policy_output = self.policy.get_actions(
+                    o, ag, self.g, task_descr=self.task_descr if self.structure == 'curious' else None,
+                    compute_Q=self.compute_Q, noise_eps=self.noise_eps if not self.exploit else 0.,
+                    random_eps=self.random_eps if not self.exploit else 0., use_target_net=self.use_target_net)
+            if self.compute_Q:
+                u, Q = policy_output
+                Qs.append(Q)
+            else:
+                u = policy_output
+            if u.ndim == 1:
+                u = u.reshape(1, -1)
+            o_new = np.empty((B, self.dims['o']))
+            ag_new = np.empty((B, self.dims['ag']))
+            success = np.zeros(B)
+            r_competence = np.zeros(B)
+            for i in range(B):                                        # rollout.py:250-263
+                if self.render:
+                    self.envs[i].render()
+                curr_o_new, r_competence[i], _, info = self.envs[i].step(u[i])
+                if 'is_success' in info:
+                    success[i] = info['is_success']
+                o_new[i] = curr_o_new['observation']
+                ag_new[i] = curr_o_new['achieved_goal']
+                self.g[i] = curr_o_new['desired_goal']
+                for idx, key in enumerate(self.info_keys):
+                    info_values[idx][t, i] = info[key]
+            if np.isnan(o_new).any():                                 # rollout.py:268-271
+                self.logger.warning('NaN caught during rollout generation. Trying again...')
+                self.reset_all_rollouts()
+                return self.generate_rollouts()
+            obs.append(o.copy())
+            achieved_goals.append(ag.copy())
+            successes.append(success.copy())
+            acts.append(u.copy())
+            goals.append(self.g.copy())
+            o[...] = o_new
+            ag[...] = ag_new
+            if multi:
+                task_descrs.append(self.task_descr.copy())
+                changes.append(np.abs(achieved_goals[0] - ag) > 1e-3)   # rollout.py:284
+        obs.append(o.copy())
+        achieved_goals.append(ag.copy())
+        episode = dict(o=obs, u=acts, g=goals, ag=achieved_goals)
+        if multi:
+            episode['task_descr'] = task_descrs
+            episode['change'] = changes
+        self.initial_o[:] = o
+        for key, value in zip(self.info_keys, info_values):
+            episode['info_{}'.format(key)] = value
+        successful = np.array(successes)[-1, :]
+        assert successful.shape == (B,)
+        mean_Q = np.mean(Qs) if self.compute_Q else None
+        tasks_now = [self.envs[i].unwrapped.task for i in range(B)] if multi else None
+        self._finish_rollout(successful, r_competence, mean_Q, tasks_now)
+        return convert_episode_to_batch_major(episode), self.CP, self.n_episodes
+
+    # ================================================================== batched path (GPU-resident envs)
+    def _generate_rollouts_batched(self):
+        self._decide_exploit()
+        B, env = self.rollout_batch_size, self.benv
+        # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
+        tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
+        goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+        env.reset_all(tasks, goals)
+        self.count += B
+        q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
+        for t in range(self.T):
+            out = self.policy.get_actions(env.o, env.ag, env.g, task_descr=env.td, compute_Q=self.compute_Q,
+                                          noise_eps=self.noise_eps if not self.exploit else 0.,
+                                          random_eps=self.random_eps if not self.exploit else 0.,
+                                          use_target_net=self.use_target_net)
+            if self.compute_Q:
+                u, Q = out
+                q_sum += Q.mean()
+            else:
+                u = out
+            env.step_all(u, t)
+        successful = env.last_success().cpu().numpy().astype(np.float64)       # one D2H sync per rollout
+        if np.isnan(successful).any() or bool(torch.isnan(env.o).any()):        # rollout.py:268-271
+            self.logger.warning('NaN caught during rollout generation. Trying again...')
+            return self._generate_rollouts_batched()
+        mean_Q = float(q_sum) / self.T if self.compute_Q else None
+        self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
+        for i in range(B):
+            self.tasks[self.rank * B + i] = int(tasks[i])
+        self.goals = [[] for _ in range(self.nb_goals_per_rollout)]
+        self._finish_rollout(successful, successful - 1.0, mean_Q, [int(x) for x in tasks])
+        return env.episode_views(), self.CP, self.n_episodes
+
+    # ================================================================== statistics, competence, task probabilities
+    def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now):
+        """rollout.py:305-404."""
+        B = self.rollout_batch_size
+        self.success_history.append(np.mean(successful))
+        self.reward_history.append(r_competence)
+        if self.compute_Q:
+            self.Q_history.append(mean_Q)
+        self.n_episodes += B * self.nb_cpu
+        if self.structure not in ('curious', 'task_experts'):
+            return
+        # C9: gather (task, success, valid) of every rank; only exploit rollouts count (rollout.py:318-330)
+        rec = np.zeros([B, 3], np.float64)
+        rec[:, 0] = tasks_now
+        rec[:, 1] = successful
+        rec[:, 2] = 1.0 if self.exploit else 0.0
+        allrec = dist.allgather_numpy(rec)
+        task_succ_list = [[] for _ in range(self.nb_tasks)]
+        for task, succ, valid in allrec:
+            if valid:
+                task_succ_list[int(task)].append(float(succ))
+        for task in range(self.nb_tasks):
+            self.competence_computers[task].update(task_succ_list[task])   # rollout.py:355-356
+        self.C = np.array([self.get_C()]).squeeze()
+        self.task_history.extend(list(self.tasks))
+        self.goal_history.extend(list(self.goals))
+        if not self.eval:
+            if self.task_selection == 'active_competence_progress' and self.structure != 'task_experts':
+                self.CP = np.array([self.get_CP()]).squeeze()
+                self.p = task_probabilities(self.CP, self.nb_tasks, 0.4)    # epsilon hard-coded (rollout.py:383)
+            elif self.structure == 'task_experts':
+                self.p = np.zeros([self.nb_tasks])
+                self.p[self.unique_task] = 1
+
+    def clear_history(self):
+        self.success_history.clear()
+        self.reward_history.clear()
+        self.Q_history.clear()
+
+    def clear_competence_queue(self):
+        for i in range(self.nb_tasks):
+            self.competence_computers[i].clear_queue()
+
+    def current_success_rate(self):
+        return np.mean(self.success_history)
+
+    def current_mean_Q(self):
+        return np.mean(self.Q_history)
+
+    def save_policy(self, path):
+        with open(path, 'wb') as f:
+            pickle.dump(self.policy, f)
+        try:
+            self.policy.save_weights(path)
+        except Exception:
+            pass
+
+    def save_goal_task_history(self, path):
+        pass                                                          # rollout.py:437-449 (commented out upstream)
+
+    def logs(self, prefix='worker'):
+        logs = []
+        logs += [('success_rate', np.mean(self.success_history))]
+        logs += [('avg_reward', np.mean(self.reward_history))]
+        if self.compute_Q:
+            logs += [('mean_Q', np.mean(self.Q_history))]
+        logs += [('episode', self.n_episodes)]
+        if prefix != '' and not prefix.endswith('/'):
+            return [(prefix + '/' + key, val) for key, val in logs]
+        return logs
+
+    def additional_logs(self, prefix='worker'):
+        logs = []
+        if self.structure in ('curious', 'task_experts'):
+            for i in range(self.nb_tasks):
+                Cs = self.get_C()
+                logs += [('C_task' + str(i), "%.3g" % Cs[i])]
+                if not self.eval:
+                    CPs = self.get_CP()
+                    logs += [('CP_task' + str(i), "%.3g" % CPs[i])]
+                    hist = [x for x in list(self.task_history)[-100:]]
+                    per = np.mean(np.array([h == i for h in hist])) if hist else 0.0
+                    logs += [('%_task' + str(i), "%.3g" % per)]
+                    logs += [('p_task' + str(i), "%.3g" % self.p[i])]
+        if prefix != '' and not prefix.endswith('/'):
+            return [(prefix + '/' + key, val) for key, val in logs]
+        return logs
+
+    def get_CP(self):
+        return [cq.CP for cq in self.competence_computers]
+
+    def get_C(self):
+        return [cq.C for cq in self.competence_computers]
+
+    def seed(self, seed):
+        if self.batched:
+            self.benv.seed(seed)
+        else:
+            for idx, env in enumerate(self.envs):
+                env.seed(seed + 1000 * idx)
