@@ -1,0 +1,357 @@
+#!/usr/bin/env python
+"""Benchmark of the CURIOUS rollout-and-update hot path on MI355X (BASELINE.json metric / configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one training cycle of train.py:148-155 on MultiTaskFetchArm4-v5 dims, per GPU:
+    generate_rollouts (256 GPU-resident envs x T=50)  ->  store_episode (+ normaliser update)
+    ->  n_batches=100 x train() (HER sample of 256 transitions, DDPG grads, all-reduce, Adam)  ->  update_target_net
+`value` = HER-sampled gradient transitions per second over the whole job (all GPUs); `env_steps_per_sec` is reported
+beside it from the same timed region.  Data is synthetic (synthetic arm env, random-init weights); arithmetic is f32.
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL); if it is started
+directly with --gpus N > 1 it re-launches itself that way before touching the GPU.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
+
+ENV = 'MultiTaskFetchArm4-v5'
+B_R = 256                      # parallel rollouts per GPU (configs[1])
+N_BATCHES = 100
+BATCH = 256
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--prefill', type=int, default=2048, help='synthetic episodes pre-loaded per buffer')
+    ap.add_argument('--phases', action='store_true', help='diagnostic: time rollout / store / updates separately '
+                                                            '(adds device syncs; not the headline number)')
+    return ap.parse_args()
+
+
+def maybe_relaunch(args):
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 1000), __file__] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+
+def build_job(use_graph, seed=0):
+    from curious_amd import dist, logger
+    from curious_amd.experiment import config
+    from curious_amd.rollout import RolloutWorker
+    params = dict(config.MULTI_TASK_PARAMS)
+    params.update(env_name=ENV, task_selection='active_competence_progress', goal_selection='random',
+                  task_replay='replay_task_cp_buffer', goal_replay='her', structure='curious', normalize_obs=False,
+                  num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=B_R,
+                  n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
+    params = config.prepare_params(params)
+    params['ddpg_params']['normalize_obs'] = False
+    params['ddpg_params']['seed'] = seed
+    dims = config.configure_dims(params)
+    buffers = config.configure_buffer(dims=dims, params=params)
+    policy = config.configure_ddpg(dims=dims, params=params, buffers=buffers, clip_return=True)
+    worker = RolloutWorker(params['make_env'], policy, dims, logger, T=params['T'], rollout_batch_size=B_R,
+                           exploit=False, use_target_net=False, compute_Q=False, noise_eps=params['noise_eps'],
+                           random_eps=params['random_eps'], structure='curious',
+                           task_selection='active_competence_progress', goal_selection='random',
+                           queue_length=params['queue_length'], eval=False)
+    worker.seed(seed + 1000000 * dist.rank())
+    return params, dims, policy, worker
+
+
+def prefill(policy, n_eps, seed):
+    """Pre-load every per-task buffer with synthetic episodes (SURVEY 8d cfg 2): float32 random walks, ag = o[:AG],
+    one-hot task constant per episode, goal on the task's slots, u ~ U(-1,1), change / success flags."""
+    import torch
+    lay = policy._layout
+    T, O, AG, N = lay.T, lay.dims['o'], lay.dims['ag'], lay.dims['task_descr']
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(seed)
+    seen = set()
+    for i in range(1, policy.nb_tasks + 1):
+        buf = policy.buffer[i]
+        if id(buf) in seen:
+            continue
+        seen.add(id(buf))
+        E = min(n_eps, buf.size)
+        rec = buf.records[:E]
+        v = lay.record_views(rec)
+        o0 = torch.randn([E, 1, O], device='cuda', generator=gen)
+        steps = 0.01 * torch.randn([E, T, O], device='cuda', generator=gen)
+        o = torch.cat([o0, o0 + torch.cumsum(steps, dim=1)], dim=1)
+        rec.zero_()
+        v['o'].copy_(o)
+        v['ag'].copy_(o[:, :, :AG])
+        task = torch.randint(0, N, [E], device='cuda', generator=gen)
+        td = torch.nn.functional.one_hot(task, N).float()
+        v['task_descr'].copy_(td[:, None, :].expand(E, T, N))
+        g = torch.zeros([E, T, AG], device='cuda')
+        for j in range(N):
+            sel = task == j
+            if sel.any():
+                g[sel, :, 3 * j:3 * j + 3] = (o[sel, T // 2, 3 * j:3 * j + 3]
+                                              + 0.03 * torch.randn([int(sel.sum()), 3], device='cuda',
+                                                                   generator=gen))[:, None, :]
+        v['g'].copy_(g)
+        v['u'].copy_(torch.rand([E, T, lay.dims['u']], device='cuda', generator=gen) * 2 - 1)
+        v['change'].copy_(((o[:, :1, :AG] - o[:, 1:, :AG]).abs() > 1e-3).float())
+        buf.current_size = E
+        buf.n_transitions_stored = E * T
+    policy._tables_dirty = True
+
+
+def cycle(policy, worker):
+    episode, cp, n_ep = worker.generate_rollouts()
+    policy.store_episode(episode, cp, n_ep)
+    for _ in range(N_BATCHES):
+        policy.train()
+    policy.update_target_net()
+
+
+def kernel_flops_bytes(policy, lay):
+    """ALGORITHMIC work of one launch of each kernel class in one update / one rollout step."""
+    c = policy
+    B, H, nl, U = c.batch_size, c.hidden, c.layers, c.dimu
+    O, G, N = c.dimo, c.dimg, c.dimtd
+    Ka, Kc = O + N + G, O + N + U + G
+    hid = nl - 1
+    her_bytes_per_transition = ((2 * O + U + G + 2 * c.dimag + N + 0.8 * c.dimag)
+                                + (c.dimag + G + O + N + U + O + G + 1)) * 4          # 1 034 B at Arm4
+    return dict(
+        # hidden layers (256^3 GEMMs): 3 + 2 chains forward per update; the actor chain per env step
+        fwd_hot_kernel=dict(bound='mfma', per_update=5 * hid * 2 * B * H * H, launches_update=2 * hid,
+                            per_env_step=hid * 2 * B_R * H * H, launches_env_step=hid),
+        # layer 0 (K = 56..60)
+        fwd_layer_kernel=dict(bound='mfma', per_update=2 * B * H * (3 * Kc + 2 * Ka), launches_update=2,
+                              per_env_step=2 * B_R * H * Ka, launches_env_step=1),
+        dx_hot_kernel=dict(bound='mfma', per_update=3 * hid * 2 * B * H * H, launches_update=2 * hid),
+        dw_hot_kernel=dict(bound='mfma', per_update=2 * hid * 2 * B * H * H, launches_update=1),
+        dw_small_kernel=dict(bound='mfma', per_update=2 * B * H * (Kc + Ka) + 2 * B * H * (1 + U),
+                             launches_update=1),
+        her_sample_kernel=dict(bound='hbm', per_update=her_bytes_per_transition * B, launches_update=1),
+        adam_kernel=dict(bound='hbm', per_update=28 * (c.P_Q + c.P_pi), launches_update=1),
+    )
+
+
+def profile_pass(policy, worker, n_cycles=1):
+    """Eager (non-graph) replay of the same cycle with every kernel launch bracketed by HIP events on its stream."""
+    from curious_amd import ops
+    import torch
+    saved = policy.use_graph
+    policy.use_graph = False
+    torch.cuda.synchronize()
+    ops.prof_collect()
+    ops.prof_enable(True)
+    for _ in range(n_cycles):
+        cycle(policy, worker)
+    ops.prof_enable(False)
+    stats = ops.prof_collect()
+    policy.use_graph = saved
+    return stats
+
+
+def roofline(policy, worker, stats, n_cycles):
+    work = kernel_flops_bytes(policy, policy._layout)
+    total = {k: v[1] for k, v in stats.items() if v[0] > 0}
+    if not total:
+        return None, {}
+    dominant = max(total, key=total.get)
+    table = {k: dict(launches=v[0], total_ms=round(v[1], 4), avg_us=round(1e3 * v[1] / v[0], 3))
+             for k, v in stats.items() if v[0] > 0}
+    w = work.get(dominant)
+    if w is None:
+        return dict(kernel=dominant, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
+                    traffic=None), table
+    launches, ms = stats[dominant]
+    units = n_cycles * N_BATCHES * w['per_update']
+    if 'per_env_step' in w:
+        units += n_cycles * worker.T * w['per_env_step']
+    per_launch = units / launches
+    avg_s = ms * 1e-3 / launches
+    if w['bound'] == 'mfma':
+        ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+    else:
+        ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
+    return dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
+                frac=round(ach / peak, 5), traffic=None, algorithmic_per_launch=round(per_launch, 1),
+                avg_launch_us=round(avg_s * 1e6, 3)), table
+
+
+def cpu_baseline(seed=0, budget_s=20.0):
+    """The oracle (NumPy port of the reference's CPU path) on ONE host core, same workload: cycles of
+    256-env rollout + store + 100 updates.  A bounded sample (whole cycles until ~budget_s)."""
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    from oracle import her as oher
+    from oracle.ddpg import OracleDDPG
+    from oracle.env import SyntheticMultiTaskArm
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    from oracle.reward import make_reward_fun
+    nb, dimo, T = 4, 40, 50
+    G = 3 * nb
+    ids = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(nb)]
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    np.random.seed(seed)
+    sampler = oher.make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer', make_reward_fun(ids, ids),
+                                                          tasks_ag_id=ids, tasks_g_id=ids)
+    cap = 4096 * T        # smaller capacity than the GPU run: only memory, not arithmetic, depends on it
+    bufs = [OBuf(shapes, cap, T, sampler) for _ in range(nb + 1)]
+    agent = OracleDDPG(dims, T, bufs, sampler, ids, ids, batch_size=BATCH, weight_rng=np.random.RandomState(seed))
+    envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=seed, env_id=i) for i in range(B_R)]
+    n_rollout_envs = 32   # the per-env Python loop is sampled on 32 envs and scaled (it is linear in the env count)
+
+    def rollout():
+        tasks = np.random.choice(range(nb), size=B_R)
+        goals = np.random.uniform(-1, 1, (B_R, 3)).astype(np.float32)
+        obs = []
+        for i, e in enumerate(envs[:n_rollout_envs]):
+            e.reset()
+            obs.append(e.reset_task_goal(goals[i], int(tasks[i])))
+        o = np.stack([x['observation'] for x in obs])
+        g = np.stack([x['desired_goal'] for x in obs])
+        td = np.stack([x['mask'] for x in obs])
+        ep = dict(o=[o.copy()], ag=[o[:, :G].copy()], u=[], g=[], task_descr=[], change=[], info_is_success=[])
+        ag0 = o[:, :G].copy()
+        for t in range(T):
+            u = agent.get_actions(o, o[:, :G], g, task_descr=td, noise_eps=0.2, random_eps=0.3)
+            res = [e.step(u[i]) for i, e in enumerate(envs[:n_rollout_envs])]
+            o = np.stack([r[0]['observation'] for r in res])
+            ep['u'].append(u.astype(np.float32)); ep['g'].append(g.copy()); ep['task_descr'].append(td.copy())
+            ep['change'].append(np.abs(ag0 - o[:, :G]) > 1e-3)
+            ep['info_is_success'].append(np.array([[r[3]['is_success']] for r in res], np.float32))
+            ep['o'].append(o.copy()); ep['ag'].append(o[:, :G].copy())
+        return {k: np.array(v).swapaxes(0, 1) for k, v in ep.items()}
+
+    with threadpool_limits(limits=1):
+        t_roll = t_store = t_train = 0.0
+        cycles = 0
+        t_start = time.time()
+        while time.time() - t_start < budget_s or cycles < 1:
+            t0 = time.time()
+            ep = rollout()
+            t1 = time.time()
+            # tile the 32 sampled episodes to the 256-episode batch of the workload before storing
+            rep = B_R // n_rollout_envs
+            ep = {k: np.concatenate([v] * rep, axis=0) for k, v in ep.items()}
+            # make sure at least one task counts as active so that the buffers fill (synthetic env: Reach moves)
+            agent.store_episode({k: v.astype(np.float64) for k, v in ep.items()}, np.zeros(nb), 0)
+            t2 = time.time()
+            for _ in range(N_BATCHES):
+                agent.train()
+            agent.update_target_net()
+            t3 = time.time()
+            t_roll += (t1 - t0) * rep
+            t_store += t2 - t1
+            t_train += t3 - t2
+            cycles += 1
+        total = t_roll + t_store + t_train
+    return dict(value=round(cycles * N_BATCHES * BATCH / total, 1), unit='HER grad transitions/s',
+                env_steps_per_sec=round(cycles * B_R * T / total, 1), cores=1, kind='port',
+                sample='%d full cycles of the NumPy oracle (256-env rollout [32 envs timed, x8] + store + 100 updates, '
+                       'batch 256) on 1 thread; %.1f s rollout, %.1f s store, %.1f s updates'
+                       % (cycles, t_roll, t_store, t_train))
+
+
+def main():
+    args = parse()
+    maybe_relaunch(args)
+    import numpy as np
+    import torch
+    from curious_amd import dist, ops
+    dist.init_from_env()
+    rank, world = dist.rank(), dist.world_size()
+    assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    np.random.seed(1234 + 1000000 * rank)                        # train.py:242
+    params, dims, policy, worker = build_job(use_graph=not args.no_graph)
+    prefill(policy, args.prefill, seed=rank)
+
+    for _ in range(args.warmup):
+        cycle(policy, worker)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cycle(policy, worker)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el)
+
+    phases = None
+    if args.phases:
+        tr = ts = tu = 0.0
+        for _ in range(5):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            episode, cp, n_ep = worker.generate_rollouts()
+            torch.cuda.synchronize(); b = time.perf_counter()
+            policy.store_episode(episode, cp, n_ep)
+            torch.cuda.synchronize(); c = time.perf_counter()
+            for _ in range(N_BATCHES):
+                policy.train()
+            policy.update_target_net()
+            torch.cuda.synchronize(); d = time.perf_counter()
+            tr += b - a; ts += c - b; tu += d - c
+        phases = dict(rollout_ms=round(tr / 5 * 1e3, 3), store_ms=round(ts / 5 * 1e3, 3),
+                      updates_ms=round(tu / 5 * 1e3, 3))
+
+    # per-kernel HIP-event timing of the same cycle (eager launches; events cannot sit inside a replayed hipGraph)
+    prof_cycles = 1
+    stats = profile_pass(policy, worker, prof_cycles)
+    roof, table = roofline(policy, worker, stats, prof_cycles)
+
+    out = None
+    if rank == 0:
+        T = params['T']
+        out = {
+            'metric': 'HER-sampled gradient transitions/sec (+ env_steps_per_sec), MultiTaskFetchArm4-v5 cycle',
+            'value': round(args.steps * N_BATCHES * BATCH * world / elapsed, 1),
+            'unit': 'transitions/s',
+            'env_steps_per_sec': round(args.steps * B_R * T * world / elapsed, 1),
+            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES / elapsed, 1),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'MultiTaskFetchArm4-v5, 256 parallel rollouts x T=50 per GPU, HER future k=4, '
+                                   'batch 256, 100 updates per cycle, 5 per-task buffers (configs[1])',
+                       'step': 'one cycle: rollout + store_episode + 100 x train() + update_target_net',
+                       'rollout_batch_size': B_R, 'batch_size': BATCH, 'n_batches': N_BATCHES,
+                       'hipgraph': not args.no_graph, 'rng': 'device (Philox)',
+                       'parallelism': 'dp%d' % world},
+            'roofline': roof,
+            'kernels': table,
+        }
+        if phases:
+            out['phases'] = phases
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -72,6 +72,10 @@ PROTOTYPES = {
     'curious_last_error': (C.c_char_p, []),
     'curious_abi_version': (C.c_int, []),
     'curious_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    'curious_prof_enable': (C.c_int, [C.c_int]),
+    'curious_prof_kernel_count': (C.c_int, []),
+    'curious_prof_kernel_name': (C.c_char_p, [C.c_int]),
+    'curious_prof_collect': (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
                                      C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
                                      _P]),
@@ -111,6 +115,12 @@ def lib():
             raise CuriousHipError(
                 'libcurious_hip.so is not built (%s). Run `python -m curious_amd.build` '
                 '(hipcc --offload-arch=gfx950); curious_amd has no CPU fallback.' % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64; the library must bind to THAT runtime instance (device pointers
+        # and streams are shared with torch), so torch is imported -- and its HIP runtime loaded -- first.
+        import torch  # noqa: F401
+        hip = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        if os.path.exists(hip):
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)            # AttributeError here = header / library mismatch

@@ -49,8 +49,8 @@ extern "C" int curious_action_noise(float* u, int32_t ldu, int32_t n, int32_t di
   CURIOUS_CHECK(any == all, "curious_action_noise: give all of randn/binom/unif or none");
   if (n <= 0) return 0;
   int total = n * dimu;
-  hipLaunchKernelGGL(action_noise_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), u, ldu, n, dimu,
-                     noise_scale, random_eps, max_u, randn, binom, unif, seed, counter);
+  { ProfScope ps__(CK_NOISE, as_stream(stream)); hipLaunchKernelGGL(action_noise_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), u, ldu, n, dimu,
+                     noise_scale, random_eps, max_u, randn, binom, unif, seed, counter); }
   CURIOUS_LAUNCH_CHECK("action_noise_kernel");
   return 0;
 }

@@ -32,3 +32,61 @@ extern "C" int curious_device_info(char* name_host, int name_len, int* cu_count_
   if (cu_count_host) *cu_count_host = prop.multiProcessorCount;
   return 0;
 }
+
+// ------------------------------------------------------------------ per-kernel event timing
+#include <vector>
+int g_curious_prof_on = 0;
+namespace {
+struct Pair { int kid; hipEvent_t a, b; };
+std::vector<Pair> g_pairs;
+std::vector<hipEvent_t> g_free;
+hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+
+void curious_prof_push(int kid, hipStream_t st, bool start) {
+  if (start) {
+    Pair p; p.kid = kid; p.a = get_event(); p.b = nullptr;
+    (void)hipEventRecord(p.a, st);
+    g_pairs.push_back(p);
+  } else {
+    Pair& p = g_pairs.back();
+    p.b = get_event();
+    (void)hipEventRecord(p.b, st);
+  }
+}
+
+static const char* k_names[CK_COUNT] = {
+    "her_sample_kernel", "store_episodes_kernel", "episode_activity_kernel", "norm_partial_kernel",
+    "norm_final_kernel", "norm_recompute_kernel", "fwd_layer_kernel", "fwd_hot_kernel", "dx_hot_kernel", "dw_hot_kernel",
+    "dw_small_kernel", "head_fwd_kernel",
+    "critic_head_kernel", "actor_dz_kernel", "adam_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel",
+    "env_step_kernel"};
+
+extern "C" int curious_prof_kernel_count(void) { return CK_COUNT; }
+extern "C" const char* curious_prof_kernel_name(int kid) { return (kid >= 0 && kid < CK_COUNT) ? k_names[kid] : ""; }
+
+extern "C" int curious_prof_enable(int on) {
+  g_curious_prof_on = on ? 1 : 0;
+  return 0;
+}
+
+// Synchronises the device, then returns per-kernel launch counts and summed durations (ms) since the last collect.
+extern "C" int curious_prof_collect(int64_t* counts_host, double* total_ms_host) {
+  hipError_t e = hipDeviceSynchronize();
+  CURIOUS_CHECK(e == hipSuccess, "curious_prof_collect: %s", hipGetErrorString(e));
+  for (int k = 0; k < CK_COUNT; ++k) { counts_host[k] = 0; total_ms_host[k] = 0.0; }
+  for (auto& p : g_pairs) {
+    float ms = 0.f;
+    if (p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      counts_host[p.kid] += 1;
+      total_ms_host[p.kid] += ms;
+    }
+    g_free.push_back(p.a);
+    if (p.b) g_free.push_back(p.b);
+  }
+  g_pairs.clear();
+  return 0;
+}

@@ -68,3 +68,17 @@ __device__ inline float fdiv(float a, float b) { return a / b; }
 __device__ inline float fclip(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 static inline hipStream_t as_stream(curious_stream_t s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------- per-kernel HIP-event timing (bench.py roofline)
+enum {
+  CK_HER_SAMPLE = 0, CK_STORE, CK_ACTIVITY, CK_NORM_PARTIAL, CK_NORM_FINAL, CK_NORM_RECOMPUTE, CK_FWD_LAYER0,
+  CK_FWD_LAYER, CK_DX, CK_DW, CK_DW_SMALL, CK_HEAD_FWD, CK_CRITIC_HEAD, CK_ACTOR_DZ, CK_ADAM, CK_POLYAK, CK_CHECKSUM, CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_COUNT
+};
+extern int g_curious_prof_on;
+void curious_prof_push(int kid, hipStream_t st, bool start);
+// Brackets ONE kernel launch with a pair of events recorded on the launch stream (no-op unless profiling is on).
+struct ProfScope {
+  int kid; hipStream_t st; bool on;
+  ProfScope(int k, hipStream_t s) : kid(k), st(s), on(g_curious_prof_on != 0) { if (on) curious_prof_push(kid, st, true); }
+  ~ProfScope() { if (on) curious_prof_push(kid, st, false); }
+};

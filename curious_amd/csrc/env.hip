@@ -53,8 +53,8 @@ extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layou
                     L->dimtd == E->ntasks && L->dimu == 4 && E->dimo >= 3 * E->ntasks + 4,
                 "curious_env_reset: layout does not match the synthetic env");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(env_reset_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
-                     tasks, goals_raw, n, o, ag, g, td, staging);
+  { ProfScope ps__(CK_ENV_RESET, as_stream(stream)); hipLaunchKernelGGL(env_reset_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
+                     tasks, goals_raw, n, o, ag, g, td, staging); }
   CURIOUS_LAUNCH_CHECK("env_reset_kernel");
   return 0;
 }
@@ -134,8 +134,8 @@ extern "C" int curious_env_step(const curious_env_cfg_t* E, const curious_layout
   CURIOUS_CHECK(E && L && episode && tasks && u && o && ag && g && td && staging, "curious_env_step: NULL argument");
   CURIOUS_CHECK(t >= 0 && t < L->T, "curious_env_step: t out of range");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(env_step_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
-                     tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps);
+  { ProfScope ps__(CK_ENV_STEP, as_stream(stream)); hipLaunchKernelGGL(env_step_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
+                     tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps); }
   CURIOUS_LAUNCH_CHECK("env_step_kernel");
   return 0;
 }

@@ -237,7 +237,7 @@ extern "C" int curious_her_sample(const float* storage, int64_t buf_stride, cons
   size_t shmem = (size_t)SPB * slot_floats * sizeof(float);
   CURIOUS_CHECK(shmem <= 64 * 1024, "curious_her_sample: record row too large for the LDS slot");
   int blocks = (n + SPB - 1) / SPB;
-  hipLaunchKernelGGL(her_sample_kernel, dim3(blocks), dim3(256), shmem, as_stream(stream), a);
+  { ProfScope ps__(CK_HER_SAMPLE, as_stream(stream)); hipLaunchKernelGGL(her_sample_kernel, dim3(blocks), dim3(256), shmem, as_stream(stream), a); }
   CURIOUS_LAUNCH_CHECK("her_sample_kernel");
   return 0;
 }

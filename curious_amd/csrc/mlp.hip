@@ -6,12 +6,21 @@
 // ddpg.py:442-443 and flatten_grads util.py:49-53 -- plus the acting forward of DDPG.get_actions
 // ddpg.py:129-146.
 //
-// Arithmetic: v_mfma_f32_16x16x4_f32 (exact f32 FMA chains, MI355X_MICROARCH "Matrix cores"); one wave owns
-// one 16x16 output tile and streams its operand fragments straight from L2 (weights 0.6 MB/net and the
-// 256-row activations are L2 resident; no reuse inside a wave that LDS staging could add at this tile size).
-// The k index inside a 16-wide chunk is permuted (lane group q supplies k = 4q+s at MFMA step s) so that
-// the row-major operand is read with one 16-byte load per lane.
-// Gradients are written directly at their offset of the flat [Q_grad | pi_grad] vector (no flatten pass).
+// Shape of the problem: batch 256, hidden 256 -> twenty 256^3 GEMMs per update that form chains of dependent
+// layers.  They are latency bound, so the design minimises time-to-result of ONE small GEMM rather than FLOP/s:
+//   * one 256-thread workgroup owns a 16 x 64 output tile; its 4 waves split the reduction dimension (split-K
+//     inside the workgroup) -> 64 workgroups per 256x256 GEMM, 64 MFMAs per wave;
+//   * v_mfma_f32_16x16x4_f32 (exact f32 FMA chains); each wave keeps 4 independent accumulators (the four
+//     16x16 tiles made of output columns {4j+e}), so no MFMA waits on its predecessor;
+//   * the k index inside a 16-wide chunk is permuted (lane group q supplies k = 4q+s at MFMA step s) and the
+//     output columns are interleaved (accumulator e owns columns 4j+e) so that EVERY operand fragment is one
+//     16-byte row-contiguous load per lane, straight from L2 into registers; all loads of a wave's whole K share
+//     are issued before the first MFMA;
+//   * partial tiles meet in LDS (16 KB), the epilogue (bias, ReLU / tanh, ReLU mask) runs on the reduced tile
+//     and stores 16 bytes per lane.
+// Independent chains (target actor / main critic / main actor ...) are grouped into one launch (blockIdx.z).
+// Output layers (N = 1 or dimu) and everything elementwise around the losses run in "one wave per batch row"
+// kernels.  Gradients are written directly at their offset of the [Q_grad | pad | pi_grad] vector.
 #include <math.h>
 
 #include "common.h"
@@ -19,8 +28,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MAX_SEG 4
-#define MAX_PROB 8
 #define MAX_LAYERS 8
+#define MAX_DW 24
+#define MAX_U 8
 
 // ------------------------------------------------------------------ operand descriptors
 struct Seg {             // one column segment of a layer input (virtual concatenation along k)
@@ -34,7 +44,7 @@ struct Seg {             // one column segment of a layer input (virtual concate
   float nclip;
   float div;             // divide by max_u                    (actor_critic.py:93,96)
   const float* W;        // weight rows of this segment [w, N] row-major (forward only)
-  int32_t vec;           // 16-byte loads legal
+  int32_t vec;           // 16-byte loads of x legal
 };
 
 struct FwdProb {
@@ -43,21 +53,19 @@ struct FwdProb {
   const float* bias;
   float* Y;
   int32_t ldy, M, N;
-  int32_t act;           // 0 linear, 1 relu, 2 max_u*tanh
-  float max_u;
-  int32_t wvec;          // unused
+  int32_t act;           // 0 linear, 1 relu
+  int32_t wvec;          // 16-byte loads of W rows legal (N % 4 == 0, aligned)
+  int32_t fast;          // every segment 16-byte loadable with w % 4 == 0, no `sub`: branch-free main loop
 };
 
-struct DxProb {          // dX[M,K] = (dY[M,N] . W[K,N]^T) (.) mask
+struct DxProb {          // dX[M,K] = (dY[M,N] . W[K,N]^T) (.) relu'(H)
   const float* dY; int32_t lddy;
   const float* W;  int32_t ldw;
-  const float* H;  int32_t ldh;      // relu mask source (post-activation of the layer below); NULL: none
+  const float* H;  int32_t ldh;
   float* dX; int32_t lddx;
   int32_t M, N, K;
-  int32_t epi;           // 0: mask only; 1: dz epilogue (actor output layer, through tanh and the l2 term)
-  const float* pi; int32_t ldpi;
-  float max_u, l2c;      // l2c = action_l2 * 2 / (max_u^2 * B * dimu)
   int32_t vec;
+  int32_t fast;          // vec && N % 4 == 0: branch-free main loop
 };
 
 struct DwProb {          // dW[w,N] = X[M,w]^T . dY[M,N];  db[N] = colsum(dY)
@@ -66,11 +74,19 @@ struct DwProb {          // dW[w,N] = X[M,w]^T . dY[M,N];  db[N] = colsum(dY)
   float* dW;
   float* db;             // nullable
   int32_t M, N;
+  int32_t yvec;          // 16-byte loads of dY rows legal
+  int32_t fast;          // yvec && no `sub` on x: branch-free main loop
 };
 
 struct FwdArgs { FwdProb p[3]; int32_t nprob; };
-struct DxArgs { DxProb p[3]; int32_t nprob; };
-struct DwArgs { DwProb p[MAX_PROB * 2]; int32_t nprob; };
+struct DxArgs { DxProb p[2]; int32_t nprob; };
+struct LossFin {         // final, fixed-order reduction of the per-row loss terms (rides on the dW launch)
+  const float* rows;     // [3][B]: (target-Q)^2, Q_pi, sum_j (pi_j/max_u)^2
+  float* out;            // [2]: Q_loss, pi_loss
+  int32_t B, U;
+  float action_l2;
+};
+struct DwArgs { DwProb p[MAX_DW]; int32_t nprob; LossFin fin; };
 
 __device__ inline float seg_xform(const Seg& s, float v, int row, int col) {
   if (s.sub) v = __fsub_rn(v, s.sub[(int64_t)row * s.ldsub + col]);
@@ -80,18 +96,26 @@ __device__ inline float seg_xform(const Seg& s, float v, int row, int col) {
   return v;
 }
 
-// four consecutive columns (col .. col+3) of row `row`; out-of-range -> 0
-__device__ inline f32x4 seg_load4(const Seg& s, int row, int col, bool row_ok) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (!row_ok || col >= s.w) return v;
-  const float* p = s.x + (int64_t)row * s.ld + col;
-  if (s.vec && col + 3 < s.w) {
-    v = *reinterpret_cast<const f32x4*>(p);
-  } else {
+__device__ inline f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+// four consecutive floats p[0..3]; element e is valid when e < nvalid; out-of-range -> 0
+__device__ inline f32x4 ldg4(const float* p, int nvalid, bool vec) {
+  f32x4 v = zero4();
+  if (nvalid <= 0) return v;
+  if (vec && nvalid >= 4) return *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (col + e < s.w) v[e] = p[e];
-  }
+  for (int e = 0; e < 4; ++e)
+    if (e < nvalid) v[e] = p[e];
+  return v;
+}
+
+// four consecutive columns (col .. col+3) of row `row` of a segment, with its input transforms
+__device__ inline f32x4 seg_load4(const Seg& s, int row, int col, bool row_ok) {
+  if (!row_ok) return zero4();
+  f32x4 v = ldg4(s.x + (int64_t)row * s.ld + col, s.w - col, s.vec != 0);
   const bool plain = !s.sub && s.clip <= 0.0f && !s.mean && s.div == 1.0f;
   if (!plain) {
 #pragma unroll
@@ -106,232 +130,907 @@ __device__ inline float seg_load1(const Seg& s, int row, int col, bool ok) {
   return seg_xform(s, s.x[(int64_t)row * s.ld + col], row, col);
 }
 
-// ------------------------------------------------------------------ forward layer
-// grid: x = ceil(N/64) (4 waves = 4 n-tiles), y = ceil(M/16), z = problem
-__global__ __launch_bounds__(256) void fwd_layer_kernel(FwdArgs args) {
-  const FwdProb& P = args.p[blockIdx.z];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 16;
-  if (m0 >= P.M || n0 >= P.N) return;
-  const int row = m0 + i, col = n0 + i;
-  const bool row_ok = row < P.M, col_ok = col < P.N;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int sidx = 0; sidx < P.nseg; ++sidx) {
-    const Seg& S = P.seg[sidx];
-    for (int k0 = 0; k0 < S.w; k0 += 16) {
-      const int kq = k0 + 4 * q;
-      f32x4 a = seg_load4(S, row, kq, row_ok);
-      float b[4];
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Scheduling fence: everything above (the loads of a wave's whole K share) is issued before anything below (the
+// MFMAs).  Without it hipcc -O3 interleaves load -> s_waitcnt -> 4 MFMA per fragment to save registers (27-40 VGPRs)
+// and exposes the full L2/Infinity-Cache latency sixteen times per wave (measured: 7.6 us vs 4 us per layer kernel).
+#define LOADS_FIRST() __builtin_amdgcn_sched_barrier(0)
+
+// Unconditional 16-byte load.  The fast paths below never branch around a load: addresses are clamped into range and
+// invalid contributions are zeroed with selects afterwards, so that hipcc can issue every load of a wave's share
+// before the first MFMA instead of waiting vmcnt(0) per guarded element (cdna_hip_programming.md 5, trap (c)).
+__device__ inline f32x4 ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline f32x4 sel4(bool ok, f32x4 v) {
+  f32x4 r;
+  r[0] = ok ? v[0] : 0.f; r[1] = ok ? v[1] : 0.f; r[2] = ok ? v[2] : 0.f; r[3] = ok ? v[3] : 0.f;
+  return r;
+}
+// segment transforms without the relative-goal subtraction (clip, normalise, divide), on a whole float4
+__device__ inline f32x4 seg_xform4(const Seg& s, f32x4 v, int col) {
+  if (s.clip > 0.0f) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) b[s] = (col_ok && kq + s < S.w) ? S.W[(int64_t)(kq + s) * P.N + col] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e) v[e] = fclip(v[e], -s.clip, s.clip);
   }
-  if (!col_ok) return;
-  const float bias = P.bias ? P.bias[col] : 0.f;
+  if (s.mean) {
+    f32x4 mu = ldv(s.mean + col), sd = ldv(s.stdv + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fclip(fdiv(__fsub_rn(v[e], mu[e]), sd[e]), -s.nclip, s.nclip);
+  }
+  if (s.div != 1.0f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fdiv(v[e], s.div);
+  }
+  return v;
+}
+
+// Partial 16x64 tiles of the 4 waves -> LDS -> summed tile.  acc[e][r] is element (row 4q+r, column 4j+e).
+// Returns the reduced float4 (columns 4*c4 .. 4*c4+3 of row `orow`) owned by this thread.
+__device__ inline f32x4 reduce_tile(float* red, const f32x4 acc[4], int wave, int q, int j, int tid, int& orow,
+                                    int& c4) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int orow = m0 + 4 * q + r;
-    if (orow < P.M) {
-      float v = acc0[r] + acc1[r] + bias;
-      if (P.act == 1) v = fmaxf(v, 0.f);
-      else if (P.act == 2) v = P.max_u * tanhf(v);
-      P.Y[(int64_t)orow * P.ldy + col] = v;
+    f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    *reinterpret_cast<f32x4*>(red + ((wave * 16 + 4 * q + r) * 64 + 4 * j)) = v;
+  }
+  __syncthreads();
+  orow = tid >> 4;
+  c4 = tid & 15;
+  f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * 16 + orow) * 64 + 4 * c4));
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(red + ((w * 16 + orow) * 64 + 4 * c4));
+    s += t;
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------ forward layer
+// Y[M,N] = act(sum_seg X_seg . W_seg + bias).  grid: x = ceil(N/64), y = ceil(M/16), z = problem
+__global__ __launch_bounds__(256) void fwd_layer_kernel(FwdArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const FwdProb& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  if (m0 >= P.M || n0 >= P.N) return;                       // uniform per workgroup
+  const int row = m0 + j;
+  const bool row_ok = row < P.M;
+  const int col = n0 + 4 * j;                               // this lane's 4 output columns: col + e
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  int ci = 0;                                               // running chunk index over the virtual K
+  if (P.fast) {
+    const int rowc = min(row, P.M - 1), colc = min(col, P.N - 4);
+    for (int sidx = 0; sidx < P.nseg; ++sidx) {
+      const Seg& S = P.seg[sidx];
+      const int nch = (S.w + 15) >> 4;
+      const float* xr = S.x + (int64_t)rowc * S.ld;
+      for (int c0 = ((wave - ci) & 3); c0 < nch; c0 += 16) {
+        f32x4 a[4], b[4][4];
+        int kqs[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kq = (c0 + 4 * u) * 16 + 4 * q;
+          ok[u] = row_ok && (kq < S.w);
+          kqs[u] = min(kq, S.w - 4);
+          a[u] = ldv(xr + kqs[u]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[u][s] = ldv(S.W + (int64_t)(kqs[u] + s) * P.N + colc);
+        }
+        LOADS_FIRST();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = sel4(ok[u], seg_xform4(S, a[u], kqs[u]));
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+        }
+      }
+      ci += nch;
     }
+  } else {
+    for (int sidx = 0; sidx < P.nseg; ++sidx) {
+      const Seg& S = P.seg[sidx];
+      const int nch = (S.w + 15) >> 4;
+      // this wave's chunks of the segment: (ci + c) % 4 == wave; up to 4 chunks are loaded before any MFMA
+      for (int c0 = ((wave - ci) & 3); c0 < nch; c0 += 16) {
+        f32x4 a[4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kq = (c0 + 4 * u) * 16 + 4 * q;
+          const bool cok = (c0 + 4 * u) < nch;
+          a[u] = cok ? seg_load4(S, row, kq, row_ok) : zero4();
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            b[u][s] = (cok && kq + s < S.w) ? ldg4(S.W + (int64_t)(kq + s) * P.N + col, P.N - col, P.wvec != 0)
+                                            : zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+      }
+      ci += nch;
+    }
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  const int grow = m0 + orow, gcol = n0 + 4 * c4;
+  if (grow >= P.M || gcol >= P.N) return;
+  f32x4 bias = P.bias ? ldg4(P.bias + gcol, P.N - gcol, P.wvec != 0) : zero4();
+  v += bias;
+  if (P.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  float* dst = P.Y + (int64_t)grow * P.ldy + gcol;
+  if (gcol + 3 < P.N && (P.ldy & 3) == 0) {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (gcol + e < P.N) dst[e] = v[e];
   }
 }
 
 // ------------------------------------------------------------------ backward: input gradient
 // dX[m][k] = sum_n dY[m][n] W[k][n], masked by relu'(H).  grid: x = ceil(K/64), y = ceil(M/16), z = problem
 __global__ __launch_bounds__(256) void dx_kernel(DxArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const DxProb& P = args.p[blockIdx.z];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, k0 = (blockIdx.x * 4 + wave) * 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
   if (m0 >= P.M || k0 >= P.K) return;
-  const int row = m0 + i, kcol = k0 + i;
-  const bool row_ok = row < P.M, k_ok = kcol < P.K;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* dyr = P.dY + (int64_t)row * P.lddy;
-  const float* wr = P.W + (int64_t)kcol * P.ldw;
-  for (int n0 = 0; n0 < P.N; n0 += 16) {
-    const int nq = n0 + 4 * q;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    if (P.vec && nq + 3 < P.N) {
-      if (row_ok) a = *reinterpret_cast<const f32x4*>(dyr + nq);
-      if (k_ok) b = *reinterpret_cast<const f32x4*>(wr + nq);
-    } else {
+  const int row = m0 + j;
+  const bool row_ok = row < P.M;
+  const int kc = k0 + 4 * j;                                 // output columns kc + e  <->  weight rows kc + e
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const int nch = (P.N + 15) >> 4;
+  if (P.fast) {
+    const float* dyr = P.dY + (int64_t)min(row, P.M - 1) * P.lddy;
+    const float* wr[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (nq + s < P.N) {
-          if (row_ok) a[s] = dyr[nq + s];
-          if (k_ok) b[s] = wr[nq + s];
+    for (int e = 0; e < 4; ++e) wr[e] = P.W + (int64_t)min(kc + e, P.K - 1) * P.ldw;
+    for (int c0 = wave; c0 < nch; c0 += 16) {
+      f32x4 a[4], b[4][4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nq = (c0 + 4 * u) * 16 + 4 * q;
+        ok[u] = row_ok && (nq < P.N);
+        const int nqc = min(nq, P.N - 4);
+        a[u] = ldv(dyr + nqc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr[e] + nqc);
+      }
+      LOADS_FIRST();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = sel4(ok[u], a[u]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][e][s], acc[e]);
+      }
+    }
+  } else {
+    const float* dyr = P.dY + (int64_t)row * P.lddy;
+    for (int c0 = wave; c0 < nch; c0 += 16) {
+      f32x4 a[4], b[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nq = (c0 + 4 * u) * 16 + 4 * q;
+        const bool cok = (c0 + 4 * u) < nch;
+        a[u] = (cok && row_ok) ? ldg4(dyr + nq, P.N - nq, P.vec != 0) : zero4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          b[u][e] = (cok && kc + e < P.K) ? ldg4(P.W + (int64_t)(kc + e) * P.ldw + nq, P.N - nq, P.vec != 0)
+                                          : zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][e][s], acc[e]);
+    }
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  const int grow = m0 + orow, gcol = k0 + 4 * c4;
+  if (grow >= P.M || gcol >= P.K) return;
+  if (P.H) {
+    f32x4 h = ldg4(P.H + (int64_t)grow * P.ldh + gcol, P.K - gcol, (P.ldh & 3) == 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
+  }
+  float* dst = P.dX + (int64_t)grow * P.lddx + gcol;
+  if (gcol + 3 < P.K && (P.lddx & 3) == 0) {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (gcol + e < P.K) dst[e] = v[e];
+  }
+}
+
+// ------------------------------------------------------------------ backward: weight gradient (grouped)
+// dW[k][n] = sum_m X[m][k] dY[m][n]; db[n] = sum_m dY[m][n].  grid: x = ceil(N/64), y = ceil(w/16), z = problem;
+// slice z == nprob finalises the losses.
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if ((int)blockIdx.z == args.nprob) {
+    // losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order by one workgroup
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    const LossFin& F = args.fin;
+    float lq = 0.f, lp = 0.f, ll = 0.f;
+    for (int m = tid; m < F.B; m += 256) {
+      lq += F.rows[m];
+      lp += F.rows[F.B + m];
+      ll += F.rows[2 * F.B + m];
+    }
+    red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+      if (tid < h) {
+        red[tid] += red[tid + h];
+        red[256 + tid] += red[256 + tid + h];
+        red[512 + tid] += red[512 + tid + h];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float invB = 1.0f / (float)F.B;
+      F.out[0] = red[0] * invB;
+      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+    }
+    return;
+  }
+  const DwProb& P = args.p[blockIdx.z];
+  const int j = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  if (k0 >= P.x.w || n0 >= P.N) return;
+  const int krow = k0 + j;                                   // A operand row index = weight row
+  const bool k_ok = krow < P.x.w;
+  const int col = n0 + 4 * j;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  const int nch = (P.M + 15) >> 4;
+  if (P.fast) {
+    const Seg& X = P.x;
+    const int krc = min(krow, X.w - 1), colc = min(col, P.N - 4);
+    const bool plain = X.clip <= 0.0f && !X.mean && X.div == 1.0f;
+    const float mu = X.mean ? X.mean[krc] : 0.f, sd = X.mean ? X.stdv[krc] : 1.f;
+    for (int c0 = wave; c0 < nch; c0 += 16) {
+      float a[4][4];
+      f32x4 b[4][4];
+      bool ok[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int mq = (c0 + 4 * u) * 16 + 4 * q;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          ok[u][s] = (mq + s) < P.M;
+          const int mc = min(mq + s, P.M - 1);
+          a[u][s] = X.x[(int64_t)mc * X.ld + krc];
+          b[u][s] = ldv(P.dY + (int64_t)mc * P.lddy + colc);
+        }
+      }
+      LOADS_FIRST();
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float av = a[u][s];
+          if (!plain) {
+            if (X.clip > 0.0f) av = fclip(av, -X.clip, X.clip);
+            if (X.mean) av = fclip(fdiv(__fsub_rn(av, mu), sd), -X.nclip, X.nclip);
+            if (X.div != 1.0f) av = fdiv(av, X.div);
+          }
+          av = (ok[u][s] && k_ok) ? av : 0.f;
+          f32x4 bv = sel4(ok[u][s], b[u][s]);
+          bsum += bv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, bv[e], acc[e]);
         }
     }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
-  }
-  if (!k_ok) return;
+  } else {
+    for (int c0 = wave; c0 < nch; c0 += 16) {
+      float a[4][4];
+      f32x4 b[4][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int orow = m0 + 4 * q + r;
-    if (orow < P.M) {
-      float v = acc0[r] + acc1[r];
-      if (P.H) v = (P.H[(int64_t)orow * P.ldh + kcol] > 0.f) ? v : 0.f;
-      if (P.epi == 1) {
-        // d pi_loss / d z  (ddpg.py:440-441 through pi = max_u * tanh(z), actor_critic.py:89)
-        float pi = P.pi[(int64_t)orow * P.ldpi + kcol];
-        float th = pi / P.max_u;
-        float dpi = v / P.max_u + P.l2c * pi;
-        v = dpi * P.max_u * (1.0f - th * th);
+      for (int u = 0; u < 4; ++u) {
+        const int mq = (c0 + 4 * u) * 16 + 4 * q;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bool mok = ((c0 + 4 * u) < nch) && (mq + s < P.M);
+          a[u][s] = seg_load1(P.x, mq + s, krow, mok && k_ok);
+          b[u][s] = mok ? ldg4(P.dY + (int64_t)(mq + s) * P.lddy + col, P.N - col, P.yvec != 0) : zero4();
+        }
       }
-      P.dX[(int64_t)orow * P.lddx + kcol] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bsum += b[u][s];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+        }
     }
   }
-}
-
-// ------------------------------------------------------------------ backward: weight gradient
-// dW[k][n] = sum_m X[m][k] dY[m][n]; db[n] = sum_m dY[m][n].  grid: x = ceil(N/64), y = ceil(w/16), z = problem
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
-  const DwProb& P = args.p[blockIdx.z];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 15, q = lane >> 4;
-  const int k0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 16;
-  if (k0 >= P.x.w || n0 >= P.N) return;
-  const int kcol = k0 + i, col = n0 + i;
-  const bool k_ok = kcol < P.x.w, col_ok = col < P.N;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  for (int mm = 0; mm < P.M; mm += 16) {
-    const int mq = mm + 4 * q;
-    float a[4], b[4];
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  const int grow = k0 + orow, gcol = n0 + 4 * c4;
+  if (grow < P.x.w && gcol < P.N) {
+    float* dst = P.dW + (int64_t)grow * P.N + gcol;
+    if (gcol + 3 < P.N && (P.N & 3) == 0 && (((uintptr_t)P.dW) & 15) == 0) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool mok = mq + s < P.M;
-      a[s] = seg_load1(P.x, mq + s, kcol, mok && k_ok);
-      b[s] = (mok && col_ok) ? P.dY[(int64_t)(mq + s) * P.lddy + col] : 0.f;
-      bsum += b[s];
+      for (int e = 0; e < 4; ++e)
+        if (gcol + e < P.N) dst[e] = v[e];
     }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
   }
   if (P.db && blockIdx.y == 0) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (q == 0 && col_ok) P.db[col] = bsum;
-  }
-  if (!col_ok) return;
+    // bias gradient: every lane summed its (q, s, chunk) share of 4 columns; fold q-groups, then the 4 waves
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int orow = k0 + 4 * q + r;
-    if (orow < P.x.w) P.dW[(int64_t)orow * P.N + col] = acc0[r] + acc1[r];
+    for (int e = 0; e < 4; ++e) {
+      float t = bsum[e];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      bsum[e] = t;
+    }
+    __syncthreads();                                         // `red` is free again
+    if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < P.N) P.db[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
   }
 }
 
-// ------------------------------------------------------------------ output-layer backward (tiny N = D)
-// For a chain with last hidden activation Hl[M,H], output weights Wout[H,D] and output gradient dOut[M,D]:
-//   dH[m][n]  = (sum_j dOut[m][j] Wout[n][j]) * (Hl[m][n] > 0)
-//   dWout[n][j] = sum_m Hl[m][n] dOut[m][j]      (optional)
-//   dbout[j]    = sum_m dOut[m][j]               (optional)
-struct HeadProb {
-  const float* Hl; int32_t ldh;
-  const float* Wout;
-  const float* dOut; int32_t lddo;
-  float* dH; int32_t lddh;
-  float* dWout; float* dbout;        // nullable
-  int32_t M, H, D;
-};
-struct HeadArgs { HeadProb p[3]; int32_t nprob; };
 
-// grid: x = ceil(H/256), y = row blocks (16 rows each) + 1 extra block row for dWout/dbout, z = problem
-__global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs args) {
-  const HeadProb& P = args.p[blockIdx.z];
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  const int nrb = (P.M + 15) / 16;
-  if ((int)blockIdx.y < nrb) {
-    if (n >= P.H) return;
-    float w[8];
-    for (int j = 0; j < P.D; ++j) w[j] = P.Wout[(int64_t)n * P.D + j];
-    const int r0 = blockIdx.y * 16, r1 = min(P.M, r0 + 16);
-    for (int m = r0; m < r1; ++m) {
-      float s = 0.f;
-      for (int j = 0; j < P.D; ++j) s += P.dOut[(int64_t)m * P.lddo + j] * w[j];
-      P.dH[(int64_t)m * P.lddh + n] = (P.Hl[(int64_t)m * P.ldh + n] > 0.f) ? s : 0.f;
+// ================================================================== lean kernels for the hot 256-wide layers
+// Same tiling as the generic kernels above, but with 56-byte problem descriptors, no bounds checks and no segment
+// machinery: tools/gemm_lab.hip measures 3.7 us per launch inside a hipGraph for this form (2.0 us of which is the
+// launch floor of an empty kernel) against 5.5-7 us for the generic form with its 1 KB kernarg.
+// Preconditions (checked on the host, else the generic kernel runs): M % 16 == 0, N % 64 == 0, reduction dim % 256
+// == 0, all pointers 16-byte aligned, leading dims % 4 == 0.
+struct GemmHot {
+  const float* A; const float* B; const float* aux; float* C; float* aux_out;
+  int32_t lda, ldb, ldc, M, N, K;
+};
+struct HotArgs { GemmHot p[3]; };
+
+__device__ inline void hot_store(float* red, const f32x4 acc[4], int wave, int q, int j, int tid, f32x4& v, int& orow,
+                                 int& c4) {
+  v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+}
+
+// C[M,N] = relu(A[M,K] . B[K,N] + bias)        grid (N/64, M/16, nprob)
+__global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const GemmHot& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const float* xr = P.A + (int64_t)(m0 + j) * P.lda;
+  const float* wc = P.B + n0 + 4 * j;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  for (int kb = 0; kb < P.K; kb += 256) {
+    f32x4 a[4], b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kq = kb + (wave + 4 * u) * 16 + 4 * q;
+      a[u] = ldv(xr + kq);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[u][s] = ldv(wc + (int64_t)(kq + s) * P.ldb);
     }
-  } else if (P.dWout) {
-    if (n < P.H) {
-      float acc[8];
-      for (int j = 0; j < P.D; ++j) acc[j] = 0.f;
-      for (int m = 0; m < P.M; ++m) {
-        float h = P.Hl[(int64_t)m * P.ldh + n];
-        for (int j = 0; j < P.D; ++j) acc[j] += h * P.dOut[(int64_t)m * P.lddo + j];
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  v += ldv(P.aux + n0 + 4 * c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
+}
+
+// C[M,K'] = (A[M,N] . B[K',N]^T) * relu'(aux[M,K'])    (K' = P.N output columns, reduction over P.K)   grid (K'/64, M/16, nprob)
+__global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const GemmHot& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+  const float* dyr = P.A + (int64_t)(m0 + j) * P.lda;
+  const float* wr = P.B + (int64_t)(k0 + 4 * j) * P.ldb;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  for (int nb = 0; nb < P.K; nb += 256) {
+    f32x4 a[4], b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nq = nb + (wave + 4 * u) * 16 + 4 * q;
+      a[u] = ldv(dyr + nq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * P.ldb + nq);
+    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][e][s], acc[e]);
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  const int64_t o = (int64_t)(m0 + orow) * P.ldc + k0 + 4 * c4;
+  f32x4 h = ldv(P.aux + o);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
+  *reinterpret_cast<f32x4*>(P.C + o) = v;
+}
+
+// C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
+struct DwHotArgs { GemmHot p[4]; int32_t tile_end[4]; int32_t nprob; };
+__global__ __launch_bounds__(256) void dw_hot_kernel(DwHotArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  int pi = 0, t = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i + 1 < args.nprob && (int)blockIdx.x >= args.tile_end[i]) { pi = i + 1; t = blockIdx.x - args.tile_end[i]; }
+  const GemmHot& P = args.p[pi];
+  const int nx = P.N >> 6;
+  const int by = t / nx, bx = t - by * nx;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int k0 = by * 16, n0 = bx * 64;
+  const float* xc = P.A + k0 + j;
+  const float* yc = P.B + n0 + 4 * j;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < P.M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = xc[(int64_t)(mq + s) * P.lda];
+        b[u][s] = ldv(yc + (int64_t)(mq + s) * P.ldb);
       }
-      for (int j = 0; j < P.D; ++j) P.dWout[(int64_t)n * P.D + j] = acc[j];
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < P.D) {
-      float s = 0.f;
-      for (int m = 0; m < P.M; ++m) s += P.dOut[(int64_t)m * P.lddo + threadIdx.x];
-      P.dbout[threadIdx.x] = s;
-    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bsum += b[u][s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+      }
   }
-}
-
-// ------------------------------------------------------------------ losses (single workgroup, fixed-order sums)
-struct LossArgs {
-  const float* Qt;      // target critic on (o_2, g_2, pi_target)   [B]
-  const float* Q;       // main critic on u                         [B]
-  const float* Qpi;     // main critic on pi                        [B]
-  const float* pi; int32_t ldpi;   // main actor output [B, U]
-  const float* r; int32_t ldr;     // reward column of the batch
-  int32_t B, U;
-  float gamma, clip_lo, clip_hi, max_u, action_l2;
-  float* dQ;            // [B]  d Q_loss / d Q
-  float* dQpi;          // [B]  d pi_loss / d Q_pi = -1/B
-  float* out_losses;    // [2]
-  float* out_Qpi;       // [B] copy of Qpi
-  int64_t* step_ctr;    // nullable
-};
-
-__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-  __shared__ float s_q[256], s_p[256], s_l[256];
-  float lq = 0.f, lp = 0.f, ll = 0.f;
-  const float invB = 1.0f / (float)a.B;
-  for (int m = threadIdx.x; m < a.B; m += 256) {
-    float target = fclip(a.r[(int64_t)m * a.ldr] + a.gamma * a.Qt[m], a.clip_lo, a.clip_hi);   // ddpg.py:437-438
-    float diff = target - a.Q[m];
-    lq += diff * diff;                                            // ddpg.py:439
-    a.dQ[m] = -2.0f * invB * diff;
-    float qp = a.Qpi[m];
-    lp += qp;                                                     // ddpg.py:440
-    a.dQpi[m] = -invB;
-    a.out_Qpi[m] = qp;
-    for (int j = 0; j < a.U; ++j) {
-      float t = a.pi[(int64_t)m * a.ldpi + j] / a.max_u;
-      ll += t * t;                                                // ddpg.py:441
-    }
-  }
-  s_q[threadIdx.x] = lq; s_p[threadIdx.x] = lp; s_l[threadIdx.x] = ll;
-  __syncthreads();
-  for (int h = 128; h >= 1; h >>= 1) {
-    if ((int)threadIdx.x < h) {
-      s_q[threadIdx.x] += s_q[threadIdx.x + h];
-      s_p[threadIdx.x] += s_p[threadIdx.x + h];
-      s_l[threadIdx.x] += s_l[threadIdx.x + h];
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  *reinterpret_cast<f32x4*>(P.C + (int64_t)(k0 + orow) * P.ldc + n0 + 4 * c4) = v;
+  if (by == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float tt = bsum[e];
+      tt += __shfl_xor(tt, 16);
+      tt += __shfl_xor(tt, 32);
+      bsum[e] = tt;
     }
     __syncthreads();
+    if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64) P.aux_out[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
   }
-  if (threadIdx.x == 0) {
-    a.out_losses[0] = s_q[0] * invB;
-    a.out_losses[1] = -s_p[0] * invB + a.action_l2 * s_l[0] / (float)(a.B * a.U);
-    if (a.step_ctr) *a.step_ctr += 1;
+}
+
+
+// Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
+//   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
+struct DwSmall {
+  const float* x; const float* dY; float* dW; float* db;
+  int32_t ldx, lddy, w, N;
+  float div;
+  int32_t tile_end;      // exclusive prefix of this problem's tiles in the 1-D grid
+};
+#define MAX_DW_SMALL 12
+struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M; LossFin fin; };
+
+__global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int pi = 0, t = blockIdx.x;
+  for (int i = 0; i + 1 < args.nprob; ++i)
+    if ((int)blockIdx.x >= args.p[i].tile_end) { pi = i + 1; t = blockIdx.x - args.p[i].tile_end; }
+  if ((int)blockIdx.x >= args.p[args.nprob - 1].tile_end) {
+    // last block: losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
+    const LossFin& F = args.fin;
+    float lq = 0.f, lp = 0.f, ll = 0.f;
+    for (int m = tid; m < F.B; m += 256) {
+      lq += F.rows[m];
+      lp += F.rows[F.B + m];
+      ll += F.rows[2 * F.B + m];
+    }
+    red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+      if (tid < h) {
+        red[tid] += red[tid + h];
+        red[256 + tid] += red[256 + tid + h];
+        red[512 + tid] += red[512 + tid + h];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float invB = 1.0f / (float)F.B;
+      F.out[0] = red[0] * invB;
+      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+    }
+    return;
+  }
+  const DwSmall& P = args.p[pi];
+  const int nx = (P.N + 63) >> 6;
+  const int by = t / nx, bx = t - by * nx;
+  const int j = lane & 15, q = lane >> 4;
+  const int k0 = by * 16, n0 = bx * 64;
+  const int krow = k0 + j, col = n0 + 4 * j;
+  const bool k_ok = krow < P.w;
+  const float* xc = P.x + min(krow, P.w - 1);
+  const bool yv = (P.N & 3) == 0;
+  const int colc = yv ? min(col, P.N - 4) : min(col, P.N - 1);
+  const float* yc = P.dY + colc;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < args.M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
+        if (yv) {
+          b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+        } else {
+          f32x4 bb = zero4();
+          bb[0] = yc[(int64_t)(mq + s) * P.lddy];        // N not a multiple of 4: only N == 1 occurs (critic output)
+          b[u][s] = bb;
+        }
+      }
+    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float av = a[u][s];
+        if (P.div != 1.0f) av = fdiv(av, P.div);
+        av = k_ok ? av : 0.f;
+        bsum += b[u][s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
+      }
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  const int grow = k0 + orow, gcol = n0 + 4 * c4;
+  if (grow < P.w && gcol < P.N) {
+    float* dst = P.dW + (int64_t)grow * P.N + gcol;
+    if (yv) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gcol + e < P.N) dst[e] = v[e];
+    }
+  }
+  if (P.db && by == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float tt = bsum[e];
+      tt += __shfl_xor(tt, 16);
+      tt += __shfl_xor(tt, 32);
+      bsum[e] = tt;
+    }
+    __syncthreads();
+    if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < P.N) P.db[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+// ------------------------------------------------------------------ one-wave-per-row kernels
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// out[m][d] = f(sum_k h[m][k] W[k][d] + b[d]),  D <= MAX_U
+struct HeadFwdProb {
+  const float* h; int32_t ldh;
+  const float* W; const float* b;
+  float* out; int32_t ldo;
+  int32_t M, H, D, act;      // act 2: max_u * tanh
+  float max_u;
+};
+struct HeadFwdArgs { HeadFwdProb p[3]; int32_t nprob; };
+
+__device__ inline void row_dot(const float* hrow, const float* W, int H, int D, int lane, float* out /*[MAX_U]*/) {
+  float acc[MAX_U];
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) acc[d] = 0.f;
+  const bool hv = ((uintptr_t)hrow & 15) == 0;
+  for (int k = 4 * lane; k < H; k += 256) {
+    f32x4 h4 = ldg4(hrow + k, H - k, hv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (k + e < H) {
+        const float* wr = W + (int64_t)(k + e) * D;
+#pragma unroll
+        for (int d = 0; d < MAX_U; ++d)
+          if (d < D) acc[d] += h4[e] * wr[d];
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) out[d] = (d < D) ? wave_sum(acc[d]) : 0.f;
+}
+
+// Branch-free specialisations (H % 4 == 0 is guaranteed by check_cfg): D = 1 (critic) and D = 4 (Fetch actor).
+// Rows k..k+3 of W[H, D] are 4*D contiguous floats, read with D unconditional 16-byte loads.
+template <int D>
+__device__ inline void row_dot_fast(const float* hrow, const float* W, int H, int lane, float* out /*[D]*/) {
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  const int trips = (H + 255) >> 8;
+  for (int t = 0; t < trips; ++t) {
+    const int k = 256 * t + 4 * lane;
+    const bool ok = k < H;
+    const int kc = min(k, H - 4);
+    f32x4 h4 = sel4(ok, ldv(hrow + kc));
+    if (D == 1) {
+      f32x4 w = ldv(W + kc);
+      acc[0] += h4[0] * w[0] + h4[1] * w[1] + h4[2] * w[2] + h4[3] * w[3];
+    } else {
+      f32x4 w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = ldv(W + (int64_t)(kc + e) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] += h4[e] * w[e][d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) out[d] = wave_sum(acc[d]);
+}
+
+// grid: x = ceil(M/4) (one wave per row), z = problem
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs args) {
+  const HeadFwdProb& P = args.p[blockIdx.z];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= P.M) return;
+  float o[MAX_U];
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) o[d] = 0.f;
+  const float* hrow = P.h + (int64_t)m * P.ldh;
+  const bool al = (((uintptr_t)hrow | (uintptr_t)P.W) & 15) == 0;
+  if (al && P.D == 4) row_dot_fast<4>(hrow, P.W, P.H, lane, o);
+  else if (al && P.D == 1) row_dot_fast<1>(hrow, P.W, P.H, lane, o);
+  else row_dot(hrow, P.W, P.H, P.D, lane, o);
+  if (lane < P.D) {
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < MAX_U; ++d)
+      if (d == lane) v = o[d];
+    v += P.b[lane];
+    if (P.act == 2) v = P.max_u * tanhf(v);                  // actor_critic.py:89
+    P.out[(int64_t)m * P.ldo + lane] = v;
+  }
+}
+
+// Critic output layers of the three critic passes + losses' per-row terms + backward through those output layers.
+struct CriticHeadArgs {
+  const float *c2, *d2, *e2;      // last hidden activations: main critic(u), main critic(pi), target critic   [B,H]
+  const float* WoutQ; const float* boutQ;          // main/Q output layer
+  const float* WoutQt; const float* boutQt;        // target/Q output layer
+  const float* r; int32_t ldr;
+  const float* pi; int32_t ldpi;
+  int32_t B, H, U;
+  float gamma, clip_lo, clip_hi, max_u;
+  float *dc2, *dd2;               // gradients wrt c2 / d2                                                      [B,H]
+  float* dQ;                      // [B] d Q_loss / d Q   (feeds dWout/dbout of main/Q)
+  float* rows;                    // [3][B] per-row loss terms
+  float* out_Qpi;                 // [B]
+  int64_t* step_ctr;
+};
+
+__global__ __launch_bounds__(256) void critic_head_kernel(CriticHeadArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_ctr) *a.step_ctr += 1;
+  if (m >= a.B) return;
+  const float* c2 = a.c2 + (int64_t)m * a.H;
+  const float* d2 = a.d2 + (int64_t)m * a.H;
+  const float* e2 = a.e2 + (int64_t)m * a.H;
+  float q_[MAX_U], qp_[MAX_U], qt_[MAX_U];
+  row_dot_fast<1>(c2, a.WoutQ, a.H, lane, q_);
+  row_dot_fast<1>(d2, a.WoutQ, a.H, lane, qp_);
+  row_dot_fast<1>(e2, a.WoutQt, a.H, lane, qt_);
+  const float Q = q_[0] + a.boutQ[0], Qpi = qp_[0] + a.boutQ[0], Qt = qt_[0] + a.boutQt[0];
+  const float invB = 1.0f / (float)a.B;
+  const float target = fclip(a.r[(int64_t)m * a.ldr] + a.gamma * Qt, a.clip_lo, a.clip_hi);   // ddpg.py:437-438
+  const float diff = target - Q;
+  const float dQ = -2.0f * invB * diff;                      // d mean((target-Q)^2) / dQ
+  const float dQpi = -invB;                                  // d (-mean(Q_pi)) / dQ_pi
+  if (lane == 0) {
+    float l2 = 0.f;
+    for (int jj = 0; jj < a.U; ++jj) {
+      float t = a.pi[(int64_t)m * a.ldpi + jj] / a.max_u;
+      l2 += t * t;                                           // ddpg.py:441
+    }
+    a.rows[m] = diff * diff;                                 // ddpg.py:439
+    a.rows[a.B + m] = Qpi;                                   // ddpg.py:440
+    a.rows[2 * a.B + m] = l2;
+    a.dQ[m] = dQ;
+    a.out_Qpi[m] = Qpi;
+  }
+  // backward through the (shared) output layer: dH = dOut * Wout^T, masked by relu'
+  const int trips = (a.H + 255) >> 8;
+  for (int t = 0; t < trips; ++t) {
+    const int k = 256 * t + 4 * lane;
+    const int kc = min(k, a.H - 4);
+    f32x4 w = ldv(a.WoutQ + kc);
+    f32x4 hc = ldv(c2 + kc), hd = ldv(d2 + kc);
+    f32x4 gc, gd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gc[e] = (hc[e] > 0.f) ? dQ * w[e] : 0.f;
+      gd[e] = (hd[e] > 0.f) ? dQpi * w[e] : 0.f;
+    }
+    if (k < a.H) {
+      *reinterpret_cast<f32x4*>(a.dc2 + (int64_t)m * a.H + k) = gc;
+      *reinterpret_cast<f32x4*>(a.dd2 + (int64_t)m * a.H + k) = gd;
+    }
+  }
+}
+
+// d pi_loss / dz through the critic's action slot, tanh and the l2 term; then backward through the actor output layer.
+struct ActorDzArgs {
+  const float* dd0;               // gradient wrt critic(pi) layer-0 pre-activation (already relu-masked)      [B,H]
+  const float* Wu;                // rows of main/Q layer-0 kernel that multiply the action: [U, H]
+  const float* pi; int32_t ldpi;
+  const float* a2;                // actor last hidden activation                                               [B,H]
+  const float* WoutPi;            // [H, U]
+  float* dz;                      // [B, U]
+  float* da2;                     // [B, H]
+  int32_t B, H, U;
+  float max_u, l2c;               // l2c = action_l2 * 2 / (max_u^2 * B * U)
+};
+
+// branch-free body for dimu == 4 (H % 4 == 0): every load is an unconditional 16-byte load
+__device__ inline void actor_dz_fast4(const ActorDzArgs& a, int m, int lane) {
+  const float* g = a.dd0 + (int64_t)m * a.H;
+  const float* h = a.a2 + (int64_t)m * a.H;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int trips = (a.H + 255) >> 8;
+  for (int t = 0; t < trips; ++t) {
+    const int k = 256 * t + 4 * lane;
+    const int kc = min(k, a.H - 4);
+    f32x4 g4 = sel4(k < a.H, ldv(g + kc));
+    f32x4 w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = ldv(a.Wu + (int64_t)d * a.H + kc);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[d] += g4[0] * w[d][0] + g4[1] * w[d][1] + g4[2] * w[d][2] + g4[3] * w[d][3];
+  }
+  f32x4 pi4 = ldv(a.pi + (int64_t)m * a.ldpi);
+  float dz[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float v = wave_sum(acc[d]);
+    float th = pi4[d] / a.max_u;
+    float dpi = v / a.max_u + a.l2c * pi4[d];                // ddpg.py:440-441
+    dz[d] = dpi * a.max_u * (1.0f - th * th);                // through pi = max_u * tanh(z)
+  }
+  if (lane == 0) {
+    f32x4 o = {dz[0], dz[1], dz[2], dz[3]};
+    *reinterpret_cast<f32x4*>(a.dz + (int64_t)m * 4) = o;
+  }
+  for (int t = 0; t < trips; ++t) {
+    const int k = 256 * t + 4 * lane;
+    const int kc = min(k, a.H - 4);
+    f32x4 h4 = ldv(h + kc);
+    f32x4 w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = ldv(a.WoutPi + (int64_t)(kc + e) * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sv = dz[0] * w[e][0] + dz[1] * w[e][1] + dz[2] * w[e][2] + dz[3] * w[e][3];
+      o[e] = (h4[e] > 0.f) ? sv : 0.f;
+    }
+    if (k < a.H) *reinterpret_cast<f32x4*>(a.da2 + (int64_t)m * a.H + k) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void actor_dz_kernel(ActorDzArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.B) return;
+  if (a.U == 4 && a.ldpi == 4 && ((((uintptr_t)a.Wu | (uintptr_t)a.WoutPi | (uintptr_t)a.pi | (uintptr_t)a.dz)) & 15) == 0) {
+    actor_dz_fast4(a, m, lane);
+    return;
+  }
+  const float* g = a.dd0 + (int64_t)m * a.H;
+  float acc[MAX_U];
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) acc[d] = 0.f;
+  for (int k = 4 * lane; k < a.H; k += 256) {
+    f32x4 g4 = ldg4(g + k, a.H - k, true);
+#pragma unroll
+    for (int d = 0; d < MAX_U; ++d)
+      if (d < a.U) {
+        f32x4 w = ldg4(a.Wu + (int64_t)d * a.H + k, a.H - k, true);
+        acc[d] += g4[0] * w[0] + g4[1] * w[1] + g4[2] * w[2] + g4[3] * w[3];
+      }
+  }
+  float dz[MAX_U];
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) {
+    dz[d] = 0.f;
+    if (d < a.U) {
+      float v = wave_sum(acc[d]);
+      float pi = a.pi[(int64_t)m * a.ldpi + d];
+      float th = pi / a.max_u;
+      float dpi = v / a.max_u + a.l2c * pi;                  // ddpg.py:440-441
+      dz[d] = dpi * a.max_u * (1.0f - th * th);              // through pi = max_u * tanh(z)
+    }
+  }
+  if (lane < a.U) {
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < MAX_U; ++d)
+      if (d == lane) v = dz[d];
+    a.dz[(int64_t)m * a.U + lane] = v;
+  }
+  const float* h = a.a2 + (int64_t)m * a.H;
+  for (int k = 4 * lane; k < a.H; k += 256) {
+    f32x4 h4 = ldg4(h + k, a.H - k, true);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+      if (k + e < a.H) {
+        const float* wr = a.WoutPi + (int64_t)(k + e) * a.U;
+#pragma unroll
+        for (int d = 0; d < MAX_U; ++d)
+          if (d < a.U) s += dz[d] * wr[d];
+      }
+      o[e] = (h4[e] > 0.f) ? s : 0.f;
+    }
+    if (k + 3 < a.H) {
+      *reinterpret_cast<f32x4*>(a.da2 + (int64_t)m * a.H + k) = o;
+    } else {
+      for (int e = 0; e < 4 && k + e < a.H; ++e) a.da2[(int64_t)m * a.H + k + e] = o[e];
+    }
   }
 }
 
@@ -382,16 +1081,17 @@ extern "C" int64_t curious_param_total(const curious_net_cfg_t* cfg) {
 static int check_cfg(const curious_net_cfg_t* c) {
   CURIOUS_CHECK(c, "net cfg is NULL");
   CURIOUS_CHECK(c->layers >= 1 && c->layers <= MAX_LAYERS, "layers must be in 1..%d", MAX_LAYERS);
-  CURIOUS_CHECK(c->hidden >= 1 && c->dimo >= 1 && c->dimg >= 0 && c->dimu >= 1 && c->dimu <= 8,
-                "bad network dimensions (dimu must be <= 8)");
+  CURIOUS_CHECK(c->hidden >= 1 && c->dimo >= 1 && c->dimg >= 0 && c->dimu >= 1 && c->dimu <= MAX_U,
+                "bad network dimensions (dimu must be <= %d)", MAX_U);
   CURIOUS_CHECK(c->modular || c->dimtd == 0, "flat networks take no task descriptor");
+  CURIOUS_CHECK(c->hidden % 4 == 0, "hidden must be a multiple of 4");
   return 0;
 }
 
 struct Ws {   // workspace carve-up
   float* act[5][MAX_LAYERS];   // chains: 0 target actor, 1 main critic(u), 2 main actor, 3 target critic, 4 main critic(pi)
   float* dact[3][MAX_LAYERS];  // gradient wrt hidden activations: 0 critic(u), 1 critic(pi), 2 actor
-  float *pi_t, *pi, *Qt, *Q, *Qpi, *dQ, *dQpi, *dz;
+  float *pi_t, *pi, *dQ, *dz, *rows;
   int64_t total;
 };
 
@@ -400,7 +1100,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   int64_t off = 0;
   auto take = [&](int64_t n) {
     float* p = base ? base + off : nullptr;
-    off += (n + 3) & ~(int64_t)3;
+    off += (n + 63) & ~(int64_t)63;
     return p;
   };
   const int64_t BH = (int64_t)B * c->hidden;
@@ -411,7 +1111,8 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.pi_t = take((int64_t)B * c->dimu);
   w.pi = take((int64_t)B * c->dimu);
   w.dz = take((int64_t)B * c->dimu);
-  w.Qt = take(B); w.Q = take(B); w.Qpi = take(B); w.dQ = take(B); w.dQpi = take(B);
+  w.dQ = take(B);
+  w.rows = take(3 * (int64_t)B);
   w.total = off;
   return w;
 }
@@ -482,57 +1183,91 @@ static int l0_segments(const curious_net_cfg_t* c, const NetOff& n, const float*
   return k;
 }
 
-static void launch_fwd(const FwdArgs& a, hipStream_t st) {
-  int maxM = 0, maxN = 0;
-  for (int i = 0; i < a.nprob; ++i) {
-    if (a.p[i].M > maxM) maxM = a.p[i].M;
-    if (a.p[i].N > maxN) maxN = a.p[i].N;
-  }
-  dim3 grid((maxN + 63) / 64, (maxM + 15) / 16, a.nprob);
-  hipLaunchKernelGGL(fwd_layer_kernel, grid, dim3(256), 0, st, a);
-}
-
-// Forward of `nch` independent chains through all layers (one launch per layer level).
+// One chain = one network applied to one set of inputs; forward_chains runs the hidden layers of up to 3
+// independent chains, one launch per layer level.
 struct Chain {
   const float* theta;   // base of this network's parameters
   NetOff off;
   ObsIn in;
   bool critic;
   float** act;          // [layers] activations out
-  float* out;           // output [M, D]
-  int act_out;          // 0 linear, 2 tanh
 };
+
+static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
 
 static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M, hipStream_t st) {
   const int H = c->hidden;
-  for (int l = 0; l <= c->layers; ++l) {
+  for (int l = 0; l < c->layers; ++l) {
+    bool hot = (l >= 1) && hot_ok(M, H, H);
+    for (int i = 0; i < nch; ++i)
+      if (!aligned16(ch[i].theta) || !aligned16(ch[i].act[0])) hot = false;
+    if (hot) {
+      HotArgs a;
+      memset(&a, 0, sizeof(a));
+      for (int i = 0; i < nch; ++i) {
+        GemmHot& p = a.p[i];
+        Chain& C = ch[i];
+        p.A = C.act[l - 1]; p.lda = H; p.B = C.theta + C.off.W[l]; p.ldb = H; p.aux = C.theta + C.off.b[l];
+        p.C = C.act[l]; p.ldc = H; p.M = M; p.N = H; p.K = H;
+      }
+      dim3 grid(H / 64, M / 16, nch);
+      { ProfScope ps__(CK_FWD_LAYER, st); hipLaunchKernelGGL(fwd_hot_kernel, grid, dim3(256), 0, st, a); }
+      CURIOUS_LAUNCH_CHECK("fwd_hot_kernel");
+      continue;
+    }
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.nprob = nch;
     for (int i = 0; i < nch; ++i) {
       FwdProb& p = a.p[i];
       Chain& C = ch[i];
-      p.M = M;
-      p.max_u = c->max_u;
+      p.M = M; p.N = H; p.Y = C.act[l]; p.ldy = H; p.act = 1;
       if (l == 0) {
         p.nseg = l0_segments(c, C.off, C.theta, C.in, C.critic, c->max_u, p.seg);
         p.bias = C.theta + C.off.b0;
       } else {
-        const float* W = (l < c->layers) ? C.theta + C.off.W[l] : C.theta + C.off.Wout;
-        p.seg[0] = make_seg(C.act[l - 1], H, H, W);
+        p.seg[0] = make_seg(C.act[l - 1], H, H, C.theta + C.off.W[l]);
         p.nseg = 1;
-        p.bias = (l < c->layers) ? C.theta + C.off.b[l] : C.theta + C.off.bout;
+        p.bias = C.theta + C.off.b[l];
       }
-      if (l < c->layers) {
-        p.N = H; p.Y = C.act[l]; p.ldy = H; p.act = 1;
-      } else {
-        p.N = C.off.D; p.Y = C.out; p.ldy = C.off.D; p.act = C.act_out;
+      p.wvec = (H % 4 == 0) && aligned16(C.theta) ? 1 : 0;
+      for (int s = 0; s < p.nseg; ++s)
+        if (!aligned16(p.seg[s].W)) p.wvec = 0;
+      p.fast = p.wvec && H >= 4;
+      for (int s = 0; s < p.nseg; ++s) {
+        const Seg& sg = p.seg[s];
+        if (!sg.vec || sg.w % 4 != 0 || sg.w < 4 || sg.sub) p.fast = 0;
+        if (sg.mean && (!aligned16(sg.mean) || !aligned16(sg.stdv))) p.fast = 0;
       }
     }
-    launch_fwd(a, st);
+    dim3 grid((H + 63) / 64, (M + 15) / 16, nch);
+    { ProfScope ps__(CK_FWD_LAYER0, st); hipLaunchKernelGGL(fwd_layer_kernel, grid, dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("fwd_layer_kernel");
   }
   return 0;
+}
+
+static int launch_head_fwd(HeadFwdArgs& ha, int M, hipStream_t st) {
+  dim3 grid((M + 3) / 4, 1, ha.nprob);
+  { ProfScope ps__(CK_HEAD_FWD, st); hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(256), 0, st, ha); }
+  CURIOUS_LAUNCH_CHECK("head_fwd_kernel");
+  return 0;
+}
+
+static HeadFwdProb head_prob(const float* h, int H, const float* W, const float* b, float* out, int M, int D, int act,
+                             float max_u) {
+  HeadFwdProb p;
+  p.h = h; p.ldh = H; p.W = W; p.b = b; p.out = out; p.ldo = D; p.M = M; p.H = H; p.D = D; p.act = act;
+  p.max_u = max_u;
+  return p;
+}
+
+static void fill_obs_stats(const curious_net_cfg_t* cfg, ObsIn& in, const float* o_stats, const float* g_stats) {
+  in.nclip = cfg->norm_clip;
+  if (cfg->normalize_obs) {
+    in.o_mean = o_stats + 2 * cfg->dimo + 1; in.o_std = o_stats + 3 * cfg->dimo + 1;
+    in.g_mean = g_stats + 2 * cfg->dimg + 1; in.g_std = g_stats + 3 * cfg->dimg + 1;
+  }
 }
 
 extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float* theta, const float* o, int32_t ldo,
@@ -549,23 +1284,30 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   hipStream_t st = as_stream(stream);
   Ws w = carve(cfg, n, workspace);
   NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
+  const int H = cfg->hidden, nl = cfg->layers;
   ObsIn in;
   memset(&in, 0, sizeof(in));
   in.o = o; in.ldo = ldo; in.td = td; in.ldtd = ldtd; in.g = g; in.ldg = ldg; in.ag = ag; in.ldag = ldag;
-  in.clip = clip_obs; in.relative = relative_goals; in.nclip = cfg->norm_clip;
-  if (cfg->normalize_obs) {
-    in.o_mean = o_stats + 2 * cfg->dimo + 1; in.o_std = o_stats + 3 * cfg->dimo + 1;
-    in.g_mean = g_stats + 2 * cfg->dimg + 1; in.g_std = g_stats + 3 * cfg->dimg + 1;
-  }
+  in.clip = clip_obs; in.relative = relative_goals;
+  fill_obs_stats(cfg, in, o_stats, g_stats);
+  const float* thPi = theta + pi_offset(cfg);
   Chain a;
-  a.theta = theta + pi_offset(cfg); a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.out = out_pi;
-  a.act_out = 2;
+  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2];
   if (forward_chains(cfg, &a, 1, n, st)) return -2;
+  HeadFwdArgs ha;
+  memset(&ha, 0, sizeof(ha));
+  ha.nprob = 1;
+  ha.p[0] = head_prob(w.act[2][nl - 1], H, thPi + offPi.Wout, thPi + offPi.bout, out_pi, n, cfg->dimu, 2, cfg->max_u);
+  if (launch_head_fwd(ha, n, st)) return -2;
   if (out_Q) {
-    Chain q;
-    q.theta = theta; q.off = offQ; q.in = in; q.in.u = out_pi; q.in.ldu = cfg->dimu; q.critic = true;
-    q.act = w.act[4]; q.out = out_Q; q.act_out = 0;
-    if (forward_chains(cfg, &q, 1, n, st)) return -2;
+    Chain qc;
+    qc.theta = theta; qc.off = offQ; qc.in = in; qc.in.u = out_pi; qc.in.ldu = cfg->dimu; qc.critic = true;
+    qc.act = w.act[4];
+    if (forward_chains(cfg, &qc, 1, n, st)) return -2;
+    memset(&ha, 0, sizeof(ha));
+    ha.nprob = 1;
+    ha.p[0] = head_prob(w.act[4][nl - 1], H, theta + offQ.Wout, theta + offQ.bout, out_Q, n, 1, 0, cfg->max_u);
+    if (launch_head_fwd(ha, n, st)) return -2;
   }
   return 0;
 }
@@ -597,61 +1339,67 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
   cur.td = batch + BL->off_td; cur.ldtd = ld;
   cur.u = batch + BL->off_u; cur.ldu = ld;
   cur.g = batch + BL->off_g; cur.ldg = ld;
-  cur.nclip = cfg->norm_clip;
-  if (cfg->normalize_obs) {
-    cur.o_mean = o_stats + 2 * cfg->dimo + 1; cur.o_std = o_stats + 3 * cfg->dimo + 1;
-    cur.g_mean = g_stats + 2 * cfg->dimg + 1; cur.g_std = g_stats + 3 * cfg->dimg + 1;
-  }
+  fill_obs_stats(cfg, cur, o_stats, g_stats);
   nxt = cur;
   nxt.o = batch + BL->off_o2;            // target nets see (o_2, g_2) (ddpg.py:427-431)
   nxt.g = batch + BL->off_g2;
 
-  // ---- forward level A: target actor, main critic(u), main actor
+  // ---- forward level A: hidden layers of target actor, main critic(u), main actor
   Chain ch[3];
   ch[0].theta = ttPi; ch[0].off = offPi; ch[0].in = nxt; ch[0].critic = false; ch[0].act = w.act[0];
-  ch[0].out = w.pi_t; ch[0].act_out = 2;
   ch[1].theta = thQ; ch[1].off = offQ; ch[1].in = cur; ch[1].critic = true; ch[1].act = w.act[1];
-  ch[1].out = w.Q; ch[1].act_out = 0;
   ch[2].theta = thPi; ch[2].off = offPi; ch[2].in = cur; ch[2].critic = false; ch[2].act = w.act[2];
-  ch[2].out = w.pi; ch[2].act_out = 2;
   if (forward_chains(cfg, ch, 3, B, st)) return -2;
-  // ---- forward level B: target critic(pi_target), main critic(pi)
-  Chain cb[2];
-  cb[0].theta = ttQ; cb[0].off = offQ; cb[0].in = nxt; cb[0].in.u = w.pi_t; cb[0].in.ldu = U; cb[0].critic = true;
-  cb[0].act = w.act[3]; cb[0].out = w.Qt; cb[0].act_out = 0;
-  cb[1].theta = thQ; cb[1].off = offQ; cb[1].in = cur; cb[1].in.u = w.pi; cb[1].in.ldu = U; cb[1].critic = true;
-  cb[1].act = w.act[4]; cb[1].out = w.Qpi; cb[1].act_out = 0;
-  if (forward_chains(cfg, cb, 2, B, st)) return -2;
-
-  // ---- losses
-  LossArgs la;
-  la.Qt = w.Qt; la.Q = w.Q; la.Qpi = w.Qpi; la.pi = w.pi; la.ldpi = U;
-  la.r = batch + BL->off_r; la.ldr = ld; la.B = B; la.U = U;
-  la.gamma = cfg->gamma; la.clip_lo = -cfg->clip_return;
-  la.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
-  la.max_u = cfg->max_u; la.action_l2 = cfg->action_l2;
-  la.dQ = w.dQ; la.dQpi = w.dQpi; la.out_losses = out_losses; la.out_Qpi = out_Q_pi; la.step_ctr = step_ctr;
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, la);
-  CURIOUS_LAUNCH_CHECK("loss_kernel");
-
-  // ---- backward through the output layers of the two critic passes
+  // ---- actor output layers: pi_target, pi
   {
-    HeadArgs ha;
+    HeadFwdArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.nprob = 2;
-    HeadProb& c0 = ha.p[0];   // critic(u): also dWout, dbout of main/Q
-    c0.Hl = w.act[1][nl - 1]; c0.ldh = H; c0.Wout = thQ + offQ.Wout; c0.dOut = w.dQ; c0.lddo = 1;
-    c0.dH = w.dact[0][nl - 1]; c0.lddh = H; c0.dWout = gQ + offQ.Wout; c0.dbout = gQ + offQ.bout;
-    c0.M = B; c0.H = H; c0.D = 1;
-    HeadProb& c1 = ha.p[1];   // critic(pi): input gradient only
-    c1 = c0;
-    c1.Hl = w.act[4][nl - 1]; c1.dOut = w.dQpi; c1.dH = w.dact[1][nl - 1]; c1.dWout = nullptr; c1.dbout = nullptr;
-    dim3 grid((H + 255) / 256, (B + 15) / 16 + 1, 2);
-    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, st, ha);
-    CURIOUS_LAUNCH_CHECK("head_bwd_kernel");
+    ha.p[0] = head_prob(w.act[0][nl - 1], H, ttPi + offPi.Wout, ttPi + offPi.bout, w.pi_t, B, U, 2, cfg->max_u);
+    ha.p[1] = head_prob(w.act[2][nl - 1], H, thPi + offPi.Wout, thPi + offPi.bout, w.pi, B, U, 2, cfg->max_u);
+    if (launch_head_fwd(ha, B, st)) return -2;
   }
-  // ---- hidden layers of the critic passes: dact[ch][l-1] = (dact[ch][l] . W_l^T) * relu'(act[l-1])
+  // ---- forward level B: hidden layers of target critic(pi_target), main critic(pi)
+  Chain cb[2];
+  cb[0].theta = ttQ; cb[0].off = offQ; cb[0].in = nxt; cb[0].in.u = w.pi_t; cb[0].in.ldu = U; cb[0].critic = true;
+  cb[0].act = w.act[3];
+  cb[1].theta = thQ; cb[1].off = offQ; cb[1].in = cur; cb[1].in.u = w.pi; cb[1].in.ldu = U; cb[1].critic = true;
+  cb[1].act = w.act[4];
+  if (forward_chains(cfg, cb, 2, B, st)) return -2;
+
+  // ---- critic output layers, per-row loss terms, backward through the output layers
+  {
+    CriticHeadArgs a;
+    a.c2 = w.act[1][nl - 1]; a.d2 = w.act[4][nl - 1]; a.e2 = w.act[3][nl - 1];
+    a.WoutQ = thQ + offQ.Wout; a.boutQ = thQ + offQ.bout;
+    a.WoutQt = ttQ + offQ.Wout; a.boutQt = ttQ + offQ.bout;
+    a.r = batch + BL->off_r; a.ldr = ld; a.pi = w.pi; a.ldpi = U;
+    a.B = B; a.H = H; a.U = U;
+    a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
+    a.max_u = cfg->max_u;
+    a.dc2 = w.dact[0][nl - 1]; a.dd2 = w.dact[1][nl - 1]; a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi;
+    a.step_ctr = step_ctr;
+    { ProfScope ps__(CK_CRITIC_HEAD, st);
+      hipLaunchKernelGGL(critic_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a); }
+    CURIOUS_LAUNCH_CHECK("critic_head_kernel");
+  }
+  // ---- hidden layers of the two critic passes: dact[k][l-1] = (dact[k][l] . W_l^T) * relu'(act[l-1])
+  const bool dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
   for (int l = nl - 1; l >= 1; --l) {
+    if (dx_hot) {
+      HotArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      for (int k = 0; k < 2; ++k) {
+        GemmHot& p = ha.p[k];
+        const int chain = (k == 0) ? 1 : 4;
+        p.A = w.dact[k][l]; p.lda = H; p.B = thQ + offQ.W[l]; p.ldb = H; p.aux = w.act[chain][l - 1];
+        p.C = w.dact[k][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
+      }
+      dim3 grid(H / 64, B / 16, 2);
+      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel, grid, dim3(256), 0, st, ha); }
+      CURIOUS_LAUNCH_CHECK("dx_hot_kernel");
+      continue;
+    }
     DxArgs da;
     memset(&da, 0, sizeof(da));
     da.nprob = 2;
@@ -660,61 +1408,74 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
       const int chain = (k == 0) ? 1 : 4;
       p.dY = w.dact[k][l]; p.lddy = H; p.W = thQ + offQ.W[l]; p.ldw = H;
       p.H = w.act[chain][l - 1]; p.ldh = H; p.dX = w.dact[k][l - 1]; p.lddx = H;
-      p.M = B; p.N = H; p.K = H; p.epi = 0; p.vec = (H % 4 == 0);
+      p.M = B; p.N = H; p.K = H; p.vec = aligned16(p.W) ? 1 : 0;
+      p.fast = p.vec && aligned16(p.dY) && H >= 4;
     }
     dim3 grid((H + 63) / 64, (B + 15) / 16, 2);
-    hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da);
+    { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel");
   }
-  // ---- through layer 0 of critic(pi) into the action slot, then through tanh + l2 term -> dz
+  // ---- into the action slot of critic(pi), through tanh + l2 term -> dz; backward through the actor output layer
   {
-    DxArgs da;
-    memset(&da, 0, sizeof(da));
-    da.nprob = 1;
-    DxProb& p = da.p[0];
+    ActorDzArgs a;
     const int64_t urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);   // first action row of W0
-    p.dY = w.dact[1][0]; p.lddy = H; p.W = thQ + offQ.W0 + urow * H; p.ldw = H;
-    p.H = nullptr; p.dX = w.dz; p.lddx = U; p.M = B; p.N = H; p.K = U; p.epi = 1;
-    p.pi = w.pi; p.ldpi = U; p.max_u = cfg->max_u;
-    p.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
-    p.vec = (H % 4 == 0);
-    dim3 grid(1, (B + 15) / 16, 1);
-    hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da);
-    CURIOUS_LAUNCH_CHECK("dx_kernel(dz)");
-  }
-  // ---- actor output layer
-  {
-    HeadArgs ha;
-    memset(&ha, 0, sizeof(ha));
-    ha.nprob = 1;
-    HeadProb& a0 = ha.p[0];
-    a0.Hl = w.act[2][nl - 1]; a0.ldh = H; a0.Wout = thPi + offPi.Wout; a0.dOut = w.dz; a0.lddo = U;
-    a0.dH = w.dact[2][nl - 1]; a0.lddh = H; a0.dWout = gPi + offPi.Wout; a0.dbout = gPi + offPi.bout;
-    a0.M = B; a0.H = H; a0.D = U;
-    dim3 grid((H + 255) / 256, (B + 15) / 16 + 1, 1);
-    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, st, ha);
-    CURIOUS_LAUNCH_CHECK("head_bwd_kernel(actor)");
+    a.dd0 = w.dact[1][0]; a.Wu = thQ + offQ.W0 + urow * H; a.pi = w.pi; a.ldpi = U;
+    a.a2 = w.act[2][nl - 1]; a.WoutPi = thPi + offPi.Wout; a.dz = w.dz; a.da2 = w.dact[2][nl - 1];
+    a.B = B; a.H = H; a.U = U; a.max_u = cfg->max_u;
+    a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+    { ProfScope ps__(CK_ACTOR_DZ, st);
+      hipLaunchKernelGGL(actor_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a); }
+    CURIOUS_LAUNCH_CHECK("actor_dz_kernel");
   }
   for (int l = nl - 1; l >= 1; --l) {
+    if (dx_hot) {
+      HotArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      GemmHot& p = ha.p[0];
+      p.A = w.dact[2][l]; p.lda = H; p.B = thPi + offPi.W[l]; p.ldb = H; p.aux = w.act[2][l - 1];
+      p.C = w.dact[2][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
+      dim3 grid(H / 64, B / 16, 1);
+      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel, grid, dim3(256), 0, st, ha); }
+      CURIOUS_LAUNCH_CHECK("dx_hot_kernel(actor)");
+      continue;
+    }
     DxArgs da;
     memset(&da, 0, sizeof(da));
     da.nprob = 1;
     DxProb& p = da.p[0];
     p.dY = w.dact[2][l]; p.lddy = H; p.W = thPi + offPi.W[l]; p.ldw = H;
     p.H = w.act[2][l - 1]; p.ldh = H; p.dX = w.dact[2][l - 1]; p.lddx = H;
-    p.M = B; p.N = H; p.K = H; p.epi = 0; p.vec = (H % 4 == 0);
+    p.M = B; p.N = H; p.K = H; p.vec = aligned16(p.W) ? 1 : 0;
+    p.fast = p.vec && aligned16(p.dY) && H >= 4;
     dim3 grid((H + 63) / 64, (B + 15) / 16, 1);
-    hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da);
+    { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel(actor)");
   }
-  // ---- every weight/bias gradient of the hidden and input layers in one grouped launch
+  // ---- weight/bias gradients: the big hidden-layer problems on the lean kernel; layer-0 segments, output layers
+  //      and the loss finalisation on the compact small-problem kernel (generic grouped kernel as fallback)
+  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) * 2 <= 4;
   {
     DwArgs wa;
     memset(&wa, 0, sizeof(wa));
-    int np = 0, maxw = 0;
-    auto add = [&](const Seg& x, const float* dY, float* dW, float* db) {
+    DwHotArgs hw;
+    memset(&hw, 0, sizeof(hw));
+    DwSmallArgs sm;
+    memset(&sm, 0, sizeof(sm));
+    int np = 0, maxw = 0, nh = 0, tiles = 0, ns_ = 0, stiles = 0;
+    bool small_ok = dw_hot && !cfg->normalize_obs;
+    auto add = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
+      if (small_ok && ns_ < MAX_DW_SMALL && !x.sub && !x.mean && x.clip <= 0.0f && (N % 4 == 0 || N == 1) &&
+          (N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) {
+        DwSmall& p = sm.p[ns_++];
+        p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
+        stiles += ((x.w + 15) / 16) * ((N + 63) / 64);
+        p.tile_end = stiles;
+        return;
+      }
       DwProb& p = wa.p[np++];
-      p.x = x; p.dY = dY; p.lddy = H; p.dW = dW; p.db = db; p.M = B; p.N = H;
+      p.x = x; p.dY = dY; p.lddy = lddy; p.dW = dW; p.db = db; p.M = B; p.N = N;
+      p.yvec = (lddy % 4 == 0) && (N % 4 == 0) && aligned16(dY);
+      p.fast = p.yvec && N >= 4 && !x.sub;
       if (x.w > maxw) maxw = x.w;
     };
     for (int net = 0; net < 2; ++net) {
@@ -723,23 +1484,63 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
       float* g = critic ? gQ : gPi;
       const int chain = critic ? 1 : 2;
       float** dact = w.dact[critic ? 0 : 2];
-      for (int l = nl - 1; l >= 1; --l)
-        add(make_seg(w.act[chain][l - 1], H, H, nullptr), dact[l], g + off.W[l], g + off.b[l]);
+      // output layer: dWout = act_last^T . dOut, dbout = colsum(dOut)
+      add(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D, g + off.Wout,
+          g + off.bout);
+      for (int l = nl - 1; l >= 1; --l) {
+        if (dw_hot) {
+          GemmHot& p = hw.p[nh];
+          p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
+          p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
+          tiles += (H / 16) * (H / 64);
+          hw.tile_end[nh] = tiles;
+          ++nh;
+        } else {
+          add(make_seg(w.act[chain][l - 1], H, H, nullptr), dact[l], H, H, g + off.W[l], g + off.b[l]);
+        }
+      }
       Seg seg[MAX_SEG];
       int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
       int64_t r = 0;
       for (int s = 0; s < ns; ++s) {
         const bool goal_branch = cfg->modular && s == ns - 1;
         float* dW = goal_branch ? g + off.Wg : g + off.W0 + r * H;
-        add(seg[s], dact[0], dW, (s == 0) ? g + off.b0 : nullptr);
+        add(seg[s], dact[0], H, H, dW, (s == 0) ? g + off.b0 : nullptr);
         if (!goal_branch) r += seg[s].w;
       }
     }
-    CURIOUS_CHECK(np <= MAX_PROB * 2, "curious_ddpg_grads: too many gradient problems");
-    wa.nprob = np;
-    dim3 grid((H + 63) / 64, (maxw + 15) / 16, np);
-    hipLaunchKernelGGL(dw_kernel, grid, dim3(256), 0, st, wa);
-    CURIOUS_LAUNCH_CHECK("dw_kernel");
+    CURIOUS_CHECK(np <= MAX_DW, "curious_ddpg_grads: too many gradient problems");
+    if (nh > 0) {
+      hw.nprob = nh;
+      { ProfScope ps__(CK_DW, st); hipLaunchKernelGGL(dw_hot_kernel, dim3(tiles), dim3(256), 0, st, hw); }
+      CURIOUS_LAUNCH_CHECK("dw_hot_kernel");
+    }
+    LossFin fin;
+    fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
+    if (ns_ > 0 && np == 0) {
+      sm.nprob = ns_; sm.M = B; sm.fin = fin;
+      { ProfScope ps__(CK_DW_SMALL, st);
+        hipLaunchKernelGGL(dw_small_kernel, dim3(stiles + 1), dim3(256), 0, st, sm); }
+      CURIOUS_LAUNCH_CHECK("dw_small_kernel");
+    } else {
+      // generic path: move anything queued on the small list back to the generic list
+      for (int i = 0; i < ns_; ++i) {
+        DwProb& p = wa.p[np++];
+        Seg x = make_seg(sm.p[i].x, sm.p[i].ldx, sm.p[i].w, nullptr);
+        x.div = sm.p[i].div;
+        p.x = x; p.dY = sm.p[i].dY; p.lddy = sm.p[i].lddy; p.dW = sm.p[i].dW; p.db = sm.p[i].db; p.M = B;
+        p.N = sm.p[i].N;
+        p.yvec = (p.lddy % 4 == 0) && (p.N % 4 == 0) && aligned16(p.dY);
+        p.fast = p.yvec && p.N >= 4;
+        if (x.w > maxw) maxw = x.w;
+      }
+      CURIOUS_CHECK(np <= MAX_DW, "curious_ddpg_grads: too many gradient problems");
+      wa.nprob = np;
+      wa.fin = fin;
+      dim3 grid((H + 63) / 64, (maxw + 15) / 16, np + 1);
+      { ProfScope ps__(CK_DW_SMALL, st); hipLaunchKernelGGL(dw_kernel, grid, dim3(256), 0, st, wa); }
+      CURIOUS_LAUNCH_CHECK("dw_kernel");
+    }
   }
   return 0;
 }

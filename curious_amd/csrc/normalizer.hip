@@ -68,12 +68,12 @@ extern "C" int curious_norm_update(const float* rows, int32_t n_rows, int32_t st
   int cp = 1;
   while (cp < dim) cp <<= 1;
   int nb = (n_rows + NB_ROWS - 1) / NB_ROWS;
-  hipLaunchKernelGGL(norm_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), rows, n_rows, stride, col_off,
-                     dim, cp, scratch);
+  { ProfScope ps__(CK_NORM_PARTIAL, as_stream(stream)); hipLaunchKernelGGL(norm_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), rows, n_rows, stride, col_off,
+                     dim, cp, scratch); }
   CURIOUS_LAUNCH_CHECK("norm_partial_kernel");
   int n = 2 * dim + 1;
-  hipLaunchKernelGGL(norm_final_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), scratch, nb, dim,
-                     n_rows, acc);
+  { ProfScope ps__(CK_NORM_FINAL, as_stream(stream)); hipLaunchKernelGGL(norm_final_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), scratch, nb, dim,
+                     n_rows, acc); }
   CURIOUS_LAUNCH_CHECK("norm_final_kernel");
   return 0;
 }
@@ -120,8 +120,8 @@ extern "C" int curious_norm_recompute(float* acc, float* state, int32_t dim, flo
                                       curious_stream_t stream) {
   CURIOUS_CHECK(acc && state, "curious_norm_recompute: NULL argument");
   CURIOUS_CHECK(dim > 0 && dim <= 1024, "curious_norm_recompute: dim must be in 1..1024 (single block)");
-  hipLaunchKernelGGL(norm_recompute_kernel, dim3(1), dim3(((dim + 63) / 64) * 64), 0, as_stream(stream), acc, state,
-                     dim, world_size, eps);
+  { ProfScope ps__(CK_NORM_RECOMPUTE, as_stream(stream)); hipLaunchKernelGGL(norm_recompute_kernel, dim3(1), dim3(((dim + 63) / 64) * 64), 0, as_stream(stream), acc, state,
+                     dim, world_size, eps); }
   CURIOUS_LAUNCH_CHECK("norm_recompute_kernel");
   return 0;
 }

@@ -57,7 +57,7 @@ extern "C" int curious_adam_update(float* theta, float* m, float* v, const float
   if (a.n <= 0) return 0;
   int blocks = (int)((a.n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+  { ProfScope ps__(CK_ADAM, as_stream(stream)); hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a); }
   CURIOUS_LAUNCH_CHECK("adam_kernel");
   return 0;
 }
@@ -76,8 +76,8 @@ extern "C" int curious_polyak_update(float* target, const float* main_, int64_t 
   if (n <= 0) return 0;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(polyak_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), target, main_, n, polyak,
-                     one_minus_polyak);
+  { ProfScope ps__(CK_POLYAK, as_stream(stream)); hipLaunchKernelGGL(polyak_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), target, main_, n, polyak,
+                     one_minus_polyak); }
   CURIOUS_LAUNCH_CHECK("polyak_kernel");
   return 0;
 }
@@ -110,8 +110,8 @@ extern "C" int curious_param_checksum(const float* theta, int64_t n, uint64_t* o
   if (n <= 0) return 0;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
-                     reinterpret_cast<const uint32_t*>(theta), n, reinterpret_cast<unsigned long long*>(out));
+  { ProfScope ps__(CK_CHECKSUM, as_stream(stream)); hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint32_t*>(theta), n, reinterpret_cast<unsigned long long*>(out)); }
   CURIOUS_LAUNCH_CHECK("checksum_kernel");
   return 0;
 }

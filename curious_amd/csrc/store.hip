@@ -38,8 +38,8 @@ extern "C" int curious_store_episodes(float* storage, const float* staging, cons
   int bx = (int)((work + 255) / 256);
   if (bx > 16) bx = 16;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_pairs), dim3(256), 0, as_stream(stream), storage, staging,
-                     pair_src, pair_dst, rec, vec_ok);
+  { ProfScope ps__(CK_STORE, as_stream(stream)); hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_pairs), dim3(256), 0, as_stream(stream), storage, staging,
+                     pair_src, pair_dst, rec, vec_ok); }
   CURIOUS_LAUNCH_CHECK("store_episodes_kernel");
   return 0;
 }
@@ -62,8 +62,8 @@ extern "C" int curious_episode_activity(const float* staging, const curious_layo
   CURIOUS_CHECK(staging && L && tasks && active, "curious_episode_activity: NULL argument");
   if (n_episodes <= 0) return 0;
   int n = n_episodes * tasks->ntasks;
-  hipLaunchKernelGGL(episode_activity_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), staging, *L,
-                     *tasks, off_change, n_episodes, active);
+  { ProfScope ps__(CK_ACTIVITY, as_stream(stream)); hipLaunchKernelGGL(episode_activity_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), staging, *L,
+                     *tasks, off_change, n_episodes, active); }
   CURIOUS_LAUNCH_CHECK("episode_activity_kernel");
   return 0;
 }

@@ -199,3 +199,16 @@ def env_step(ecfg, layout, env_id0, episode, tasks, u, t, n, o, ag, g, td, stagi
                                  int(u.stride(0)), int(t), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
                                  int(layout.off['change']), int(layout.off['info_is_success']), float(reward_eps),
                                  current_stream()), 'curious_env_step')
+
+
+def prof_enable(on):
+    check(lib().curious_prof_enable(int(bool(on))), 'curious_prof_enable')
+
+
+def prof_collect():
+    """{kernel name: (launch count, total ms)} since the last collect (synchronises the device)."""
+    n = lib().curious_prof_kernel_count()
+    counts = (C.c_int64 * n)()
+    ms = (C.c_double * n)()
+    check(lib().curious_prof_collect(counts, ms), 'curious_prof_collect')
+    return {lib().curious_prof_kernel_name(k).decode(): (int(counts[k]), float(ms[k])) for k in range(n)}

@@ -104,6 +104,14 @@ int curious_abi_version(void);
 /* name of the device the library runs on + its CU count; fails when no gfx950 device is present */
 int curious_device_info(char* name_host, int name_len, int* cu_count_host);
 
+/* Per-kernel HIP-event timing for bench.py's roofline: while enabled, every kernel launch of this library is
+ * bracketed by two events recorded on its launch stream.  Not for use during hipGraph capture.
+ * curious_prof_collect synchronises and returns, per kernel id, the launch count and summed duration (ms). */
+int curious_prof_enable(int on);
+int curious_prof_kernel_count(void);
+const char* curious_prof_kernel_name(int kid);
+int curious_prof_collect(int64_t* counts_host, double* total_ms_host);
+
 /* HER sample + goal/task relabel + reward + clip, written already permuted.
  * Replaces replay_buffer.py:37-55, her.py:99-183 (or :20-66), ddpg.py:326-353.
  * storage: [nbuf_phys][capacity][T+1][row_stride]; buf_stride = floats between buffers.
