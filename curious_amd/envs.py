@@ -93,6 +93,10 @@ class BatchedSyntheticArm(ArmSpec):
         self.tasks = torch.zeros(n, dtype=torch.int32, device=dev)
         self.tasks_host = np.zeros(n, np.int32)
         self.goals_host = np.zeros([n, 3], np.float32)
+        # pinned staging for the per-rollout task / goal upload: the copy is enqueued without blocking the host,
+        # so the next rollout can be queued behind the previous cycle's updates
+        self._pin = torch.empty(n * 4, dtype=torch.float32).pin_memory()
+        self._goals_dev = torch.zeros([n, 3], device=dev)
         self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
 
     @property
@@ -108,10 +112,14 @@ class BatchedSyntheticArm(ArmSpec):
         """tasks[n] int, goals_raw[n,3] in [-1,1] (rollout.py:120-143 for every env at once)."""
         self.tasks_host[:] = tasks
         self.goals_host[:] = goals_raw
-        self.tasks.copy_(torch.from_numpy(self.tasks_host))
-        goals = torch.from_numpy(self.goals_host).to(self.device)
-        ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, goals, self.n, self.o, self.ag,
-                      self.g, self.td, self.staging)
+        n = self.n
+        # the previous use of the pinned block has completed: every rollout ends with a device->host sync
+        self._pin[:n].view(torch.int32).copy_(torch.from_numpy(self.tasks_host))
+        self._pin[n:].view(n, 3).copy_(torch.from_numpy(self.goals_host))
+        self.tasks.copy_(self._pin[:n].view(torch.int32), non_blocking=True)
+        self._goals_dev.copy_(self._pin[n:].view(n, 3), non_blocking=True)
+        ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
+                      self.o, self.ag, self.g, self.td, self.staging)
         self.episode += 1
 
     def step_all(self, u, t):
