@@ -150,35 +150,58 @@ def kernel_flops_bytes(policy, lay):
 
 
 def profile_pass(policy, worker, n_cycles=1):
-    """Eager (non-graph) replay of the same cycle with every kernel launch bracketed by HIP events on its stream."""
+    """Per-kernel launch durations from HIP events recorded on the launch stream.
+
+    Events cannot sit inside a replayed hipGraph, so the same cycle is replayed with eager launches, every kernel
+    launch bracketed by an event pair (curious_prof_*).  A bracket costs a fixed amount of stream time itself; it is
+    calibrated in the same run as  c = (sum of the bracketed durations of a 100-update block - one event pair around
+    the identical block without brackets) / number of launches  and subtracted, so that the per-kernel averages add
+    up to the real duration of the sequence (the quantity rocprofv3 --kernel-trace reports)."""
     from curious_amd import ops
     import torch
     saved = policy.use_graph
     policy.use_graph = False
+
+    def updates():
+        for _ in range(N_BATCHES):
+            policy.train()
+    updates()                                                     # warm the eager path
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    updates()
+    e1.record()
+    torch.cuda.synchronize()
+    t_plain = e0.elapsed_time(e1)                                 # ms, no brackets
     ops.prof_collect()
+    ops.prof_enable(True)
+    updates()
+    ops.prof_enable(False)
+    st = ops.prof_collect()
+    n_launch = sum(v[0] for v in st.values())
+    overhead_ms = max(0.0, (sum(v[1] for v in st.values()) - t_plain) / max(1, n_launch))
     ops.prof_enable(True)
     for _ in range(n_cycles):
         cycle(policy, worker)
     ops.prof_enable(False)
     stats = ops.prof_collect()
     policy.use_graph = saved
-    return stats
+    return stats, overhead_ms, t_plain / N_BATCHES
 
 
-def roofline(policy, worker, stats, n_cycles):
+def roofline(policy, worker, stats, n_cycles, overhead_ms):
     work = kernel_flops_bytes(policy, policy._layout)
-    total = {k: v[1] for k, v in stats.items() if v[0] > 0}
-    if not total:
+    cal = {k: (v[0], max(v[1] - v[0] * overhead_ms, 0.0)) for k, v in stats.items() if v[0] > 0}
+    if not cal:
         return None, {}
-    dominant = max(total, key=total.get)
-    table = {k: dict(launches=v[0], total_ms=round(v[1], 4), avg_us=round(1e3 * v[1] / v[0], 3))
-             for k, v in stats.items() if v[0] > 0}
+    dominant = max(cal, key=lambda k: cal[k][1])
+    table = {k: dict(launches=v[0], total_ms=round(v[1], 4), avg_us=round(1e3 * v[1] / v[0], 3),
+                     avg_us_bracketed=round(1e3 * stats[k][1] / v[0], 3)) for k, v in cal.items()}
     w = work.get(dominant)
     if w is None:
         return dict(kernel=dominant, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
                     traffic=None), table
-    launches, ms = stats[dominant]
+    launches, ms = cal[dominant]
     units = n_cycles * N_BATCHES * w['per_update']
     if 'per_env_step' in w:
         units += n_cycles * worker.T * w['per_env_step']
@@ -190,7 +213,7 @@ def roofline(policy, worker, stats, n_cycles):
         ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
     return dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
                 frac=round(ach / peak, 5), traffic=None, algorithmic_per_launch=round(per_launch, 1),
-                avg_launch_us=round(avg_s * 1e6, 3)), table
+                avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3)), table
 
 
 def cpu_baseline(seed=0, budget_s=20.0):
@@ -320,8 +343,8 @@ def main():
 
     # per-kernel HIP-event timing of the same cycle (eager launches; events cannot sit inside a replayed hipGraph)
     prof_cycles = 1
-    stats = profile_pass(policy, worker, prof_cycles)
-    roof, table = roofline(policy, worker, stats, prof_cycles)
+    stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles)
+    roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms)
 
     out = None
     if rank == 0:

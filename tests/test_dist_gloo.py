@@ -1,0 +1,203 @@
+"""The N > 1 path on CPU: world_size-2 gloo process groups exercising curious_amd.dist and every piece of host
+logic that sits on top of a collective (SURVEY 2.3 C1-C13 replacements).  GPU kernels are not involved; where a
+computing agent is needed the oracle (NumPy) plays that role, with its all-reduce hooks wired to curious_amd.dist."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn_name, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from curious_amd import dist
+    dist.init_from_env(backend='gloo')
+    try:
+        out[rank] = globals()[fn_name](rank, world)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def run2(fn_name):
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, fn_name, out), nprocs=2, join=True)
+    return dict(out)
+
+
+# ------------------------------------------------------------------ collectives
+def _collectives(rank, world):
+    from curious_amd import dist
+    from curious_amd.util import mpi_average
+    assert dist.is_distributed() and dist.world_size() == 2 and dist.rank() == rank
+    g = torch.full([1000], float(rank + 1))
+    dist.allreduce_sum_(g)                                            # C1/C2: SUM, not mean
+    theta = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    dist.broadcast_(theta, 0)                                         # C3
+    rec = np.array([[rank, 1.0, 1.0], [rank, 0.0, 1.0]])
+    allrec = dist.allgather_numpy(rec)                                # C9
+    avg = mpi_average([float(rank), float(rank) + 2.0])              # C11
+    obj = dist.broadcast_object({'i_policy': 7 + rank}, 0)            # C12
+    return dict(g=g.numpy().copy(), theta=theta.numpy().copy(), allrec=allrec, avg=avg, obj=obj)
+
+
+def test_collectives_world2():
+    out = run2('_collectives')
+    for r in (0, 1):
+        np.testing.assert_array_equal(out[r]['g'], np.full(1000, 3.0, np.float32))
+        np.testing.assert_array_equal(out[r]['theta'], np.arange(10, dtype=np.float32))
+        np.testing.assert_array_equal(out[r]['allrec'], np.array([[0, 1, 1], [0, 0, 1], [1, 1, 1], [1, 0, 1]], float))
+        assert out[r]['avg'] == (0 + 2 + 1 + 3) / 4.0
+        assert out[r]['obj'] == {'i_policy': 7}
+
+
+# ------------------------------------------------------------------ data-parallel DDPG arithmetic
+def _make_agent(rank, world, allreduce):
+    from oracle import her as oher
+    from oracle.ddpg import OracleDDPG
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    from oracle.reward import make_reward_fun
+    from test_gpu_agent import synth_episodes, tables, T
+    nb, dimo = 4, 40
+    ids, _ = tables(nb)
+    G = 12
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    rng = np.random.RandomState(1000 + rank)                          # rank-local data and sampler stream
+    sampler = oher.make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer', make_reward_fun(ids, ids),
+                                                          tasks_ag_id=ids, tasks_g_id=ids, rng=rng)
+    bufs = [OBuf(shapes, T * 32, T, sampler, rng=rng) for _ in range(nb + 1)]
+    agent = OracleDDPG(dims, T, bufs, sampler, ids, ids, hidden=32, batch_size=64, rng=rng,
+                       weight_rng=np.random.RandomState(5), allreduce_sum=allreduce, comm_size=world)
+    agent.store_episode({k: v.astype(np.float64) for k, v in synth_episodes(rng, 8, nb, dimo).items()},
+                        np.zeros(nb), 8)
+    return agent
+
+
+def _dp_train(rank, world):
+    """Two ranks, private buffers, gradients SUMMED by curious_amd.dist (ddpg.py:452, mpi_adam.py:26) and normaliser
+    sums AVERAGED (normalizer.py:84-94)."""
+    from curious_amd import dist
+
+    def allreduce(x):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        dist.allreduce_sum_(t)
+        return t.numpy()
+    agent = _make_agent(rank, world, allreduce)
+    losses = [float(agent.train()[0]) for _ in range(3)]
+    return dict(theta=agent.theta.copy(), o_mean=agent.o_stats.mean.copy(), o_count=agent.o_stats.count.copy(),
+                losses=losses)
+
+
+def test_data_parallel_sum_of_gradients_and_mean_of_stats():
+    out = run2('_dp_train')
+    # replicas stay bit-identical (what check_synced asserts, mpi_adam.py:42-50)
+    np.testing.assert_array_equal(out[0]['theta'], out[1]['theta'])
+    np.testing.assert_array_equal(out[0]['o_mean'], out[1]['o_mean'])
+    # single-process emulation of the same two ranks
+    agents, pending = [], {}
+
+    class Bus:
+        """Lock-step all-reduce between the two in-process agents."""
+        def __init__(self):
+            self.slots = []
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    a0 = _make_agent(0, 2, None)
+    a1 = _make_agent(1, 2, None)
+    # normaliser: recompute with the mean of both ranks' local sums -> redo store-time stats jointly
+    # (the agents above already consumed their local stats with comm_size=2 and no all-reduce, i.e. sum/2 of their
+    #  own data; rebuild the expected value from the two agents' recorded per-rank sums)
+    import copy
+    for k in range(3):
+        b0, b1 = a0.sample_batch(), a1.sample_batch()
+        g0, g1 = a0.grads(b0), a1.grads(b1)
+        Qg = g0['Q_grad'] + g1['Q_grad']
+        pig = g0['pi_grad'] + g1['pi_grad']
+        from oracle.optim import adam_update
+        for a in (a0, a1):
+            PQ = a.math.P_Q
+            th, m, v, a.t_Q = adam_update(a.theta[:PQ], a.m[:PQ], a.v[:PQ], a.t_Q, Qg, a.Q_lr)
+            a.theta[:PQ], a.m[:PQ], a.v[:PQ] = th, m, v
+            th, m, v, a.t_pi = adam_update(a.theta[PQ:], a.m[PQ:], a.v[PQ:], a.t_pi, pig, a.pi_lr)
+            a.theta[PQ:], a.m[PQ:], a.v[PQ:] = th, m, v
+        assert abs(float(g0['Q_loss']) - out[0]['losses'][k]) < 1e-6 * max(1.0, abs(out[0]['losses'][k]))
+        assert abs(float(g1['Q_loss']) - out[1]['losses'][k]) < 1e-6 * max(1.0, abs(out[1]['losses'][k]))
+    np.testing.assert_allclose(a0.theta, out[0]['theta'], rtol=0, atol=1e-6)
+    # count after one store on both ranks: 1 + mean(400, 400) = 401
+    assert float(out[0]['o_count'][0]) == 1.0 + 8 * 50
+
+
+# ------------------------------------------------------------------ competence queues / task probabilities
+def _rollout_ranks(rank, world):
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    from oracle.env import SyntheticMultiTaskArm
+    from test_host_logic import FakePolicy
+    from conftest import load_golden
+    G = load_golden('rollout')
+    nb, dimo, T, B = [int(x) for x in G['cfg']]
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    counter = [0]
+
+    def make_env():
+        e = SyntheticMultiTaskArm(nb, dimo, T, seed=rank, env_id=rank * 100 + counter[0])
+        counter[0] += 1
+        return e
+    np.random.seed(7 + 1000000 * rank)                               # train.py:242
+    w = RolloutWorker(make_env, FakePolicy(G['A']), dims, logger, T=T, rollout_batch_size=B, noise_eps=0.2,
+                      random_eps=0.3, structure='curious', task_selection='active_competence_progress',
+                      queue_length=4, eval=False)
+    hist = []
+    for c in range(40):
+        ep, CP, n_ep = w.generate_rollouts()
+        hist.append((bool(w.exploit), np.asarray(w.p).copy(), np.asarray(CP).copy(), np.asarray(w.C).copy(), n_ep,
+                     [q.size for q in w.competence_computers]))
+    return hist
+
+
+def test_competence_allgather_makes_ranks_agree():
+    out = run2('_rollout_ranks')
+    h0, h1 = out[0], out[1]
+    saw_asym = False
+    for (e0, p0, cp0, c0, n0, s0), (e1, p1, cp1, c1, n1, s1) in zip(h0, h1):
+        # exploit flags are rank-local draws (rollout.py:184) yet queues, C, CP agree on every rank (C9 -> C10)
+        np.testing.assert_array_equal(cp0, cp1)
+        np.testing.assert_array_equal(c0, c1)
+        assert s0 == s1 and n0 == n1
+        if not e0 and not e1:
+            np.testing.assert_array_equal(p0, p1)
+        saw_asym |= (e0 != e1)
+    assert h0[-1][4] == 40 * 3 * 2                                    # n_episodes counts both ranks (rollout.py:313)
+    assert saw_asym
+    assert any(cp.sum() > 0 for _, _, cp, _, _, _ in h0)
+
+
+def _distinct_seed_check(rank, world):
+    """train.py:207-212: ranks must hold different NumPy streams."""
+    from curious_amd import dist
+    np.random.seed(5 + 1000000 * rank)
+    local = float(np.random.uniform())
+    root = dist.broadcast_object(local, 0)
+    return (local, root)
+
+
+def test_rank_seeds_differ():
+    out = run2('_distinct_seed_check')
+    assert out[1][0] != out[1][1] and out[0][0] == out[0][1]
