@@ -302,7 +302,7 @@ def main():
     dist.init_from_env()
     rank, world = dist.rank(), dist.world_size()
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dist.local_device_index())
     np.random.seed(1234 + 1000000 * rank)                        # train.py:242
     params, dims, policy, worker = build_job(use_graph=not args.no_graph)
     prefill(policy, args.prefill, seed=rank)

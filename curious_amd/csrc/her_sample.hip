@@ -16,15 +16,6 @@
 #define STREAM_SAMPLE_A 11u
 #define STREAM_SAMPLE_B 12u
 
-struct SampleMeta {
-  int64_t row;        // float offset of record row t in storage
-  int64_t fut;        // float offset of record row future_t
-  int32_t her;        // 1 = HER-relabelled
-  int32_t rtask;      // task to replay (<0: keep own / none)
-  int32_t out_row;
-  int32_t valid;
-};
-
 struct HerArgs {
   const float* storage;
   int64_t buf_stride;
@@ -37,56 +28,17 @@ struct HerArgs {
   int32_t n;
   float* batch;
   curious_batch_layout_t BL;
-  int32_t capacity_rows;   // unused (kept for debugging bounds)
 };
 
-__device__ inline void make_meta(const HerArgs& a, int gi, SampleMeta& m) {
-  const curious_layout_t& L = a.L;
-  int buf, ep, t, ttr, out_row;
-  double u_her, u_off;
-  if (!a.use_rng) {
-    buf = a.plan.buf ? a.plan.buf[gi] : 0;
-    ep = a.plan.ep[gi];
-    t = a.plan.t[gi];
-    u_her = a.plan.u_her[gi];
-    u_off = a.plan.u_off[gi];
-    ttr = a.plan.task_to_replay ? a.plan.task_to_replay[gi] : -1;
-    out_row = a.plan.out_row ? a.plan.out_row[gi] : gi;
-  } else {
-    const curious_sample_rng_t& R = a.rng;
-    int64_t step = R.step_ctr ? *R.step_ctr : R.step_host;
-    int lb = 0;
-    for (int b = 0; b < R.nbuf; ++b)
-      if (gi >= R.prop_prefix[b + 1]) lb = b + 1;
-    if (lb >= R.nbuf) lb = R.nbuf - 1;
-    buf = R.buf_alias ? R.buf_alias[lb] : lb;
-    ttr = R.buf_task ? R.buf_task[lb] : -1;
-    uint32_t E = (uint32_t)R.cur_size[buf];
-    Philox4 r1 = philox4x32((uint32_t)gi, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_A,
-                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
-    Philox4 r2 = philox4x32((uint32_t)gi, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_B,
-                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
-    ep = (int)(((uint64_t)r1.x * E) >> 32);
-    t = (int)(((uint64_t)r1.y * (uint32_t)L.T) >> 32);
-    u_her = u01_f64(r1.z, r1.w);
-    u_off = u01_f64(r2.x, r2.y);
-    out_row = gi;
-  }
-  // her.py:115-118 in float64 / truncation toward zero
-  int her = u_her < a.P.future_p;
-  int off = (int)(u_off * (double)(L.T - t));
-  int future_t = t + 1 + off;
-  int64_t ep_base = (int64_t)buf * a.buf_stride + (int64_t)ep * (L.T + 1) * L.row_stride;
-  m.row = ep_base + (int64_t)t * L.row_stride;
-  m.fut = ep_base + (int64_t)future_t * L.row_stride;
-  m.her = her;
-  m.rtask = ttr;
-  m.out_row = out_row;
-  m.valid = 1;
-}
+#define TAB_INTS (CURIOUS_MAX_TASKS * (1 + 2 * CURIOUS_MAX_TASK_DIMS))   // len | g_id | ag_id, contiguous in the struct
 
+// Dependent global round trips are what this kernel costs (its data volume is ~1 KB per transition), so it is
+// organised as exactly two: (1) everything needed to decide WHERE to read -- the task tables (into LDS), the
+// sampling tables / host plan and the step counter, all issued together; (2) the three row segments of the
+// transition.  Relabelling, reward and clipping then run out of LDS / registers.
 __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs a) {
   extern __shared__ float lds[];
+  __shared__ int32_t s_tab[TAB_INTS];
   const curious_layout_t& L = a.L;
   const curious_batch_layout_t& BL = a.BL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -98,89 +50,123 @@ __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs a) {
   float* s_fut = s_next + head;                         // future ag
   float* s_g = s_fut + L.dimag;                         // relabelled goal
   float* s_td = s_g + L.dimg;                           // relabelled task descriptor
-  float* s_r = s_td + L.dimtd;                          // reward
-  __shared__ SampleMeta meta[SPB];
+  const int32_t* s_len = s_tab;
+  const int32_t* s_gid = s_tab + CURIOUS_MAX_TASKS;
+  const int32_t* s_agid = s_gid + CURIOUS_MAX_TASKS * CURIOUS_MAX_TASK_DIMS;
 
-  const int gi = blockIdx.x * SPB + wave;
-  if (lane == 0) {
-    if (gi < a.n) make_meta(a, gi, meta[wave]);
-    else meta[wave].valid = 0;
+  // ---- round trip 1
+  {
+    const int32_t* src = a.tasks.len;                   // len, g_id, ag_id are contiguous after ntasks
+    for (int i = threadIdx.x; i < TAB_INTS; i += 256) s_tab[i] = src[i];
   }
-  __syncthreads();
-  const SampleMeta m = meta[wave];
-  if (m.valid) {
-    const float* src = a.storage + m.row;
-    for (int i = lane; i < L.row_stride; i += 64) s_row[i] = src[i];
-    const float* nxt = src + L.row_stride;              // row t+1 (replay_buffer.py:47-48)
-    for (int i = lane; i < head; i += 64) s_next[i] = nxt[i];
-    const float* fut = a.storage + m.fut + L.off_ag;
+  const int gi = blockIdx.x * SPB + wave;
+  const bool valid = gi < a.n;
+  const int gic = valid ? gi : a.n - 1;
+  int buf, ep, t, ttr, out_row;
+  double u_her, u_off;
+  if (!a.use_rng) {
+    buf = a.plan.buf ? a.plan.buf[gic] : 0;
+    ep = a.plan.ep[gic];
+    t = a.plan.t[gic];
+    u_her = a.plan.u_her[gic];
+    u_off = a.plan.u_off[gic];
+    ttr = a.plan.task_to_replay ? a.plan.task_to_replay[gic] : -1;
+    out_row = a.plan.out_row ? a.plan.out_row[gic] : gic;
+  } else {
+    const curious_sample_rng_t& R = a.rng;
+    // lane b looks at logical buffer b: all table entries are fetched in one batch
+    const int b = min(lane, R.nbuf - 1);
+    const int pe = R.prop_prefix[b + 1];
+    const int al = R.buf_alias ? R.buf_alias[b] : b;
+    const int tk = R.buf_task ? R.buf_task[b] : -1;
+    const int cs = R.cur_size[b];
+    const int64_t step = R.step_ctr ? *R.step_ctr : R.step_host;
+    const unsigned long long beyond = __ballot(lane < R.nbuf && gic >= pe);
+    int lb = __popcll(beyond);
+    if (lb >= R.nbuf) lb = R.nbuf - 1;
+    buf = __shfl(al, lb);
+    ttr = __shfl(tk, lb);
+    const uint32_t E = (uint32_t)__shfl(cs, lb);
+    Philox4 r1 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_A,
+                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
+    Philox4 r2 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_B,
+                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
+    ep = (int)(((uint64_t)r1.x * E) >> 32);
+    t = (int)(((uint64_t)r1.y * (uint32_t)L.T) >> 32);
+    u_her = u01_f64(r1.z, r1.w);
+    u_off = u01_f64(r2.x, r2.y);
+    out_row = gic;
+  }
+  // her.py:115-118 in float64 / truncation toward zero
+  const bool her = u_her < a.P.future_p;
+  const int off = (int)(u_off * (double)(L.T - t));
+  const int future_t = t + 1 + off;
+  const int64_t ep_base = (int64_t)buf * a.buf_stride + (int64_t)ep * (L.T + 1) * L.row_stride;
+
+  // ---- round trip 2: row t, the (o, ag) head of row t+1 (replay_buffer.py:47-48) and the future achieved goal
+  {
+    const float* src = a.storage + ep_base + (int64_t)t * L.row_stride;
+    const float* fut = a.storage + ep_base + (int64_t)future_t * L.row_stride + L.off_ag;
+    const int n1 = L.row_stride + head;                 // rows t and t+1 are adjacent: one contiguous span
+    for (int i = lane; i < n1; i += 64) s_row[i] = src[i];
     for (int i = lane; i < L.dimag; i += 64) s_fut[i] = fut[i];
   }
   __syncthreads();
-  if (m.valid) {
-    const curious_tasks_t& T = a.tasks;
-    const int mode = a.P.relabel_mode;
-    // current task of the sampled transition = position of the 1 in task_descr (her.py:133,159)
-    int cur = 0;
-    for (int j = 1; j < L.dimtd; ++j)
-      if (s_row[L.off_td + j] > s_row[L.off_td + cur]) cur = j;
-    int rt = cur;
-    if (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK)
-      rt = (m.rtask >= 0) ? m.rtask : cur;
-    const bool relabel = m.her != 0;
-    for (int i = lane; i < L.dimg; i += 64) {
-      float v = s_row[L.off_g + i];
-      if (relabel) {
-        if (mode == CURIOUS_RELABEL_FLAT) {
-          int p = 0;
-          for (int t = 0; t < T.ntasks; ++t)
-            for (int k = 0; k < T.len[t]; ++k, ++p)
-              if (p == i) v = s_fut[T.ag_id[t][k]];      // her.py:43-47
-        } else {
-          if (mode != CURIOUS_RELABEL_CURRENT_TASK) v = 0.0f;   // her.py:151
-          for (int k = 0; k < T.len[rt]; ++k)
-            if (T.g_id[rt][k] == i) v = s_fut[T.ag_id[rt][k]];  // her.py:154 / :164
-        }
+
+  const int mode = a.P.relabel_mode;
+  // current task of the sampled transition = position of the 1 in task_descr (her.py:133,159)
+  int cur = 0;
+  for (int jj = 1; jj < L.dimtd; ++jj)
+    if (s_row[L.off_td + jj] > s_row[L.off_td + cur]) cur = jj;
+  int rt = cur;
+  if (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK) rt = (ttr >= 0) ? ttr : cur;
+  const int ntasks = a.tasks.ntasks;
+  for (int i = lane; i < L.dimg; i += 64) {
+    float v = s_row[L.off_g + i];
+    if (her) {
+      if (mode == CURIOUS_RELABEL_FLAT) {
+        int p = 0;
+        for (int tt = 0; tt < ntasks; ++tt)
+          for (int k = 0; k < s_len[tt]; ++k, ++p)
+            if (p == i) v = s_fut[s_agid[tt * CURIOUS_MAX_TASK_DIMS + k]];          // her.py:43-47
+      } else {
+        if (mode != CURIOUS_RELABEL_CURRENT_TASK) v = 0.0f;                          // her.py:151
+        for (int k = 0; k < s_len[rt]; ++k)
+          if (s_gid[rt * CURIOUS_MAX_TASK_DIMS + k] == i) v = s_fut[s_agid[rt * CURIOUS_MAX_TASK_DIMS + k]];   // her.py:154 / :164
       }
-      s_g[i] = v;
     }
-    for (int i = lane; i < L.dimtd; i += 64) {
-      float v = s_row[L.off_td + i];
-      if (relabel && (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK))
-        v = (i == rt) ? 1.0f : 0.0f;                     // her.py:152,155
-      s_td[i] = v;
-    }
+    s_g[i] = v;
   }
+  // task descriptor after relabelling (her.py:152,155); its argmax is the reward's task
+  const bool retask = her && (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK);
+  for (int i = lane; i < L.dimtd; i += 64) s_td[i] = retask ? ((i == rt) ? 1.0f : 0.0f) : s_row[L.off_td + i];
+  const int rtask = retask ? rt : cur;                  // first maximum of the (one-hot) descriptor
   __syncthreads();
-  if (m.valid && lane == 0) {
-    // reward (oracle/reward.py): float64, sequential, no FMA, correctly rounded sqrt
-    const curious_tasks_t& T = a.tasks;
-    const float* ag2 = s_next + L.dimo;
-    double d2 = 0.0;
-    if (a.P.flat_reward) {
-      for (int t = 0; t < T.ntasks; ++t)
-        for (int k = 0; k < T.len[t]; ++k) {
-          double d = __dsub_rn((double)ag2[T.ag_id[t][k]], (double)s_g[T.g_id[t][k]]);
-          d2 = __dadd_rn(d2, __dmul_rn(d, d));
-        }
-    } else {
-      int task = 0;
-      for (int j = 1; j < L.dimtd; ++j)
-        if (s_td[j] > s_td[task]) task = j;              // np.argmax: first maximum
-      for (int k = 0; k < T.len[task]; ++k) {
-        double d = __dsub_rn((double)ag2[T.ag_id[task][k]], (double)s_g[T.g_id[task][k]]);
+
+  // reward (oracle/reward.py): float64, sequential, no FMA, correctly rounded sqrt; computed redundantly by all lanes
+  const float* ag2 = s_next + L.dimo;
+  double d2 = 0.0;
+  if (a.P.flat_reward) {
+    for (int tt = 0; tt < ntasks; ++tt)
+      for (int k = 0; k < s_len[tt]; ++k) {
+        double d = __dsub_rn((double)ag2[s_agid[tt * CURIOUS_MAX_TASK_DIMS + k]],
+                             (double)s_g[s_gid[tt * CURIOUS_MAX_TASK_DIMS + k]]);
         d2 = __dadd_rn(d2, __dmul_rn(d, d));
       }
+  } else {
+    for (int k = 0; k < s_len[rtask]; ++k) {
+      double d = __dsub_rn((double)ag2[s_agid[rtask * CURIOUS_MAX_TASK_DIMS + k]],
+                           (double)s_g[s_gid[rtask * CURIOUS_MAX_TASK_DIMS + k]]);
+      d2 = __dadd_rn(d2, __dmul_rn(d, d));
     }
-    s_r[0] = (sqrt(d2) > a.P.reward_eps) ? -1.0f : 0.0f;
   }
-  __syncthreads();
-  if (m.valid) {
-    float* out = a.batch + (int64_t)m.out_row * BL.stride;
+  const float reward = (sqrt(d2) > a.P.reward_eps) ? -1.0f : 0.0f;
+
+  if (valid) {
+    float* out = a.batch + (int64_t)out_row * BL.stride;
     const float c = a.P.clip_obs;
     const bool rel = a.P.relative_goals != 0;
     const float* ag = s_row + L.off_ag;
-    const float* ag2 = s_next + L.dimo;
     for (int i = lane; i < L.dimo; i += 64) {
       out[BL.off_o + i] = fclip(s_row[L.off_o + i], -c, c);      // ddpg.py:125
       out[BL.off_o2 + i] = fclip(s_next[i], -c, c);
@@ -199,7 +185,7 @@ __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs a) {
       out[BL.off_ag2 + i] = ag2[i];
     }
     for (int i = lane; i < L.dimextra; i += 64) out[BL.off_extra + i] = s_row[L.off_extra + i];
-    if (lane == 0) out[BL.off_r] = s_r[0];
+    if (lane == 0) out[BL.off_r] = reward;
   }
 }
 
@@ -212,6 +198,7 @@ extern "C" int curious_her_sample(const float* storage, int64_t buf_stride, cons
   CURIOUS_CHECK(n >= 0, "curious_her_sample: negative n");
   CURIOUS_CHECK(L->off_o == 0 && L->off_ag == L->dimo, "curious_her_sample: record rows must start with [o | ag]");
   CURIOUS_CHECK(tasks->ntasks <= CURIOUS_MAX_TASKS, "curious_her_sample: too many tasks");
+  CURIOUS_CHECK(!rng || rng->nbuf <= 64, "curious_her_sample: at most 64 logical buffers");
   CURIOUS_CHECK(!P->relative_goals || L->dimg == L->dimag, "relative_goals needs dimg == dimag (config.py:177-179)");
   if (n == 0) return 0;
   HerArgs a;

@@ -370,9 +370,7 @@ class DDPG(object):
         assert self.proportions.sum() == self.batch_size             # ddpg.py:323
         prefix = np.concatenate([[0], np.cumsum(self.proportions)]).astype(np.int32)
         alias = np.array([self.buffer[i].pool_index for i in range(nb1)], np.int32)
-        cur = np.zeros(self._pool.n_buffers, np.int32)
-        for i in range(nb1):
-            cur[self.buffer[i].pool_index] = self.buffer[i].current_size
+        cur = np.array([self.buffer[i].current_size for i in range(nb1)], np.int32)    # per LOGICAL buffer
         for i in range(nb1):
             assert self.proportions[i] == 0 or self.buffer[i].current_size > 0   # replay_buffer.py:43
         task = np.array([-1 if self._task_of_buffer(i) is None else self._task_of_buffer(i) for i in range(nb1)],

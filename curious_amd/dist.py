@@ -30,11 +30,19 @@ def init_from_env(backend=None):
     if ws <= 1 or (td.is_available() and td.is_initialized()):
         return
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        # CURIOUS_DIST_BACKEND=gloo lets several ranks share one GPU (functional testing of the N > 1 path on a
+        # single-GPU box; RCCL refuses two ranks on one device)
+        backend = os.environ.get('CURIOUS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     td.init_process_group(backend=backend)
+
+
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, folded onto the visible devices."""
+    n = max(1, torch.cuda.device_count())
+    return int(os.environ.get('LOCAL_RANK', '0')) % n
 
 
 def allreduce_sum_(t):

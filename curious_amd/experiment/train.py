@@ -153,7 +153,7 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     dist.init_from_env()
     rank = dist.rank()
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(dist.local_device_index())
     if rank == 0:
         save_dir = find_save_path(save_root + env + "/", trial_id)
         logger.configure(dir=save_dir)

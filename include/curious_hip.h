@@ -93,7 +93,7 @@ typedef struct curious_sample_rng {
   const int64_t* step_ctr;        /* device counter, advanced by curious_ddpg_grads */
   int64_t step_host;              /* used when step_ctr == NULL */
   const int32_t* prop_prefix;     /* [nbuf+1] exclusive prefix of DDPG.proportions (ddpg.py:282-286) */
-  const int32_t* cur_size;        /* [nbuf] episodes stored per buffer (replay_buffer.py:27) */
+  const int32_t* cur_size;        /* [nbuf] episodes stored in each LOGICAL buffer (replay_buffer.py:27) */
   const int32_t* buf_alias;       /* [nbuf] physical buffer of each logical buffer (ddpg.py:106-110) */
   const int32_t* buf_task;        /* [nbuf] task_to_replay of each logical buffer, <0 = None */
   int32_t nbuf;
