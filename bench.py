@@ -138,7 +138,7 @@ def kernel_flops_bytes(policy, lay):
         fwd_hot_kernel=dict(bound='mfma', per_update=5 * hid * 2 * B * H * H, launches_update=2 * hid,
                             per_env_step=hid * 2 * B_R * H * H, launches_env_step=hid),
         # layer 0 (K = 56..60)
-        fwd_layer_kernel=dict(bound='mfma', per_update=2 * B * H * (3 * Kc + 2 * Ka), launches_update=2,
+        fwd_l0_kernel=dict(bound='mfma', per_update=2 * B * H * (3 * Kc + 2 * Ka), launches_update=2,
                               per_env_step=2 * B_R * H * Ka, launches_env_step=1),
         dx_hot_kernel=dict(bound='mfma', per_update=3 * hid * 2 * B * H * H, launches_update=2 * hid),
         dw_hot_kernel=dict(bound='mfma', per_update=2 * hid * 2 * B * H * H, launches_update=1),

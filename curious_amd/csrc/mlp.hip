@@ -656,7 +656,8 @@ __global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
   for (int i = 0; i + 1 < args.nprob; ++i)
     if ((int)blockIdx.x >= args.p[i].tile_end) { pi = i + 1; t = blockIdx.x - args.p[i].tile_end; }
   if ((int)blockIdx.x >= args.p[args.nprob - 1].tile_end) {
-    // last block: losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
+    // extra last block (only launched when fin.rows != NULL): losses (ddpg.py:439-441) from the per-row terms,
+    // summed in a fixed order
     const LossFin& F = args.fin;
     float lq = 0.f, lp = 0.f, ll = 0.f;
     for (int m = tid; m < F.B; m += 256) {
@@ -751,6 +752,70 @@ __global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
     __syncthreads();
     if (tid < 64 && n0 + tid < P.N) P.db[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
   }
+}
+
+
+// ------------------------------------------------------------------ lean layer-0 forward (total K <= 64)
+// Y[M,N] = relu(sum_seg (clip(X_seg) / div) . W_seg + bias): the input is a virtual concatenation of up to 4 column
+// segments of row matrices (batch columns [o | td | u], the actor output, g ...), each a multiple of 4 wide.  With
+// K <= 64 every wave owns exactly one 16-wide chunk: 1 + 4 loads and 16 MFMAs per wave.
+struct SegL { const float* x; const float* W; int32_t ld, w; float div, clip; };
+struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy; };
+struct L0Args { L0Prob p[3]; };
+
+__global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const L0Prob& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  // locate this lane's 4 virtual columns kv .. kv+3 (16-byte group never straddles a segment: widths % 4 == 0)
+  int kv = 16 * wave + 4 * q;
+  const float* xp = P.seg[0].x;
+  const float* wp = P.seg[0].W;
+  int ld = P.seg[0].ld;
+  float dv = 1.0f, cl = 0.0f;
+  bool ok = false;
+#pragma unroll
+  for (int s = 0; s < MAX_SEG; ++s) {
+    if (s < P.nseg && !ok) {
+      if (kv < P.seg[s].w) {
+        ok = true;
+        xp = P.seg[s].x + kv; wp = P.seg[s].W + (int64_t)kv * P.N; ld = P.seg[s].ld;
+        dv = P.seg[s].div; cl = P.seg[s].clip;
+      } else {
+        kv -= P.seg[s].w;
+      }
+    }
+  }
+  if (!ok) { xp = P.seg[0].x; wp = P.seg[0].W; ld = P.seg[0].ld; }     // any valid address; contribution zeroed
+  const int row = min(m0 + j, P.M - 1);
+  f32x4 a = ldv(xp + (int64_t)row * ld);
+  f32x4 b[4];
+  const float* wc = wp + n0 + 4 * j;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b[s] = ldv(wc + (int64_t)s * P.N);
+  LOADS_FIRST();
+  if (cl > 0.0f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fclip(a[e], -cl, cl);
+  }
+  if (dv != 1.0f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fdiv(a[e], dv);
+  }
+  a = sel4(ok && (m0 + j < P.M), a);
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[s], b[s][e], acc[e]);
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  if (m0 + orow >= P.M) return;
+  v += ldv(P.bias + n0 + 4 * c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
 }
 
 // ------------------------------------------------------------------ one-wave-per-row kernels
@@ -1215,6 +1280,33 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
       CURIOUS_LAUNCH_CHECK("fwd_hot_kernel");
       continue;
     }
+    if (l == 0 && (H % 64 == 0)) {
+      L0Args la;
+      memset(&la, 0, sizeof(la));
+      bool lean = true;
+      for (int i = 0; i < nch && lean; ++i) {
+        Chain& C = ch[i];
+        Seg seg[MAX_SEG];
+        const int ns = l0_segments(c, C.off, C.theta, C.in, C.critic, c->max_u, seg);
+        L0Prob& p = la.p[i];
+        int ktot = 0;
+        for (int s = 0; s < ns; ++s) {
+          const Seg& sg = seg[s];
+          if (!sg.vec || sg.w % 4 != 0 || sg.sub || sg.mean || !aligned16(sg.W)) lean = false;
+          p.seg[s].x = sg.x; p.seg[s].W = sg.W; p.seg[s].ld = sg.ld; p.seg[s].w = sg.w; p.seg[s].div = sg.div;
+          p.seg[s].clip = sg.clip > 0.0f ? sg.clip : 0.0f;
+          ktot += sg.w;
+        }
+        if (ktot > 64 || !aligned16(C.act[0]) || !aligned16(C.theta + C.off.b0)) lean = false;
+        p.nseg = ns; p.bias = C.theta + C.off.b0; p.Y = C.act[0]; p.M = M; p.N = H; p.ldy = H;
+      }
+      if (lean) {
+        dim3 grid(H / 64, (M + 15) / 16, nch);
+        { ProfScope ps__(CK_FWD_LAYER0, st); hipLaunchKernelGGL(fwd_l0_kernel, grid, dim3(256), 0, st, la); }
+        CURIOUS_LAUNCH_CHECK("fwd_l0_kernel");
+        continue;
+      }
+    }
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.nprob = nch;
@@ -1415,6 +1507,58 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
     { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel");
   }
+  // ---- weight/bias gradients: problem lists for the lean kernels (launched after the actor's backward chain)
+  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && !cfg->normalize_obs;
+  LossFin fin;
+  fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
+  auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
+    int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
+    bool ok = true;
+    const NetOff& off = critic ? offQ : offPi;
+    float* g = critic ? gQ : gPi;
+    const int chain = critic ? 1 : 2;
+    float** dact = w.dact[critic ? 0 : 2];
+    auto add_small = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
+      if (ns_ >= MAX_DW_SMALL || x.sub || x.mean || x.clip > 0.0f || !(N % 4 == 0 || N == 1) ||
+          !(N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) { ok = false; return; }
+      DwSmall& p = sm.p[ns_++];
+      p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
+      stiles += ((x.w + 15) / 16) * ((N + 63) / 64);
+      p.tile_end = stiles;
+    };
+    add_small(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D,
+              g + off.Wout, g + off.bout);
+    for (int l = nl - 1; l >= 1; --l) {
+      GemmHot& p = hw.p[nh];
+      p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
+      p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
+      tiles += (H / 16) * (H / 64);
+      hw.tile_end[nh] = tiles;
+      ++nh;
+    }
+    hw.nprob = nh;
+    Seg seg[MAX_SEG];
+    int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
+    int64_t r = 0;
+    for (int s = 0; s < ns; ++s) {
+      const bool goal_branch = cfg->modular && s == ns - 1;
+      float* dW = goal_branch ? g + off.Wg : g + off.W0 + r * H;
+      add_small(seg[s], dact[0], H, H, dW, (s == 0) ? g + off.b0 : nullptr);
+      if (!goal_branch) r += seg[s].w;
+    }
+    sm.nprob = ns_; sm.M = B;
+    return ok;
+  };
+  // (Measured: running the critic's gradient kernels on a forked side stream -- a parallel branch of the captured
+  //  graph -- made every update 70 % SLOWER on this stack, and slowed unrelated eager launches once a second hardware
+  //  queue was active; everything therefore stays on the caller's stream.)
+  DwHotArgs hwAll;
+  DwSmallArgs smAll;
+  memset(&hwAll, 0, sizeof(hwAll));
+  memset(&smAll, 0, sizeof(smAll));
+  int tAll = 0, stAll = 0;
+  bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
+  if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
   // ---- into the action slot of critic(pi), through tanh + l2 term -> dz; backward through the actor output layer
   {
     ActorDzArgs a;
@@ -1451,27 +1595,21 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
     { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel(actor)");
   }
-  // ---- weight/bias gradients: the big hidden-layer problems on the lean kernel; layer-0 segments, output layers
-  //      and the loss finalisation on the compact small-problem kernel (generic grouped kernel as fallback)
-  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) * 2 <= 4;
-  {
+  if (lean_dw) {
+    if (hwAll.nprob > 0) {
+      { ProfScope ps__(CK_DW, st); hipLaunchKernelGGL(dw_hot_kernel, dim3(tAll), dim3(256), 0, st, hwAll); }
+      CURIOUS_LAUNCH_CHECK("dw_hot_kernel");
+    }
+    smAll.fin = fin;
+    { ProfScope ps__(CK_DW_SMALL, st);
+      hipLaunchKernelGGL(dw_small_kernel, dim3(stAll + 1), dim3(256), 0, st, smAll); }
+    CURIOUS_LAUNCH_CHECK("dw_small_kernel");
+  } else {
+    // generic path: every weight/bias gradient + the loss finalisation in one grouped launch
     DwArgs wa;
     memset(&wa, 0, sizeof(wa));
-    DwHotArgs hw;
-    memset(&hw, 0, sizeof(hw));
-    DwSmallArgs sm;
-    memset(&sm, 0, sizeof(sm));
-    int np = 0, maxw = 0, nh = 0, tiles = 0, ns_ = 0, stiles = 0;
-    bool small_ok = dw_hot && !cfg->normalize_obs;
+    int np = 0, maxw = 0;
     auto add = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
-      if (small_ok && ns_ < MAX_DW_SMALL && !x.sub && !x.mean && x.clip <= 0.0f && (N % 4 == 0 || N == 1) &&
-          (N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) {
-        DwSmall& p = sm.p[ns_++];
-        p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
-        stiles += ((x.w + 15) / 16) * ((N + 63) / 64);
-        p.tile_end = stiles;
-        return;
-      }
       DwProb& p = wa.p[np++];
       p.x = x; p.dY = dY; p.lddy = lddy; p.dW = dW; p.db = db; p.M = B; p.N = N;
       p.yvec = (lddy % 4 == 0) && (N % 4 == 0) && aligned16(dY);
@@ -1484,63 +1622,26 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
       float* g = critic ? gQ : gPi;
       const int chain = critic ? 1 : 2;
       float** dact = w.dact[critic ? 0 : 2];
-      // output layer: dWout = act_last^T . dOut, dbout = colsum(dOut)
       add(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D, g + off.Wout,
           g + off.bout);
-      for (int l = nl - 1; l >= 1; --l) {
-        if (dw_hot) {
-          GemmHot& p = hw.p[nh];
-          p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
-          p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
-          tiles += (H / 16) * (H / 64);
-          hw.tile_end[nh] = tiles;
-          ++nh;
-        } else {
-          add(make_seg(w.act[chain][l - 1], H, H, nullptr), dact[l], H, H, g + off.W[l], g + off.b[l]);
-        }
-      }
+      for (int l = nl - 1; l >= 1; --l)
+        add(make_seg(w.act[chain][l - 1], H, H, nullptr), dact[l], H, H, g + off.W[l], g + off.b[l]);
       Seg seg[MAX_SEG];
       int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
       int64_t r = 0;
-      for (int s = 0; s < ns; ++s) {
-        const bool goal_branch = cfg->modular && s == ns - 1;
+      for (int s2 = 0; s2 < ns; ++s2) {
+        const bool goal_branch = cfg->modular && s2 == ns - 1;
         float* dW = goal_branch ? g + off.Wg : g + off.W0 + r * H;
-        add(seg[s], dact[0], H, H, dW, (s == 0) ? g + off.b0 : nullptr);
-        if (!goal_branch) r += seg[s].w;
+        add(seg[s2], dact[0], H, H, dW, (s2 == 0) ? g + off.b0 : nullptr);
+        if (!goal_branch) r += seg[s2].w;
       }
     }
     CURIOUS_CHECK(np <= MAX_DW, "curious_ddpg_grads: too many gradient problems");
-    if (nh > 0) {
-      hw.nprob = nh;
-      { ProfScope ps__(CK_DW, st); hipLaunchKernelGGL(dw_hot_kernel, dim3(tiles), dim3(256), 0, st, hw); }
-      CURIOUS_LAUNCH_CHECK("dw_hot_kernel");
-    }
-    LossFin fin;
-    fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
-    if (ns_ > 0 && np == 0) {
-      sm.nprob = ns_; sm.M = B; sm.fin = fin;
-      { ProfScope ps__(CK_DW_SMALL, st);
-        hipLaunchKernelGGL(dw_small_kernel, dim3(stiles + 1), dim3(256), 0, st, sm); }
-      CURIOUS_LAUNCH_CHECK("dw_small_kernel");
-    } else {
-      // generic path: move anything queued on the small list back to the generic list
-      for (int i = 0; i < ns_; ++i) {
-        DwProb& p = wa.p[np++];
-        Seg x = make_seg(sm.p[i].x, sm.p[i].ldx, sm.p[i].w, nullptr);
-        x.div = sm.p[i].div;
-        p.x = x; p.dY = sm.p[i].dY; p.lddy = sm.p[i].lddy; p.dW = sm.p[i].dW; p.db = sm.p[i].db; p.M = B;
-        p.N = sm.p[i].N;
-        p.yvec = (p.lddy % 4 == 0) && (p.N % 4 == 0) && aligned16(p.dY);
-        p.fast = p.yvec && p.N >= 4;
-        if (x.w > maxw) maxw = x.w;
-      }
-      CURIOUS_CHECK(np <= MAX_DW, "curious_ddpg_grads: too many gradient problems");
-      wa.nprob = np;
-      wa.fin = fin;
-      dim3 grid((H + 63) / 64, (maxw + 15) / 16, np + 1);
-      { ProfScope ps__(CK_DW_SMALL, st); hipLaunchKernelGGL(dw_kernel, grid, dim3(256), 0, st, wa); }
-      CURIOUS_LAUNCH_CHECK("dw_kernel");
-    }
+    wa.nprob = np;
+    wa.fin = fin;
+    dim3 grid((H + 63) / 64, (maxw + 15) / 16, np + 1);
+    { ProfScope ps__(CK_DW_SMALL, st); hipLaunchKernelGGL(dw_kernel, grid, dim3(256), 0, st, wa); }
+    CURIOUS_LAUNCH_CHECK("dw_kernel");
   }
   return 0;
 }
