@@ -140,7 +140,8 @@ def kernel_flops_bytes(policy, lay):
         # layer 0 (K = 56..60)
         fwd_l0_kernel=dict(bound='mfma', per_update=2 * B * H * (3 * Kc + 2 * Ka), launches_update=2,
                               per_env_step=2 * B_R * H * Ka, launches_env_step=1),
-        dx_hot_kernel=dict(bound='mfma', per_update=3 * hid * 2 * B * H * H, launches_update=2 * hid),
+        dx_hot_kernel=dict(bound='mfma', per_update=(3 * hid - 2) * 2 * B * H * H, launches_update=2 * hid - 1),
+        dx_crit_kernel=dict(bound='mfma', per_update=2 * 2 * B * H * H + 3 * 2 * B * H, launches_update=1),
         dw_hot_kernel=dict(bound='mfma', per_update=2 * hid * 2 * B * H * H, launches_update=1),
         dw_small_kernel=dict(bound='mfma', per_update=2 * B * H * (Kc + Ka) + 2 * B * H * (1 + U),
                              launches_update=1),

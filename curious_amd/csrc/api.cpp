@@ -62,7 +62,7 @@ static const char* k_names[CK_COUNT] = {
     "her_sample_kernel", "store_episodes_kernel", "episode_activity_kernel", "norm_partial_kernel",
     "norm_final_kernel", "norm_recompute_kernel", "fwd_l0_kernel", "fwd_hot_kernel", "dx_hot_kernel", "dw_hot_kernel",
     "dw_small_kernel", "head_fwd_kernel",
-    "critic_head_kernel", "actor_dz_kernel", "adam_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel",
+    "dx_crit_kernel", "actor_dz_kernel", "adam_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel",
     "env_step_kernel"};
 
 extern "C" int curious_prof_kernel_count(void) { return CK_COUNT; }

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
   const float* xr = P.A + (int64_t)(m0 + j) * P.lda;
   const float* wc = P.B + n0 + 4 * j;
+  const f32x4 bias = ldv(P.aux + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int kb = 0; kb < P.K; kb += 256) {
     f32x4 a[4], b[4][4];
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
   }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
-  v += ldv(P.aux + n0 + 4 * c4);
+  v += bias;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
@@ -553,6 +554,8 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
   const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
   const float* dyr = P.A + (int64_t)(m0 + j) * P.lda;
   const float* wr = P.B + (int64_t)(k0 + 4 * j) * P.ldb;
+  const int64_t o = (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
+  const f32x4 h = ldv(P.aux + o);                           // relu mask source, issued with the first batch
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int nb = 0; nb < P.K; nb += 256) {
     f32x4 a[4], b[4][4];
@@ -573,8 +576,6 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
   }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
-  const int64_t o = (int64_t)(m0 + orow) * P.ldc + k0 + 4 * c4;
-  f32x4 h = ldv(P.aux + o);
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
   *reinterpret_cast<f32x4*>(P.C + o) = v;
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   const float* wc = wp + n0 + 4 * j;
 #pragma unroll
   for (int s = 0; s < 4; ++s) b[s] = ldv(wc + (int64_t)s * P.N);
+  const f32x4 bias = ldv(P.bias + n0 + 4 * (tid & 15));
   LOADS_FIRST();
   if (cl > 0.0f) {
 #pragma unroll
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
   if (m0 + orow >= P.M) return;
-  v += ldv(P.bias + n0 + 4 * c4);
+  v += bias;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
@@ -975,6 +977,139 @@ __global__ __launch_bounds__(256) void critic_head_kernel(CriticHeadArgs a) {
       *reinterpret_cast<f32x4*>(a.dd2 + (int64_t)m * a.H + k) = gd;
     }
   }
+}
+
+
+// ------------------------------------------------------------------ fused: critic heads + losses + first backward level
+// critic_head_kernel + dx_hot_kernel(level nl-1) in one launch (saves one ~4.5 us dependent stage per update).
+// Every workgroup recomputes, for its 16 batch rows, what it needs of the output layers (Q, target Q -> dQ; the
+// critic(pi) pass needs no head at all: dQ_pi = -1/B), builds the A operand dY[m][n] = dOut[m] * Wout[n] * relu'(h[m][n])
+// on the fly and runs the usual split-K tile.  Column-tile 0 also writes what later kernels read: dY itself (for the
+// weight gradients), dQ, the per-row loss terms and Q_pi.
+struct DxCritArgs {
+  const float* hl[2];      // last hidden activations: critic(u), critic(pi)            [B,H]
+  const float* hprev[2];   // activations one layer below (relu mask of the result)       [B,H]
+  float* dY[2];            // gradient wrt hl (written by column-tile 0)                  [B,H]
+  float* dX[2];            // gradient wrt hprev's pre-activation                         [B,H]
+  const float* W;          // main/Q kernel of layer nl-1                                 [H,H]
+  const float* WoutQ; const float* boutQ;
+  const float* e2; const float* WoutQt; const float* boutQt;
+  const float* r; int32_t ldr;
+  const float* pi; int32_t ldpi;
+  int32_t B, H, U;
+  float gamma, clip_lo, clip_hi, max_u;
+  float* dQ; float* rows; float* out_Qpi; int64_t* step_ctr;
+};
+
+__device__ inline float dot_row(const float* a, const float* b, int H, int lane) {
+  float acc = 0.f;
+  for (int k = 4 * lane; k < H; k += 256) {
+    f32x4 x = ldv(a + k), y = ldv(b + k);
+    acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+  }
+  return wave_sum(acc);
+}
+
+// H == 256 only (one 16-byte fragment per lane covers a row): every global load of the kernel -- the 4 rows of the
+// prologue, the output-layer weights and the main loop's 24 fragments -- is issued in one batch before any use.
+__global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ float s_dq[16];
+  const int ch = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+  const int H = 256;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0 && tid == 0 && a.step_ctr) *a.step_ctr += 1;
+  const float* hrow = a.hl[ch] + (int64_t)(m0 + j) * H;
+  const float* wr = a.W + (int64_t)(k0 + 4 * j) * H;
+  const float invB = 1.0f / (float)a.B;
+  const bool need_dots = (ch == 0) || (blockIdx.x == 0);
+  // ---- all loads
+  f32x4 pr_h[4], pr_e[4];                                   // prologue rows m0 + 4*wave + r, this lane's 4 columns
+  const int pm = m0 + 4 * wave;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pr_h[r] = ldv(a.hl[ch] + (int64_t)(pm + r) * H + 4 * lane);
+    pr_e[r] = ldv(a.e2 + (int64_t)(pm + r) * H + 4 * lane);
+  }
+  const f32x4 wq = ldv(a.WoutQ + 4 * lane), wt = ldv(a.WoutQt + 4 * lane);
+  const float bq = a.boutQ[0], bt = a.boutQt[0];
+  float rew[4], l2v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    rew[r] = a.r[(int64_t)(pm + r) * a.ldr];
+    // sum_j (pi_j / max_u)^2 of row pm + r: lanes 0..U-1 hold one term each (ddpg.py:441)
+    const float pv = (lane < a.U) ? a.pi[(int64_t)(pm + r) * a.ldpi + lane] : 0.f;
+    l2v[r] = pv;
+  }
+  const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
+  const f32x4 hm = ldv(a.hprev[ch] + o);
+  f32x4 hv[4], wo[4], b[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int nq = (wave + 4 * u) * 16 + 4 * q;
+    hv[u] = ldv(hrow + nq);
+    wo[u] = ldv(a.WoutQ + nq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
+  }
+  LOADS_FIRST();
+  // ---- prologue: output-layer values of this wave's 4 rows
+  if (need_dots) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = pm + r;
+      float d1 = pr_h[r][0] * wq[0] + pr_h[r][1] * wq[1] + pr_h[r][2] * wq[2] + pr_h[r][3] * wq[3];
+      float d2 = pr_e[r][0] * wt[0] + pr_e[r][1] * wt[1] + pr_e[r][2] * wt[2] + pr_e[r][3] * wt[3];
+      d1 = wave_sum(d1);
+      d2 = wave_sum(d2);
+      if (ch == 0) {
+        const float Q = d1 + bq, Qt = d2 + bt;
+        const float target = fclip(rew[r] + a.gamma * Qt, a.clip_lo, a.clip_hi);   // ddpg.py:437-438
+        const float diff = target - Q;
+        const float dq = -2.0f * invB * diff;
+        if (lane == 0) {
+          s_dq[4 * wave + r] = dq;
+          if (blockIdx.x == 0) {
+            a.rows[m] = diff * diff;                         // ddpg.py:439
+            a.dQ[m] = dq;
+          }
+        }
+      } else {
+        const float Qpi = d1 + bq;
+        const float tt = l2v[r] / a.max_u;
+        const float l2 = wave_sum(tt * tt);
+        if (lane == 0) {
+          a.rows[a.B + m] = Qpi;                             // ddpg.py:440
+          a.rows[2 * a.B + m] = l2;
+          a.out_Qpi[m] = Qpi;
+        }
+      }
+    }
+  }
+  if (ch == 1 && lane < 4) s_dq[4 * wave + lane] = -invB;    // d(-mean(Q_pi)) / dQ_pi
+  __syncthreads();
+  const float dq = s_dq[j];
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x4 av;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) av[s] = (hv[u][s] > 0.f) ? dq * wo[u][s] : 0.f;
+    if (blockIdx.x == 0) {
+      const int nq = (wave + 4 * u) * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(a.dY[ch] + (int64_t)(m0 + j) * H + nq) = av;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(av[s], b[u][e][s], acc[e]);
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (hm[e] > 0.f) ? v[e] : 0.f;
+  *reinterpret_cast<f32x4*>(a.dX[ch] + o) = v;
 }
 
 // d pi_loss / dz through the critic's action slot, tanh and the l2 term; then backward through the actor output layer.
@@ -1459,7 +1594,30 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
   cb[1].act = w.act[4];
   if (forward_chains(cfg, cb, 2, B, st)) return -2;
 
-  // ---- critic output layers, per-row loss terms, backward through the output layers
+  // ---- critic output layers, per-row loss terms, backward through the output layers (fused with the first hidden
+  //      backward level when the lean kernels apply)
+  const bool dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
+  const bool fuse_crit = dx_hot && nl >= 2 && H == 256;
+  if (fuse_crit) {
+    DxCritArgs a;
+    memset(&a, 0, sizeof(a));
+    const int l = nl - 1;
+    a.hl[0] = w.act[1][l]; a.hl[1] = w.act[4][l];
+    a.hprev[0] = w.act[1][l - 1]; a.hprev[1] = w.act[4][l - 1];
+    a.dY[0] = w.dact[0][l]; a.dY[1] = w.dact[1][l];
+    a.dX[0] = w.dact[0][l - 1]; a.dX[1] = w.dact[1][l - 1];
+    a.W = thQ + offQ.W[l];
+    a.WoutQ = thQ + offQ.Wout; a.boutQ = thQ + offQ.bout;
+    a.e2 = w.act[3][l]; a.WoutQt = ttQ + offQ.Wout; a.boutQt = ttQ + offQ.bout;
+    a.r = batch + BL->off_r; a.ldr = ld; a.pi = w.pi; a.ldpi = U;
+    a.B = B; a.H = H; a.U = U;
+    a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
+    a.max_u = cfg->max_u;
+    a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
+    dim3 grid(H / 64, B / 16, 2);
+    { ProfScope ps__(CK_CRITIC_HEAD, st); hipLaunchKernelGGL(dx_crit_kernel, grid, dim3(256), 0, st, a); }
+    CURIOUS_LAUNCH_CHECK("dx_crit_kernel");
+  } else
   {
     CriticHeadArgs a;
     a.c2 = w.act[1][nl - 1]; a.d2 = w.act[4][nl - 1]; a.e2 = w.act[3][nl - 1];
@@ -1476,8 +1634,7 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
     CURIOUS_LAUNCH_CHECK("critic_head_kernel");
   }
   // ---- hidden layers of the two critic passes: dact[k][l-1] = (dact[k][l] . W_l^T) * relu'(act[l-1])
-  const bool dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
-  for (int l = nl - 1; l >= 1; --l) {
+  for (int l = fuse_crit ? nl - 2 : nl - 1; l >= 1; --l) {
     if (dx_hot) {
       HotArgs ha;
       memset(&ha, 0, sizeof(ha));

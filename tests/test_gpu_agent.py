@@ -270,3 +270,65 @@ def test_batched_rollout_matches_oracle():
         assert bool(w.exploit) == bool(exploit)
     # the staging block feeds store_episode directly
     agent.store_episode(ep, CP, n_ep)
+
+
+def test_task_experts_share_buffers_and_match_oracle():
+    """structure='task_experts' (train.py:65-121, ddpg.py:302-318,335): one DDPG per task on shared buffers, each
+    sampling from buffer t_id+1 and relabelling to its own task."""
+    from curious_amd.ddpg import DDPG
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    from oracle import her as oher
+    from oracle.ddpg import OracleDDPG
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    from oracle.reward import make_reward_fun
+    nb, dimo = 4, 40
+    G = 12
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    tr = 'replay_current_task_buffer'
+    sampler = make_sample_multi_task_her_transitions('her', 4, tr, sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    bufs = make_pooled_buffers(shapes, T * 64, T, sampler, nb + 1, alias_from=5)
+    osampler = oher.make_sample_multi_task_her_transitions('her', 4, tr, make_reward_fun(ag_ids, g_ids),
+                                                           tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    obufs = [OBuf(shapes, T * 64, T, osampler) for _ in range(nb + 1)]
+    gamma = 1. - 1. / T
+    experts, oracles = [], []
+    for t_id in range(2):
+        experts.append(DDPG(input_dims=dims, hidden=64, layers=3,
+                            network_class='curious_amd.actor_critic:MultiTaskActorCritic', polyak=0.95, batch_size=128,
+                            Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1., clip_obs=200.,
+                            scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None, relative_goals=False,
+                            clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                            sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids,
+                            tasks_g_id=g_ids, task_replay=tr, eps_task=0.4, structure='task_experts', t_id=t_id,
+                            seed=10 + t_id))
+        oracles.append(OracleDDPG(dims, T, obufs, osampler, ag_ids, g_ids, hidden=64, batch_size=128,
+                                  task_replay=tr, structure='task_experts', t_id=t_id,
+                                  weight_rng=np.random.RandomState(10 + t_id)))
+    assert experts[0].buffer[1] is experts[1].buffer[1] and experts[0].scope == 'ddpg0'
+    rng = np.random.RandomState(2)
+    ep = synth_episodes(rng, 30, nb, dimo)
+    np.random.seed(1)
+    experts[0].store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(nb), 30)
+    np.random.seed(1)
+    oracles[0].store_episode({k: v.astype(np.float64) for k, v in ep.items()}, np.zeros(nb), 30)
+    for t_id in range(2):
+        np.random.seed(40 + t_id)
+        got = [x.cpu().numpy() for x in experts[t_id].sample_batch()]
+        np.random.seed(40 + t_id)
+        want = oracles[t_id].sample_batch()
+        np.testing.assert_array_equal(experts[t_id].proportions, oracles[t_id].proportions)
+        assert experts[t_id].proportions[t_id + 1] == 128
+        for name, a, b in zip(['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r'], got, want):
+            np.testing.assert_array_equal(a.astype(np.float64), np.asarray(b, dtype=np.float64), err_msg=name)
+        # every HER-relabelled row now belongs to this expert's task
+        np.random.seed(50 + t_id)
+        ql, _ = oracles[t_id].train()
+        np.random.seed(50 + t_id)
+        cl, _ = experts[t_id].train()
+        assert abs(float(cl) - float(ql)) <= 1e-5 * abs(float(ql))

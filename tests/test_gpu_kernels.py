@@ -412,3 +412,87 @@ def test_env_bit_exact_vs_oracle(ops, name):
             np.testing.assert_array_equal(rec['change'][:, t].cpu().numpy(), want_change)
         moved = np.abs(o.cpu().numpy()[:, 3:6] - np.stack([x['observation'] for x in obs])[:, 3:6]).max()
         assert moved > 0      # at least one object was carried
+
+
+def test_ddpg_grads_flat_network_vs_oracle(ops):
+    """structure='flat': ActorCritic (single input [o | g (| u/max_u)], actor_critic.py:5-48)."""
+    from curious_amd.layout import RecordLayout
+    from oracle.networks import DDPGMath
+    dimo, G, B, T = 25, 3, 96, 50
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1))
+    layout = RecordLayout(shapes, T)
+    assert layout.dims['task_descr'] == 0
+    rng = np.random.RandomState(3)
+    batch = np.zeros([B, layout.batch_stride], np.float32)
+    c = layout.batch_cols
+    for k, v in dict(o=rng.randn(B, dimo), o_2=rng.randn(B, dimo), g=rng.randn(B, G), u=rng.uniform(-1, 1, (B, 4)),
+                     r=-(rng.rand(B, 1) > 0.3).astype(np.float32)).items():
+        batch[:, c[k][0]:c[k][0] + c[k][1]] = v
+    batch[:, c['g_2'][0]:c['g_2'][0] + G] = batch[:, c['g'][0]:c['g'][0] + G]
+    m64 = DDPGMath(dimo, G, 4, 0, 64, 3, 1.0, 0.98, 50., True, 1.0, False, np.float64)
+    theta, theta_t = m64.init(rng).astype(np.float32), m64.init(rng).astype(np.float32)
+    ncfg = ops.make_net_cfg(dimo, G, 4, 0, 64, 3, False, 1.0, 0.98, 50., 1.0)
+    PQ, Ppi, off_pi, total = ops.param_layout(ncfg)
+    assert (PQ, Ppi) == (m64.P_Q, m64.P_pi)
+    ws = torch.zeros(ops.workspace_floats(ncfg, B), device='cuda')
+    grad = torch.zeros(total, device='cuda')
+    losses = torch.zeros(2, device='cuda')
+    Qpi = torch.zeros(B, device='cuda')
+    ops.ddpg_grads(ncfg, dev(ops.pad_params(ncfg, theta)), dev(ops.pad_params(ncfg, theta_t)), dev(batch), layout, B,
+                   ws, grad, losses, Qpi)
+    bd = {k: batch[:, o:o + d] for k, (o, d) in layout.batch_cols.items()}
+    bd['task_descr'] = np.zeros((B, 0))
+    ref = m64.losses_and_grads(theta.astype(np.float64), theta_t.astype(np.float64), bd)
+    got_l = losses.cpu().numpy()
+    assert abs(got_l[0] - ref['Q_loss']) <= 1e-5 * abs(ref['Q_loss'])
+    assert abs(got_l[1] - ref['pi_loss']) <= 1e-5 * abs(ref['pi_loss'])
+    g = ops.unpad_params(ncfg, grad.cpu().numpy())
+    assert np.abs(g[:PQ] - ref['Q_grad']).max() <= 1e-5 * np.abs(ref['Q_grad']).max()
+    assert np.abs(g[PQ:] - ref['pi_grad']).max() <= 1e-5 * np.abs(ref['pi_grad']).max()
+
+
+def test_ddpg_grads_with_input_normalisation(ops):
+    """normalize_obs=True (actor_critic.py:76-83): nets see clip((x - mean) / std, +-norm_clip)."""
+    from curious_amd.layout import RecordLayout
+    from oracle.networks import DDPGMath
+    nb, dimo, B, T = 4, 40, 256, 50
+    G = 12
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), task_descr=(T, nb), change=(T, G),
+                  info_is_success=(T, 1))
+    layout = RecordLayout(shapes, T)
+    rng = np.random.RandomState(21)
+    batch = _rand_batch(rng, layout, B, nb)
+    c = layout.batch_cols
+    batch[:, c['o'][0]:c['o'][0] + dimo] *= 4.0          # so that the +-5 clip after normalisation bites
+    o_mean, o_std = rng.randn(dimo).astype(np.float32) * 0.3, (0.5 + rng.rand(dimo)).astype(np.float32)
+    g_mean, g_std = rng.randn(G).astype(np.float32) * 0.1, (0.5 + rng.rand(G)).astype(np.float32)
+
+    def state(mean, std):
+        d = mean.shape[0]
+        s = np.zeros(4 * d + 1, np.float32)
+        s[2 * d] = 1
+        s[2 * d + 1:3 * d + 1] = mean
+        s[3 * d + 1:] = std
+        return s
+    m64 = DDPGMath(dimo, G, 4, nb, 256, 3, 1.0, 0.98, 50., True, 1.0, True, np.float64)
+    theta, theta_t = m64.init(rng).astype(np.float32), m64.init(rng).astype(np.float32)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, 256, 3, True, 1.0, 0.98, 50., 1.0, normalize_obs=True, norm_clip=5.0)
+    PQ, Ppi, off_pi, total = ops.param_layout(ncfg)
+    ws = torch.zeros(ops.workspace_floats(ncfg, B), device='cuda')
+    grad = torch.zeros(total, device='cuda')
+    losses = torch.zeros(2, device='cuda')
+    Qpi = torch.zeros(B, device='cuda')
+    ops.ddpg_grads(ncfg, dev(ops.pad_params(ncfg, theta)), dev(ops.pad_params(ncfg, theta_t)), dev(batch), layout, B,
+                   ws, grad, losses, Qpi, o_stats=dev(state(o_mean, o_std)), g_stats=dev(state(g_mean, g_std)))
+    bd = {k: batch[:, o:o + d].astype(np.float64) for k, (o, d) in layout.batch_cols.items()}
+    f = np.float32
+    for k, mu, sd in (('o', o_mean, o_std), ('o_2', o_mean, o_std), ('g', g_mean, g_std), ('g_2', g_mean, g_std)):
+        bd[k] = np.clip((bd[k].astype(f) - mu) / sd, -5, 5).astype(np.float64)
+    assert np.abs(bd['o']).max() == 5.0
+    ref = m64.losses_and_grads(theta.astype(np.float64), theta_t.astype(np.float64), bd)
+    got_l = losses.cpu().numpy()
+    assert abs(got_l[0] - ref['Q_loss']) <= 1e-5 * abs(ref['Q_loss'])
+    assert abs(got_l[1] - ref['pi_loss']) <= 1e-5 * abs(ref['pi_loss'])
+    g = ops.unpad_params(ncfg, grad.cpu().numpy())
+    assert np.abs(g[:PQ] - ref['Q_grad']).max() <= 1e-5 * np.abs(ref['Q_grad']).max()
+    assert np.abs(g[PQ:] - ref['pi_grad']).max() <= 1e-5 * np.abs(ref['pi_grad']).max()
