@@ -96,6 +96,10 @@ PROTOTYPES = {
     'curious_action_noise': (C.c_int, [_P, _I32, _I32, _I32, _D, _D, _D, _P, _P, _P, _U64, _U64, _P]),
     'curious_adam_update': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, C.POINTER(C.c_float), _F, _F,
                                       _F, _F, _F, _P]),
+    'curious_adam_update_and_sample': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, C.POINTER(C.c_float),
+                                                 _F, _F, _F, _F, _F, _P, _I64, C.POINTER(Layout), C.POINTER(Tasks),
+                                                 C.POINTER(SampleParams), C.POINTER(SampleRng), _I32, _P,
+                                                 C.POINTER(BatchLayout), _P]),
     'curious_polyak_update': (C.c_int, [_P, _P, _I64, _F, _F, _P]),
     'curious_param_checksum': (C.c_int, [_P, _I64, _P, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,

@@ -5,6 +5,7 @@
 // correctly-rounded op (no FMA contraction) so results equal NumPy's float32 arithmetic bit for bit
 // (oracle/optim.py, nep50=False).  HBM traffic: 28 B/param (read g,m,v,theta; write m,v,theta).
 #include "common.h"
+#include "her_body.h"
 
 struct AdamArgs {
   float* theta;
@@ -20,16 +21,16 @@ struct AdamArgs {
   float b1, omb1, b2, omb2, eps;
 };
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+__device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks) {
   float aQ = a.a_Q, aPi = a.a_pi;
   if (a.alpha_tab) {
-    int64_t idx = (*a.step_ctr) - 1 - a.tab_base;        // the step counter was advanced by ddpg_grads
-    if (idx < 0) idx = 0;
-    if (idx >= a.tab_len) idx = a.tab_len - 1;
+    // the step counter was advanced by ddpg_grads; the table is a ring refilled by the host every tab_len steps
+    int64_t idx = ((*a.step_ctr) - 1 - a.tab_base) % a.tab_len;
+    if (idx < 0) idx += a.tab_len;
     aQ = a.alpha_tab[2 * idx];
     aPi = a.alpha_tab[2 * idx + 1];
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.n; i += (int64_t)nblocks * 256) {
     float g = a.grad[i];
     float m = __fadd_rn(__fmul_rn(a.b1, a.m[i]), __fmul_rn(a.omb1, g));              // mpi_adam.py:31
     float v = __fadd_rn(__fmul_rn(a.b2, a.v[i]), __fmul_rn(a.omb2, __fmul_rn(g, g)));  // mpi_adam.py:32
@@ -41,23 +42,69 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
-extern "C" int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
-                                   const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base,
-                                   int32_t tab_len, const float* alpha_host, float beta1, float one_minus_beta1,
-                                   float beta2, float one_minus_beta2, float epsilon, curious_stream_t stream) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) { adam_body(a, blockIdx.x, gridDim.x); }
+
+// Adam + the HER gather of the NEXT update in one launch: the gather does not depend on the parameters, so its
+// workgroups (the first n_her blocks) ride along with the optimiser's instead of being a dependent launch of their
+// own at the head of the next update (~7 us per update).  Stream order guarantees that every reader of the previous
+// staged batch (layer-0 forward, layer-0 weight gradients) has finished before this launch starts.
+__global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her) {
+  extern __shared__ float lds[];
+  if ((int)blockIdx.x < n_her) her_sample_body(h, blockIdx.x, lds);
+  else adam_body(a, blockIdx.x - n_her, gridDim.x - n_her);
+}
+
+static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
+                     const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
+                     const float* alpha_host, float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
+                     float epsilon) {
   CURIOUS_CHECK(theta && m && v && grad, "curious_adam_update: NULL argument");
   CURIOUS_CHECK((alpha_tab && step_ctr && tab_len > 0) || alpha_host, "curious_adam_update: no step size given");
-  AdamArgs a;
   a.theta = theta; a.m = m; a.v = v; a.grad = grad;
   a.n_Q = n_Q; a.n = n_Q + n_pi;
   a.alpha_tab = alpha_tab; a.step_ctr = step_ctr; a.tab_base = tab_base; a.tab_len = tab_len;
   a.a_Q = alpha_host ? alpha_host[0] : 0.f;
   a.a_pi = alpha_host ? alpha_host[1] : 0.f;
   a.b1 = beta1; a.omb1 = one_minus_beta1; a.b2 = beta2; a.omb2 = one_minus_beta2; a.eps = epsilon;
+  return 0;
+}
+
+extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, const float* grad, int64_t n_Q,
+                                              int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,
+                                              int64_t tab_base, int32_t tab_len, const float* alpha_host, float beta1,
+                                              float one_minus_beta1, float beta2, float one_minus_beta2, float epsilon,
+                                              const float* storage, int64_t buf_stride, const curious_layout_t* L,
+                                              const curious_tasks_t* tasks, const curious_sample_params_t* P,
+                                              const curious_sample_rng_t* rng, int32_t n, float* batch,
+                                              const curious_batch_layout_t* BL, curious_stream_t stream) {
+  AdamArgs a;
+  if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
+                one_minus_beta1, beta2, one_minus_beta2, epsilon)) return -1;
+  HerArgs h;
+  if (her_fill_args(h, storage, buf_stride, L, tasks, P, nullptr, rng, n, batch, BL)) return -1;
+  int n_her = (n + SPB - 1) / SPB;
+  int blocks = (int)((a.n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  { ProfScope ps__(CK_ADAM, as_stream(stream));
+    hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + blocks), dim3(256), her_lds_bytes(L), as_stream(stream), a, h,
+                       n_her); }
+  CURIOUS_LAUNCH_CHECK("adam_her_kernel");
+  return 0;
+}
+
+extern "C" int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
+                                   const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base,
+                                   int32_t tab_len, const float* alpha_host, float beta1, float one_minus_beta1,
+                                   float beta2, float one_minus_beta2, float epsilon, curious_stream_t stream) {
+  AdamArgs a;
+  if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
+                one_minus_beta1, beta2, one_minus_beta2, epsilon)) return -1;
   if (a.n <= 0) return 0;
   int blocks = (int)((a.n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  { ProfScope ps__(CK_ADAM, as_stream(stream)); hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a); }
+  { ProfScope ps__(CK_ADAM, as_stream(stream));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a); }
   CURIOUS_LAUNCH_CHECK("adam_kernel");
   return 0;
 }

@@ -84,6 +84,7 @@ class DDPG(object):
         self._staged = None
         self._graph = None
         self._tables_dirty = True
+        self._batch_stale = True
 
     # ------------------------------------------------------------------ construction
     def _create_network(self, reuse=False):
@@ -222,15 +223,36 @@ class DDPG(object):
                 ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, active)
                 active = active.cpu().numpy().reshape(batch_size, self.nb_tasks)   # one D2H sync per cycle
                 per_buffer = {}
-                for b in range(batch_size):                          # ddpg.py:178-195, order of the RNG draws kept
+                fast_src, fast_dst = [], []
+                routed = active.astype(bool)
+                if self.nb_tasks >= 5:
+                    routed[:, 5:] = False                            # only tasks j < 5 are routed (ddpg.py:183)
+                counts = routed.sum(axis=0)
+                fits = all(self.buffer[j + 1].current_size + int(counts[j]) <= self.buffer[j + 1].size
+                           for j in range(self.nb_tasks) if counts[j])
+                if fits and len({id(self.buffer[j + 1]) for j in range(self.nb_tasks) if counts[j]}) == \
+                        int((counts > 0).sum()):
+                    # no buffer overflows within this batch -> slots are consecutive and no random number is drawn
+                    # (replay_buffer.py:94-95): same result as the per-episode loop below, without the loop
                     for j in range(self.nb_tasks):
-                        if active[b, j] and (self.nb_tasks < 5 or j < 5):
+                        if counts[j]:
                             buf = self.buffer[j + 1]
-                            slot = buf._get_storage_idx(1)
-                            buf.n_transitions_stored += self.T
-                            per_buffer.setdefault(id(buf), (buf, [], []))
-                            per_buffer[id(buf)][1].append(b)
-                            per_buffer[id(buf)][2].append(slot)
+                            eps = np.nonzero(routed[:, j])[0]
+                            slots = np.arange(buf.current_size, buf.current_size + eps.size)
+                            buf.current_size += eps.size
+                            buf.n_transitions_stored += eps.size * self.T
+                            fast_src.append(eps.astype(np.int32))
+                            fast_dst.append(slots.astype(np.int64) + buf.pool_index * buf.pool.capacity)
+                else:
+                    for b in range(batch_size):                      # ddpg.py:178-195, order of the RNG draws kept
+                        for j in range(self.nb_tasks):
+                            if routed[b, j]:
+                                buf = self.buffer[j + 1]
+                                slot = buf._get_storage_idx(1)
+                                buf.n_transitions_stored += self.T
+                                per_buffer.setdefault(id(buf), (buf, [], []))
+                                per_buffer[id(buf)][1].append(b)
+                                per_buffer[id(buf)][2].append(slot)
                 # sequential semantics of the reference: when two episodes of this batch draw the same (random)
                 # slot the later one wins -> keep only the last writer of every destination
                 last = {}
@@ -238,7 +260,9 @@ class DDPG(object):
                     for b, s in zip(eps, slots):
                         last[int(s) + buf.pool_index * buf.pool.capacity] = b
                 dst, src = list(last.keys()), list(last.values())
-                if src:
+                if fast_src:
+                    src, dst = np.concatenate(fast_src), np.concatenate(fast_dst)
+                if len(src):
                     ops.store_episodes(self._pool.storage, staging, layout,
                                        torch.as_tensor(np.asarray(src, np.int32)).to(self.device),
                                        torch.as_tensor(np.asarray(dst, np.int64)).to(self.device))
@@ -479,14 +503,18 @@ class DDPG(object):
 
     # ------------------------------------------------------------------ training
     def _fill_alpha_table(self):
+        """Adam step sizes of the next ALPHA_TAB updates (float64 on the host exactly as mpi_adam.py:30, rounded to
+        float32).  The device table is a ring indexed by (step - 1) mod ALPHA_TAB (the base is baked into captured
+        launches, so it never changes); the refill is stream-ordered behind the updates that still read old entries."""
         t0 = self.Q_adam.t
         n = ALPHA_TAB
-        tab = np.empty([n, 2], np.float32)
         ts = np.arange(t0 + 1, t0 + n + 1)
-        tab[:, 0] = [self.Q_adam.alpha(self.Q_lr, int(t)) for t in ts]
-        tab[:, 1] = [self.pi_adam.alpha(self.pi_lr, int(t)) for t in ts]
+        tab = np.empty([n, 2], np.float32)
+        pos = (ts - 1) % n
+        tab[pos, 0] = [self.Q_adam.alpha(self.Q_lr, int(t)) for t in ts]
+        tab[pos, 1] = [self.pi_adam.alpha(self.pi_lr, int(t)) for t in ts]
         self._alpha_tab.copy_(torch.from_numpy(tab))
-        self._alpha_base = t0
+        self._alpha_base = 0
         self._alpha_filled = t0 + n
         self._step_ctr.fill_(t0)
 
@@ -507,18 +535,27 @@ class DDPG(object):
         return critic_loss, actor_loss
 
     def _train_graph(self):
+        """hipGraph replay of one update.  The HER gather of update k+1 rides in the Adam launch of update k
+        (curious_adam_update_and_sample); an explicit gather is issued whenever the buffers or the sampling tables
+        changed since the last one, so every batch is still drawn after the latest store_episode."""
         if self._tables_dirty:
             self._refresh_device_tables()
+            self._batch_stale = True
         if self.Q_adam.t + 1 > self._alpha_filled or self._alpha_filled == 0:
             self._fill_alpha_table()
         if self._graph is None:
+            self._sample_packed()                                   # allocate / fill the staging tensor before capture
             if dist.is_distributed():
-                # the all-reduce stays outside: graph A = sample + grads, graph B = Adam
-                self._graph = self._capture(lambda: (self._sample_packed(), self._grads()))
-                self._graph_b = self._capture(lambda: self._adam_only())
+                # the all-reduce stays outside: graph A = grads, graph B = Adam + next gather
+                self._graph = self._capture(self._grads)
+                self._graph_b = self._capture(self._adam_and_sample)
             else:
                 self._graph = self._capture(self._train_body_nocheck)
                 self._graph_b = None
+            self._batch_stale = True
+        if self._batch_stale:
+            self._sample_packed()
+            self._batch_stale = False
         if self.Q_adam.t % 100 == 0 and dist.is_distributed():
             self.Q_adam.theta = self.theta
             MpiAdam.check_synced(self.Q_adam)
@@ -535,10 +572,17 @@ class DDPG(object):
         ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
                         alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base)
 
+    def _adam_and_sample(self):
+        S = self.sample_transitions
+        ops.adam_update_and_sample(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
+                                   self._alpha_tab, self._step_ctr, self._alpha_base, self._pool.storage,
+                                   self._pool.buf_stride, self._layout, S.tasks,
+                                   S.params(self.clip_obs, self.relative_goals), self._rng_desc, self.batch_size,
+                                   self._staged)
+
     def _train_body_nocheck(self):
-        self._sample_packed()
         self._grads()
-        self._adam_only()
+        self._adam_and_sample()
 
     def _capture(self, fn):
         """Capture `fn`'s kernel launches into a hipGraph (after one eager warm-up on a side stream)."""

@@ -168,6 +168,20 @@ def adam_update(theta, m, v, grad, n_Q, n_pi, alpha_Q=None, alpha_pi=None, beta1
                                     float(f(epsilon)), current_stream()), 'curious_adam_update')
 
 
+def adam_update_and_sample(theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, storage, buf_stride, layout,
+                           tasks, params, rng, n, batch, beta1=0.9, beta2=0.999, epsilon=1e-08):
+    """Fused Adam (table-driven step sizes) + device-drawn HER gather of the next update."""
+    f = np.float32
+    L = layout.c_layout()
+    BL = layout.c_batch_layout()
+    check(lib().curious_adam_update_and_sample(
+        ptr(_dev(theta, 'theta')), ptr(m), ptr(v), ptr(grad), int(n_Q), int(n_pi), ptr(alpha_tab), ptr(step_ctr),
+        int(tab_base), int(alpha_tab.shape[0]), None, float(f(beta1)), float(f(1 - beta1)), float(f(beta2)),
+        float(f(1 - beta2)), float(f(epsilon)), ptr(_dev(storage, 'storage')), int(buf_stride), C.byref(L),
+        C.byref(tasks), C.byref(params), C.byref(rng), int(n), ptr(batch), C.byref(BL), current_stream()),
+        'curious_adam_update_and_sample')
+
+
 def polyak_update(target, main, polyak):
     f = np.float32
     check(lib().curious_polyak_update(ptr(_dev(target, 'target')), ptr(main), int(target.numel()),

@@ -200,11 +200,24 @@ int curious_action_noise(float* u, int32_t ldu, int32_t n, int32_t dimu, double 
 
 /* MpiAdam.update after the all-reduce (mpi_adam.py:29-35) on the fused [theta_Q | theta_pi] vector;
  * the two optimisers keep separate step sizes a_Q / a_pi = lr*sqrt(1-b2^t)/(1-b1^t), rounded to float32.
- * alpha_tab (device, [tab_len][2]) indexed by (*step_ctr - 1 - tab_base) when non-NULL, else alpha_host. */
+ * alpha_tab (device, [tab_len][2]) is a ring indexed by (*step_ctr - 1 - tab_base) mod tab_len when non-NULL, else
+ * alpha_host is used. */
 int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
                         const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
                         const float* alpha_host, float beta1, float one_minus_beta1, float beta2,
                         float one_minus_beta2, float epsilon, curious_stream_t stream);
+
+/* curious_adam_update + the device-drawn HER gather of the NEXT update (curious_her_sample with `rng`) in ONE launch:
+ * the gather does not depend on the parameters, so it rides along with the optimiser instead of heading the next
+ * update as a dependent launch.  The caller resamples explicitly after anything that changes the buffers
+ * (DDPG.store_episode), which keeps "sample after store" (train.py:150-154). */
+int curious_adam_update_and_sample(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
+                                   const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
+                                   const float* alpha_host, float beta1, float one_minus_beta1, float beta2,
+                                   float one_minus_beta2, float epsilon, const float* storage, int64_t buf_stride,
+                                   const curious_layout_t* L, const curious_tasks_t* tasks,
+                                   const curious_sample_params_t* P, const curious_sample_rng_t* rng, int32_t n,
+                                   float* batch, const curious_batch_layout_t* BL, curious_stream_t stream);
 
 /* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
  * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */

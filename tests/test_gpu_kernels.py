@@ -185,13 +185,15 @@ def test_adam_table_mode_and_polyak(ops):
     theta = rng.randn(P).astype(np.float32)
     th, m, v = dev(theta), torch.zeros(P, device='cuda'), torch.zeros(P, device='cuda')
     tab = np.array([[ops.adam_alpha(1e-3, t), ops.adam_alpha(5e-4, t)] for t in range(1, 9)], np.float32)
+    tab = np.roll(tab, 3, axis=0)                  # ring: entry of step t lives at (t - 1 - base) mod len, base = 5
+    base = 5
     ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
     oQ = (theta[:nQ].copy(), np.zeros(nQ, np.float32), np.zeros(nQ, np.float32), 0)
     oP = (theta[nQ:].copy(), np.zeros(P - nQ, np.float32), np.zeros(P - nQ, np.float32), 0)
     for k in range(8):
         g = rng.randn(P).astype(np.float32)
         ctr += 1                                  # what curious_ddpg_grads does
-        ops.adam_update(th, m, v, dev(g), nQ, P - nQ, alpha_tab=dev(tab), step_ctr=ctr, tab_base=0)
+        ops.adam_update(th, m, v, dev(g), nQ, P - nQ, alpha_tab=dev(tab), step_ctr=ctr, tab_base=base)
         oQ = adam_update(*oQ, g[:nQ], 1e-3)
         oP = adam_update(*oP, g[nQ:], 5e-4)
     np.testing.assert_array_equal(th.cpu().numpy(), np.concatenate([oQ[0], oP[0]]))
