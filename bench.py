@@ -190,6 +190,19 @@ def profile_pass(policy, worker, n_cycles=1):
     return stats, overhead_ms, t_plain / N_BATCHES
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
+    the bytes of 16-byte-per-lane streaming reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)[kernel]
+        return int(2 * d['FETCH_SIZE']['avg_KB'] * 1024 + d['WRITE_SIZE']['avg_KB'] * 1024)
+    except Exception:
+        return None
+
+
 def roofline(policy, worker, stats, n_cycles, overhead_ms):
     work = kernel_flops_bytes(policy, policy._layout)
     cal = {k: (v[0], max(v[1] - v[0] * overhead_ms, 0.0)) for k, v in stats.items() if v[0] > 0}
@@ -213,7 +226,7 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms):
     else:
         ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
     return dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
-                frac=round(ach / peak, 5), traffic=None, algorithmic_per_launch=round(per_launch, 1),
+                frac=round(ach / peak, 5), traffic=pmc_traffic(dominant), algorithmic_per_launch=round(per_launch, 1),
                 avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3)), table
 
 
