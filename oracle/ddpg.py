@@ -170,11 +170,15 @@ class OracleDDPG:
         batch_size = episode_batch['ag'].shape[0]
         self.cp = cp
         self.n_episodes = n_ep
+        multi = ('buffer' in self.task_replay) or self.task_replay == 'hand_designed'
         for b in range(batch_size):
             act = active_tasks_of(episode_batch['change'][b, -1], self.tasks_ag_id, self.tasks_g_id)
             ep = {k: v[b].reshape([1, v.shape[1], v.shape[2]]) for k, v in episode_batch.items()}
-            for task in act:                                         # ddpg.py:194-195
-                self.buffer[task + 1].store_episode(ep)
+            if multi:
+                for task in act:                                     # ddpg.py:194-195
+                    self.buffer[task + 1].store_episode(ep)
+            else:
+                self.buffer.store_episode(ep)                        # ddpg.py:196-197
         if update_stats:
             eb = dict(episode_batch)
             eb['o_2'] = eb['o'][:, 1:, :]
@@ -188,7 +192,26 @@ class OracleDDPG:
             self.g_stats.recompute_stats()
 
     # ------------------------------------------------------------------ sampling
+    def _finish_batch(self, transitions):
+        o, o_2, g = transitions['o'], transitions['o_2'], transitions['g']
+        ag, ag_2 = transitions['ag'], transitions['ag_2']
+        transitions['o'], transitions['g'] = preprocess_og(o, ag, g, self.clip_obs, self.relative_goals)
+        transitions['o_2'], transitions['g_2'] = preprocess_og(o_2, ag_2, g, self.clip_obs, self.relative_goals)
+        return [transitions[k] for k in STAGE_KEYS]                  # ddpg.py:350-358
+
     def sample_batch(self):
+        if not (('buffer' in self.task_replay) or self.task_replay == 'hand_designed'):
+            # single buffer (ddpg.py:288-299): the sampler picks the replay task itself
+            proba = None
+            if self.task_replay == 'replay_cp_task_transition':
+                CP = np.asarray(self.cp, dtype=np.float64).copy()
+                if CP.sum() == 0:
+                    proba = (1 / self.nb_tasks) * np.ones([self.nb_tasks])
+                else:
+                    proba = self.eps_task * (1 / self.nb_tasks) * np.ones([self.nb_tasks]) + \
+                        (1 - self.eps_task) * CP / CP.sum()
+                proba[-1] = 1 - proba[:-1].sum()
+            return self._finish_batch(self.buffer.sample(self.batch_size, task_to_replay=None, cp_proba=proba))
         sizes = np.array([self.buffer[i].current_size * self.T for i in range(self.nb_tasks + 1)])
         if self.structure == 'curious':
             self.proportions = buffer_proportions(sizes, self.T, self.batch_size, self.task_replay,

@@ -332,3 +332,99 @@ def test_task_experts_share_buffers_and_match_oracle():
         np.random.seed(50 + t_id)
         cl, _ = experts[t_id].train()
         assert abs(float(cl) - float(ql)) <= 1e-5 * abs(float(ql))
+
+
+@pytest.mark.parametrize('task_replay', ['replay_cp_task_transition', 'replay_random_task_transition',
+                                         'replay_current_task_transition'])
+def test_single_buffer_replay_modes_match_oracle(task_replay):
+    """The single-buffer task-replay strategies (train.py:38-45, her.py:138-164, ddpg.py:288-299)."""
+    from curious_amd.ddpg import DDPG
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import ReplayBuffer
+    from oracle import her as oher
+    from oracle.ddpg import OracleDDPG
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    from oracle.reward import make_reward_fun
+    nb, dimo, G = 4, 40, 12
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    sampler = make_sample_multi_task_her_transitions('her', 4, task_replay,
+                                                     sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    buf = ReplayBuffer(shapes, T * 48, T, sampler)
+    gamma = 1. - 1. / T
+    agent = DDPG(input_dims=dims, hidden=64, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
+                 polyak=0.95, batch_size=128, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1.,
+                 action_l2=1., clip_obs=200., scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None,
+                 relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                 sample_transitions=sampler, gamma=gamma, buffers=buf, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
+                 task_replay=task_replay, eps_task=0.4, structure='curious', seed=4)
+    osampler = oher.make_sample_multi_task_her_transitions('her', 4, task_replay, make_reward_fun(ag_ids, g_ids),
+                                                           tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    oracle = OracleDDPG(dims, T, OBuf(shapes, T * 48, T, osampler), osampler, ag_ids, g_ids, hidden=64,
+                        batch_size=128, task_replay=task_replay, weight_rng=np.random.RandomState(4))
+    rng = np.random.RandomState(6)
+    cp = np.array([0.3, 0.0, 0.1, 0.2])
+    for k in range(2):                                                 # 2 x 30 episodes into 48 slots -> overflow
+        ep = synth_episodes(rng, 30, nb, dimo)
+        np.random.seed(20 + k)
+        agent.store_episode({k2: v.copy() for k2, v in ep.items()}, cp, 30)
+        np.random.seed(20 + k)
+        oracle.store_episode({k2: v.astype(np.float64) for k2, v in ep.items()}, cp, 30)
+    assert agent.buffer.current_size == oracle.buffer.current_size == 48
+    E = 48
+    for key, v in agent.buffer.buffers.items():
+        np.testing.assert_array_equal(v[:E].cpu().numpy().astype(np.float64), oracle.buffer.buffers[key][:E])
+    np.random.seed(77)
+    got = [x.cpu().numpy() for x in agent.sample_batch()]
+    s1 = np.random.uniform()
+    np.random.seed(77)
+    want = oracle.sample_batch()
+    s2 = np.random.uniform()
+    assert s1 == s2
+    for name, a, b in zip(['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r'], got, want):
+        np.testing.assert_array_equal(a.astype(np.float64), np.asarray(b, dtype=np.float64), err_msg=name)
+    np.random.seed(78)
+    ql, _ = oracle.train()
+    np.random.seed(78)
+    cl, _ = agent.train()
+    assert abs(float(cl) - float(ql)) <= 1e-5 * abs(float(ql))
+
+
+def test_generic_env_path_drives_gpu_agent():
+    """Real-env adapter flow: a Python list of host envs (here the NumPy oracle arm) stepped by the
+    reference's loop, actions from the GPU policy, NumPy episode dicts stored and trained on."""
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    from oracle.env import SyntheticMultiTaskArm
+    agent, oracle = build_pair(4, 40, batch_size=64)
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+    counter = [0]
+
+    def make_env():
+        e = SyntheticMultiTaskArm(4, 40, T, seed=3, env_id=counter[0])
+        counter[0] += 1
+        return e
+    np.random.seed(5)
+    w = RolloutWorker(make_env, agent, dims, logger, T=T, rollout_batch_size=3, noise_eps=0.2, random_eps=0.3,
+                      structure='curious', task_selection='active_competence_progress', queue_length=6, eval=False)
+    assert not w.batched
+    for c in range(3):
+        ep, CP, n_ep = w.generate_rollouts()
+        assert ep['o'].shape == (3, T + 1, 40) and ep['o'].dtype == np.float32 and ep['change'].dtype == bool
+        assert np.abs(ep['u']).max() <= 1.0
+        agent.store_episode(ep, CP, n_ep)
+    assert agent.buffer[1].current_size > 0                           # the gripper moved: Reach episodes stored
+    ev = RolloutWorker(make_env, agent, dims, logger, T=T, rollout_batch_size=2, exploit=True, compute_Q=True,
+                       structure='curious', task_selection='active_competence_progress', queue_length=6, eval=True)
+    ev.generate_rollouts()
+    assert np.isfinite(ev.current_mean_Q())
+    first = None
+    for k in range(20):
+        cl, _ = agent.train()
+        first = float(cl) if first is None else first
+    agent.update_target_net()
+    assert np.isfinite(float(cl)) and float(cl) < first
