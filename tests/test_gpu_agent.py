@@ -428,3 +428,47 @@ def test_generic_env_path_drives_gpu_agent():
         first = float(cl) if first is None else first
     agent.update_target_net()
     assert np.isfinite(float(cl)) and float(cl) < first
+
+
+def test_training_state_checkpoint_resumes_bit_exactly(tmp_path):
+    """save -> continue == load into a fresh job -> continue (parameters, Adam state, buffers, queues)."""
+    from curious_amd.checkpoint import load_training_state, save_training_state
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+
+    def job():
+        agent, _ = build_pair(4, 40, rng_mode='device', use_graph=True, batch_size=64, hidden=64)
+        w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=8,
+                          noise_eps=0.2, random_eps=0.3, structure='curious',
+                          task_selection='active_competence_progress', queue_length=6, eval=False)
+        w.seed(11)
+        return agent, w
+
+    def cycles(agent, w, n):
+        for _ in range(n):
+            ep, cp, n_ep = w.generate_rollouts()
+            agent.store_episode(ep, cp, n_ep)
+            for _ in range(7):
+                agent.train()
+            agent.update_target_net()
+    a1, w1 = job()
+    np.random.seed(123)
+    cycles(a1, w1, 3)
+    path = str(tmp_path / 'state.pt')
+    save_training_state(path, a1, [w1])
+    cycles(a1, w1, 2)
+    a2, w2 = job()
+    np.random.seed(999)                                               # overwritten by the checkpoint
+    load_training_state(path, a2, [w2])
+    cycles(a2, w2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(a1.theta, a2.theta) and torch.equal(a1.theta_target, a2.theta_target)
+    assert torch.equal(a1._m, a2._m) and torch.equal(a1._v, a2._v)
+    assert torch.equal(a1.o_stats.state, a2.o_stats.state)
+    assert a1.Q_adam.t == a2.Q_adam.t == 35 and w1.n_episodes == w2.n_episodes
+    for b1, b2 in zip(a1.buffer[1:], a2.buffer[1:]):
+        assert b1.current_size == b2.current_size
+        assert torch.equal(b1.records[:b1.current_size], b2.records[:b2.current_size])
+    np.testing.assert_array_equal(w1.p, w2.p)
