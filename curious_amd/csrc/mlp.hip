@@ -24,6 +24,8 @@
 #include <math.h>
 
 #include "common.h"
+#include "env_body.h"
+#include "noise_body.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1234,6 +1236,55 @@ __global__ __launch_bounds__(256) void actor_dz_kernel(ActorDzArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ fused acting step of the batched rollout
+// Actor output layer + max_u*tanh + exploration noise + clip + eps-greedy + one synthetic-env step, one wavefront per
+// environment: replaces head_fwd_kernel + action_noise_kernel + env_step_kernel (3 dependent launches -> 1 per env step).
+struct ActStepArgs {
+  const float* a_last;      // actor last hidden activation [n, H]
+  const float* Wout; const float* bout;
+  int32_t H, U, n;
+  float max_u_f;
+  double noise_scale, random_eps, max_u;
+  uint64_t seed, counter;
+  float* u_out; int32_t ldu;                 // actions as given to the env (also recorded in the episode row)
+  curious_env_cfg_t E; curious_layout_t L;
+  int32_t env_id0, t, off_change, off_success;
+  const int32_t* episode; const int32_t* tasks;
+  float* o; float* ag; const float* g; const float* td; float* staging;
+  double reward_eps;
+};
+
+__global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
+  __shared__ float s_u[4][MAX_U];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= a.n) return;
+  float o_[MAX_U];
+#pragma unroll
+  for (int d = 0; d < MAX_U; ++d) o_[d] = 0.f;
+  const float* hrow = a.a_last + (int64_t)e * a.H;
+  const bool al = (((uintptr_t)hrow | (uintptr_t)a.Wout) & 15) == 0;
+  if (al && a.U == 4) row_dot_fast<4>(hrow, a.Wout, a.H, lane, o_);
+  else row_dot(hrow, a.Wout, a.H, a.U, lane, o_);
+  if (lane < a.U) {
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < MAX_U; ++d)
+      if (d == lane) v = o_[d];
+    v = a.max_u_f * tanhf(v + a.bout[lane]);                  // actor_critic.py:89
+    v = noise_apply(v, e * a.U + lane, e, a.noise_scale, a.random_eps, a.max_u, nullptr, nullptr, nullptr, a.seed,
+                    a.counter);                               // ddpg.py:149-152
+    s_u[wave][lane] = v;
+    a.u_out[(int64_t)e * a.ldu + lane] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u[wave], a.t, a.o, a.ag, a.g, a.td, a.staging,
+                a.off_change, a.off_success, a.reward_eps, e, lane);
+}
+
 // ================================================================== host side
 struct NetOff {
   int32_t modular, nl, S, G, H, D;
@@ -1536,6 +1587,49 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
     ha.p[0] = head_prob(w.act[4][nl - 1], H, theta + offQ.Wout, theta + offQ.bout, out_Q, n, 1, 0, cfg->max_u);
     if (launch_head_fwd(ha, n, st)) return -2;
   }
+  return 0;
+}
+
+extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                           float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                           uint64_t counter, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                                           const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
+                                           const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
+                                           const float* td, float* staging, int32_t off_change, int32_t off_success,
+                                           double reward_eps, curious_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
+                "curious_policy_act_env_step: NULL argument");
+  CURIOUS_CHECK(!cfg->normalize_obs && cfg->modular, "curious_policy_act_env_step: modular nets without input "
+                                                     "normalisation only (use curious_policy_forward otherwise)");
+  CURIOUS_CHECK(cfg->dimu == 4 && L->dimu == 4 && cfg->dimo == E->dimo && cfg->dimtd == E->ntasks &&
+                    cfg->dimg == 3 * E->ntasks, "curious_policy_act_env_step: network / env dimensions differ");
+  CURIOUS_CHECK(t >= 0 && t < L->T, "curious_policy_act_env_step: t out of range");
+  if (n <= 0) return 0;
+  hipStream_t st = as_stream(stream);
+  Ws w = carve(cfg, n, workspace);
+  NetOff offPi = net_off(cfg, false);
+  const int H = cfg->hidden, nl = cfg->layers;
+  ObsIn in;
+  memset(&in, 0, sizeof(in));
+  in.o = o; in.ldo = E->dimo; in.td = td; in.ldtd = E->ntasks; in.g = g; in.ldg = 3 * E->ntasks;
+  in.clip = clip_obs;
+  const float* thPi = theta + pi_offset(cfg);
+  Chain a;
+  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2];
+  if (forward_chains(cfg, &a, 1, n, st)) return -2;
+  ActStepArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a_last = w.act[2][nl - 1]; k.Wout = thPi + offPi.Wout; k.bout = thPi + offPi.bout;
+  k.H = H; k.U = cfg->dimu; k.n = n; k.max_u_f = cfg->max_u;
+  k.noise_scale = noise_scale; k.random_eps = random_eps; k.max_u = (double)cfg->max_u;
+  k.seed = seed; k.counter = counter; k.u_out = u_out; k.ldu = ldu;
+  k.E = *E; k.L = *L; k.env_id0 = env_id0; k.t = t; k.off_change = off_change; k.off_success = off_success;
+  k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
+  k.reward_eps = reward_eps;
+  { ProfScope ps__(CK_ENV_STEP, st);
+    hipLaunchKernelGGL(act_step_kernel, dim3((n + 3) / 4), dim3(256), 0, st, k); }
+  CURIOUS_LAUNCH_CHECK("act_step_kernel");
   return 0;
 }
 

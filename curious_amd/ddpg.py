@@ -208,6 +208,31 @@ class DDPG(object):
             return [u_h, Q.cpu().numpy()] if compute_Q else u_h
         return [u, Q] if compute_Q else u
 
+    def can_act_and_step(self, env, compute_Q):
+        """The fused acting step applies to the GPU-resident synthetic env in throughput mode."""
+        return (self.rng_mode == 'device' and not compute_Q and self.modular and not self.normalize_obs
+                and not self.relative_goals and self.dimu == 4 and hasattr(env, 'step_all')
+                and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
+
+    def act_and_step(self, env, t, noise_eps=0., random_eps=0., use_target_net=False):
+        """policy.get_actions(...) + env.step(...) for every env of a BatchedSyntheticArm in 4 launches
+        (curious_policy_act_env_step); same numbers as get_actions followed by env.step_all."""
+        n = env.n
+        theta = self.theta_target if use_target_net else self.theta
+        ws = self._act_ws.get(n)
+        if ws is None:
+            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+            self._act_ws[n] = ws
+        if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
+            self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+        self._noise_counter += 1
+        from curious_amd.envs import REWARD_EPS
+        ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
+                                self.seed * 2654435761 + 12345 + dist.rank() * 1000003, self._noise_counter,
+                                self._act_u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, t, env.o,
+                                env.ag, env.g, env.td, env.staging, REWARD_EPS)
+        return self._act_u
+
     # ------------------------------------------------------------------ storing
     def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging

@@ -211,7 +211,13 @@ class RolloutWorker:
         env.reset_all(tasks, goals)
         self.count += B
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
+        fused = hasattr(self.policy, 'can_act_and_step') and self.policy.can_act_and_step(env, self.compute_Q)
         for t in range(self.T):
+            if fused:
+                self.policy.act_and_step(env, t, noise_eps=self.noise_eps if not self.exploit else 0.,
+                                         random_eps=self.random_eps if not self.exploit else 0.,
+                                         use_target_net=self.use_target_net)
+                continue
             out = self.policy.get_actions(env.o, env.ag, env.g, task_descr=env.td, compute_Q=self.compute_Q,
                                           noise_eps=self.noise_eps if not self.exploit else 0.,
                                           random_eps=self.random_eps if not self.exploit else 0.,

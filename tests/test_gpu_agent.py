@@ -472,3 +472,28 @@ def test_training_state_checkpoint_resumes_bit_exactly(tmp_path):
         assert b1.current_size == b2.current_size
         assert torch.equal(b1.records[:b1.current_size], b2.records[:b2.current_size])
     np.testing.assert_array_equal(w1.p, w2.p)
+
+
+def test_fused_act_and_step_equals_unfused():
+    """curious_policy_act_env_step == get_actions + env.step_all, bit for bit (throughput mode)."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+    recs = []
+    for fused in (True, False):
+        agent, _ = build_pair(4, 40, rng_mode='device')
+        if not fused:
+            agent.can_act_and_step = lambda env, compute_Q: False
+        w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=37,
+                          noise_eps=0.2, random_eps=0.3, structure='curious',
+                          task_selection='active_competence_progress', queue_length=6, eval=False)
+        w.seed(5)
+        np.random.seed(8)
+        for _ in range(2):
+            ep, _, _ = w.generate_rollouts()
+        torch.cuda.synchronize()
+        recs.append(ep.records.clone())
+    assert torch.equal(recs[0], recs[1])
+    u = recs[0][:, :T, 64:68]
+    assert float(u.abs().max()) <= 1.0 and float(u.abs().sum()) > 0
