@@ -111,26 +111,16 @@ def test_data_parallel_sum_of_gradients_and_mean_of_stats():
     # replicas stay bit-identical (what check_synced asserts, mpi_adam.py:42-50)
     np.testing.assert_array_equal(out[0]['theta'], out[1]['theta'])
     np.testing.assert_array_equal(out[0]['o_mean'], out[1]['o_mean'])
-    # single-process emulation of the same two ranks
-    agents, pending = [], {}
-
-    class Bus:
-        """Lock-step all-reduce between the two in-process agents."""
-        def __init__(self):
-            self.slots = []
+    # single-process emulation of the same two ranks: identical data / sampler streams, gradients summed by hand
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     a0 = _make_agent(0, 2, None)
     a1 = _make_agent(1, 2, None)
-    # normaliser: recompute with the mean of both ranks' local sums -> redo store-time stats jointly
-    # (the agents above already consumed their local stats with comm_size=2 and no all-reduce, i.e. sum/2 of their
-    #  own data; rebuild the expected value from the two agents' recorded per-rank sums)
-    import copy
+    from oracle.optim import adam_update
     for k in range(3):
         b0, b1 = a0.sample_batch(), a1.sample_batch()
         g0, g1 = a0.grads(b0), a1.grads(b1)
         Qg = g0['Q_grad'] + g1['Q_grad']
         pig = g0['pi_grad'] + g1['pi_grad']
-        from oracle.optim import adam_update
         for a in (a0, a1):
             PQ = a.math.P_Q
             th, m, v, a.t_Q = adam_update(a.theta[:PQ], a.m[:PQ], a.v[:PQ], a.t_Q, Qg, a.Q_lr)
