@@ -119,8 +119,7 @@ def prefill(policy, n_eps, seed):
 def cycle(policy, worker):
     episode, cp, n_ep = worker.generate_rollouts()
     policy.store_episode(episode, cp, n_ep)
-    for _ in range(N_BATCHES):
-        policy.train()
+    policy.train_batches(N_BATCHES)                               # = for _ in range(N_BATCHES): policy.train()
     policy.update_target_net()
 
 
@@ -133,20 +132,25 @@ def kernel_flops_bytes(policy, lay):
     hid = nl - 1
     her_bytes_per_transition = ((2 * O + U + G + 2 * c.dimag + N + 0.8 * c.dimag)
                                 + (c.dimag + G + O + N + U + O + G + 1)) * 4          # 1 034 B at Arm4
+    adam_bytes = 28 * (c.P_Q + c.P_pi)
     return dict(
-        # hidden layers (256^3 GEMMs): 3 + 2 chains forward per update; the actor chain per env step
-        fwd_hot_kernel=dict(bound='mfma', per_update=5 * hid * 2 * B * H * H, launches_update=2 * hid,
+        # hidden layers (256^3 GEMMs): level A (3 chains, layers 1..) + level B (2 chains, layers 2..) per update;
+        # the actor chain per env step
+        fwd_hot_kernel=dict(bound='mfma', per_update=(5 * hid - 2) * 2 * B * H * H, launches_update=2 * hid - 1,
                             per_env_step=hid * 2 * B_R * H * H, launches_env_step=hid),
-        # layer 0 (K = 56..60)
-        fwd_l0_kernel=dict(bound='mfma', per_update=2 * B * H * (3 * Kc + 2 * Ka), launches_update=2,
-                              per_env_step=2 * B_R * H * Ka, launches_env_step=1),
-        dx_hot_kernel=dict(bound='mfma', per_update=(3 * hid - 2) * 2 * B * H * H, launches_update=2 * hid - 1),
+        # layer 0 (K = 56..60): 3 chains + the 2 action-free pre-activations of level B in one launch
+        fwd_l0_kernel=dict(bound='mfma', per_update=2 * B * H * (Kc + 4 * Ka), launches_update=1,
+                           per_env_step=2 * B_R * H * Ka, launches_env_step=1),
+        # level B layer 1 with the actor heads and the action rows of layer 0 in its prologue
+        fwd_pi_kernel=dict(bound='mfma', per_update=2 * (2 * B * H * H + 4 * B * H * U), launches_update=1),
+        dx_hot_kernel=dict(bound='mfma', per_update=(3 * hid - 3) * 2 * B * H * H, launches_update=2 * hid - 2),
         dx_crit_kernel=dict(bound='mfma', per_update=2 * 2 * B * H * H + 3 * 2 * B * H, launches_update=1),
-        dw_hot_kernel=dict(bound='mfma', per_update=2 * hid * 2 * B * H * H, launches_update=1),
-        dw_small_kernel=dict(bound='mfma', per_update=2 * B * H * (Kc + Ka) + 2 * B * H * (1 + U),
-                             launches_update=1),
-        her_sample_kernel=dict(bound='hbm', per_update=her_bytes_per_transition * B, launches_update=1),
-        adam_kernel=dict(bound='hbm', per_update=28 * (c.P_Q + c.P_pi), launches_update=1),
+        dx_actor_kernel=dict(bound='mfma', per_update=2 * B * H * H + 4 * B * H * U, launches_update=1),
+        # every weight gradient + Adam (28 B/param) + the next HER gather in one launch; priced on its MFMA work
+        dw_adam_her_kernel=dict(bound='mfma', per_update=2 * hid * 2 * B * H * H + 2 * B * H * (Kc + Ka)
+                                + 2 * B * H * (1 + U), launches_update=1,
+                                hbm_bytes_per_update=adam_bytes + her_bytes_per_transition * B),
+        her_sample_kernel=dict(bound='hbm', per_update=0, launches_update=0),
     )
 
 
@@ -347,8 +351,7 @@ def main():
             torch.cuda.synchronize(); b = time.perf_counter()
             policy.store_episode(episode, cp, n_ep)
             torch.cuda.synchronize(); c = time.perf_counter()
-            for _ in range(N_BATCHES):
-                policy.train()
+            policy.train_batches(N_BATCHES)
             policy.update_target_net()
             torch.cuda.synchronize(); d = time.perf_counter()
             tr += b - a; ts += c - b; tu += d - c

@@ -60,6 +60,19 @@ class NetCfg(C.Structure):
                 ('clip_pos_returns', C.c_int32), ('normalize_obs', C.c_int32), ('norm_clip', C.c_float)]
 
 
+class AdamState(C.Structure):
+    _fields_ = [('m', C.c_void_p), ('v', C.c_void_p), ('alpha_tab', C.c_void_p), ('tab_base', C.c_int64),
+                ('tab_len', C.c_int32), ('alpha_Q', C.c_float), ('alpha_pi', C.c_float), ('beta1', C.c_float),
+                ('one_minus_beta1', C.c_float), ('beta2', C.c_float), ('one_minus_beta2', C.c_float),
+                ('epsilon', C.c_float)]
+
+
+class NextBatch(C.Structure):
+    _fields_ = [('storage', C.c_void_p), ('buf_stride', C.c_int64), ('L', C.POINTER(Layout)),
+                ('tasks', C.POINTER(Tasks)), ('P', C.POINTER(SampleParams)), ('rng', C.POINTER(SampleRng)),
+                ('batch', C.c_void_p)]
+
+
 class EnvCfg(C.Structure):
     _fields_ = [('ntasks', C.c_int32), ('dimo', C.c_int32), ('T', C.c_int32), ('seed', C.c_uint64)]
 
@@ -91,6 +104,8 @@ PROTOTYPES = {
     'curious_workspace_floats': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_ddpg_grads': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
                                      _P, _P, _P, _P]),
+    'curious_ddpg_update': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
+                                      _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
     'curious_policy_forward': (C.c_int, [C.POINTER(NetCfg), _P, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _F,
                                          _I32, _P, _P, _P, _P, _P, _P]),
     'curious_action_noise': (C.c_int, [_P, _I32, _I32, _I32, _D, _D, _D, _P, _P, _P, _U64, _U64, _P]),

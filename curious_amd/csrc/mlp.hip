@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "env_body.h"
+#include "her_body.h"
 #include "noise_body.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -496,7 +497,59 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
 }
 
 
+
 // ================================================================== lean kernels for the hot 256-wide layers
+// Adam applied where the gradient is produced (curious_ddpg_update, single-rank): the workgroup that finishes a tile
+// of dW / db owns the matching elements of theta, m and v, so the optimiser needs no launch of its own.  Arithmetic and
+// step-size lookup are those of optim.hip's adam_body (mpi_adam.py:29-35), bit for bit.
+struct AdamFuse {
+  float* theta; float* m; float* v;
+  const float* grad;              // base of the gradient vector: (gradient pointer - grad) = parameter index
+  int64_t n_Q;
+  const float* alpha_tab; const int64_t* step_ctr; int64_t tab_base; int32_t tab_len;
+  float a_Q, a_pi, b1, omb1, b2, omb2, eps;
+};
+
+__device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi) {
+  aQ = A.a_Q; aPi = A.a_pi;
+  if (A.alpha_tab) {
+    int64_t idx = ((*A.step_ctr) - 1 - A.tab_base) % A.tab_len;
+    if (idx < 0) idx += A.tab_len;
+    aQ = A.alpha_tab[2 * idx];
+    aPi = A.alpha_tab[2 * idx + 1];
+  }
+}
+
+__device__ inline float adam_elem(const AdamFuse& A, float na, float g, float& m, float& v, float th) {
+  m = __fadd_rn(__fmul_rn(A.b1, m), __fmul_rn(A.omb1, g));                       // mpi_adam.py:31
+  v = __fadd_rn(__fmul_rn(A.b2, v), __fmul_rn(A.omb2, __fmul_rn(g, g)));         // mpi_adam.py:32
+  const float step = fdiv(__fmul_rn(na, m), __fadd_rn(sqrtf(v), A.eps));         // mpi_adam.py:33
+  return __fadd_rn(th, step);                                                    // mpi_adam.py:34
+}
+
+struct AdamPre4 { f32x4 m, v, th; };
+__device__ inline AdamPre4 adam_prefetch4(const AdamFuse& A, int64_t i) {
+  AdamPre4 p;
+  p.m = ldv(A.m + i); p.v = ldv(A.v + i); p.th = ldv(A.theta + i);
+  return p;
+}
+__device__ inline void adam_apply4(const AdamFuse& A, float na, int64_t i, const f32x4& g, AdamPre4& p) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.m[e], v = p.v[e];
+    p.th[e] = adam_elem(A, na, g[e], m, v, p.th[e]);
+    p.m[e] = m; p.v[e] = v;
+  }
+  *reinterpret_cast<f32x4*>(A.m + i) = p.m;
+  *reinterpret_cast<f32x4*>(A.v + i) = p.v;
+  *reinterpret_cast<f32x4*>(A.theta + i) = p.th;
+}
+__device__ inline void adam_apply1(const AdamFuse& A, float na, int64_t i, float g) {
+  float m = A.m[i], v = A.v[i];
+  const float th = adam_elem(A, na, g, m, v, A.theta[i]);
+  A.m[i] = m; A.v[i] = v; A.theta[i] = th;
+}
+
 // Same tiling as the generic kernels above, but with 56-byte problem descriptors, no bounds checks and no segment
 // machinery: tools/gemm_lab.hip measures 3.7 us per launch inside a hipGraph for this form (2.0 us of which is the
 // launch floor of an empty kernel) against 5.5-7 us for the generic form with its 1 KB kernarg.
@@ -585,12 +638,12 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
 struct DwHotArgs { GemmHot p[4]; int32_t tile_end[4]; int32_t nprob; };
-__global__ __launch_bounds__(256) void dw_hot_kernel(DwHotArgs args) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  int pi = 0, t = blockIdx.x;
+template <bool ADAM>
+__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red) {
+  int pi = 0, t = bid;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    if (i + 1 < args.nprob && (int)blockIdx.x >= args.tile_end[i]) { pi = i + 1; t = blockIdx.x - args.tile_end[i]; }
+    if (i + 1 < args.nprob && bid >= args.tile_end[i]) { pi = i + 1; t = bid - args.tile_end[i]; }
   const GemmHot& P = args.p[pi];
   const int nx = P.N >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -598,6 +651,17 @@ __global__ __launch_bounds__(256) void dw_hot_kernel(DwHotArgs args) {
   const int k0 = by * 16, n0 = bx * 64;
   const float* xc = P.A + k0 + j;
   const float* yc = P.B + n0 + 4 * j;
+  // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0)
+  float* const dst = P.C + (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
+  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
+  AdamPre4 pre;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  if (ADAM) {
+    adam_alphas(A, aQ, aPi);
+    pre = adam_prefetch4(A, pidx);
+    if (by == 0 && tid < 64) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+  }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < P.M; mb += 256) {
@@ -624,7 +688,8 @@ __global__ __launch_bounds__(256) void dw_hot_kernel(DwHotArgs args) {
   }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
-  *reinterpret_cast<f32x4*>(P.C + (int64_t)(k0 + orow) * P.ldc + n0 + 4 * c4) = v;
+  *reinterpret_cast<f32x4*>(dst) = v;
+  if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx, v, pre);
   if (by == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -636,7 +701,14 @@ __global__ __launch_bounds__(256) void dw_hot_kernel(DwHotArgs args) {
     __syncthreads();
     if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
     __syncthreads();
-    if (tid < 64) P.aux_out[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    if (tid < 64) {
+      const float gb = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+      P.aux_out[n0 + tid] = gb;
+      if (ADAM) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+      }
+    }
   }
 }
 
@@ -652,13 +724,13 @@ struct DwSmall {
 #define MAX_DW_SMALL 12
 struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M; LossFin fin; };
 
-__global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+template <bool ADAM>
+__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  int pi = 0, t = blockIdx.x;
+  int pi = 0, t = bid;
   for (int i = 0; i + 1 < args.nprob; ++i)
-    if ((int)blockIdx.x >= args.p[i].tile_end) { pi = i + 1; t = blockIdx.x - args.p[i].tile_end; }
-  if ((int)blockIdx.x >= args.p[args.nprob - 1].tile_end) {
+    if (bid >= args.p[i].tile_end) { pi = i + 1; t = bid - args.p[i].tile_end; }
+  if (bid >= args.p[args.nprob - 1].tile_end) {
     // extra last block (only launched when fin.rows != NULL): losses (ddpg.py:439-441) from the per-row terms,
     // summed in a fixed order
     const LossFin& F = args.fin;
@@ -696,6 +768,8 @@ __global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
   const bool yv = (P.N & 3) == 0;
   const int colc = yv ? min(col, P.N - 4) : min(col, P.N - 1);
   const float* yc = P.dY + colc;
+  float aQ = 0.f, aPi = 0.f;
+  if (ADAM) adam_alphas(A, aQ, aPi);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < args.M; mb += 256) {
@@ -734,12 +808,21 @@ __global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
   const int grow = k0 + orow, gcol = n0 + 4 * c4;
   if (grow < P.w && gcol < P.N) {
     float* dst = P.dW + (int64_t)grow * P.N + gcol;
+    const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+    const float na = (pidx < A.n_Q) ? -aQ : -aPi;
     if (yv) {
       *reinterpret_cast<f32x4*>(dst) = v;
+      if (ADAM) {
+        AdamPre4 pre = adam_prefetch4(A, pidx);
+        adam_apply4(A, na, pidx, v, pre);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (gcol + e < P.N) dst[e] = v[e];
+        if (gcol + e < P.N) {
+          dst[e] = v[e];
+          if (ADAM) adam_apply1(A, na, pidx + e, v[e]);
+        }
     }
   }
   if (P.db && by == 0) {
@@ -753,18 +836,48 @@ __global__ __launch_bounds__(256) void dw_small_kernel(DwSmallArgs args) {
     __syncthreads();
     if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
     __syncthreads();
-    if (tid < 64 && n0 + tid < P.N) P.db[n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    if (tid < 64 && n0 + tid < P.N) {
+      const float gb = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+      P.db[n0 + tid] = gb;
+      if (ADAM) {
+        const int64_t bidx = (int64_t)(P.db + n0 + tid - A.grad);
+        adam_apply1(A, (bidx < A.n_Q) ? -aQ : -aPi, bidx, gb);
+      }
+    }
   }
 }
 
+
+// Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
+// hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
+// launches only bought a second ~4.5 us dependent stage).
+struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
+__global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  AdamFuse none;
+  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red);
+  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red);
+}
+
+// The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
+// applied in the tile epilogue, the loss finalisation, and -- in the first n_her blocks -- the HER gather of the NEXT
+// update's batch (it depends on nothing this update computes; it must target a different staging buffer than the one
+// the layer-0 gradient tiles of this launch still read).
+__global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int bid = (int)blockIdx.x - n_her;
+  if (bid < 0) her_sample_body(h, blockIdx.x, red);
+  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red);
+  else dw_small_body<true>(args.small, A, bid - args.n_hot, red);
+}
 
 // ------------------------------------------------------------------ lean layer-0 forward (total K <= 64)
 // Y[M,N] = relu(sum_seg (clip(X_seg) / div) . W_seg + bias): the input is a virtual concatenation of up to 4 column
 // segments of row matrices (batch columns [o | td | u], the actor output, g ...), each a multiple of 4 wide.  With
 // K <= 64 every wave owns exactly one 16-wide chunk: 1 + 4 loads and 16 MFMAs per wave.
 struct SegL { const float* x; const float* W; int32_t ld, w; float div, clip; };
-struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy; };
-struct L0Args { L0Prob p[3]; };
+struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy, relu; };
+struct L0Args { L0Prob p[5]; };
 
 __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
@@ -817,16 +930,42 @@ __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
   if (m0 + orow >= P.M) return;
   v += bias;
+  if (P.relu) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
   *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
 }
 
 // ------------------------------------------------------------------ one-wave-per-row kernels
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+// Sum over the 64 lanes of a wavefront, result uniform.  Four DPP steps (quad xor 1, quad xor 2, half-row mirror, row
+// mirror) leave the sum of each 16-lane row in all its lanes -- plain VALU moves, no LDS crossbar round trips; the four
+// row sums are then read as scalars.  (The ds_bpermute butterfly this replaces cost ~30 ns per dependent step; the
+// fused prologues below run 16 of these reductions.)
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ inline float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
   return v;
+}
+__device__ inline float lane_read(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ inline float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_read(v, 0) + lane_read(v, 16)) + (lane_read(v, 32) + lane_read(v, 48));
+}
+// lane i < 16 gets vals[i] (uniform inputs): lets ONE lane per value do the expensive scalar math of a prologue
+__device__ inline float pick16(const float (&vals)[16], int lane) {
+  float m = vals[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = (lane == i) ? vals[i] : m;
+  return m;
 }
 
 // out[m][d] = f(sum_k h[m][k] W[k][d] + b[d]),  D <= MAX_U
@@ -914,6 +1053,98 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs args) {
     P.out[(int64_t)m * P.ldo + lane] = v;
   }
 }
+
+// Layer 1 of the two critic(pi) passes with the actor output layer and the critic's layer 0 folded into its prologue
+// (replaces head_fwd_kernel + a second fwd_l0_kernel: two ~4.5 us dependent stages per update).  The first layer-0
+// launch already produced zp = [o | td] . W0 + g . Wg + b0 (everything but the action rows, no relu).  Every workgroup
+// recomputes pi = max_u * tanh(a_last . Wout + bout) for its 16 batch rows (a wavefront per row, the arithmetic and
+// order of head_fwd_kernel), builds its A operand  h0[m][k] = relu(zp[m][k] + sum_d (pi[m][d] / max_u) * Wu[d][k])
+// on the fly and runs the usual split-K tile.  Column-tile 0 writes pi and h0 for the backward pass.  H == 256, dimu == 4.
+struct FwdPiProb {
+  const float* a_last; const float* WoutPi; const float* boutPi;
+  const float* zp; const float* Wu; const float* W1; const float* b1;
+  float* pi_out; float* h0_out; float* C;
+};
+struct FwdPiArgs { FwdPiProb p[2]; float max_u; };
+
+__global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float s_pi[16 * 4];
+  const FwdPiProb& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const int H = 256;
+  const int pm = m0 + 4 * wave;
+  // ---- all loads
+  f32x4 pr_h[4], wp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pr_h[r] = ldv(P.a_last + (int64_t)(pm + r) * H + 4 * lane);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wp[e] = ldv(P.WoutPi + (int64_t)(4 * lane + e) * 4);
+  const float bo = P.boutPi[lane & 3];
+  const float* xr = P.zp + (int64_t)(m0 + j) * H;
+  const float* wc = P.W1 + n0 + 4 * j;
+  const f32x4 bias = ldv(P.b1 + n0 + 4 * (tid & 15));
+  f32x4 z[4], wu[4][4], b[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kq = (wave + 4 * u) * 16 + 4 * q;
+    z[u] = ldv(xr + kq);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) wu[u][d] = ldv(P.Wu + (int64_t)d * H + kq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[u][s] = ldv(wc + (int64_t)(kq + s) * H);
+  }
+  LOADS_FIRST();
+  // ---- prologue: actor output layer of this wave's 4 rows; lane 4r+d finishes pi[pm + r][d]
+  {
+    float sums[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += pr_h[r][e] * wp[e][d];
+        sums[4 * r + d] = wave_sum(acc);
+      }
+    const float mine = pick16(sums, lane);
+    if (lane < 16) {
+      const float pv = args.max_u * tanhf(mine + bo);           // actor_critic.py:89
+      s_pi[16 * wave + lane] = pv;
+      if (blockIdx.x == 0 && P.pi_out) P.pi_out[(int64_t)pm * 4 + lane] = pv;
+    }
+  }
+  __syncthreads();
+  f32x4 ud = *reinterpret_cast<const f32x4*>(s_pi + 4 * j);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) ud[d] = fdiv(ud[d], args.max_u);  // actor_critic.py:93 (pi_tf / max_u)
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x4 av;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float t = ud[0] * wu[u][0][s] + ud[1] * wu[u][1][s] + ud[2] * wu[u][2][s] + ud[3] * wu[u][3][s];
+      av[s] = fmaxf(z[u][s] + t, 0.f);
+    }
+    if (blockIdx.x == 0 && P.h0_out) {
+      const int kq = (wave + 4 * u) * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(P.h0_out + (int64_t)(m0 + j) * H + kq) = av;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(av[s], b[u][s][e], acc[e]);
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  v += bias;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
+}
+
 
 // Critic output layers of the three critic passes + losses' per-row terms + backward through those output layers.
 struct CriticHeadArgs {
@@ -1042,7 +1273,7 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
     rew[r] = a.r[(int64_t)(pm + r) * a.ldr];
     // sum_j (pi_j / max_u)^2 of row pm + r: lanes 0..U-1 hold one term each (ddpg.py:441)
     const float pv = (lane < a.U) ? a.pi[(int64_t)(pm + r) * a.ldpi + lane] : 0.f;
-    l2v[r] = pv;
+    l2v[r] = (ch == 1) ? pv : 0.f;
   }
   const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
   const f32x4 hm = ldv(a.hprev[ch] + o);
@@ -1237,6 +1468,98 @@ __global__ __launch_bounds__(256) void actor_dz_kernel(ActorDzArgs a) {
 }
 
 
+// actor_dz_kernel + dx_hot_kernel(actor level nl-1) in one launch, same idea as dx_crit_kernel: every workgroup
+// recomputes dz for its 16 batch rows (a wavefront per row, 4 rows per wave: the arithmetic and its order are those of
+// actor_dz_fast4, so the results are bit-identical), builds the A operand
+//   da2[m][n] = (sum_d dz[m][d] * WoutPi[n][d]) * relu'(a2[m][n])
+// on the fly and runs the split-K tile against main/pi's layer nl-1 kernel.  Column-tile 0 writes dz and da2, which
+// the weight-gradient launch reads.  H == 256, dimu == 4.
+struct DxActorArgs {
+  const float* dd0; const float* Wu; const float* pi; const float* a2; const float* WoutPi;
+  const float* hprev;      // actor activations one layer below a2 (relu mask of the result)   [B,H]
+  const float* W;          // main/pi kernel of layer nl-1                                     [H,H]
+  float* dz; float* da2; float* dX;
+  int32_t B;
+  float max_u, l2c;
+};
+
+__global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float s_dz[16 * 4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+  const int H = 256;
+  const int pm = m0 + 4 * wave;
+  // ---- all loads
+  f32x4 g4[4], wu[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g4[r] = ldv(a.dd0 + (int64_t)(pm + r) * H + 4 * lane);
+  const float pim = a.pi[(int64_t)pm * 4 + (lane & 15)];      // lane 4r+d: pi[pm + r][d]
+#pragma unroll
+  for (int d = 0; d < 4; ++d) wu[d] = ldv(a.Wu + (int64_t)d * H + 4 * lane);
+  const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
+  const f32x4 hm = ldv(a.hprev + o);
+  const float* hrow = a.a2 + (int64_t)(m0 + j) * H;
+  const float* wr = a.W + (int64_t)(k0 + 4 * j) * H;
+  f32x4 hv[4], wo[4][4], b[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int nq = (wave + 4 * u) * 16 + 4 * q;
+    hv[u] = ldv(hrow + nq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wo[u][s] = ldv(a.WoutPi + (int64_t)(nq + s) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
+  }
+  LOADS_FIRST();
+  // ---- prologue: dz of this wave's 4 rows; lane 4r+d finishes dz[pm + r][d]
+  {
+    float sums[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float acc = 0.f;
+        acc += g4[r][0] * wu[d][0] + g4[r][1] * wu[d][1] + g4[r][2] * wu[d][2] + g4[r][3] * wu[d][3];
+        sums[4 * r + d] = wave_sum(acc);
+      }
+    const float v = pick16(sums, lane);
+    if (lane < 16) {
+      const float th = pim / a.max_u;
+      const float dpi = v / a.max_u + a.l2c * pim;              // ddpg.py:440-441
+      const float dz = dpi * a.max_u * (1.0f - th * th);        // through pi = max_u * tanh(z)
+      s_dz[16 * wave + lane] = dz;
+      if (blockIdx.x == 0) a.dz[(int64_t)pm * 4 + lane] = dz;
+    }
+  }
+  __syncthreads();
+  const f32x4 dzr = *reinterpret_cast<const f32x4*>(s_dz + 4 * j);
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x4 av;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float sv = dzr[0] * wo[u][s][0] + dzr[1] * wo[u][s][1] + dzr[2] * wo[u][s][2] + dzr[3] * wo[u][s][3];
+      av[s] = (hv[u][s] > 0.f) ? sv : 0.f;
+    }
+    if (blockIdx.x == 0) {
+      const int nq = (wave + 4 * u) * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(a.da2 + (int64_t)(m0 + j) * H + nq) = av;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(av[s], b[u][e][s], acc[e]);
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (hm[e] > 0.f) ? v[e] : 0.f;
+  *reinterpret_cast<f32x4*>(a.dX + o) = v;
+}
+
+
 // ------------------------------------------------------------------ fused acting step of the batched rollout
 // Actor output layer + max_u*tanh + exploration noise + clip + eps-greedy + one synthetic-env step, one wavefront per
 // environment: replaces head_fwd_kernel + action_noise_kernel + env_step_kernel (3 dependent launches -> 1 per env step).
@@ -1343,6 +1666,7 @@ struct Ws {   // workspace carve-up
   float* act[5][MAX_LAYERS];   // chains: 0 target actor, 1 main critic(u), 2 main actor, 3 target critic, 4 main critic(pi)
   float* dact[3][MAX_LAYERS];  // gradient wrt hidden activations: 0 critic(u), 1 critic(pi), 2 actor
   float *pi_t, *pi, *dQ, *dz, *rows;
+  float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
   int64_t total;
 };
 
@@ -1364,6 +1688,8 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.dz = take((int64_t)B * c->dimu);
   w.dQ = take(B);
   w.rows = take(3 * (int64_t)B);
+  w.zp[0] = take(BH);
+  w.zp[1] = take(BH);
   w.total = off;
   return w;
 }
@@ -1446,9 +1772,32 @@ struct Chain {
 
 static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
 
-static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M, hipStream_t st) {
+// Fills the lean layer-0 descriptor of one chain; false when the lean kernel does not apply.
+static bool l0_lean_prob(const curious_net_cfg_t* c, const Chain& C, bool with_u, bool relu, float* Y, int M,
+                         L0Prob& p) {
+  Seg seg[MAX_SEG];
   const int H = c->hidden;
-  for (int l = 0; l < c->layers; ++l) {
+  const int ns = l0_segments(c, C.off, C.theta, C.in, with_u, c->max_u, seg);
+  bool lean = (H % 64 == 0);
+  int ktot = 0;
+  for (int s = 0; s < ns; ++s) {
+    const Seg& sg = seg[s];
+    if (!sg.vec || sg.w % 4 != 0 || sg.sub || sg.mean || !aligned16(sg.W)) lean = false;
+    p.seg[s].x = sg.x; p.seg[s].W = sg.W; p.seg[s].ld = sg.ld; p.seg[s].w = sg.w; p.seg[s].div = sg.div;
+    p.seg[s].clip = sg.clip > 0.0f ? sg.clip : 0.0f;
+    ktot += sg.w;
+  }
+  if (ktot > 64 || !aligned16(Y) || !aligned16(C.theta + C.off.b0)) lean = false;
+  p.nseg = ns; p.bias = C.theta + C.off.b0; p.Y = Y; p.M = M; p.N = H; p.ldy = H; p.relu = relu ? 1 : 0;
+  return lean;
+}
+
+// `pre`/`npre`: extra layer-0 problems (pre-activations without the action rows, see fwd_pi_kernel) that ride on the
+// layer-0 launch; only valid when the caller has verified that the lean layer-0 kernel applies to every problem.
+static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M, hipStream_t st, int l_begin = 0,
+                          const L0Prob* pre = nullptr, int npre = 0) {
+  const int H = c->hidden;
+  for (int l = l_begin; l < c->layers; ++l) {
     bool hot = (l >= 1) && hot_ok(M, H, H);
     for (int i = 0; i < nch; ++i)
       if (!aligned16(ch[i].theta) || !aligned16(ch[i].act[0])) hot = false;
@@ -1470,28 +1819,15 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
       L0Args la;
       memset(&la, 0, sizeof(la));
       bool lean = true;
-      for (int i = 0; i < nch && lean; ++i) {
-        Chain& C = ch[i];
-        Seg seg[MAX_SEG];
-        const int ns = l0_segments(c, C.off, C.theta, C.in, C.critic, c->max_u, seg);
-        L0Prob& p = la.p[i];
-        int ktot = 0;
-        for (int s = 0; s < ns; ++s) {
-          const Seg& sg = seg[s];
-          if (!sg.vec || sg.w % 4 != 0 || sg.sub || sg.mean || !aligned16(sg.W)) lean = false;
-          p.seg[s].x = sg.x; p.seg[s].W = sg.W; p.seg[s].ld = sg.ld; p.seg[s].w = sg.w; p.seg[s].div = sg.div;
-          p.seg[s].clip = sg.clip > 0.0f ? sg.clip : 0.0f;
-          ktot += sg.w;
-        }
-        if (ktot > 64 || !aligned16(C.act[0]) || !aligned16(C.theta + C.off.b0)) lean = false;
-        p.nseg = ns; p.bias = C.theta + C.off.b0; p.Y = C.act[0]; p.M = M; p.N = H; p.ldy = H;
-      }
+      for (int i = 0; i < nch && lean; ++i) lean = l0_lean_prob(c, ch[i], ch[i].critic, true, ch[i].act[0], M, la.p[i]);
       if (lean) {
-        dim3 grid(H / 64, (M + 15) / 16, nch);
+        for (int i = 0; i < npre; ++i) la.p[nch + i] = pre[i];
+        dim3 grid(H / 64, (M + 15) / 16, nch + npre);
         { ProfScope ps__(CK_FWD_LAYER0, st); hipLaunchKernelGGL(fwd_l0_kernel, grid, dim3(256), 0, st, la); }
         CURIOUS_LAUNCH_CHECK("fwd_l0_kernel");
         continue;
       }
+      CURIOUS_CHECK(npre == 0, "forward_chains: lean layer-0 kernel expected");
     }
     FwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -1627,16 +1963,26 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   k.E = *E; k.L = *L; k.env_id0 = env_id0; k.t = t; k.off_change = off_change; k.off_success = off_success;
   k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
   k.reward_eps = reward_eps;
-  { ProfScope ps__(CK_ENV_STEP, st);
+  { ProfScope ps__(CK_ACT_STEP, st);
     hipLaunchKernelGGL(act_step_kernel, dim3((n + 3) / 4), dim3(256), 0, st, k); }
   CURIOUS_LAUNCH_CHECK("act_step_kernel");
   return 0;
 }
 
-extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
-                                  const float* batch, const curious_batch_layout_t* BL, int32_t B,
-                                  const float* o_stats, const float* g_stats, float* workspace, float* grad,
-                                  float* out_losses, float* out_Q_pi, int64_t* step_ctr, curious_stream_t stream) {
+// What follows the gradients in curious_ddpg_update: Adam (+ the gather of the next batch).
+struct UpdateTail {
+  AdamFuse adam;
+  bool her;
+  HerArgs h;
+  const curious_adam_state_t* st;
+  const curious_next_batch_t* next;
+  int64_t n_pi;
+};
+
+static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
+                           const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
+                           const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                           int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta_main && theta_target && batch && BL && workspace && grad && out_losses && out_Q_pi,
                 "curious_ddpg_grads: NULL argument");
@@ -1670,23 +2016,56 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
   ch[0].theta = ttPi; ch[0].off = offPi; ch[0].in = nxt; ch[0].critic = false; ch[0].act = w.act[0];
   ch[1].theta = thQ; ch[1].off = offQ; ch[1].in = cur; ch[1].critic = true; ch[1].act = w.act[1];
   ch[2].theta = thPi; ch[2].off = offPi; ch[2].in = cur; ch[2].critic = false; ch[2].act = w.act[2];
-  if (forward_chains(cfg, ch, 3, B, st)) return -2;
-  // ---- actor output layers: pi_target, pi
-  {
+  // level B = hidden layers of target critic(pi_target), main critic(pi)
+  Chain cb[2];
+  cb[0].theta = ttQ; cb[0].off = offQ; cb[0].in = nxt; cb[0].in.u = w.pi_t; cb[0].in.ldu = U; cb[0].critic = true;
+  cb[0].act = w.act[3];
+  cb[1].theta = thQ; cb[1].off = offQ; cb[1].in = cur; cb[1].in.u = w.pi; cb[1].in.ldu = U; cb[1].critic = true;
+  cb[1].act = w.act[4];
+  const int64_t urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);   // first action row of W0
+  // Lean route: the action-independent part of level B's layer 0 rides on level A's layer-0 launch, the actor output
+  // layers and the action rows are folded into level B's layer-1 launch (fwd_pi_kernel).
+  L0Prob pre[2];
+  memset(pre, 0, sizeof(pre));
+  bool fuse_pi = nl >= 2 && H == 256 && U == 4 && (B % 16 == 0) && aligned16(thQ) && aligned16(thPi) && aligned16(ttQ) &&
+                 aligned16(ttPi) && aligned16(workspace) && aligned16(thPi + offPi.Wout) &&
+                 aligned16(thQ + offQ.W0 + urow * H);
+  if (fuse_pi) {
+    L0Prob tmp;
+    for (int i = 0; i < 3 && fuse_pi; ++i) fuse_pi = l0_lean_prob(cfg, ch[i], ch[i].critic, true, ch[i].act[0], B, tmp);
+    for (int i = 0; i < 2 && fuse_pi; ++i) fuse_pi = l0_lean_prob(cfg, cb[i], false, false, w.zp[i], B, pre[i]);
+  }
+  if (fuse_pi) {
+    if (forward_chains(cfg, ch, 3, B, st, 0, pre, 2)) return -2;
+    FwdPiArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.max_u = cfg->max_u;
+    for (int i = 0; i < 2; ++i) {
+      FwdPiProb& p = fa.p[i];
+      const float* tq = (i == 0) ? ttQ : thQ;
+      const float* tp = (i == 0) ? ttPi : thPi;
+      p.a_last = w.act[i == 0 ? 0 : 2][nl - 1]; p.WoutPi = tp + offPi.Wout; p.boutPi = tp + offPi.bout;
+      p.zp = w.zp[i]; p.Wu = tq + offQ.W0 + urow * H; p.W1 = tq + offQ.W[1]; p.b1 = tq + offQ.b[1];
+      p.pi_out = (i == 0) ? nullptr : w.pi;                 // pi_target is consumed here only
+      p.h0_out = (i == 0) ? nullptr : w.act[4][0];          // relu mask of the actor-loss backward pass
+      p.C = w.act[i == 0 ? 3 : 4][1];
+    }
+    dim3 grid(H / 64, B / 16, 2);
+    { ProfScope ps__(CK_FWD_PI, st); hipLaunchKernelGGL(fwd_pi_kernel, grid, dim3(256), 0, st, fa); }
+    CURIOUS_LAUNCH_CHECK("fwd_pi_kernel");
+    if (forward_chains(cfg, cb, 2, B, st, 2)) return -2;
+  } else {
+    if (forward_chains(cfg, ch, 3, B, st)) return -2;
+    // ---- actor output layers: pi_target, pi
     HeadFwdArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.nprob = 2;
     ha.p[0] = head_prob(w.act[0][nl - 1], H, ttPi + offPi.Wout, ttPi + offPi.bout, w.pi_t, B, U, 2, cfg->max_u);
     ha.p[1] = head_prob(w.act[2][nl - 1], H, thPi + offPi.Wout, thPi + offPi.bout, w.pi, B, U, 2, cfg->max_u);
     if (launch_head_fwd(ha, B, st)) return -2;
+    // ---- forward level B
+    if (forward_chains(cfg, cb, 2, B, st)) return -2;
   }
-  // ---- forward level B: hidden layers of target critic(pi_target), main critic(pi)
-  Chain cb[2];
-  cb[0].theta = ttQ; cb[0].off = offQ; cb[0].in = nxt; cb[0].in.u = w.pi_t; cb[0].in.ldu = U; cb[0].critic = true;
-  cb[0].act = w.act[3];
-  cb[1].theta = thQ; cb[1].off = offQ; cb[1].in = cur; cb[1].in.u = w.pi; cb[1].in.ldu = U; cb[1].critic = true;
-  cb[1].act = w.act[4];
-  if (forward_chains(cfg, cb, 2, B, st)) return -2;
 
   // ---- critic output layers, per-row loss terms, backward through the output layers (fused with the first hidden
   //      backward level when the lean kernels apply)
@@ -1803,26 +2182,39 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
   // (Measured: running the critic's gradient kernels on a forked side stream -- a parallel branch of the captured
   //  graph -- made every update 70 % SLOWER on this stack, and slowed unrelated eager launches once a second hardware
   //  queue was active; everything therefore stays on the caller's stream.)
-  DwHotArgs hwAll;
-  DwSmallArgs smAll;
-  memset(&hwAll, 0, sizeof(hwAll));
-  memset(&smAll, 0, sizeof(smAll));
+  DwAllArgs dwAll;
+  memset(&dwAll, 0, sizeof(dwAll));
+  DwHotArgs& hwAll = dwAll.hot;
+  DwSmallArgs& smAll = dwAll.small;
   int tAll = 0, stAll = 0;
   bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
   if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
   // ---- into the action slot of critic(pi), through tanh + l2 term -> dz; backward through the actor output layer
-  {
+  //      (fused with the actor's first hidden backward level when the lean kernels apply)
+  const float l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+  const bool fuse_actor = fuse_crit && U == 4 && aligned16(w.pi) && aligned16(w.dz) && aligned16(thQ + offQ.W0 + urow * H) &&
+                          aligned16(thPi + offPi.Wout);
+  if (fuse_actor) {
+    DxActorArgs a;
+    const int l = nl - 1;
+    a.dd0 = w.dact[1][0]; a.Wu = thQ + offQ.W0 + urow * H; a.pi = w.pi;
+    a.a2 = w.act[2][l]; a.WoutPi = thPi + offPi.Wout; a.hprev = w.act[2][l - 1]; a.W = thPi + offPi.W[l];
+    a.dz = w.dz; a.da2 = w.dact[2][l]; a.dX = w.dact[2][l - 1];
+    a.B = B; a.max_u = cfg->max_u; a.l2c = l2c;
+    dim3 grid(H / 64, B / 16, 1);
+    { ProfScope ps__(CK_ACTOR_DZ, st); hipLaunchKernelGGL(dx_actor_kernel, grid, dim3(256), 0, st, a); }
+    CURIOUS_LAUNCH_CHECK("dx_actor_kernel");
+  } else {
     ActorDzArgs a;
-    const int64_t urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);   // first action row of W0
     a.dd0 = w.dact[1][0]; a.Wu = thQ + offQ.W0 + urow * H; a.pi = w.pi; a.ldpi = U;
     a.a2 = w.act[2][nl - 1]; a.WoutPi = thPi + offPi.Wout; a.dz = w.dz; a.da2 = w.dact[2][nl - 1];
     a.B = B; a.H = H; a.U = U; a.max_u = cfg->max_u;
-    a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+    a.l2c = l2c;
     { ProfScope ps__(CK_ACTOR_DZ, st);
       hipLaunchKernelGGL(actor_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("actor_dz_kernel");
   }
-  for (int l = nl - 1; l >= 1; --l) {
+  for (int l = fuse_actor ? nl - 2 : nl - 1; l >= 1; --l) {
     if (dx_hot) {
       HotArgs ha;
       memset(&ha, 0, sizeof(ha));
@@ -1847,14 +2239,19 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
     CURIOUS_LAUNCH_CHECK("dx_kernel(actor)");
   }
   if (lean_dw) {
-    if (hwAll.nprob > 0) {
-      { ProfScope ps__(CK_DW, st); hipLaunchKernelGGL(dw_hot_kernel, dim3(tAll), dim3(256), 0, st, hwAll); }
-      CURIOUS_LAUNCH_CHECK("dw_hot_kernel");
-    }
     smAll.fin = fin;
-    { ProfScope ps__(CK_DW_SMALL, st);
-      hipLaunchKernelGGL(dw_small_kernel, dim3(stAll + 1), dim3(256), 0, st, smAll); }
-    CURIOUS_LAUNCH_CHECK("dw_small_kernel");
+    dwAll.n_hot = tAll;
+    if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
+      const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
+      { ProfScope ps__(CK_DW_ADAM_HER, st);
+        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + stAll + 1), dim3(256), 0, st, dwAll, tail->adam,
+                           tail->h, n_her); }
+      CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
+      return 0;
+    }
+    { ProfScope ps__(CK_DW, st);
+      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + stAll + 1), dim3(256), 0, st, dwAll); }
+    CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
     // generic path: every weight/bias gradient + the loss finalisation in one grouped launch
     DwArgs wa;
@@ -1894,5 +2291,59 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
     { ProfScope ps__(CK_DW_SMALL, st); hipLaunchKernelGGL(dw_kernel, grid, dim3(256), 0, st, wa); }
     CURIOUS_LAUNCH_CHECK("dw_kernel");
   }
+  if (tail) {
+    // the lean gradient launch was not applicable: same result from the stand-alone optimiser (+ gather) launch
+    const curious_adam_state_t* a = tail->st;
+    const float ah[2] = {a->alpha_Q, a->alpha_pi};
+    const int64_t n_Q = pi_offset(cfg);
+    if (tail->her) {
+      const curious_next_batch_t* nx = tail->next;
+      return curious_adam_update_and_sample(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi,
+                                            a->alpha_tab, step_ctr, a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah,
+                                            a->beta1, a->one_minus_beta1, a->beta2, a->one_minus_beta2, a->epsilon,
+                                            nx->storage, nx->buf_stride, nx->L, nx->tasks, nx->P, nx->rng, B, nx->batch,
+                                            BL, stream);
+    }
+    return curious_adam_update(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi, a->alpha_tab, step_ctr,
+                               a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah, a->beta1, a->one_minus_beta1,
+                               a->beta2, a->one_minus_beta2, a->epsilon, stream);
+  }
   return 0;
+}
+
+extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
+                                  const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                                  const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                                  float* out_losses, float* out_Q_pi, int64_t* step_ctr, curious_stream_t stream) {
+  return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
+                         out_Q_pi, step_ctr, stream, nullptr);
+}
+
+extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
+                                   const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                                   const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                                   float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                                   const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                                   curious_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  CURIOUS_CHECK(adam && adam->m && adam->v, "curious_ddpg_update: NULL optimiser state");
+  CURIOUS_CHECK(!adam->alpha_tab || (step_ctr && adam->tab_len > 0), "curious_ddpg_update: step-size table needs step_ctr");
+  UpdateTail t;
+  memset(&t, 0, sizeof(t));
+  t.st = adam; t.next = next;
+  t.n_pi = curious_param_total(cfg) - pi_offset(cfg);
+  AdamFuse& A = t.adam;
+  A.theta = theta_main; A.m = adam->m; A.v = adam->v; A.grad = grad; A.n_Q = pi_offset(cfg);
+  A.alpha_tab = adam->alpha_tab; A.step_ctr = step_ctr; A.tab_base = adam->tab_base; A.tab_len = adam->tab_len;
+  A.a_Q = adam->alpha_Q; A.a_pi = adam->alpha_pi;
+  A.b1 = adam->beta1; A.omb1 = adam->one_minus_beta1; A.b2 = adam->beta2; A.omb2 = adam->one_minus_beta2;
+  A.eps = adam->epsilon;
+  if (next) {
+    CURIOUS_CHECK(next->batch && next->batch != batch, "curious_ddpg_update: the next batch needs its own staging buffer");
+    if (her_fill_args(t.h, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
+                      next->batch, BL)) return -1;
+    t.her = true;
+  }
+  return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
+                         out_Q_pi, step_ctr, stream, &t);
 }

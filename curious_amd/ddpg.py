@@ -27,6 +27,7 @@ from curious_amd.replay_buffer import EpisodeViews, ReplayBuffer, as_records
 from curious_amd.util import import_function, store_args, transitions_in_episode_batch
 
 ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
+CHAIN = 10              # updates per chained hipGraph launch in train_batches (even: the staging tensors alternate)
 
 
 def dims_to_shapes(input_dims):
@@ -82,7 +83,10 @@ class DDPG(object):
         self.cp = np.zeros(self.nb_tasks) if hasattr(self, 'nb_tasks') else None
         self.proportions = None
         self._staged = None
-        self._graph = None
+        self._pp = None                                              # the two staging tensors of the device loop
+        self._cur = 0
+        self._graph = self._graph_b = self._graph_chain = None
+        self._graphs = [None, None]
         self._tables_dirty = True
         self._batch_stale = True
 
@@ -453,7 +457,7 @@ class DDPG(object):
         if self._multi_buffer():
             layout = self._layout
             if self._staged is None or self._staged.shape != (B, layout.batch_stride):
-                self._staged = torch.empty([B, layout.batch_stride], dtype=torch.float32, device=self.device)
+                self._staged = torch.zeros([B, layout.batch_stride], dtype=torch.float32, device=self.device)
             if self.rng_mode == 'device':
                 if self._tables_dirty:
                     self._refresh_device_tables()
@@ -499,7 +503,7 @@ class DDPG(object):
         ep, t, uh, uo, given = S.draw(buf.current_size, self.T, B, cp_proba)
         plan = upload_plan(B, ep, t, uh, uo, buf=np.full(B, buf.pool_index, np.int32), ttr=given)
         if self._staged is None or self._staged.shape != (B, layout.batch_stride):
-            self._staged = torch.empty([B, layout.batch_stride], dtype=torch.float32, device=self.device)
+            self._staged = torch.zeros([B, layout.batch_stride], dtype=torch.float32, device=self.device)
         ops.her_sample(buf.pool.storage, buf.pool.buf_stride, layout, S.tasks, P, B, self._staged, plan=plan)
         self._layout_for_batch = layout
         return self._staged
@@ -543,59 +547,122 @@ class DDPG(object):
         self._alpha_filled = t0 + n
         self._step_ctr.fill_(t0)
 
-    def _train_body(self):
-        self._sample_packed()
-        self._grads()
-        self._update(use_table=True)
+    def _device_loop(self):
+        """The device-resident update loop applies: device-drawn batches from the pooled per-task buffers."""
+        return self.rng_mode == 'device' and self._multi_buffer()
 
     def train(self, stage=True):
         """One update (ddpg.py:368-373).  Returns (critic_loss, actor_loss) as GPU tensors (no host sync);
         actor_loss is main.Q_pi like in the reference (ddpg.py:237-243)."""
-        if self.use_graph and self.rng_mode == 'device' and stage and self._multi_buffer():
-            return self._train_graph()
+        if stage and self._device_loop():
+            return self._train_device(1)
         if stage:
             self.stage_batch()
         critic_loss, actor_loss, Q_grad, pi_grad = self._grads()
         self._update(Q_grad, pi_grad)
         return critic_loss, actor_loss
 
-    def _train_graph(self):
-        """hipGraph replay of one update.  The HER gather of update k+1 rides in the Adam launch of update k
-        (curious_adam_update_and_sample); an explicit gather is issued whenever the buffers or the sampling tables
+    def train_batches(self, n):
+        """`for _ in range(n): policy.train()` (the inner loop of train.py:152-153) -- same updates, same order, same
+        result.  On the single-rank hipGraph path runs of CHAIN updates are replayed as ONE graph launch: a graph
+        boundary costs ~5 us of idle GPU on this stack (tools/graph_chain_probe.py), 7 % of an update."""
+        out = None
+        while n > 0:
+            k = 1
+            if self._device_loop() and self.use_graph and not dist.is_distributed() and n >= CHAIN and self._cur == 0:
+                k = CHAIN
+            out = self._train_device(k) if self._device_loop() else self.train()
+            n -= k
+        return out
+
+    def _train_device(self, k):
+        """k updates of the device-resident loop.  Single rank: each update is curious_ddpg_update -- gradients, Adam in
+        the weight-gradient launch and the HER gather of the NEXT batch riding on that launch -- over two staging
+        tensors used alternately, replayed from hipGraphs when use_graph is set (one graph per parity, plus one for a
+        chain of CHAIN updates).  Several ranks: the gradient all-reduce splits every update into graph A (gradients)
+        and graph B (Adam + next gather).  An explicit gather is issued whenever the buffers or the sampling tables
         changed since the last one, so every batch is still drawn after the latest store_episode."""
         if self._tables_dirty:
             self._refresh_device_tables()
             self._batch_stale = True
-        if self.Q_adam.t + 1 > self._alpha_filled or self._alpha_filled == 0:
+        if self.Q_adam.t + k > self._alpha_filled or self._alpha_filled == 0:
             self._fill_alpha_table()
-        if self._graph is None:
-            self._sample_packed()                                   # allocate / fill the staging tensor before capture
-            if dist.is_distributed():
-                # the all-reduce stays outside: graph A = grads, graph B = Adam + next gather
-                self._graph = self._capture(self._grads)
-                self._graph_b = self._capture(self._adam_and_sample)
+        if self._pp is None:
+            shape = [self.batch_size, self._layout.batch_stride]
+            self._pp = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._cur = 0
+            self._batch_stale = True
+        if self._staged is not self._pp[self._cur]:
+            self._staged = self._pp[self._cur]
+            self._batch_stale = True
+        self._layout_for_batch = self._layout
+        if dist.is_distributed():
+            assert k == 1
+            return self._train_device_ranks()
+        graph = None
+        if self.use_graph:
+            # capturing runs the launches once for real: parameters and counter are restored by _capture, the staged
+            # batch (overwritten by the gathers of a chain) is simply drawn again below
+            if k == 1:
+                if self._graphs[self._cur] is None:
+                    cur = self._cur
+                    self._graphs[cur] = self._capture(lambda: self._update_fused(cur))
+                    self._batch_stale = True
+                graph = self._graphs[self._cur]
             else:
-                self._graph = self._capture(self._train_body_nocheck)
-                self._graph_b = None
+                assert k == CHAIN and k % 2 == 0 and self._cur == 0
+                if self._graph_chain is None:
+                    self._graph_chain = self._capture(lambda: [self._update_fused(i & 1) for i in range(CHAIN)])
+                    self._batch_stale = True
+                graph = self._graph_chain
+        if self._batch_stale:
+            self._sample_packed()
+            self._batch_stale = False
+        if graph is not None:
+            graph.replay()
+            self._cur ^= (k & 1)
+        else:
+            for _ in range(k):
+                self._update_fused(self._cur)
+                self._cur ^= 1
+        self._staged = self._pp[self._cur]
+        self.Q_adam.t += k
+        self.pi_adam.t += k
+        return self._losses[0], self._Q_pi
+
+    def _train_device_ranks(self):
+        if self._graph is None and self.use_graph:
+            self._graph = self._capture(self._grads)
+            self._graph_b = self._capture(self._adam_and_sample)
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False
-        if self.Q_adam.t % 100 == 0 and dist.is_distributed():
-            self.Q_adam.theta = self.theta
+        if self.Q_adam.t % 100 == 0:
+            self.Q_adam.theta = self.theta                           # checksum over the fused vector (C4)
             MpiAdam.check_synced(self.Q_adam)
             self.Q_adam.theta = self.theta[:self.off_pi]
-        self._graph.replay()
-        if self._graph_b is not None:
-            dist.allreduce_sum_(self.grad)
+        if self.use_graph:
+            self._graph.replay()
+            dist.allreduce_sum_(self.grad)                           # C1+C2 fused; SUM, not mean (ddpg.py:452)
             self._graph_b.replay()
+        else:
+            self._grads()
+            dist.allreduce_sum_(self.grad)
+            self._adam_and_sample()
         self.Q_adam.t += 1
         self.pi_adam.t += 1
         return self._losses[0], self._Q_pi
 
-    def _adam_only(self):
-        ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
-                        alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base)
+    def _update_fused(self, p):
+        S = self.sample_transitions
+        ops.ddpg_update(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self.batch_size,
+                        self._workspace, self.grad, self._losses, self._Q_pi, self._m, self._v,
+                        step_ctr=self._step_ctr, alpha_tab=self._alpha_tab, tab_base=self._alpha_base,
+                        o_stats=self.o_stats.state if self.normalize_obs else None,
+                        g_stats=self.g_stats.state if self.normalize_obs else None,
+                        next_batch=self._pp[p ^ 1], storage=self._pool.storage, buf_stride=self._pool.buf_stride,
+                        tasks=S.tasks, params=S.params(self.clip_obs, self.relative_goals), rng=self._rng_desc)
 
     def _adam_and_sample(self):
         S = self.sample_transitions
@@ -604,10 +671,6 @@ class DDPG(object):
                                    self._pool.buf_stride, self._layout, S.tasks,
                                    S.params(self.clip_obs, self.relative_goals), self._rng_desc, self.batch_size,
                                    self._staged)
-
-    def _train_body_nocheck(self):
-        self._grads()
-        self._adam_and_sample()
 
     def _capture(self, fn):
         """Capture `fn`'s kernel launches into a hipGraph (after one eager warm-up on a side stream)."""
@@ -694,7 +757,7 @@ class DDPG(object):
         """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521)."""
         excluded = ['_tf', '_op', '_vars', '_adam', 'buffer', 'sess', '_stats', 'main', 'target', 'lock', 'env',
                     'sample_transitions', 'stage_shapes', 'create_actor_critic', 'theta', 'grad', 'net_cfg',
-                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_workspace',
+                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_pp', '_workspace',
                     '_act_ws', '_losses', '_Q_pi', '_step_ctr', '_alpha_tab', '_m', '_v', 'kwargs']
         state = {k: v for k, v in self.__dict__.items() if all(sub not in k for sub in excluded)}
         state['weights'] = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),

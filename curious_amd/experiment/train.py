@@ -66,8 +66,7 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
             for _ in range(n_cycles):
                 episode, cp, n_ep = rollout_worker[i_policy].generate_rollouts()
                 policy[i_policy].store_episode(episode, cp, n_ep)
-                for _ in range(n_batches):
-                    policy[i_policy].train()
+                policy[i_policy].train_batches(n_batches)             # = n_batches x train() (train.py:101-102)
                 policy[i_policy].update_target_net()
             evaluator.clear_history()
             for _ in range(n_test_rollouts):
@@ -91,8 +90,7 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
             for cyc in range(n_cycles):                               # train.py:148-155 -- the hot loop
                 episode, cp, n_ep = rollout_worker.generate_rollouts()
                 policy.store_episode(episode, cp, n_ep)
-                for j in range(n_batches):
-                    policy.train()
+                policy.train_batches(n_batches)                      # = n_batches x train() (train.py:152-153)
                 policy.update_target_net()
             evaluator.clear_history()
             for _ in range(n_test_rollouts):

@@ -133,6 +133,36 @@ def ddpg_grads(cfg, theta_main, theta_target, batch, layout, B, workspace, grad,
                                    current_stream()), 'curious_ddpg_grads')
 
 
+def ddpg_update(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi, m, v,
+                step_ctr=None, alpha_tab=None, tab_base=0, alpha_Q=0.0, alpha_pi=0.0, beta1=0.9, beta2=0.999,
+                epsilon=1e-08, o_stats=None, g_stats=None, next_batch=None, storage=None, buf_stride=0, tasks=None,
+                params=None, rng=None):
+    """One whole single-rank update (curious_ddpg_update): gradients with Adam applied in the weight-gradient launch;
+    with `next_batch` (a staging tensor other than `batch`) the device-drawn HER gather of the next update rides along."""
+    f = np.float32
+    BL = layout.c_batch_layout()
+    A = _lib.AdamState()
+    A.m, A.v = ptr(_dev(m, 'm')), ptr(_dev(v, 'v'))
+    A.alpha_tab = ptr(alpha_tab)
+    A.tab_base, A.tab_len = int(tab_base), int(alpha_tab.shape[0]) if alpha_tab is not None else 0
+    A.alpha_Q, A.alpha_pi = float(alpha_Q), float(alpha_pi)
+    A.beta1, A.one_minus_beta1 = float(f(beta1)), float(f(1 - beta1))
+    A.beta2, A.one_minus_beta2 = float(f(beta2)), float(f(1 - beta2))
+    A.epsilon = float(f(epsilon))
+    nb = None
+    if next_batch is not None:
+        L = layout.c_layout()
+        N = _lib.NextBatch()
+        N.storage, N.buf_stride = ptr(_dev(storage, 'storage')), int(buf_stride)
+        N.L, N.tasks, N.P, N.rng = C.pointer(L), C.pointer(tasks), C.pointer(params), C.pointer(rng)
+        N.batch = ptr(_dev(next_batch, 'next_batch'))
+        nb = C.byref(N)
+    check(lib().curious_ddpg_update(C.byref(cfg), ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
+                                    ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
+                                    ptr(workspace), ptr(grad), ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr),
+                                    C.byref(A), nb, current_stream()), 'curious_ddpg_update')
+
+
 def policy_forward(cfg, theta, o, g, td, n, clip_obs, workspace, out_pi, out_Q=None, ag=None,
                    relative_goals=False, o_stats=None, g_stats=None):
     _dev(o, 'o')

@@ -219,6 +219,34 @@ int curious_adam_update_and_sample(float* theta, float* m, float* v, const float
                                    const curious_sample_params_t* P, const curious_sample_rng_t* rng, int32_t n,
                                    float* batch, const curious_batch_layout_t* BL, curious_stream_t stream);
 
+/* One whole single-rank update: DDPG._grads + both MpiAdam.update calls (ddpg.py:235-248, mpi_adam.py:29-35 with no
+ * ranks to reduce over) with the optimiser applied in the epilogue of the weight-gradient launch, and optionally the
+ * HER gather of the NEXT update's batch (ddpg.py:251-360, device-drawn plan) riding on that launch.  Results (theta,
+ * m, v, grad, losses, Q_pi, next batch) are bit-identical to curious_ddpg_grads followed by
+ * curious_adam_update_and_sample.  `next->batch` must not alias `batch`.  Multi-rank training cannot use it: the
+ * gradient all-reduce sits between the two halves (mpi_adam.py:26-28). */
+typedef struct curious_adam_state {
+  float* m; float* v;                  /* [curious_param_total] moments, same layout as theta */
+  const float* alpha_tab;              /* [tab_len][2] ring of (Q, pi) step sizes indexed by *step_ctr, or NULL */
+  int64_t tab_base;
+  int32_t tab_len;
+  float alpha_Q, alpha_pi;             /* step sizes when alpha_tab == NULL */
+  float beta1, one_minus_beta1, beta2, one_minus_beta2, epsilon;
+} curious_adam_state_t;
+
+typedef struct curious_next_batch {
+  const float* storage; int64_t buf_stride;
+  const curious_layout_t* L; const curious_tasks_t* tasks; const curious_sample_params_t* P;
+  const curious_sample_rng_t* rng;
+  float* batch;
+} curious_next_batch_t;
+
+int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
+                        const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                        const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                        float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                        const curious_adam_state_t* adam, const curious_next_batch_t* next, curious_stream_t stream);
+
 /* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
  * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */
 int curious_polyak_update(float* target, const float* main_, int64_t n, float polyak, float one_minus_polyak,

@@ -202,12 +202,19 @@ def test_device_rng_graph_equals_eager_and_learns():
         a.store_episode({k: v.copy() for k, v in ep.items()}, cp, 48)
     first = None
     for k in range(30):
-        lg, _ = a_graph.train()
         le, _ = a_eager.train()
         if first is None:
             first = float(le)
+    # 7 single-update graphs (leaves the staging parity odd), then train_batches: one more single update to get back to
+    # parity 0, two chained graphs of CHAIN updates, two singles
+    for k in range(7):
+        a_graph.train()
+    lg, _ = a_graph.train_batches(23)
     torch.cuda.synchronize()
+    assert a_graph._graph_chain is not None and all(g is not None for g in a_graph._graphs)
     assert torch.equal(a_graph.theta, a_eager.theta)
+    assert torch.equal(a_graph._m, a_eager._m) and torch.equal(a_graph._v, a_eager._v)
+    assert torch.equal(a_graph._staged, a_eager._staged)             # the batch of update 31 is already staged
     assert float(lg) == float(le)
     assert np.isfinite(float(le)) and float(le) < first              # critic loss goes down on a fixed buffer
     assert int(a_graph._step_ctr) == 30 == a_graph.Q_adam.t
@@ -217,6 +224,36 @@ def test_device_rng_graph_equals_eager_and_learns():
     assert set(np.unique(r)) <= {0.0, -1.0}
     td = b[3].cpu().numpy()
     assert np.all(td.sum(axis=1) == 1)
+
+
+@pytest.mark.parametrize('small', [False, True])
+def test_fused_update_equals_unfused_sequence(small):
+    """curious_ddpg_update (Adam in the weight-gradient launch + next gather riding along) against the three separate
+    launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit, lean kernels and generic fallback."""
+    kw = dict(batch_size=64, hidden=64) if small else {}
+    a_f, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
+    a_u, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
+    rng = np.random.RandomState(5)
+    cp = np.array([0.3, 0.0, 0.2, 0.1])
+    ep = synth_episodes(rng, 40, 4, 40)
+    for a in (a_f, a_u):
+        np.random.seed(2)
+        a.store_episode({k: v.copy() for k, v in ep.items()}, cp, 40)
+    for k in range(9):
+        lf, qf = a_f.train()
+        if a_u._tables_dirty:
+            a_u._refresh_device_tables()
+        if a_u._alpha_filled == 0:
+            a_u._fill_alpha_table()
+        batch_u = a_u._sample_packed().clone()
+        lu, qu, _, _ = a_u._grads()
+        a_u._update(use_table=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a_f._pp[k & 1], batch_u)                  # update k consumed the same batch
+        assert torch.equal(a_f.grad, a_u.grad)
+        assert torch.equal(a_f.theta, a_u.theta) and torch.equal(a_f._m, a_u._m) and torch.equal(a_f._v, a_u._v)
+        assert float(lf) == float(lu) and torch.equal(qf, qu)
+    assert float(a_f.theta.abs().sum()) != float(a_f.theta_target.abs().sum())   # the parameters did move
 
 
 def test_batched_rollout_matches_oracle():
