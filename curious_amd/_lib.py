@@ -117,7 +117,7 @@ PROTOTYPES = {
                                                  C.POINTER(BatchLayout), _P]),
     'curious_polyak_update': (C.c_int, [_P, _P, _I64, _F, _F, _P]),
     'curious_param_checksum': (C.c_int, [_P, _I64, _P, _P]),
-    'curious_policy_act_env_step': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _I32,
+    'curious_policy_act_env_step': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
                                               C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _P, _P, _P, _P,
                                               _P, _I32, _I32, _D, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,

@@ -1570,6 +1570,7 @@ struct ActStepArgs {
   float max_u_f;
   double noise_scale, random_eps, max_u;
   uint64_t seed, counter;
+  const int64_t* counter_base;               // optional device-resident offset of the noise counter (graph replay)
   float* u_out; int32_t ldu;                 // actions as given to the env (also recorded in the episode row)
   curious_env_cfg_t E; curious_layout_t L;
   int32_t env_id0, t, off_change, off_success;
@@ -1596,8 +1597,9 @@ __global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
     for (int d = 0; d < MAX_U; ++d)
       if (d == lane) v = o_[d];
     v = a.max_u_f * tanhf(v + a.bout[lane]);                  // actor_critic.py:89
+    const uint64_t ctr = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
     v = noise_apply(v, e * a.U + lane, e, a.noise_scale, a.random_eps, a.max_u, nullptr, nullptr, nullptr, a.seed,
-                    a.counter);                               // ddpg.py:149-152
+                    ctr);                                     // ddpg.py:149-152
     s_u[wave][lane] = v;
     a.u_out[(int64_t)e * a.ldu + lane] = v;
   }
@@ -1928,7 +1930,8 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
 
 extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                                            float* workspace, double noise_scale, double random_eps, uint64_t seed,
-                                           uint64_t counter, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                                           uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                           const curious_env_cfg_t* E,
                                            const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
                                            const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
                                            const float* td, float* staging, int32_t off_change, int32_t off_success,
@@ -1959,7 +1962,7 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   k.a_last = w.act[2][nl - 1]; k.Wout = thPi + offPi.Wout; k.bout = thPi + offPi.bout;
   k.H = H; k.U = cfg->dimu; k.n = n; k.max_u_f = cfg->max_u;
   k.noise_scale = noise_scale; k.random_eps = random_eps; k.max_u = (double)cfg->max_u;
-  k.seed = seed; k.counter = counter; k.u_out = u_out; k.ldu = ldu;
+  k.seed = seed; k.counter = counter; k.counter_base = counter_base; k.u_out = u_out; k.ldu = ldu;
   k.E = *E; k.L = *L; k.env_id0 = env_id0; k.t = t; k.off_change = off_change; k.off_success = off_success;
   k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
   k.reward_eps = reward_eps;

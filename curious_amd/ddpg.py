@@ -237,6 +237,51 @@ class DDPG(object):
                                 env.ag, env.g, env.td, env.staging, REWARD_EPS)
         return self._act_u
 
+    def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
+        """The T-step acting loop of a batched rollout (rollout.py:226-303 for every env): T x act_and_step.  With
+        use_graph the 4*T launches are captured once per (env, noise setting) and replayed as one hipGraph -- the eager
+        loop is bound by host launch overhead (~29 us per step against ~19 us of kernels); the Philox noise counter is
+        (t + 1) + a device-resident base that advances by T per rollout, so replays draw fresh noise and the eager loop
+        draws the same numbers."""
+        from curious_amd.envs import REWARD_EPS
+        n = env.n
+        theta = self.theta_target if use_target_net else self.theta
+        ws = self._act_ws.get(n)
+        if ws is None:
+            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+            self._act_ws[n] = ws
+        if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
+            self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+        if getattr(self, '_noise_base', None) is None:
+            self._noise_base = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._roll_graphs = {}
+        seed = self.seed * 2654435761 + 12345 + dist.rank() * 1000003     # same stream as get_actions / act_and_step
+        u_out = self._act_u
+
+        def steps():
+            for t in range(T):
+                ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
+                                        seed, t + 1, u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks,
+                                        t, env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS,
+                                        counter_base=self._noise_base)
+            self._noise_base.add_(T)
+
+        self._noise_counter += T
+        if not self.use_graph:
+            steps()
+            return
+        key = (id(env), T, float(noise_eps), float(random_eps), bool(use_target_net))
+        g = self._roll_graphs.get(key)
+        if g is None:
+            # capture only records (the side-stream warm-up torch recommends is skipped on purpose: it would step the
+            # envs for real); the library's kernels need no lazy initialisation
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                steps()
+            self._roll_graphs[key] = g
+        g.replay()
+
     # ------------------------------------------------------------------ storing
     def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
@@ -248,9 +293,27 @@ class DDPG(object):
         batch_size = staging.shape[0]
         if self.structure in ('curious', 'task_experts'):
             if 'buffer' in self.task_replay or self.task_replay == 'hand_designed':
-                active = torch.empty(batch_size * self.nb_tasks, dtype=torch.int32, device=self.device)
-                ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, active)
-                active = active.cpu().numpy().reshape(batch_size, self.nb_tasks)   # one D2H sync per cycle
+                na = batch_size * self.nb_tasks
+                if getattr(self, '_route_bufs', None) is None or self._route_bufs[0].numel() < na:
+                    # device + pinned host mirrors for the activity flags and the (src, dst) routing pairs
+                    self._route_bufs = (torch.empty(na, dtype=torch.int32, device=self.device),
+                                        torch.empty(na, dtype=torch.int32).pin_memory(),
+                                        torch.empty(na, dtype=torch.int32).pin_memory(),
+                                        torch.empty(na, dtype=torch.int64).pin_memory(),
+                                        torch.empty(na, dtype=torch.int32, device=self.device),
+                                        torch.empty(na, dtype=torch.int64, device=self.device))
+                active_dev, active_host = self._route_bufs[0][:na], self._route_bufs[1][:na]
+                ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, active_dev)
+                active_host.copy_(active_dev, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record()
+                if update_stats and self.rng_mode == 'device':
+                    # the normaliser update needs no host decision and (in this mode) no NumPy draw: enqueue it now, so
+                    # that the GPU works while the host routes the episodes
+                    self._update_stats(staging, batch_size)
+                    update_stats = False
+                arrived.synchronize()                                # one D2H sync per cycle
+                active = active_host.numpy().reshape(batch_size, self.nb_tasks)
                 per_buffer = {}
                 fast_src, fast_dst = [], []
                 routed = active.astype(bool)
@@ -292,9 +355,14 @@ class DDPG(object):
                 if fast_src:
                     src, dst = np.concatenate(fast_src), np.concatenate(fast_dst)
                 if len(src):
-                    ops.store_episodes(self._pool.storage, staging, layout,
-                                       torch.as_tensor(np.asarray(src, np.int32)).to(self.device),
-                                       torch.as_tensor(np.asarray(dst, np.int64)).to(self.device))
+                    k = len(src)
+                    assert k <= na
+                    src_h, dst_h, src_d, dst_d = (b[:k] for b in self._route_bufs[2:])
+                    src_h.numpy()[:] = np.asarray(src, np.int32)
+                    dst_h.numpy()[:] = np.asarray(dst, np.int64)
+                    src_d.copy_(src_h, non_blocking=True)
+                    dst_d.copy_(dst_h, non_blocking=True)
+                    ops.store_episodes(self._pool.storage, staging, layout, src_d, dst_d)
             else:
                 for b in range(batch_size):
                     slot = self.buffer._get_storage_idx(1)
@@ -308,28 +376,37 @@ class DDPG(object):
         self._tables_dirty = True
 
         if update_stats:                                             # ddpg.py:207-223
-            views = EpisodeViews(staging, layout)
-            n = batch_size * self.T
-            if self.rng_mode == 'numpy':
-                ep, t, u_her, u_off, given = self.sample_transitions.draw(batch_size, self.T, n)
-                plan = upload_plan(n, ep, t, u_her, u_off, ttr=given)
-                rng = None
-            else:
-                plan, rng = None, self._stats_rng(batch_size, n)
-            batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
-            P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
-            ops.her_sample(views.records, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
-            cols = layout.batch_cols
-            self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
-            self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
-            recompute_many([self.o_stats, self.g_stats])
+            self._update_stats(staging, batch_size)
+
+    def _update_stats(self, staging, batch_size):
+        """HER-sample batch_size * T transitions from the fresh episodes and feed both normalisers (ddpg.py:207-223)."""
+        layout = self._layout
+        views = EpisodeViews(staging, layout)
+        n = batch_size * self.T
+        if self.rng_mode == 'numpy':
+            ep, t, u_her, u_off, given = self.sample_transitions.draw(batch_size, self.T, n)
+            plan = upload_plan(n, ep, t, u_her, u_off, ttr=given)
+            rng = None
+        else:
+            plan, rng = None, self._stats_rng(batch_size, n)
+        if getattr(self, '_stats_batch', None) is None or self._stats_batch.shape[0] != n:
+            self._stats_batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
+        batch = self._stats_batch
+        P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
+        ops.her_sample(views.records, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
+        cols = layout.batch_cols
+        self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
+        self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
+        recompute_many([self.o_stats, self.g_stats])
 
     def _stats_rng(self, n_episodes, n):
         r = _lib.SampleRng()
-        self._stats_tables = (torch.tensor([0, n], dtype=torch.int32, device=self.device),
-                              torch.tensor([n_episodes], dtype=torch.int32, device=self.device),
-                              torch.tensor([0], dtype=torch.int32, device=self.device),
-                              torch.tensor([-1], dtype=torch.int32, device=self.device))
+        if getattr(self, '_stats_tables_key', None) != (n_episodes, n):
+            self._stats_tables = (torch.tensor([0, n], dtype=torch.int32, device=self.device),
+                                  torch.tensor([n_episodes], dtype=torch.int32, device=self.device),
+                                  torch.tensor([0], dtype=torch.int32, device=self.device),
+                                  torch.tensor([-1], dtype=torch.int32, device=self.device))
+            self._stats_tables_key = (n_episodes, n)
         r.seed = (self.seed * 7919 + 17 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
         r.step_ctr = None
         self._stats_calls = getattr(self, '_stats_calls', 0) + 1
@@ -757,7 +834,7 @@ class DDPG(object):
         """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521)."""
         excluded = ['_tf', '_op', '_vars', '_adam', 'buffer', 'sess', '_stats', 'main', 'target', 'lock', 'env',
                     'sample_transitions', 'stage_shapes', 'create_actor_critic', 'theta', 'grad', 'net_cfg',
-                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_pp', '_workspace',
+                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_pp', '_workspace', '_roll_graphs', '_noise_base', '_act_u', '_route_bufs', '_stats_batch', '_stats_tables',
                     '_act_ws', '_losses', '_Q_pi', '_step_ctr', '_alpha_tab', '_m', '_v', 'kwargs']
         state = {k: v for k, v in self.__dict__.items() if all(sub not in k for sub in excluded)}
         state['weights'] = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),

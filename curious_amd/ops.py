@@ -238,11 +238,12 @@ def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td,
 
 
 def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
-                        env_id0, episode, tasks, t, o, ag, g, td, staging, reward_eps):
+                        env_id0, episode, tasks, t, o, ag, g, td, staging, reward_eps, counter_base=None):
     L = layout.c_layout()
     check(lib().curious_policy_act_env_step(C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs),
                                             ptr(workspace), float(noise_scale), float(random_eps),
-                                            int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(u_out),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(counter_base),
+                                            ptr(u_out),
                                             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0),
                                             ptr(episode), ptr(tasks), int(t), ptr(o), ptr(ag), ptr(g), ptr(td),
                                             ptr(staging), int(layout.off['change']),

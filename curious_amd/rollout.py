@@ -212,7 +212,11 @@ class RolloutWorker:
         self.count += B
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
         fused = hasattr(self.policy, 'can_act_and_step') and self.policy.can_act_and_step(env, self.compute_Q)
-        for t in range(self.T):
+        if fused and hasattr(self.policy, 'act_rollout'):
+            self.policy.act_rollout(env, self.T, noise_eps=self.noise_eps if not self.exploit else 0.,
+                                    random_eps=self.random_eps if not self.exploit else 0.,
+                                    use_target_net=self.use_target_net)
+        for t in range(self.T if not (fused and hasattr(self.policy, 'act_rollout')) else 0):
             if fused:
                 self.policy.act_and_step(env, t, noise_eps=self.noise_eps if not self.exploit else 0.,
                                          random_eps=self.random_eps if not self.exploit else 0.,
@@ -233,11 +237,11 @@ class RolloutWorker:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
             return self._generate_rollouts_batched()
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
+        task_list = tasks.tolist()
         self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
-        for i in range(B):
-            self.tasks[self.rank * B + i] = int(tasks[i])
+        self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
         self.goals = [[] for _ in range(self.nb_goals_per_rollout)]
-        self._finish_rollout(successful, successful - 1.0, mean_Q, [int(x) for x in tasks])
+        self._finish_rollout(successful, successful - 1.0, mean_Q, task_list)
         return env.episode_views(), self.CP, self.n_episodes
 
     # ================================================================== statistics, competence, task probabilities
@@ -257,10 +261,9 @@ class RolloutWorker:
         rec[:, 1] = successful
         rec[:, 2] = 1.0 if self.exploit else 0.0
         allrec = dist.allgather_numpy(rec)
-        task_succ_list = [[] for _ in range(self.nb_tasks)]
-        for task, succ, valid in allrec:
-            if valid:
-                task_succ_list[int(task)].append(float(succ))
+        valid = allrec[:, 2] != 0
+        task_ids = allrec[:, 0].astype(np.int64)
+        task_succ_list = [allrec[valid & (task_ids == task), 1].tolist() for task in range(self.nb_tasks)]
         for task in range(self.nb_tasks):
             self.competence_computers[task].update(task_succ_list[task])   # rollout.py:355-356
         self.C = np.array([self.get_C()]).squeeze()

@@ -279,10 +279,13 @@ int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int3
 /* Fused acting step of the batched rollout: actor forward on the envs' current (o, g, td), output layer + noise +
  * clip + eps-greedy (device Philox, as curious_action_noise in throughput mode) and ONE env step, i.e.
  * policy.get_actions + env.step of rollout.py:226-263 for all n envs in 4 launches instead of 6.  u_out receives the
- * actions.  Same results, bit for bit, as curious_policy_forward + curious_action_noise + curious_env_step. */
+ * actions.  Same results, bit for bit, as curious_policy_forward + curious_action_noise + curious_env_step.
+ * The Philox noise counter is counter + *counter_base (counter_base: optional device int64, so that a T-step rollout
+ * captured once in a hipGraph draws fresh noise on every replay). */
 int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                                 float* workspace, double noise_scale, double random_eps, uint64_t seed,
-                                uint64_t counter, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                                uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                const curious_env_cfg_t* E,
                                 const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
                                 const int32_t* tasks, int32_t t, float* o, float* ag, const float* g, const float* td,
                                 float* staging, int32_t off_change, int32_t off_success, double reward_eps,
