@@ -134,13 +134,13 @@ def kernel_flops_bytes(policy, lay):
                                 + (c.dimag + G + O + N + U + O + G + 1)) * 4          # 1 034 B at Arm4
     adam_bytes = 28 * (c.P_Q + c.P_pi)
     return dict(
-        # hidden layers (256^3 GEMMs): level A (3 chains, layers 1..) + level B (2 chains, layers 2..) per update;
+        # layers 0 + 1 in one launch: level A's 3 chains (+ the 2 action-free pre-activations of level B) per update;
         # the actor chain per env step
-        fwd_hot_kernel=dict(bound='mfma', per_update=(5 * hid - 2) * 2 * B * H * H, launches_update=2 * hid - 1,
-                            per_env_step=hid * 2 * B_R * H * H, launches_env_step=hid),
-        # layer 0 (K = 56..60): 3 chains + the 2 action-free pre-activations of level B in one launch
-        fwd_l0_kernel=dict(bound='mfma', per_update=2 * B * H * (Kc + 4 * Ka), launches_update=1,
-                           per_env_step=2 * B_R * H * Ka, launches_env_step=1),
+        fwd_l01_kernel=dict(bound='mfma', per_update=3 * 2 * B * H * H + 2 * B * H * (Kc + 4 * Ka), launches_update=1,
+                            per_env_step=2 * B_R * H * H + 2 * B_R * H * Ka, launches_env_step=1),
+        # remaining hidden layers (256^3 GEMMs): level A layers 2.. (3 chains), level B layers 2.. (2 chains)
+        fwd_hot_kernel=dict(bound='mfma', per_update=5 * (hid - 1) * 2 * B * H * H, launches_update=2 * (hid - 1),
+                            per_env_step=(hid - 1) * 2 * B_R * H * H, launches_env_step=hid - 1),
         # level B layer 1 with the actor heads and the action rows of layer 0 in its prologue
         fwd_pi_kernel=dict(bound='mfma', per_update=2 * (2 * B * H * H + 4 * B * H * U), launches_update=1),
         dx_hot_kernel=dict(bound='mfma', per_update=(3 * hid - 3) * 2 * B * H * H, launches_update=2 * hid - 2),

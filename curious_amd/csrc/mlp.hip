@@ -22,6 +22,7 @@
 // Output layers (N = 1 or dimu) and everything elementwise around the losses run in "one wave per batch row"
 // kernels.  Gradients are written directly at their offset of the [Q_grad | pad | pi_grad] vector.
 #include <math.h>
+#include <algorithm>
 
 #include "common.h"
 #include "env_body.h"
@@ -637,13 +638,11 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
 }
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
-struct DwHotArgs { GemmHot p[4]; int32_t tile_end[4]; int32_t nprob; };
+struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
 __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red) {
-  int pi = 0, t = bid;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (i + 1 < args.nprob && bid >= args.tile_end[i]) { pi = i + 1; t = bid - args.tile_end[i]; }
+  // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
+  const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
   const GemmHot& P = args.p[pi];
   const int nx = P.N >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -719,18 +718,17 @@ struct DwSmall {
   const float* x; const float* dY; float* dW; float* db;
   int32_t ldx, lddy, w, N;
   float div;
-  int32_t tile_end;      // exclusive prefix of this problem's tiles in the 1-D grid
 };
 #define MAX_DW_SMALL 12
-struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M; LossFin fin; };
+struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin; };   // `slots` block ids per problem
 
 template <bool ADAM>
 __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  int pi = 0, t = bid;
-  for (int i = 0; i + 1 < args.nprob; ++i)
-    if (bid >= args.p[i].tile_end) { pi = i + 1; t = bid - args.p[i].tile_end; }
-  if (bid >= args.p[args.nprob - 1].tile_end) {
+  // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
+  // arithmetic, so the descriptor load does not wait for a search through the table
+  const int pi = bid / args.slots, t = bid - pi * args.slots;
+  if (pi >= args.nprob) {
     // extra last block (only launched when fin.rows != NULL): losses (ddpg.py:439-441) from the per-row terms,
     // summed in a fixed order
     const LossFin& F = args.fin;
@@ -759,6 +757,7 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
   }
   const DwSmall& P = args.p[pi];
   const int nx = (P.N + 63) >> 6;
+  if (t >= ((P.w + 15) >> 4) * nx) return;
   const int by = t / nx, bx = t - by * nx;
   const int j = lane & 15, q = lane >> 4;
   const int k0 = by * 16, n0 = bx * 64;
@@ -768,8 +767,25 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
   const bool yv = (P.N & 3) == 0;
   const int colc = yv ? min(col, P.N - 4) : min(col, P.N - 1);
   const float* yc = P.dY + colc;
-  float aQ = 0.f, aPi = 0.f;
-  if (ADAM) adam_alphas(A, aQ, aPi);
+  // optimiser operands of what this thread finishes, fetched with the first batch of loads
+  const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
+  const bool own = grow < P.w && gcol < P.N;
+  float* const dst = P.dW + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
+  const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  AdamPre4 pre;
+  pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
+  if (ADAM) {
+    adam_alphas(A, aQ, aPi);
+    if (yv) {
+      pre = adam_prefetch4(A, own ? pidx : 0);
+    } else if (own) {                                       // N == 1: one element per owning thread
+      pre.m[0] = A.m[pidx]; pre.v[0] = A.v[pidx]; pre.th[0] = A.theta[pidx];
+    }
+    if (own_b) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+  }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < args.M; mb += 256) {
@@ -805,24 +821,18 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
   }
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
-  const int grow = k0 + orow, gcol = n0 + 4 * c4;
-  if (grow < P.w && gcol < P.N) {
-    float* dst = P.dW + (int64_t)grow * P.N + gcol;
-    const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  if (own) {
     const float na = (pidx < A.n_Q) ? -aQ : -aPi;
     if (yv) {
       *reinterpret_cast<f32x4*>(dst) = v;
-      if (ADAM) {
-        AdamPre4 pre = adam_prefetch4(A, pidx);
-        adam_apply4(A, na, pidx, v, pre);
-      }
+      if (ADAM) adam_apply4(A, na, pidx, v, pre);
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (gcol + e < P.N) {
-          dst[e] = v[e];
-          if (ADAM) adam_apply1(A, na, pidx + e, v[e]);
-        }
+      dst[0] = v[0];                                        // N == 1 (gcol == 0)
+      if (ADAM) {
+        float m = pre.m[0], vv = pre.v[0];
+        const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
+        A.m[pidx] = m; A.v[pidx] = vv; A.theta[pidx] = th;
+      }
     }
   }
   if (P.db && by == 0) {
@@ -836,12 +846,12 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
     __syncthreads();
     if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
     __syncthreads();
-    if (tid < 64 && n0 + tid < P.N) {
+    if (own_b) {
       const float gb = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
       P.db[n0 + tid] = gb;
       if (ADAM) {
-        const int64_t bidx = (int64_t)(P.db + n0 + tid - A.grad);
-        adam_apply1(A, (bidx < A.n_Q) ? -aQ : -aPi, bidx, gb);
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
       }
     }
   }
@@ -879,9 +889,7 @@ struct SegL { const float* x; const float* W; int32_t ld, w; float div, clip; };
 struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy, relu; };
 struct L0Args { L0Prob p[5]; };
 
-__global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  const L0Prob& P = args.p[blockIdx.z];
+__device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
   // locate this lane's 4 virtual columns kv .. kv+3 (16-byte group never straddles a segment: widths % 4 == 0)
@@ -935,6 +943,120 @@ __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   }
   *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
+}
+
+
+__global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  fwd_l0_body(args.p[blockIdx.z], red);
+}
+
+// ------------------------------------------------------------------ layers 0 + 1 in one launch
+// C[M,256] = relu(relu(X . W0 + b0) . W1 + b1) for H == 256, total layer-0 K <= 64, M % 16 == 0.  Every workgroup
+// first computes the FULL layer-0 tile h0[16 rows][256] of its batch rows (wave w: columns 64w..64w+63, all of K: 4 + 16
+// loads and 64 MFMAs), parks it in LDS, and then runs the usual split-K layer-1 tile out of LDS.  The 4 column tiles of
+// a row block recompute h0 (0.25 MFLOP each) -- that buys one dependent launch (~4.3 us) per forward pass.  Column
+// tile 0 stores h0 when the backward pass needs it.  Problems z >= n01 of the same launch are plain layer-0 problems
+// (the action-free pre-activations of fwd_pi_kernel).
+struct L01Prob { L0Prob l0; const float* W1; const float* b1; float* C; };
+struct L01Args { L01Prob p[3]; L0Prob pre[2]; int32_t n01; };
+#define H0_LD 260      // LDS row stride of the h0 tile: 260 % 64 = 4 -> the 16 rows of a b128 read hit distinct banks
+
+__device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
+  const L0Prob& P = Q.l0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const int H = 256;
+  // ---- all global loads: 4 input fragments + 16 layer-0 weight fragments, 16 layer-1 weight fragments, biases
+  f32x4 xa[4], w0[4][4], w1[4][4];
+  float dv[4], cl[4];
+  bool okv[4];
+  // segment table read once, unconditionally (unused entries are zero-width); the per-lane lookup below is pure
+  // select arithmetic -- no divergent branches, no dependent scalar loads
+  const SegL g0 = P.seg[0], g1 = P.seg[1], g2 = P.seg[2], g3 = P.seg[3];
+  const int e0 = g0.w, e1 = e0 + g1.w, e2 = e1 + g2.w, e3 = e2 + g3.w;     // exclusive ends of the segments
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kv = 16 * i + 4 * q;                 // this lane's virtual input columns kv .. kv+3 of k-group i
+    const bool in0 = kv < e0, in1 = kv < e1, in2 = kv < e2, in3 = kv < e3;
+    const float* xb = in0 ? g0.x : in1 ? g1.x : in2 ? g2.x : in3 ? g3.x : g0.x;
+    const float* wb = in0 ? g0.W : in1 ? g1.W : in2 ? g2.W : in3 ? g3.W : g0.W;
+    const int ld = in0 ? g0.ld : in1 ? g1.ld : in2 ? g2.ld : in3 ? g3.ld : g0.ld;
+    const int kl = in3 ? kv - (in0 ? 0 : in1 ? e0 : in2 ? e1 : e2) : 0;       // column inside the segment
+    dv[i] = in0 ? g0.div : in1 ? g1.div : in2 ? g2.div : in3 ? g3.div : 1.0f;
+    cl[i] = in0 ? g0.clip : in1 ? g1.clip : in2 ? g2.clip : in3 ? g3.clip : 0.0f;
+    okv[i] = in3;
+    xa[i] = ldv(xb + kl + (int64_t)(m0 + j) * ld);
+    const float* wc0 = wb + (int64_t)kl * H + 64 * wave + 4 * j;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) w0[i][s2] = ldv(wc0 + (int64_t)s2 * H);
+  }
+  const f32x4 bias0 = ldv(P.bias + 64 * wave + 4 * j);
+  const float* wc1 = Q.W1 + n0 + 4 * j;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kq = (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) w1[u][s2] = ldv(wc1 + (int64_t)(kq + s2) * H);
+  }
+  const f32x4 bias1 = ldv(Q.b1 + n0 + 4 * (tid & 15));
+  LOADS_FIRST();
+  // ---- layer 0: h0[rows 4q..4q+3][cols 64*wave + 4j + e]
+  const bool any_div = (g0.div != 1.0f) || (g1.w > 0 && g1.div != 1.0f) || (g2.w > 0 && g2.div != 1.0f) ||
+                       (g3.w > 0 && g3.div != 1.0f);               // uniform: only the critic's action segment divides
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 a = xa[i];
+    const float c = (cl[i] > 0.0f) ? cl[i] : INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fclip(a[e], -c, c);
+    if (any_div) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fdiv(a[e], dv[i]);
+    }
+    a = sel4(okv[i], a);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[s2], w0[i][s2][e], acc[e]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 hv = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    hv += bias0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = fmaxf(hv[e], 0.f);
+    *reinterpret_cast<f32x4*>(h0s + (4 * q + r) * H0_LD + 64 * wave + 4 * j) = hv;
+    if (blockIdx.x == 0 && P.Y)
+      *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + 4 * q + r) * H + 64 * wave + 4 * j) = hv;
+  }
+  __syncthreads();
+  // ---- layer 1 out of LDS
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = zero4();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kq = (wave + 4 * u) * 16 + 4 * q;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(h0s + j * H0_LD + kq);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[s2], w1[u][s2][e], acc[e]);
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  v += bias1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  *reinterpret_cast<f32x4*>(Q.C + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
+}
+
+__global__ __launch_bounds__(256) void fwd_l01_kernel(L01Args args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float h0s[16 * H0_LD];
+  if ((int)blockIdx.z < args.n01) fwd_l01_body(args.p[blockIdx.z], red, h0s);
+  else fwd_l0_body(args.pre[blockIdx.z - args.n01], red);
 }
 
 // ------------------------------------------------------------------ one-wave-per-row kernels
@@ -1770,6 +1892,7 @@ struct Chain {
   ObsIn in;
   bool critic;
   float** act;          // [layers] activations out
+  bool store_h0 = true; // layer-0 activations are needed later (backward pass); acting passes drop them
 };
 
 static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
@@ -1803,6 +1926,28 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
     bool hot = (l >= 1) && hot_ok(M, H, H);
     for (int i = 0; i < nch; ++i)
       if (!aligned16(ch[i].theta) || !aligned16(ch[i].act[0])) hot = false;
+    if (l == 0 && c->layers >= 2 && H == 256 && hot_ok(M, H, H) && nch <= 3 && npre <= 2) {
+      // layers 0 and 1 in one launch
+      L01Args fa;
+      memset(&fa, 0, sizeof(fa));
+      bool lean = true;
+      for (int i = 0; i < nch && lean; ++i) {
+        Chain& C = ch[i];
+        lean = aligned16(C.theta) && aligned16(C.act[0]) &&
+               l0_lean_prob(c, C, C.critic, true, C.store_h0 ? C.act[0] : nullptr, M, fa.p[i].l0);
+        if (!C.store_h0) lean = lean && aligned16(C.theta + C.off.b0);
+        fa.p[i].W1 = C.theta + C.off.W[1]; fa.p[i].b1 = C.theta + C.off.b[1]; fa.p[i].C = C.act[1];
+      }
+      if (lean) {
+        for (int i = 0; i < npre; ++i) fa.pre[i] = pre[i];
+        fa.n01 = nch;
+        dim3 grid(H / 64, M / 16, nch + npre);
+        { ProfScope ps__(CK_FWD_L01, st); hipLaunchKernelGGL(fwd_l01_kernel, grid, dim3(256), 0, st, fa); }
+        CURIOUS_LAUNCH_CHECK("fwd_l01_kernel");
+        ++l;                                        // layer 1 is done as well
+        continue;
+      }
+    }
     if (hot) {
       HotArgs a;
       memset(&a, 0, sizeof(a));
@@ -1908,7 +2053,7 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   fill_obs_stats(cfg, in, o_stats, g_stats);
   const float* thPi = theta + pi_offset(cfg);
   Chain a;
-  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2];
+  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
   if (forward_chains(cfg, &a, 1, n, st)) return -2;
   HeadFwdArgs ha;
   memset(&ha, 0, sizeof(ha));
@@ -1917,7 +2062,7 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   if (launch_head_fwd(ha, n, st)) return -2;
   if (out_Q) {
     Chain qc;
-    qc.theta = theta; qc.off = offQ; qc.in = in; qc.in.u = out_pi; qc.in.ldu = cfg->dimu; qc.critic = true;
+    qc.theta = theta; qc.off = offQ; qc.in = in; qc.in.u = out_pi; qc.in.ldu = cfg->dimu; qc.critic = true; qc.store_h0 = false;
     qc.act = w.act[4];
     if (forward_chains(cfg, &qc, 1, n, st)) return -2;
     memset(&ha, 0, sizeof(ha));
@@ -1955,7 +2100,7 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   in.clip = clip_obs;
   const float* thPi = theta + pi_offset(cfg);
   Chain a;
-  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2];
+  a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
   if (forward_chains(cfg, &a, 1, n, st)) return -2;
   ActStepArgs k;
   memset(&k, 0, sizeof(k));
@@ -2156,8 +2301,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
           !(N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) { ok = false; return; }
       DwSmall& p = sm.p[ns_++];
       p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
-      stiles += ((x.w + 15) / 16) * ((N + 63) / 64);
-      p.tile_end = stiles;
+      stiles = std::max(stiles, ((x.w + 15) / 16) * ((N + 63) / 64));   // -> slots per problem
     };
     add_small(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D,
               g + off.Wout, g + off.bout);
@@ -2166,7 +2310,6 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
       p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
       p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
       tiles += (H / 16) * (H / 64);
-      hw.tile_end[nh] = tiles;
       ++nh;
     }
     hw.nprob = nh;
@@ -2244,16 +2387,19 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   if (lean_dw) {
     smAll.fin = fin;
     dwAll.n_hot = tAll;
+    hwAll.tiles_per = (H / 16) * (H / 64);
+    smAll.slots = stAll > 0 ? stAll : 1;
+    const int nsmall = smAll.nprob * smAll.slots;           // + 1 block for the loss finalisation
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       { ProfScope ps__(CK_DW_ADAM_HER, st);
-        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + stAll + 1), dim3(256), 0, st, dwAll, tail->adam,
+        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + nsmall + 1), dim3(256), 0, st, dwAll, tail->adam,
                            tail->h, n_her); }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
       return 0;
     }
     { ProfScope ps__(CK_DW, st);
-      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + stAll + 1), dim3(256), 0, st, dwAll); }
+      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1), dim3(256), 0, st, dwAll); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
     // generic path: every weight/bias gradient + the loss finalisation in one grouped launch
