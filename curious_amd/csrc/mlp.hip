@@ -189,6 +189,36 @@ __device__ inline f32x4 reduce_tile(float* red, const f32x4 acc[4], int wave, in
   return s;
 }
 
+// Sum over the 64 lanes of a wavefront, result uniform.  Four DPP steps (quad xor 1, quad xor 2, half-row mirror, row
+// mirror) leave the sum of each 16-lane row in all its lanes -- plain VALU moves, no LDS crossbar round trips; the four
+// row sums are then read as scalars.  (The ds_bpermute butterfly this replaces cost ~30 ns per dependent step; the
+// fused prologues below run 16 of these reductions.)
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ inline float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  return v;
+}
+__device__ inline float lane_read(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ inline float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_read(v, 0) + lane_read(v, 16)) + (lane_read(v, 32) + lane_read(v, 48));
+}
+// lane i < 16 gets vals[i] (uniform inputs): lets ONE lane per value do the expensive scalar math of a prologue
+__device__ inline float pick16(const float (&vals)[16], int lane) {
+  float m = vals[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = (lane == i) ? vals[i] : m;
+  return m;
+}
+
 // ------------------------------------------------------------------ forward layer
 // Y[M,N] = act(sum_seg X_seg . W_seg + bias).  grid: x = ceil(N/64), y = ceil(M/16), z = problem
 __global__ __launch_bounds__(256) void fwd_layer_kernel(FwdArgs args) {
@@ -559,6 +589,11 @@ __device__ inline void adam_apply1(const AdamFuse& A, float na, int64_t i, float
 struct GemmHot {
   const float* A; const float* B; const float* aux; float* C; float* aux_out;
   int32_t lda, ldb, ldc, M, N, K;
+  // optional epilogue (DOT kernels): partial products of the output tile with a narrow matrix that the NEXT launch
+  // would otherwise have to contract over whole rows (output layers, the critic's action rows):
+  //   dot_out[tile][m][d] = sum_{c in this 64-column tile} C[m][c] * w(c, d)
+  // dot_mode 1: D = 1, w = dot_w[c];  2: D = 4, w = dot_w[c * 4 + d];  3: D = 4, w = dot_w[d * dot_ld + c]
+  const float* dot_w; float* dot_out; int32_t dot_mode, dot_ld;
 };
 struct HotArgs { GemmHot p[3]; };
 
@@ -567,7 +602,42 @@ __device__ inline void hot_store(float* red, const f32x4 acc[4], int wave, int q
   v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
 }
 
+struct DotW { f32x4 w[4]; };
+__device__ inline DotW dot_prefetch(const GemmHot& P, int c) {
+  // branch-free (4 unconditional loads at selected addresses): a branch on dot_mode here would make every load that
+  // follows in program order wait for the scalar load of dot_mode.  dot_w is a valid address for every problem of a
+  // DOT launch (the host points it at the weight matrix when dot_mode == 0).
+  DotW d;
+  const int m = P.dot_mode;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t off = (m == 2) ? (int64_t)(c + e) * 4 : (m == 3) ? (int64_t)e * P.dot_ld + c : (m == 1) ? c : 0;
+    d.w[e] = ldv(P.dot_w + off);
+  }
+  return d;
+}
+// v: this thread's 4 consecutive output columns of row `row`; the 16 threads of a row are one DPP row
+__device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4& v, int row, int tile, int c4) {
+  if (P.dot_mode == 0) return;
+  f32x4 pd = zero4();
+  if (P.dot_mode == 1) {
+    pd[0] = v[0] * d.w[0][0] + v[1] * d.w[0][1] + v[2] * d.w[0][2] + v[3] * d.w[0][3];
+    pd[0] = row16_sum(pd[0]);
+    if (c4 == 0) P.dot_out[(int64_t)tile * P.M + row] = pd[0];
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = 0.f;
+    if (P.dot_mode == 2) t = v[0] * d.w[0][k] + v[1] * d.w[1][k] + v[2] * d.w[2][k] + v[3] * d.w[3][k];
+    else t = v[0] * d.w[k][0] + v[1] * d.w[k][1] + v[2] * d.w[k][2] + v[3] * d.w[k][3];
+    pd[k] = row16_sum(t);
+  }
+  if (c4 == 0) *reinterpret_cast<f32x4*>(P.dot_out + ((int64_t)tile * P.M + row) * 4) = pd;
+}
+
 // C[M,N] = relu(A[M,K] . B[K,N] + bias)        grid (N/64, M/16, nprob)
+template <bool DOT>
 __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const GemmHot& P = args.p[blockIdx.z];
@@ -576,6 +646,8 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
   const float* xr = P.A + (int64_t)(m0 + j) * P.lda;
   const float* wc = P.B + n0 + 4 * j;
   const f32x4 bias = ldv(P.aux + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
+  DotW dw;
+  if (DOT) dw = dot_prefetch(P, n0 + 4 * (tid & 15));
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int kb = 0; kb < P.K; kb += 256) {
     f32x4 a[4], b[4][4];
@@ -600,9 +672,11 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
 }
 
 // C[M,K'] = (A[M,N] . B[K',N]^T) * relu'(aux[M,K'])    (K' = P.N output columns, reduction over P.K)   grid (K'/64, M/16, nprob)
+template <bool DOT>
 __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const GemmHot& P = args.p[blockIdx.z];
@@ -612,6 +686,8 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
   const float* wr = P.B + (int64_t)(k0 + 4 * j) * P.ldb;
   const int64_t o = (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
   const f32x4 h = ldv(P.aux + o);                           // relu mask source, issued with the first batch
+  DotW dw;
+  if (DOT) dw = dot_prefetch(P, k0 + 4 * (tid & 15));
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int nb = 0; nb < P.K; nb += 256) {
     f32x4 a[4], b[4][4];
@@ -635,6 +711,7 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
   *reinterpret_cast<f32x4*>(P.C + o) = v;
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
 }
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
@@ -1060,35 +1137,6 @@ __global__ __launch_bounds__(256) void fwd_l01_kernel(L01Args args) {
 }
 
 // ------------------------------------------------------------------ one-wave-per-row kernels
-// Sum over the 64 lanes of a wavefront, result uniform.  Four DPP steps (quad xor 1, quad xor 2, half-row mirror, row
-// mirror) leave the sum of each 16-lane row in all its lanes -- plain VALU moves, no LDS crossbar round trips; the four
-// row sums are then read as scalars.  (The ds_bpermute butterfly this replaces cost ~30 ns per dependent step; the
-// fused prologues below run 16 of these reductions.)
-template <int CTRL>
-__device__ inline float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ inline float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);    // row_half_mirror
-  v += dpp_mov<0x140>(v);    // row_mirror
-  return v;
-}
-__device__ inline float lane_read(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ inline float wave_sum(float v) {
-  v = row16_sum(v);
-  return (lane_read(v, 0) + lane_read(v, 16)) + (lane_read(v, 32) + lane_read(v, 48));
-}
-// lane i < 16 gets vals[i] (uniform inputs): lets ONE lane per value do the expensive scalar math of a prologue
-__device__ inline float pick16(const float (&vals)[16], int lane) {
-  float m = vals[0];
-#pragma unroll
-  for (int i = 1; i < 16; ++i) m = (lane == i) ? vals[i] : m;
-  return m;
-}
 
 // out[m][d] = f(sum_k h[m][k] W[k][d] + b[d]),  D <= MAX_U
 struct HeadFwdProb {
@@ -1183,12 +1231,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs args) {
 // order of head_fwd_kernel), builds its A operand  h0[m][k] = relu(zp[m][k] + sum_d (pi[m][d] / max_u) * Wu[d][k])
 // on the fly and runs the usual split-K tile.  Column-tile 0 writes pi and h0 for the backward pass.  H == 256, dimu == 4.
 struct FwdPiProb {
+  const float* part;       // PART: [4][B][4] partial products a_last . Wout of the producing launch's column tiles
   const float* a_last; const float* WoutPi; const float* boutPi;
   const float* zp; const float* Wu; const float* W1; const float* b1;
   float* pi_out; float* h0_out; float* C;
 };
-struct FwdPiArgs { FwdPiProb p[2]; float max_u; };
+struct FwdPiArgs { FwdPiProb p[2]; float max_u; int32_t B; };
 
+template <bool PART>
 __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float s_pi[16 * 4];
@@ -1199,10 +1249,17 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
   const int pm = m0 + 4 * wave;
   // ---- all loads
   f32x4 pr_h[4], wp[4];
+  float pp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (PART) {
+    // thread t < 64 finishes pi[m0 + t/4][t%4] from the 4 column-tile partials
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pr_h[r] = ldv(P.a_last + (int64_t)(pm + r) * H + 4 * lane);
+    for (int t = 0; t < 4; ++t) pp[t] = P.part[((int64_t)t * args.B + m0) * 4 + (tid & 63)];
+  } else {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) wp[e] = ldv(P.WoutPi + (int64_t)(4 * lane + e) * 4);
+    for (int r = 0; r < 4; ++r) pr_h[r] = ldv(P.a_last + (int64_t)(pm + r) * H + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wp[e] = ldv(P.WoutPi + (int64_t)(4 * lane + e) * 4);
+  }
   const float bo = P.boutPi[lane & 3];
   const float* xr = P.zp + (int64_t)(m0 + j) * H;
   const float* wc = P.W1 + n0 + 4 * j;
@@ -1218,8 +1275,15 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
     for (int s = 0; s < 4; ++s) b[u][s] = ldv(wc + (int64_t)(kq + s) * H);
   }
   LOADS_FIRST();
-  // ---- prologue: actor output layer of this wave's 4 rows; lane 4r+d finishes pi[pm + r][d]
-  {
+  // ---- prologue: actor output layer of the 16 rows
+  if (PART) {
+    if (tid < 64) {
+      const float pv = args.max_u * tanhf(((pp[0] + pp[1]) + (pp[2] + pp[3])) + bo);   // actor_critic.py:89
+      s_pi[tid] = pv;
+      if (blockIdx.x == 0 && P.pi_out) P.pi_out[(int64_t)m0 * 4 + tid] = pv;
+    }
+  } else {
+    // lane 4r+d of wave w finishes pi[pm + r][d]
     float sums[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1342,6 +1406,7 @@ __global__ __launch_bounds__(256) void critic_head_kernel(CriticHeadArgs a) {
 // on the fly and runs the usual split-K tile.  Column-tile 0 also writes what later kernels read: dY itself (for the
 // weight gradients), dQ, the per-row loss terms and Q_pi.
 struct DxCritArgs {
+  const float* partQ; const float* partQt; const float* partQpi;   // PART: [4][B] column-tile partials of the heads
   const float* hl[2];      // last hidden activations: critic(u), critic(pi)            [B,H]
   const float* hprev[2];   // activations one layer below (relu mask of the result)       [B,H]
   float* dY[2];            // gradient wrt hl (written by column-tile 0)                  [B,H]
@@ -1367,6 +1432,7 @@ __device__ inline float dot_row(const float* a, const float* b, int H, int lane)
 
 // H == 256 only (one 16-byte fragment per lane covers a row): every global load of the kernel -- the 4 rows of the
 // prologue, the output-layer weights and the main loop's 24 fragments -- is issued in one batch before any use.
+template <bool PART>
 __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ float s_dq[16];
@@ -1382,20 +1448,35 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
   // ---- all loads
   f32x4 pr_h[4], pr_e[4];                                   // prologue rows m0 + 4*wave + r, this lane's 4 columns
   const int pm = m0 + 4 * wave;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pr_h[r] = ldv(a.hl[ch] + (int64_t)(pm + r) * H + 4 * lane);
-    pr_e[r] = ldv(a.e2 + (int64_t)(pm + r) * H + 4 * lane);
-  }
-  const f32x4 wq = ldv(a.WoutQ + 4 * lane), wt = ldv(a.WoutQt + 4 * lane);
+  f32x4 wq = zero4(), wt = zero4();
   const float bq = a.boutQ[0], bt = a.boutQt[0];
   float rew[4], l2v[4];
+  float pq[4] = {0.f, 0.f, 0.f, 0.f}, pt[4] = {0.f, 0.f, 0.f, 0.f}, rew_j = 0.f;
+  f32x4 pi_j = zero4();
+  if (PART) {
+    // every lane finishes the heads of its own row m0 + j from the 4 column-tile partials
+    const float* p1 = (ch == 0) ? a.partQ : a.partQpi;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    rew[r] = a.r[(int64_t)(pm + r) * a.ldr];
-    // sum_j (pi_j / max_u)^2 of row pm + r: lanes 0..U-1 hold one term each (ddpg.py:441)
-    const float pv = (lane < a.U) ? a.pi[(int64_t)(pm + r) * a.ldpi + lane] : 0.f;
-    l2v[r] = (ch == 1) ? pv : 0.f;
+    for (int t = 0; t < 4; ++t) {
+      pq[t] = p1[(int64_t)t * a.B + m0 + j];
+      pt[t] = a.partQt[(int64_t)t * a.B + m0 + j];
+    }
+    rew_j = a.r[(int64_t)(m0 + j) * a.ldr];
+    pi_j = ldv(a.pi + (int64_t)(m0 + j) * 4);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr_h[r] = ldv(a.hl[ch] + (int64_t)(pm + r) * H + 4 * lane);
+      pr_e[r] = ldv(a.e2 + (int64_t)(pm + r) * H + 4 * lane);
+    }
+    wq = ldv(a.WoutQ + 4 * lane); wt = ldv(a.WoutQt + 4 * lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rew[r] = a.r[(int64_t)(pm + r) * a.ldr];
+      // sum_j (pi_j / max_u)^2 of row pm + r: lanes 0..U-1 hold one term each (ddpg.py:441)
+      const float pv = (lane < a.U) ? a.pi[(int64_t)(pm + r) * a.ldpi + lane] : 0.f;
+      l2v[r] = (ch == 1) ? pv : 0.f;
+    }
   }
   const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
   const f32x4 hm = ldv(a.hprev[ch] + o);
@@ -1409,6 +1490,36 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
     for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
   }
   LOADS_FIRST();
+  float dq;
+  if (PART) {
+    const bool writer = blockIdx.x == 0 && wave == 0 && q == 0;        // lanes 0..15 <-> rows m0 + j
+    const int m = m0 + j;
+    const float d1 = ((pq[0] + pq[1]) + (pq[2] + pq[3]));
+    if (ch == 0) {
+      const float Q = d1 + bq, Qt = ((pt[0] + pt[1]) + (pt[2] + pt[3])) + bt;
+      const float target = fclip(rew_j + a.gamma * Qt, a.clip_lo, a.clip_hi);     // ddpg.py:437-438
+      const float diff = target - Q;
+      dq = -2.0f * invB * diff;
+      if (writer) {
+        a.rows[m] = diff * diff;                               // ddpg.py:439
+        a.dQ[m] = dq;
+      }
+    } else {
+      dq = -invB;                                              // d(-mean(Q_pi)) / dQ_pi
+      if (writer) {
+        const float Qpi = d1 + bq;
+        float l2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float tt = pi_j[d] / a.max_u;
+          l2 += tt * tt;                                       // ddpg.py:441
+        }
+        a.rows[a.B + m] = Qpi;                                 // ddpg.py:440
+        a.rows[2 * a.B + m] = l2;
+        a.out_Qpi[m] = Qpi;
+      }
+    }
+  } else {
   // ---- prologue: output-layer values of this wave's 4 rows
   if (need_dots) {
 #pragma unroll
@@ -1444,7 +1555,8 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
   }
   if (ch == 1 && lane < 4) s_dq[4 * wave + lane] = -invB;    // d(-mean(Q_pi)) / dQ_pi
   __syncthreads();
-  const float dq = s_dq[j];
+  dq = s_dq[j];
+  }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -1597,6 +1709,7 @@ __global__ __launch_bounds__(256) void actor_dz_kernel(ActorDzArgs a) {
 // on the fly and runs the split-K tile against main/pi's layer nl-1 kernel.  Column-tile 0 writes dz and da2, which
 // the weight-gradient launch reads.  H == 256, dimu == 4.
 struct DxActorArgs {
+  const float* part;       // PART: [4][B][4] column-tile partials of dd0 . Wu^T
   const float* dd0; const float* Wu; const float* pi; const float* a2; const float* WoutPi;
   const float* hprev;      // actor activations one layer below a2 (relu mask of the result)   [B,H]
   const float* W;          // main/pi kernel of layer nl-1                                     [H,H]
@@ -1605,6 +1718,7 @@ struct DxActorArgs {
   float max_u, l2c;
 };
 
+template <bool PART>
 __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float s_dz[16 * 4];
@@ -1614,11 +1728,20 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
   const int pm = m0 + 4 * wave;
   // ---- all loads
   f32x4 g4[4], wu[4];
+  float pp[4] = {0.f, 0.f, 0.f, 0.f};
+  float pim;
+  if (PART) {
+    // thread t < 64 finishes dz[m0 + t/4][t%4] from the 4 column-tile partials
 #pragma unroll
-  for (int r = 0; r < 4; ++r) g4[r] = ldv(a.dd0 + (int64_t)(pm + r) * H + 4 * lane);
-  const float pim = a.pi[(int64_t)pm * 4 + (lane & 15)];      // lane 4r+d: pi[pm + r][d]
+    for (int t = 0; t < 4; ++t) pp[t] = a.part[((int64_t)t * a.B + m0) * 4 + (tid & 63)];
+    pim = a.pi[(int64_t)m0 * 4 + (tid & 63)];
+  } else {
 #pragma unroll
-  for (int d = 0; d < 4; ++d) wu[d] = ldv(a.Wu + (int64_t)d * H + 4 * lane);
+    for (int r = 0; r < 4; ++r) g4[r] = ldv(a.dd0 + (int64_t)(pm + r) * H + 4 * lane);
+    pim = a.pi[(int64_t)pm * 4 + (lane & 15)];                // lane 4r+d: pi[pm + r][d]
+#pragma unroll
+    for (int d = 0; d < 4; ++d) wu[d] = ldv(a.Wu + (int64_t)d * H + 4 * lane);
+  }
   const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
   const f32x4 hm = ldv(a.hprev + o);
   const float* hrow = a.a2 + (int64_t)(m0 + j) * H;
@@ -1634,8 +1757,18 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
     for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
   }
   LOADS_FIRST();
-  // ---- prologue: dz of this wave's 4 rows; lane 4r+d finishes dz[pm + r][d]
-  {
+  // ---- prologue: dz of the 16 rows
+  if (PART) {
+    if (tid < 64) {
+      const float v = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+      const float th = pim / a.max_u;
+      const float dpi = v / a.max_u + a.l2c * pim;              // ddpg.py:440-441
+      const float dz = dpi * a.max_u * (1.0f - th * th);        // through pi = max_u * tanh(z)
+      s_dz[tid] = dz;
+      if (blockIdx.x == 0) a.dz[(int64_t)m0 * 4 + tid] = dz;
+    }
+  } else {
+    // lane 4r+d of wave w finishes dz[pm + r][d]
     float sums[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1686,6 +1819,7 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
 // Actor output layer + max_u*tanh + exploration noise + clip + eps-greedy + one synthetic-env step, one wavefront per
 // environment: replaces head_fwd_kernel + action_noise_kernel + env_step_kernel (3 dependent launches -> 1 per env step).
 struct ActStepArgs {
+  const float* part;        // PART: [4][n][4] column-tile partials of a_last . Wout (dot epilogue of the last layer)
   const float* a_last;      // actor last hidden activation [n, H]
   const float* Wout; const float* bout;
   int32_t H, U, n;
@@ -1701,6 +1835,7 @@ struct ActStepArgs {
   double reward_eps;
 };
 
+template <bool PART>
 __global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
   __shared__ float s_u[4][MAX_U];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1709,10 +1844,20 @@ __global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
   float o_[MAX_U];
 #pragma unroll
   for (int d = 0; d < MAX_U; ++d) o_[d] = 0.f;
-  const float* hrow = a.a_last + (int64_t)e * a.H;
-  const bool al = (((uintptr_t)hrow | (uintptr_t)a.Wout) & 15) == 0;
-  if (al && a.U == 4) row_dot_fast<4>(hrow, a.Wout, a.H, lane, o_);
-  else row_dot(hrow, a.Wout, a.H, a.U, lane, o_);
+  if (PART) {
+    // dimu == 4: lane d sums the 4 partials of output d
+    float pp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pp[t] = a.part[((int64_t)t * a.n + e) * 4 + (lane & 3)];
+    const float sv = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o_[d] = sv;                    // only o_[lane] of lanes 0..3 is used below
+  } else {
+    const float* hrow = a.a_last + (int64_t)e * a.H;
+    const bool al = (((uintptr_t)hrow | (uintptr_t)a.Wout) & 15) == 0;
+    if (al && a.U == 4) row_dot_fast<4>(hrow, a.Wout, a.H, lane, o_);
+    else row_dot(hrow, a.Wout, a.H, a.U, lane, o_);
+  }
   if (lane < a.U) {
     float v = 0.f;
 #pragma unroll
@@ -1791,6 +1936,7 @@ struct Ws {   // workspace carve-up
   float* dact[3][MAX_LAYERS];  // gradient wrt hidden activations: 0 critic(u), 1 critic(pi), 2 actor
   float *pi_t, *pi, *dQ, *dz, *rows;
   float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
+  float* part[6];              // dot-epilogue partials [4 tiles][B][<=4]: pi_target, pi, Q, Q_target, Q_pi, dz
   int64_t total;
 };
 
@@ -1814,6 +1960,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.rows = take(3 * (int64_t)B);
   w.zp[0] = take(BH);
   w.zp[1] = take(BH);
+  for (int i = 0; i < 6; ++i) w.part[i] = take(16 * (int64_t)B);
   w.total = off;
   return w;
 }
@@ -1893,6 +2040,9 @@ struct Chain {
   bool critic;
   float** act;          // [layers] activations out
   bool store_h0 = true; // layer-0 activations are needed later (backward pass); acting passes drop them
+  int dot_mode = 0;     // dot epilogue on the LAST hidden layer (GemmHot::dot_*)
+  const float* dot_w = nullptr;
+  float* dot_out = nullptr;
 };
 
 static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
@@ -1948,6 +2098,10 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
         continue;
       }
     }
+    const bool last = (l == c->layers - 1);
+    bool want_dot = false;
+    for (int i = 0; i < nch; ++i) want_dot = want_dot || (last && ch[i].dot_mode != 0);
+    CURIOUS_CHECK(!want_dot || hot, "forward_chains: dot epilogue needs the lean hidden-layer kernel");
     if (hot) {
       HotArgs a;
       memset(&a, 0, sizeof(a));
@@ -1956,9 +2110,13 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
         Chain& C = ch[i];
         p.A = C.act[l - 1]; p.lda = H; p.B = C.theta + C.off.W[l]; p.ldb = H; p.aux = C.theta + C.off.b[l];
         p.C = C.act[l]; p.ldc = H; p.M = M; p.N = H; p.K = H;
+        p.dot_w = p.B;
+        if (last && C.dot_mode) { p.dot_mode = C.dot_mode; p.dot_w = C.dot_w; p.dot_out = C.dot_out; p.dot_ld = H; }
       }
       dim3 grid(H / 64, M / 16, nch);
-      { ProfScope ps__(CK_FWD_LAYER, st); hipLaunchKernelGGL(fwd_hot_kernel, grid, dim3(256), 0, st, a); }
+      { ProfScope ps__(CK_FWD_LAYER, st);
+        if (want_dot) hipLaunchKernelGGL(fwd_hot_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(fwd_hot_kernel<false>, grid, dim3(256), 0, st, a); }
       CURIOUS_LAUNCH_CHECK("fwd_hot_kernel");
       continue;
     }
@@ -2101,9 +2259,14 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   const float* thPi = theta + pi_offset(cfg);
   Chain a;
   a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
+  // output layer as a dot epilogue of the last hidden layer when that layer runs on the lean kernel
+  const bool part = nl >= 3 && H == 256 && hot_ok(n, H, H) && aligned16(thPi) && aligned16(workspace) &&
+                    aligned16(thPi + offPi.Wout);
+  if (part) { a.dot_mode = 2; a.dot_w = thPi + offPi.Wout; a.dot_out = w.part[1]; }
   if (forward_chains(cfg, &a, 1, n, st)) return -2;
   ActStepArgs k;
   memset(&k, 0, sizeof(k));
+  k.part = part ? w.part[1] : nullptr;
   k.a_last = w.act[2][nl - 1]; k.Wout = thPi + offPi.Wout; k.bout = thPi + offPi.bout;
   k.H = H; k.U = cfg->dimu; k.n = n; k.max_u_f = cfg->max_u;
   k.noise_scale = noise_scale; k.random_eps = random_eps; k.max_u = (double)cfg->max_u;
@@ -2112,7 +2275,8 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
   k.reward_eps = reward_eps;
   { ProfScope ps__(CK_ACT_STEP, st);
-    hipLaunchKernelGGL(act_step_kernel, dim3((n + 3) / 4), dim3(256), 0, st, k); }
+    if (part) hipLaunchKernelGGL(act_step_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(act_step_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, k); }
   CURIOUS_LAUNCH_CHECK("act_step_kernel");
   return 0;
 }
@@ -2183,15 +2347,27 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     for (int i = 0; i < 3 && fuse_pi; ++i) fuse_pi = l0_lean_prob(cfg, ch[i], ch[i].critic, true, ch[i].act[0], B, tmp);
     for (int i = 0; i < 2 && fuse_pi; ++i) fuse_pi = l0_lean_prob(cfg, cb[i], false, false, w.zp[i], B, pre[i]);
   }
+  // With >= 3 layers the last hidden layer of every chain runs on the lean kernel, whose dot epilogue leaves the
+  // output-layer products as 4 column-tile partials: the fused prologues downstream then add 4 numbers per row
+  // instead of contracting 256-wide rows.  part[]: 0 pi_target, 1 pi, 2 Q, 3 Q_target, 4 Q_pi, 5 dz.
+  const bool use_part = fuse_pi && nl >= 3;
+  if (use_part) {
+    ch[0].dot_mode = 2; ch[0].dot_w = ttPi + offPi.Wout; ch[0].dot_out = w.part[0];
+    ch[1].dot_mode = 1; ch[1].dot_w = thQ + offQ.Wout; ch[1].dot_out = w.part[2];
+    ch[2].dot_mode = 2; ch[2].dot_w = thPi + offPi.Wout; ch[2].dot_out = w.part[1];
+    cb[0].dot_mode = 1; cb[0].dot_w = ttQ + offQ.Wout; cb[0].dot_out = w.part[3];
+    cb[1].dot_mode = 1; cb[1].dot_w = thQ + offQ.Wout; cb[1].dot_out = w.part[4];
+  }
   if (fuse_pi) {
     if (forward_chains(cfg, ch, 3, B, st, 0, pre, 2)) return -2;
     FwdPiArgs fa;
     memset(&fa, 0, sizeof(fa));
-    fa.max_u = cfg->max_u;
+    fa.max_u = cfg->max_u; fa.B = B;
     for (int i = 0; i < 2; ++i) {
       FwdPiProb& p = fa.p[i];
       const float* tq = (i == 0) ? ttQ : thQ;
       const float* tp = (i == 0) ? ttPi : thPi;
+      p.part = w.part[i];
       p.a_last = w.act[i == 0 ? 0 : 2][nl - 1]; p.WoutPi = tp + offPi.Wout; p.boutPi = tp + offPi.bout;
       p.zp = w.zp[i]; p.Wu = tq + offQ.W0 + urow * H; p.W1 = tq + offQ.W[1]; p.b1 = tq + offQ.b[1];
       p.pi_out = (i == 0) ? nullptr : w.pi;                 // pi_target is consumed here only
@@ -2199,7 +2375,9 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
       p.C = w.act[i == 0 ? 3 : 4][1];
     }
     dim3 grid(H / 64, B / 16, 2);
-    { ProfScope ps__(CK_FWD_PI, st); hipLaunchKernelGGL(fwd_pi_kernel, grid, dim3(256), 0, st, fa); }
+    { ProfScope ps__(CK_FWD_PI, st);
+      if (use_part) hipLaunchKernelGGL(fwd_pi_kernel<true>, grid, dim3(256), 0, st, fa);
+      else hipLaunchKernelGGL(fwd_pi_kernel<false>, grid, dim3(256), 0, st, fa); }
     CURIOUS_LAUNCH_CHECK("fwd_pi_kernel");
     if (forward_chains(cfg, cb, 2, B, st, 2)) return -2;
   } else {
@@ -2219,9 +2397,11 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   //      backward level when the lean kernels apply)
   const bool dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
   const bool fuse_crit = dx_hot && nl >= 2 && H == 256;
+  CURIOUS_CHECK(!use_part || fuse_crit, "curious_ddpg_grads: inconsistent lean-path conditions");
   if (fuse_crit) {
     DxCritArgs a;
     memset(&a, 0, sizeof(a));
+    a.partQ = w.part[2]; a.partQt = w.part[3]; a.partQpi = w.part[4];
     const int l = nl - 1;
     a.hl[0] = w.act[1][l]; a.hl[1] = w.act[4][l];
     a.hprev[0] = w.act[1][l - 1]; a.hprev[1] = w.act[4][l - 1];
@@ -2236,7 +2416,9 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     a.max_u = cfg->max_u;
     a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
     dim3 grid(H / 64, B / 16, 2);
-    { ProfScope ps__(CK_CRITIC_HEAD, st); hipLaunchKernelGGL(dx_crit_kernel, grid, dim3(256), 0, st, a); }
+    { ProfScope ps__(CK_CRITIC_HEAD, st);
+      if (use_part) hipLaunchKernelGGL(dx_crit_kernel<true>, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(dx_crit_kernel<false>, grid, dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("dx_crit_kernel");
   } else
   {
@@ -2264,9 +2446,15 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
         const int chain = (k == 0) ? 1 : 4;
         p.A = w.dact[k][l]; p.lda = H; p.B = thQ + offQ.W[l]; p.ldb = H; p.aux = w.act[chain][l - 1];
         p.C = w.dact[k][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
+        p.dot_w = p.B;
+        if (use_part && l == 1 && k == 1) {                  // d pi_loss / d(action slot): dd0 . Wu^T as partials
+          p.dot_mode = 3; p.dot_w = thQ + offQ.W0 + urow * H; p.dot_out = w.part[5]; p.dot_ld = H;
+        }
       }
       dim3 grid(H / 64, B / 16, 2);
-      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel, grid, dim3(256), 0, st, ha); }
+      { ProfScope ps__(CK_DX, st);
+        if (use_part && l == 1) hipLaunchKernelGGL(dx_hot_kernel<true>, grid, dim3(256), 0, st, ha);
+        else hipLaunchKernelGGL(dx_hot_kernel<false>, grid, dim3(256), 0, st, ha); }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel");
       continue;
     }
@@ -2340,15 +2528,19 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   const float l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
   const bool fuse_actor = fuse_crit && U == 4 && aligned16(w.pi) && aligned16(w.dz) && aligned16(thQ + offQ.W0 + urow * H) &&
                           aligned16(thPi + offPi.Wout);
+  CURIOUS_CHECK(!use_part || fuse_actor, "curious_ddpg_grads: inconsistent lean-path conditions");
   if (fuse_actor) {
     DxActorArgs a;
     const int l = nl - 1;
+    a.part = w.part[5];
     a.dd0 = w.dact[1][0]; a.Wu = thQ + offQ.W0 + urow * H; a.pi = w.pi;
     a.a2 = w.act[2][l]; a.WoutPi = thPi + offPi.Wout; a.hprev = w.act[2][l - 1]; a.W = thPi + offPi.W[l];
     a.dz = w.dz; a.da2 = w.dact[2][l]; a.dX = w.dact[2][l - 1];
     a.B = B; a.max_u = cfg->max_u; a.l2c = l2c;
     dim3 grid(H / 64, B / 16, 1);
-    { ProfScope ps__(CK_ACTOR_DZ, st); hipLaunchKernelGGL(dx_actor_kernel, grid, dim3(256), 0, st, a); }
+    { ProfScope ps__(CK_ACTOR_DZ, st);
+      if (use_part) hipLaunchKernelGGL(dx_actor_kernel<true>, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(dx_actor_kernel<false>, grid, dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("dx_actor_kernel");
   } else {
     ActorDzArgs a;
@@ -2368,7 +2560,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
       p.A = w.dact[2][l]; p.lda = H; p.B = thPi + offPi.W[l]; p.ldb = H; p.aux = w.act[2][l - 1];
       p.C = w.dact[2][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
       dim3 grid(H / 64, B / 16, 1);
-      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel, grid, dim3(256), 0, st, ha); }
+      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel<false>, grid, dim3(256), 0, st, ha); }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel(actor)");
       continue;
     }
