@@ -201,8 +201,16 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
     try:
         with open(path) as f:
-            d = json.load(f)[kernel]
-        return int(2 * d['FETCH_SIZE']['avg_KB'] * 1024 + d['WRITE_SIZE']['avg_KB'] * 1024)
+            table = json.load(f)
+        tot = {'FETCH_SIZE': [0, 0.0], 'WRITE_SIZE': [0, 0.0]}
+        for name, counters in table.items():                      # template instances: fwd_hot_kernel<true>, <false>
+            if name == kernel or name.startswith(kernel + '<'):
+                for c in tot:
+                    tot[c][0] += counters[c]['launches']
+                    tot[c][1] += counters[c]['launches'] * counters[c]['avg_KB']
+        if not tot['FETCH_SIZE'][0] or not tot['WRITE_SIZE'][0]:
+            return None
+        return int(1024 * (2 * tot['FETCH_SIZE'][1] / tot['FETCH_SIZE'][0] + tot['WRITE_SIZE'][1] / tot['WRITE_SIZE'][0]))
     except Exception:
         return None
 
