@@ -13,6 +13,7 @@ rng_mode='numpy' (default): every random draw comes from the NumPy global stream
 with a seeded reference run).  rng_mode='device': Philox streams on the GPU, nothing crosses PCIe per update and the
 whole train() step can be replayed from a hipGraph (use_graph=True).
 """
+import os
 import pickle
 from collections import OrderedDict
 
@@ -646,7 +647,8 @@ class DDPG(object):
         out = None
         while n > 0:
             k = 1
-            if self._device_loop() and self.use_graph and not dist.is_distributed() and n >= CHAIN and self._cur == 0:
+            chainable = not dist.is_distributed() or (self._graph_allreduce() and self.Q_adam.t % CHAIN == 0)
+            if self._device_loop() and self.use_graph and chainable and n >= CHAIN and self._cur == 0:
                 k = CHAIN
             out = self._train_device(k) if self._device_loop() else self.train()
             n -= k
@@ -674,8 +676,8 @@ class DDPG(object):
             self._batch_stale = True
         self._layout_for_batch = self._layout
         if dist.is_distributed():
-            assert k == 1
-            return self._train_device_ranks()
+            assert k == 1 or (k == CHAIN and self._graph_allreduce() and 100 % CHAIN == 0)
+            return self._train_device_ranks(k)
         graph = None
         if self.use_graph:
             # capturing runs the launches once for real: parameters and counter are restored by _capture, the staged
@@ -707,10 +709,29 @@ class DDPG(object):
         self.pi_adam.t += k
         return self._losses[0], self._Q_pi
 
-    def _train_device_ranks(self):
-        if self._graph is None and self.use_graph:
+    @staticmethod
+    def _graph_allreduce():
+        """CURIOUS_GRAPH_ALLREDUCE=1: capture the RCCL all-reduce inside the update graph (one graph launch per update
+        or per chain instead of graph + eager collective + graph).  Opt-in: it could only be exercised against a
+        single-rank RCCL communicator on the 1-GPU development boxes."""
+        return os.environ.get('CURIOUS_GRAPH_ALLREDUCE', '0') == '1'
+
+    def _ranks_update(self):
+        self._grads()
+        dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
+        self._adam_and_sample()
+
+    def _train_device_ranks(self, k=1):
+        one_graph = self.use_graph and self._graph_allreduce()
+        if self.use_graph and not one_graph and self._graph is None:
             self._graph = self._capture(self._grads)
             self._graph_b = self._capture(self._adam_and_sample)
+            self._batch_stale = True
+        if one_graph and k == 1 and self._graphs[0] is None:
+            self._graphs[0] = self._capture(self._ranks_update)
+            self._batch_stale = True
+        if one_graph and k > 1 and self._graph_chain is None:
+            self._graph_chain = self._capture(lambda: [self._ranks_update() for _ in range(CHAIN)])
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
@@ -719,16 +740,16 @@ class DDPG(object):
             self.Q_adam.theta = self.theta                           # checksum over the fused vector (C4)
             MpiAdam.check_synced(self.Q_adam)
             self.Q_adam.theta = self.theta[:self.off_pi]
-        if self.use_graph:
+        if one_graph:
+            (self._graph_chain if k > 1 else self._graphs[0]).replay()
+        elif self.use_graph:
             self._graph.replay()
-            dist.allreduce_sum_(self.grad)                           # C1+C2 fused; SUM, not mean (ddpg.py:452)
+            dist.allreduce_sum_(self.grad)
             self._graph_b.replay()
         else:
-            self._grads()
-            dist.allreduce_sum_(self.grad)
-            self._adam_and_sample()
-        self.Q_adam.t += 1
-        self.pi_adam.t += 1
+            self._ranks_update()
+        self.Q_adam.t += k
+        self.pi_adam.t += k
         return self._losses[0], self._Q_pi
 
     def _update_fused(self, p):

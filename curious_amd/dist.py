@@ -12,8 +12,14 @@ import torch
 import torch.distributed as td
 
 
+def _forced():
+    """CURIOUS_FORCE_DIST=1: take the multi-rank code paths (RCCL communicator, split update graphs, collectives) even
+    with WORLD_SIZE=1 -- lets a single-GPU box exercise them against the real RCCL library."""
+    return os.environ.get('CURIOUS_FORCE_DIST', '0') == '1'
+
+
 def is_distributed():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _forced())
 
 
 def rank():
@@ -27,7 +33,7 @@ def world_size():
 def init_from_env(backend=None):
     """Initialise the process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for 1 rank."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or (td.is_available() and td.is_initialized()):
+    if (ws <= 1 and not _forced()) or (td.is_available() and td.is_initialized()):
         return
     if backend is None:
         # CURIOUS_DIST_BACKEND=gloo lets several ranks share one GPU (functional testing of the N > 1 path on a

@@ -256,6 +256,30 @@ def test_fused_update_equals_unfused_sequence(small):
     assert float(a_f.theta.abs().sum()) != float(a_f.theta_target.abs().sum())   # the parameters did move
 
 
+def test_rank_paths_match_single_rank():
+    """The multi-rank update paths (split graphs + eager RCCL all-reduce; all-reduce captured in the graph), run on
+    a one-rank RCCL communicator, leave bit-identical parameters to the fused single-rank path."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for extra in ({}, {'CURIOUS_FORCE_DIST': '1'}, {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '1'}):
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), **extra)
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rank_path_check.py')], env=env, cwd=root,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1].split()
+        assert line[2] == '35'
+        digests.append(line[1])
+    assert digests[0] == digests[1] == digests[2], digests
+
+
 def test_batched_rollout_matches_oracle():
     """GPU-resident rollout (actor forward + noise + env step kernels) against the oracle env + oracle policy."""
     from curious_amd.envs import EnvFactory

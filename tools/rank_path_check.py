@@ -1,0 +1,31 @@
+"""Prints a digest of the parameters after 35 updates of the bench job.  Run it plain, with CURIOUS_FORCE_DIST=1 (split
+graphs + eager RCCL all-reduce on a one-rank communicator) and with CURIOUS_GRAPH_ALLREDUCE=1 on top (all-reduce
+captured in the update graph): the three digests must be equal (tests/test_gpu_agent.py::test_rank_paths...)."""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    from curious_amd import dist
+    dist.init_from_env()
+    torch.cuda.set_device(0)
+    params, dims, policy, worker = bench.build_job(use_graph=True)
+    bench.prefill(policy, 256, seed=0)
+    for _ in range(5):
+        policy.train()
+    policy.train_batches(30)
+    torch.cuda.synchronize()
+    h = hashlib.sha256(policy.theta.cpu().numpy().tobytes()).hexdigest()
+    print('DIGEST', h, int(policy._step_ctr), float(policy._losses[0]), flush=True)
+    # skip interpreter teardown: destroying an RCCL communicator while captured graphs still reference its streams
+    # aborts now and then on this stack, and nothing here needs a clean shutdown
+    os._exit(0)
+
+
+if __name__ == '__main__':
+    main()
