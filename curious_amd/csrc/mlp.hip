@@ -22,6 +22,7 @@
 // Output layers (N = 1 or dimu) and everything elementwise around the losses run in "one wave per batch row"
 // kernels.  Gradients are written directly at their offset of the [Q_grad | pad | pi_grad] vector.
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 #include "common.h"
@@ -767,18 +768,14 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   *reinterpret_cast<f32x4*>(dst) = v;
   if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx, v, pre);
   if (by == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float tt = bsum[e];
-      tt += __shfl_xor(tt, 16);
-      tt += __shfl_xor(tt, 32);
-      bsum[e] = tt;
-    }
+    // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
     __syncthreads();
-    if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
     __syncthreads();
     if (tid < 64) {
-      const float gb = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
       P.aux_out[n0 + tid] = gb;
       if (ADAM) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
@@ -799,9 +796,116 @@ struct DwSmall {
 #define MAX_DW_SMALL 12
 struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin; };   // `slots` block ids per problem
 
+// One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
+// layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
+// load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
+template <bool ADAM, bool YV>
+__device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nx = (P.N + 63) >> 6;
+  const int by = t / nx, bx = t - by * nx;
+  const int j = lane & 15, q = lane >> 4;
+  const int k0 = by * 16, n0 = bx * 64;
+  const int krow = k0 + j, col = n0 + 4 * j;
+  const bool k_ok = krow < P.w;
+  const float* xc = P.x + min(krow, P.w - 1);
+  const int colc = YV ? min(col, P.N - 4) : 0;
+  const float* yc = P.dY + colc;
+  // optimiser operands of what this thread finishes, fetched with the first batch of loads
+  const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
+  const bool own = grow < P.w && gcol < P.N;
+  float* const dst = P.dW + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
+  const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  AdamPre4 pre;
+  pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
+  if (ADAM) {
+    adam_alphas(A, aQ, aPi);
+    if (YV) {
+      pre = adam_prefetch4(A, own ? pidx : 0);
+    } else if (own) {                                       // N == 1: one element per owning thread
+      pre.m[0] = A.m[pidx]; pre.v[0] = A.v[pidx]; pre.th[0] = A.theta[pidx];
+    }
+    if (own_b) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+  }
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
+        if (YV) {
+          b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+        } else {
+          b[u][s] = zero4();
+          b[u][s][0] = yc[(int64_t)(mq + s) * P.lddy];
+        }
+      }
+    }
+    LOADS_FIRST();
+    if (P.div != 1.0f) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[u][s] = fdiv(a[u][s], P.div);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = k_ok ? a[u][s] : 0.f;
+        bsum += b[u][s];
+        if (YV) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
+        } else {
+          acc[0] = MFMA(av, b[u][s][0], acc[0]);
+        }
+      }
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  if (own) {
+    const float na = (pidx < A.n_Q) ? -aQ : -aPi;
+    if (YV) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+      if (ADAM) adam_apply4(A, na, pidx, v, pre);
+    } else {
+      dst[0] = v[0];                                        // N == 1 (gcol == 0)
+      if (ADAM) {
+        float m = pre.m[0], vv = pre.v[0];
+        const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
+        A.m[pidx] = m; A.v[pidx] = vv; A.theta[pidx] = th;
+      }
+    }
+  }
+  if (P.db && by == 0) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (own_b) {
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+      P.db[n0 + tid] = gb;
+      if (ADAM) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+      }
+    }
+  }
+}
+
 template <bool ADAM>
 __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x;
   // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
   // arithmetic, so the descriptor load does not wait for a search through the table
   const int pi = bid / args.slots, t = bid - pi * args.slots;
@@ -833,107 +937,10 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
     return;
   }
   const DwSmall& P = args.p[pi];
-  const int nx = (P.N + 63) >> 6;
-  if (t >= ((P.w + 15) >> 4) * nx) return;
-  const int by = t / nx, bx = t - by * nx;
-  const int j = lane & 15, q = lane >> 4;
-  const int k0 = by * 16, n0 = bx * 64;
-  const int krow = k0 + j, col = n0 + 4 * j;
-  const bool k_ok = krow < P.w;
-  const float* xc = P.x + min(krow, P.w - 1);
-  const bool yv = (P.N & 3) == 0;
-  const int colc = yv ? min(col, P.N - 4) : min(col, P.N - 1);
-  const float* yc = P.dY + colc;
-  // optimiser operands of what this thread finishes, fetched with the first batch of loads
-  const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
-  const bool own = grow < P.w && gcol < P.N;
-  float* const dst = P.dW + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
-  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
-  const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
-  const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
-  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
-  AdamPre4 pre;
-  pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
-  if (ADAM) {
-    adam_alphas(A, aQ, aPi);
-    if (yv) {
-      pre = adam_prefetch4(A, own ? pidx : 0);
-    } else if (own) {                                       // N == 1: one element per owning thread
-      pre.m[0] = A.m[pidx]; pre.v[0] = A.v[pidx]; pre.th[0] = A.theta[pidx];
-    }
-    if (own_b) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
-  }
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  f32x4 bsum = zero4();
-  for (int mb = 0; mb < args.M; mb += 256) {
-    float a[4][4];
-    f32x4 b[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
-        if (yv) {
-          b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
-        } else {
-          f32x4 bb = zero4();
-          bb[0] = yc[(int64_t)(mq + s) * P.lddy];        // N not a multiple of 4: only N == 1 occurs (critic output)
-          b[u][s] = bb;
-        }
-      }
-    }
-    LOADS_FIRST();
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float av = a[u][s];
-        if (P.div != 1.0f) av = fdiv(av, P.div);
-        av = k_ok ? av : 0.f;
-        bsum += b[u][s];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
-      }
-  }
-  int orow, c4;
-  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
-  if (own) {
-    const float na = (pidx < A.n_Q) ? -aQ : -aPi;
-    if (yv) {
-      *reinterpret_cast<f32x4*>(dst) = v;
-      if (ADAM) adam_apply4(A, na, pidx, v, pre);
-    } else {
-      dst[0] = v[0];                                        // N == 1 (gcol == 0)
-      if (ADAM) {
-        float m = pre.m[0], vv = pre.v[0];
-        const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
-        A.m[pidx] = m; A.v[pidx] = vv; A.theta[pidx] = th;
-      }
-    }
-  }
-  if (P.db && by == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float tt = bsum[e];
-      tt += __shfl_xor(tt, 16);
-      tt += __shfl_xor(tt, 32);
-      bsum[e] = tt;
-    }
-    __syncthreads();
-    if (q == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + 4 * j) = bsum;
-    __syncthreads();
-    if (own_b) {
-      const float gb = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
-      P.db[n0 + tid] = gb;
-      if (ADAM) {
-        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
-      }
-    }
-  }
+  if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red);
 }
-
 
 // Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
 // hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
