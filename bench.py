@@ -391,6 +391,10 @@ def main():
                        'hipgraph': not args.no_graph, 'rng': 'device (Philox)',
                        'parallelism': 'dp%d' % world},
             'roofline': roof,
+            # SURVEY 8d whole-update figure: 47 213 algorithmic bytes per gradient transition (HER rows + 40 B/param)
+            'step_hbm': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS * world,
+                         'achieved': round(args.steps * N_BATCHES * BATCH * world / elapsed * 47213 / 1e9, 2),
+                         'frac': round(args.steps * N_BATCHES * BATCH / elapsed * 47213 / 1e9 / HBM_PEAK_GBS, 5)},
             'kernels': table,
         }
         if phases:
