@@ -29,6 +29,9 @@ from curious_amd.util import import_function, store_args, transitions_in_episode
 
 ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
 CHAIN = 10              # updates per chained hipGraph launch in train_batches (even: the staging tensors alternate)
+# hipStreamCaptureModeThreadLocal: HIP calls of OTHER threads (the RCCL watchdog polling events) must not invalidate a
+# capture that only this thread's launches take part in
+CAPTURE_MODE = 'thread_local'
 
 
 def dims_to_shapes(input_dims):
@@ -278,7 +281,7 @@ class DDPG(object):
             # envs for real); the library's kernels need no lazy initialisation
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 steps()
             self._roll_graphs[key] = g
         g.replay()
@@ -781,7 +784,7 @@ class DDPG(object):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             fn()
         # undo the side effects of the warm-up / capture runs
         self._step_ctr.copy_(ctr)
