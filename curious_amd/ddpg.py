@@ -512,7 +512,10 @@ class DDPG(object):
         host = np.concatenate([prefix, alias, task, cur])
         if getattr(self, '_tables', None) is None or self._tables.numel() != host.size:
             self._tables = torch.zeros(host.size, dtype=torch.int32, device=self.device)
-        self._tables.copy_(torch.from_numpy(host), non_blocking=False)
+            self._tables_host = torch.zeros(host.size, dtype=torch.int32).pin_memory()
+        # pinned + asynchronous: the previous upload from this buffer finished long ago (every cycle has a D2H sync)
+        self._tables_host.numpy()[:] = host
+        self._tables.copy_(self._tables_host, non_blocking=True)
         n0 = nb1 + 1
         r = _lib.SampleRng()
         r.seed = (self.seed * 104729 + 7 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF

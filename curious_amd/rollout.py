@@ -232,8 +232,11 @@ class RolloutWorker:
             else:
                 u = out
             env.step_all(u, t)
-        successful = env.last_success().cpu().numpy().astype(np.float64)       # one D2H sync per rollout
-        if np.isnan(successful).any() or bool(torch.isnan(env.o).any()):        # rollout.py:268-271
+        # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
+        succ = env.last_success()
+        both = torch.cat([succ, torch.isnan(env.o).any().to(succ.dtype).reshape(1)]).cpu().numpy().astype(np.float64)
+        successful, o_has_nan = both[:-1], both[-1] != 0
+        if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
             return self._generate_rollouts_batched()
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
