@@ -256,6 +256,25 @@ def test_fused_update_equals_unfused_sequence(small):
     assert float(a_f.theta.abs().sum()) != float(a_f.theta_target.abs().sum())   # the parameters did move
 
 
+def test_step_size_ring_refill_under_chained_graphs():
+    """4 200 updates cross the 4 096-entry ring of Adam step sizes: chained hipGraph replay stays bit-identical to
+    eager launches across the refill (and to the float64 host formula of mpi_adam.py:30 at the end)."""
+    a_graph, _ = build_pair(4, 40, rng_mode='device', use_graph=True, batch_size=64, hidden=64)
+    a_eager, _ = build_pair(4, 40, rng_mode='device', use_graph=False, batch_size=64, hidden=64)
+    rng = np.random.RandomState(3)
+    ep = synth_episodes(rng, 32, 4, 40)
+    for a in (a_graph, a_eager):
+        np.random.seed(4)
+        a.store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(4), 32)
+    a_graph.train_batches(4200)
+    for _ in range(4200):
+        a_eager.train()
+    torch.cuda.synchronize()
+    assert a_graph.Q_adam.t == a_eager.Q_adam.t == 4200 == int(a_graph._step_ctr)
+    assert torch.equal(a_graph.theta, a_eager.theta)
+    assert torch.isfinite(a_graph.theta).all()
+
+
 def test_rank_paths_match_single_rank():
     """The multi-rank update paths (split graphs + eager RCCL all-reduce; all-reduce captured in the graph), run on
     a one-rank RCCL communicator, leave bit-identical parameters to the fused single-rank path."""
