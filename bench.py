@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--prefill', type=int, default=2048, help='synthetic episodes pre-loaded per buffer')
+    ap.add_argument('--env', default=ENV, help='diagnostic: another synthetic env (the headline is %s)' % ENV)
     ap.add_argument('--phases', action='store_true', help='diagnostic: time rollout / store / updates separately '
                                                             '(adds device syncs; not the headline number)')
     return ap.parse_args()
@@ -51,12 +52,12 @@ def maybe_relaunch(args):
         sys.exit(subprocess.call(cmd))
 
 
-def build_job(use_graph, seed=0):
+def build_job(use_graph, seed=0, env=None):
     from curious_amd import dist, logger
     from curious_amd.experiment import config
     from curious_amd.rollout import RolloutWorker
     params = dict(config.MULTI_TASK_PARAMS)
-    params.update(env_name=ENV, task_selection='active_competence_progress', goal_selection='random',
+    params.update(env_name=env or ENV, task_selection='active_competence_progress', goal_selection='random',
                   task_replay='replay_task_cp_buffer', goal_replay='her', structure='curious', normalize_obs=False,
                   num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=B_R,
                   n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
@@ -330,7 +331,7 @@ def main():
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
     torch.cuda.set_device(dist.local_device_index())
     np.random.seed(1234 + 1000000 * rank)                        # train.py:242
-    params, dims, policy, worker = build_job(use_graph=not args.no_graph)
+    params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env)
     prefill(policy, args.prefill, seed=rank)
 
     for _ in range(args.warmup):

@@ -198,7 +198,7 @@ template <int CTRL>
 __device__ inline float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ inline float row16_sum(float v) {
+__device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
   v += dpp_mov<0x141>(v);    // row_half_mirror
@@ -208,12 +208,12 @@ __device__ inline float row16_sum(float v) {
 __device__ inline float lane_read(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-__device__ inline float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
   return (lane_read(v, 0) + lane_read(v, 16)) + (lane_read(v, 32) + lane_read(v, 48));
 }
 // lane i < 16 gets vals[i] (uniform inputs): lets ONE lane per value do the expensive scalar math of a prologue
-__device__ inline float pick16(const float (&vals)[16], int lane) {
+__device__ __forceinline__ float pick16(const float (&vals)[16], int lane) {
   float m = vals[0];
 #pragma unroll
   for (int i = 1; i < 16; ++i) m = (lane == i) ? vals[i] : m;
@@ -970,54 +970,73 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFu
 // segments of row matrices (batch columns [o | td | u], the actor output, g ...), each a multiple of 4 wide.  With
 // K <= 64 every wave owns exactly one 16-wide chunk: 1 + 4 loads and 16 MFMAs per wave.
 struct SegL { const float* x; const float* W; int32_t ld, w; float div, clip; };
-struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy, relu; };
+struct L0Prob { SegL seg[MAX_SEG]; const float* bias; float* Y; int32_t nseg, M, N, ldy, relu, ktot; };
 struct L0Args { L0Prob p[5]; };
 
-__device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
-  // locate this lane's 4 virtual columns kv .. kv+3 (16-byte group never straddles a segment: widths % 4 == 0)
-  int kv = 16 * wave + 4 * q;
-  const float* xp = P.seg[0].x;
-  const float* wp = P.seg[0].W;
-  int ld = P.seg[0].ld;
-  float dv = 1.0f, cl = 0.0f;
-  bool ok = false;
+// Branch-free lookup of the segment holding virtual input columns kv .. kv+3 (a 16-byte group never straddles a
+// segment: widths % 4 == 0).  The segment table is read unconditionally (unused entries are zero-width); no divergent
+// branches, no dependent scalar loads.
+struct SegPick { const float* x; const float* W; int ld, kl; float dv, cl; bool ok; };
+__device__ __forceinline__ SegPick seg_pick(const L0Prob& P, int kv) {
+  // (fields are read straight from the kernarg struct: copying SegL structs around sent them through scratch memory
+  //  and turned every dependent load into a flat load)
+  const int e0 = P.seg[0].w, e1 = e0 + P.seg[1].w, e2 = e1 + P.seg[2].w, e3 = e2 + P.seg[3].w;   // exclusive ends
+  const bool in0 = kv < e0, in1 = kv < e1, in2 = kv < e2, in3 = kv < e3;
+  SegPick p;
+  p.x = in0 ? P.seg[0].x : in1 ? P.seg[1].x : in2 ? P.seg[2].x : in3 ? P.seg[3].x : P.seg[0].x;
+  p.W = in0 ? P.seg[0].W : in1 ? P.seg[1].W : in2 ? P.seg[2].W : in3 ? P.seg[3].W : P.seg[0].W;
+  p.ld = in0 ? P.seg[0].ld : in1 ? P.seg[1].ld : in2 ? P.seg[2].ld : in3 ? P.seg[3].ld : P.seg[0].ld;
+  p.kl = in3 ? kv - (in0 ? 0 : in1 ? e0 : in2 ? e1 : e2) : 0;                   // column inside the segment
+  p.dv = in0 ? P.seg[0].div : in1 ? P.seg[1].div : in2 ? P.seg[2].div : in3 ? P.seg[3].div : 1.0f;
+  p.cl = in0 ? P.seg[0].clip : in1 ? P.seg[1].clip : in2 ? P.seg[2].clip : in3 ? P.seg[3].clip : 0.0f;
+  p.ok = in3;
+  return p;
+}
+__device__ __forceinline__ bool seg_any_div(const L0Prob& P) {   // uniform: only the critic's action segment divides
+  return (P.seg[0].div != 1.0f) || (P.seg[1].w > 0 && P.seg[1].div != 1.0f) ||
+         (P.seg[2].w > 0 && P.seg[2].div != 1.0f) || (P.seg[3].w > 0 && P.seg[3].div != 1.0f);
+}
+__device__ inline f32x4 seg_prep(f32x4 a, float cl, float dv, bool any_div, bool ok) {
+  const float c = (cl > 0.0f) ? cl : INFINITY;
 #pragma unroll
-  for (int s = 0; s < MAX_SEG; ++s) {
-    if (s < P.nseg && !ok) {
-      if (kv < P.seg[s].w) {
-        ok = true;
-        xp = P.seg[s].x + kv; wp = P.seg[s].W + (int64_t)kv * P.N; ld = P.seg[s].ld;
-        dv = P.seg[s].div; cl = P.seg[s].clip;
-      } else {
-        kv -= P.seg[s].w;
-      }
-    }
-  }
-  if (!ok) { xp = P.seg[0].x; wp = P.seg[0].W; ld = P.seg[0].ld; }     // any valid address; contribution zeroed
-  const int row = min(m0 + j, P.M - 1);
-  f32x4 a = ldv(xp + (int64_t)row * ld);
-  f32x4 b[4];
-  const float* wc = wp + n0 + 4 * j;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) b[s] = ldv(wc + (int64_t)s * P.N);
-  const f32x4 bias = ldv(P.bias + n0 + 4 * (tid & 15));
-  LOADS_FIRST();
-  if (cl > 0.0f) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = fclip(a[e], -cl, cl);
-  }
-  if (dv != 1.0f) {
+  for (int e = 0; e < 4; ++e) a[e] = fclip(a[e], -c, c);
+  if (any_div) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = fdiv(a[e], dv);
   }
-  a = sel4(ok && (m0 + j < P.M), a);
+  return sel4(ok, a);
+}
+
+// NC = number of 64-wide k chunks (total K <= 64 * NC): wave w owns the 16-wide group w of every chunk
+template <int NC>
+__device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const int row = min(m0 + j, P.M - 1);
+  f32x4 a[NC], b[NC][4];
+  float dv[NC], cl[NC];
+  bool ok[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const SegPick sp = seg_pick(P, 64 * c + 16 * wave + 4 * q);
+    dv[c] = sp.dv; cl[c] = sp.cl; ok[c] = sp.ok;
+    a[c] = ldv(sp.x + sp.kl + (int64_t)row * sp.ld);
+    const float* wc = sp.W + (int64_t)sp.kl * P.N + n0 + 4 * j;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[c][s] = ldv(wc + (int64_t)s * P.N);
+  }
+  const f32x4 bias = ldv(P.bias + n0 + 4 * (tid & 15));
+  LOADS_FIRST();
+  const bool any_div = seg_any_div(P);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int c = 0; c < NC; ++c) {
+    const f32x4 av = seg_prep(a[c], cl[c], dv[c], any_div, ok[c] && (m0 + j < P.M));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[s], b[s][e], acc[e]);
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(av[s], b[c][s][e], acc[e]);
+  }
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
   if (m0 + orow >= P.M) return;
@@ -1030,9 +1049,10 @@ __device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
 }
 
 
+template <int NC>
 __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  fwd_l0_body(args.p[blockIdx.z], red);
+  fwd_l0_body<NC>(args.p[blockIdx.z], red);
 }
 
 // ------------------------------------------------------------------ layers 0 + 1 in one launch
@@ -1046,32 +1066,23 @@ struct L01Prob { L0Prob l0; const float* W1; const float* b1; float* C; };
 struct L01Args { L01Prob p[3]; L0Prob pre[2]; int32_t n01; };
 #define H0_LD 260      // LDS row stride of the h0 tile: 260 % 64 = 4 -> the 16 rows of a b128 read hit distinct banks
 
+template <int NC>
 __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
   const L0Prob& P = Q.l0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
   const int H = 256;
   // ---- all global loads: 4 input fragments + 16 layer-0 weight fragments, 16 layer-1 weight fragments, biases
-  f32x4 xa[4], w0[4][4], w1[4][4];
-  float dv[4], cl[4];
-  bool okv[4];
-  // segment table read once, unconditionally (unused entries are zero-width); the per-lane lookup below is pure
-  // select arithmetic -- no divergent branches, no dependent scalar loads
-  const SegL g0 = P.seg[0], g1 = P.seg[1], g2 = P.seg[2], g3 = P.seg[3];
-  const int e0 = g0.w, e1 = e0 + g1.w, e2 = e1 + g2.w, e3 = e2 + g3.w;     // exclusive ends of the segments
+  constexpr int NG = 4 * NC;                       // 16-wide k groups of layer 0
+  f32x4 xa[NG], w0[NG][4], w1[4][4];
+  float dv[NG], cl[NG];
+  bool okv[NG];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kv = 16 * i + 4 * q;                 // this lane's virtual input columns kv .. kv+3 of k-group i
-    const bool in0 = kv < e0, in1 = kv < e1, in2 = kv < e2, in3 = kv < e3;
-    const float* xb = in0 ? g0.x : in1 ? g1.x : in2 ? g2.x : in3 ? g3.x : g0.x;
-    const float* wb = in0 ? g0.W : in1 ? g1.W : in2 ? g2.W : in3 ? g3.W : g0.W;
-    const int ld = in0 ? g0.ld : in1 ? g1.ld : in2 ? g2.ld : in3 ? g3.ld : g0.ld;
-    const int kl = in3 ? kv - (in0 ? 0 : in1 ? e0 : in2 ? e1 : e2) : 0;       // column inside the segment
-    dv[i] = in0 ? g0.div : in1 ? g1.div : in2 ? g2.div : in3 ? g3.div : 1.0f;
-    cl[i] = in0 ? g0.clip : in1 ? g1.clip : in2 ? g2.clip : in3 ? g3.clip : 0.0f;
-    okv[i] = in3;
-    xa[i] = ldv(xb + kl + (int64_t)(m0 + j) * ld);
-    const float* wc0 = wb + (int64_t)kl * H + 64 * wave + 4 * j;
+  for (int i = 0; i < NG; ++i) {
+    const SegPick sp = seg_pick(P, 16 * i + 4 * q);  // this lane's virtual input columns of k-group i
+    dv[i] = sp.dv; cl[i] = sp.cl; okv[i] = sp.ok;
+    xa[i] = ldv(sp.x + sp.kl + (int64_t)(m0 + j) * sp.ld);
+    const float* wc0 = sp.W + (int64_t)sp.kl * H + 64 * wave + 4 * j;
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) w0[i][s2] = ldv(wc0 + (int64_t)s2 * H);
   }
@@ -1086,20 +1097,11 @@ __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
   const f32x4 bias1 = ldv(Q.b1 + n0 + 4 * (tid & 15));
   LOADS_FIRST();
   // ---- layer 0: h0[rows 4q..4q+3][cols 64*wave + 4j + e]
-  const bool any_div = (g0.div != 1.0f) || (g1.w > 0 && g1.div != 1.0f) || (g2.w > 0 && g2.div != 1.0f) ||
-                       (g3.w > 0 && g3.div != 1.0f);               // uniform: only the critic's action segment divides
+  const bool any_div = seg_any_div(P);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f32x4 a = xa[i];
-    const float c = (cl[i] > 0.0f) ? cl[i] : INFINITY;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = fclip(a[e], -c, c);
-    if (any_div) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = fdiv(a[e], dv[i]);
-    }
-    a = sel4(okv[i], a);
+  for (int i = 0; i < NG; ++i) {
+    const f32x4 a = seg_prep(xa[i], cl[i], dv[i], any_div, okv[i]);
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
@@ -1136,11 +1138,12 @@ __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
   *reinterpret_cast<f32x4*>(Q.C + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
 }
 
+template <int NC>
 __global__ __launch_bounds__(256) void fwd_l01_kernel(L01Args args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float h0s[16 * H0_LD];
-  if ((int)blockIdx.z < args.n01) fwd_l01_body(args.p[blockIdx.z], red, h0s);
-  else fwd_l0_body(args.pre[blockIdx.z - args.n01], red);
+  if ((int)blockIdx.z < args.n01) fwd_l01_body<NC>(args.p[blockIdx.z], red, h0s);
+  else fwd_l0_body<NC>(args.pre[blockIdx.z - args.n01], red);
 }
 
 // ------------------------------------------------------------------ one-wave-per-row kernels
@@ -2069,8 +2072,9 @@ static bool l0_lean_prob(const curious_net_cfg_t* c, const Chain& C, bool with_u
     p.seg[s].clip = sg.clip > 0.0f ? sg.clip : 0.0f;
     ktot += sg.w;
   }
-  if (ktot > 64 || !aligned16(Y) || !aligned16(C.theta + C.off.b0)) lean = false;
+  if (ktot > 128 || !aligned16(Y) || !aligned16(C.theta + C.off.b0)) lean = false;
   p.nseg = ns; p.bias = C.theta + C.off.b0; p.Y = Y; p.M = M; p.N = H; p.ldy = H; p.relu = relu ? 1 : 0;
+  p.ktot = ktot;
   return lean;
 }
 
@@ -2096,10 +2100,14 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
         fa.p[i].W1 = C.theta + C.off.W[1]; fa.p[i].b1 = C.theta + C.off.b[1]; fa.p[i].C = C.act[1];
       }
       if (lean) {
-        for (int i = 0; i < npre; ++i) fa.pre[i] = pre[i];
+        int kmax = 0;
+        for (int i = 0; i < nch; ++i) kmax = std::max(kmax, (int)fa.p[i].l0.ktot);
+        for (int i = 0; i < npre; ++i) { fa.pre[i] = pre[i]; kmax = std::max(kmax, (int)pre[i].ktot); }
         fa.n01 = nch;
         dim3 grid(H / 64, M / 16, nch + npre);
-        { ProfScope ps__(CK_FWD_L01, st); hipLaunchKernelGGL(fwd_l01_kernel, grid, dim3(256), 0, st, fa); }
+        { ProfScope ps__(CK_FWD_L01, st);
+          if (kmax <= 64) hipLaunchKernelGGL(fwd_l01_kernel<1>, grid, dim3(256), 0, st, fa);
+          else hipLaunchKernelGGL(fwd_l01_kernel<2>, grid, dim3(256), 0, st, fa); }
         CURIOUS_LAUNCH_CHECK("fwd_l01_kernel");
         ++l;                                        // layer 1 is done as well
         continue;
@@ -2133,9 +2141,13 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
       bool lean = true;
       for (int i = 0; i < nch && lean; ++i) lean = l0_lean_prob(c, ch[i], ch[i].critic, true, ch[i].act[0], M, la.p[i]);
       if (lean) {
-        for (int i = 0; i < npre; ++i) la.p[nch + i] = pre[i];
+        int kmax = 0;
+        for (int i = 0; i < nch; ++i) kmax = std::max(kmax, (int)la.p[i].ktot);
+        for (int i = 0; i < npre; ++i) { la.p[nch + i] = pre[i]; kmax = std::max(kmax, (int)pre[i].ktot); }
         dim3 grid(H / 64, (M + 15) / 16, nch + npre);
-        { ProfScope ps__(CK_FWD_LAYER0, st); hipLaunchKernelGGL(fwd_l0_kernel, grid, dim3(256), 0, st, la); }
+        { ProfScope ps__(CK_FWD_LAYER0, st);
+          if (kmax <= 64) hipLaunchKernelGGL(fwd_l0_kernel<1>, grid, dim3(256), 0, st, la);
+          else hipLaunchKernelGGL(fwd_l0_kernel<2>, grid, dim3(256), 0, st, la); }
         CURIOUS_LAUNCH_CHECK("fwd_l0_kernel");
         continue;
       }
