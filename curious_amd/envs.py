@@ -54,6 +54,14 @@ class ArmSpec:
         self.action_space = _Space([self.dimu])
         self.reward_spec = dict(kind='sparse_l2', eps=REWARD_EPS)
 
+    def _compute_goal(self, g, task, eval=False):
+        """Goal-space image of a raw draw g in [-1, 1]^3 for `task` (the protocol of rollout.py:85-86,135)."""
+        goal = np.zeros(self.dimg, np.float32)
+        goal[self.tasks_g_id[task]] = np.float32(0.5) * np.asarray(g, dtype=np.float32)
+        mask = np.zeros(self.nb_tasks, np.float32)
+        mask[task] = 1
+        return goal, mask
+
     def dims(self):
         return dict(o=self.dimo, u=self.dimu, g=self.dimg, ag=self.dimag, task_descr=self.nb_tasks,
                     info_is_success=1)
@@ -159,13 +167,6 @@ class SyntheticArmEnv(ArmSpec):
         self._b.reset_all(np.array([self.task]), np.zeros([1, 3], np.float32))
         self._t = 0
         return self._obs()
-
-    def _compute_goal(self, g, task, eval=False):
-        goal = np.zeros(self.dimg, np.float32)
-        goal[self.tasks_g_id[task]] = np.float32(0.5) * np.asarray(g, dtype=np.float32)
-        mask = np.zeros(self.nb_tasks, np.float32)
-        mask[task] = 1
-        return goal, mask
 
     def reset_task_goal(self, goal, task=0, directly=False, eval=False):
         """Sets task and goal of the CURRENT episode (the state drawn by reset() is kept)."""

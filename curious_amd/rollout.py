@@ -29,8 +29,8 @@ class RolloutWorker:
                  temperature=None, **kwargs):
         """Same arguments as the reference (rollout.py:16-40)."""
         assert self.T > 0
-        if goal_selection != 'random':
-            raise NotImplementedError("only goal_selection='random' is supported (readme.md:19)")
+        if goal_selection not in ('random', 'active'):
+            raise ValueError("goal_selection must be 'random' or 'active' (rollout.py:37)")
         self.batched = hasattr(make_env, 'make_batched')
         self.rank = dist.rank()
         self.nb_cpu = dist.world_size()
@@ -64,6 +64,13 @@ class RolloutWorker:
             self.competence_computers = [CompetenceQueue(window=queue_length) for _ in range(self.nb_tasks)]
             self.task_history = deque()
             self.goal_history = deque()
+            self.split_histories = [deque() for _ in range(self.nb_tasks)]
+            if goal_selection == 'active':                       # SAGG-RIAC per task (rollout.py:81-87)
+                from curious_amd.active_goal_sampling import SAGG_RIAC
+                ids = self.tasks_g_id
+                lo = [spec._compute_goal(-np.ones([len(ids[i])]), i, eval=False)[0][ids[i]] for i in range(self.nb_tasks)]
+                hi = [spec._compute_goal(np.ones([len(ids[i])]), i, eval=False)[0][ids[i]] for i in range(self.nb_tasks)]
+                self.goal_selectors = [SAGG_RIAC(lo[i], hi[i]) for i in range(self.nb_tasks)]
         elif structure == 'flat':
             if self.batched:
                 raise NotImplementedError('the batched synthetic env is multi-task only')
@@ -81,12 +88,16 @@ class RolloutWorker:
         obs = self.envs[i].reset()
         if self.structure in ('curious', 'task_experts'):
             task = int(np.random.choice(range(self.nb_tasks), p=self.p, size=1)[0])          # rollout.py:120
-            goal = np.random.uniform(-1, 1, len(self.tasks_g_id[task]))                       # rollout.py:129
+            active_goal = self.goal_selection == 'active' and not self.eval                   # rollout.py:121-128
+            if active_goal:
+                goal = self.goal_selectors[task].sample_goal()
+            else:
+                goal = np.random.uniform(-1, 1, len(self.tasks_g_id[task]))                   # rollout.py:129
             self.tasks[self.rank * self.rollout_batch_size + i] = task
             self.goals[self.rank * self.rollout_batch_size + i] = \
                 self.envs[i].unwrapped._compute_goal(goal, task, eval=self.eval)[0][self.tasks_g_id[task]]
             self.count += 1
-            obs = self.envs[i].unwrapped.reset_task_goal(goal=goal, task=task, directly=False, eval=self.eval)
+            obs = self.envs[i].unwrapped.reset_task_goal(goal=goal, task=task, directly=active_goal, eval=self.eval)
         else:
             goal = np.random.uniform(-1, 1, self.dims['g'])
             obs = self.envs[i].unwrapped.reset_task_goal(goal=goal)
@@ -198,7 +209,11 @@ class RolloutWorker:
         assert successful.shape == (B,)
         mean_Q = np.mean(Qs) if self.compute_Q else None
         tasks_now = [self.envs[i].unwrapped.task for i in range(B)] if multi else None
-        self._finish_rollout(successful, r_competence, mean_Q, tasks_now)
+        goals_now = None
+        if multi and self.goal_selection == 'active' and not self.eval and self.exploit:           # rollout.py:321
+            goals_now = np.stack([np.asarray(self.envs[i].unwrapped.goal)[self.tasks_g_id[tasks_now[i]]]
+                                  for i in range(B)])
+        self._finish_rollout(successful, r_competence, mean_Q, tasks_now, goals_now)
         return convert_episode_to_batch_major(episode), self.CP, self.n_episodes
 
     # ================================================================== batched path (GPU-resident envs)
@@ -207,7 +222,11 @@ class RolloutWorker:
         B, env = self.rollout_batch_size, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
         tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
-        goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+        if self.goal_selection == 'active' and not self.eval:
+            # SAGG-RIAC goals live in goal space; reset_task_goal(directly=True) (rollout.py:143) = raw draw x 2 here
+            goals = np.stack([2.0 * self.goal_selectors[int(ta)].sample_goal() for ta in tasks]).astype(np.float32)
+        else:
+            goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
         env.reset_all(tasks, goals)
         self.count += B
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
@@ -244,12 +263,15 @@ class RolloutWorker:
         self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
         self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
         self.goals = [[] for _ in range(self.nb_goals_per_rollout)]
-        self._finish_rollout(successful, successful - 1.0, mean_Q, task_list)
+        goals_now = None
+        if self.goal_selection == 'active' and not self.eval and self.exploit:
+            goals_now = 0.5 * goals                               # the envs' goals on their task slots (goal space)
+        self._finish_rollout(successful, successful - 1.0, mean_Q, task_list, goals_now)
         return env.episode_views(), self.CP, self.n_episodes
 
     # ================================================================== statistics, competence, task probabilities
-    def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now):
-        """rollout.py:305-404."""
+    def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now, goals_now=None):
+        """rollout.py:305-404.  goals_now: [B, len(task slots)] goals of the exploit rollouts for SAGG-RIAC."""
         B = self.rollout_batch_size
         self.success_history.append(np.mean(successful))
         self.reward_history.append(r_competence)
@@ -269,6 +291,16 @@ class RolloutWorker:
         task_succ_list = [allrec[valid & (task_ids == task), 1].tolist() for task in range(self.nb_tasks)]
         for task in range(self.nb_tasks):
             self.competence_computers[task].update(task_succ_list[task])   # rollout.py:355-356
+        if self.goal_selection == 'active' and not self.eval:             # rollout.py:357-365
+            gdim = len(self.tasks_g_id[0])
+            grec = np.zeros([B, gdim], np.float64) if goals_now is None else np.asarray(goals_now, np.float64)
+            allgoals = dist.allgather_numpy(grec)                          # same order as allrec: every rank agrees
+            for task in range(self.nb_tasks):
+                sel = valid & (task_ids == task)
+                new_split, _ = self.goal_selectors[task].update([g.astype(np.float32) for g in allgoals[sel]],
+                                                                allrec[sel, 1].tolist())
+                self.split_histories[task].append(
+                    [self.goal_selectors[task].get_regions, self.goal_selectors[task].probas] if new_split else None)
         self.C = np.array([self.get_C()]).squeeze()
         self.task_history.extend(list(self.tasks))
         self.goal_history.extend(list(self.goals))

@@ -554,6 +554,37 @@ def test_training_state_checkpoint_resumes_bit_exactly(tmp_path):
     np.testing.assert_array_equal(w1.p, w2.p)
 
 
+def test_active_goal_selection_feeds_sagg_riac():
+    """goal_selection='active' (rollout.py:81-87,121-128,357-365): goals come from the per-task SAGG-RIAC selectors,
+    are applied `directly`, and exploit rollouts feed (goal, success) back into the selector of their task."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+    agent, _ = build_pair(4, 40, rng_mode='device')
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=64, exploit=True,
+                      structure='curious', task_selection='active_competence_progress', goal_selection='active',
+                      queue_length=6, eval=False)
+    w.seed(5)
+    w._decide_exploit = lambda: setattr(w, 'exploit', True)        # rollout.py:184 draws this with p = 0.1; pin it
+    np.random.seed(11)
+    n_per_task = np.zeros(4, int)
+    for _ in range(5):
+        ep, _, _ = w.generate_rollouts()
+        torch.cuda.synchronize()
+        g = w.benv.g.cpu().numpy()
+        tasks = w.benv.tasks.cpu().numpy()
+        for b in range(64):
+            own = g[b, 3 * tasks[b]:3 * tasks[b] + 3]
+            assert np.all(np.abs(own) <= 0.5) and np.count_nonzero(g[b]) <= 3       # goal only on the task's slots
+            n_per_task[tasks[b]] += 1
+    for task in range(4):
+        sel = w.goal_selectors[task]
+        stored = sum(len(r[0]) for r in sel.regions)
+        assert stored == n_per_task[task] > 0 and len(w.split_histories[task]) == 5
+        assert abs(sum(sel.probas) - 1.0) < 1e-9
+
+
 def test_fused_act_and_step_equals_unfused():
     """curious_policy_act_env_step == get_actions + env.step_all, bit for bit (throughput mode)."""
     from curious_amd.envs import EnvFactory

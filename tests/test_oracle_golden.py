@@ -149,3 +149,28 @@ def test_mpi_moments_single_rank():
     for x, mean, std in zip(G['xs'], G['means'], G['stds']):
         np.testing.assert_allclose(np.mean(x), mean, rtol=1e-14)
         np.testing.assert_allclose(np.std(x), std, rtol=1e-12)
+
+
+def test_sagg_riac_matches_reference():
+    """curious_amd.active_goal_sampling.SAGG_RIAC replays the reference's run (tools/gen_golden.py::gen_sagg_riac):
+    same split decisions, region tree, sampling probabilities and sampled goals on the same seeded NumPy stream."""
+    from curious_amd.active_goal_sampling import SAGG_RIAC
+    d = load_golden('sagg_riac')
+    np.random.seed(77)
+    sel = SAGG_RIAC(d['lo'], d['hi'])
+    for i in range(int(d['n_rounds'])):
+        goals = [g for g in d['goals_%d' % i]]
+        new_split, order = sel.update(goals, d['comp_%d' % i].tolist())
+        assert bool(new_split) == bool(d['splits'][i]), i
+        np.testing.assert_array_equal(np.array(order if order is not None else [], np.int64), d['order_%d' % i])
+        assert sel.nb_regions == d['nregs'][i]
+        got = np.array([sel.sample_goal() for _ in range(3)], np.float32)
+        np.testing.assert_array_equal(got, d['samples_%d' % i])
+    assert d['splits'].sum() >= 2 and sel.nb_regions >= 3          # the fixture does exercise splitting
+    np.testing.assert_array_equal(np.array([b.low for b in sel.get_regions]), d['final_low'])
+    np.testing.assert_array_equal(np.array([b.high for b in sel.get_regions]), d['final_high'])
+    np.testing.assert_array_equal(np.array(sel.probas), d['final_probas'])
+    np.testing.assert_array_equal(np.array(sel.interest, np.float64), d['final_interest'])
+    np.testing.assert_array_equal(np.array([len(r[0]) for r in sel.regions]), d['final_sizes'])
+    assert sel.max_difference == float(d['max_difference'])
+    assert np.random.uniform() == float(d['end_draw'])             # same amount of the stream consumed

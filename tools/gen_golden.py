@@ -65,8 +65,19 @@ def install_stubs():
     spaces = types.ModuleType('gym.spaces')
 
     class Box:
+        # the members SAGG-RIAC uses, with gym's semantics (private copies of the bounds, closed intervals); sample()
+        # draws from the NumPy GLOBAL stream (gym keeps a private generator) so that the fixture is reproducible
         def __init__(self, low, high, dtype=np.float32):
-            self.low, self.high = np.asarray(low), np.asarray(high)
+            self.low, self.high = np.array(low, dtype=dtype), np.array(high, dtype=dtype)
+            self.shape = self.low.shape
+            self.dtype = np.dtype(dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low)) and bool(np.all(x <= self.high))
+
+        def sample(self):
+            return np.random.uniform(low=self.low, high=self.high).astype(self.dtype)
     spaces.Box = Box
     gym.spaces = spaces
     gym.make = lambda name: None
@@ -376,8 +387,49 @@ def gen_mpi_moments():
     save('mpi_moments', xs=np.array(xs), means=np.array(means), stds=np.array(stds))
 
 
+def gen_sagg_riac():
+    """baselines/her/active_goal_sampling.py driven for 60 rounds on a 3-D goal space whose competence improves over
+    time in the half-space x > 0.1 only (so that regions split): inputs, the split decisions, the region tree and the
+    goals sampled in between, all on one seeded NumPy stream."""
+    import contextlib
+    import io
+    from baselines.her.active_goal_sampling import SAGG_RIAC
+    np.random.seed(77)
+    lo, hi = -0.5 * np.ones(3, np.float32), 0.5 * np.ones(3, np.float32)
+    sel = SAGG_RIAC(lo, hi)
+    data_rng = np.random.RandomState(5)
+    rounds_goals, rounds_comp, splits, orders, samples, nregs = [], [], [], [], [], []
+    for rnd in range(60):
+        n = int(data_rng.randint(0, 40))
+        goals = [data_rng.uniform(lo, hi).astype(np.float32) for _ in range(n)]
+        p_succ = min(1.0, rnd / 25.0)
+        comp = [float(g[0] > 0.1 and data_rng.rand() < p_succ) for g in goals]
+        with contextlib.redirect_stdout(io.StringIO()):          # the reference prints while it searches
+            new_split, order = sel.update(goals, comp)
+        rounds_goals.append(np.array(goals, np.float32).reshape(n, 3))
+        rounds_comp.append(np.array(comp, np.float64))
+        splits.append(bool(new_split))
+        orders.append(np.array(order if order is not None else [], np.int64))
+        nregs.append(sel.nb_regions)
+        samples.append(np.array([sel.sample_goal() for _ in range(3)], np.float32))
+    assert sel.nb_regions >= 3, sel.nb_regions
+    arrs = dict(lo=lo, hi=hi, n_rounds=np.array(60), splits=np.array(splits), nregs=np.array(nregs),
+                final_low=np.array([b.low for b in sel.region_bounds]),
+                final_high=np.array([b.high for b in sel.region_bounds]),
+                final_probas=np.array(sel.probas), final_interest=np.array(sel.interest, np.float64),
+                final_sizes=np.array([len(r[0]) for r in sel.regions]), max_difference=np.array(sel.max_difference),
+                end_draw=np.array(np.random.uniform()))
+    for i in range(60):
+        arrs['goals_%d' % i] = rounds_goals[i]
+        arrs['comp_%d' % i] = rounds_comp[i]
+        arrs['order_%d' % i] = orders[i]
+        arrs['samples_%d' % i] = samples[i]
+    save('sagg_riac', **arrs)
+
+
 if __name__ == '__main__':
     install_stubs()
+    gen_sagg_riac()
     gen_her()
     gen_replay_buffer()
     gen_queues()
