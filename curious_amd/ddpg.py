@@ -89,7 +89,7 @@ class DDPG(object):
         self._staged = None
         self._pp = None                                              # the two staging tensors of the device loop
         self._cur = 0
-        self._graph = self._graph_b = self._graph_chain = None
+        self._graph = self._graph_b = self._graph_ba = self._graph_chain = None
         self._graphs = [None, None]
         self._tables_dirty = True
         self._batch_stale = True
@@ -649,8 +649,16 @@ class DDPG(object):
     def train_batches(self, n):
         """`for _ in range(n): policy.train()` (the inner loop of train.py:152-153) -- same updates, same order, same
         result.  On the single-rank hipGraph path runs of CHAIN updates are replayed as ONE graph launch: a graph
-        boundary costs ~5 us of idle GPU on this stack (tools/graph_chain_probe.py), 7 % of an update."""
+        boundary costs ~5 us of idle GPU on this stack (tools/graph_chain_probe.py), 7 % of an update.  With several
+        ranks the eager all-reduce splits every update; the loop is then software-pipelined so that Adam of update k
+        and the gradients of update k+1 share one graph launch."""
         out = None
+        if self._device_loop() and self.use_graph and dist.is_distributed() and not self._graph_allreduce():
+            while n > 0:
+                k = min(n, 1000)
+                out = self._train_ranks_pipelined(k)
+                n -= k
+            return out
         while n > 0:
             k = 1
             chainable = not dist.is_distributed() or (self._graph_allreduce() and self.Q_adam.t % CHAIN == 0)
@@ -660,6 +668,43 @@ class DDPG(object):
             n -= k
         return out
 
+    def _train_ranks_pipelined(self, n):
+        """n updates on several ranks: A(0); [all-reduce; B(k)+A(k+1)] x (n-1); all-reduce; B(n-1), where A = the 8
+        gradient launches and B = Adam + the gather of the next batch.  Same launches in the same order as n x train()."""
+        self._train_device_prologue(n)
+        if self._graph is None:
+            self._graph = self._capture(self._grads)
+            self._graph_b = self._capture(self._adam_and_sample)
+            self._batch_stale = True
+        if self._graph_ba is None:
+            self._graph_ba = self._capture(lambda: (self._adam_and_sample(), self._grads()))
+            self._batch_stale = True
+        if self._batch_stale:
+            self._sample_packed()
+            self._batch_stale = False
+        t = self.Q_adam.t
+        if t % 100 == 0:
+            self._check_synced()
+        self._graph.replay()
+        for i in range(1, n):
+            dist.allreduce_sum_(self.grad)                           # C1+C2 fused; SUM, not mean (ddpg.py:452)
+            if (t + i) % 100 == 0:                                   # C4 between the two halves, parameters at rest
+                self._graph_b.replay()
+                self._check_synced()
+                self._graph.replay()
+            else:
+                self._graph_ba.replay()
+        dist.allreduce_sum_(self.grad)
+        self._graph_b.replay()
+        self.Q_adam.t += n
+        self.pi_adam.t += n
+        return self._losses[0], self._Q_pi
+
+    def _check_synced(self):
+        self.Q_adam.theta = self.theta                               # checksum over the fused vector (C4)
+        MpiAdam.check_synced(self.Q_adam)
+        self.Q_adam.theta = self.theta[:self.off_pi]
+
     def _train_device(self, k):
         """k updates of the device-resident loop.  Single rank: each update is curious_ddpg_update -- gradients, Adam in
         the weight-gradient launch and the HER gather of the NEXT batch riding on that launch -- over two staging
@@ -667,20 +712,7 @@ class DDPG(object):
         chain of CHAIN updates).  Several ranks: the gradient all-reduce splits every update into graph A (gradients)
         and graph B (Adam + next gather).  An explicit gather is issued whenever the buffers or the sampling tables
         changed since the last one, so every batch is still drawn after the latest store_episode."""
-        if self._tables_dirty:
-            self._refresh_device_tables()
-            self._batch_stale = True
-        if self.Q_adam.t + k > self._alpha_filled or self._alpha_filled == 0:
-            self._fill_alpha_table()
-        if self._pp is None:
-            shape = [self.batch_size, self._layout.batch_stride]
-            self._pp = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
-            self._cur = 0
-            self._batch_stale = True
-        if self._staged is not self._pp[self._cur]:
-            self._staged = self._pp[self._cur]
-            self._batch_stale = True
-        self._layout_for_batch = self._layout
+        self._train_device_prologue(k)
         if dist.is_distributed():
             assert k == 1 or (k == CHAIN and self._graph_allreduce() and 100 % CHAIN == 0)
             return self._train_device_ranks(k)
@@ -727,6 +759,22 @@ class DDPG(object):
         dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
         self._adam_and_sample()
 
+    def _train_device_prologue(self, k):
+        if self._tables_dirty:
+            self._refresh_device_tables()
+            self._batch_stale = True
+        if self.Q_adam.t + k > self._alpha_filled or self._alpha_filled == 0:
+            self._fill_alpha_table()
+        if self._pp is None:
+            shape = [self.batch_size, self._layout.batch_stride]
+            self._pp = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._cur = 0
+            self._batch_stale = True
+        if self._staged is not self._pp[self._cur]:
+            self._staged = self._pp[self._cur]
+            self._batch_stale = True
+        self._layout_for_batch = self._layout
+
     def _train_device_ranks(self, k=1):
         one_graph = self.use_graph and self._graph_allreduce()
         if self.use_graph and not one_graph and self._graph is None:
@@ -743,9 +791,7 @@ class DDPG(object):
             self._sample_packed()
             self._batch_stale = False
         if self.Q_adam.t % 100 == 0:
-            self.Q_adam.theta = self.theta                           # checksum over the fused vector (C4)
-            MpiAdam.check_synced(self.Q_adam)
-            self.Q_adam.theta = self.theta[:self.off_pi]
+            self._check_synced()
         if one_graph:
             (self._graph_chain if k > 1 else self._graphs[0]).replay()
         elif self.use_graph:
