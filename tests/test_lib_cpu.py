@@ -34,6 +34,17 @@ def test_argument_validation_without_gpu():
     cfg.dimo, cfg.dimg, cfg.dimu, cfg.dimtd, cfg.hidden, cfg.layers, cfg.modular = 40, 12, 4, 4, 256, 3, 1
     assert L.curious_param_count_Q(C.byref(cfg)) == 147457
     assert L.curious_param_count_pi(C.byref(cfg)) == 147204
+    # the fused update refuses a missing optimiser state and a next batch that aliases the current one
+    rc = L.curious_ddpg_update(C.byref(cfg), None, None, None, None, 256, None, None, None, None, None, None, None,
+                               None, None, None)
+    assert rc != 0 and b'optimiser' in L.curious_last_error()
+    st = _lib.AdamState()
+    st.m, st.v = 64, 64                                       # never dereferenced: validation fails first
+    nb = _lib.NextBatch()
+    nb.batch = 4096
+    rc = L.curious_ddpg_update(C.byref(cfg), None, None, C.c_void_p(4096), None, 256, None, None, None, None, None,
+                               None, None, C.byref(st), C.byref(nb), None)
+    assert rc != 0 and b'staging' in L.curious_last_error()
     cfg.dimo, cfg.dimg, cfg.dimtd = 52, 24, 8
     assert L.curious_param_count_pi(C.byref(cfg)) == (52 + 8) * 256 + 256 + 24 * 256 + 2 * (256 * 256 + 256) + 256 * 4 + 4
 
