@@ -286,6 +286,53 @@ class DDPG(object):
             self._roll_graphs[key] = g
         g.replay()
 
+    def can_eval_rollout(self, env, noise_eps, random_eps):
+        """Noise-free rollouts (evaluator, exploit) of the GPU-resident env can be replayed from one hipGraph: with both
+        eps at 0 the result does not depend on the noise counter, so nothing host-side changes between replays."""
+        return (self.rng_mode == 'device' and self.use_graph and noise_eps == 0 and random_eps == 0
+                and hasattr(env, 'step_all'))
+
+    def eval_rollout(self, env, T, use_target_net=False, compute_Q=False):
+        """T x [get_actions(noise 0) -> env.step_all (-> mean Q)] (rollout.py:226-263 for every env), the launches of
+        the unfused acting path captured once per (env, settings) and replayed.  Returns the sum over steps of the
+        batch-mean Q (a GPU scalar) when compute_Q, else None."""
+        n = env.n
+        theta = self.theta_target if use_target_net else self.theta
+        if getattr(self, '_roll_graphs', None) is None:
+            self._roll_graphs = {}
+        key = ('eval', id(env), T, bool(use_target_net), bool(compute_Q))
+        entry = self._roll_graphs.get(key)
+        if entry is None:
+            ws = self._act_ws.get(n)
+            if ws is None:
+                ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+                self._act_ws[n] = ws
+            u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+            Q = torch.empty([n, 1], dtype=torch.float32, device=self.device) if compute_Q else None
+            q_acc = torch.zeros((), dtype=torch.float32, device=self.device)
+            seed = self.seed * 2654435761 + 12345 + dist.rank() * 1000003
+
+            def steps():
+                q_acc.zero_()
+                for t in range(T):
+                    ops.policy_forward(self.net_cfg, theta, env.o, env.g, env.td if self.dimtd > 0 else None, n,
+                                       self.clip_obs, ws, u, Q, ag=env.ag, relative_goals=self.relative_goals,
+                                       o_stats=self.o_stats.state if self.normalize_obs else None,
+                                       g_stats=self.g_stats.state if self.normalize_obs else None)
+                    ops.action_noise(u, n, self.dimu, 0.0, 0.0, self.max_u, seed=seed, counter=0)   # the clip only
+                    env.step_all(u, t)
+                    if compute_Q:
+                        q_acc.add_(Q.mean())
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                steps()
+            entry = (g, q_acc, u, Q)
+            self._roll_graphs[key] = entry
+        self._noise_counter += T
+        entry[0].replay()
+        return entry[1] if compute_Q else None
+
     # ------------------------------------------------------------------ storing
     def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging

@@ -235,7 +235,16 @@ class RolloutWorker:
             self.policy.act_rollout(env, self.T, noise_eps=self.noise_eps if not self.exploit else 0.,
                                     random_eps=self.random_eps if not self.exploit else 0.,
                                     use_target_net=self.use_target_net)
-        for t in range(self.T if not (fused and hasattr(self.policy, 'act_rollout')) else 0):
+        noise_eps = self.noise_eps if not self.exploit else 0.
+        random_eps = self.random_eps if not self.exploit else 0.
+        graphed = not fused and hasattr(self.policy, 'can_eval_rollout') and \
+            self.policy.can_eval_rollout(env, noise_eps, random_eps)
+        if graphed:                                              # evaluator / exploit rollouts: one graph replay
+            q_acc = self.policy.eval_rollout(env, self.T, use_target_net=self.use_target_net,
+                                             compute_Q=self.compute_Q)
+            if self.compute_Q:
+                q_sum = q_acc
+        for t in range(self.T if not (graphed or (fused and hasattr(self.policy, 'act_rollout'))) else 0):
             if fused:
                 self.policy.act_and_step(env, t, noise_eps=self.noise_eps if not self.exploit else 0.,
                                          random_eps=self.random_eps if not self.exploit else 0.,

@@ -585,6 +585,31 @@ def test_active_goal_selection_feeds_sagg_riac():
         assert abs(sum(sel.probas) - 1.0) < 1e-9
 
 
+def test_evaluator_rollout_graph_equals_eager():
+    """Evaluator rollouts (exploit, compute_Q): the hipGraph replay of the noise-free acting loop writes the same
+    episode records and reports the same mean Q as the eager per-step loop."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+    recs, qs = [], []
+    for use_graph in (True, False):
+        agent, _ = build_pair(4, 40, rng_mode='device', use_graph=use_graph)
+        w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=48,
+                          exploit=True, compute_Q=True, structure='curious', task_selection='active_competence_progress',
+                          queue_length=6, eval=True)
+        w.seed(5)
+        np.random.seed(8)
+        for _ in range(3):
+            ep, _, _ = w.generate_rollouts()
+        torch.cuda.synchronize()
+        assert (('eval', id(w.benv), T, False, True) in getattr(agent, '_roll_graphs', {})) == use_graph
+        recs.append(ep.records.clone())
+        qs.append(list(w.Q_history))
+    assert torch.equal(recs[0], recs[1])
+    assert qs[0] == qs[1] and len(qs[0]) == 3 and np.isfinite(qs[0]).all()
+
+
 def test_fused_act_and_step_equals_unfused():
     """curious_policy_act_env_step == get_actions + env.step_all, bit for bit (throughput mode)."""
     from curious_amd.envs import EnvFactory
