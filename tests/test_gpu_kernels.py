@@ -264,6 +264,8 @@ def _rand_batch(rng, layout, B, nb):
 @pytest.mark.parametrize('cfg', [
     dict(nb=4, dimo=40, B=256, hidden=256, layers=3, max_u=1.0),
     dict(nb=8, dimo=52, B=256, hidden=256, layers=3, max_u=1.0),
+    dict(nb=4, dimo=40, B=256, hidden=256, layers=2, max_u=1.0),     # lean path without the dot-epilogue partials
+    dict(nb=4, dimo=40, B=512, hidden=256, layers=4, max_u=2.0),     # deeper net, two batch chunks, max_u != 1
     dict(nb=4, dimo=40, B=37, hidden=64, layers=2, max_u=1.5),       # ragged rows / other depth
     dict(nb=3, dimo=10, B=5, hidden=24, layers=1, max_u=2.0),        # tiny, nothing multiple of 16
 ])
