@@ -299,6 +299,31 @@ def test_rank_paths_match_single_rank():
     assert digests[0] == digests[1] == digests[2], digests
 
 
+def test_two_ranks_share_one_gpu_over_gloo():
+    """World size 2 on ONE GPU (gloo carries the collectives; RCCL refuses two ranks per device): private buffers and
+    RNG streams per rank, summed gradients, pipelined update graphs -- both ranks must end with bit-identical
+    parameters (and pass check_synced on the way), which differ from a single-rank run."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CURIOUS_DIST_BACKEND='gloo', CURIOUS_RANK_CHECK_CYCLES='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CURIOUS_FORCE_DIST', 'CURIOUS_GRAPH_ALLREDUCE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
+                          os.path.join(root, 'tools', 'rank_path_check.py')], env=env, cwd=root, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith('DIGEST')]
+    assert len(lines) == 2 and lines[0][1] == lines[1][1], lines
+    assert lines[0][2] == lines[1][2] == '235'
+
+
 def test_batched_rollout_matches_oracle():
     """GPU-resident rollout (actor forward + noise + env step kernels) against the oracle env + oracle policy."""
     from curious_amd.envs import EnvFactory

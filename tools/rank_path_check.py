@@ -13,12 +13,15 @@ import bench  # noqa: E402
 def main():
     from curious_amd import dist
     dist.init_from_env()
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(dist.local_device_index())
     params, dims, policy, worker = bench.build_job(use_graph=True)
-    bench.prefill(policy, 256, seed=0)
+    bench.prefill(policy, 256, seed=dist.rank())
     for _ in range(5):
         policy.train()
     policy.train_batches(30)
+    # optional: whole cycles (rollout + store + updates) so that ranks diverge in data and must agree through collectives
+    for _ in range(int(os.environ.get('CURIOUS_RANK_CHECK_CYCLES', '0'))):
+        bench.cycle(policy, worker)
     torch.cuda.synchronize()
     h = hashlib.sha256(policy.theta.cpu().numpy().tobytes()).hexdigest()
     print('DIGEST', h, int(policy._step_ctr), float(policy._losses[0]), flush=True)
