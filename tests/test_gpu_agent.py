@@ -311,7 +311,9 @@ def test_two_ranks_share_one_gpu_over_gloo():
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, CURIOUS_DIST_BACKEND='gloo', CURIOUS_RANK_CHECK_CYCLES='2')
+    import tempfile
+    prefix = os.path.join(tempfile.mkdtemp(), 'digest')
+    env = dict(os.environ, CURIOUS_DIST_BACKEND='gloo', CURIOUS_RANK_CHECK_CYCLES='2', CURIOUS_RANK_CHECK_OUT=prefix)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CURIOUS_FORCE_DIST', 'CURIOUS_GRAPH_ALLREDUCE'):
         env.pop(k, None)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -319,9 +321,9 @@ def test_two_ranks_share_one_gpu_over_gloo():
                           os.path.join(root, 'tools', 'rank_path_check.py')], env=env, cwd=root, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
-    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith('DIGEST')]
-    assert len(lines) == 2 and lines[0][1] == lines[1][1], lines
-    assert lines[0][2] == lines[1][2] == '235'
+    found = [open('%s.rank%d' % (prefix, r)).read().split() for r in range(2)]
+    assert found[0][1] == found[1][1] and len(found[0][1]) == 64, found
+    assert found[0][2] == found[1][2] == '235'
 
 
 def test_batched_rollout_matches_oracle():
