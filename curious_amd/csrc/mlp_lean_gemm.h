@@ -1,0 +1,438 @@
+// Lean 16x64 split-K tiles for the 256-wide hidden layers: forward / input-gradient kernels with the dot epilogue,
+// weight-gradient tiles with Adam in the epilogue, the update tail launch (included by mlp.hip).
+#pragma once
+
+// ================================================================== lean kernels for the hot 256-wide layers
+// Adam applied where the gradient is produced (curious_ddpg_update, single-rank): the workgroup that finishes a tile
+// of dW / db owns the matching elements of theta, m and v, so the optimiser needs no launch of its own.  Arithmetic and
+// step-size lookup are those of optim.hip's adam_body (mpi_adam.py:29-35), bit for bit.
+struct AdamFuse {
+  float* theta; float* m; float* v;
+  const float* grad;              // base of the gradient vector: (gradient pointer - grad) = parameter index
+  int64_t n_Q;
+  const float* alpha_tab; const int64_t* step_ctr; int64_t tab_base; int32_t tab_len;
+  float a_Q, a_pi, b1, omb1, b2, omb2, eps;
+};
+
+__device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi) {
+  aQ = A.a_Q; aPi = A.a_pi;
+  if (A.alpha_tab) {
+    int64_t idx = ((*A.step_ctr) - 1 - A.tab_base) % A.tab_len;
+    if (idx < 0) idx += A.tab_len;
+    aQ = A.alpha_tab[2 * idx];
+    aPi = A.alpha_tab[2 * idx + 1];
+  }
+}
+
+__device__ inline float adam_elem(const AdamFuse& A, float na, float g, float& m, float& v, float th) {
+  m = __fadd_rn(__fmul_rn(A.b1, m), __fmul_rn(A.omb1, g));                       // mpi_adam.py:31
+  v = __fadd_rn(__fmul_rn(A.b2, v), __fmul_rn(A.omb2, __fmul_rn(g, g)));         // mpi_adam.py:32
+  const float step = fdiv(__fmul_rn(na, m), __fadd_rn(sqrtf(v), A.eps));         // mpi_adam.py:33
+  return __fadd_rn(th, step);                                                    // mpi_adam.py:34
+}
+
+struct AdamPre4 { f32x4 m, v, th; };
+__device__ inline AdamPre4 adam_prefetch4(const AdamFuse& A, int64_t i) {
+  AdamPre4 p;
+  p.m = ldv(A.m + i); p.v = ldv(A.v + i); p.th = ldv(A.theta + i);
+  return p;
+}
+__device__ inline void adam_apply4(const AdamFuse& A, float na, int64_t i, const f32x4& g, AdamPre4& p) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.m[e], v = p.v[e];
+    p.th[e] = adam_elem(A, na, g[e], m, v, p.th[e]);
+    p.m[e] = m; p.v[e] = v;
+  }
+  *reinterpret_cast<f32x4*>(A.m + i) = p.m;
+  *reinterpret_cast<f32x4*>(A.v + i) = p.v;
+  *reinterpret_cast<f32x4*>(A.theta + i) = p.th;
+}
+__device__ inline void adam_apply1(const AdamFuse& A, float na, int64_t i, float g) {
+  float m = A.m[i], v = A.v[i];
+  const float th = adam_elem(A, na, g, m, v, A.theta[i]);
+  A.m[i] = m; A.v[i] = v; A.theta[i] = th;
+}
+
+// Same tiling as the generic kernels above, but with 56-byte problem descriptors, no bounds checks and no segment
+// machinery: tools/gemm_lab.hip measures 3.7 us per launch inside a hipGraph for this form (2.0 us of which is the
+// launch floor of an empty kernel) against 5.5-7 us for the generic form with its 1 KB kernarg.
+// Preconditions (checked on the host, else the generic kernel runs): M % 16 == 0, N % 64 == 0, reduction dim % 256
+// == 0, all pointers 16-byte aligned, leading dims % 4 == 0.
+struct GemmHot {
+  const float* A; const float* B; const float* aux; float* C; float* aux_out;
+  int32_t lda, ldb, ldc, M, N, K;
+  // optional epilogue (DOT kernels): partial products of the output tile with a narrow matrix that the NEXT launch
+  // would otherwise have to contract over whole rows (output layers, the critic's action rows):
+  //   dot_out[tile][m][d] = sum_{c in this 64-column tile} C[m][c] * w(c, d)
+  // dot_mode 1: D = 1, w = dot_w[c];  2: D = 4, w = dot_w[c * 4 + d];  3: D = 4, w = dot_w[d * dot_ld + c]
+  const float* dot_w; float* dot_out; int32_t dot_mode, dot_ld;
+};
+struct HotArgs { GemmHot p[3]; };
+
+__device__ inline void hot_store(float* red, const f32x4 acc[4], int wave, int q, int j, int tid, f32x4& v, int& orow,
+                                 int& c4) {
+  v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+}
+
+struct DotW { f32x4 w[4]; };
+__device__ inline DotW dot_prefetch(const GemmHot& P, int c) {
+  // branch-free (4 unconditional loads at selected addresses): a branch on dot_mode here would make every load that
+  // follows in program order wait for the scalar load of dot_mode.  dot_w is a valid address for every problem of a
+  // DOT launch (the host points it at the weight matrix when dot_mode == 0).
+  DotW d;
+  const int m = P.dot_mode;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t off = (m == 2) ? (int64_t)(c + e) * 4 : (m == 3) ? (int64_t)e * P.dot_ld + c : (m == 1) ? c : 0;
+    d.w[e] = ldv(P.dot_w + off);
+  }
+  return d;
+}
+// v: this thread's 4 consecutive output columns of row `row`; the 16 threads of a row are one DPP row
+__device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4& v, int row, int tile, int c4) {
+  if (P.dot_mode == 0) return;
+  f32x4 pd = zero4();
+  if (P.dot_mode == 1) {
+    pd[0] = v[0] * d.w[0][0] + v[1] * d.w[0][1] + v[2] * d.w[0][2] + v[3] * d.w[0][3];
+    pd[0] = row16_sum(pd[0]);
+    if (c4 == 0) P.dot_out[(int64_t)tile * P.M + row] = pd[0];
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = 0.f;
+    if (P.dot_mode == 2) t = v[0] * d.w[0][k] + v[1] * d.w[1][k] + v[2] * d.w[2][k] + v[3] * d.w[3][k];
+    else t = v[0] * d.w[k][0] + v[1] * d.w[k][1] + v[2] * d.w[k][2] + v[3] * d.w[k][3];
+    pd[k] = row16_sum(t);
+  }
+  if (c4 == 0) *reinterpret_cast<f32x4*>(P.dot_out + ((int64_t)tile * P.M + row) * 4) = pd;
+}
+
+// C[M,N] = relu(A[M,K] . B[K,N] + bias)        grid (N/64, M/16, nprob)
+template <bool DOT>
+__global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const GemmHot& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const float* xr = P.A + (int64_t)(m0 + j) * P.lda;
+  const float* wc = P.B + n0 + 4 * j;
+  const f32x4 bias = ldv(P.aux + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
+  DotW dw;
+  if (DOT) dw = dot_prefetch(P, n0 + 4 * (tid & 15));
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  for (int kb = 0; kb < P.K; kb += 256) {
+    f32x4 a[4], b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kq = kb + (wave + 4 * u) * 16 + 4 * q;
+      a[u] = ldv(xr + kq);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[u][s] = ldv(wc + (int64_t)(kq + s) * P.ldb);
+    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  v += bias;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
+}
+
+// C[M,K'] = (A[M,N] . B[K',N]^T) * relu'(aux[M,K'])    (K' = P.N output columns, reduction over P.K)   grid (K'/64, M/16, nprob)
+template <bool DOT>
+__global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const GemmHot& P = args.p[blockIdx.z];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+  const float* dyr = P.A + (int64_t)(m0 + j) * P.lda;
+  const float* wr = P.B + (int64_t)(k0 + 4 * j) * P.ldb;
+  const int64_t o = (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
+  const f32x4 h = ldv(P.aux + o);                           // relu mask source, issued with the first batch
+  DotW dw;
+  if (DOT) dw = dot_prefetch(P, k0 + 4 * (tid & 15));
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  for (int nb = 0; nb < P.K; nb += 256) {
+    f32x4 a[4], b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nq = nb + (wave + 4 * u) * 16 + 4 * q;
+      a[u] = ldv(dyr + nq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * P.ldb + nq);
+    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][e][s], acc[e]);
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
+  *reinterpret_cast<f32x4*>(P.C + o) = v;
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
+}
+
+// C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
+struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
+template <bool ADAM>
+__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red) {
+  // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
+  const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
+  const GemmHot& P = args.p[pi];
+  const int nx = P.N >> 6;
+  const int by = t / nx, bx = t - by * nx;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int k0 = by * 16, n0 = bx * 64;
+  const float* xc = P.A + k0 + j;
+  const float* yc = P.B + n0 + 4 * j;
+  // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0)
+  float* const dst = P.C + (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
+  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
+  AdamPre4 pre;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  if (ADAM) {
+    adam_alphas(A, aQ, aPi);
+    pre = adam_prefetch4(A, pidx);
+    if (by == 0 && tid < 64) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+  }
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < P.M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = xc[(int64_t)(mq + s) * P.lda];
+        b[u][s] = ldv(yc + (int64_t)(mq + s) * P.ldb);
+      }
+    }
+    LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bsum += b[u][s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+      }
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  *reinterpret_cast<f32x4*>(dst) = v;
+  if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx, v, pre);
+  if (by == 0) {
+    // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+      P.aux_out[n0 + tid] = gb;
+      if (ADAM) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+      }
+    }
+  }
+}
+
+
+// Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
+//   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
+struct DwSmall {
+  const float* x; const float* dY; float* dW; float* db;
+  int32_t ldx, lddy, w, N;
+  float div;
+};
+#define MAX_DW_SMALL 12
+struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin; };   // `slots` block ids per problem
+
+// One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
+// layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
+// load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
+template <bool ADAM, bool YV>
+__device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nx = (P.N + 63) >> 6;
+  const int by = t / nx, bx = t - by * nx;
+  const int j = lane & 15, q = lane >> 4;
+  const int k0 = by * 16, n0 = bx * 64;
+  const int krow = k0 + j, col = n0 + 4 * j;
+  const bool k_ok = krow < P.w;
+  const float* xc = P.x + min(krow, P.w - 1);
+  const int colc = YV ? min(col, P.N - 4) : 0;
+  const float* yc = P.dY + colc;
+  // optimiser operands of what this thread finishes, fetched with the first batch of loads
+  const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
+  const bool own = grow < P.w && gcol < P.N;
+  float* const dst = P.dW + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
+  const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  AdamPre4 pre;
+  pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
+  if (ADAM) {
+    adam_alphas(A, aQ, aPi);
+    if (YV) {
+      pre = adam_prefetch4(A, own ? pidx : 0);
+    } else if (own) {                                       // N == 1: one element per owning thread
+      pre.m[0] = A.m[pidx]; pre.v[0] = A.v[pidx]; pre.th[0] = A.theta[pidx];
+    }
+    if (own_b) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+  }
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
+        if (YV) {
+          b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+        } else {
+          b[u][s] = zero4();
+          b[u][s][0] = yc[(int64_t)(mq + s) * P.lddy];
+        }
+      }
+    }
+    LOADS_FIRST();
+    if (P.div != 1.0f) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[u][s] = fdiv(a[u][s], P.div);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = k_ok ? a[u][s] : 0.f;
+        bsum += b[u][s];
+        if (YV) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
+        } else {
+          acc[0] = MFMA(av, b[u][s][0], acc[0]);
+        }
+      }
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  if (own) {
+    const float na = (pidx < A.n_Q) ? -aQ : -aPi;
+    if (YV) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+      if (ADAM) adam_apply4(A, na, pidx, v, pre);
+    } else {
+      dst[0] = v[0];                                        // N == 1 (gcol == 0)
+      if (ADAM) {
+        float m = pre.m[0], vv = pre.v[0];
+        const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
+        A.m[pidx] = m; A.v[pidx] = vv; A.theta[pidx] = th;
+      }
+    }
+  }
+  if (P.db && by == 0) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (own_b) {
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+      P.db[n0 + tid] = gb;
+      if (ADAM) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+      }
+    }
+  }
+}
+
+template <bool ADAM>
+__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red) {
+  const int tid = threadIdx.x;
+  // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
+  // arithmetic, so the descriptor load does not wait for a search through the table
+  const int pi = bid / args.slots, t = bid - pi * args.slots;
+  if (pi >= args.nprob) {
+    // extra last block (only launched when fin.rows != NULL): losses (ddpg.py:439-441) from the per-row terms,
+    // summed in a fixed order
+    const LossFin& F = args.fin;
+    float lq = 0.f, lp = 0.f, ll = 0.f;
+    for (int m = tid; m < F.B; m += 256) {
+      lq += F.rows[m];
+      lp += F.rows[F.B + m];
+      ll += F.rows[2 * F.B + m];
+    }
+    red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+      if (tid < h) {
+        red[tid] += red[tid + h];
+        red[256 + tid] += red[256 + tid + h];
+        red[512 + tid] += red[512 + tid + h];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float invB = 1.0f / (float)F.B;
+      F.out[0] = red[0] * invB;
+      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+    }
+    return;
+  }
+  const DwSmall& P = args.p[pi];
+  if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red);
+}
+
+// Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
+// hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
+// launches only bought a second ~4.5 us dependent stage).
+struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
+__global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  AdamFuse none;
+  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red);
+  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red);
+}
+
+// The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
+// applied in the tile epilogue, the loss finalisation, and -- in the first n_her blocks -- the HER gather of the NEXT
+// update's batch (it depends on nothing this update computes; it must target a different staging buffer than the one
+// the layer-0 gradient tiles of this launch still read).
+__global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int bid = (int)blockIdx.x - n_her;
+  if (bid < 0) her_sample_body(h, blockIdx.x, red);
+  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red);
+  else dw_small_body<true>(args.small, A, bid - args.n_hot, red);
+}
