@@ -462,28 +462,48 @@ struct UpdateTail {
   int64_t n_pi;
 };
 
-static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
-                           const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
-                           const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                           int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail) {
+// One pass of DDPG._grads (+ the optimiser tail of curious_ddpg_update): the launch sequence of DESIGN.md section 4.
+// setup() validates and carves, then forward() -> critic_backward() -> actor_backward() -> weight_grads() enqueue the
+// 9 launches of the lean route (or their generic equivalents).
+struct DdpgPass {
+  // arguments
+  const curious_net_cfg_t* cfg; const float* theta_main; const float* theta_target; const float* batch;
+  const curious_batch_layout_t* BL; int32_t B; const float* o_stats; const float* g_stats; float* workspace;
+  float* grad; float* out_losses; float* out_Q_pi; int64_t* step_ctr;
+  // derived
+  hipStream_t st; int H, nl, U, ld;
+  Ws w; NetOff offQ, offPi;
+  const float *thQ, *thPi, *ttQ, *ttPi; float *gQ, *gPi;
+  ObsIn cur, nxt;
+  Chain ch[3], cb[2];            // level A: target actor, main critic(u), main actor; level B: target critic(pi'), critic(pi)
+  int64_t urow; L0Prob pre[2];
+  bool fuse_pi, use_part, dx_hot, fuse_crit;
+
+  int setup(curious_stream_t stream);
+  int forward();
+  int critic_backward();
+  int actor_backward();
+  int weight_grads(const UpdateTail* tail);
+};
+
+int DdpgPass::setup(curious_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta_main && theta_target && batch && BL && workspace && grad && out_losses && out_Q_pi,
                 "curious_ddpg_grads: NULL argument");
   CURIOUS_CHECK(B > 0, "curious_ddpg_grads: empty batch");
   CURIOUS_CHECK(!cfg->normalize_obs || (o_stats && g_stats), "curious_ddpg_grads: normalize_obs needs stats");
-  hipStream_t st = as_stream(stream);
-  const int H = cfg->hidden, nl = cfg->layers, U = cfg->dimu;
-  Ws w = carve(cfg, B, workspace);
-  NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
-  const float* thQ = theta_main;
-  const float* thPi = theta_main + pi_offset(cfg);
-  const float* ttQ = theta_target;
-  const float* ttPi = theta_target + pi_offset(cfg);
-  float* gQ = grad;
-  float* gPi = grad + pi_offset(cfg);
-  const int ld = BL->stride;
+  st = as_stream(stream);
+  H = cfg->hidden; nl = cfg->layers; U = cfg->dimu;
+  w = carve(cfg, B, workspace);
+  offQ = net_off(cfg, true); offPi = net_off(cfg, false);
+  thQ = theta_main;
+  thPi = theta_main + pi_offset(cfg);
+  ttQ = theta_target;
+  ttPi = theta_target + pi_offset(cfg);
+  gQ = grad;
+  gPi = grad + pi_offset(cfg);
+  ld = BL->stride;
 
-  ObsIn cur, nxt;
   memset(&cur, 0, sizeof(cur));
   cur.o = batch + BL->off_o; cur.ldo = ld;
   cur.td = batch + BL->off_td; cur.ldtd = ld;
@@ -493,24 +513,24 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   nxt = cur;
   nxt.o = batch + BL->off_o2;            // target nets see (o_2, g_2) (ddpg.py:427-431)
   nxt.g = batch + BL->off_g2;
+  return 0;
+}
 
+int DdpgPass::forward() {
   // ---- forward level A: hidden layers of target actor, main critic(u), main actor
-  Chain ch[3];
   ch[0].theta = ttPi; ch[0].off = offPi; ch[0].in = nxt; ch[0].critic = false; ch[0].act = w.act[0];
   ch[1].theta = thQ; ch[1].off = offQ; ch[1].in = cur; ch[1].critic = true; ch[1].act = w.act[1];
   ch[2].theta = thPi; ch[2].off = offPi; ch[2].in = cur; ch[2].critic = false; ch[2].act = w.act[2];
   // level B = hidden layers of target critic(pi_target), main critic(pi)
-  Chain cb[2];
   cb[0].theta = ttQ; cb[0].off = offQ; cb[0].in = nxt; cb[0].in.u = w.pi_t; cb[0].in.ldu = U; cb[0].critic = true;
   cb[0].act = w.act[3];
   cb[1].theta = thQ; cb[1].off = offQ; cb[1].in = cur; cb[1].in.u = w.pi; cb[1].in.ldu = U; cb[1].critic = true;
   cb[1].act = w.act[4];
-  const int64_t urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);   // first action row of W0
+  urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);                 // first action row of W0
   // Lean route: the action-independent part of level B's layer 0 rides on level A's layer-0 launch, the actor output
   // layers and the action rows are folded into level B's layer-1 launch (fwd_pi_kernel).
-  L0Prob pre[2];
   memset(pre, 0, sizeof(pre));
-  bool fuse_pi = nl >= 2 && H == 256 && U == 4 && (B % 16 == 0) && aligned16(thQ) && aligned16(thPi) && aligned16(ttQ) &&
+  fuse_pi = nl >= 2 && H == 256 && U == 4 && (B % 16 == 0) && aligned16(thQ) && aligned16(thPi) && aligned16(ttQ) &&
                  aligned16(ttPi) && aligned16(workspace) && aligned16(thPi + offPi.Wout) &&
                  aligned16(thQ + offQ.W0 + urow * H);
   if (fuse_pi) {
@@ -521,7 +541,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   // With >= 3 layers the last hidden layer of every chain runs on the lean kernel, whose dot epilogue leaves the
   // output-layer products as 4 column-tile partials: the fused prologues downstream then add 4 numbers per row
   // instead of contracting 256-wide rows.  part[]: 0 pi_target, 1 pi, 2 Q, 3 Q_target, 4 Q_pi, 5 dz.
-  const bool use_part = fuse_pi && nl >= 3;
+  use_part = fuse_pi && nl >= 3;
   if (use_part) {
     ch[0].dot_mode = 2; ch[0].dot_w = ttPi + offPi.Wout; ch[0].dot_out = w.part[0];
     ch[1].dot_mode = 1; ch[1].dot_w = thQ + offQ.Wout; ch[1].dot_out = w.part[2];
@@ -563,11 +583,14 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     // ---- forward level B
     if (forward_chains(cfg, cb, 2, B, st)) return -2;
   }
+  return 0;
+}
 
+int DdpgPass::critic_backward() {
   // ---- critic output layers, per-row loss terms, backward through the output layers (fused with the first hidden
   //      backward level when the lean kernels apply)
-  const bool dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
-  const bool fuse_crit = dx_hot && nl >= 2 && H == 256;
+  dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
+  fuse_crit = dx_hot && nl >= 2 && H == 256;
   CURIOUS_CHECK(!use_part || fuse_crit, "curious_ddpg_grads: inconsistent lean-path conditions");
   if (fuse_crit) {
     DxCritArgs a;
@@ -644,56 +667,10 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel");
   }
-  // ---- weight/bias gradients: problem lists for the lean kernels (launched after the actor's backward chain)
-  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && !cfg->normalize_obs;
-  LossFin fin;
-  fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
-  auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
-    int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
-    bool ok = true;
-    const NetOff& off = critic ? offQ : offPi;
-    float* g = critic ? gQ : gPi;
-    const int chain = critic ? 1 : 2;
-    float** dact = w.dact[critic ? 0 : 2];
-    auto add_small = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
-      if (ns_ >= MAX_DW_SMALL || x.sub || x.mean || x.clip > 0.0f || !(N % 4 == 0 || N == 1) ||
-          !(N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) { ok = false; return; }
-      DwSmall& p = sm.p[ns_++];
-      p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
-      stiles = std::max(stiles, ((x.w + 15) / 16) * ((N + 63) / 64));   // -> slots per problem
-    };
-    add_small(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D,
-              g + off.Wout, g + off.bout);
-    for (int l = nl - 1; l >= 1; --l) {
-      GemmHot& p = hw.p[nh];
-      p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
-      p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
-      tiles += (H / 16) * (H / 64);
-      ++nh;
-    }
-    hw.nprob = nh;
-    Seg seg[MAX_SEG];
-    int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
-    int64_t r = 0;
-    for (int s = 0; s < ns; ++s) {
-      const bool goal_branch = cfg->modular && s == ns - 1;
-      float* dW = goal_branch ? g + off.Wg : g + off.W0 + r * H;
-      add_small(seg[s], dact[0], H, H, dW, (s == 0) ? g + off.b0 : nullptr);
-      if (!goal_branch) r += seg[s].w;
-    }
-    sm.nprob = ns_; sm.M = B;
-    return ok;
-  };
-  // (Measured: running the critic's gradient kernels on a forked side stream -- a parallel branch of the captured
-  //  graph -- made every update 70 % SLOWER on this stack, and slowed unrelated eager launches once a second hardware
-  //  queue was active; everything therefore stays on the caller's stream.)
-  DwAllArgs dwAll;
-  memset(&dwAll, 0, sizeof(dwAll));
-  DwHotArgs& hwAll = dwAll.hot;
-  DwSmallArgs& smAll = dwAll.small;
-  int tAll = 0, stAll = 0;
-  bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
-  if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
+  return 0;
+}
+
+int DdpgPass::actor_backward() {
   // ---- into the action slot of critic(pi), through tanh + l2 term -> dz; backward through the actor output layer
   //      (fused with the actor's first hidden backward level when the lean kernels apply)
   const float l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
@@ -747,6 +724,60 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel(actor)");
   }
+  return 0;
+}
+
+int DdpgPass::weight_grads(const UpdateTail* tail) {
+  // ---- weight/bias gradients: problem lists for the lean kernels (launched after the actor's backward chain)
+  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && !cfg->normalize_obs;
+  LossFin fin;
+  fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
+  auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
+    int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
+    bool ok = true;
+    const NetOff& off = critic ? offQ : offPi;
+    float* g = critic ? gQ : gPi;
+    const int chain = critic ? 1 : 2;
+    float** dact = w.dact[critic ? 0 : 2];
+    auto add_small = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
+      if (ns_ >= MAX_DW_SMALL || x.sub || x.mean || x.clip > 0.0f || !(N % 4 == 0 || N == 1) ||
+          !(N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) { ok = false; return; }
+      DwSmall& p = sm.p[ns_++];
+      p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
+      stiles = std::max(stiles, ((x.w + 15) / 16) * ((N + 63) / 64));   // -> slots per problem
+    };
+    add_small(make_seg(w.act[chain][nl - 1], H, H, nullptr), critic ? w.dQ : w.dz, critic ? 1 : U, off.D,
+              g + off.Wout, g + off.bout);
+    for (int l = nl - 1; l >= 1; --l) {
+      GemmHot& p = hw.p[nh];
+      p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
+      p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
+      tiles += (H / 16) * (H / 64);
+      ++nh;
+    }
+    hw.nprob = nh;
+    Seg seg[MAX_SEG];
+    int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
+    int64_t r = 0;
+    for (int s = 0; s < ns; ++s) {
+      const bool goal_branch = cfg->modular && s == ns - 1;
+      float* dW = goal_branch ? g + off.Wg : g + off.W0 + r * H;
+      add_small(seg[s], dact[0], H, H, dW, (s == 0) ? g + off.b0 : nullptr);
+      if (!goal_branch) r += seg[s].w;
+    }
+    sm.nprob = ns_; sm.M = B;
+    return ok;
+  };
+  // (Measured: running the critic's gradient kernels on a forked side stream -- a parallel branch of the captured
+  //  graph -- made every update 70 % SLOWER on this stack, and slowed unrelated eager launches once a second hardware
+  //  queue was active; everything therefore stays on the caller's stream.)
+  DwAllArgs dwAll;
+  memset(&dwAll, 0, sizeof(dwAll));
+  DwHotArgs& hwAll = dwAll.hot;
+  DwSmallArgs& smAll = dwAll.small;
+  int tAll = 0, stAll = 0;
+  bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
+  if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
   if (lean_dw) {
     smAll.fin = fin;
     dwAll.n_hot = tAll;
@@ -814,13 +845,29 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
                                             a->alpha_tab, step_ctr, a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah,
                                             a->beta1, a->one_minus_beta1, a->beta2, a->one_minus_beta2, a->epsilon,
                                             nx->storage, nx->buf_stride, nx->L, nx->tasks, nx->P, nx->rng, B, nx->batch,
-                                            BL, stream);
+                                            BL, (curious_stream_t)st);
     }
     return curious_adam_update(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi, a->alpha_tab, step_ctr,
                                a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah, a->beta1, a->one_minus_beta1,
-                               a->beta2, a->one_minus_beta2, a->epsilon, stream);
+                               a->beta2, a->one_minus_beta2, a->epsilon, (curious_stream_t)st);
   }
   return 0;
+}
+
+static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
+                           const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
+                           const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                           int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail) {
+  DdpgPass p;
+  p.cfg = cfg; p.theta_main = theta_main; p.theta_target = theta_target; p.batch = batch; p.BL = BL; p.B = B;
+  p.o_stats = o_stats; p.g_stats = g_stats; p.workspace = workspace; p.grad = grad; p.out_losses = out_losses;
+  p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
+  int rc = p.setup(stream);
+  if (!rc) rc = p.forward();
+  if (!rc) rc = p.critic_backward();
+  if (!rc) rc = p.actor_backward();
+  if (!rc) rc = p.weight_grads(tail);
+  return rc;
 }
 
 extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
