@@ -9,6 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
+ABI_VERSION = 2          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -84,6 +85,7 @@ _I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_doub
 PROTOTYPES = {
     'curious_last_error': (C.c_char_p, []),
     'curious_abi_version': (C.c_int, []),
+    'curious_build_digest': (C.c_char_p, []),
     'curious_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     'curious_prof_enable': (C.c_int, [C.c_int]),
     'curious_prof_kernel_count': (C.c_int, []),
@@ -148,8 +150,14 @@ def lib():
             fn = getattr(L, name)            # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.curious_abi_version() != 1:
-            raise CuriousHipError('libcurious_hip ABI version mismatch')
+        if L.curious_abi_version() != ABI_VERSION:
+            raise CuriousHipError('libcurious_hip ABI version %d, the binding expects %d: rebuild with '
+                                  '`python -m curious_amd.build`' % (L.curious_abi_version(), ABI_VERSION))
+        from curious_amd.build import source_digest
+        built = L.curious_build_digest().decode()
+        if built != source_digest():
+            raise CuriousHipError('libcurious_hip.so was built from other sources than the ones in curious_amd/csrc '
+                                  '(digest %s...): rebuild with `python -m curious_amd.build`' % built[:12])
         _lib = L
     return _lib
 

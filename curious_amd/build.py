@@ -15,6 +15,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=o
          '-x', 'hip']
 
 
+def source_digest():
+    return _digest()
+
+
 def _digest():
     h = hashlib.sha256()
     for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
@@ -35,7 +39,10 @@ def build(force=False, verbose=True):
     procs = []
     for s in SOURCES:
         obj = os.path.join(LIBDIR, s.rsplit('.', 1)[0] + '.o')
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', obj]
+        # the source digest is compiled into the library (curious_build_digest): _lib.lib() refuses a binary that was
+        # built from other sources than the ones next to it (the stamp file below is only the fast path of this function)
+        extra = ['-DCURIOUS_BUILD_DIGEST="%s"' % dig] if s == 'api.cpp' else []
+        cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -28,7 +28,6 @@ def policy_state(policy):
         o_stats=policy.o_stats.state.cpu(), g_stats=policy.g_stats.state.cpu(), stats_acc=policy._stats_acc.cpu(),
         cp=None if policy.cp is None else np.asarray(policy.cp, dtype=np.float64).copy(),
         noise_counter=policy._noise_counter, stats_calls=getattr(policy, '_stats_calls', 0),
-        noise_base=int(policy._noise_base) if getattr(policy, '_noise_base', None) is not None else 0,
         buffers=[])
     for i, b in _buffers_of(policy):
         st['buffers'].append(dict(index=i, current_size=b.current_size, n_transitions_stored=b.n_transitions_stored,
@@ -47,12 +46,9 @@ def load_policy_state(policy, st):
     policy.g_stats.state.copy_(st['g_stats'])
     policy._stats_acc.copy_(st['stats_acc'])
     policy.cp = st['cp']
-    policy._noise_counter = st['noise_counter']
-    if st.get('noise_base', 0) or getattr(policy, '_noise_base', None) is not None:
-        if getattr(policy, '_noise_base', None) is None:
-            policy._noise_base = torch.zeros(1, dtype=torch.int64, device=policy.device)
-            policy._roll_graphs = {}
-        policy._noise_base.fill_(st.get('noise_base', 0))
+    policy._noise_counter = st['noise_counter']               # the device mirror follows lazily (DDPG.act_rollout)
+    if getattr(policy, '_noise_base', None) is not None:
+        policy._noise_base_val = None
     policy._stats_calls = st['stats_calls']
     by_index = {i: b for i, b in _buffers_of(policy)}
     for bs in st['buffers']:

@@ -16,6 +16,11 @@ extern "C" const char* curious_last_error(void) { return g_err; }
 
 extern "C" int curious_abi_version(void) { return CURIOUS_ABI_VERSION; }
 
+#ifndef CURIOUS_BUILD_DIGEST
+#define CURIOUS_BUILD_DIGEST "unknown"
+#endif
+extern "C" const char* curious_build_digest(void) { return CURIOUS_BUILD_DIGEST; }
+
 extern "C" int curious_device_info(char* name_host, int name_len, int* cu_count_host) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

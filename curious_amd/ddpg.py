@@ -49,6 +49,8 @@ class DDPG(object):
         """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph."""
         if self.clip_return is None:
             self.clip_return = np.inf
+        self._extra_kwargs = tuple(kwargs.keys())                    # e.g. info, use_mpi: stored by store_args, pickled
+        self._scope_arg = scope
         self.create_actor_critic = import_function(self.network_class)
         self.dimo, self.dimg = self.input_dims['o'], self.input_dims['g']
         self.dimag, self.dimu = self.input_dims['ag'], self.input_dims['u']
@@ -258,7 +260,15 @@ class DDPG(object):
             self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
         if getattr(self, '_noise_base', None) is None:
             self._noise_base = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._noise_base_val = 0
             self._roll_graphs = {}
+        # ONE logical noise counter for every acting path: the host value `_noise_counter` (get_actions / act_and_step
+        # pass it as a kernel argument) and its device mirror `_noise_base` (read by the captured launches below).  The
+        # mirror is brought up to date here when host-side acting calls ran since the last rollout, so no two acting
+        # calls of one agent ever draw from the same (seed, counter) pair.
+        if self._noise_base_val != self._noise_counter:
+            self._noise_base.fill_(self._noise_counter)
+            self._noise_base_val = self._noise_counter
         seed = self.seed * 2654435761 + 12345 + dist.rank() * 1000003     # same stream as get_actions / act_and_step
         u_out = self._act_u
 
@@ -271,6 +281,7 @@ class DDPG(object):
             self._noise_base.add_(T)
 
         self._noise_counter += T
+        self._noise_base_val = self._noise_counter                   # steps() ends with the device-side += T
         if not self.use_graph:
             steps()
             return
@@ -329,8 +340,7 @@ class DDPG(object):
                 steps()
             entry = (g, q_acc, u, Q)
             self._roll_graphs[key] = entry
-        self._noise_counter += T
-        entry[0].replay()
+        entry[0].replay()                                            # noise-free: the noise counter does not move
         return entry[1] if compute_Q else None
 
     # ------------------------------------------------------------------ storing
@@ -934,15 +944,16 @@ class DDPG(object):
     def save_weights(self, path):
         """Pickled list of lists in the reference's order: main/Q, main/pi, target/Q, target/pi, o_stats, g_stats
         (ddpg.py:481-497)."""
-        to_save = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),
-                   self._net_arrays(self.theta_target, True), self._net_arrays(self.theta_target, False),
-                   self._stats_arrays(self.o_stats), self._stats_arrays(self.g_stats)]
         with open(path + '_weights.pkl', 'wb') as f:
-            pickle.dump(to_save, f)
+            pickle.dump(self._weights_lists(), f)
 
-    def load_weights(self, path):
-        with open(path + '_weights.pkl', 'rb') as f:
-            weights = pickle.load(f)                                 # ddpg.py:499-509
+    def _weights_lists(self):
+        return [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),
+                self._net_arrays(self.theta_target, True), self._net_arrays(self.theta_target, False),
+                self._stats_arrays(self.o_stats), self._stats_arrays(self.g_stats)]
+
+    def _set_weights_lists(self, weights):
+        assert len(weights) == 6, 'expected main/Q, main/pi, target/Q, target/pi, o_stats, g_stats (ddpg.py:483-484)'
         self._load_net_arrays(self.theta, True, weights[0])
         self._load_net_arrays(self.theta, False, weights[1])
         self._load_net_arrays(self.theta_target, True, weights[2])
@@ -950,29 +961,27 @@ class DDPG(object):
         for nz, arrs in ((self.o_stats, weights[4]), (self.g_stats, weights[5])):
             nz.state.copy_(torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs])))
 
+    def load_weights(self, path):
+        with open(path + '_weights.pkl', 'rb') as f:
+            weights = pickle.load(f)                                 # ddpg.py:499-509
+        self._set_weights_lists(weights)
+
     def __getstate__(self):
-        """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521)."""
-        excluded = ['_tf', '_op', '_vars', '_adam', 'buffer', 'sess', '_stats', 'main', 'target', 'lock', 'env',
-                    'sample_transitions', 'stage_shapes', 'create_actor_critic', 'theta', 'grad', 'net_cfg',
-                    'device', '_pool', '_layout', '_graph', '_tables', '_rng_desc', '_staged', '_pp', '_workspace', '_roll_graphs', '_noise_base', '_act_u', '_route_bufs', '_stats_batch', '_stats_tables',
-                    '_act_ws', '_losses', '_Q_pi', '_step_ctr', '_alpha_tab', '_m', '_v', 'kwargs']
-        state = {k: v for k, v in self.__dict__.items() if all(sub not in k for sub in excluded)}
-        state['weights'] = [self._net_arrays(self.theta, True), self._net_arrays(self.theta, False),
-                            self._net_arrays(self.theta_target, True), self._net_arrays(self.theta_target, False),
-                            self._stats_arrays(self.o_stats), self._stats_arrays(self.g_stats)]
+        """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521).
+        The state is the constructor's own arguments (the reference filters __dict__ by substrings, which here would
+        also drop e.g. use_graph) plus the weights in save_weights order."""
+        import inspect
+        names = [n for n in inspect.signature(DDPG.__init__).parameters if n not in ('self', 'kwargs')]
+        names += list(getattr(self, '_extra_kwargs', ()))
+        skip = ('buffers', 'sample_transitions')                     # ddpg.py:514-516: no buffers, no sampler
+        state = {k: self.__dict__[k] for k in names if k in self.__dict__ and k not in skip}
+        state['scope'] = self._scope_arg
+        state['weights'] = self._weights_lists()
         return state
 
     def __setstate__(self, state):
         weights = state.pop('weights')
         if 'sample_transitions' not in state:
             state['sample_transitions'] = None
-        for k in ('dimo', 'dimg', 'dimag', 'dimu', 'dimtd', 'modular', 'P_Q', 'P_pi', 'off_pi', 'P_total', 'first',
-                  'cp', 'proportions', 'nb_tasks', 'n_episodes'):
-            state.pop(k, None)
         self.__init__(**state)
-        self._load_net_arrays(self.theta, True, weights[0])
-        self._load_net_arrays(self.theta, False, weights[1])
-        self._load_net_arrays(self.theta_target, True, weights[2])
-        self._load_net_arrays(self.theta_target, False, weights[3])
-        for nz, arrs in ((self.o_stats, weights[4]), (self.g_stats, weights[5])):
-            nz.state.copy_(torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs])))
+        self._set_weights_lists(weights)

@@ -337,12 +337,16 @@ class RolloutWorker:
         return np.mean(self.Q_history)
 
     def save_policy(self, path):
+        """rollout.py:425-433.  The reference swallows every exception of save_weights because a task_experts policy
+        is a list without that method; here the list case is handled (one weights file per expert) and real errors
+        surface."""
         with open(path, 'wb') as f:
             pickle.dump(self.policy, f)
-        try:
+        if isinstance(self.policy, (list, tuple)):
+            for i, p in enumerate(self.policy):
+                p.save_weights(path + str(i))
+        else:
             self.policy.save_weights(path)
-        except Exception:
-            pass
 
     def save_goal_task_history(self, path):
         pass                                                          # rollout.py:437-449 (commented out upstream)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 1
+#define CURIOUS_ABI_VERSION 2      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -101,6 +101,9 @@ typedef struct curious_sample_rng {
 
 const char* curious_last_error(void);
 int curious_abi_version(void);
+/* sha256 of the sources (csrc, this header, compiler flags) the library was built from; the Python binding compares it
+ * with the sources next to it and refuses a stale binary */
+const char* curious_build_digest(void);
 /* name of the device the library runs on + its CU count; fails when no gfx950 device is present */
 int curious_device_info(char* name_host, int name_len, int* cu_count_host);
 

@@ -19,7 +19,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(L, name), name
-    assert L.curious_abi_version() == 1
+    assert L.curious_abi_version() == _lib.ABI_VERSION
+    from curious_amd.build import source_digest
+    assert L.curious_build_digest().decode() == source_digest()
 
 
 def test_argument_validation_without_gpu():
