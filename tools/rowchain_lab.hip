@@ -1,0 +1,175 @@
+// Micro-lab: a chain of dependent 256-wide layers computed ROW-LOCALLY -- every workgroup owns R batch rows and walks
+// the whole chain h <- relu(h . W_l + b_l), l = 0..L-1, inside one launch (no inter-workgroup exchange, no kernel
+// boundary per layer).  Question it answers: what does one layer cost when the only shared resource is the weight
+// stream L2 -> CU (256 KB per layer per workgroup)?  Compare with 4.8 us per layer launch of the product's
+// 16x64 split-K tiles (profiles/README.md).
+//   hipcc --offload-arch=gfx950 -O3 tools/rowchain_lab.hip -o /tmp/rowchain_lab && /tmp/rowchain_lab
+// MFMA used: v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 rows x 4 columns, K = 1): the A operand is the same 4 rows in
+// every block (lane l supplies row l % 4), the B operand of lane l is W[k][4l + e] -> one instruction = 4 rows x 64
+// columns {4l + e}, four instructions (e = 0..3) cover 4 rows x 256 columns for one k.  The 4 waves split K.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#define H 256
+#define HLD 260            // LDS row stride of the activation rows
+
+__device__ inline f32x4 ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// R = rows per workgroup (4 or 8).  grid (B / R, nchains).  W: [nchains][L][256][256], bias: [nchains][L][256].
+template <int R>
+__global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, const float* __restrict__ W,
+                                                const float* __restrict__ bias, float* __restrict__ Y, int L, int B) {
+  constexpr int G = R / 4;                                  // row groups of 4
+  __shared__ __attribute__((aligned(16))) float hs[R * HLD];
+  __shared__ __attribute__((aligned(16))) float part[4 * R * H];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = blockIdx.x * R, chain = blockIdx.y;
+  const float* Wc = W + (size_t)chain * L * H * H;
+  const float* bc = bias + (size_t)chain * L * H;
+  const float* Xc = X + (size_t)chain * B * H;
+  float* Yc = Y + (size_t)chain * B * H;
+  for (int i = tid; i < R * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(Xc + (size_t)(r0 + r) * H + c);
+  }
+  // weight fragments of this wave's K quarter: k = 64 * wave + 16 * c + i, lane's 4 columns 4 * lane ..
+  f32x4 b[2][16];
+  const float* wl = Wc + (size_t)(64 * wave) * H + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b[0][i] = ldv(wl + (size_t)i * H);
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    f32x4 acc[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[g][e] = zero4();
+    const float bv = bc[(size_t)l * H + tid];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // prefetch the next 16-deep chunk (of the next layer after the last chunk: weights do not depend on activations)
+      const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
+      if (c < 3 || l + 1 < L) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[(c + 1) & 1][i] = ldv(nx + (size_t)i * H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        f32x4 a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          a[g] = *reinterpret_cast<const f32x4*>(hs + (4 * g + (lane & 3)) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][e] = MFMA4(a[g][s], b[c & 1][4 * kq + s][e], acc[g][e]);
+      }
+    }
+    wl += (size_t)H * H;
+    // partial rows of this wave -> LDS; acc[g][e][r] = out[row 4g + r][col 4 * lane + e]
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {acc[g][0][r], acc[g][1][r], acc[g][2][r], acc[g][3][r]};
+        *reinterpret_cast<f32x4*>(part + ((wave * R + 4 * g + r) * H + 4 * lane)) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = (part[(0 * R + r) * H + tid] + part[(1 * R + r) * H + tid]) +
+                (part[(2 * R + r) * H + tid] + part[(3 * R + r) * H + tid]);
+      s = fmaxf(s + bv, 0.f);
+      hs[r * HLD + tid] = s;
+      if (l == L - 1) Yc[(size_t)(r0 + r) * H + tid] = s;
+    }
+    __syncthreads();
+  }
+}
+
+static void cpu_chain(const std::vector<float>& X, const std::vector<float>& W, const std::vector<float>& b,
+                      std::vector<float>& Y, int L, int B) {
+  std::vector<double> h(X.begin(), X.begin() + (size_t)B * H), n((size_t)B * H);
+  for (int l = 0; l < L; ++l) {
+    for (int m = 0; m < B; ++m)
+      for (int c = 0; c < H; ++c) {
+        double s = b[(size_t)l * H + c];
+        for (int k = 0; k < H; ++k) s += h[(size_t)m * H + k] * W[((size_t)l * H + k) * H + c];
+        n[(size_t)m * H + c] = s > 0 ? s : 0;
+      }
+    h.swap(n);
+  }
+  Y.assign(h.begin(), h.end());
+}
+
+template <int R>
+static float run(const float* X, const float* W, const float* b, float* Y, int L, int B, int nch, int iters) {
+  dim3 grid(B / R, nch);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(rowchain<R>, grid, dim3(256), 0, 0, X, W, b, Y, L, B);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(rowchain<R>, grid, dim3(256), 0, 0, X, W, b, Y, L, B);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+int main() {
+  const int B = 256, LMAX = 16, NCH = 3;
+  std::vector<float> hX((size_t)NCH * B * H), hW((size_t)NCH * LMAX * H * H), hb((size_t)NCH * LMAX * H);
+  srand(1);
+  for (auto& v : hX) v = (float)rand() / RAND_MAX - 0.5f;
+  const float lim = sqrtf(6.0f / (H + H));
+  for (auto& v : hW) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * lim * 1.4f;
+  for (auto& v : hb) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  float *X, *W, *b, *Y;
+  CK(hipMalloc(&X, hX.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, hb.size() * 4));
+  CK(hipMalloc(&Y, hX.size() * 4));
+  CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  // ---- correctness (chain 0, L = 3; the weight layout is [chain][L][..] with the L of the launch)
+  {
+    const int L = 3;
+    std::vector<float> ref, got((size_t)B * H);
+    cpu_chain(hX, hW, hb, ref, L, B);
+    for (int R : {4, 8}) {
+      CK(hipMemset(Y, 0, hX.size() * 4));
+      if (R == 4) hipLaunchKernelGGL(rowchain<4>, dim3(B / 4, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
+      else hipLaunchKernelGGL(rowchain<8>, dim3(B / 8, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(got.data(), Y, got.size() * 4, hipMemcpyDeviceToHost));
+      double maxerr = 0, maxref = 0;
+      for (size_t i = 0; i < got.size(); ++i) {
+        maxerr = fmax(maxerr, fabs(got[i] - ref[i]));
+        maxref = fmax(maxref, fabs(ref[i]));
+      }
+      printf("check R=%d L=%d: max abs err %.3e (max |ref| %.3f)\n", R, L, maxerr, maxref);
+    }
+  }
+  // ---- timing: per launch for L layers; the slope over L is the per-layer cost without the launch floor
+  for (int nch : {1, 3}) {
+    for (int R : {4, 8}) {
+      float t[3];
+      const int Ls[3] = {2, 8, 14};
+      for (int i = 0; i < 3; ++i)
+        t[i] = (R == 4) ? run<4>(X, W, b, Y, Ls[i], B, nch, 300) : run<8>(X, W, b, Y, Ls[i], B, nch, 300);
+      printf("rowchain R=%d chains=%d (%3d WGs): L=2 %.2f us, L=8 %.2f us, L=14 %.2f us -> %.2f us per layer\n", R, nch,
+             B / R * nch, t[0], t[1], t[2], (t[2] - t[0]) / 12.f);
+    }
+  }
+  return 0;
+}
