@@ -108,6 +108,9 @@ PROTOTYPES = {
                                      _P, _P, _P, _P]),
     'curious_ddpg_update': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
                                       _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
+    'curious_ddpg_update_experts': (C.c_int, [C.POINTER(NetCfg), _I32, _I64, _U64, _P, _P, _P, C.POINTER(BatchLayout),
+                                              _I32, _P, _P, _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch),
+                                              _P]),
     'curious_policy_forward': (C.c_int, [C.POINTER(NetCfg), _P, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _F,
                                          _I32, _P, _P, _P, _P, _P, _P]),
     'curious_action_noise': (C.c_int, [_P, _I32, _I32, _I32, _D, _D, _D, _P, _P, _P, _U64, _U64, _P]),

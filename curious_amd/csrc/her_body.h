@@ -27,7 +27,10 @@ struct HerArgs {
 // organised as exactly two: (1) everything needed to decide WHERE to read -- the task tables (into LDS), the
 // sampling tables / host plan and the step counter, all issued together; (2) the three row segments of the
 // transition.  Relabelling, reward and clipping then run out of LDS / registers.
-__device__ __forceinline__ void her_sample_body(const HerArgs& a, const int block, float* lds) {
+// eo / seed_add: batched experts (mlp_common.h "Ex"): the staged batch, the sampling tables and the step counter of
+// expert e live eo floats behind expert 0's, its Philox key is seed + seed_add; the replay storage is shared.
+__device__ __forceinline__ void her_sample_body(const HerArgs& a, const int block, float* lds, const int64_t eo = 0,
+                                                const uint64_t seed_add = 0) {
   __shared__ int32_t s_tab[TAB_INTS];
   const curious_layout_t& L = a.L;
   const curious_batch_layout_t& BL = a.BL;
@@ -66,11 +69,13 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     const curious_sample_rng_t& R = a.rng;
     // lane b looks at logical buffer b: all table entries are fetched in one batch
     const int b = min(lane, R.nbuf - 1);
-    const int pe = R.prop_prefix[b + 1];
-    const int al = R.buf_alias ? R.buf_alias[b] : b;
-    const int tk = R.buf_task ? R.buf_task[b] : -1;
-    const int cs = R.cur_size[b];
-    const int64_t step = R.step_ctr ? *R.step_ctr : R.step_host;
+    const int pe = R.prop_prefix[eo + b + 1];
+    const int al = R.buf_alias ? R.buf_alias[eo + b] : b;
+    const int tk = R.buf_task ? R.buf_task[eo + b] : -1;
+    const int cs = R.cur_size[eo + b];
+    const int64_t step = R.step_ctr
+        ? *reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(R.step_ctr) + eo) : R.step_host;
+    const uint64_t seed = R.seed + seed_add;
     const unsigned long long beyond = __ballot(lane < R.nbuf && gic >= pe);
     int lb = __popcll(beyond);
     if (lb >= R.nbuf) lb = R.nbuf - 1;
@@ -78,9 +83,9 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     ttr = __shfl(tk, lb);
     const uint32_t E = (uint32_t)__shfl(cs, lb);
     Philox4 r1 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_A,
-                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
     Philox4 r2 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_B,
-                            (uint32_t)R.seed, (uint32_t)(R.seed >> 32));
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
     ep = (int)(((uint64_t)r1.x * E) >> 32);
     t = (int)(((uint64_t)r1.y * (uint32_t)L.T) >> 32);
     u_her = u01_f64(r1.z, r1.w);
@@ -153,7 +158,7 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
   const float reward = (sqrt(d2) > a.P.reward_eps) ? -1.0f : 0.0f;
 
   if (valid) {
-    float* out = a.batch + (int64_t)out_row * BL.stride;
+    float* out = a.batch + eo + (int64_t)out_row * BL.stride;
     const float c = a.P.clip_obs;
     const bool rel = a.P.relative_goals != 0;
     const float* ag = s_row + L.off_ag;

@@ -209,6 +209,14 @@ struct Chain {
 
 static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
 
+// Batched experts (mlp_common.h "Ex"): nex agents per launch, slabs `stride` floats apart.
+struct ExDim { int nex = 1; int64_t stride = 0; };
+static Ex make_ex(const ExDim& d, int nprob) {
+  Ex e;
+  e.stride = d.stride; e.nprob = nprob; e.zmul = (uint32_t)((65536 + nprob - 1) / nprob);
+  return e;
+}
+
 // Fills the lean layer-0 descriptor of one chain; false when the lean kernel does not apply.
 static bool l0_lean_prob(const curious_net_cfg_t* c, const Chain& C, bool with_u, bool relu, float* Y, int M,
                          L0Prob& p) {
@@ -233,8 +241,9 @@ static bool l0_lean_prob(const curious_net_cfg_t* c, const Chain& C, bool with_u
 // `pre`/`npre`: extra layer-0 problems (pre-activations without the action rows, see fwd_pi_kernel) that ride on the
 // layer-0 launch; only valid when the caller has verified that the lean layer-0 kernel applies to every problem.
 static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M, hipStream_t st, int l_begin = 0,
-                          const L0Prob* pre = nullptr, int npre = 0) {
+                          const L0Prob* pre = nullptr, int npre = 0, const ExDim& xd = ExDim()) {
   const int H = c->hidden;
+  const bool exb = xd.nex > 1;
   for (int l = l_begin; l < c->layers; ++l) {
     bool hot = (l >= 1) && hot_ok(M, H, H);
     for (int i = 0; i < nch; ++i)
@@ -256,10 +265,16 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
         for (int i = 0; i < nch; ++i) kmax = std::max(kmax, (int)fa.p[i].l0.ktot);
         for (int i = 0; i < npre; ++i) { fa.pre[i] = pre[i]; kmax = std::max(kmax, (int)pre[i].ktot); }
         fa.n01 = nch;
-        dim3 grid(H / 64, M / 16, nch + npre);
+        dim3 grid(H / 64, M / 16, (nch + npre) * xd.nex);
+        const Ex ex = make_ex(xd, nch + npre);
         { ProfScope ps__(CK_FWD_L01, st);
-          if (kmax <= 64) hipLaunchKernelGGL(fwd_l01_kernel<1>, grid, dim3(256), 0, st, fa);
-          else hipLaunchKernelGGL(fwd_l01_kernel<2>, grid, dim3(256), 0, st, fa); }
+          if (kmax <= 64) {
+            if (exb) hipLaunchKernelGGL((fwd_l01_kernel<1, true>), grid, dim3(256), 0, st, fa, ex);
+            else hipLaunchKernelGGL((fwd_l01_kernel<1, false>), grid, dim3(256), 0, st, fa, ex);
+          } else {
+            if (exb) hipLaunchKernelGGL((fwd_l01_kernel<2, true>), grid, dim3(256), 0, st, fa, ex);
+            else hipLaunchKernelGGL((fwd_l01_kernel<2, false>), grid, dim3(256), 0, st, fa, ex);
+          } }
         CURIOUS_LAUNCH_CHECK("fwd_l01_kernel");
         ++l;                                        // layer 1 is done as well
         continue;
@@ -280,13 +295,20 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
         p.dot_w = p.B;
         if (last && C.dot_mode) { p.dot_mode = C.dot_mode; p.dot_w = C.dot_w; p.dot_out = C.dot_out; p.dot_ld = H; }
       }
-      dim3 grid(H / 64, M / 16, nch);
+      dim3 grid(H / 64, M / 16, nch * xd.nex);
+      const Ex ex = make_ex(xd, nch);
       { ProfScope ps__(CK_FWD_LAYER, st);
-        if (want_dot) hipLaunchKernelGGL(fwd_hot_kernel<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(fwd_hot_kernel<false>, grid, dim3(256), 0, st, a); }
+        if (want_dot) {
+          if (exb) hipLaunchKernelGGL((fwd_hot_kernel<true, true>), grid, dim3(256), 0, st, a, ex);
+          else hipLaunchKernelGGL((fwd_hot_kernel<true, false>), grid, dim3(256), 0, st, a, ex);
+        } else {
+          if (exb) hipLaunchKernelGGL((fwd_hot_kernel<false, true>), grid, dim3(256), 0, st, a, ex);
+          else hipLaunchKernelGGL((fwd_hot_kernel<false, false>), grid, dim3(256), 0, st, a, ex);
+        } }
       CURIOUS_LAUNCH_CHECK("fwd_hot_kernel");
       continue;
     }
+    CURIOUS_CHECK(!exb, "batched experts need the lean route (hidden 256, >= 3 layers, batch % 256 == 0)");
     if (l == 0 && (H % 64 == 0)) {
       L0Args la;
       memset(&la, 0, sizeof(la));
@@ -470,6 +492,7 @@ struct DdpgPass {
   const curious_net_cfg_t* cfg; const float* theta_main; const float* theta_target; const float* batch;
   const curious_batch_layout_t* BL; int32_t B; const float* o_stats; const float* g_stats; float* workspace;
   float* grad; float* out_losses; float* out_Q_pi; int64_t* step_ctr;
+  ExDim xd; uint64_t seed_stride = 0;     // batched experts: every pointer above is expert 0's
   // derived
   hipStream_t st; int H, nl, U, ld;
   Ws w; NetOff offQ, offPi;
@@ -542,6 +565,8 @@ int DdpgPass::forward() {
   // output-layer products as 4 column-tile partials: the fused prologues downstream then add 4 numbers per row
   // instead of contracting 256-wide rows.  part[]: 0 pi_target, 1 pi, 2 Q, 3 Q_target, 4 Q_pi, 5 dz.
   use_part = fuse_pi && nl >= 3;
+  CURIOUS_CHECK(xd.nex == 1 || use_part,
+                "batched experts need the lean route (hidden 256, >= 3 layers, dimu 4, batch % 256 == 0)");
   if (use_part) {
     ch[0].dot_mode = 2; ch[0].dot_w = ttPi + offPi.Wout; ch[0].dot_out = w.part[0];
     ch[1].dot_mode = 1; ch[1].dot_w = thQ + offQ.Wout; ch[1].dot_out = w.part[2];
@@ -550,7 +575,7 @@ int DdpgPass::forward() {
     cb[1].dot_mode = 1; cb[1].dot_w = thQ + offQ.Wout; cb[1].dot_out = w.part[4];
   }
   if (fuse_pi) {
-    if (forward_chains(cfg, ch, 3, B, st, 0, pre, 2)) return -2;
+    if (forward_chains(cfg, ch, 3, B, st, 0, pre, 2, xd)) return -2;
     FwdPiArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.max_u = cfg->max_u; fa.B = B;
@@ -565,12 +590,17 @@ int DdpgPass::forward() {
       p.h0_out = (i == 0) ? nullptr : w.act[4][0];          // relu mask of the actor-loss backward pass
       p.C = w.act[i == 0 ? 3 : 4][1];
     }
-    dim3 grid(H / 64, B / 16, 2);
+    dim3 grid(H / 64, B / 16, 2 * xd.nex);
+    const Ex ex = make_ex(xd, 2);
     { ProfScope ps__(CK_FWD_PI, st);
-      if (use_part) hipLaunchKernelGGL(fwd_pi_kernel<true>, grid, dim3(256), 0, st, fa);
-      else hipLaunchKernelGGL(fwd_pi_kernel<false>, grid, dim3(256), 0, st, fa); }
+      if (use_part) {
+        if (xd.nex > 1) hipLaunchKernelGGL((fwd_pi_kernel<true, true>), grid, dim3(256), 0, st, fa, ex);
+        else hipLaunchKernelGGL((fwd_pi_kernel<true, false>), grid, dim3(256), 0, st, fa, ex);
+      } else {
+        hipLaunchKernelGGL((fwd_pi_kernel<false, false>), grid, dim3(256), 0, st, fa, ex);
+      } }
     CURIOUS_LAUNCH_CHECK("fwd_pi_kernel");
-    if (forward_chains(cfg, cb, 2, B, st, 2)) return -2;
+    if (forward_chains(cfg, cb, 2, B, st, 2, nullptr, 0, xd)) return -2;
   } else {
     if (forward_chains(cfg, ch, 3, B, st)) return -2;
     // ---- actor output layers: pi_target, pi
@@ -592,6 +622,7 @@ int DdpgPass::critic_backward() {
   dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
   fuse_crit = dx_hot && nl >= 2 && H == 256;
   CURIOUS_CHECK(!use_part || fuse_crit, "curious_ddpg_grads: inconsistent lean-path conditions");
+  CURIOUS_CHECK(xd.nex == 1 || (fuse_crit && use_part), "batched experts need the lean route");
   if (fuse_crit) {
     DxCritArgs a;
     memset(&a, 0, sizeof(a));
@@ -609,10 +640,15 @@ int DdpgPass::critic_backward() {
     a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
     a.max_u = cfg->max_u;
     a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
-    dim3 grid(H / 64, B / 16, 2);
+    dim3 grid(H / 64, B / 16, 2 * xd.nex);
+    const Ex ex = make_ex(xd, 2);
     { ProfScope ps__(CK_CRITIC_HEAD, st);
-      if (use_part) hipLaunchKernelGGL(dx_crit_kernel<true>, grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(dx_crit_kernel<false>, grid, dim3(256), 0, st, a); }
+      if (use_part) {
+        if (xd.nex > 1) hipLaunchKernelGGL((dx_crit_kernel<true, true>), grid, dim3(256), 0, st, a, ex);
+        else hipLaunchKernelGGL((dx_crit_kernel<true, false>), grid, dim3(256), 0, st, a, ex);
+      } else {
+        hipLaunchKernelGGL((dx_crit_kernel<false, false>), grid, dim3(256), 0, st, a, ex);
+      } }
     CURIOUS_LAUNCH_CHECK("dx_crit_kernel");
   } else
   {
@@ -645,10 +681,16 @@ int DdpgPass::critic_backward() {
           p.dot_mode = 3; p.dot_w = thQ + offQ.W0 + urow * H; p.dot_out = w.part[5]; p.dot_ld = H;
         }
       }
-      dim3 grid(H / 64, B / 16, 2);
+      dim3 grid(H / 64, B / 16, 2 * xd.nex);
+      const Ex ex = make_ex(xd, 2);
       { ProfScope ps__(CK_DX, st);
-        if (use_part && l == 1) hipLaunchKernelGGL(dx_hot_kernel<true>, grid, dim3(256), 0, st, ha);
-        else hipLaunchKernelGGL(dx_hot_kernel<false>, grid, dim3(256), 0, st, ha); }
+        if (use_part && l == 1) {
+          if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<true, true>), grid, dim3(256), 0, st, ha, ex);
+          else hipLaunchKernelGGL((dx_hot_kernel<true, false>), grid, dim3(256), 0, st, ha, ex);
+        } else {
+          if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<false, true>), grid, dim3(256), 0, st, ha, ex);
+          else hipLaunchKernelGGL((dx_hot_kernel<false, false>), grid, dim3(256), 0, st, ha, ex);
+        } }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel");
       continue;
     }
@@ -685,10 +727,15 @@ int DdpgPass::actor_backward() {
     a.a2 = w.act[2][l]; a.WoutPi = thPi + offPi.Wout; a.hprev = w.act[2][l - 1]; a.W = thPi + offPi.W[l];
     a.dz = w.dz; a.da2 = w.dact[2][l]; a.dX = w.dact[2][l - 1];
     a.B = B; a.max_u = cfg->max_u; a.l2c = l2c;
-    dim3 grid(H / 64, B / 16, 1);
+    dim3 grid(H / 64, B / 16, xd.nex);
+    const Ex ex = make_ex(xd, 1);
     { ProfScope ps__(CK_ACTOR_DZ, st);
-      if (use_part) hipLaunchKernelGGL(dx_actor_kernel<true>, grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(dx_actor_kernel<false>, grid, dim3(256), 0, st, a); }
+      if (use_part) {
+        if (xd.nex > 1) hipLaunchKernelGGL((dx_actor_kernel<true, true>), grid, dim3(256), 0, st, a, ex);
+        else hipLaunchKernelGGL((dx_actor_kernel<true, false>), grid, dim3(256), 0, st, a, ex);
+      } else {
+        hipLaunchKernelGGL((dx_actor_kernel<false, false>), grid, dim3(256), 0, st, a, ex);
+      } }
     CURIOUS_LAUNCH_CHECK("dx_actor_kernel");
   } else {
     ActorDzArgs a;
@@ -707,8 +754,11 @@ int DdpgPass::actor_backward() {
       GemmHot& p = ha.p[0];
       p.A = w.dact[2][l]; p.lda = H; p.B = thPi + offPi.W[l]; p.ldb = H; p.aux = w.act[2][l - 1];
       p.C = w.dact[2][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
-      dim3 grid(H / 64, B / 16, 1);
-      { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_hot_kernel<false>, grid, dim3(256), 0, st, ha); }
+      dim3 grid(H / 64, B / 16, xd.nex);
+      const Ex ex = make_ex(xd, 1);
+      { ProfScope ps__(CK_DX, st);
+        if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<false, true>), grid, dim3(256), 0, st, ha, ex);
+        else hipLaunchKernelGGL((dx_hot_kernel<false, false>), grid, dim3(256), 0, st, ha, ex); }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel(actor)");
       continue;
     }
@@ -778,6 +828,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   int tAll = 0, stAll = 0;
   bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
   if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
+  CURIOUS_CHECK(xd.nex == 1 || (lean_dw && tail), "batched experts need the lean weight-gradient launch");
   if (lean_dw) {
     smAll.fin = fin;
     dwAll.n_hot = tAll;
@@ -787,11 +838,12 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       { ProfScope ps__(CK_DW_ADAM_HER, st);
-        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + nsmall + 1), dim3(256), 0, st, dwAll, tail->adam,
-                           tail->h, n_her); }
+        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll,
+                           tail->adam, tail->h, n_her, xd.stride, seed_stride); }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
       return 0;
     }
+    CURIOUS_CHECK(xd.nex == 1, "batched experts need the fused update tail");
     { ProfScope ps__(CK_DW, st);
       hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1), dim3(256), 0, st, dwAll); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
@@ -857,8 +909,10 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
 static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                            const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
                            const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                           int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail) {
+                           int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail,
+                           const ExDim& xd = ExDim(), uint64_t seed_stride = 0) {
   DdpgPass p;
+  p.xd = xd; p.seed_stride = seed_stride;
   p.cfg = cfg; p.theta_main = theta_main; p.theta_target = theta_target; p.batch = batch; p.BL = BL; p.B = B;
   p.o_stats = o_stats; p.g_stats = g_stats; p.workspace = workspace; p.grad = grad; p.out_losses = out_losses;
   p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
@@ -878,12 +932,12 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
                          out_Q_pi, step_ctr, stream, nullptr);
 }
 
-extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
-                                   const float* batch, const curious_batch_layout_t* BL, int32_t B,
-                                   const float* o_stats, const float* g_stats, float* workspace, float* grad,
-                                   float* out_losses, float* out_Q_pi, int64_t* step_ctr,
-                                   const curious_adam_state_t* adam, const curious_next_batch_t* next,
-                                   curious_stream_t stream) {
+static int ddpg_update_impl(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
+                            const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                            const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                            float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                            const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                            curious_stream_t stream, const ExDim& xd, uint64_t seed_stride) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(adam && adam->m && adam->v, "curious_ddpg_update: NULL optimiser state");
   CURIOUS_CHECK(!adam->alpha_tab || (step_ctr && adam->tab_len > 0), "curious_ddpg_update: step-size table needs step_ctr");
@@ -904,5 +958,33 @@ extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_ma
     t.her = true;
   }
   return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
-                         out_Q_pi, step_ctr, stream, &t);
+                         out_Q_pi, step_ctr, stream, &t, xd, seed_stride);
+}
+
+extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
+                                   const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                                   const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                                   float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                                   const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                                   curious_stream_t stream) {
+  return ddpg_update_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
+                          out_Q_pi, step_ctr, adam, next, stream, ExDim(), 0);
+}
+
+extern "C" int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
+                                           uint64_t seed_stride, float* theta_main, const float* theta_target,
+                                           const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                                           float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                                           int64_t* step_ctr, const curious_adam_state_t* adam,
+                                           const curious_next_batch_t* next, curious_stream_t stream) {
+  CURIOUS_CHECK(n_experts >= 1 && n_experts <= 64, "curious_ddpg_update_experts: n_experts must be in 1..64");
+  CURIOUS_CHECK(n_experts == 1 || (expert_stride > 0 && expert_stride % 64 == 0),
+                "curious_ddpg_update_experts: expert_stride must be a positive multiple of 64 floats");
+  CURIOUS_CHECK(cfg && !cfg->normalize_obs, "curious_ddpg_update_experts: input normalisation is not supported");
+  CURIOUS_CHECK(step_ctr && adam && adam->alpha_tab && next,
+                "curious_ddpg_update_experts: device step counter, step-size table and next batch are required");
+  ExDim xd;
+  xd.nex = n_experts; xd.stride = expert_stride;
+  return ddpg_update_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
+                          out_Q_pi, step_ctr, adam, next, stream, xd, seed_stride);
 }

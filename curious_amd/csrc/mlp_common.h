@@ -105,6 +105,32 @@ __device__ inline float seg_load1(const Seg& s, int row, int col, bool ok) {
   return seg_xform(s, s.x[(int64_t)row * s.ld + col], row, col);
 }
 
+// ------------------------------------------------------------------ batched experts (structure='task_experts')
+// N agents with identical shapes go through ONE launch sequence (curious_ddpg_update_experts): every piece of
+// per-expert state -- parameters, target, gradient, Adam moments, step counter and step-size ring, workspace, staged
+// batches, sampling tables, loss outputs -- sits at the same offset of a per-expert slab, the slabs are `stride`
+// floats apart, so expert e's pointer is the expert-0 pointer of the descriptor + e * stride.  Only the replay
+// storage is shared.  Kernels are instantiated twice: EX = false is the single-agent path (no extra scalar work, the
+// descriptor index is blockIdx.z itself); EX = true decodes blockIdx.z = e * nprob + problem.
+struct Ex {
+  int64_t stride;          // floats between the slabs of consecutive experts
+  int32_t nprob;           // problems per expert in this launch (grid.z = n_experts * nprob)
+  uint32_t zmul;           // ceil(65536 / nprob): e = (z * zmul) >> 16 (exact for z < 8192)
+};
+template <bool EX>
+__device__ __forceinline__ int ex_decode(const Ex& ex, int z, int64_t& eo) {
+  if (!EX) { eo = 0; return z; }
+  const int e = (int)(((uint32_t)z * ex.zmul) >> 16);
+  eo = (int64_t)e * ex.stride;
+  return z - e * ex.nprob;
+}
+__device__ __forceinline__ int64_t* ex_i64(int64_t* p, int64_t eo) {      // an int64 living in the float slab
+  return reinterpret_cast<int64_t*>(reinterpret_cast<float*>(p) + eo);
+}
+__device__ __forceinline__ const int64_t* ex_i64(const int64_t* p, int64_t eo) {
+  return reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(p) + eo);
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // Scheduling fence: everything above (the loads of a wave's whole K share) is issued before anything below (the

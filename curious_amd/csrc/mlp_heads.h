@@ -104,11 +104,12 @@ struct FwdPiProb {
 };
 struct FwdPiArgs { FwdPiProb p[2]; float max_u; int32_t B; };
 
-template <bool PART>
-__global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
+template <bool PART, bool EX>
+__global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float s_pi[16 * 4];
-  const FwdPiProb& P = args.p[blockIdx.z];
+  int64_t eo;
+  const FwdPiProb& P = args.p[ex_decode<EX>(ex, blockIdx.z, eo)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
   const int H = 256;
@@ -119,24 +120,24 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
   if (PART) {
     // thread t < 64 finishes pi[m0 + t/4][t%4] from the 4 column-tile partials
 #pragma unroll
-    for (int t = 0; t < 4; ++t) pp[t] = P.part[((int64_t)t * args.B + m0) * 4 + (tid & 63)];
+    for (int t = 0; t < 4; ++t) pp[t] = P.part[eo + ((int64_t)t * args.B + m0) * 4 + (tid & 63)];
   } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pr_h[r] = ldv(P.a_last + (int64_t)(pm + r) * H + 4 * lane);
+    for (int r = 0; r < 4; ++r) pr_h[r] = ldv(P.a_last + eo + (int64_t)(pm + r) * H + 4 * lane);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wp[e] = ldv(P.WoutPi + (int64_t)(4 * lane + e) * 4);
+    for (int e = 0; e < 4; ++e) wp[e] = ldv(P.WoutPi + eo + (int64_t)(4 * lane + e) * 4);
   }
-  const float bo = P.boutPi[lane & 3];
-  const float* xr = P.zp + (int64_t)(m0 + j) * H;
-  const float* wc = P.W1 + n0 + 4 * j;
-  const f32x4 bias = ldv(P.b1 + n0 + 4 * (tid & 15));
+  const float bo = P.boutPi[eo + (lane & 3)];
+  const float* xr = P.zp + eo + (int64_t)(m0 + j) * H;
+  const float* wc = P.W1 + eo + n0 + 4 * j;
+  const f32x4 bias = ldv(P.b1 + eo + n0 + 4 * (tid & 15));
   f32x4 z[4], wu[4][4], b[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int kq = (wave + 4 * u) * 16 + 4 * q;
     z[u] = ldv(xr + kq);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) wu[u][d] = ldv(P.Wu + (int64_t)d * H + kq);
+    for (int d = 0; d < 4; ++d) wu[u][d] = ldv(P.Wu + eo + (int64_t)d * H + kq);
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[u][s] = ldv(wc + (int64_t)(kq + s) * H);
   }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
     if (tid < 64) {
       const float pv = args.max_u * tanhf(((pp[0] + pp[1]) + (pp[2] + pp[3])) + bo);   // actor_critic.py:89
       s_pi[tid] = pv;
-      if (blockIdx.x == 0 && P.pi_out) P.pi_out[(int64_t)m0 * 4 + tid] = pv;
+      if (blockIdx.x == 0 && P.pi_out) P.pi_out[eo + (int64_t)m0 * 4 + tid] = pv;
     }
   } else {
     // lane 4r+d of wave w finishes pi[pm + r][d]
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
     if (lane < 16) {
       const float pv = args.max_u * tanhf(mine + bo);           // actor_critic.py:89
       s_pi[16 * wave + lane] = pv;
-      if (blockIdx.x == 0 && P.pi_out) P.pi_out[(int64_t)pm * 4 + lane] = pv;
+      if (blockIdx.x == 0 && P.pi_out) P.pi_out[eo + (int64_t)pm * 4 + lane] = pv;
     }
   }
   __syncthreads();
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
     }
     if (blockIdx.x == 0 && P.h0_out) {
       const int kq = (wave + 4 * u) * 16 + 4 * q;
-      *reinterpret_cast<f32x4*>(P.h0_out + (int64_t)(m0 + j) * H + kq) = av;
+      *reinterpret_cast<f32x4*>(P.h0_out + eo + (int64_t)(m0 + j) * H + kq) = av;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void fwd_pi_kernel(FwdPiArgs args) {
   v += bias;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
+  *reinterpret_cast<f32x4*>(P.C + eo + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
 }
 
 
@@ -298,24 +299,25 @@ __device__ inline float dot_row(const float* a, const float* b, int H, int lane)
 
 // H == 256 only (one 16-byte fragment per lane covers a row): every global load of the kernel -- the 4 rows of the
 // prologue, the output-layer weights and the main loop's 24 fragments -- is issued in one batch before any use.
-template <bool PART>
-__global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
+template <bool PART, bool EX>
+__global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ float s_dq[16];
-  const int ch = blockIdx.z;
+  int64_t eo;
+  const int ch = ex_decode<EX>(ex, blockIdx.z, eo);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
   const int H = 256;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0 && tid == 0 && a.step_ctr) *a.step_ctr += 1;
-  const float* hrow = a.hl[ch] + (int64_t)(m0 + j) * H;
-  const float* wr = a.W + (int64_t)(k0 + 4 * j) * H;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0 && tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+  const float* hrow = a.hl[ch] + eo + (int64_t)(m0 + j) * H;
+  const float* wr = a.W + eo + (int64_t)(k0 + 4 * j) * H;
   const float invB = 1.0f / (float)a.B;
   const bool need_dots = (ch == 0) || (blockIdx.x == 0);
   // ---- all loads
   f32x4 pr_h[4], pr_e[4];                                   // prologue rows m0 + 4*wave + r, this lane's 4 columns
   const int pm = m0 + 4 * wave;
   f32x4 wq = zero4(), wt = zero4();
-  const float bq = a.boutQ[0], bt = a.boutQt[0];
+  const float bq = a.boutQ[eo], bt = a.boutQt[eo];
   float rew[4], l2v[4];
   float pq[4] = {0.f, 0.f, 0.f, 0.f}, pt[4] = {0.f, 0.f, 0.f, 0.f}, rew_j = 0.f;
   f32x4 pi_j = zero4();
@@ -324,38 +326,39 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
     const float* p1 = (ch == 0) ? a.partQ : a.partQpi;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      pq[t] = p1[(int64_t)t * a.B + m0 + j];
-      pt[t] = a.partQt[(int64_t)t * a.B + m0 + j];
+      pq[t] = p1[eo + (int64_t)t * a.B + m0 + j];
+      pt[t] = a.partQt[eo + (int64_t)t * a.B + m0 + j];
     }
-    rew_j = a.r[(int64_t)(m0 + j) * a.ldr];
-    pi_j = ldv(a.pi + (int64_t)(m0 + j) * 4);
+    rew_j = a.r[eo + (int64_t)(m0 + j) * a.ldr];
+    pi_j = ldv(a.pi + eo + (int64_t)(m0 + j) * 4);
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pr_h[r] = ldv(a.hl[ch] + (int64_t)(pm + r) * H + 4 * lane);
-      pr_e[r] = ldv(a.e2 + (int64_t)(pm + r) * H + 4 * lane);
+      pr_h[r] = ldv(a.hl[ch] + eo + (int64_t)(pm + r) * H + 4 * lane);
+      pr_e[r] = ldv(a.e2 + eo + (int64_t)(pm + r) * H + 4 * lane);
     }
-    wq = ldv(a.WoutQ + 4 * lane); wt = ldv(a.WoutQt + 4 * lane);
+    wq = ldv(a.WoutQ + eo + 4 * lane); wt = ldv(a.WoutQt + eo + 4 * lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      rew[r] = a.r[(int64_t)(pm + r) * a.ldr];
+      rew[r] = a.r[eo + (int64_t)(pm + r) * a.ldr];
       // sum_j (pi_j / max_u)^2 of row pm + r: lanes 0..U-1 hold one term each (ddpg.py:441)
-      const float pv = (lane < a.U) ? a.pi[(int64_t)(pm + r) * a.ldpi + lane] : 0.f;
+      const float pv = (lane < a.U) ? a.pi[eo + (int64_t)(pm + r) * a.ldpi + lane] : 0.f;
       l2v[r] = (ch == 1) ? pv : 0.f;
     }
   }
-  const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
+  const int64_t o = eo + (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
   const f32x4 hm = ldv(a.hprev[ch] + o);
   f32x4 hv[4], wo[4], b[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int nq = (wave + 4 * u) * 16 + 4 * q;
     hv[u] = ldv(hrow + nq);
-    wo[u] = ldv(a.WoutQ + nq);
+    wo[u] = ldv(a.WoutQ + eo + nq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
   }
   LOADS_FIRST();
+  float* const rows_ = a.rows + eo; float* const dQ_ = a.dQ + eo; float* const Qpi_ = a.out_Qpi + eo;
   float dq;
   if (PART) {
     const bool writer = blockIdx.x == 0 && wave == 0 && q == 0;        // lanes 0..15 <-> rows m0 + j
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
       const float diff = target - Q;
       dq = -2.0f * invB * diff;
       if (writer) {
-        a.rows[m] = diff * diff;                               // ddpg.py:439
-        a.dQ[m] = dq;
+        rows_[m] = diff * diff;                               // ddpg.py:439
+        dQ_[m] = dq;
       }
     } else {
       dq = -invB;                                              // d(-mean(Q_pi)) / dQ_pi
@@ -380,9 +383,9 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
           const float tt = pi_j[d] / a.max_u;
           l2 += tt * tt;                                       // ddpg.py:441
         }
-        a.rows[a.B + m] = Qpi;                                 // ddpg.py:440
-        a.rows[2 * a.B + m] = l2;
-        a.out_Qpi[m] = Qpi;
+        rows_[a.B + m] = Qpi;                                 // ddpg.py:440
+        rows_[2 * a.B + m] = l2;
+        Qpi_[m] = Qpi;
       }
     }
   } else {
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
         if (lane == 0) {
           s_dq[4 * wave + r] = dq;
           if (blockIdx.x == 0) {
-            a.rows[m] = diff * diff;                         // ddpg.py:439
-            a.dQ[m] = dq;
+            rows_[m] = diff * diff;                         // ddpg.py:439
+            dQ_[m] = dq;
           }
         }
       } else {
@@ -412,9 +415,9 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
         const float tt = l2v[r] / a.max_u;
         const float l2 = wave_sum(tt * tt);
         if (lane == 0) {
-          a.rows[a.B + m] = Qpi;                             // ddpg.py:440
-          a.rows[2 * a.B + m] = l2;
-          a.out_Qpi[m] = Qpi;
+          rows_[a.B + m] = Qpi;                             // ddpg.py:440
+          rows_[2 * a.B + m] = l2;
+          Qpi_[m] = Qpi;
         }
       }
     }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a) {
     for (int s = 0; s < 4; ++s) av[s] = (hv[u][s] > 0.f) ? dq * wo[u][s] : 0.f;
     if (blockIdx.x == 0) {
       const int nq = (wave + 4 * u) * 16 + 4 * q;
-      *reinterpret_cast<f32x4*>(a.dY[ch] + (int64_t)(m0 + j) * H + nq) = av;
+      *reinterpret_cast<f32x4*>(a.dY[ch] + eo + (int64_t)(m0 + j) * H + nq) = av;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -584,10 +587,12 @@ struct DxActorArgs {
   float max_u, l2c;
 };
 
-template <bool PART>
-__global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
+template <bool PART, bool EX>
+__global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float s_dz[16 * 4];
+  int64_t eo;
+  (void)ex_decode<EX>(ex, blockIdx.z, eo);                   // one problem per expert
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
   const int H = 256;
@@ -599,26 +604,26 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
   if (PART) {
     // thread t < 64 finishes dz[m0 + t/4][t%4] from the 4 column-tile partials
 #pragma unroll
-    for (int t = 0; t < 4; ++t) pp[t] = a.part[((int64_t)t * a.B + m0) * 4 + (tid & 63)];
-    pim = a.pi[(int64_t)m0 * 4 + (tid & 63)];
+    for (int t = 0; t < 4; ++t) pp[t] = a.part[eo + ((int64_t)t * a.B + m0) * 4 + (tid & 63)];
+    pim = a.pi[eo + (int64_t)m0 * 4 + (tid & 63)];
   } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) g4[r] = ldv(a.dd0 + (int64_t)(pm + r) * H + 4 * lane);
-    pim = a.pi[(int64_t)pm * 4 + (lane & 15)];                // lane 4r+d: pi[pm + r][d]
+    for (int r = 0; r < 4; ++r) g4[r] = ldv(a.dd0 + eo + (int64_t)(pm + r) * H + 4 * lane);
+    pim = a.pi[eo + (int64_t)pm * 4 + (lane & 15)];                // lane 4r+d: pi[pm + r][d]
 #pragma unroll
-    for (int d = 0; d < 4; ++d) wu[d] = ldv(a.Wu + (int64_t)d * H + 4 * lane);
+    for (int d = 0; d < 4; ++d) wu[d] = ldv(a.Wu + eo + (int64_t)d * H + 4 * lane);
   }
-  const int64_t o = (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
+  const int64_t o = eo + (int64_t)(m0 + (tid >> 4)) * H + k0 + 4 * (tid & 15);
   const f32x4 hm = ldv(a.hprev + o);
-  const float* hrow = a.a2 + (int64_t)(m0 + j) * H;
-  const float* wr = a.W + (int64_t)(k0 + 4 * j) * H;
+  const float* hrow = a.a2 + eo + (int64_t)(m0 + j) * H;
+  const float* wr = a.W + eo + (int64_t)(k0 + 4 * j) * H;
   f32x4 hv[4], wo[4][4], b[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int nq = (wave + 4 * u) * 16 + 4 * q;
     hv[u] = ldv(hrow + nq);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wo[u][s] = ldv(a.WoutPi + (int64_t)(nq + s) * 4);
+    for (int s = 0; s < 4; ++s) wo[u][s] = ldv(a.WoutPi + eo + (int64_t)(nq + s) * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[u][e] = ldv(wr + (int64_t)e * H + nq);
   }
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
       const float dpi = v / a.max_u + a.l2c * pim;              // ddpg.py:440-441
       const float dz = dpi * a.max_u * (1.0f - th * th);        // through pi = max_u * tanh(z)
       s_dz[tid] = dz;
-      if (blockIdx.x == 0) a.dz[(int64_t)m0 * 4 + tid] = dz;
+      if (blockIdx.x == 0) a.dz[eo + (int64_t)m0 * 4 + tid] = dz;
     }
   } else {
     // lane 4r+d of wave w finishes dz[pm + r][d]
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
       const float dpi = v / a.max_u + a.l2c * pim;              // ddpg.py:440-441
       const float dz = dpi * a.max_u * (1.0f - th * th);        // through pi = max_u * tanh(z)
       s_dz[16 * wave + lane] = dz;
-      if (blockIdx.x == 0) a.dz[(int64_t)pm * 4 + lane] = dz;
+      if (blockIdx.x == 0) a.dz[eo + (int64_t)pm * 4 + lane] = dz;
     }
   }
   __syncthreads();
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void dx_actor_kernel(DxActorArgs a) {
     }
     if (blockIdx.x == 0) {
       const int nq = (wave + 4 * u) * 16 + 4 * q;
-      *reinterpret_cast<f32x4*>(a.da2 + (int64_t)(m0 + j) * H + nq) = av;
+      *reinterpret_cast<f32x4*>(a.da2 + eo + (int64_t)(m0 + j) * H + nq) = av;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)

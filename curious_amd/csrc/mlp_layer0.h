@@ -45,7 +45,7 @@ __device__ inline f32x4 seg_prep(f32x4 a, float cl, float dv, bool any_div, bool
 
 // NC = number of 64-wide k chunks (total K <= 64 * NC): wave w owns the 16-wide group w of every chunk
 template <int NC>
-__device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
+__device__ inline void fwd_l0_body(const L0Prob& P, float* red, const int64_t eo) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
   const int row = min(m0 + j, P.M - 1);
@@ -56,12 +56,12 @@ __device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
   for (int c = 0; c < NC; ++c) {
     const SegPick sp = seg_pick(P, 64 * c + 16 * wave + 4 * q);
     dv[c] = sp.dv; cl[c] = sp.cl; ok[c] = sp.ok;
-    a[c] = ldv(sp.x + sp.kl + (int64_t)row * sp.ld);
-    const float* wc = sp.W + (int64_t)sp.kl * P.N + n0 + 4 * j;
+    a[c] = ldv(sp.x + eo + sp.kl + (int64_t)row * sp.ld);
+    const float* wc = sp.W + eo + (int64_t)sp.kl * P.N + n0 + 4 * j;
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[c][s] = ldv(wc + (int64_t)s * P.N);
   }
-  const f32x4 bias = ldv(P.bias + n0 + 4 * (tid & 15));
+  const f32x4 bias = ldv(P.bias + eo + n0 + 4 * (tid & 15));
   LOADS_FIRST();
   const bool any_div = seg_any_div(P);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -81,14 +81,14 @@ __device__ inline void fwd_l0_body(const L0Prob& P, float* red) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   }
-  *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
+  *reinterpret_cast<f32x4*>(P.Y + eo + (int64_t)(m0 + orow) * P.ldy + n0 + 4 * c4) = v;
 }
 
 
 template <int NC>
 __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  fwd_l0_body<NC>(args.p[blockIdx.z], red);
+  fwd_l0_body<NC>(args.p[blockIdx.z], red, 0);
 }
 
 // ------------------------------------------------------------------ layers 0 + 1 in one launch
@@ -103,7 +103,7 @@ struct L01Args { L01Prob p[3]; L0Prob pre[2]; int32_t n01; };
 #define H0_LD 260      // LDS row stride of the h0 tile: 260 % 64 = 4 -> the 16 rows of a b128 read hit distinct banks
 
 template <int NC>
-__device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
+__device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s, const int64_t eo) {
   const L0Prob& P = Q.l0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
@@ -117,20 +117,20 @@ __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
   for (int i = 0; i < NG; ++i) {
     const SegPick sp = seg_pick(P, 16 * i + 4 * q);  // this lane's virtual input columns of k-group i
     dv[i] = sp.dv; cl[i] = sp.cl; okv[i] = sp.ok;
-    xa[i] = ldv(sp.x + sp.kl + (int64_t)(m0 + j) * sp.ld);
-    const float* wc0 = sp.W + (int64_t)sp.kl * H + 64 * wave + 4 * j;
+    xa[i] = ldv(sp.x + eo + sp.kl + (int64_t)(m0 + j) * sp.ld);
+    const float* wc0 = sp.W + eo + (int64_t)sp.kl * H + 64 * wave + 4 * j;
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) w0[i][s2] = ldv(wc0 + (int64_t)s2 * H);
   }
-  const f32x4 bias0 = ldv(P.bias + 64 * wave + 4 * j);
-  const float* wc1 = Q.W1 + n0 + 4 * j;
+  const f32x4 bias0 = ldv(P.bias + eo + 64 * wave + 4 * j);
+  const float* wc1 = Q.W1 + eo + n0 + 4 * j;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int kq = (wave + 4 * u) * 16 + 4 * q;
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) w1[u][s2] = ldv(wc1 + (int64_t)(kq + s2) * H);
   }
-  const f32x4 bias1 = ldv(Q.b1 + n0 + 4 * (tid & 15));
+  const f32x4 bias1 = ldv(Q.b1 + eo + n0 + 4 * (tid & 15));
   LOADS_FIRST();
   // ---- layer 0: h0[rows 4q..4q+3][cols 64*wave + 4j + e]
   const bool any_div = seg_any_div(P);
@@ -151,7 +151,7 @@ __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
     for (int e = 0; e < 4; ++e) hv[e] = fmaxf(hv[e], 0.f);
     *reinterpret_cast<f32x4*>(h0s + (4 * q + r) * H0_LD + 64 * wave + 4 * j) = hv;
     if (blockIdx.x == 0 && P.Y)
-      *reinterpret_cast<f32x4*>(P.Y + (int64_t)(m0 + 4 * q + r) * H + 64 * wave + 4 * j) = hv;
+      *reinterpret_cast<f32x4*>(P.Y + eo + (int64_t)(m0 + 4 * q + r) * H + 64 * wave + 4 * j) = hv;
   }
   __syncthreads();
   // ---- layer 1 out of LDS
@@ -171,13 +171,15 @@ __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s) {
   v += bias1;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  *reinterpret_cast<f32x4*>(Q.C + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
+  *reinterpret_cast<f32x4*>(Q.C + eo + (int64_t)(m0 + orow) * H + n0 + 4 * c4) = v;
 }
 
-template <int NC>
-__global__ __launch_bounds__(256) void fwd_l01_kernel(L01Args args) {
+template <int NC, bool EX>
+__global__ __launch_bounds__(256) void fwd_l01_kernel(L01Args args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float h0s[16 * H0_LD];
-  if ((int)blockIdx.z < args.n01) fwd_l01_body<NC>(args.p[blockIdx.z], red, h0s);
-  else fwd_l0_body<NC>(args.pre[blockIdx.z - args.n01], red);
+  int64_t eo;
+  const int pz = ex_decode<EX>(ex, blockIdx.z, eo);
+  if (pz < args.n01) fwd_l01_body<NC>(args.p[pz], red, h0s, eo);
+  else fwd_l0_body<NC>(args.pre[pz - args.n01], red, eo);
 }

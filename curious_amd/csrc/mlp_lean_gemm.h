@@ -14,13 +14,15 @@ struct AdamFuse {
   float a_Q, a_pi, b1, omb1, b2, omb2, eps;
 };
 
-__device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi) {
+// eo: slab offset of the expert this block works for (0 for a single agent); i / pidx / bidx below are indices into
+// the parameter vector, the moments and the parameters are addressed at index + eo
+__device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int64_t eo) {
   aQ = A.a_Q; aPi = A.a_pi;
   if (A.alpha_tab) {
-    int64_t idx = ((*A.step_ctr) - 1 - A.tab_base) % A.tab_len;
+    int64_t idx = ((*ex_i64(A.step_ctr, eo)) - 1 - A.tab_base) % A.tab_len;
     if (idx < 0) idx += A.tab_len;
-    aQ = A.alpha_tab[2 * idx];
-    aPi = A.alpha_tab[2 * idx + 1];
+    aQ = A.alpha_tab[eo + 2 * idx];
+    aPi = A.alpha_tab[eo + 2 * idx + 1];
   }
 }
 
@@ -76,7 +78,7 @@ __device__ inline void hot_store(float* red, const f32x4 acc[4], int wave, int q
 }
 
 struct DotW { f32x4 w[4]; };
-__device__ inline DotW dot_prefetch(const GemmHot& P, int c) {
+__device__ inline DotW dot_prefetch(const GemmHot& P, int c, int64_t eo) {
   // branch-free (4 unconditional loads at selected addresses): a branch on dot_mode here would make every load that
   // follows in program order wait for the scalar load of dot_mode.  dot_w is a valid address for every problem of a
   // DOT launch (the host points it at the weight matrix when dot_mode == 0).
@@ -85,18 +87,19 @@ __device__ inline DotW dot_prefetch(const GemmHot& P, int c) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t off = (m == 2) ? (int64_t)(c + e) * 4 : (m == 3) ? (int64_t)e * P.dot_ld + c : (m == 1) ? c : 0;
-    d.w[e] = ldv(P.dot_w + off);
+    d.w[e] = ldv(P.dot_w + eo + off);
   }
   return d;
 }
 // v: this thread's 4 consecutive output columns of row `row`; the 16 threads of a row are one DPP row
-__device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4& v, int row, int tile, int c4) {
+__device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4& v, int row, int tile, int c4,
+                                    int64_t eo) {
   if (P.dot_mode == 0) return;
   f32x4 pd = zero4();
   if (P.dot_mode == 1) {
     pd[0] = v[0] * d.w[0][0] + v[1] * d.w[0][1] + v[2] * d.w[0][2] + v[3] * d.w[0][3];
     pd[0] = row16_sum(pd[0]);
-    if (c4 == 0) P.dot_out[(int64_t)tile * P.M + row] = pd[0];
+    if (c4 == 0) P.dot_out[eo + (int64_t)tile * P.M + row] = pd[0];
     return;
   }
 #pragma unroll
@@ -106,21 +109,22 @@ __device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4
     else t = v[0] * d.w[k][0] + v[1] * d.w[k][1] + v[2] * d.w[k][2] + v[3] * d.w[k][3];
     pd[k] = row16_sum(t);
   }
-  if (c4 == 0) *reinterpret_cast<f32x4*>(P.dot_out + ((int64_t)tile * P.M + row) * 4) = pd;
+  if (c4 == 0) *reinterpret_cast<f32x4*>(P.dot_out + eo + ((int64_t)tile * P.M + row) * 4) = pd;
 }
 
 // C[M,N] = relu(A[M,K] . B[K,N] + bias)        grid (N/64, M/16, nprob)
-template <bool DOT>
-__global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
+template <bool DOT, bool EX>
+__global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  const GemmHot& P = args.p[blockIdx.z];
+  int64_t eo;
+  const GemmHot& P = args.p[ex_decode<EX>(ex, blockIdx.z, eo)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
-  const float* xr = P.A + (int64_t)(m0 + j) * P.lda;
-  const float* wc = P.B + n0 + 4 * j;
-  const f32x4 bias = ldv(P.aux + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
+  const float* xr = P.A + eo + (int64_t)(m0 + j) * P.lda;
+  const float* wc = P.B + eo + n0 + 4 * j;
+  const f32x4 bias = ldv(P.aux + eo + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
   DotW dw;
-  if (DOT) dw = dot_prefetch(P, n0 + 4 * (tid & 15));
+  if (DOT) dw = dot_prefetch(P, n0 + 4 * (tid & 15), eo);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int kb = 0; kb < P.K; kb += 256) {
     f32x4 a[4], b[4][4];
@@ -144,23 +148,24 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args) {
   v += bias;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  *reinterpret_cast<f32x4*>(P.C + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
-  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
+  *reinterpret_cast<f32x4*>(P.C + eo + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4, eo);
 }
 
 // C[M,K'] = (A[M,N] . B[K',N]^T) * relu'(aux[M,K'])    (K' = P.N output columns, reduction over P.K)   grid (K'/64, M/16, nprob)
-template <bool DOT>
-__global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
+template <bool DOT, bool EX>
+__global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  const GemmHot& P = args.p[blockIdx.z];
+  int64_t eo;
+  const GemmHot& P = args.p[ex_decode<EX>(ex, blockIdx.z, eo)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
-  const float* dyr = P.A + (int64_t)(m0 + j) * P.lda;
-  const float* wr = P.B + (int64_t)(k0 + 4 * j) * P.ldb;
-  const int64_t o = (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
+  const float* dyr = P.A + eo + (int64_t)(m0 + j) * P.lda;
+  const float* wr = P.B + eo + (int64_t)(k0 + 4 * j) * P.ldb;
+  const int64_t o = eo + (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
   const f32x4 h = ldv(P.aux + o);                           // relu mask source, issued with the first batch
   DotW dw;
-  if (DOT) dw = dot_prefetch(P, k0 + 4 * (tid & 15));
+  if (DOT) dw = dot_prefetch(P, k0 + 4 * (tid & 15), eo);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   for (int nb = 0; nb < P.K; nb += 256) {
     f32x4 a[4], b[4][4];
@@ -184,13 +189,14 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
   *reinterpret_cast<f32x4*>(P.C + o) = v;
-  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4);
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4, eo);
 }
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
-__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red) {
+__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
+                                   const int64_t eo) {
   // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
   const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
   const GemmHot& P = args.p[pi];
@@ -198,18 +204,20 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   const int by = t / nx, bx = t - by * nx;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
   const int k0 = by * 16, n0 = bx * 64;
-  const float* xc = P.A + k0 + j;
-  const float* yc = P.B + n0 + 4 * j;
-  // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0)
-  float* const dst = P.C + (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
-  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  const float* xc = P.A + eo + k0 + j;
+  const float* yc = P.B + eo + n0 + 4 * j;
+  // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0);
+  // pidx / bidx = parameter indices (the same for every expert), addressed at index + eo
+  const int64_t toff = (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
+  float* const dst = P.C + eo + toff;
+  const int64_t pidx = ADAM ? (int64_t)(P.C - A.grad) + toff : 0;
   const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
   AdamPre4 pre;
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
   if (ADAM) {
-    adam_alphas(A, aQ, aPi);
-    pre = adam_prefetch4(A, pidx);
-    if (by == 0 && tid < 64) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+    adam_alphas(A, aQ, aPi, eo);
+    pre = adam_prefetch4(A, pidx + eo);
+    if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
@@ -238,7 +246,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   *reinterpret_cast<f32x4*>(dst) = v;
-  if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx, v, pre);
+  if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
   if (by == 0) {
     // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
     __syncthreads();
@@ -248,10 +256,10 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
       float gb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.aux_out[n0 + tid] = gb;
+      P.aux_out[eo + n0 + tid] = gb;
       if (ADAM) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
       }
     }
   }
@@ -272,7 +280,8 @@ struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin f
 // layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
 template <bool ADAM, bool YV>
-__device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red) {
+__device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
+                                     const int64_t eo) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -280,27 +289,27 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   const int k0 = by * 16, n0 = bx * 64;
   const int krow = k0 + j, col = n0 + 4 * j;
   const bool k_ok = krow < P.w;
-  const float* xc = P.x + min(krow, P.w - 1);
+  const float* xc = P.x + eo + min(krow, P.w - 1);
   const int colc = YV ? min(col, P.N - 4) : 0;
-  const float* yc = P.dY + colc;
+  const float* yc = P.dY + eo + colc;
   // optimiser operands of what this thread finishes, fetched with the first batch of loads
   const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
   const bool own = grow < P.w && gcol < P.N;
-  float* const dst = P.dW + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
-  const int64_t pidx = ADAM ? (int64_t)(dst - A.grad) : 0;
+  float* const dst = P.dW + eo + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - eo - A.grad) : 0;      // parameter index, addressed at index + eo
   const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
   const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
   AdamPre4 pre;
   pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
   if (ADAM) {
-    adam_alphas(A, aQ, aPi);
+    adam_alphas(A, aQ, aPi, eo);
     if (YV) {
-      pre = adam_prefetch4(A, own ? pidx : 0);
+      pre = adam_prefetch4(A, (own ? pidx : 0) + eo);
     } else if (own) {                                       // N == 1: one element per owning thread
-      pre.m[0] = A.m[pidx]; pre.v[0] = A.v[pidx]; pre.th[0] = A.theta[pidx];
+      pre.m[0] = A.m[pidx + eo]; pre.v[0] = A.v[pidx + eo]; pre.th[0] = A.theta[pidx + eo];
     }
-    if (own_b) { bm = A.m[bidx]; bv = A.v[bidx]; bth = A.theta[bidx]; }
+    if (own_b) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
@@ -348,13 +357,13 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
     const float na = (pidx < A.n_Q) ? -aQ : -aPi;
     if (YV) {
       *reinterpret_cast<f32x4*>(dst) = v;
-      if (ADAM) adam_apply4(A, na, pidx, v, pre);
+      if (ADAM) adam_apply4(A, na, pidx + eo, v, pre);
     } else {
       dst[0] = v[0];                                        // N == 1 (gcol == 0)
       if (ADAM) {
         float m = pre.m[0], vv = pre.v[0];
         const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
-        A.m[pidx] = m; A.v[pidx] = vv; A.theta[pidx] = th;
+        A.m[pidx + eo] = m; A.v[pidx + eo] = vv; A.theta[pidx + eo] = th;
       }
     }
   }
@@ -366,17 +375,18 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
       float gb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.db[n0 + tid] = gb;
+      P.db[eo + n0 + tid] = gb;
       if (ADAM) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-        A.m[bidx] = bm; A.v[bidx] = bv; A.theta[bidx] = th;
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
       }
     }
   }
 }
 
 template <bool ADAM>
-__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red) {
+__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
+                                     const int64_t eo) {
   const int tid = threadIdx.x;
   // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
   // arithmetic, so the descriptor load does not wait for a search through the table
@@ -387,9 +397,9 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
     const LossFin& F = args.fin;
     float lq = 0.f, lp = 0.f, ll = 0.f;
     for (int m = tid; m < F.B; m += 256) {
-      lq += F.rows[m];
-      lp += F.rows[F.B + m];
-      ll += F.rows[2 * F.B + m];
+      lq += F.rows[eo + m];
+      lp += F.rows[eo + F.B + m];
+      ll += F.rows[eo + 2 * F.B + m];
     }
     red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
     __syncthreads();
@@ -403,15 +413,15 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
     }
     if (tid == 0) {
       const float invB = 1.0f / (float)F.B;
-      F.out[0] = red[0] * invB;
-      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+      F.out[eo + 0] = red[0] * invB;
+      F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
     }
     return;
   }
   const DwSmall& P = args.p[pi];
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red);
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo);
 }
 
 // Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
@@ -421,18 +431,22 @@ struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
 __global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   AdamFuse none;
-  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red);
-  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red);
+  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red, 0);
+  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red, 0);
 }
 
 // The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
 // applied in the tile epilogue, the loss finalisation, and -- in the first n_her blocks -- the HER gather of the NEXT
 // update's batch (it depends on nothing this update computes; it must target a different staging buffer than the one
 // the layer-0 gradient tiles of this launch still read).
-__global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her) {
+// Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
+// sampler seed is h.rng.seed + expert * seed_stride.
+__global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her,
+                                                          int64_t ex_stride, uint64_t seed_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const int bid = (int)blockIdx.x - n_her;
-  if (bid < 0) her_sample_body(h, blockIdx.x, red);
-  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red);
-  else dw_small_body<true>(args.small, A, bid - args.n_hot, red);
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  if (bid < 0) her_sample_body(h, blockIdx.x, red, eo, (uint64_t)blockIdx.y * seed_stride);
+  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red, eo);
+  else dw_small_body<true>(args.small, A, bid - args.n_hot, red, eo);
 }

@@ -49,7 +49,10 @@ class DDPG(object):
         """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph."""
         if self.clip_return is None:
             self.clip_return = np.inf
-        self._extra_kwargs = tuple(kwargs.keys())                    # e.g. info, use_mpi: stored by store_args, pickled
+        # e.g. info, use_mpi: stored by store_args, pickled with the policy; names with a leading underscore are
+        # construction hooks of this implementation (_alloc: slab allocator of curious_amd.experts.ExpertBank)
+        self._extra_kwargs = tuple(k for k in kwargs.keys() if not k.startswith('_'))
+        self._alloc = kwargs.get('_alloc')
         self._scope_arg = scope
         self.create_actor_critic = import_function(self.network_class)
         self.dimo, self.dimg = self.input_dims['o'], self.input_dims['g']
@@ -97,6 +100,13 @@ class DDPG(object):
         self._batch_stale = True
 
     # ------------------------------------------------------------------ construction
+    def _new(self, shape, dtype=torch.float32):
+        """Zero-filled device tensor holding per-agent update state.  An ExpertBank passes an allocator that carves these
+        tensors out of the agent's slab (same order and sizes for every expert -> same offsets)."""
+        if self._alloc is not None:
+            return self._alloc(shape, dtype)
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
     def _create_network(self, reuse=False):
         cfg = ops.make_net_cfg(self.dimo, self.dimg, self.dimu, self.dimtd, self.hidden, self.layers, self.modular,
                                self.max_u, self.gamma, self.clip_return, self.action_l2, self.clip_pos_returns,
@@ -112,21 +122,22 @@ class DDPG(object):
         # generator (not NumPy's), so a private RandomState is used and the NumPy global stream is left untouched.
         wrng = np.random.RandomState(self.seed)
         flat = np.concatenate([self._xavier(self._shapes(True), wrng), self._xavier(self._shapes(False), wrng)])
-        self.theta = torch.from_numpy(ops.pad_params(cfg, flat)).to(dev)
-        self.theta_target = torch.empty_like(self.theta)
-        self.grad = torch.zeros_like(self.theta)
-        self._m = torch.zeros_like(self.theta)
-        self._v = torch.zeros_like(self.theta)
+        self.theta = self._new([self.P_total])
+        self.theta.copy_(torch.from_numpy(ops.pad_params(cfg, flat)))
+        self.theta_target = self._new([self.P_total])
+        self.grad = self._new([self.P_total])
+        self._m = self._new([self.P_total])
+        self._v = self._new([self.P_total])
         self.Q_adam = MpiAdam(self.theta[:self.off_pi], scale_grad_by_procs=False)       # ddpg.py:452-453
         self.pi_adam = MpiAdam(self.theta[self.off_pi:], scale_grad_by_procs=False)
         self.Q_adam.m, self.Q_adam.v = self._m[:self.off_pi], self._v[:self.off_pi]
         self.pi_adam.m, self.pi_adam.v = self._m[self.off_pi:], self._v[self.off_pi:]
-        self._workspace = torch.empty(ops.workspace_floats(cfg, self.batch_size), dtype=torch.float32, device=dev)
+        self._workspace = self._new([ops.workspace_floats(cfg, self.batch_size)])
         self._act_ws = {}
-        self._losses = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._Q_pi = torch.zeros([self.batch_size, 1], dtype=torch.float32, device=dev)
-        self._step_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        self._alpha_tab = torch.zeros([ALPHA_TAB, 2], dtype=torch.float32, device=dev)
+        self._losses = self._new([2])
+        self._Q_pi = self._new([self.batch_size, 1])
+        self._step_ctr = self._new([1], torch.int64)
+        self._alpha_tab = self._new([ALPHA_TAB, 2])
         self._alpha_base = 0
         self._alpha_filled = 0
         self._noise_counter = 0
@@ -176,16 +187,28 @@ class DDPG(object):
         """ddpg.py:129-161.  NumPy inputs -> NumPy outputs (host envs); GPU tensors -> GPU tensors (batched env)."""
         host_io = not isinstance(o, torch.Tensor)
         dev = self.device
-
-        def up(x, d):
-            if x is None:
-                return None
-            if isinstance(x, torch.Tensor):
-                return x.reshape(-1, d)
-            return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1, d))).to(dev)
-        o_d, g_d, ag_d = up(o, self.dimo), up(g, self.dimg), up(ag, self.dimag)
-        td_d = up(task_descr, self.dimtd) if self.dimtd > 0 else None
-        n = o_d.shape[0]
+        if host_io:
+            # host envs (rollout.py:226-232 with a Python list of envs): [o | ag | g | td] of all envs goes up in ONE
+            # asynchronous copy from a pinned block, the actions (and Q) come back through a pinned block; two blocks
+            # alternate so that the caller may fill the next step's inputs while this step's copies are in flight
+            n = int(np.asarray(o).reshape(-1, self.dimo).shape[0])
+            io = self._host_io_blocks(n)
+            hin = io['hin'][io['k']]
+            view = hin.numpy()
+            c0, c1, c2 = self.dimo, self.dimo + self.dimag, self.dimo + self.dimag + self.dimg
+            view[:, :c0] = np.asarray(o, dtype=np.float32).reshape(n, self.dimo)
+            view[:, c0:c1] = np.asarray(ag, dtype=np.float32).reshape(n, self.dimag)
+            view[:, c1:c2] = np.asarray(g, dtype=np.float32).reshape(n, self.dimg)
+            if self.dimtd > 0:
+                view[:, c2:c2 + self.dimtd] = np.asarray(task_descr, dtype=np.float32).reshape(n, self.dimtd)
+            din = io['din'][io['k']]
+            din.copy_(hin, non_blocking=True)
+            o_d, ag_d, g_d = din[:, :c0], din[:, c0:c1], din[:, c1:c2]
+            td_d = din[:, c2:c2 + self.dimtd] if self.dimtd > 0 else None
+        else:
+            o_d, g_d, ag_d = o.reshape(-1, self.dimo), g.reshape(-1, self.dimg), ag.reshape(-1, self.dimag)
+            td_d = task_descr.reshape(-1, self.dimtd) if self.dimtd > 0 else None
+            n = o_d.shape[0]
         theta = self.theta_target if use_target_net else self.theta
         ws = self._act_ws.get(n)
         if ws is None:
@@ -212,11 +235,33 @@ class DDPG(object):
             ops.action_noise(u, n, self.dimu, noise_scale, random_eps, self.max_u,
                              seed=self.seed * 2654435761 + 12345 + dist.rank() * 1000003, counter=self._noise_counter)
         if host_io:
-            u_h = u.cpu().numpy()
+            hout = io['hout'][io['k']]
+            hout[:, :self.dimu].copy_(u, non_blocking=True)
+            if compute_Q:
+                hout[:, self.dimu:].copy_(Q, non_blocking=True)
+            io['done'].record()
+            io['k'] ^= 1
+            io['done'].synchronize()                                 # the only host wait of an acting step
+            out = hout.numpy()
+            u_h = out[:, :self.dimu].copy()
             if u_h.shape[0] == 1:
                 u_h = u_h[0]
-            return [u_h, Q.cpu().numpy()] if compute_Q else u_h
+            return [u_h, out[:, self.dimu:].copy()] if compute_Q else u_h
         return [u, Q] if compute_Q else u
+
+    def _host_io_blocks(self, n):
+        io = getattr(self, '_host_io', {}).get(n)
+        if io is None:
+            w = self.dimo + self.dimag + self.dimg + max(self.dimtd, 0)
+            w = (w + 3) & ~3                                         # rows stay 16-byte aligned (lean layer-0 loads)
+            io = dict(hin=[torch.zeros([n, w], dtype=torch.float32).pin_memory() for _ in range(2)],
+                      din=[torch.zeros([n, w], dtype=torch.float32, device=self.device) for _ in range(2)],
+                      hout=[torch.zeros([n, self.dimu + 1], dtype=torch.float32).pin_memory() for _ in range(2)],
+                      done=torch.cuda.Event(), k=0)
+            if not hasattr(self, '_host_io'):
+                self._host_io = {}
+            self._host_io[n] = io
+        return io
 
     def can_act_and_step(self, env, compute_Q):
         """The fused acting step applies to the GPU-resident synthetic env in throughput mode."""
@@ -424,6 +469,7 @@ class DDPG(object):
                     src_d.copy_(src_h, non_blocking=True)
                     dst_d.copy_(dst_h, non_blocking=True)
                     ops.store_episodes(self._pool.storage, staging, layout, src_d, dst_d)
+                    self._pool.version += 1
             else:
                 for b in range(batch_size):
                     slot = self.buffer._get_storage_idx(1)
@@ -555,6 +601,25 @@ class DDPG(object):
             return i - 1 if i > 0 else None                          # ddpg.py:329-333
         return self.t_id                                             # ddpg.py:335
 
+    def _sizes_key(self):
+        return (self._pool.version,) + tuple(self.buffer[i].current_size for i in range(self.nb_tasks + 1))
+
+    def _tables_stale(self):
+        """The device sampling tables follow the buffers: task experts share their buffers, so an episode stored through
+        ANOTHER expert (train.py:99) must be seen here too, like the reference's sample_batch reading current_size."""
+        return self._tables_dirty or getattr(self, '_tables_sizes', None) != self._sizes_key()
+
+    def _prealloc_device_loop(self):
+        """Allocate what the device-resident update loop otherwise allocates lazily (ExpertBank: identical slab layouts)."""
+        if self._pp is None:
+            shape = [self.batch_size, self._layout.batch_stride]
+            self._pp = [self._new(shape) for _ in range(2)]
+            self._cur = 0
+        if getattr(self, '_tables', None) is None:
+            n = 4 * (self.nb_tasks + 1) + 1
+            self._tables = self._new([n], torch.int32)
+            self._tables_host = torch.zeros(n, dtype=torch.int32).pin_memory()
+
     def _refresh_device_tables(self):
         nb1 = self.nb_tasks + 1
         self.proportions = self._proportions()
@@ -568,7 +633,7 @@ class DDPG(object):
                         np.int32)
         host = np.concatenate([prefix, alias, task, cur])
         if getattr(self, '_tables', None) is None or self._tables.numel() != host.size:
-            self._tables = torch.zeros(host.size, dtype=torch.int32, device=self.device)
+            self._tables = self._new([host.size], torch.int32)
             self._tables_host = torch.zeros(host.size, dtype=torch.int32).pin_memory()
         # pinned + asynchronous: the previous upload from this buffer finished long ago (every cycle has a D2H sync)
         self._tables_host.numpy()[:] = host
@@ -585,22 +650,35 @@ class DDPG(object):
         r.nbuf = nb1
         self._rng_desc = r
         self._tables_dirty = False
+        self._tables_sizes = self._sizes_key()
 
     def _multi_buffer(self):
         return self.structure in ('curious', 'task_experts') and \
             ('buffer' in self.task_replay or self.task_replay == 'hand_designed')
 
+    def _host_reward_fixup(self, packed, layout):
+        """Host-evaluated reward (real-env parity-audit mode, her.py:166-176): the batch was gathered un-clipped so that
+        the reward sees the sampler's goals; the clip of ddpg.py:350-353 follows (torch, off the throughput path)."""
+        S = self.sample_transitions
+        S.apply_host_reward(packed, layout)
+        for key in ('o', 'g', 'o_2', 'g_2'):
+            off, dim = layout.batch_cols[key]
+            packed[:, off:off + dim].clamp_(-self.clip_obs, self.clip_obs)
+
     def _sample_packed(self):
         """One packed, clipped, permuted minibatch [batch_size, stride] on the GPU."""
         S = self.sample_transitions
-        P = S.params(self.clip_obs, self.relative_goals)
+        host_r = getattr(S, 'host_reward', None) is not None
+        if host_r and self.relative_goals:
+            raise NotImplementedError('a host-evaluated reward with relative_goals is not supported')
+        P = S.params(np.inf if host_r else self.clip_obs, self.relative_goals)
         B = self.batch_size
         if self._multi_buffer():
             layout = self._layout
             if self._staged is None or self._staged.shape != (B, layout.batch_stride):
                 self._staged = torch.zeros([B, layout.batch_stride], dtype=torch.float32, device=self.device)
             if self.rng_mode == 'device':
-                if self._tables_dirty:
+                if self._tables_stale():
                     self._refresh_device_tables()
                 ops.her_sample(self._pool.storage, self._pool.buf_stride, layout, S.tasks, P, B, self._staged,
                                rng=self._rng_desc)
@@ -626,6 +704,8 @@ class DDPG(object):
                                    buf=np.concatenate(bufi), ttr=np.concatenate(ttr), out_row=out_row)
                 ops.her_sample(self._pool.storage, self._pool.buf_stride, layout, S.tasks, P, B, self._staged,
                                plan=plan)
+            if host_r:
+                self._host_reward_fixup(self._staged, layout)
             self._layout_for_batch = layout
             return self._staged
         # single buffer (flat, or the *_task_transition replay modes): ddpg.py:288-299,320,348
@@ -646,6 +726,8 @@ class DDPG(object):
         if self._staged is None or self._staged.shape != (B, layout.batch_stride):
             self._staged = torch.zeros([B, layout.batch_stride], dtype=torch.float32, device=self.device)
         ops.her_sample(buf.pool.storage, buf.pool.buf_stride, layout, S.tasks, P, B, self._staged, plan=plan)
+        if host_r:
+            self._host_reward_fixup(self._staged, layout)
         self._layout_for_batch = layout
         return self._staged
 
@@ -690,7 +772,8 @@ class DDPG(object):
 
     def _device_loop(self):
         """The device-resident update loop applies: device-drawn batches from the pooled per-task buffers."""
-        return self.rng_mode == 'device' and self._multi_buffer()
+        return self.rng_mode == 'device' and self._multi_buffer() and \
+            getattr(self.sample_transitions, 'host_reward', None) is None
 
     def train(self, stage=True):
         """One update (ddpg.py:368-373).  Returns (critic_loss, actor_loss) as GPU tensors (no host sync);
@@ -817,14 +900,14 @@ class DDPG(object):
         self._adam_and_sample()
 
     def _train_device_prologue(self, k):
-        if self._tables_dirty:
+        if self._tables_stale():
             self._refresh_device_tables()
             self._batch_stale = True
         if self.Q_adam.t + k > self._alpha_filled or self._alpha_filled == 0:
             self._fill_alpha_table()
         if self._pp is None:
             shape = [self.batch_size, self._layout.batch_stride]
-            self._pp = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._pp = [self._new(shape) for _ in range(2)]
             self._cur = 0
             self._batch_stale = True
         if self._staged is not self._pp[self._cur]:

@@ -53,6 +53,33 @@ class ArmSpec:
                                                  desired_goal=_Space([self.dimg])))
         self.action_space = _Space([self.dimu])
         self.reward_spec = dict(kind='sparse_l2', eps=REWARD_EPS)
+        self.flat = False
+
+    def set_flat_env(self):
+        """Single-task view (config.py:116-117, rollout.py:93-95): goals span every slot, the reward is the sparse L2
+        threshold over the whole goal vector."""
+        self.flat = True
+
+    def compute_reward(self, achieved_goal, goal, task_descr=None, info=None):
+        """The env's own reward (what config.py:158-159 wraps): -1 while the L2 distance between the achieved and the
+        desired goal on the task's slots (all slots for the flat view) exceeds reward_spec['eps'], else 0; float64,
+        shape [n, 1].  Same rule as the HER kernel evaluates on the GPU."""
+        ag = np.asarray(achieved_goal, dtype=np.float64).reshape(-1, self.dimag)
+        g = np.asarray(goal, dtype=np.float64).reshape(-1, self.dimg)
+        n = ag.shape[0]
+        if self.flat or task_descr is None:
+            ids_g = [i for ids in self.tasks_g_id for i in ids]
+            ids_ag = [i for ids in self.tasks_ag_id for i in ids]
+            sel_g, sel_ag = g[:, ids_g], ag[:, ids_ag]
+        else:
+            task = np.argmax(np.asarray(task_descr).reshape(n, self.nb_tasks), axis=1)
+            sel_g = np.stack([g[i, self.tasks_g_id[task[i]]] for i in range(n)])
+            sel_ag = np.stack([ag[i, self.tasks_ag_id[task[i]][:len(self.tasks_g_id[task[i]])]] for i in range(n)])
+        d2 = np.zeros(n)
+        for k in range(sel_g.shape[1]):                       # sequential float64 sum, like the kernel
+            d = sel_ag[:, k] - sel_g[:, k]
+            d2 = d2 + d * d
+        return -(np.sqrt(d2) > self.reward_spec['eps']).astype(np.float64).reshape(n, 1)
 
     def _compute_goal(self, g, task, eval=False):
         """Goal-space image of a raw draw g in [-1, 1]^3 for `task` (the protocol of rollout.py:85-86,135)."""
@@ -175,7 +202,10 @@ class SyntheticArmEnv(ArmSpec):
         b = self._b
         b.tasks_host[0] = self.task
         b.tasks.copy_(torch.from_numpy(b.tasks_host))
-        full, mask = self._compute_goal(raw, self.task)
+        if self.flat:                                                # the goal spans every slot (rollout.py:93-95)
+            full, mask = np.float32(0.5) * raw.reshape(self.dimg), np.zeros(self.nb_tasks, np.float32)
+        else:
+            full, mask = self._compute_goal(raw, self.task)
         self.goal = full
         b.g[0].copy_(torch.from_numpy(full))
         b.td[0].copy_(torch.from_numpy(mask))
@@ -186,12 +216,12 @@ class SyntheticArmEnv(ArmSpec):
         t = min(self._t, self.T - 1)
         self._b.step_all(u_d, t)
         self._t += 1
-        succ = float(self._b.staging[0, t, self._b.layout.off['info_is_success']])
-        return self._obs(), succ - 1.0, False, {'is_success': succ}
-
-    def compute_reward(self, achieved_goal, goal, task_descr=None, info=None):
-        raise NotImplementedError('the sparse reward is evaluated inside curious_her_sample on the GPU '
-                                  '(reward_spec = %r)' % (self.reward_spec,))
+        obs = self._obs()
+        if self.flat:
+            succ = float(self.compute_reward(obs['achieved_goal'], obs['desired_goal'])[0, 0] + 1.0)
+        else:
+            succ = float(self._b.staging[0, t, self._b.layout.off['info_is_success']])
+        return obs, succ - 1.0, False, {'is_success': succ}
 
     def render(self):
         pass

@@ -97,10 +97,12 @@ def configure_her(params):
     if params['structure'] == 'flat':
         env.unwrapped.set_flat_env()
     spec = getattr(env.unwrapped, 'reward_spec', None)
-    if spec is None:
-        raise NotImplementedError('the environment must expose reward_spec (sparse per-task L2 threshold) so that the '
-                                  'HER kernel can recompute rewards on the GPU')
-    reward_fun = sparse_reward_fun(spec)
+    if spec is not None and not params.get('host_reward', False):
+        reward_fun = sparse_reward_fun(spec)                        # evaluated inside the HER kernel
+    else:
+        # a real environment (gym_flowers): the reference's closure, evaluated on the host per sampled batch
+        def reward_fun(ag_2, g, task_descr=None, info=None):        # config.py:158-159
+            return env.unwrapped.compute_reward(achieved_goal=ag_2, goal=g, task_descr=task_descr, info=info)
     her_params = {
         'reward_fun': reward_fun,
         'tasks_ag_id': params['tasks_ag_id'],
@@ -147,8 +149,8 @@ def configure_buffer(dims, params):
     return ReplayBuffer(buffer_shapes, buffer_size, T, sample_her_transitions)
 
 
-def configure_ddpg(dims, params, buffers, reuse=False, use_mpi=True, clip_return=True, t_id=None):
-    """config.py:219-254."""
+def configure_ddpg(dims, params, buffers, reuse=False, use_mpi=True, clip_return=True, t_id=None, **hooks):
+    """config.py:219-254.  `hooks`: construction hooks of this implementation (curious_amd.experts.ExpertBank)."""
     sample_her_transitions = configure_her(params)
     gamma = params['gamma']
     rollout_batch_size = params['rollout_batch_size']
@@ -169,10 +171,14 @@ def configure_ddpg(dims, params, buffers, reuse=False, use_mpi=True, clip_return
                         'tasks_ag_id': params['tasks_ag_id'],
                         'tasks_g_id': params['tasks_g_id'],
                         'eps_task': params['eps_task']})
+    kw = dict(ddpg_params)
     if t_id is not None:
-        ddpg_params.update({'t_id': t_id})
-    ddpg_params['info'] = {'env_name': params['env_name']}
-    return DDPG(reuse=reuse, **ddpg_params, buffers=buffers, use_mpi=use_mpi)
+        # the reference's experts get different TensorFlow initialisations; here expert t_id draws its weights (and its
+        # device RNG streams) from seed + t_id
+        kw.update({'t_id': t_id, 'seed': int(ddpg_params.get('seed', 0)) + int(t_id)})
+    kw['info'] = {'env_name': params['env_name']}
+    kw.update(hooks)
+    return DDPG(reuse=reuse, **kw, buffers=buffers, use_mpi=use_mpi)
 
 
 def configure_dims(params):

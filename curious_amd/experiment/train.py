@@ -31,8 +31,9 @@ t0 = time.time()
 
 
 def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
-          save_policies, structure, task_selection, params, perturbation_study=False, **kwargs):
-    """train.py:49-166."""
+          save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None, **kwargs):
+    """train.py:49-166.  expert_bank (task_experts only): update ALL experts in one batched launch sequence after
+    every rollout (BASELINE configs[4]) instead of only the expert that collected it."""
     rank = dist.rank()
     if rank == 0 and logger.get_dir() is not None:
         latest_policy_path = os.path.join(logger.get_dir(), 'policy_latest.pkl')
@@ -66,6 +67,11 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
             for _ in range(n_cycles):
                 episode, cp, n_ep = rollout_worker[i_policy].generate_rollouts()
                 policy[i_policy].store_episode(episode, cp, n_ep)
+                if expert_bank is not None:
+                    if expert_bank.trainable():
+                        expert_bank.train_batches(n_batches)          # every expert, one launch sequence per update
+                        expert_bank.update_target_net()
+                    continue
                 policy[i_policy].train_batches(n_batches)             # = n_batches x train() (train.py:101-102)
                 policy[i_policy].update_target_net()
             evaluator.clear_history()
@@ -185,7 +191,14 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
 
     dims = config.configure_dims(params)
     buffers = config.configure_buffer(dims=dims, params=params)
-    if structure == 'task_experts':
+    expert_bank = None
+    if structure == 'task_experts' and params.get('experts_update', 'sequential') == 'batched':
+        from curious_amd.experts import ExpertBank
+        expert_bank = ExpertBank(lambda i, **hooks: config.configure_ddpg(dims=dims, params=params, buffers=buffers,
+                                                                           clip_return=clip_return, t_id=i, **hooks),
+                                 params['nb_tasks'])
+        policy = list(expert_bank)
+    elif structure == 'task_experts':
         policy = [config.configure_ddpg(dims=dims, params=params, buffers=buffers, clip_return=clip_return, t_id=i)
                   for i in range(params['nb_tasks'])]
     else:
@@ -215,7 +228,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     return train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
                  n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],
                  n_batches=params['n_batches'], perturbation_study=perturb, policy_save_interval=policy_save_interval,
-                 save_policies=save_policies, structure=structure, task_selection=task_selection, params=params)
+                 save_policies=save_policies, structure=structure, task_selection=task_selection, params=params,
+                 expert_bank=expert_bank)
 
 
 def main(argv=None):
@@ -240,8 +254,11 @@ def main(argv=None):
     parser.add_argument('--use_graph', type=int, default=1)
     parser.add_argument('--n_cycles', type=int, default=None)
     parser.add_argument('--n_batches', type=int, default=None)
+    parser.add_argument('--experts_update', type=str, default='sequential', choices=['sequential', 'batched'],
+                        help="task_experts: 'batched' updates all experts in one launch sequence per update")
     args = vars(parser.parse_args(argv))
-    over = {'rng_mode': args.pop('rng_mode'), 'use_graph': bool(args.pop('use_graph'))}
+    over = {'rng_mode': args.pop('rng_mode'), 'use_graph': bool(args.pop('use_graph')),
+            'experts_update': args.pop('experts_update')}
     for k in ('rollout_batch_size', 'n_cycles', 'n_batches'):
         v = args.pop(k)
         if v is not None:

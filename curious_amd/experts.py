@@ -1,0 +1,178 @@
+"""Batched multi-policy update for structure='task_experts' (BASELINE configs[4]).
+
+The reference keeps one DDPG per task on shared replay buffers (train.py:285-291) and trains them one after the other,
+one expert per epoch (train.py:65-121); expert t_id samples its minibatch from buffer t_id + 1 and relabels to its own
+task (ddpg.py:302-318,335).  The experts are independent given the buffers, so here all N of them go through ONE launch
+sequence per update (curious_ddpg_update_experts: the 9 launches of a single-agent update with the expert on grid.z /
+grid.y) and -- with several ranks -- one all-reduce of the concatenated N x P gradient.
+
+Layout: every expert's update state (parameters, target, gradient, Adam moments, step counter, step-size ring,
+workspace, the two staged batches, sampling tables, loss outputs) is carved, in the same order, out of row e of one
+[N, stride] float32 tensor, so that expert e's copy of anything is `stride` floats behind expert 0's.
+"""
+import numpy as np
+import torch
+
+from curious_amd import _lib, dist, ops
+from curious_amd.ddpg import CAPTURE_MODE, CHAIN
+
+SEED_STRIDE_SAMPLER = 104729            # DDPG._refresh_device_tables: sampler key = seed * 104729 + ...
+
+
+class _Carver:
+    """Allocator handed to DDPG(_alloc=...): consecutive 256-byte aligned pieces of one slab row (or, in measuring mode,
+    stand-alone tensors while the total is added up)."""
+
+    def __init__(self, device, row=None):
+        self.device, self.row, self.off = device, row, 0
+
+    def __call__(self, shape, dtype):
+        n = int(np.prod(shape))
+        words = n * (2 if dtype == torch.int64 else 1)
+        start = self.off
+        self.off += (words + 63) & ~63
+        if self.row is None:
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+        if self.off > self.row.numel():
+            raise RuntimeError('expert slab too small: the experts do not allocate identically')
+        piece = self.row[start:start + words]
+        piece.zero_()
+        if dtype != torch.float32:
+            piece = piece.view(dtype)
+        return piece.view(*shape)
+
+
+class ExpertBank:
+    """N task experts updated together.
+
+    `make_expert(t_id, **hooks)` must build the DDPG of expert t_id (config.configure_ddpg with t_id) forwarding the
+    hook keyword arguments to the DDPG constructor.  Expert seeds must be consecutive (seed_0 + t_id): the batched
+    launch derives expert e's sampler key from expert 0's.
+    """
+
+    def __init__(self, make_expert, n_experts):
+        self.n = int(n_experts)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        probe_alloc = _Carver(dev)
+        probe = make_expert(0, _alloc=probe_alloc)
+        probe._prealloc_device_loop()
+        self.stride = (probe_alloc.off + 63) & ~63
+        del probe
+        self.slab = torch.zeros([self.n, self.stride], dtype=torch.float32, device=dev)
+        self.experts = []
+        for e in range(self.n):
+            x = make_expert(e, _alloc=_Carver(dev, self.slab[e]))
+            x._prealloc_device_loop()
+            self.experts.append(x)
+        x0 = self.experts[0]
+        for e, x in enumerate(self.experts):
+            if x.seed != x0.seed + e:
+                raise ValueError('expert seeds must be consecutive (seed_0 + t_id)')
+            if not x._device_loop() or x.normalize_obs:
+                raise ValueError("the batched update needs rng_mode='device', per-task buffers and normalize_obs=False")
+            for name in ('theta', 'theta_target', 'grad', '_m', '_v', '_workspace', '_losses', '_Q_pi', '_step_ctr',
+                         '_alpha_tab', '_tables'):
+                a, b = getattr(x, name), getattr(x0, name)
+                assert a.data_ptr() - b.data_ptr() == 4 * e * self.stride, name
+        self.use_graph = bool(x0.use_graph)
+        self._graphs = {}
+        self._cur = 0
+        self.batched = True                     # False after the library refused the shapes (sequential updates then)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return self.experts[i]
+
+    def __iter__(self):
+        return iter(self.experts)
+
+    # ------------------------------------------------------------------ updates
+    def trainable(self):
+        """Every expert can draw a batch once any buffer holds an episode (ddpg.py:302-318)."""
+        x0 = self.experts[0]
+        return sum(x0.buffer[i].current_size for i in range(x0.nb_tasks + 1)) > 0
+
+    def _prologue(self, k):
+        for x in self.experts:
+            if x._cur != self._cur:
+                x._cur = self._cur
+                x._batch_stale = True
+            x._train_device_prologue(k)
+        for x in self.experts:
+            if x._batch_stale:
+                x._sample_packed()
+                x._batch_stale = False
+
+    def _update_all(self, p):
+        x0 = self.experts[0]
+        S = x0.sample_transitions
+        ops.ddpg_update_experts(x0.net_cfg, self.n, self.stride, SEED_STRIDE_SAMPLER, x0.theta, x0.theta_target,
+                                x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi,
+                                x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base, x0._pp[p ^ 1],
+                                x0._pool.storage, x0._pool.buf_stride, S.tasks,
+                                S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc)
+
+    def _capture(self, fn):
+        """Capture `fn` after one eager warm-up; the slab (all experts' state) is restored afterwards."""
+        saved = self.slab.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+            fn()
+        self.slab.copy_(saved)
+        return g
+
+    def _train(self, k):
+        """k updates of every expert (k = 1 or CHAIN)."""
+        if dist.is_distributed():
+            raise NotImplementedError('the batched expert update runs on one rank per replica set; use '
+                                      'experts_update=sequential with several ranks')
+        self._prologue(k)
+        p0 = self._cur
+        if self.use_graph:
+            key = (k, p0)
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(lambda: [self._update_all((p0 + i) & 1) for i in range(k)])
+                for x in self.experts:                       # the warm-up overwrote the staged batches
+                    x._sample_packed()
+            self._graphs[key].replay()
+        else:
+            for i in range(k):
+                self._update_all((p0 + i) & 1)
+        self._cur ^= (k & 1)
+        for x in self.experts:
+            x._cur = self._cur
+            x._staged = x._pp[x._cur]
+            x.Q_adam.t += k
+            x.pi_adam.t += k
+
+    def train(self):
+        """One update of every expert.  Returns [(critic_loss, Q_pi)] per expert (GPU tensors)."""
+        return self.train_batches(1)
+
+    def train_batches(self, n):
+        """n x [policy[e].train() for every expert e] -- bit-identical to the sequential loops."""
+        if not self.batched:
+            return [x.train_batches(n) for x in self.experts]
+        try:
+            while n > 0:
+                k = CHAIN if (self.use_graph and n >= CHAIN and self._cur == 0) else 1
+                self._train(k)
+                n -= k
+        except _lib.CuriousHipError as err:
+            if 'lean' not in str(err):
+                raise
+            self.batched = False                             # shapes outside the lean route: sequential from now on
+            return [x.train_batches(n) for x in self.experts]
+        return [(x._losses[0], x._Q_pi) for x in self.experts]
+
+    def update_target_net(self):
+        for x in self.experts:
+            x.update_target_net()

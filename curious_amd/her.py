@@ -7,9 +7,11 @@
 The random draws consume the NumPy legacy global stream in exactly the reference's order (her.py:108-116, and the
 per-sample np.random.choice of her.py:139,142), so a seeded run selects the same episodes, time steps, HER mask and
 future offsets as the reference; everything after the draws (index math, gather, goal/task relabel, reward) runs in
-curious_her_sample.  The reward must be the sparse per-task L2 threshold (a `reward_fun` carrying a `.spec`
-{'kind': 'sparse_l2', 'eps': e}); an arbitrary Python reward callable is rejected instead of silently evaluated on
-the host.
+curious_her_sample.  Rewards: a `reward_fun` carrying `.spec = {'kind': 'sparse_l2', 'eps': e}` (curious_amd.envs) is
+evaluated inside the kernel.  Any other callable -- the closure over env.compute_reward of config.py:158-159 for a real
+gym_flowers environment -- is evaluated ON THE HOST for every sampled batch (her.py:166-176: download ag_2 / g /
+task_descr / info_*, call it, upload r): the parity-audit mode for real environments, one PCIe round trip per batch, and
+not available to the device-resident update loop.
 """
 from collections import OrderedDict
 
@@ -27,12 +29,16 @@ class TransitionBatch(OrderedDict):
 
 
 def _reward_spec(reward_fun):
+    """(kernel threshold, host callable or None)."""
     spec = getattr(reward_fun, 'spec', None)
-    if not spec or spec.get('kind') != 'sparse_l2':
-        raise NotImplementedError(
-            "curious_amd evaluates the reward inside the HER kernel and supports the sparse per-task L2 threshold "
-            "only; pass a reward_fun with .spec = {'kind': 'sparse_l2', 'eps': ...} (curious_amd.envs provides one)")
-    return float(spec['eps'])
+    if spec:
+        if spec.get('kind') != 'sparse_l2':
+            raise NotImplementedError("reward spec %r: the HER kernel implements {'kind': 'sparse_l2', 'eps': ...}; "
+                                      "pass a plain callable to have the reward evaluated on the host" % (spec,))
+        return float(spec['eps']), None
+    if not callable(reward_fun):
+        raise TypeError('reward_fun must be callable (config.py:158-159) or carry a .spec')
+    return 0.0, reward_fun
 
 
 def upload_plan(n, ep, t, u_her, u_off, buf=None, ttr=None, out_row=None):
@@ -65,7 +71,7 @@ class HerSampler:
         self.nb_tasks = len(tasks_ag_id)
         self.tasks_ag_id, self.tasks_g_id = tasks_ag_id, tasks_g_id
         self.tasks = _lib.make_tasks(tasks_ag_id, tasks_g_id)
-        self.reward_eps = _reward_spec(reward_fun)
+        self.reward_eps, self.host_reward = _reward_spec(reward_fun)
         self.reward_fun = reward_fun
         self.multiple_buffers = ('buffer' in task_replay) or task_replay == 'hand_designed'   # her.py:94-97
         if flat:
@@ -105,6 +111,21 @@ class HerSampler:
         P.flat_reward = int(self.flat)
         return P
 
+    def apply_host_reward(self, batch, layout):
+        """her.py:166-176 on the host: r = reward_fun(ag_2, g, task_descr, info) for a staged batch (float64 like the
+        reference's buffers), written into the batch's r column.  `batch` must hold the un-clipped relabelled goals."""
+        if self.host_reward is None:
+            return
+        info_keys = [k for k in layout.batch_cols if k.startswith('info_')]
+        names = ['ag_2', 'g'] + (['task_descr'] if 'task_descr' in layout.batch_cols and not self.flat else [])
+        views = layout.batch_views(batch, names + info_keys)
+        host = {k: v.cpu().numpy().astype(np.float64) for k, v in views.items()}
+        kw = {k: host[k] for k in names}
+        kw['info'] = {k.replace('info_', ''): host[k] for k in info_keys}
+        r = np.asarray(self.host_reward(**kw), dtype=np.float32).reshape(batch.shape[0], 1)
+        off = layout.batch_cols['r'][0]
+        batch[:, off:off + 1].copy_(torch.from_numpy(r))
+
     def __call__(self, episode_batch, batch_size_in_transitions, task_to_replay=None, cp_proba=None):
         layout = episode_batch.layout if isinstance(episode_batch, EpisodeViews) else None
         if layout is None:
@@ -122,6 +143,7 @@ class HerSampler:
         plan = upload_plan(B, ep, t, u_her, u_off, ttr=ttr)
         batch = torch.empty([B, layout.batch_stride], dtype=torch.float32, device=records.device)
         ops.her_sample(records, 0, layout, self.tasks, self.params(), B, batch, plan=plan)
+        self.apply_host_reward(batch, layout)
         out = TransitionBatch()
         keys = [k for k in episode_batch.keys()] + ['r']
         if 'o_2' not in episode_batch:

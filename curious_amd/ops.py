@@ -163,6 +163,39 @@ def ddpg_update(cfg, theta_main, theta_target, batch, layout, B, workspace, grad
                                     C.byref(A), nb, current_stream()), 'curious_ddpg_update')
 
 
+def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsilon):
+    f = np.float32
+    A = _lib.AdamState()
+    A.m, A.v = ptr(_dev(m, 'm')), ptr(_dev(v, 'v'))
+    A.alpha_tab = ptr(alpha_tab)
+    A.tab_base, A.tab_len = int(tab_base), int(alpha_tab.shape[0]) if alpha_tab is not None else 0
+    A.alpha_Q, A.alpha_pi = float(alpha_Q), float(alpha_pi)
+    A.beta1, A.one_minus_beta1 = float(f(beta1)), float(f(1 - beta1))
+    A.beta2, A.one_minus_beta2 = float(f(beta2)), float(f(1 - beta2))
+    A.epsilon = float(f(epsilon))
+    return A
+
+
+def ddpg_update_experts(cfg, n_experts, expert_stride, seed_stride, theta_main, theta_target, batch, layout, B,
+                        workspace, grad, out_losses, out_Q_pi, m, v, step_ctr, alpha_tab, tab_base, next_batch, storage,
+                        buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08):
+    """One update of n_experts agents in one launch sequence (curious_ddpg_update_experts).  Every tensor is expert
+    0's view of a slab [n_experts, expert_stride]; `rng` is expert 0's sampler description."""
+    BL = layout.c_batch_layout()
+    A = _adam_state(m, v, alpha_tab, tab_base, 0.0, 0.0, beta1, beta2, epsilon)
+    L = layout.c_layout()
+    N = _lib.NextBatch()
+    N.storage, N.buf_stride = ptr(_dev(storage, 'storage')), int(buf_stride)
+    N.L, N.tasks, N.P, N.rng = C.pointer(L), C.pointer(tasks), C.pointer(params), C.pointer(rng)
+    N.batch = ptr(_dev(next_batch, 'next_batch'))
+    check(lib().curious_ddpg_update_experts(C.byref(cfg), int(n_experts), int(expert_stride),
+                                            int(seed_stride) & 0xFFFFFFFFFFFFFFFF,
+                                            ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
+                                            ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),
+                                            ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr), C.byref(A), C.byref(N),
+                                            current_stream()), 'curious_ddpg_update_experts')
+
+
 def policy_forward(cfg, theta, o, g, td, n, clip_obs, workspace, out_pi, out_Q=None, ag=None,
                    relative_goals=False, o_stats=None, g_stats=None):
     _dev(o, 'o')

@@ -33,6 +33,7 @@ class ReplayPool:
         self.storage = torch.empty([n_buffers, self.capacity, layout.T + 1, layout.row_stride],
                                    dtype=torch.float32, device=_device())
         self.buf_stride = self.capacity * layout.rec_floats
+        self.version = 0          # bumped by every store / clear: agents sharing the pool re-draw their staged batches
 
 
 class EpisodeViews(OrderedDict):
@@ -122,6 +123,7 @@ class ReplayBuffer:
         src = torch.as_tensor(np.fromiter(last.values(), dtype=np.int32, count=len(last))).to(staging.device)
         dst = torch.as_tensor(np.fromiter(last.keys(), dtype=np.int64, count=len(last))).to(staging.device)
         ops.store_episodes(self.pool.storage, staging, self.layout, src, dst)
+        self.pool.version += 1
 
     def get_current_episode_size(self):
         return self.current_size
@@ -134,6 +136,7 @@ class ReplayBuffer:
 
     def clear_buffer(self):
         self.current_size = 0
+        self.pool.version += 1
 
     def _get_storage_idx(self, inc=None):
         inc = inc or 1

@@ -31,7 +31,8 @@ class RolloutWorker:
         assert self.T > 0
         if goal_selection not in ('random', 'active'):
             raise ValueError("goal_selection must be 'random' or 'active' (rollout.py:37)")
-        self.batched = hasattr(make_env, 'make_batched')
+        # the GPU-resident batched env is multi-task; the flat structure (rollout.py:93-95) runs the generic host loop
+        self.batched = hasattr(make_env, 'make_batched') and structure != 'flat'
         self.rank = dist.rank()
         self.nb_cpu = dist.world_size()
         if self.batched:
@@ -72,8 +73,6 @@ class RolloutWorker:
                 hi = [spec._compute_goal(np.ones([len(ids[i])]), i, eval=False)[0][ids[i]] for i in range(self.nb_tasks)]
                 self.goal_selectors = [SAGG_RIAC(lo[i], hi[i]) for i in range(self.nb_tasks)]
         elif structure == 'flat':
-            if self.batched:
-                raise NotImplementedError('the batched synthetic env is multi-task only')
             for i in range(rollout_batch_size):
                 self.envs[i].unwrapped.set_flat_env()
         self.stochastic_reset = False
@@ -222,6 +221,11 @@ class RolloutWorker:
         B, env = self.rollout_batch_size, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
         tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
+        experts = isinstance(self.policy, (list, tuple))          # task_experts evaluator (rollout.py:212-224)
+        if experts:
+            # the draws are i.i.d., so any order of the envs is the same distribution: sorted by task, every expert's
+            # envs are one contiguous row range of the batched env
+            tasks = np.sort(tasks)
         if self.goal_selection == 'active' and not self.eval:
             # SAGG-RIAC goals live in goal space; reset_task_goal(directly=True) (rollout.py:143) = raw draw x 2 here
             goals = np.stack([2.0 * self.goal_selectors[int(ta)].sample_goal() for ta in tasks]).astype(np.float32)
@@ -230,21 +234,24 @@ class RolloutWorker:
         env.reset_all(tasks, goals)
         self.count += B
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
-        fused = hasattr(self.policy, 'can_act_and_step') and self.policy.can_act_and_step(env, self.compute_Q)
+        if experts:
+            q_sum = self._expert_steps(env, tasks, q_sum)
+        fused = not experts and hasattr(self.policy, 'can_act_and_step') and \
+            self.policy.can_act_and_step(env, self.compute_Q)
         if fused and hasattr(self.policy, 'act_rollout'):
             self.policy.act_rollout(env, self.T, noise_eps=self.noise_eps if not self.exploit else 0.,
                                     random_eps=self.random_eps if not self.exploit else 0.,
                                     use_target_net=self.use_target_net)
         noise_eps = self.noise_eps if not self.exploit else 0.
         random_eps = self.random_eps if not self.exploit else 0.
-        graphed = not fused and hasattr(self.policy, 'can_eval_rollout') and \
+        graphed = not fused and not experts and hasattr(self.policy, 'can_eval_rollout') and \
             self.policy.can_eval_rollout(env, noise_eps, random_eps)
         if graphed:                                              # evaluator / exploit rollouts: one graph replay
             q_acc = self.policy.eval_rollout(env, self.T, use_target_net=self.use_target_net,
                                              compute_Q=self.compute_Q)
             if self.compute_Q:
                 q_sum = q_acc
-        for t in range(self.T if not (graphed or (fused and hasattr(self.policy, 'act_rollout'))) else 0):
+        for t in range(self.T if not (experts or graphed or (fused and hasattr(self.policy, 'act_rollout'))) else 0):
             if fused:
                 self.policy.act_and_step(env, t, noise_eps=self.noise_eps if not self.exploit else 0.,
                                          random_eps=self.random_eps if not self.exploit else 0.,
@@ -277,6 +284,31 @@ class RolloutWorker:
             goals_now = 0.5 * goals                               # the envs' goals on their task slots (goal space)
         self._finish_rollout(successful, successful - 1.0, mean_Q, task_list, goals_now)
         return env.episode_views(), self.CP, self.n_episodes
+
+    def _expert_steps(self, env, tasks, q_sum):
+        """The T acting steps with one expert per task (rollout.py:212-224: policy[task_of_env].get_actions per env):
+        expert j acts on the contiguous rows of the envs that drew task j."""
+        B = self.rollout_batch_size
+        bounds = np.searchsorted(tasks, np.arange(self.nb_tasks + 1))
+        u_all = torch.empty([B, self.dims['u']], dtype=torch.float32, device=env.device)
+        noise_eps = self.noise_eps if not self.exploit else 0.
+        random_eps = self.random_eps if not self.exploit else 0.
+        for t in range(self.T):
+            for j in range(self.nb_tasks):
+                a, b = int(bounds[j]), int(bounds[j + 1])
+                if a == b:
+                    continue
+                out = self.policy[j].get_actions(env.o[a:b], env.ag[a:b], env.g[a:b], task_descr=env.td[a:b],
+                                                 compute_Q=self.compute_Q, noise_eps=noise_eps, random_eps=random_eps,
+                                                 use_target_net=self.use_target_net)
+                if self.compute_Q:
+                    u, Q = out
+                    q_sum += Q.sum() / B
+                else:
+                    u = out
+                u_all[a:b].copy_(u)
+            env.step_all(u_all, t)
+        return q_sum
 
     # ================================================================== statistics, competence, task probabilities
     def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now, goals_now=None):

@@ -250,6 +250,23 @@ int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const f
                         float* out_losses, float* out_Q_pi, int64_t* step_ctr,
                         const curious_adam_state_t* adam, const curious_next_batch_t* next, curious_stream_t stream);
 
+/* Batched task_experts update (BASELINE configs[4]): curious_ddpg_update for n_experts agents of identical shape in
+ * ONE launch sequence (9 launches, grid.z / grid.y carry the expert).  The reference keeps one DDPG per task on shared
+ * buffers and trains them one after the other (train.py:65-121; sampling rule ddpg.py:302-318,335).  Every per-expert
+ * array -- theta_main, theta_target, batch, workspace, grad, out_losses, out_Q_pi, step_ctr, adam->m / v / alpha_tab,
+ * next->batch and the sampling tables of next->rng (prop_prefix, cur_size, buf_alias, buf_task, step_ctr) -- is passed
+ * for expert 0 and lives at the same offset of a per-expert slab; expert e's copy is expert_stride FLOATS (a multiple
+ * of 64) further.  Shared: next->storage, the layouts, tasks, sampler parameters.  Expert e draws its batches with the
+ * Philox key next->rng->seed + e * seed_stride.  Results per expert are bit-identical to curious_ddpg_update on that
+ * expert alone.  Requires the lean route (hidden 256, >= 3 layers, dimu 4, B % 256 == 0, no input normalisation) and
+ * fails with an error otherwise (the caller then updates the experts one by one). */
+int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
+                                uint64_t seed_stride, float* theta_main, const float* theta_target,
+                                const float* batch, const curious_batch_layout_t* BL, int32_t B, float* workspace,
+                                float* grad, float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                                const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                                curious_stream_t stream);
+
 /* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
  * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */
 int curious_polyak_update(float* target, const float* main_, int64_t n, float polyak, float one_minus_polyak,

@@ -1,0 +1,416 @@
+"""Round-2 parity cases on a real MI355X: batched task experts (BASELINE configs[4]), the configs[0] plumbing run
+through launch(), the Arm8 / 1 024-env acting path (configs[2]), reference-format persistence, the host-evaluated reward."""
+import csv
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_agent import T, build_pair, synth_episodes, tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _expert_kit(nb=4, dimo=40, batch_size=256, hidden=256, cap_eps=64):
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    G = 3 * nb
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    tr = 'replay_current_task_buffer'
+    sampler = make_sample_multi_task_her_transitions('her', 4, tr, sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    bufs = make_pooled_buffers(shapes, T * cap_eps, T, sampler, nb + 1, alias_from=5)
+    gamma = 1. - 1. / T
+
+    def make(t_id, use_graph=False, **hooks):
+        from curious_amd.ddpg import DDPG
+        return DDPG(input_dims=dims, hidden=hidden, layers=3,
+                    network_class='curious_amd.actor_critic:MultiTaskActorCritic', polyak=0.95, batch_size=batch_size,
+                    Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1., clip_obs=200.,
+                    scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None, relative_goals=False,
+                    clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                    sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
+                    task_replay=tr, eps_task=0.4, structure='task_experts', t_id=t_id, seed=10 + t_id,
+                    rng_mode='device', use_graph=use_graph, **hooks)
+    return make, bufs, dims, shapes, (ag_ids, g_ids), tr
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_batched_experts_equal_sequential_experts_and_oracle(use_graph):
+    """curious_ddpg_update_experts: N = 4 experts in one launch sequence per update, bit-identical to 4 DDPG(t_id=i)
+    objects updated one after the other (train.py:65-121, ddpg.py:302-318,335); every expert's loss within 1e-5 of the
+    float64 oracle on the batch it drew."""
+    from curious_amd.experts import ExpertBank
+    from oracle.ddpg import OracleDDPG
+    from curious_amd import ops
+    from oracle.ddpg import STAGE_KEYS
+    nb = 4
+    rng = np.random.RandomState(2)
+    ep = synth_episodes(rng, 40, nb, 40)
+    groups = []
+    for batched in (True, False):
+        make, bufs, dims, shapes, ids, tr = _expert_kit()
+        if batched:
+            bank = ExpertBank(lambda t, **h: make(t, use_graph=use_graph, **h), nb)
+            xs = list(bank)
+        else:
+            bank = None
+            xs = [make(t, use_graph=use_graph) for t in range(nb)]
+        np.random.seed(1)
+        xs[0].store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(nb), 40)
+        groups.append((bank, xs))
+    (bank, bx), (_, sx) = groups
+    assert all(b.current_size > 0 for b in bx[0].buffer[1:nb + 1])
+    # identical starting points
+    for a, b in zip(bx, sx):
+        assert torch.equal(a.theta, b.theta) and a.scope == b.scope
+    assert not torch.equal(bx[0].theta, bx[1].theta)                   # experts differ (seed + t_id)
+    n_up = 23                                                          # singles to even parity + 2 chains + singles
+    bank.train_batches(1)
+    for x in sx:
+        x.train_batches(1)
+    # the oracle sees the batch every expert will consume in update 2 (it sits staged now) with the current parameters
+    want = []
+    for e, x in enumerate(bx):
+        batch = [v.cpu().numpy().astype(np.float64) for v in x._layout.batch_views(x._staged, STAGE_KEYS).values()]
+        orc = OracleDDPG(dims, T, [None] * (nb + 1), None, ids[0], ids[1], hidden=256, batch_size=256,
+                         task_replay=tr, structure='task_experts', t_id=e, weight_rng=np.random.RandomState(0),
+                         dtype=np.float64)
+        orc.theta = ops.unpad_params(x.net_cfg, x.theta.cpu().numpy()).astype(np.float64)
+        orc.theta_target = ops.unpad_params(x.net_cfg, x.theta_target.cpu().numpy()).astype(np.float64)
+        want.append(float(orc.grads(batch)['Q_loss']))
+    bank.train_batches(1)
+    for x in sx:
+        x.train_batches(1)
+    for e, x in enumerate(bx):
+        got = float(x._losses[0])
+        assert abs(got - want[e]) <= 1e-5 * abs(want[e]), (e, got, want[e])
+    bank.train_batches(n_up - 2)
+    for x in sx:
+        x.train_batches(n_up - 2)
+    bank.update_target_net()
+    for x in sx:
+        x.update_target_net()
+    torch.cuda.synchronize()
+    assert bank.batched
+    for a, b in zip(bx, sx):
+        assert a.Q_adam.t == b.Q_adam.t == n_up and int(a._step_ctr) == n_up
+        assert torch.equal(a.theta, b.theta) and torch.equal(a._m, b._m) and torch.equal(a._v, b._v)
+        assert torch.equal(a.theta_target, b.theta_target)
+        assert torch.equal(a._staged, b._staged)                       # next batch drawn with the same key
+        assert float(a._losses[0]) == float(b._losses[0]) and torch.equal(a._Q_pi, b._Q_pi)
+    # every expert samples its own buffer and relabels to its own task (ddpg.py:335)
+    for e, x in enumerate(bx):
+        td = x._layout.batch_views(x._staged, ['task_descr'])['task_descr'].cpu().numpy()
+        assert x.proportions[e + 1] == 256
+        assert np.all(td.sum(axis=1) == 1)
+
+
+def test_batched_experts_fall_back_outside_the_lean_route():
+    """Shapes the batched launch does not cover (hidden 64): the bank reports it and updates the experts one by one."""
+    from curious_amd.experts import ExpertBank
+    make, bufs, dims, shapes, ids, tr = _expert_kit(hidden=64, batch_size=64)
+    bank = ExpertBank(lambda t, **h: make(t, **h), 2)
+    ref = [make(t) for t in range(2)]
+    # (the reference experts above share `bufs` with the bank: one store feeds both groups)
+    ep = synth_episodes(np.random.RandomState(3), 20, 4, 40)
+    np.random.seed(1)
+    bank[0].store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(4), 20)
+    bank.train_batches(3)
+    for x in ref:
+        x.train_batches(3)
+    assert not bank.batched
+    for a, b in zip(bank, ref):
+        assert torch.equal(a.theta, b.theta)
+
+
+# progress.csv columns of the reference: train.py:170-193 + ddpg.py:469-479 + rollout.py:451-483
+def _expected_keys(nb, structure):
+    keys = ['epoch', 'test/success_rate', 'test/avg_reward', 'test/mean_Q', 'test/episode', 'train/success_rate',
+            'train/avg_reward', 'train/episode', 'stats_o/mean', 'stats_o/std', 'stats_g/mean', 'stats_g/std', 'Time']
+    if structure in ('curious', 'task_experts'):
+        for i in range(nb):
+            keys += ['train/C_task%d' % i, 'train/CP_task%d' % i, 'train/%%_task%d' % i, 'train/p_task%d' % i,
+                     'test/C_task%d' % i]
+    if structure == 'task_experts':
+        keys.append('IND_TASK_rollout')
+    return set(keys)
+
+
+@pytest.mark.parametrize('structure,extra', [
+    ('curious', dict(task_selection='random')),                       # BASELINE configs[0]
+    ('task_experts', dict(task_selection='random')),
+    ('task_experts', dict(task_selection='random', experts_update='batched')),
+    ('flat', dict(task_selection='random')),
+])
+def test_launch_runs_every_structure_and_logs_the_reference_columns(tmp_path, structure, extra):
+    """experiment.train.launch() end to end (train.py:217-339 -> train() :49-166): configs[0] = num_cpu 1, structure
+    curious, task_selection random, rollout_batch_size 2; plus the other structures the CLI offers."""
+    from curious_amd.experiment import config, train
+    config.CACHED_ENVS.clear()
+    over = dict(rollout_batch_size=2, n_cycles=2, n_batches=5, n_test_rollouts=2, rng_mode='device', use_graph=True,
+                batch_size=256)
+    extra = dict(extra)
+    task_selection = extra.pop('task_selection')
+    over.update(extra)
+    task_replay = 'replay_task_cp_buffer' if structure == 'curious' else \
+        'replay_current_task_buffer' if structure == 'task_experts' else ''
+    if structure == 'flat':
+        over.update(rng_mode='numpy', use_graph=False)
+    best = train.launch(env='MultiTaskFetchArm4-v5', trial_id=0, n_epochs=2, num_cpu=1, seed=5, policy_save_interval=1,
+                        clip_return=1, normalize_obs=False, structure=structure, task_selection=task_selection,
+                        goal_selection='random', goal_replay='her', task_replay=task_replay, save_policies=True,
+                        override_params=over, save_root=str(tmp_path) + '/')
+    assert 0.0 <= best <= 1.0
+    run_dir = os.path.join(str(tmp_path), 'MultiTaskFetchArm4-v5', '0')
+    rows = list(csv.DictReader(open(os.path.join(run_dir, 'progress.csv'))))
+    assert len(rows) == 3                                              # epoch -1 (before training), 0, 1
+    assert set(rows[-1].keys()) == _expected_keys(4, structure)
+    assert [int(float(r['epoch'])) for r in rows] == [-1, 0, 1]
+    assert all(np.isfinite(float(r['stats_o/std'])) for r in rows)
+    # policy_{best,latest,N}.pkl cadence (train.py:195-205) + the weights files next to them
+    for name in ('policy_best.pkl', 'policy_latest.pkl', 'policy_0.pkl', 'policy_1.pkl', 'params.json'):
+        assert os.path.exists(os.path.join(run_dir, name)), name
+    pol = pickle.load(open(os.path.join(run_dir, 'policy_latest.pkl'), 'rb'))
+    first = pol[0] if isinstance(pol, list) else pol
+    assert first.info['env_name'] == 'MultiTaskFetchArm4-v5'          # play.py:27 reads it
+    logger_dir = run_dir
+    assert os.path.exists(os.path.join(logger_dir, 'policy_latest.pkl0_weights.pkl' if isinstance(pol, list)
+                                       else 'policy_latest.pkl_weights.pkl'))
+
+
+@pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 48),
+                                                 ('MultiTaskFetchArm8-v5', 8, 52, 48),
+                                                 ('MultiTaskFetchArm8-v5', 8, 52, 37)])
+def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B):
+    """curious_policy_act_env_step (fwd_l01<1|2> + fwd_hot<DOT> + act_step<PART> when B % 16 == 0, generic kernels
+    otherwise) == get_actions + env.step_all, bit for bit, eager and as a replayed hipGraph -- on both env sizes."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    G = 3 * nb
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    recs = []
+    for mode in ('fused_graph', 'fused_eager', 'unfused'):
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=(mode == 'fused_graph'))
+        if mode == 'unfused':
+            agent.can_act_and_step = lambda env, compute_Q: False
+        w = RolloutWorker(EnvFactory(env_name), agent, dims, logger, T=T, rollout_batch_size=B, noise_eps=0.2,
+                          random_eps=0.3, structure='curious', task_selection='active_competence_progress',
+                          queue_length=6, eval=False)
+        w.seed(5)
+        np.random.seed(8)
+        for _ in range(2):
+            ep, _, _ = w.generate_rollouts()
+        torch.cuda.synchronize()
+        recs.append(ep.records.clone())
+    assert torch.equal(recs[0], recs[1]) and torch.equal(recs[1], recs[2])
+    off_u = w.benv.layout.off['u']
+    u = recs[0][:, :T, off_u:off_u + 4]
+    assert float(u.abs().max()) <= 1.0 and float(u.abs().sum()) > 0
+
+
+def test_arm8_batched_rollout_matches_oracle_env_and_policy():
+    """configs[2] env on the lean acting path (B = 32: fwd_l01<2>, 8 tasks): every step against the oracle env and the
+    oracle policy, like test_batched_rollout_matches_oracle does for Arm4."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    from oracle.env import SyntheticMultiTaskArm
+    nb, dimo, B = 8, 52, 32
+    agent, oracle = build_pair(nb, dimo)
+    dims = dict(o=dimo, u=4, g=24, ag=24, task_descr=nb, info_is_success=1)
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm8-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                      noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='active_competence_progress',
+                      queue_length=4, eval=False)
+    w.seed(77)
+    envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=77, env_id=i) for i in range(B)]
+    np.random.seed(50)
+    rs = np.random.get_state()
+    ep, CP, n_ep = w.generate_rollouts()
+    rec = {k: v.cpu().numpy() for k, v in ep.items()}
+    np.random.set_state(rs)
+    exploit = np.random.random() < 0.1                                 # rollout.py:183-186
+    tasks = np.random.choice(range(nb), p=np.ones(nb) / nb, size=B)
+    goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+    obs = []
+    for i, e in enumerate(envs):
+        e.reset()
+        obs.append(e.reset_task_goal(goals[i], task=int(tasks[i])))
+    o = np.stack([x['observation'] for x in obs])
+    g = np.stack([x['desired_goal'] for x in obs])
+    td = np.stack([x['mask'] for x in obs])
+    np.testing.assert_array_equal(rec['o'][:, 0], o)
+    for t in range(T):
+        ne, re = (0., 0.) if exploit else (0.2, 0.3)
+        ou = oracle.get_actions(o, o[:, :24], g, task_descr=td, noise_eps=ne, random_eps=re)
+        np.testing.assert_allclose(rec['u'][:, t], ou, rtol=1e-4, atol=2e-5)
+        res = [e.step(rec['u'][i, t]) for i, e in enumerate(envs)]
+        o = np.stack([r[0]['observation'] for r in res])
+        np.testing.assert_array_equal(rec['o'][:, t + 1], o)
+        np.testing.assert_array_equal(rec['task_descr'][:, t], td)
+        np.testing.assert_array_equal(rec['info_is_success'][:, t, 0],
+                                      np.array([r[3]['is_success'] for r in res], np.float32))
+
+
+def test_1024_env_rollout_store_and_update_properties():
+    """configs[2] at its stated size: 1 024 GPU-resident Arm8 envs, CP-driven task selection, per-task CP buffers.
+    Size-independent properties: record consistency (o/ag chain, change flag, one-hot task, goal on the task's slots),
+    routing (every stored episode sits in the buffers of the tasks it changed), finite updates."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    nb, dimo, B = 8, 52, 1024
+    agent, _ = build_pair(nb, dimo, cap_eps=4096, rng_mode='device', use_graph=True)
+    dims = dict(o=dimo, u=4, g=24, ag=24, task_descr=nb, info_is_success=1)
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm8-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                      noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='active_competence_progress',
+                      queue_length=300, eval=False)
+    w.seed(3)
+    np.random.seed(4)
+    for cycle in range(3):
+        ep, cp, n_ep = w.generate_rollouts()
+        rec = {k: v.cpu().numpy() for k, v in ep.items()}
+        assert rec['o'].shape == (B, T + 1, dimo) and rec['u'].shape == (B, T, 4)
+        np.testing.assert_array_equal(rec['ag'], rec['o'][:, :, :24])          # achieved goal = object coordinates
+        np.testing.assert_array_equal(rec['change'] != 0, np.abs(rec['ag'][:, :1] - rec['ag'][:, 1:]) > 1e-3)
+        assert np.all(rec['task_descr'].sum(axis=2) == 1) and np.all(np.abs(rec['u']) <= 1)
+        task = rec['task_descr'][:, 0].argmax(axis=1)
+        for i in (0, 511, 1023):
+            off_task = np.ones(24, bool)
+            off_task[3 * task[i]:3 * task[i] + 3] = False
+            assert np.all(rec['g'][i][:, off_task] == 0)
+        sizes0 = [b.current_size for b in agent.buffer[1:6]]
+        agent.store_episode(ep, cp, n_ep)
+        active = (rec['change'][:, -1].reshape(B, nb, 3) != 0).any(axis=2)
+        grew = [b.current_size - s for b, s in zip(agent.buffer[1:6], sizes0)]
+        assert grew == [int(active[:, j].sum()) for j in range(5)]            # only tasks j < 5 are routed (ddpg.py:183)
+        cl, _ = agent.train_batches(20)
+        agent.update_target_net()
+    torch.cuda.synchronize()
+    assert n_ep == 3 * B and np.isfinite(float(cl)) and bool(torch.isfinite(agent.theta).all())
+
+
+def test_reference_format_weights_and_pickle_round_trip(tmp_path):
+    """save_weights / load_weights (ddpg.py:481-509): pickled list of lists in the order main/Q, main/pi, target/Q,
+    target/pi, o_stats, g_stats with the TF variable shapes; pickle.dumps(policy) (ddpg.py:511-537) reloads a policy that
+    acts identically and keeps its constructor arguments."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    agent, _ = build_pair(4, 40, rng_mode='device', use_graph=True)
+    ep = synth_episodes(np.random.RandomState(5), 30, 4, 40)
+    np.random.seed(1)
+    agent.store_episode({k: v.copy() for k, v in ep.items()}, np.array([0.2, 0.1, 0., 0.3]), 30)
+    agent.train_batches(12)
+    agent.update_target_net()
+    path = str(tmp_path / 'policy_latest.pkl')
+    agent.save_weights(path)
+    saved = pickle.load(open(path + '_weights.pkl', 'rb'))
+    H, O, N, G, U = 256, 40, 4, 12, 4
+    q_shapes = [(O + N + U, H), (H,), (G, H), (H, H), (H,), (H, H), (H,), (H, 1), (1,)]
+    pi_shapes = [(O + N, H), (H,), (G, H), (H, H), (H,), (H, H), (H,), (H, U), (U,)]
+    assert [len(x) for x in saved] == [9, 9, 9, 9, 5, 5]
+    assert [a.shape for a in saved[0]] == q_shapes and [a.shape for a in saved[2]] == q_shapes
+    assert [a.shape for a in saved[1]] == pi_shapes and [a.shape for a in saved[3]] == pi_shapes
+    assert [a.shape for a in saved[4]] == [(O,), (O,), (1,), (O,), (O,)]      # sum, sumsq, count, mean, std
+    assert [a.shape for a in saved[5]] == [(G,), (G,), (1,), (G,), (G,)]
+    assert not np.array_equal(saved[0][3], saved[2][3])                       # main and target differ after training
+    fresh, _ = build_pair(4, 40, rng_mode='device', use_graph=True, seed=99)
+    assert not torch.equal(fresh.theta, agent.theta)
+    fresh.load_weights(path)
+    assert torch.equal(fresh.theta, agent.theta) and torch.equal(fresh.theta_target, agent.theta_target)
+    assert torch.equal(fresh.o_stats.state, agent.o_stats.state) and torch.equal(fresh.g_stats.state, agent.g_stats.state)
+    # pickled policy: same actions, constructor arguments kept (use_graph used to be dropped by a substring filter)
+    clone = pickle.loads(pickle.dumps(agent))
+    assert clone.use_graph is True and clone.rng_mode == 'device' and clone.scope == agent.scope
+    assert clone.buffer is None if hasattr(clone, 'buffer') else True
+    rng = np.random.RandomState(1)
+    o, g = rng.randn(7, 40).astype(np.float32), rng.randn(7, 12).astype(np.float32)
+    td = np.eye(4, dtype=np.float32)[rng.randint(4, size=7)]
+    u1, q1 = agent.get_actions(o, o[:, :12], g, task_descr=td, compute_Q=True)
+    u2, q2 = clone.get_actions(o, o[:, :12], g, task_descr=td, compute_Q=True)
+    np.testing.assert_array_equal(u1, u2)
+    np.testing.assert_array_equal(q1, q2)
+    # RolloutWorker.save_policy (rollout.py:425-433) writes both files and surfaces errors
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dict(o=40, u=4, g=12, ag=12, task_descr=4,
+                      info_is_success=1), logger, T=T, rollout_batch_size=4, structure='curious', eval=True)
+    p2 = str(tmp_path / 'policy_best.pkl')
+    w.save_policy(p2)
+    assert os.path.exists(p2) and os.path.exists(p2 + '_weights.pkl')
+    with pytest.raises(Exception):
+        w.save_policy(str(tmp_path / 'no_such_dir' / 'x.pkl'))
+
+
+def test_host_evaluated_reward_matches_the_kernel_reward():
+    """Real-env adapter (config.py:158-159, her.py:166-176): a reward_fun without .spec is evaluated on the host per
+    sampled batch.  With the synthetic env's own compute_reward as that callable, batches and losses must equal the
+    kernel-evaluated path bit for bit; a different reward (dense negative distance) flows through unchanged."""
+    from curious_amd.ddpg import DDPG
+    from curious_amd.envs import SyntheticArmEnv, sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    nb, dimo = 4, 40
+    G = 12
+    ag_ids, g_ids = tables(nb)
+    env = SyntheticArmEnv('MultiTaskFetchArm4-v5')
+    calls = []
+
+    def host_sparse(ag_2, g, task_descr=None, info=None):
+        calls.append((ag_2.dtype, g.shape, sorted(info.keys())))
+        return env.compute_reward(achieved_goal=ag_2, goal=g, task_descr=task_descr, info=info)
+
+    def host_dense(ag_2, g, task_descr=None, info=None):
+        t = task_descr.argmax(axis=1)
+        return -np.stack([np.linalg.norm(ag_2[i, 3 * t[i]:3 * t[i] + 3] - g[i, 3 * t[i]:3 * t[i] + 3])
+                          for i in range(len(t))]).reshape(-1, 1)
+
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    gamma = 1. - 1. / T
+    agents = []
+    for rf in (sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)), host_sparse, host_dense):
+        sampler = make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer', rf, tasks_ag_id=ag_ids,
+                                                         tasks_g_id=g_ids)
+        bufs = make_pooled_buffers(shapes, T * 64, T, sampler, nb + 1, alias_from=5)
+        agents.append(DDPG(input_dims=dims, hidden=256, layers=3,
+                           network_class='curious_amd.actor_critic:MultiTaskActorCritic', polyak=0.95, batch_size=256,
+                           Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1., clip_obs=200.,
+                           scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None, relative_goals=False,
+                           clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                           sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids,
+                           tasks_g_id=g_ids, task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious',
+                           rng_mode='numpy', seed=3))
+    ep = synth_episodes(np.random.RandomState(6), 30, nb, dimo)
+    cp = np.array([0.3, 0.1, 0.0, 0.2])
+    for a in agents:
+        np.random.seed(1)
+        a.store_episode({k: v.copy() for k, v in ep.items()}, cp, 30)
+    outs = []
+    for a in agents:
+        np.random.seed(2)
+        b = [x.cpu().numpy() for x in a.sample_batch()]
+        np.random.seed(3)
+        cl, _ = a.train()
+        outs.append((b, float(cl)))
+    kern, hs, hd = outs
+    for x, y in zip(kern[0], hs[0]):
+        np.testing.assert_array_equal(x, y)
+    assert kern[1] == hs[1]
+    assert calls and calls[0][0] == np.float64 and calls[0][2] == ['is_success']
+    assert set(np.unique(kern[0][7])) <= {0.0, -1.0}
+    for x, y in zip(kern[0][:7], hd[0][:7]):                          # everything but r is the same batch
+        np.testing.assert_array_equal(x, y)
+    r = hd[0][7]
+    assert r.shape == (256, 1) and np.all(r <= 0) and len(np.unique(r)) > 10 and np.isfinite(hd[1])
+    # ReplayBuffer.sample (replay_buffer.py:37-55) goes through the same host call
+    np.random.seed(4)
+    tr = agents[2].buffer[1].sample(32, task_to_replay=0)
+    assert len(np.unique(tr['r'].cpu().numpy())) > 4
