@@ -42,6 +42,14 @@ def parse():
     ap.add_argument('--env', default=ENV, help='diagnostic: another synthetic env (the headline is %s)' % ENV)
     ap.add_argument('--phases', action='store_true', help='diagnostic: time rollout / store / updates separately '
                                                             '(adds device syncs; not the headline number)')
+    ap.add_argument('--rollout-batch-size', type=int, default=B_R,
+                    help='diagnostic: parallel rollouts per GPU (configs[2]: --env MultiTaskFetchArm8-v5 with 1024)')
+    ap.add_argument('--structure', default='curious', choices=['curious', 'task_experts'],
+                    help="diagnostic: 'task_experts' = BASELINE configs[4], every expert updated in one batched launch "
+                         "sequence per update (curious_ddpg_update_experts)")
+    ap.add_argument('--cpu-ranks', type=int, default=-1,
+                    help='ranks of the multi-process CPU baseline (default min(19, host cores); 0 = skip)')
+    ap.add_argument('--cpu-rank-worker', type=int, nargs=4, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -52,14 +60,14 @@ def maybe_relaunch(args):
         sys.exit(subprocess.call(cmd))
 
 
-def build_job(use_graph, seed=0, env=None):
+def build_job(use_graph, seed=0, env=None, b_r=B_R):
     from curious_amd import dist, logger
     from curious_amd.experiment import config
     from curious_amd.rollout import RolloutWorker
     params = dict(config.MULTI_TASK_PARAMS)
     params.update(env_name=env or ENV, task_selection='active_competence_progress', goal_selection='random',
                   task_replay='replay_task_cp_buffer', goal_replay='her', structure='curious', normalize_obs=False,
-                  num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=B_R,
+                  num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=b_r,
                   n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = False
@@ -67,13 +75,50 @@ def build_job(use_graph, seed=0, env=None):
     dims = config.configure_dims(params)
     buffers = config.configure_buffer(dims=dims, params=params)
     policy = config.configure_ddpg(dims=dims, params=params, buffers=buffers, clip_return=True)
-    worker = RolloutWorker(params['make_env'], policy, dims, logger, T=params['T'], rollout_batch_size=B_R,
+    worker = RolloutWorker(params['make_env'], policy, dims, logger, T=params['T'], rollout_batch_size=b_r,
                            exploit=False, use_target_net=False, compute_Q=False, noise_eps=params['noise_eps'],
                            random_eps=params['random_eps'], structure='curious',
                            task_selection='active_competence_progress', goal_selection='random',
                            queue_length=params['queue_length'], eval=False)
     worker.seed(seed + 1000000 * dist.rank())
     return params, dims, policy, worker
+
+
+def build_experts_job(use_graph, seed=0, env=None, b_r=B_R):
+    """BASELINE configs[4]: one expert per task on shared per-task buffers (train.py:285-291), all updated together."""
+    from curious_amd import dist, logger
+    from curious_amd.experiment import config
+    from curious_amd.experts import ExpertBank
+    from curious_amd.rollout import RolloutWorker
+    params = dict(config.MULTI_TASK_PARAMS)
+    params.update(env_name=env or ENV, task_selection='random', goal_selection='random',
+                  task_replay='replay_current_task_buffer', goal_replay='her', structure='task_experts',
+                  normalize_obs=False, num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed,
+                  rollout_batch_size=b_r, n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
+    params = config.prepare_params(params)
+    params['ddpg_params']['normalize_obs'] = False
+    params['ddpg_params']['seed'] = seed
+    dims = config.configure_dims(params)
+    buffers = config.configure_buffer(dims=dims, params=params)
+    bank = ExpertBank(lambda i, **hooks: config.configure_ddpg(dims=dims, params=params, buffers=buffers,
+                                                               clip_return=True, t_id=i, **hooks), params['nb_tasks'])
+    workers = [RolloutWorker(params['make_env'], bank[i], dims, logger, T=params['T'], rollout_batch_size=b_r,
+                             exploit=False, use_target_net=False, compute_Q=False, noise_eps=params['noise_eps'],
+                             random_eps=params['random_eps'], structure='task_experts', task_selection='random',
+                             goal_selection='random', queue_length=params['queue_length'], eval=False, unique_task=i)
+               for i in range(params['nb_tasks'])]
+    for i, w in enumerate(workers):
+        w.seed(seed + 1000000 * dist.rank() + i)
+    return params, dims, bank, workers
+
+
+def experts_cycle(bank, workers, k):
+    """One cycle of train.py:96-103 for the expert whose turn it is, with the update of ALL experts batched."""
+    i = k % len(workers)
+    episode, cp, n_ep = workers[i].generate_rollouts()
+    bank[i].store_episode(episode, cp, n_ep)
+    bank.train_batches(N_BATCHES)
+    bank.update_target_net()
 
 
 def prefill(policy, n_eps, seed):
@@ -124,7 +169,7 @@ def cycle(policy, worker):
     policy.update_target_net()
 
 
-def kernel_flops_bytes(policy, lay):
+def kernel_flops_bytes(policy, lay, B_R=B_R):
     """ALGORITHMIC work of one launch of each kernel class in one update / one rollout step."""
     c = policy
     B, H, nl, U = c.batch_size, c.hidden, c.layers, c.dimu
@@ -199,7 +244,9 @@ def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
     the bytes of 16-byte-per-lane streaming reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
     try:
         with open(path) as f:
             table = json.load(f)
@@ -217,7 +264,7 @@ def pmc_traffic(kernel):
 
 
 def roofline(policy, worker, stats, n_cycles, overhead_ms):
-    work = kernel_flops_bytes(policy, policy._layout)
+    work = kernel_flops_bytes(policy, policy._layout, worker.rollout_batch_size)
     cal = {k: (v[0], max(v[1] - v[0] * overhead_ms, 0.0)) for k, v in stats.items() if v[0] > 0}
     if not cal:
         return None, {}
@@ -320,9 +367,136 @@ def cpu_baseline(seed=0, budget_s=20.0):
                        % (cycles, t_roll, t_store, t_train))
 
 
+def cpu_rank_worker(rank, world, port, budget_s):
+    """One rank of the multi-process CPU baseline (SURVEY 8d ii): the reference's own regime -- one single-threaded
+    process per rank (util.py:155-160), rollout_batch_size 2 and batch 256 per rank (config.py:70-73), gradients SUMMED
+    over ranks before Adam (mpi_adam.py:26-28), normaliser sums averaged over ranks (normalizer.py:84-94) -- with gloo
+    standing in for MPI.  Prints one JSON line (cycles, seconds)."""
+    os.environ.update(OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import numpy as np
+    import torch
+    import torch.distributed as td
+    from oracle import her as oher
+    from oracle.ddpg import OracleDDPG
+    from oracle.env import SyntheticMultiTaskArm
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    from oracle.reward import make_reward_fun
+    torch.set_num_threads(1)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+
+    def allreduce_sum(x):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t.numpy()
+
+    nb, dimo, T, b_r = 4, 40, 50, 2
+    G = 3 * nb
+    ids = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(nb)]
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    np.random.seed(1000000 * rank)                                  # train.py:242
+    sampler = oher.make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer', make_reward_fun(ids, ids),
+                                                          tasks_ag_id=ids, tasks_g_id=ids)
+    bufs = [OBuf(shapes, 2048 * T, T, sampler) for _ in range(nb + 1)]
+    agent = OracleDDPG(dims, T, bufs, sampler, ids, ids, batch_size=BATCH, weight_rng=np.random.RandomState(0),
+                       allreduce_sum=allreduce_sum, comm_size=world)
+    envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=0, env_id=rank * b_r + i) for i in range(b_r)]
+
+    def rollout():
+        tasks = np.random.choice(range(nb), size=b_r)
+        goals = np.random.uniform(-1, 1, (b_r, 3)).astype(np.float32)
+        obs = []
+        for i, e in enumerate(envs):
+            e.reset()
+            obs.append(e.reset_task_goal(goals[i], int(tasks[i])))
+        o = np.stack([x['observation'] for x in obs])
+        g = np.stack([x['desired_goal'] for x in obs])
+        tdm = np.stack([x['mask'] for x in obs])
+        ep = dict(o=[o.copy()], ag=[o[:, :G].copy()], u=[], g=[], task_descr=[], change=[], info_is_success=[])
+        ag0 = o[:, :G].copy()
+        for t in range(T):
+            u = agent.get_actions(o, o[:, :G], g, task_descr=tdm, noise_eps=0.2, random_eps=0.3).reshape(b_r, 4)
+            res = [e.step(u[i]) for i, e in enumerate(envs)]
+            o = np.stack([r[0]['observation'] for r in res])
+            ep['u'].append(u.astype(np.float32)); ep['g'].append(g.copy()); ep['task_descr'].append(tdm.copy())
+            ep['change'].append(np.abs(ag0 - o[:, :G]) > 1e-3)
+            ep['info_is_success'].append(np.array([[r[3]['is_success']] for r in res], np.float32))
+            ep['o'].append(o.copy()); ep['ag'].append(o[:, :G].copy())
+        return {k: np.array(v).swapaxes(0, 1) for k, v in ep.items()}
+
+    # a few stored episodes per rank before the clock starts, so that every per-task buffer can be sampled
+    for _ in range(3):
+        agent.store_episode({k: v.astype(np.float64) for k, v in rollout().items()}, np.zeros(nb), 0)
+    td.barrier()
+    t0 = time.time()
+    cycles = 0
+    go = torch.ones(1)
+    while True:
+        ep = rollout()
+        agent.store_episode({k: v.astype(np.float64) for k, v in ep.items()}, np.zeros(nb), 0)
+        for _ in range(N_BATCHES):
+            agent.train()
+        agent.update_target_net()
+        cycles += 1
+        go[0] = 1.0 if time.time() - t0 < budget_s else 0.0       # rank 0 decides, everybody stops together
+        td.broadcast(go, src=0)
+        if go[0] == 0:
+            break
+    td.barrier()
+    elapsed = time.time() - t0
+    if rank == 0:
+        print(json.dumps(dict(cycles=cycles, seconds=elapsed)), flush=True)
+    td.destroy_process_group()
+
+
+def cpu_baseline_ranks(n_ranks, budget_s=12.0):
+    """R single-threaded oracle processes with summed gradients (the reference's 19-rank MPI regime, readme.md:16), as
+    child processes of this script; returns the aggregate rates."""
+    port = 29700 + os.getpid() % 200
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-rank-worker', str(r), str(n_ranks),
+                               str(port), str(int(budget_s))], stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1',
+                                                                  CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES=''))
+             for r in range(n_ranks)]
+    try:
+        out, _ = procs[0].communicate(timeout=budget_s * 6 + 120)
+        for p in procs[1:]:
+            p.wait(timeout=60)
+        rec = json.loads(out.decode().strip().splitlines()[-1])
+    except Exception as err:                                        # a baseline leg must never sink the bench line
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return dict(error='%s: %s' % (type(err).__name__, err), cores=n_ranks)
+    total = rec['seconds']
+    return dict(value=round(n_ranks * rec['cycles'] * N_BATCHES * BATCH / total, 1), unit='HER grad transitions/s',
+                env_steps_per_sec=round(n_ranks * rec['cycles'] * 2 * 50 / total, 1), cores=n_ranks, kind='port',
+                sample='%d cycles per rank of the NumPy oracle on %d single-threaded processes (per rank: 2 rollouts x '
+                       'T=50, 100 updates of batch 256; gradients summed and normaliser sums averaged over ranks with gloo '
+                       'in place of MPI), %.1f s' % (rec['cycles'], n_ranks, total))
+
+
+def teardown(policies, bank=None):
+    """Captured graphs hold the communicator's streams: drop them before the process group goes, then leave through the
+    normal interpreter exit (curious_amd.experiment.train.shutdown)."""
+    from curious_amd.experiment.train import shutdown
+    shutdown(policies, bank)
+
+
 def main():
     args = parse()
+    if args.cpu_rank_worker is not None:
+        cpu_rank_worker(*args.cpu_rank_worker)
+        return
     maybe_relaunch(args)
+    # the CPU legs run first, before this process touches the GPU (rank 0 of a one-GPU run only)
+    cpu = None
+    if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+        n_ranks = min(19, os.cpu_count() or 1) if args.cpu_ranks < 0 else args.cpu_ranks
+        if n_ranks >= 2:
+            cpu['ranks'] = cpu_baseline_ranks(n_ranks)
     import numpy as np
     import torch
     from curious_amd import dist, ops
@@ -331,17 +505,32 @@ def main():
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
     torch.cuda.set_device(dist.local_device_index())
     np.random.seed(1234 + 1000000 * rank)                        # train.py:242
-    params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env)
-    prefill(policy, args.prefill, seed=rank)
+    b_r = args.rollout_batch_size
+    experts = args.structure == 'task_experts'
+    if experts:
+        params, dims, bank, workers = build_experts_job(use_graph=not args.no_graph, env=args.env, b_r=b_r)
+        prefill(bank[0], args.prefill, seed=rank)                 # the buffers are shared by the experts
+        counter = [0]
+
+        def step():
+            experts_cycle(bank, workers, counter[0])
+            counter[0] += 1
+        policy, worker = bank[0], workers[0]
+    else:
+        params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=b_r)
+        prefill(policy, args.prefill, seed=rank)
+
+        def step():
+            cycle(policy, worker)
 
     for _ in range(args.warmup):
-        cycle(policy, worker)
+        step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cycle(policy, worker)
+        step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -352,7 +541,7 @@ def main():
     elapsed = float(el)
 
     phases = None
-    if args.phases:
+    if args.phases and not experts:
         tr = ts = tu = 0.0
         for _ in range(5):
             torch.cuda.synchronize(); a = time.perf_counter()
@@ -368,42 +557,53 @@ def main():
                       updates_ms=round(tu / 5 * 1e3, 3))
 
     # per-kernel HIP-event timing of the same cycle (eager launches; events cannot sit inside a replayed hipGraph)
-    prof_cycles = 1
-    stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles)
-    roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms)
+    roof, table = None, {}
+    if not experts:
+        prof_cycles = 1
+        stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles)
+        roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms)
 
-    out = None
     if rank == 0:
         T = params['T']
+        n_pol = len(bank) if experts else 1
+        headline = (args.env == ENV and b_r == B_R and not experts)
+        workload = ('%s, %d parallel rollouts x T=%d per GPU, HER future k=4, batch %d, %d updates per cycle, %d per-task '
+                    'buffers' % (args.env, b_r, T, BATCH, N_BATCHES, policy.nb_tasks + 1))
+        if headline:
+            workload += ' (configs[1])'
+        elif experts:
+            workload += ('; structure=task_experts: %d experts, every update applies to all of them in one batched launch '
+                         'sequence (configs[4], diagnostic)' % n_pol)
+        else:
+            workload += ' (diagnostic, not the headline configuration)'
         out = {
-            'metric': 'HER-sampled gradient transitions/sec (+ env_steps_per_sec), MultiTaskFetchArm4-v5 cycle',
-            'value': round(args.steps * N_BATCHES * BATCH * world / elapsed, 1),
+            'metric': 'HER-sampled gradient transitions/sec (+ env_steps_per_sec), %s cycle' % args.env,
+            'value': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed, 1),
             'unit': 'transitions/s',
-            'env_steps_per_sec': round(args.steps * B_R * T * world / elapsed, 1),
-            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES / elapsed, 1),
+            'env_steps_per_sec': round(args.steps * b_r * T * world / elapsed, 1),
+            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES * n_pol / elapsed, 1),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'MultiTaskFetchArm4-v5, 256 parallel rollouts x T=50 per GPU, HER future k=4, '
-                                   'batch 256, 100 updates per cycle, 5 per-task buffers (configs[1])',
+            'config': {'workload': workload,
                        'step': 'one cycle: rollout + store_episode + 100 x train() + update_target_net',
-                       'rollout_batch_size': B_R, 'batch_size': BATCH, 'n_batches': N_BATCHES,
+                       'rollout_batch_size': b_r, 'batch_size': BATCH, 'n_batches': N_BATCHES,
                        'hipgraph': not args.no_graph, 'rng': 'device (Philox)',
                        'parallelism': 'dp%d' % world},
             'roofline': roof,
             # SURVEY 8d whole-update figure: 47 213 algorithmic bytes per gradient transition (HER rows + 40 B/param)
             'step_hbm': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS * world,
-                         'achieved': round(args.steps * N_BATCHES * BATCH * world / elapsed * 47213 / 1e9, 2),
-                         'frac': round(args.steps * N_BATCHES * BATCH / elapsed * 47213 / 1e9 / HBM_PEAK_GBS, 5)},
+                         'achieved': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed * 47213 / 1e9, 2),
+                         'frac': round(args.steps * N_BATCHES * BATCH * n_pol / elapsed * 47213 / 1e9 / HBM_PEAK_GBS, 5)},
             'kernels': table,
         }
         if phases:
             out['phases'] = phases
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
-    dist.barrier()
+    teardown(list(bank) if experts else [policy], bank if experts else None)
 
 
 if __name__ == '__main__':

@@ -209,6 +209,19 @@ struct Chain {
 
 static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) && (K % 256 == 0); }
 
+// XCD-aware block placement of the 256 x 256 hidden-layer launches (mlp_lean_gemm.h tile_ids): rows-per-unit 0 (plain
+// grid), 4 or 8; CURIOUS_XCD_MAP overrides the default for A/B measurements.
+static int xcd_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CURIOUS_XCD_MAP");
+    v = e ? atoi(e) : 0;
+    if (v != 4 && v != 8) v = 0;
+  }
+  return v;
+}
+template <int XR> static dim3 xcd_grid(int nprob) { return dim3(8, 4 * XR, (nprob * (16 / XR) + 7) / 8); }
+
 // Batched experts (mlp_common.h "Ex"): nex agents per launch, slabs `stride` floats apart.
 struct ExDim { int nex = 1; int64_t stride = 0; };
 static Ex make_ex(const ExDim& d, int nprob) {
@@ -298,11 +311,16 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
       dim3 grid(H / 64, M / 16, nch * xd.nex);
       const Ex ex = make_ex(xd, nch);
       { ProfScope ps__(CK_FWD_LAYER, st);
+        const int xr = (!exb && M == 256 && H == 256) ? xcd_rows() : 0;
         if (want_dot) {
           if (exb) hipLaunchKernelGGL((fwd_hot_kernel<true, true>), grid, dim3(256), 0, st, a, ex);
+          else if (xr == 8) hipLaunchKernelGGL((fwd_hot_kernel<true, false, 8>), xcd_grid<8>(nch), dim3(256), 0, st, a, ex);
+          else if (xr == 4) hipLaunchKernelGGL((fwd_hot_kernel<true, false, 4>), xcd_grid<4>(nch), dim3(256), 0, st, a, ex);
           else hipLaunchKernelGGL((fwd_hot_kernel<true, false>), grid, dim3(256), 0, st, a, ex);
         } else {
           if (exb) hipLaunchKernelGGL((fwd_hot_kernel<false, true>), grid, dim3(256), 0, st, a, ex);
+          else if (xr == 8) hipLaunchKernelGGL((fwd_hot_kernel<false, false, 8>), xcd_grid<8>(nch), dim3(256), 0, st, a, ex);
+          else if (xr == 4) hipLaunchKernelGGL((fwd_hot_kernel<false, false, 4>), xcd_grid<4>(nch), dim3(256), 0, st, a, ex);
           else hipLaunchKernelGGL((fwd_hot_kernel<false, false>), grid, dim3(256), 0, st, a, ex);
         } }
       CURIOUS_LAUNCH_CHECK("fwd_hot_kernel");
@@ -684,11 +702,16 @@ int DdpgPass::critic_backward() {
       dim3 grid(H / 64, B / 16, 2 * xd.nex);
       const Ex ex = make_ex(xd, 2);
       { ProfScope ps__(CK_DX, st);
+        const int xr = (xd.nex == 1 && B == 256 && H == 256) ? xcd_rows() : 0;
         if (use_part && l == 1) {
           if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<true, true>), grid, dim3(256), 0, st, ha, ex);
+          else if (xr == 8) hipLaunchKernelGGL((dx_hot_kernel<true, false, 8>), xcd_grid<8>(2), dim3(256), 0, st, ha, ex);
+          else if (xr == 4) hipLaunchKernelGGL((dx_hot_kernel<true, false, 4>), xcd_grid<4>(2), dim3(256), 0, st, ha, ex);
           else hipLaunchKernelGGL((dx_hot_kernel<true, false>), grid, dim3(256), 0, st, ha, ex);
         } else {
           if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<false, true>), grid, dim3(256), 0, st, ha, ex);
+          else if (xr == 8) hipLaunchKernelGGL((dx_hot_kernel<false, false, 8>), xcd_grid<8>(2), dim3(256), 0, st, ha, ex);
+          else if (xr == 4) hipLaunchKernelGGL((dx_hot_kernel<false, false, 4>), xcd_grid<4>(2), dim3(256), 0, st, ha, ex);
           else hipLaunchKernelGGL((dx_hot_kernel<false, false>), grid, dim3(256), 0, st, ha, ex);
         } }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel");
@@ -756,8 +779,11 @@ int DdpgPass::actor_backward() {
       p.C = w.dact[2][l - 1]; p.ldc = H; p.M = B; p.N = H; p.K = H;
       dim3 grid(H / 64, B / 16, xd.nex);
       const Ex ex = make_ex(xd, 1);
+      const int xr = (xd.nex == 1 && B == 256 && H == 256) ? xcd_rows() : 0;
       { ProfScope ps__(CK_DX, st);
         if (xd.nex > 1) hipLaunchKernelGGL((dx_hot_kernel<false, true>), grid, dim3(256), 0, st, ha, ex);
+        else if (xr == 8) hipLaunchKernelGGL((dx_hot_kernel<false, false, 8>), xcd_grid<8>(1), dim3(256), 0, st, ha, ex);
+        else if (xr == 4) hipLaunchKernelGGL((dx_hot_kernel<false, false, 4>), xcd_grid<4>(1), dim3(256), 0, st, ha, ex);
         else hipLaunchKernelGGL((dx_hot_kernel<false, false>), grid, dim3(256), 0, st, ha, ex); }
       CURIOUS_LAUNCH_CHECK("dx_hot_kernel(actor)");
       continue;

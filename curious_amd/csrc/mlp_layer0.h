@@ -100,7 +100,12 @@ __global__ __launch_bounds__(256) void fwd_l0_kernel(L0Args args) {
 // (the action-free pre-activations of fwd_pi_kernel).
 struct L01Prob { L0Prob l0; const float* W1; const float* b1; float* C; };
 struct L01Args { L01Prob p[3]; L0Prob pre[2]; int32_t n01; };
-#define H0_LD 260      // LDS row stride of the h0 tile: 260 % 64 = 4 -> the 16 rows of a b128 read hit distinct banks
+// LDS row stride of the h0 tile.  A ds_read_b128 is served in 4 groups of 16 lanes (MI355X_MICROARCH.md, LDS), each
+// lane covering 4 of the 64 banks; lane (j = row, q) reads dwords j * H0_LD + 4 q + const.  With 264 (= 8 mod 64) the 16
+// lanes of every group land on 16 disjoint bank quads and the 8-lane groups of the b128 tile stores stay conflict free
+// too; 260 left a 2-way conflict in every read group (SQ_LDS_BANK_CONFLICT = 11 % of this kernel's LDS cycles in
+// profiles/r01_pmc_sq_counters.json).
+#define H0_LD 264
 
 template <int NC>
 __device__ inline void fwd_l01_body(const L01Prob& Q, float* red, float* h0s, const int64_t eo) {

@@ -70,7 +70,23 @@ struct GemmHot {
   // dot_mode 1: D = 1, w = dot_w[c];  2: D = 4, w = dot_w[c * 4 + d];  3: D = 4, w = dot_w[d * dot_ld + c]
   const float* dot_w; float* dot_out; int32_t dot_mode, dot_ld;
 };
-struct HotArgs { GemmHot p[3]; };
+struct HotArgs { GemmHot p[4]; };       // <= 3 problems; p[3] stays zeroed (the XCD-aware grids below index it)
+
+// Block id -> (column tile, row block, problem).  XR == 0: the plain grid (N/64, M/16, nprob).  XR == 4 / 8 (M == 256,
+// N == 256 only): XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs in linear block-id order, so with
+// grid (8, 4 * XR, rounds) blockIdx.x IS the XCD (speed only -- nothing depends on it for correctness).  A "unit" = XR
+// consecutive row blocks x all 4 column tiles of one problem lives on one XCD: its activation rows are fetched into
+// that XCD's L2 once instead of four times, its weight matrix 16 / XR times instead of twice per column tile.  Units
+// beyond the last problem read the zeroed descriptor and exit.
+template <int XR>
+__device__ __forceinline__ void tile_ids(int& bx, int& by, int& pz) {
+  if (XR == 0) { bx = blockIdx.x; by = blockIdx.y; pz = blockIdx.z; return; }
+  constexpr int UPC = 16 / (XR ? XR : 1);                  // units per problem at M = 256
+  const int unit = blockIdx.x + 8 * blockIdx.z;
+  pz = unit / UPC;
+  bx = blockIdx.y & 3;
+  by = (unit % UPC) * XR + (blockIdx.y >> 2);
+}
 
 __device__ inline void hot_store(float* red, const f32x4 acc[4], int wave, int q, int j, int tid, f32x4& v, int& orow,
                                  int& c4) {
@@ -113,13 +129,16 @@ __device__ inline void dot_epilogue(const GemmHot& P, const DotW& d, const f32x4
 }
 
 // C[M,N] = relu(A[M,K] . B[K,N] + bias)        grid (N/64, M/16, nprob)
-template <bool DOT, bool EX>
+template <bool DOT, bool EX, int XR = 0>
 __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   int64_t eo;
-  const GemmHot& P = args.p[ex_decode<EX>(ex, blockIdx.z, eo)];
+  int bx, by, bz;
+  tile_ids<XR>(bx, by, bz);
+  const GemmHot& P = args.p[ex_decode<EX>(ex, bz, eo)];
+  if (XR != 0 && P.A == nullptr) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+  const int m0 = by * 16, n0 = bx * 64;
   const float* xr = P.A + eo + (int64_t)(m0 + j) * P.lda;
   const float* wc = P.B + eo + n0 + 4 * j;
   const f32x4 bias = ldv(P.aux + eo + n0 + 4 * (tid & 15));      // epilogue operand, issued with the first batch
@@ -149,17 +168,20 @@ __global__ __launch_bounds__(256) void fwd_hot_kernel(HotArgs args, Ex ex) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   *reinterpret_cast<f32x4*>(P.C + eo + (int64_t)(m0 + orow) * P.ldc + n0 + 4 * c4) = v;
-  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4, eo);
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, bx, c4, eo);
 }
 
 // C[M,K'] = (A[M,N] . B[K',N]^T) * relu'(aux[M,K'])    (K' = P.N output columns, reduction over P.K)   grid (K'/64, M/16, nprob)
-template <bool DOT, bool EX>
+template <bool DOT, bool EX, int XR = 0>
 __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   int64_t eo;
-  const GemmHot& P = args.p[ex_decode<EX>(ex, blockIdx.z, eo)];
+  int bx, by, bz;
+  tile_ids<XR>(bx, by, bz);
+  const GemmHot& P = args.p[ex_decode<EX>(ex, bz, eo)];
+  if (XR != 0 && P.A == nullptr) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+  const int m0 = by * 16, k0 = bx * 64;
   const float* dyr = P.A + eo + (int64_t)(m0 + j) * P.lda;
   const float* wr = P.B + eo + (int64_t)(k0 + 4 * j) * P.ldb;
   const int64_t o = eo + (int64_t)(m0 + (tid >> 4)) * P.ldc + k0 + 4 * (tid & 15);
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (h[e] > 0.f) ? v[e] : 0.f;
   *reinterpret_cast<f32x4*>(P.C + o) = v;
-  if (DOT) dot_epilogue(P, dw, v, m0 + orow, blockIdx.x, c4, eo);
+  if (DOT) dot_epilogue(P, dw, v, m0 + orow, bx, c4, eo);
 }
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list

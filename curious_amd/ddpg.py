@@ -540,9 +540,7 @@ class DDPG(object):
     def _update(self, Q_grad=None, pi_grad=None, use_table=False):
         """Both MpiAdam.update calls of ddpg.py:246-248 as one all-reduce + one kernel over [theta_Q | theta_pi]."""
         if self.Q_adam.t % 100 == 0:
-            self.Q_adam.theta = self.theta                           # checksum over the fused vector (C4)
-            MpiAdam.check_synced(self.Q_adam)
-            self.Q_adam.theta = self.theta[:self.off_pi]
+            self._check_synced()                                     # C4
         dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
         self.Q_adam.t += 1
         self.pi_adam.t += 1
@@ -840,10 +838,37 @@ class DDPG(object):
         self.pi_adam.t += n
         return self._losses[0], self._Q_pi
 
-    def _check_synced(self):
-        self.Q_adam.theta = self.theta                               # checksum over the fused vector (C4)
-        MpiAdam.check_synced(self.Q_adam)
-        self.Q_adam.theta = self.theta[:self.off_pi]
+    def _check_synced(self, wait=False):
+        """mpi_adam.py:42-50 (every 100 updates) off the critical path: a 128-bit checksum of the fused parameter vector
+        and rank 0's copy of it go to pinned host memory asynchronously; the comparison happens at the NEXT check (or at
+        finish_sync_checks()), when the copy has long completed -- no host wait inside the update loop."""
+        if not dist.is_distributed():
+            return
+        self.finish_sync_checks()
+        if getattr(self, '_sync_buf', None) is None:
+            self._sync_buf = (torch.zeros(2, dtype=torch.int64, device=self.device),
+                              torch.zeros(2, dtype=torch.int64, device=self.device),
+                              torch.zeros(4, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        mine, root, host, ev = self._sync_buf
+        ops.param_checksum(self.theta, mine)
+        root.copy_(mine)
+        dist.broadcast_(root, 0)
+        host[:2].copy_(mine, non_blocking=True)
+        host[2:].copy_(root, non_blocking=True)
+        ev.record()
+        self._sync_pending = self.Q_adam.t
+        if wait:
+            self.finish_sync_checks()
+
+    def finish_sync_checks(self):
+        t = getattr(self, '_sync_pending', None)
+        if t is None:
+            return
+        _, _, host, ev = self._sync_buf
+        ev.synchronize()
+        self._sync_pending = None
+        assert torch.equal(host[:2], host[2:]), \
+            'parameters diverged between ranks (rank %d, detected at update %d)' % (dist.rank(), t)
 
     def _train_device(self, k):
         """k updates of the device-resident loop.  Single rank: each update is curious_ddpg_update -- gradients, Adam in

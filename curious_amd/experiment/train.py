@@ -225,11 +225,32 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     evaluator = RolloutWorker(params['make_env'], policy, dims, logger, **eval_params)
     evaluator.seed(rank_seed + 100)
 
-    return train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
+    best = train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
                  n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],
                  n_batches=params['n_batches'], perturbation_study=perturb, policy_save_interval=policy_save_interval,
                  save_policies=save_policies, structure=structure, task_selection=task_selection, params=params,
                  expert_bank=expert_bank)
+    shutdown(policy if isinstance(policy, list) else [policy], expert_bank)
+    return best
+
+
+def shutdown(policies, expert_bank=None):
+    """End of a job: last divergence check, then drop every captured graph BEFORE the process group goes away (graphs
+    reference the communicator's streams), so that the interpreter exits normally."""
+    import gc
+    for p in policies:
+        p.finish_sync_checks()
+        p._graph = p._graph_b = p._graph_ba = p._graph_chain = None
+        p._graphs = [None, None]
+        p._roll_graphs = {}
+    if expert_bank is not None:
+        expert_bank._graphs = {}
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist.is_distributed():
+        dist.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def main(argv=None):

@@ -34,11 +34,15 @@ def _worker(rank, world, port, fn_name, out):
         torch.distributed.destroy_process_group()
 
 
-def run2(fn_name):
+def run_world(fn_name, world):
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, fn_name, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, fn_name, out), nprocs=world, join=True)
     return dict(out)
+
+
+def run2(fn_name):
+    return run_world(fn_name, 2)
 
 
 # ------------------------------------------------------------------ collectives
@@ -191,3 +195,67 @@ def _distinct_seed_check(rank, world):
 def test_rank_seeds_differ():
     out = run2('_distinct_seed_check')
     assert out[1][0] != out[1][1] and out[0][0] == out[0][1]
+
+
+# ------------------------------------------------------------------ world sizes 4 and 8 (the 1/2/4/8-GPU job shapes)
+def _dp_exchanges(rank, world):
+    """The three exchange steps of the data-parallel path at a given world size: C1+C2 gradient SUM on the fused
+    vector (mpi_adam.py:26), C5 normaliser accumulators averaged over ranks (normalizer.py:84-94) through the oracle
+    normaliser wired to curious_amd.dist, C9 competence all-gather feeding identical queues on every rank
+    (rollout.py:332-356 -> RolloutWorker._finish_rollout)."""
+    from curious_amd import dist, logger
+    from curious_amd.rollout import RolloutWorker
+    from oracle.normalizer import Normalizer
+    from oracle.env import SyntheticMultiTaskArm
+
+    def allreduce(x):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        dist.allreduce_sum_(t)
+        return t.numpy()
+    rng = np.random.RandomState(100 + rank)
+    g = torch.from_numpy(rng.randn(294_661 // 64).astype(np.float32))
+    g_local = g.clone()
+    dist.allreduce_sum_(g)
+    nz = Normalizer(5, 0.01, 5.0, allreduce, world)
+    rows = rng.randn(10 + rank, 5)                                   # ranks contribute different row counts
+    nz.update(rows)
+    nz.recompute_stats()
+    nb, dimo, T, B = 4, 40, 5, 3
+
+    class Pol:
+        def get_actions(self, o, ag, g, **kw):
+            return np.zeros([o.shape[0], 4], np.float32)
+    counter = [0]
+
+    def make_env():
+        e = SyntheticMultiTaskArm(nb, dimo, T, seed=rank, env_id=rank * 100 + counter[0])
+        counter[0] += 1
+        return e
+    np.random.seed(9 + 1000000 * rank)
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    w = RolloutWorker(make_env, Pol(), dims, logger, T=T, rollout_batch_size=B, structure='curious',
+                      task_selection='active_competence_progress', queue_length=4, eval=False)
+    for _ in range(25):
+        w.generate_rollouts()
+    return dict(g=g.numpy().copy(), g_local=g_local.numpy().copy(), rows=rows, mean=nz.mean.copy(), std=nz.std.copy(),
+                count=float(nz.count[0]), CP=np.asarray(w.CP).copy(), C=np.asarray(w.C).copy(), n_ep=w.n_episodes,
+                qsizes=[q.size for q in w.competence_computers])
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_exchange_steps_at_world_4_and_8(world):
+    out = run_world('_dp_exchanges', world)
+    total = np.sum([out[r]['g_local'].astype(np.float64) for r in range(world)], axis=0)
+    for r in range(world):
+        np.testing.assert_array_equal(out[r]['g'], out[0]['g'])                  # replicas agree bit for bit
+        np.testing.assert_allclose(out[r]['g'], total, rtol=1e-6, atol=1e-6)     # and hold the SUM, not the mean
+        np.testing.assert_array_equal(out[r]['mean'], out[0]['mean'])
+        np.testing.assert_array_equal(out[r]['CP'], out[0]['CP'])
+        np.testing.assert_array_equal(out[r]['C'], out[0]['C'])
+        assert out[r]['qsizes'] == out[0]['qsizes'] and out[r]['n_ep'] == 25 * 3 * world
+    # normaliser: count = 1 + mean over ranks of the local counts, sums likewise (normalizer.py:37-39,84-94)
+    counts = [out[r]['rows'].shape[0] for r in range(world)]
+    assert out[0]['count'] == pytest.approx(1.0 + np.mean(counts), rel=1e-6)
+    s = np.mean([out[r]['rows'].astype(np.float32).sum(axis=0) for r in range(world)], axis=0)
+    np.testing.assert_allclose(out[0]['mean'], s / out[0]['count'], rtol=1e-5, atol=1e-6)
+    assert sum(out[0]['qsizes']) > 0

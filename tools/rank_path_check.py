@@ -31,9 +31,9 @@ def main():
             f.write(line)
     sys.stdout.write(line)
     sys.stdout.flush()
-    # skip interpreter teardown: destroying an RCCL communicator while captured graphs still reference its streams
-    # aborts now and then on this stack, and nothing here needs a clean shutdown
-    os._exit(0)
+    # clean shutdown: captured graphs are dropped before the process group is destroyed
+    from curious_amd.experiment.train import shutdown
+    shutdown([policy])
 
 
 if __name__ == '__main__':
