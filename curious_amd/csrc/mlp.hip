@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mlp_lean_gemm.h"
 #include "mlp_layer0.h"
 #include "mlp_heads.h"
+#include "mlp_rows.h"
 
 // ================================================================== host side
 struct NetOff {
@@ -521,6 +522,8 @@ struct DdpgPass {
   bool fuse_pi, use_part, dx_hot, fuse_crit;
 
   int setup(curious_stream_t stream);
+  bool rows_route() const;
+  int rows_pass();
   int forward();
   int critic_backward();
   int actor_backward();
@@ -554,6 +557,72 @@ int DdpgPass::setup(curious_stream_t stream) {
   nxt = cur;
   nxt.o = batch + BL->off_o2;            // target nets see (o_2, g_2) (ddpg.py:427-431)
   nxt.g = batch + BL->off_g2;
+  return 0;
+}
+
+// The row-local route (mlp_rows.h): forward + backward in one launch.  CURIOUS_ROWS=0 keeps the tiled 8-launch route
+// (A/B measurements, and the reference point of the parity tests between the two routes).
+static bool rows_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CURIOUS_ROWS");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0;
+}
+
+bool DdpgPass::rows_route() const {
+  return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % ROWS_R == 0) &&
+         !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= XLD && aligned16(thQ) && aligned16(thPi) &&
+         aligned16(ttQ) && aligned16(ttPi) && aligned16(workspace) && (offQ.Wout % 4 == 0) && (offPi.Wout % 4 == 0) &&
+         ((cfg->dimo + cfg->dimtd) % 4 == 0) && (cfg->dimg % 4 == 0);
+}
+
+static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
+  RowsNet n;
+  memset(&n, 0, sizeof(n));
+  n.th = th; n.W0 = (int32_t)o.W0; n.b0 = (int32_t)o.b0; n.Wg = (int32_t)o.Wg; n.Wout = (int32_t)o.Wout;
+  n.bout = (int32_t)o.bout;
+  for (int l = 1; l < nl; ++l) { n.W[l] = (int32_t)o.W[l]; n.b[l] = (int32_t)o.b[l]; }
+  return n;
+}
+
+int DdpgPass::rows_pass() {
+  RowsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tQ = rows_net(ttQ, offQ, nl); a.tPi = rows_net(ttPi, offPi, nl);
+  a.mQ = rows_net(thQ, offQ, nl); a.mPi = rows_net(thPi, offPi, nl);
+  a.batch = batch; a.ld = ld;
+  a.off_o = BL->off_o; a.off_td = BL->off_td; a.off_u = BL->off_u; a.off_g = BL->off_g; a.off_o2 = BL->off_o2;
+  a.off_g2 = BL->off_g2; a.off_r = BL->off_r;
+  for (int l = 0; l < nl; ++l) {
+    a.actc[l] = w.act[1][l]; a.dactc[l] = w.dact[0][l];
+    a.acta[l] = w.act[2][l]; a.dacta[l] = w.dact[2][l];
+  }
+  a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
+  a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
+  a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
+  a.max_u = cfg->max_u;
+  a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+  const Ex ex = make_ex(xd, 1);
+  const size_t lds = rows_lds_floats(nl) * sizeof(float);
+  static bool lds_set = false;
+  if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_set = true;
+  }
+  dim3 grid(B / ROWS_R, 2, xd.nex);
+  { ProfScope ps__(CK_ROWS, st);
+    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
+    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }
+  CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");
+  // what weight_grads() reads of the tiled route's state
+  dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
+  fuse_pi = use_part = fuse_crit = false;
+  urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);
   return 0;
 }
 
@@ -943,9 +1012,13 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   p.o_stats = o_stats; p.g_stats = g_stats; p.workspace = workspace; p.grad = grad; p.out_losses = out_losses;
   p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
   int rc = p.setup(stream);
-  if (!rc) rc = p.forward();
-  if (!rc) rc = p.critic_backward();
-  if (!rc) rc = p.actor_backward();
+  if (!rc && p.rows_route()) {
+    rc = p.rows_pass();
+  } else {
+    if (!rc) rc = p.forward();
+    if (!rc) rc = p.critic_backward();
+    if (!rc) rc = p.actor_backward();
+  }
   if (!rc) rc = p.weight_grads(tail);
   return rc;
 }

@@ -1,0 +1,494 @@
+// Row-local DDPG pass: the whole forward / backward chain of one update in ONE launch (included by mlp.hip).
+//
+// Replaces the 8 dependent launches fwd_l01 -> fwd_hot -> fwd_pi -> fwd_hot -> dx_crit -> dx_hot -> dx_actor -> dx_hot
+// (DESIGN.md section 4).  Those kernels split every 256 x 256 layer over 64 workgroups and pay a kernel boundary
+// (1.5 us) plus a cold start (~3 us) per layer.  Here a workgroup owns FOUR batch rows and walks all layers of its
+// networks by itself: activations never leave the CU (LDS), nothing is exchanged between workgroups, and the only
+// per-layer cost is streaming the layer's 256 KB of weights L2 -> CU (tools/rowchain_lab.hip: 2.3-2.9 us per layer).
+// Two kinds of workgroup per row group, both 2 * (layers - 1) hidden-layer applications deep forward + backward:
+//   critic side: target actor -> target critic(pi') -> Q';  main critic(u) -> Q, loss terms, dQ;  backward of critic(u)
+//   actor side:  main actor -> pi;  main critic(pi) -> Q_pi;  backward through critic(pi) into the action slot -> dz;
+//                backward of the actor
+// (ddpg.py:419-449 for the graph, actor_critic.py:51-98 / util.py:73-107 for the networks.)  Everything the weight-
+// gradient launch needs -- layer inputs, masked output gradients, dQ, dz, per-row loss terms -- is written to the same
+// workspace arrays the tiled kernels fill, so dw_adam_her_kernel / dw_all_kernel run unchanged afterwards.
+//
+// Matrix instruction: v_mfma_f32_4x4x1_16b_f32 = 16 independent blocks of (4 rows x 4 columns, K = 1), exact f32 FMA.
+//   forward  (h . W):   lane l supplies A = h[l & 3][k] and B = W[k][4 l + e]; accumulator e holds columns {4 l + e}
+//                       of the 4 rows; the 4 waves split k (64 each) and meet in LDS.  One 16-byte load of W[k][4l..]
+//                       feeds 4 instructions; a wave instruction reads one contiguous 1 KB row.
+//   backward (dY . W^T): lane l = (bn, bk, j) supplies B = W[64 w + 16 a + 4 bk + j][n] for n = 16 c + 4 bn + s: wave w
+//                       owns output columns 64 w .. 64 w + 63 over all n, the four bn classes split n inside the wave
+//                       (their partial sums meet in LDS); a wave instruction reads 16 weight rows x 64 contiguous bytes.
+#pragma once
+
+#define ROWS_MAXL 4          // layers per network on this route (layer 0 + up to 3 hidden layers)
+#define ROWS_R 4             // batch rows per workgroup
+#define RLD 264              // LDS row stride of an activation row (8 mod 64: conflict-free b128 broadcast reads)
+#define XLD 96               // LDS row stride of the layer-0 input row [o | td | action | g]
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+struct RowsNet {             // one network: parameter base + float offsets of its pieces (NetOff)
+  const float* th;
+  int32_t W0, b0, Wg, Wout, bout;
+  int32_t W[ROWS_MAXL], b[ROWS_MAXL];
+};
+struct RowsArgs {
+  RowsNet tQ, tPi, mQ, mPi;
+  const float* batch;
+  int32_t ld, off_o, off_td, off_u, off_g, off_o2, off_g2, off_r;
+  float* actc[ROWS_MAXL]; float* dactc[ROWS_MAXL];     // main critic(u): layer outputs, masked output gradients [B,H]
+  float* acta[ROWS_MAXL]; float* dacta[ROWS_MAXL];     // main actor
+  float* dQ; float* dz; float* rows; float* out_Qpi;
+  int64_t* step_ctr;
+  int32_t B, nl, dimo, dimtd, dimg;
+  float gamma, clip_lo, clip_hi, max_u, l2c;
+  unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [2][32] s_memtime stamps of row group 0, else NULL
+};
+#define ROWS_STAMP(k)                                                                                   \
+  do {                                                                                                  \
+    if (a.stamps && blockIdx.x == 0 && x.tid == 0) a.stamps[blockIdx.y * 32 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+
+struct RCtx {
+  float* hs; float* part; float* xin; float* sm; float* keep;
+  float* stage;              // this wave's private staging area of the backward layers: [2][64 rows][SLD]
+  int tid, wave, lane, r0;
+};
+#define SLD 36               // LDS row stride of a staged 32-wide weight-row chunk (36 l mod 64 hits 16 distinct bank quads)
+
+// ---- weight fragments of one 16-deep chunk (forward) / one 64-wide n super-chunk (backward)
+__device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int wave, int lane, int c) {
+  const float* p = W + (int64_t)(64 * wave + 16 * c) * 256 + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b[i] = ldv(p + (int64_t)i * 256);
+}
+// backward chunk c (n = 32 c .. 32 c + 31) of this wave's 64 weight rows: instruction r8 fetches rows 8 r8 .. 8 r8 + 7,
+// 8 lanes x 16 bytes = 128 contiguous bytes per row
+__device__ __forceinline__ void rows_bw_load(f32x4* g /*[8]*/, const float* W, int wave, int lane, int c) {
+  const float* p = W + (int64_t)(64 * wave + (lane >> 3)) * 256 + 32 * c + 4 * (lane & 7);
+#pragma unroll
+  for (int r8 = 0; r8 < 8; ++r8) g[r8] = ldv(p + (int64_t)(8 * r8) * 256);
+}
+
+// ---- what a layer routine loads ahead for its successor (weights do not depend on activations): the successor's
+// first chunk lands in wb[0] while this layer's last chunk is multiplied / its epilogue runs
+enum { RN_NONE = 0, RN_FWD = 1, RN_BWD = 2, RN_L0 = 3 };
+struct RNext { int kind; const float* W; int S; const float* Wg; int nk; };     // RN_L0: W = W0
+__device__ __forceinline__ RNext rnext(int kind, const float* W, int S = 0, const float* Wg = nullptr, int nk = 0) {
+  RNext n;
+  n.kind = kind; n.W = W; n.S = S; n.Wg = Wg; n.nk = nk;
+  return n;
+}
+// layer-0 rows of the virtual k = 4 (t0 + t) + wave, t = 0..15 (rows past the end are clamped to row 0 and ignored)
+__device__ __forceinline__ void rows_l0_load(f32x4 (&b)[16], const float* W0, int S, const float* Wg, int nk, int wave,
+                                             int lane, int t0) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int kv = 4 * (t0 + t) + wave;
+    const int kc = (kv < nk) ? kv : 0;
+    const float* p = (kc < S) ? W0 + (int64_t)kc * 256 : Wg + (int64_t)(kc - S) * 256;
+    b[t] = ldv(p + 4 * lane);
+  }
+}
+__device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, int wave, int lane) {
+  if (n.kind == RN_FWD) rows_fw_load(b, n.W, wave, lane, 0);
+  else if (n.kind == RN_BWD) { rows_bw_load(&b[0], n.W, wave, lane, 0); rows_bw_load(&b[8], n.W, wave, lane, 1); }
+  else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
+}
+__device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c,
+                                            f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * RLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA4(a[s], b[4 * kq + s][e], acc[e]);
+  }
+}
+// ---- epilogues: partial tiles -> LDS -> finished rows (next layer's input in hs, optional copies)
+// forward: acc[e][r] = partial of out[row r][column 4 lane + e] over this wave's k quarter
+// bv = bias[tid], loaded by the caller at the start of the layer (not here: its latency would be exposed)
+__device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[4], const float bv, float* keep,
+                                               float* gout) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    *reinterpret_cast<f32x4*>(x.part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = (x.part[(0 * 4 + r) * 256 + x.tid] + x.part[(1 * 4 + r) * 256 + x.tid]) +
+              (x.part[(2 * 4 + r) * 256 + x.tid] + x.part[(3 * 4 + r) * 256 + x.tid]);
+    s = fmaxf(s + bv, 0.f);
+    x.hs[r * RLD + x.tid] = s;
+    if (keep) keep[r * 256 + x.tid] = s;
+    if (gout) gout[(int64_t)(x.r0 + r) * 256 + x.tid] = s;
+  }
+  __syncthreads();
+}
+// ---- one 256 x 256 hidden layer, forward: hs <- relu(hs . W + bias)
+// (the first chunk of W is already in flight into wb[0]: rows_prefetch of the predecessor)
+__device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* bias,
+                                             float* keep, float* gout, const RNext& next) {
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const float bv = bias[x.tid];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < 3) rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
+    else rows_prefetch(wb[0], next, x.wave, x.lane);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
+  }
+  rows_fw_finish(x, acc, bv, keep, gout);
+}
+// ---- one 256 x 256 hidden layer, backward: hs <- (hs . W^T) * relu'(mask).
+// dX[i][k] = sum_n dY[i][n] W[k][n]: the matrix instruction wants lane l to supply W[k_l][n] for ONE n per instruction,
+// memory offers W[k][n .. n+3] contiguously -- a direct 16-byte load per lane makes every quad of lanes touch 4
+// different rows (measured: 2.5x the forward layer's time).  So the wave's 64 weight rows (= its 64 output columns, over
+// ALL n: no partial sums between waves) are staged through a private LDS tile: coalesced global loads (8 rows x 128 B
+// per instruction) -> ds_write_b128 rows of SLD floats -> every lane reads back ITS row (conflict free), one
+// ds_read_b128 = the B operands of four instructions.  Four accumulators take n mod 4 so that no instruction waits on
+// its predecessor.  (RN_BWD prefetch = chunks 0 and 1 in wb[0][0..7] / wb[0][8..15].)
+__device__ __forceinline__ void rows_big_bwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* mask,
+                                             float* gout, const RNext& next) {
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  float* const st = x.stage;
+  const int wrow = (x.lane >> 3) * SLD + 4 * (x.lane & 7);           // where this lane's 16 bytes of a fetched row go
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    f32x4* g = &wb[0][8 * (c & 1)];
+    float* buf = st + (c & 1) * 64 * SLD;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<f32x4*>(buf + 8 * r8 * SLD + wrow) = g[r8];
+    if (c + 2 < 8) rows_bw_load(g, W, x.wave, x.lane, c + 2);
+    else if (c == 7) rows_prefetch(wb[0], next, x.wave, x.lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(buf + x.lane * SLD + 4 * q);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x.hs + (x.lane & 3) * RLD + 32 * c + 4 * q);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc[s2] = MFMA4(a[s2], b[s2], acc[s2]);
+    }
+  }
+  // lane l owns column 64 wave + l of the 4 rows
+  const int col = 64 * x.wave + x.lane;
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+    o[i] = (mask[i * 256 + col] > 0.f) ? v : 0.f;
+  }
+  __syncthreads();                                           // every wave has read its dY operands out of hs
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x.hs[i * RLD + col] = o[i];
+    if (gout) gout[(int64_t)(x.r0 + i) * 256 + col] = o[i];
+  }
+  __syncthreads();
+}
+
+// ---- layer 0: hs <- relu(x . W0 + g . Wg + b0).  The input row in LDS is xin[i] = [o | td | action slot | g]: the first
+// S entries meet the S rows of W0 (S excludes the action slot for an actor), the G entries from `gofs` on meet Wg
+// (util.py:79-92).  Wave w takes the virtual k = 4 t + w of the concatenation.
+__device__ __forceinline__ void rows_l0_mac(const RCtx& x, const f32x4 (&b)[16], int S, int nk, int gofs, int t0,
+                                            f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int kv = 4 * (t0 + t) + x.wave;
+    const bool ok = kv < nk;
+    const int kc = ok ? kv : 0;
+    const float v = x.xin[(x.lane & 3) * XLD + ((kc < S) ? kc : gofs + (kc - S))];
+    const float av = ok ? v : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = MFMA4(av, b[t][e], acc[e]);
+  }
+}
+// (rows t < 16 are already in flight into wb[0]; a second pass covers inputs wider than 64)
+__device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W0, int S, const float* Wg,
+                                            int G, int gofs, const float* bias, float* keep, float* gout,
+                                            const RNext& next) {
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const float bv = bias[x.tid];
+  const int nk = S + G;
+  const bool two = nk > 64;
+  if (two) rows_l0_load(wb[1], W0, S, Wg, nk, x.wave, x.lane, 16);
+  __builtin_amdgcn_sched_barrier(0);
+  rows_l0_mac(x, wb[0], S, nk, gofs, 0, acc);
+  rows_prefetch(wb[0], next, x.wave, x.lane);
+  __builtin_amdgcn_sched_barrier(0);
+  if (two) rows_l0_mac(x, wb[1], S, nk, gofs, 16, acc);
+  rows_fw_finish(x, acc, bv, keep, gout);
+}
+
+// ---- output layers: wave i finishes batch row r0 + i; the result is uniform over the wave
+template <int D>
+__device__ __forceinline__ void rows_head(const RCtx& x, const float* Wout, float (&out)[D]) {
+  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+  if (D == 1) {
+    const f32x4 w = ldv(Wout + 4 * x.lane);
+    out[0] = wave_sum(h4[0] * w[0] + h4[1] * w[1] + h4[2] * w[2] + h4[3] * w[3]);
+  } else {
+    f32x4 w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = ldv(Wout + (int64_t)(4 * x.lane + e) * 4);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      out[d] = wave_sum(h4[0] * w[0][d] + h4[1] * w[1][d] + h4[2] * w[2][d] + h4[3] * w[3][d]);
+  }
+}
+
+// layer-0 input rows of the workgroup's 4 batch rows: xin[i] = [o | td | action slot | g]; the action slot receives
+// the batch action / max_u (actor_critic.py:96) when with_u, else it is filled later from the actor's output
+__device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& a, const float* batch, int off_o,
+                                                 int off_g, bool with_u) {
+  const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
+  for (int idx = x.tid; idx < 4 * tot; idx += 256) {
+    const int i = idx / tot, k = idx - i * tot;
+    const float* row = batch + (int64_t)(x.r0 + i) * a.ld;
+    float v;
+    if (k < a.dimo) v = row[off_o + k];
+    else if (k < Sa) v = row[a.off_td + (k - a.dimo)];
+    else if (k < S) v = with_u ? fdiv(row[a.off_u + (k - Sa)], a.max_u) : 0.f;
+    else v = row[off_g + (k - S)];
+    x.xin[i * XLD + k] = v;
+  }
+}
+
+// hidden layers 1 .. nl-1 of a network, forward; which: 0 nothing stored, 1 -> a.actc[l], 2 -> a.acta[l]
+// (the kernarg arrays are indexed in place: handing their address around would copy the struct to scratch memory)
+// `after` = what follows the network's last hidden layer
+__device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
+                                                const float* th, float* keep0, int which, int64_t eo,
+                                                const RNext& after) {
+  for (int l = 1; l < a.nl; ++l) {
+    float* g = (which == 1) ? a.actc[l] + eo : (which == 2) ? a.acta[l] + eo : nullptr;
+    const RNext nx = (l + 1 < a.nl) ? rnext(RN_FWD, th + N.W[l + 1]) : after;
+    rows_big_fwd(x, wb, th + N.W[l], th + N.b[l], keep0 ? keep0 + l * 1024 : nullptr, g, nx);
+  }
+}
+// hidden layers nl-1 .. 1 of a network, backward; which: 0 nothing stored, 1 -> a.dactc[l-1], 2 -> a.dacta[l-1]
+__device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
+                                                const float* th, const float* keep0, int which, int64_t eo,
+                                                const RNext& after) {
+  for (int l = a.nl - 1; l >= 1; --l) {
+    float* g = (which == 1) ? a.dactc[l - 1] + eo : (which == 2) ? a.dacta[l - 1] + eo : nullptr;
+    const RNext nx = (l > 1) ? rnext(RN_BWD, th + N.W[l - 1]) : after;
+    rows_big_bwd(x, wb, th + N.W[l], keep0 + (l - 1) * 1024, g, nx);
+  }
+}
+
+// ================================================================== the kernel
+// grid (B / 4, 2, n_experts): blockIdx.y = 0 critic side, 1 actor side.
+static inline size_t rows_lds_floats(int nl) {
+  return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256 + 4 * 2 * 64 * SLD;
+}
+
+template <bool EX>
+__global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
+  extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+  RCtx x;
+  x.hs = rows_lds;
+  x.part = x.hs + 4 * RLD;
+  x.xin = x.part + 4 * 4 * 256;
+  x.sm = x.xin + 4 * XLD;
+  x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
+  x.stage = x.keep + 2 * a.nl * 4 * 256 + x.wave * (2 * 64 * SLD);
+  x.r0 = blockIdx.x * ROWS_R;
+  int64_t eo;
+  (void)ex_decode<EX>(ex, blockIdx.z, eo);                  // one problem per expert: blockIdx.z = expert
+  const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
+  const float* batch = a.batch + eo;
+  const int m = x.r0 + x.wave;                              // the batch row whose output layers this wave finishes
+  const float invB = 1.0f / (float)a.B;
+  float* sm_s = x.sm;                                       // [4] per-row scalar handed from wave i to the column threads
+  float* sm_v = x.sm + 16;                                  // [4][4] per-row 4-vectors (pi, dz)
+  f32x4 wb[2][16];
+
+  if (blockIdx.y == 0) {
+    // ================================================= critic side
+    if (blockIdx.x == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+    const float* tp = a.tPi.th + eo;
+    const float* tq = a.tQ.th + eo;
+    const float* mq = a.mQ.th + eo;
+    // ---- target actor on (o_2, g_2): pi' = max_u tanh(.)                                  (ddpg.py:427-431)
+    ROWS_STAMP(0);
+    rows_l0_load(wb[0], tp + a.tPi.W0, Sa, tp + a.tPi.Wg, Sa + G, x.wave, x.lane, 0);
+    rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false);
+    __syncthreads();
+    ROWS_STAMP(1);
+    rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, tp + a.tPi.b0, nullptr, nullptr,
+                rnext(RN_FWD, tp + a.tPi.W[1]));
+    ROWS_STAMP(2);
+    rows_hidden_fwd(x, wb, a, a.tPi, tp, nullptr, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
+    ROWS_STAMP(3);
+    {
+      float z[4];
+      rows_head<4>(x, tp + a.tPi.Wout, z);
+      if (x.lane < 4) {
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v = (x.lane == d) ? z[d] : v;
+        v = a.max_u * tanhf(v + tp[a.tPi.bout + x.lane]);                                  // actor_critic.py:89
+        x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                              // actor_critic.py:93
+      }
+    }
+    __syncthreads();
+    ROWS_STAMP(4);
+    // ---- target critic on (o_2, g_2, pi') -> Q'
+    rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, tq + a.tQ.b0, nullptr, nullptr,
+                rnext(RN_FWD, tq + a.tQ.W[1]));
+    rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
+    ROWS_STAMP(5);
+    float qt[1];
+    rows_head<1>(x, tq + a.tQ.Wout, qt);
+    const float Qt = qt[0] + tq[a.tQ.bout];
+    // ---- main critic on (o, g, u): activations kept for the backward pass and the weight gradients
+    __syncthreads();                                         // every wave is done with hs / xin of the target pass
+    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
+    __syncthreads();
+    ROWS_STAMP(6);
+    rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, x.keep, a.actc[0] + eo,
+                rnext(RN_FWD, mq + a.mQ.W[1]));
+    rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
+    ROWS_STAMP(7);
+    float q1[1];
+    rows_head<1>(x, mq + a.mQ.Wout, q1);
+    {
+      const float Q = q1[0] + mq[a.mQ.bout];
+      const float target = fclip(batch[(int64_t)m * a.ld + a.off_r] + a.gamma * Qt, a.clip_lo, a.clip_hi);   // ddpg.py:437-438
+      const float diff = target - Q;
+      const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
+      if (x.lane == 0) {
+        a.rows[eo + m] = diff * diff;                        // ddpg.py:439
+        a.dQ[eo + m] = dq;
+        sm_s[x.wave] = dq;
+      }
+    }
+    __syncthreads();
+    // ---- backward through the output layer: dY[i][c] = dQ[i] Wout[c] relu'(h[i][c])
+    {
+      const int L = nl - 1;
+      const float w = mq[a.mQ.Wout + x.tid];
+      const float* hk = x.keep + L * 1024;
+      float* g = a.dactc[L] + eo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = (hk[i * 256 + x.tid] > 0.f) ? sm_s[i] * w : 0.f;
+        x.hs[i * RLD + x.tid] = v;
+        g[(int64_t)(x.r0 + i) * 256 + x.tid] = v;
+      }
+    }
+    __syncthreads();
+    ROWS_STAMP(8);
+    rows_hidden_bwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rnext(RN_NONE, nullptr));
+    ROWS_STAMP(9);
+    return;
+  }
+
+  // =================================================== actor side
+  const float* mp = a.mPi.th + eo;
+  const float* mq = a.mQ.th + eo;
+  float* keepA = x.keep;                                    // actor activations
+  float* keepD = x.keep + nl * 1024;                        // critic(pi) activations
+  ROWS_STAMP(0);
+  rows_l0_load(wb[0], mp + a.mPi.W0, Sa, mp + a.mPi.Wg, Sa + G, x.wave, x.lane, 0);
+  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false);
+  __syncthreads();
+  ROWS_STAMP(1);
+  rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, mp + a.mPi.b0, keepA, a.acta[0] + eo,
+              rnext(RN_FWD, mp + a.mPi.W[1]));
+  ROWS_STAMP(2);
+  rows_hidden_fwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
+  ROWS_STAMP(3);
+  float pi[4];
+  {
+    float z[4];
+    rows_head<4>(x, mp + a.mPi.Wout, z);
+    float l2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      pi[d] = a.max_u * tanhf(z[d] + mp[a.mPi.bout + d]);                                  // actor_critic.py:89
+      const float t = pi[d] / a.max_u;
+      l2 += t * t;                                                                         // ddpg.py:441
+    }
+    if (x.lane < 4) {
+      float v = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) v = (x.lane == d) ? pi[d] : v;
+      x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                // actor_critic.py:93
+    }
+    if (x.lane == 0) a.rows[eo + 2 * a.B + m] = l2;
+  }
+  __syncthreads();
+  ROWS_STAMP(4);
+  // ---- main critic on (o, g, pi) -> Q_pi
+  rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, keepD, nullptr,
+              rnext(RN_FWD, mq + a.mQ.W[1]));
+  rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
+  ROWS_STAMP(5);
+  {
+    float q1[1];
+    rows_head<1>(x, mq + a.mQ.Wout, q1);
+    const float Qpi = q1[0] + mq[a.mQ.bout];
+    if (x.lane == 0) {
+      a.rows[eo + a.B + m] = Qpi;                            // ddpg.py:440
+      a.out_Qpi[eo + m] = Qpi;
+    }
+  }
+  __syncthreads();
+  // ---- backward of -mean(Q_pi) through the critic into the action slot
+  {
+    const float w = mq[a.mQ.Wout + x.tid] * (-invB);
+    const float* hk = keepD + (nl - 1) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x.hs[i * RLD + x.tid] = (hk[i * 256 + x.tid] > 0.f) ? w : 0.f;
+  }
+  __syncthreads();
+  ROWS_STAMP(6);
+  rows_hidden_bwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mp + a.mPi.W[nl - 1]));
+  ROWS_STAMP(7);
+  {
+    // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
+    // pi = max_u tanh(z) and the l2 term (ddpg.py:440-441)
+    const float* Wu = mq + a.mQ.W0 + (int64_t)Sa * 256;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+    float dz[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const f32x4 w = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
+      const float v = wave_sum(g4[0] * w[0] + g4[1] * w[1] + g4[2] * w[2] + g4[3] * w[3]);
+      const float th = pi[d] / a.max_u;
+      const float dpi = v / a.max_u + a.l2c * pi[d];
+      dz[d] = dpi * a.max_u * (1.0f - th * th);
+    }
+    if (x.lane == 0) {
+      const f32x4 o = {dz[0], dz[1], dz[2], dz[3]};
+      *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
+      *reinterpret_cast<f32x4*>(sm_v + 4 * x.wave) = o;
+    }
+  }
+  __syncthreads();
+  // ---- backward through the actor's output layer: dY[i][c] = (sum_d dz[i][d] Wout[c][d]) relu'(a[i][c])
+  {
+    const int L = nl - 1;
+    const f32x4 w = ldv(mp + a.mPi.Wout + 4 * x.tid);
+    const float* hk = keepA + L * 1024;
+    float* g = a.dacta[L] + eo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 dzr = *reinterpret_cast<const f32x4*>(sm_v + 4 * i);
+      const float sv = dzr[0] * w[0] + dzr[1] * w[1] + dzr[2] * w[2] + dzr[3] * w[3];
+      const float v = (hk[i * 256 + x.tid] > 0.f) ? sv : 0.f;
+      x.hs[i * RLD + x.tid] = v;
+      g[(int64_t)(x.r0 + i) * 256 + x.tid] = v;
+    }
+  }
+  __syncthreads();
+  ROWS_STAMP(8);
+  rows_hidden_bwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_NONE, nullptr));
+  ROWS_STAMP(9);
+}

@@ -1,0 +1,97 @@
+// Micro-lab for the row-local DDPG pass (curious_amd/csrc/mlp_rows.h): runs ddpg_rows_kernel on synthetic Arm4-sized
+// networks, prints the launch time (weights left warm in L2 / rewritten before every launch like Adam does) and the
+// in-kernel s_memtime stamps of row group 0.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Icurious_amd/csrc tools/rows_lab.hip -o tools/rows_lab
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+#include "common.h"
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mlp_common.h"
+#include "mlp_rows.h"
+void curious_set_error(const char*, ...) {}
+int g_curious_prof_on = 0;
+void curious_prof_push(int, hipStream_t, bool) {}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void touch(float* p, size_t n) {   // rewrite the parameters (what the optimiser launch does)
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = p[i] * 1.0f;
+}
+
+int main() {
+  const int B = 256, H = 256, O = 40, N = 4, G = 12, U = 4, nl = 3, ld = 152;
+  const int Sa = O + N, Sc = Sa + U;
+  auto net_size = [&](int S, int D) { return S * H + H + G * H + (nl - 1) * (H * H + H) + H * D + D; };
+  const int PQ = net_size(Sc, 1), PP = net_size(Sa, U);
+  const int offP = (PQ + 63) & ~63, total = offP + ((PP + 63) & ~63);
+  std::vector<float> th(2 * (size_t)total), batch((size_t)B * ld);
+  srand(3);
+  for (auto& v : th) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
+  for (auto& v : batch) v = ((float)rand() / RAND_MAX - 0.5f);
+  float *dth, *dbatch, *ws;
+  unsigned long long* dst;
+  CK(hipMalloc(&dth, th.size() * 4)); CK(hipMalloc(&dbatch, batch.size() * 4));
+  const size_t BH = (size_t)B * H;
+  CK(hipMalloc(&ws, (4 * nl * BH + 16 * B) * 4));
+  CK(hipMalloc(&dst, 64 * 8));
+  CK(hipMemcpy(dth, th.data(), th.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dbatch, batch.data(), batch.size() * 4, hipMemcpyHostToDevice));
+  auto mk = [&](const float* base, int S, int D) {
+    RowsNet n; memset(&n, 0, sizeof(n));
+    int off = 0;
+    n.th = base; n.W0 = off; off += S * H; n.b0 = off; off += H; n.Wg = off; off += G * H;
+    for (int l = 1; l < nl; ++l) { n.W[l] = off; off += H * H; n.b[l] = off; off += H; }
+    n.Wout = off; off += H * D; n.bout = off;
+    return n;
+  };
+  RowsArgs a; memset(&a, 0, sizeof(a));
+  a.mQ = mk(dth, Sc, 1); a.mPi = mk(dth + offP, Sa, U);
+  a.tQ = mk(dth + total, Sc, 1); a.tPi = mk(dth + total + offP, Sa, U);
+  a.batch = dbatch; a.ld = ld; a.off_o = 0; a.off_td = 40; a.off_u = 44; a.off_g = 48; a.off_o2 = 60; a.off_g2 = 100;
+  a.off_r = 112;
+  for (int l = 0; l < nl; ++l) {
+    a.actc[l] = ws + (0 * nl + l) * BH; a.dactc[l] = ws + (1 * nl + l) * BH;
+    a.acta[l] = ws + (2 * nl + l) * BH; a.dacta[l] = ws + (3 * nl + l) * BH;
+  }
+  float* tail = ws + 4 * nl * BH;
+  a.dQ = tail; a.dz = tail + B; a.rows = tail + 5 * B; a.out_Qpi = tail + 8 * B;
+  a.B = B; a.nl = nl; a.dimo = O; a.dimtd = N; a.dimg = G;
+  a.gamma = 0.98f; a.clip_lo = -50.f; a.clip_hi = 0.f; a.max_u = 1.f; a.l2c = 2.0f / (B * U);
+  a.stamps = dst;
+  Ex ex; ex.stride = 0; ex.nprob = 1; ex.zmul = 0;
+  const size_t lds = rows_lds_floats(nl) * sizeof(float);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  dim3 grid(B / ROWS_R, 2, 1);
+  auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
+  for (int i = 0; i < 5; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int cold = 0; cold < 2; ++cold) {
+    float tot = 0.f;
+    const int it = 100;
+    for (int i = 0; i < it; ++i) {
+      if (cold) hipLaunchKernelGGL(touch, dim3((2 * total + 255) / 256), dim3(256), 0, 0, dth, (size_t)2 * total);
+      CK(hipEventRecord(e0, 0));
+      launch();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      tot += ms;
+    }
+    printf("%s weights: %.2f us per launch (event pair around one launch)\n", cold ? "rewritten" : "warm", tot * 1000.f / it);
+    unsigned long long st[64];
+    CK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    const char* names[2][10] = {{"start", "inputs", "L0 tpi", "hidden tpi", "head pi'", "L0+hidden tQ", "head Q' + inputs",
+                                 "L0+hidden mQ", "head Q + dY", "bwd mQ"},
+                                {"start", "inputs", "L0 pi", "hidden pi", "head pi", "L0+hidden Q(pi)", "head + dY",
+                                 "bwd Q(pi)", "dz + dY", "bwd pi"}};
+    for (int ty = 0; ty < 2; ++ty) {
+      printf("  %s side (shader cycles): ", ty ? "actor" : "critic");
+      for (int k = 1; k < 10; ++k) printf("%s %llu | ", names[ty][k], st[ty * 32 + k] - st[ty * 32 + k - 1]);
+      printf("total %llu\n", st[ty * 32 + 9] - st[ty * 32]);
+    }
+  }
+  return 0;
+}
