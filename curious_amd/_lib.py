@@ -99,6 +99,8 @@ PROTOTYPES = {
     'curious_norm_update': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'curious_norm_scratch_doubles': (_I64, [_I32, _I32]),
     'curious_norm_recompute': (C.c_int, [_P, _P, _I32, _F, _F, _P]),
+    'curious_norm_pair_scratch_doubles': (_I64, [_I32, _I32, _I32]),
+    'curious_norm_update_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F, _F, _P, _P]),
     'curious_param_count_Q': (_I64, [C.POINTER(NetCfg)]),
     'curious_param_count_pi': (_I64, [C.POINTER(NetCfg)]),
     'curious_param_offset_pi': (_I64, [C.POINTER(NetCfg)]),
@@ -124,11 +126,12 @@ PROTOTYPES = {
     'curious_param_checksum': (C.c_int, [_P, _I64, _P, _P]),
     'curious_policy_act_env_step': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
                                               C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _P, _P, _P, _P,
-                                              _P, _I32, _I32, _D, _P]),
+                                              _P, _I32, _I32, _D, _P, _P]),
+    'curious_counter_add': (C.c_int, [_P, _I64, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,
                                     _P, _P]),
     'curious_env_step': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _I32, _I32, _P,
-                                   _P, _P, _P, _P, _I32, _I32, _D, _P]),
+                                   _P, _P, _P, _P, _I32, _I32, _D, _P, _P]),
 }
 
 _lib = None

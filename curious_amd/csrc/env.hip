@@ -7,7 +7,7 @@
 #include "env_body.h"
 
 __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_t env_id0,
-                                 const int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
+                                 int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
                                  const float* __restrict__ goals_raw, int32_t n, float* __restrict__ o,
                                  float* __restrict__ ag, float* __restrict__ g, float* __restrict__ td,
                                  float* __restrict__ staging) {
@@ -17,8 +17,10 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
   float* oe = o + (int64_t)e * E.dimo;
   float* row0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
   for (int i = 0; i < E.dimo; ++i) oe[i] = 0.0f;
+  const int32_t epi = episode[e];
+  episode[e] = epi + 1;                                     // episodes started so far (the env's step stream reads it)
   for (int s = 0; s < (AG + 3) / 4; ++s) {
-    Philox4 r = philox4x32((uint32_t)(env_id0 + e), (uint32_t)episode[e], (uint32_t)s, STREAM_RESET,
+    Philox4 r = philox4x32((uint32_t)(env_id0 + e), (uint32_t)epi, (uint32_t)s, STREAM_RESET,
                            (uint32_t)E.seed, (uint32_t)(E.seed >> 32));
     uint32_t w[4] = {r.x, r.y, r.z, r.w};
     for (int k = 0; k < 4; ++k) {
@@ -41,7 +43,7 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
 }
 
 extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
-                                 const int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                                 int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
                                  float* o, float* ag, float* g, float* td, float* staging,
                                  curious_stream_t stream) {
   CURIOUS_CHECK(E && L && episode && tasks && goals_raw && o && ag && g && td && staging,
@@ -62,23 +64,34 @@ __global__ __launch_bounds__(256) void env_step_kernel(curious_env_cfg_t E, curi
                                                        int32_t ldu, int32_t t, int32_t n, float* __restrict__ o,
                                                        float* __restrict__ ag, const float* __restrict__ g,
                                                        const float* __restrict__ td, float* __restrict__ staging,
-                                                       int32_t off_change, int32_t off_success, double reward_eps) {
+                                                       int32_t off_change, int32_t off_success, double reward_eps,
+                                                       float* __restrict__ flags) {
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= n) return;
   env_step_body(E, L, env_id0, episode, tasks, u + (int64_t)e * ldu, t, o, ag, g, td, staging, off_change,
-                off_success, reward_eps, e, lane);
+                off_success, reward_eps, e, lane, flags, n);
 }
 
 extern "C" int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                                 const int32_t* episode, const int32_t* tasks, const float* u, int32_t ldu, int32_t t,
                                 int32_t n, float* o, float* ag, const float* g, const float* td, float* staging,
-                                int32_t off_change, int32_t off_success, double reward_eps,
+                                int32_t off_change, int32_t off_success, double reward_eps, float* flags,
                                 curious_stream_t stream) {
   CURIOUS_CHECK(E && L && episode && tasks && u && o && ag && g && td && staging, "curious_env_step: NULL argument");
   CURIOUS_CHECK(t >= 0 && t < L->T, "curious_env_step: t out of range");
   if (n <= 0) return 0;
   { ProfScope ps__(CK_ENV_STEP, as_stream(stream)); hipLaunchKernelGGL(env_step_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), *E, *L, env_id0, episode,
-                     tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps); }
+                     tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps, flags); }
   CURIOUS_LAUNCH_CHECK("env_step_kernel");
+  return 0;
+}
+
+// *p += delta on the device (one thread): the noise-counter base of a captured rollout advances inside the graph.
+__global__ void counter_add_kernel(int64_t* p, int64_t delta) { *p += delta; }
+
+extern "C" int curious_counter_add(int64_t* p, int64_t delta, curious_stream_t stream) {
+  CURIOUS_CHECK(p, "curious_counter_add: NULL argument");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), p, delta);
+  CURIOUS_LAUNCH_CHECK("counter_add_kernel");
   return 0;
 }

@@ -13,7 +13,8 @@ __device__ inline void env_step_body(const curious_env_cfg_t& E, const curious_l
                                      const float* ue /* the env's 4 action values (global or LDS) */, int32_t t,
                                      float* __restrict__ o, float* __restrict__ ag, const float* __restrict__ g,
                                      const float* __restrict__ td, float* __restrict__ staging, int32_t off_change,
-                                     int32_t off_success, double reward_eps, const int e, const int lane) {
+                                     int32_t off_success, double reward_eps, const int e, const int lane,
+                                     float* __restrict__ flags = nullptr, const int n = 0) {
   const int AG = 3 * E.ntasks;
   float* oe = o + (int64_t)e * E.dimo;
   float* ep0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
@@ -84,6 +85,20 @@ __device__ inline void env_step_body(const curious_env_cfg_t& E, const curious_l
     double d = __dsub_rn((double)__shfl(nv_first, 3 * task + k), (double)ge[3 * task + k]);
     d2 = __dadd_rn(d2, __dmul_rn(d, d));
   }
-  if (lane == 0) row[off_success] = (sqrt(d2) > reward_eps) ? 0.0f : 1.0f;
+  const float succ = (sqrt(d2) > reward_eps) ? 0.0f : 1.0f;
+  if (lane == 0) row[off_success] = succ;
+  // rollout flags (rollout.py:268-271,306): flags[e] = is_success of the final step, flags[n] = 1 when an observation
+  // of any env ended up NaN.  flags[n] is cleared by env 0 at t = 0 and only set (to the same value) at t = T - 1 --
+  // different launches of one stream, no ordering problem.
+  if (flags) {
+    if (t == 0 && e == 0 && lane == 0) flags[n] = 0.0f;
+    if (t == L.T - 1) {
+      const bool bad = __any(nv_first != nv_first);
+      if (lane == 0) {
+        flags[e] = succ;
+        if (bad) flags[n] = 1.0f;
+      }
+    }
+  }
 }
 

@@ -39,6 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mlp_layer0.h"
 #include "mlp_heads.h"
 #include "mlp_rows.h"
+#include "mlp_rows_act.h"
 
 // ================================================================== host side
 struct NetOff {
@@ -393,6 +394,39 @@ static HeadFwdProb head_prob(const float* h, int H, const float* W, const float*
   return p;
 }
 
+// The row-local routes (mlp_rows.h, mlp_rows_act.h).  CURIOUS_ROWS=0 keeps the tiled multi-launch routes (A/B
+// measurements, and the reference point of parity checks between the two).
+static bool rows_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CURIOUS_ROWS");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0;
+}
+
+static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
+  RowsNet n;
+  memset(&n, 0, sizeof(n));
+  n.th = th; n.W0 = (int32_t)o.W0; n.b0 = (int32_t)o.b0; n.Wg = (int32_t)o.Wg; n.Wout = (int32_t)o.Wout;
+  n.bout = (int32_t)o.bout;
+  for (int l = 1; l < nl; ++l) { n.W[l] = (int32_t)o.W[l]; n.b[l] = (int32_t)o.b[l]; }
+  return n;
+}
+
+static bool act_rows_ok(const curious_net_cfg_t* c, int n, bool relative, const float* theta) {
+  return rows_enabled() && c->modular && c->layers >= 2 && c->layers <= ROWS_MAXL && c->hidden == 256 && c->dimu == 4 &&
+         (n % ROWS_R == 0) && !c->normalize_obs && !relative && c->dimo + c->dimtd + 4 + c->dimg <= XLD &&
+         aligned16(theta) && ((c->dimo + c->dimtd) % 4 == 0) && (c->dimg % 4 == 0);
+}
+
+static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
+  { ProfScope ps__(CK_ACT_ROWS, st);
+    hipLaunchKernelGGL(policy_rows_kernel, dim3(n / ROWS_R), dim3(256), act_rows_lds_floats() * sizeof(float), st, a); }
+  CURIOUS_LAUNCH_CHECK("policy_rows_kernel");
+  return 0;
+}
+
 static void fill_obs_stats(const curious_net_cfg_t* cfg, ObsIn& in, const float* o_stats, const float* g_stats) {
   in.nclip = cfg->norm_clip;
   if (cfg->normalize_obs) {
@@ -416,12 +450,21 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   Ws w = carve(cfg, n, workspace);
   NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
   const int H = cfg->hidden, nl = cfg->layers;
+  const float* thPi = theta + pi_offset(cfg);
+  if (act_rows_ok(cfg, n, relative_goals != 0, theta) && aligned16(thPi)) {
+    ActRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pi = rows_net(thPi, offPi, nl); a.q = rows_net(theta, offQ, nl);
+    a.o = o; a.td = td; a.g = g; a.ldo = ldo; a.ldtd = ldtd; a.ldg = ldg; a.clip = clip_obs;
+    a.n = n; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg; a.max_u = cfg->max_u;
+    a.out_pi = out_pi; a.ldpi = cfg->dimu; a.out_Q = out_Q;
+    return launch_policy_rows(a, n, st);
+  }
   ObsIn in;
   memset(&in, 0, sizeof(in));
   in.o = o; in.ldo = ldo; in.td = td; in.ldtd = ldtd; in.g = g; in.ldg = ldg; in.ag = ag; in.ldag = ldag;
   in.clip = clip_obs; in.relative = relative_goals;
   fill_obs_stats(cfg, in, o_stats, g_stats);
-  const float* thPi = theta + pi_offset(cfg);
   Chain a;
   a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
   if (forward_chains(cfg, &a, 1, n, st)) return -2;
@@ -450,7 +493,7 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
                                            const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
                                            const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
                                            const float* td, float* staging, int32_t off_change, int32_t off_success,
-                                           double reward_eps, curious_stream_t stream) {
+                                           double reward_eps, float* flags, curious_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
                 "curious_policy_act_env_step: NULL argument");
@@ -464,11 +507,25 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   Ws w = carve(cfg, n, workspace);
   NetOff offPi = net_off(cfg, false);
   const int H = cfg->hidden, nl = cfg->layers;
+  const float* thPi = theta + pi_offset(cfg);
+  if (act_rows_ok(cfg, n, false, theta) && aligned16(thPi)) {
+    ActRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pi = rows_net(thPi, offPi, nl);
+    a.o = o; a.td = td; a.g = g; a.ldo = E->dimo; a.ldtd = E->ntasks; a.ldg = 3 * E->ntasks; a.clip = clip_obs;
+    a.n = n; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg; a.max_u = cfg->max_u;
+    a.fused = 1;
+    a.noise_scale = noise_scale; a.random_eps = random_eps; a.max_u_d = (double)cfg->max_u;
+    a.seed = seed; a.counter = counter; a.counter_base = counter_base; a.u_out = u_out; a.ldu = ldu;
+    a.E = *E; a.L = *L; a.env_id0 = env_id0; a.t = t; a.off_change = off_change; a.off_success = off_success;
+    a.episode = episode; a.tasks = tasks; a.eo = o; a.eag = ag; a.staging = staging; a.reward_eps = reward_eps;
+    a.flags = flags;
+    return launch_policy_rows(a, n, st);
+  }
   ObsIn in;
   memset(&in, 0, sizeof(in));
   in.o = o; in.ldo = E->dimo; in.td = td; in.ldtd = E->ntasks; in.g = g; in.ldg = 3 * E->ntasks;
   in.clip = clip_obs;
-  const float* thPi = theta + pi_offset(cfg);
   Chain a;
   a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
   // output layer as a dot epilogue of the last hidden layer when that layer runs on the lean kernel
@@ -486,6 +543,7 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
   k.E = *E; k.L = *L; k.env_id0 = env_id0; k.t = t; k.off_change = off_change; k.off_success = off_success;
   k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
   k.reward_eps = reward_eps;
+  k.flags = flags;
   { ProfScope ps__(CK_ACT_STEP, st);
     if (part) hipLaunchKernelGGL(act_step_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, k);
     else hipLaunchKernelGGL(act_step_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, k); }
@@ -560,31 +618,11 @@ int DdpgPass::setup(curious_stream_t stream) {
   return 0;
 }
 
-// The row-local route (mlp_rows.h): forward + backward in one launch.  CURIOUS_ROWS=0 keeps the tiled 8-launch route
-// (A/B measurements, and the reference point of the parity tests between the two routes).
-static bool rows_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CURIOUS_ROWS");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0;
-}
-
 bool DdpgPass::rows_route() const {
   return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % ROWS_R == 0) &&
          !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= XLD && aligned16(thQ) && aligned16(thPi) &&
          aligned16(ttQ) && aligned16(ttPi) && aligned16(workspace) && (offQ.Wout % 4 == 0) && (offPi.Wout % 4 == 0) &&
          ((cfg->dimo + cfg->dimtd) % 4 == 0) && (cfg->dimg % 4 == 0);
-}
-
-static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
-  RowsNet n;
-  memset(&n, 0, sizeof(n));
-  n.th = th; n.W0 = (int32_t)o.W0; n.b0 = (int32_t)o.b0; n.Wg = (int32_t)o.Wg; n.Wout = (int32_t)o.Wout;
-  n.bout = (int32_t)o.bout;
-  for (int l = 1; l < nl; ++l) { n.W[l] = (int32_t)o.W[l]; n.b[l] = (int32_t)o.b[l]; }
-  return n;
 }
 
 int DdpgPass::rows_pass() {

@@ -704,6 +704,7 @@ struct ActStepArgs {
   const int32_t* episode; const int32_t* tasks;
   float* o; float* ag; const float* g; const float* td; float* staging;
   double reward_eps;
+  float* flags;                              // optional rollout flags (env_step_body)
 };
 
 template <bool PART>
@@ -745,5 +746,5 @@ __global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u[wave], a.t, a.o, a.ag, a.g, a.td, a.staging,
-                a.off_change, a.off_success, a.reward_eps, e, lane);
+                a.off_change, a.off_success, a.reward_eps, e, lane, a.flags, a.n);
 }

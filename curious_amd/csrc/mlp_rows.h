@@ -223,21 +223,25 @@ __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], c
   rows_fw_finish(x, acc, bv, keep, gout);
 }
 
-// ---- output layers: wave i finishes batch row r0 + i; the result is uniform over the wave
-template <int D>
-__device__ __forceinline__ void rows_head(const RCtx& x, const float* Wout, float (&out)[D]) {
+// ---- output layers: wave i finishes batch row r0 + i; the result is uniform over the wave.  The output-layer weights
+// are fetched into registers BEFORE the network's hidden layers run (rows_head*_w), so that no load latency sits
+// between the last hidden layer and the head.
+struct HeadW4 { f32x4 w[4]; };
+__device__ __forceinline__ HeadW4 rows_head4_w(const float* Wout, int lane) {      // Wout[256][4]: rows 4 lane .. +3
+  HeadW4 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h.w[e] = ldv(Wout + (int64_t)(4 * lane + e) * 4);
+  return h;
+}
+__device__ __forceinline__ void rows_head4(const RCtx& x, const HeadW4& h, float (&out)[4]) {
   const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
-  if (D == 1) {
-    const f32x4 w = ldv(Wout + 4 * x.lane);
-    out[0] = wave_sum(h4[0] * w[0] + h4[1] * w[1] + h4[2] * w[2] + h4[3] * w[3]);
-  } else {
-    f32x4 w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = ldv(Wout + (int64_t)(4 * x.lane + e) * 4);
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      out[d] = wave_sum(h4[0] * w[0][d] + h4[1] * w[1][d] + h4[2] * w[2][d] + h4[3] * w[3][d]);
-  }
+  for (int d = 0; d < 4; ++d)
+    out[d] = wave_sum(h4[0] * h.w[0][d] + h4[1] * h.w[1][d] + h4[2] * h.w[2][d] + h4[3] * h.w[3][d]);
+}
+__device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {        // w = Wout[4 lane .. +3] of a [256][1]
+  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+  return wave_sum(h4[0] * w[0] + h4[1] * w[1] + h4[2] * w[2] + h4[3] * w[3]);
 }
 
 // layer-0 input rows of the workgroup's 4 batch rows: xin[i] = [o | td | action slot | g]; the action slot receives
@@ -320,19 +324,23 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false);
     __syncthreads();
     ROWS_STAMP(1);
+    const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
+    const float bpi_t = tp[a.tPi.bout + (x.lane & 3)];
     rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, tp + a.tPi.b0, nullptr, nullptr,
                 rnext(RN_FWD, tp + a.tPi.W[1]));
     ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.tPi, tp, nullptr, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
     ROWS_STAMP(3);
+    const f32x4 wq_t = ldv(tq + a.tQ.Wout + 4 * x.lane);
+    const float bq_t = tq[a.tQ.bout];
     {
       float z[4];
-      rows_head<4>(x, tp + a.tPi.Wout, z);
+      rows_head4(x, wpi_t, z);
       if (x.lane < 4) {
         float v = 0.f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) v = (x.lane == d) ? z[d] : v;
-        v = a.max_u * tanhf(v + tp[a.tPi.bout + x.lane]);                                  // actor_critic.py:89
+        v = a.max_u * tanhf(v + bpi_t);                                                    // actor_critic.py:89
         x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                              // actor_critic.py:93
       }
     }
@@ -343,9 +351,12 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
                 rnext(RN_FWD, tq + a.tQ.W[1]));
     rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
     ROWS_STAMP(5);
-    float qt[1];
-    rows_head<1>(x, tq + a.tQ.Wout, qt);
-    const float Qt = qt[0] + tq[a.tQ.bout];
+    const float Qt = rows_head1(x, wq_t) + bq_t;
+    // operands of the main critic's head / loss / first backward step, fetched ahead of its hidden layers
+    const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
+    const float bq_m = mq[a.mQ.bout];
+    const float wq_col = mq[a.mQ.Wout + x.tid];
+    const float rew = batch[(int64_t)m * a.ld + a.off_r];
     // ---- main critic on (o, g, u): activations kept for the backward pass and the weight gradients
     __syncthreads();                                         // every wave is done with hs / xin of the target pass
     rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
@@ -355,11 +366,9 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
                 rnext(RN_FWD, mq + a.mQ.W[1]));
     rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
     ROWS_STAMP(7);
-    float q1[1];
-    rows_head<1>(x, mq + a.mQ.Wout, q1);
     {
-      const float Q = q1[0] + mq[a.mQ.bout];
-      const float target = fclip(batch[(int64_t)m * a.ld + a.off_r] + a.gamma * Qt, a.clip_lo, a.clip_hi);   // ddpg.py:437-438
+      const float Q = rows_head1(x, wq_m) + bq_m;
+      const float target = fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi);                // ddpg.py:437-438
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
       if (x.lane == 0) {
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     // ---- backward through the output layer: dY[i][c] = dQ[i] Wout[c] relu'(h[i][c])
     {
       const int L = nl - 1;
-      const float w = mq[a.mQ.Wout + x.tid];
+      const float w = wq_col;
       const float* hk = x.keep + L * 1024;
       float* g = a.dactc[L] + eo;
 #pragma unroll
@@ -399,6 +408,8 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   rows_load_inputs(x, a, batch, a.off_o, a.off_g, false);
   __syncthreads();
   ROWS_STAMP(1);
+  const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);
+  const f32x4 bpi = ldv(mp + a.mPi.bout);
   rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, mp + a.mPi.b0, keepA, a.acta[0] + eo,
               rnext(RN_FWD, mp + a.mPi.W[1]));
   ROWS_STAMP(2);
@@ -407,11 +418,11 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   float pi[4];
   {
     float z[4];
-    rows_head<4>(x, mp + a.mPi.Wout, z);
+    rows_head4(x, wpi, z);
     float l2 = 0.f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      pi[d] = a.max_u * tanhf(z[d] + mp[a.mPi.bout + d]);                                  // actor_critic.py:89
+      pi[d] = a.max_u * tanhf(z[d] + bpi[d]);                                              // actor_critic.py:89
       const float t = pi[d] / a.max_u;
       l2 += t * t;                                                                         // ddpg.py:441
     }
@@ -425,15 +436,18 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   }
   __syncthreads();
   ROWS_STAMP(4);
+  // operands of the critic's head, of the first backward step, of the action-slot product and of the actor's first
+  // backward step, fetched ahead of the layers in between
+  const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
+  const float bq_m = mq[a.mQ.bout];
+  const float wq_col = mq[a.mQ.Wout + x.tid];
   // ---- main critic on (o, g, pi) -> Q_pi
   rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, keepD, nullptr,
               rnext(RN_FWD, mq + a.mQ.W[1]));
   rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
   ROWS_STAMP(5);
   {
-    float q1[1];
-    rows_head<1>(x, mq + a.mQ.Wout, q1);
-    const float Qpi = q1[0] + mq[a.mQ.bout];
+    const float Qpi = rows_head1(x, wq_m) + bq_m;
     if (x.lane == 0) {
       a.rows[eo + a.B + m] = Qpi;                            // ddpg.py:440
       a.out_Qpi[eo + m] = Qpi;
@@ -442,24 +456,30 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   __syncthreads();
   // ---- backward of -mean(Q_pi) through the critic into the action slot
   {
-    const float w = mq[a.mQ.Wout + x.tid] * (-invB);
+    const float w = wq_col * (-invB);
     const float* hk = keepD + (nl - 1) * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) x.hs[i * RLD + x.tid] = (hk[i * 256 + x.tid] > 0.f) ? w : 0.f;
   }
   __syncthreads();
   ROWS_STAMP(6);
+  f32x4 wu[4];
+  {
+    const float* Wu = mq + a.mQ.W0 + (int64_t)Sa * 256;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) wu[d] = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
+  }
+  const f32x4 wpi_row = ldv(mp + a.mPi.Wout + 4 * x.tid);
   rows_hidden_bwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mp + a.mPi.W[nl - 1]));
   ROWS_STAMP(7);
   {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
     // pi = max_u tanh(z) and the l2 term (ddpg.py:440-441)
-    const float* Wu = mq + a.mQ.W0 + (int64_t)Sa * 256;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
     float dz[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const f32x4 w = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
+      const f32x4 w = wu[d];
       const float v = wave_sum(g4[0] * w[0] + g4[1] * w[1] + g4[2] * w[2] + g4[3] * w[3]);
       const float th = pi[d] / a.max_u;
       const float dpi = v / a.max_u + a.l2c * pi[d];
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   // ---- backward through the actor's output layer: dY[i][c] = (sum_d dz[i][d] Wout[c][d]) relu'(a[i][c])
   {
     const int L = nl - 1;
-    const f32x4 w = ldv(mp + a.mPi.Wout + 4 * x.tid);
+    const f32x4 w = wpi_row;
     const float* hk = keepA + L * 1024;
     float* g = a.dacta[L] + eo;
 #pragma unroll

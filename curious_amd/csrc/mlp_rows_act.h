@@ -1,0 +1,117 @@
+// Row-local acting pass (included by mlp.hip after mlp_rows.h): actor forward (+ critic forward, or + exploration noise
+// and one step of the GPU-resident env) for 4 envs / batch rows per workgroup in ONE launch.
+//
+// Replaces, per env step of a batched rollout (rollout.py:226-263 for every env), the 3 launches fwd_l01 -> fwd_hot<DOT>
+// -> act_step of the tiled route; and, for DDPG.get_actions (ddpg.py:129-146), fwd_l01 / fwd_hot / head_fwd (+ the same
+// again for Q).  Both entry points share this kernel, so the fused acting step stays bit-identical to
+// curious_policy_forward + curious_action_noise + curious_env_step.
+#pragma once
+
+struct ActRowsArgs {
+  RowsNet pi, q;                       // main (or target) actor; critic only when out_Q
+  const float* o; const float* td; const float* g;
+  int32_t ldo, ldtd, ldg;
+  float clip;                          // clip_obs (ddpg.py:118-127); <= 0: none
+  int32_t n, nl, dimo, dimtd, dimg;
+  float max_u;
+  float* out_pi; int32_t ldpi;         // plain forward: actions without noise
+  float* out_Q;                        // optional [n]
+  int32_t fused;                       // != 0: noise + clip + eps-greedy + env step (the fields of ActStepArgs below)
+  double noise_scale, random_eps, max_u_d;
+  uint64_t seed, counter;
+  const int64_t* counter_base;
+  float* u_out; int32_t ldu;
+  curious_env_cfg_t E; curious_layout_t L;
+  int32_t env_id0, t, off_change, off_success;
+  const int32_t* episode; const int32_t* tasks;
+  float* eo; float* eag; float* staging;          // env state (o is also the network input `o`), episode records
+  double reward_eps;
+  float* flags;                                   // optional rollout flags (env_step_body)
+};
+
+static inline size_t act_rows_lds_floats() { return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64; }
+
+__global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+  RCtx x;
+  x.hs = rows_lds;
+  x.part = x.hs + 4 * RLD;
+  x.xin = x.part + 4 * 4 * 256;
+  x.sm = x.xin + 4 * XLD;
+  x.keep = nullptr; x.stage = nullptr;
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
+  x.r0 = blockIdx.x * ROWS_R;
+  const int Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
+  const int m = x.r0 + x.wave;                              // the env / row this wave finishes
+  const float* pp = a.pi.th;
+  f32x4 wb[2][16];
+  rows_l0_load(wb[0], pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G, x.wave, x.lane, 0);
+  const HeadW4 wpi = rows_head4_w(pp + a.pi.Wout, x.lane);
+  const float bpi = pp[a.pi.bout + (x.lane & 3)];
+  // ---- inputs: xin[i] = [clip(o) | td | action slot | clip(g)]
+  {
+    const int tot = Sc + G;
+    const float c = (a.clip > 0.f) ? a.clip : INFINITY;
+    for (int idx = x.tid; idx < 4 * tot; idx += 256) {
+      const int i = idx / tot, k = idx - i * tot;
+      const int64_t r = x.r0 + i;
+      float v;
+      if (k < a.dimo) v = fclip(a.o[r * a.ldo + k], -c, c);
+      else if (k < Sa) v = a.td[r * a.ldtd + (k - a.dimo)];
+      else if (k < Sc) v = 0.f;
+      else v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+      x.xin[i * XLD + k] = v;
+    }
+  }
+  // the exploration noise does not depend on the policy output: draw it now, while the first loads are in flight
+  NoiseDraw nd;
+  nd.z = nd.b = nd.ru = 0.0;
+  if (a.fused && x.lane < 4) {
+    const uint64_t ctr = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
+    nd = noise_draw(m * 4 + x.lane, m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed, ctr);
+  }
+  __syncthreads();
+  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, nullptr, nullptr,
+              rnext(RN_FWD, pp + a.pi.W[1]));
+  const float* qp = a.q.th;
+  const RNext after = a.out_Q ? rnext(RN_L0, qp + a.q.W0, Sc, qp + a.q.Wg, Sc + G) : rnext(RN_NONE, nullptr);
+  for (int l = 1; l < a.nl; ++l)
+    rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], nullptr, nullptr,
+                 (l + 1 < a.nl) ? rnext(RN_FWD, pp + a.pi.W[l + 1]) : after);
+  float z[4];
+  rows_head4(x, wpi, z);
+  float v = 0.f;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) v = ((x.lane & 3) == d) ? z[d] : v;
+  v = a.max_u * tanhf(v + bpi);                                                            // actor_critic.py:89
+  if (a.fused) {
+    // exploration noise, clip, eps-greedy (ddpg.py:149-152) and one env step, one wavefront per env
+    float* s_u = x.sm + 8 * x.wave;
+    if (x.lane < 4) {
+      v = noise_mix(v, nd, a.noise_scale, a.max_u_d);
+      s_u[x.lane] = v;
+      a.u_out[(int64_t)m * a.ldu + x.lane] = v;
+    }
+    // (the network inputs were copied to LDS before layer 0: the env arrays they came from may be overwritten now)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u, a.t, a.eo, a.eag, a.g, a.td, a.staging, a.off_change,
+                  a.off_success, a.reward_eps, m, x.lane, a.flags, a.n);
+    return;
+  }
+  if (x.lane < 4) {
+    a.out_pi[(int64_t)m * a.ldpi + x.lane] = v;
+    x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                  // actor_critic.py:93
+  }
+  if (!a.out_Q) return;
+  const f32x4 wq = ldv(qp + a.q.Wout + 4 * x.lane);
+  const float bq = qp[a.q.bout];
+  __syncthreads();
+  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp + a.q.b0, nullptr, nullptr, rnext(RN_FWD, qp + a.q.W[1]));
+  for (int l = 1; l < a.nl; ++l)
+    rows_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], nullptr, nullptr,
+                 (l + 1 < a.nl) ? rnext(RN_FWD, qp + a.q.W[l + 1]) : rnext(RN_NONE, nullptr));
+  const float Q = rows_head1(x, wq) + bq;
+  if (x.lane == 0) a.out_Q[m] = Q;
+}

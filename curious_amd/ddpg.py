@@ -285,7 +285,7 @@ class DDPG(object):
         ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
                                 self.seed * 2654435761 + 12345 + dist.rank() * 1000003, self._noise_counter,
                                 self._act_u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, t, env.o,
-                                env.ag, env.g, env.td, env.staging, REWARD_EPS)
+                                env.ag, env.g, env.td, env.staging, REWARD_EPS, flags=getattr(env, 'flags', None))
         return self._act_u
 
     def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
@@ -322,8 +322,8 @@ class DDPG(object):
                 ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
                                         seed, t + 1, u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks,
                                         t, env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS,
-                                        counter_base=self._noise_base)
-            self._noise_base.add_(T)
+                                        counter_base=self._noise_base, flags=getattr(env, 'flags', None))
+            ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T
         self._noise_base_val = self._noise_counter                   # steps() ends with the device-side += T
@@ -502,9 +502,18 @@ class DDPG(object):
         P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
         ops.her_sample(views.records, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
         cols = layout.batch_cols
-        self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
-        self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
-        recompute_many([self.o_stats, self.g_stats])
+        # both normalisers from the one batch in two launches; on a single rank the second one also recomputes the
+        # statistics, with several ranks the (packed) accumulators are all-reduced first (normalizer.py:84-94)
+        need = ops.norm_pair_scratch_doubles(n, self.dimo, self.dimg)
+        if getattr(self, '_stats_scratch', None) is None or self._stats_scratch.numel() < need:
+            self._stats_scratch = torch.empty(need, dtype=torch.float64, device=self.device)
+        single = not dist.is_distributed()
+        ops.norm_update_pair(batch, n, batch.stride(0), cols['o'][0], self.dimo, cols['g'][0], self.dimg,
+                             self.o_stats.acc, self.g_stats.acc, self.o_stats.state if single else None,
+                             self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
+                             self._stats_scratch)
+        if not single:
+            recompute_many([self.o_stats, self.g_stats])
 
     def _stats_rng(self, n_episodes, n):
         r = _lib.SampleRng()

@@ -133,6 +133,10 @@ class BatchedSyntheticArm(ArmSpec):
         self._pin = torch.empty(n * 4, dtype=torch.float32).pin_memory()
         self._goals_dev = torch.zeros([n, 3], device=dev)
         self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
+        # rollout flags written by the last env step: is_success per env + one "an observation is NaN" word
+        self.flags = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self._flags_pin = torch.zeros(n + 1, dtype=torch.float32).pin_memory()
+        self._flags_ready = torch.cuda.Event()
 
     @property
     def unwrapped(self):
@@ -154,12 +158,19 @@ class BatchedSyntheticArm(ArmSpec):
         self.tasks.copy_(self._pin[:n].view(torch.int32), non_blocking=True)
         self._goals_dev.copy_(self._pin[n:].view(n, 3), non_blocking=True)
         ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
-                      self.o, self.ag, self.g, self.td, self.staging)
-        self.episode += 1
+                      self.o, self.ag, self.g, self.td, self.staging)      # also advances self.episode on the device
 
     def step_all(self, u, t):
         ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,
-                     self.g, self.td, self.staging, REWARD_EPS)
+                     self.g, self.td, self.staging, REWARD_EPS, flags=self.flags)
+
+    def fetch_flags(self):
+        """(is_success of the final step per env [n], any observation NaN) -- the one D2H sync of a rollout."""
+        self._flags_pin.copy_(self.flags, non_blocking=True)
+        self._flags_ready.record()
+        self._flags_ready.synchronize()
+        host = self._flags_pin.numpy()
+        return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
 
     def episode_views(self):
         return EpisodeViews(self.staging, self.layout, with_next=False)

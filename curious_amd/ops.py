@@ -76,6 +76,18 @@ def norm_update(rows, n_rows, stride, col_off, dim, acc, scratch):
                                     ptr(acc), ptr(scratch), current_stream()), 'curious_norm_update')
 
 
+def norm_update_pair(rows, n_rows, stride, off_a, dim_a, off_b, dim_b, acc_a, acc_b, state_a, state_b, eps_a, eps_b,
+                     scratch):
+    check(lib().curious_norm_update_pair(ptr(_dev(rows, 'rows')), int(n_rows), int(stride), int(off_a), int(dim_a),
+                                         int(off_b), int(dim_b), ptr(acc_a), ptr(acc_b), ptr(state_a), ptr(state_b),
+                                         float(eps_a), float(eps_b), ptr(scratch), current_stream()),
+          'curious_norm_update_pair')
+
+
+def norm_pair_scratch_doubles(n_rows, dim_a, dim_b):
+    return int(lib().curious_norm_pair_scratch_doubles(int(n_rows), int(dim_a), int(dim_b)))
+
+
 def norm_recompute(acc, state, dim, world_size, eps):
     check(lib().curious_norm_recompute(ptr(_dev(acc, 'acc')), ptr(state), int(dim), float(world_size), float(eps),
                                        current_stream()), 'curious_norm_recompute')
@@ -270,8 +282,12 @@ def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td,
                                   current_stream()), 'curious_env_reset')
 
 
+def counter_add(p, delta):
+    check(lib().curious_counter_add(ptr(_dev(p, 'p')), int(delta), current_stream()), 'curious_counter_add')
+
+
 def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
-                        env_id0, episode, tasks, t, o, ag, g, td, staging, reward_eps, counter_base=None):
+                        env_id0, episode, tasks, t, o, ag, g, td, staging, reward_eps, counter_base=None, flags=None):
     L = layout.c_layout()
     check(lib().curious_policy_act_env_step(C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs),
                                             ptr(workspace), float(noise_scale), float(random_eps),
@@ -280,16 +296,17 @@ def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_
                                             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0),
                                             ptr(episode), ptr(tasks), int(t), ptr(o), ptr(ag), ptr(g), ptr(td),
                                             ptr(staging), int(layout.off['change']),
-                                            int(layout.off['info_is_success']), float(reward_eps), current_stream()),
+                                            int(layout.off['info_is_success']), float(reward_eps), ptr(flags),
+                                            current_stream()),
           'curious_policy_act_env_step')
 
 
-def env_step(ecfg, layout, env_id0, episode, tasks, u, t, n, o, ag, g, td, staging, reward_eps):
+def env_step(ecfg, layout, env_id0, episode, tasks, u, t, n, o, ag, g, td, staging, reward_eps, flags=None):
     L = layout.c_layout()
     check(lib().curious_env_step(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), ptr(u),
                                  int(u.stride(0)), int(t), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
                                  int(layout.off['change']), int(layout.off['info_is_success']), float(reward_eps),
-                                 current_stream()), 'curious_env_step')
+                                 ptr(flags), current_stream()), 'curious_env_step')
 
 
 def prof_enable(on):

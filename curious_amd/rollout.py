@@ -268,9 +268,7 @@ class RolloutWorker:
                 u = out
             env.step_all(u, t)
         # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
-        succ = env.last_success()
-        both = torch.cat([succ, torch.isnan(env.o).any().to(succ.dtype).reshape(1)]).cpu().numpy().astype(np.float64)
-        successful, o_has_nan = both[:-1], both[-1] != 0
+        successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
         if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
             return self._generate_rollouts_batched()

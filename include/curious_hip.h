@@ -151,6 +151,16 @@ int64_t curious_norm_scratch_doubles(int32_t n_rows, int32_t dim);
 int curious_norm_recompute(float* acc, float* state, int32_t dim, float world_size, float eps,
                            curious_stream_t stream);
 
+/* Normalizer.update of TWO normalisers fed from one row matrix (DDPG.store_episode: o_stats and g_stats from the
+ * same HER-sampled batch, ddpg.py:216-223) in two launches: partial column sums over [a | b], then a finishing launch
+ * (wavefront reductions, the accumulator update of normalizer.py:68-70).  With state_a / state_b given (single rank)
+ * the finishing launch also runs recompute_stats (normalizer.py:96-118, world size 1) and zeroes the accumulators;
+ * with several ranks pass NULL, all-reduce the accumulators and call curious_norm_recompute. */
+int64_t curious_norm_pair_scratch_doubles(int32_t n_rows, int32_t dim_a, int32_t dim_b);
+int curious_norm_update_pair(const float* rows, int32_t n_rows, int32_t stride, int32_t off_a, int32_t dim_a,
+                             int32_t off_b, int32_t dim_b, float* acc_a, float* acc_b, float* state_a, float* state_b,
+                             float eps_a, float eps_b, double* scratch, curious_stream_t stream);
+
 /* ---- networks ---------------------------------------------------------------------------------
  * Parameter vector of one agent = [theta_Q | pad | theta_pi | pad] (ddpg.py:456 main_vars order); theta_pi
  * starts at curious_param_offset_pi() (P_Q rounded up to 64 floats), the vector is curious_param_total()
@@ -283,18 +293,25 @@ typedef struct curious_env_cfg {
   uint64_t seed;
 } curious_env_cfg_t;
 
-/* Reset n envs: o[n][dimo] from Philox stream (env_id0+i, episode[i]); writes record row 0 of the
+/* Reset n envs: o[n][dimo] from Philox stream (env_id0+i, episode[i]); episode[i] (episodes started so far) is
+ * incremented afterwards, on the device; writes record row 0 of the
  * staging block (o, ag, g, td) and the working arrays o/ag/g/td. goals_raw[n][3] in [-1,1], tasks[n]. */
 int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
-                      const int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                      int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
                       float* o, float* ag, float* g, float* td, float* staging, curious_stream_t stream);
 
 /* One step of n envs with actions u[n][dimu]: updates o/ag in place, writes u, g, td, change, is_success
- * into staging row t and o, ag into row t+1 (the episode record of rollout.py:273-303). */
+ * into staging row t and o, ag into row t+1 (the episode record of rollout.py:273-303).
+ * flags (optional, [n+1] floats): at the last step t = T-1, flags[i] = is_success of env i and flags[n] = 1 if any
+ * observation is NaN (flags[n] is cleared at t = 0) -- what rollout.py:268-271,306 reads, in one small D2H copy. */
 int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                      const int32_t* episode, const int32_t* tasks, const float* u, int32_t ldu, int32_t t,
                      int32_t n, float* o, float* ag, const float* g, const float* td, float* staging,
-                     int32_t off_change, int32_t off_success, double reward_eps, curious_stream_t stream);
+                     int32_t off_change, int32_t off_success, double reward_eps, float* flags,
+                     curious_stream_t stream);
+
+/* *p += delta on the device, stream ordered (the noise-counter base of a captured rollout advances inside the graph). */
+int curious_counter_add(int64_t* p, int64_t delta, curious_stream_t stream);
 
 /* Fused acting step of the batched rollout: actor forward on the envs' current (o, g, td), output layer + noise +
  * clip + eps-greedy (device Philox, as curious_action_noise in throughput mode) and ONE env step, i.e.
@@ -309,7 +326,7 @@ int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta
                                 const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
                                 const int32_t* tasks, int32_t t, float* o, float* ag, const float* g, const float* td,
                                 float* staging, int32_t off_change, int32_t off_success, double reward_eps,
-                                curious_stream_t stream);
+                                float* flags, curious_stream_t stream);
 
 #ifdef __cplusplus
 }
