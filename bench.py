@@ -179,7 +179,15 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     her_bytes_per_transition = ((2 * O + U + G + 2 * c.dimag + N + 0.8 * c.dimag)
                                 + (c.dimag + G + O + N + U + O + G + 1)) * 4          # 1 034 B at Arm4
     adam_bytes = 28 * (c.P_Q + c.P_pi)
+    Sa, Sc = O + N, O + N + U
+    net = lambda S, D: (S + G) * H + hid * H * H + H * D          # multiply-adds of one forward pass per row
+    rows_fwd = 2 * net(Sa, U) + 3 * net(Sc, 1)                    # target actor, actor; target critic, critic(u), critic(pi)
+    rows_bwd = (hid * H * H + H) + (hid * H * H + H + U * H) + (hid * H * H + H * U)
     return dict(
+        # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
+        ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1),
+        policy_rows_kernel=dict(bound='mfma', per_update=0, launches_update=0, per_env_step=2 * B_R * net(Sa, U),
+                                launches_env_step=1),
         # layers 0 + 1 in one launch: level A's 3 chains (+ the 2 action-free pre-activations of level B) per update;
         # the actor chain per env step
         fwd_l01_kernel=dict(bound='mfma', per_update=3 * 2 * B * H * H + 2 * B * H * (Kc + 4 * Ka), launches_update=1,

@@ -619,7 +619,7 @@ int DdpgPass::setup(curious_stream_t stream) {
 }
 
 bool DdpgPass::rows_route() const {
-  return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % ROWS_R == 0) &&
+  return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % 16 == 0) &&
          !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= XLD && aligned16(thQ) && aligned16(thPi) &&
          aligned16(ttQ) && aligned16(ttPi) && aligned16(workspace) && (offQ.Wout % 4 == 0) && (offPi.Wout % 4 == 0) &&
          ((cfg->dimo + cfg->dimtd) % 4 == 0) && (cfg->dimg % 4 == 0);
@@ -652,7 +652,7 @@ int DdpgPass::rows_pass() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     lds_set = true;
   }
-  dim3 grid(B / ROWS_R, 2, xd.nex);
+  dim3 grid(2 * (B / ROWS_R), 1, xd.nex);
   { ProfScope ps__(CK_ROWS, st);
     if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
     else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }

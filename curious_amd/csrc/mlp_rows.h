@@ -47,7 +47,7 @@ struct RowsArgs {
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
-    if (a.stamps && blockIdx.x == 0 && x.tid == 0) a.stamps[blockIdx.y * 32 + (k)] = __builtin_readcyclecounter(); \
+    if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[side * 32 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
 
 struct RCtx {
@@ -285,7 +285,7 @@ __device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16
 }
 
 // ================================================================== the kernel
-// grid (B / 4, 2, n_experts): blockIdx.y = 0 critic side, 1 actor side.
+// grid (2 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
   return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256 + 4 * 2 * 64 * SLD;
 }
@@ -301,7 +301,12 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   x.stage = x.keep + 2 * a.nl * 4 * 256 + x.wave * (2 * 64 * SLD);
-  x.r0 = blockIdx.x * ROWS_R;
+  // Workgroups are dealt round-robin over the 8 XCDs in block-id order: block b lands on XCD b % 8 (speed only).  XCDs
+  // 0-3 take the critic-side workgroups, 4-7 the actor-side ones, so that an XCD's L2 pulls in only the weights of
+  // its side (3 resp. 2 of the 4 networks) instead of all of them.  grid.x = 2 * B / 4.
+  const int side = (blockIdx.x >> 2) & 1;
+  const int rgrp = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+  x.r0 = rgrp * ROWS_R;
   int64_t eo;
   (void)ex_decode<EX>(ex, blockIdx.z, eo);                  // one problem per expert: blockIdx.z = expert
   const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
@@ -312,9 +317,9 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   float* sm_v = x.sm + 16;                                  // [4][4] per-row 4-vectors (pi, dz)
   f32x4 wb[2][16];
 
-  if (blockIdx.y == 0) {
+  if (side == 0) {
     // ================================================= critic side
-    if (blockIdx.x == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+    if (rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
     const float* mq = a.mQ.th + eo;

@@ -414,3 +414,41 @@ def test_host_evaluated_reward_matches_the_kernel_reward():
     np.random.seed(4)
     tr = agents[2].buffer[1].sample(32, task_to_replay=0)
     assert len(np.unique(tr['r'].cpu().numpy())) > 4
+
+
+def test_torch_custom_op_face_matches_the_ctypes_face():
+    """torch.ops.curious_hip.* (curious_amd/torch_ops.py) call the same library entry points as curious_amd.ops."""
+    import curious_amd.torch_ops  # noqa: F401  (registers the ops)
+    from curious_amd import ops
+    agent, _ = build_pair(4, 40, rng_mode='numpy')
+    ep = synth_episodes(np.random.RandomState(5), 20, 4, 40)
+    np.random.seed(1)
+    agent.store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(4), 20)
+    np.random.seed(2)
+    agent.stage_batch()
+    cl, qpi, _, _ = agent._grads()
+    c = agent.net_cfg
+    cfg_i = [c.dimo, c.dimg, c.dimu, c.dimtd, c.hidden, c.layers, c.modular, c.clip_pos_returns, c.normalize_obs]
+    cfg_f = [c.max_u, c.gamma, c.clip_return, c.action_l2, c.norm_clip]
+    BL = agent._layout.c_batch_layout()
+    bl = [getattr(BL, f[0]) for f in BL._fields_]
+    grad = torch.zeros_like(agent.grad)
+    losses, Q_pi = torch.ops.curious_hip.ddpg_grads(cfg_i, cfg_f, agent.theta, agent.theta_target, agent._staged, bl,
+                                                    grad)
+    assert float(losses[0]) == float(cl) and torch.equal(Q_pi, qpi) and torch.equal(grad, agent.grad)
+    o = agent._staged[:, :40].contiguous()
+    g = agent._staged[:, 48:60].contiguous()
+    td = agent._staged[:, 40:44].contiguous()
+    pi, Q = torch.ops.curious_hip.policy_forward(cfg_i, cfg_f, agent.theta, o, g, td, 200.0, True)
+    u2, q2 = agent.get_actions(o, o[:, :12], g, task_descr=td, compute_Q=True)
+    assert torch.equal(pi, u2) and torch.equal(Q, q2)
+    tgt = agent.theta_target.clone()
+    torch.ops.curious_hip.polyak_update(tgt, agent.theta, 0.95)
+    agent.update_target_net()
+    assert torch.equal(tgt, agent.theta_target)
+    s1 = torch.ops.curious_hip.param_checksum(agent.theta)
+    s2 = torch.zeros(2, dtype=torch.int64, device='cuda')
+    ops.param_checksum(agent.theta, s2)
+    assert torch.equal(s1, s2)
+    with pytest.raises(Exception):
+        torch.ops.curious_hip.polyak_update(tgt.cpu(), agent.theta.cpu(), 0.95)      # no CPU implementation

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-2 profiles: rocprofv3 kernel stats + PMC passes of bench.py, default bench line, one-rank RCCL path.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2e; mkdir -p $O
+cd $R && python -m curious_amd.build > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.json 2> $O/stats.log
+S="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $S > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $S > /dev/null 2> $O/pmc_write.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq1 -- $S > /dev/null 2> $O/pmc_sq1.log
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2 -- $S > /dev/null 2> $O/pmc_sq2.log
+cd $R
+python tools/pmc_summary.py $O/pmc_hbm_traffic.json $O/pmc_fetch $O/pmc_write > $O/pmc_hbm.txt 2>&1
+python tools/pmc_summary.py $O/pmc_sq_counters.json $O/pmc_sq1 $O/pmc_sq2 > $O/pmc_sq.txt 2>&1
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+# big raw traces are not needed back home
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?" >> $O/bench_default.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 CURIOUS_FORCE_DIST=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_forcedist.json 2> $O/bench_forcedist.err; echo "rc=$?" >> $O/bench_forcedist.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 CURIOUS_FORCE_DIST=1 CURIOUS_GRAPH_ALLREDUCE=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_forcedist_graph.json 2> $O/bench_forcedist_graph.err; echo "rc=$?" >> $O/bench_forcedist_graph.err
+timeout 200 python bench.py --structure task_experts --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_experts.json 2> $O/bench_experts.err
+timeout 200 python bench.py --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_arm8_1024.json 2> $O/bench_arm8_1024.err
+head -c 600 $O/bench_kernel_stats.csv; cat $O/pmc_hbm.txt | tail -20; tail -n 2 $O/*.err

@@ -63,7 +63,7 @@ int main() {
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  dim3 grid(B / ROWS_R, 2, 1);
+  dim3 grid(2 * (B / ROWS_R), 1, 1);
   auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
