@@ -563,7 +563,8 @@ struct UpdateTail {
 
 // One pass of DDPG._grads (+ the optimiser tail of curious_ddpg_update): the launch sequence of DESIGN.md section 4.
 // setup() validates and carves, then forward() -> critic_backward() -> actor_backward() -> weight_grads() enqueue the
-// 9 launches of the lean route (or their generic equivalents).
+// launches: the row-local route (rows_pass: one launch) or the 8 tiled launches (or their generic equivalents), then
+// the weight-gradient launch.
 struct DdpgPass {
   // arguments
   const curious_net_cfg_t* cfg; const float* theta_main; const float* theta_target; const float* batch;

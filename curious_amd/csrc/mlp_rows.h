@@ -50,7 +50,13 @@ struct RowsArgs {
     if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[side * 32 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
 
+#ifdef ROWS_DEBUG           // tools/rows_lab.hip: fine-grained stamps inside the layer routines
+#define ROWS_DBG(x) do { if ((x).dbg && (x).tid == 0) *(x).dbg++ = __builtin_readcyclecounter(); } while (0)
+#else
+#define ROWS_DBG(x) do { } while (0)
+#endif
 struct RCtx {
+  mutable unsigned long long* dbg;
   float* hs; float* part; float* xin; float* sm; float* keep;
   float* stage;              // this wave's private staging area of the backward layers: [2][64 rows][SLD]
   int tid, wave, lane, r0;
@@ -135,14 +141,17 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
                                              float* keep, float* gout, const RNext& next) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const float bv = bias[x.tid];
+  ROWS_DBG(x);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c < 3) rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
     else rows_prefetch(wb[0], next, x.wave, x.lane);
     __builtin_amdgcn_sched_barrier(0);
     rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
+    ROWS_DBG(x);
   }
   rows_fw_finish(x, acc, bv, keep, gout);
+  ROWS_DBG(x);
 }
 // ---- one 256 x 256 hidden layer, backward: hs <- (hs . W^T) * relu'(mask).
 // dX[i][k] = sum_n dY[i][n] W[k][n]: the matrix instruction wants lane l to supply W[k_l][n] for ONE n per instruction,
@@ -294,6 +303,7 @@ template <bool EX>
 __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
+  x.dbg = nullptr;
   x.hs = rows_lds;
   x.part = x.hs + 4 * RLD;
   x.xin = x.part + 4 * 4 * 256;
@@ -307,6 +317,9 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   const int side = (blockIdx.x >> 2) & 1;
   const int rgrp = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
   x.r0 = rgrp * ROWS_R;
+#ifdef ROWS_DEBUG
+  if (a.stamps && rgrp == 0 && side == 1) x.dbg = a.stamps + 64;
+#endif
   int64_t eo;
   (void)ex_decode<EX>(ex, blockIdx.z, eo);                  // one problem per expert: blockIdx.z = expert
   const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;

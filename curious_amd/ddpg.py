@@ -29,6 +29,8 @@ from curious_amd.util import import_function, store_args, transitions_in_episode
 
 ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
 CHAIN = 10              # updates per chained hipGraph launch in train_batches (even: the staging tensors alternate)
+LONG_CHAIN = 50         # single-rank path: a longer chain when that many updates are due (a graph launch leaves the GPU
+                        # idle for ~5 us; at 48 us per update that is 1 % per 10-update chain)
 # hipStreamCaptureModeThreadLocal: HIP calls of OTHER threads (the RCCL watchdog polling events) must not invalidate a
 # capture that only this thread's launches take part in
 CAPTURE_MODE = 'thread_local'
@@ -94,7 +96,7 @@ class DDPG(object):
         self._staged = None
         self._pp = None                                              # the two staging tensors of the device loop
         self._cur = 0
-        self._graph = self._graph_b = self._graph_ba = self._graph_chain = None
+        self._graph = self._graph_b = self._graph_ba = self._graph_chain = self._graph_long = None
         self._graphs = [None, None]
         self._tables_dirty = True
         self._batch_stale = True
@@ -270,7 +272,7 @@ class DDPG(object):
                 and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
 
     def act_and_step(self, env, t, noise_eps=0., random_eps=0., use_target_net=False):
-        """policy.get_actions(...) + env.step(...) for every env of a BatchedSyntheticArm in 4 launches
+        """policy.get_actions(...) + env.step(...) for every env of a BatchedSyntheticArm in one launch
         (curious_policy_act_env_step); same numbers as get_actions followed by env.step_all."""
         n = env.n
         theta = self.theta_target if use_target_net else self.theta
@@ -810,7 +812,7 @@ class DDPG(object):
             k = 1
             chainable = not dist.is_distributed() or (self._graph_allreduce() and self.Q_adam.t % CHAIN == 0)
             if self._device_loop() and self.use_graph and chainable and n >= CHAIN and self._cur == 0:
-                k = CHAIN
+                k = LONG_CHAIN if (n >= LONG_CHAIN and not dist.is_distributed()) else CHAIN
             out = self._train_device(k) if self._device_loop() else self.train()
             n -= k
         return out
@@ -901,11 +903,17 @@ class DDPG(object):
                     self._batch_stale = True
                 graph = self._graphs[self._cur]
             else:
-                assert k == CHAIN and k % 2 == 0 and self._cur == 0
-                if self._graph_chain is None:
-                    self._graph_chain = self._capture(lambda: [self._update_fused(i & 1) for i in range(CHAIN)])
-                    self._batch_stale = True
-                graph = self._graph_chain
+                assert k in (CHAIN, LONG_CHAIN) and k % 2 == 0 and self._cur == 0
+                if k == CHAIN:
+                    if self._graph_chain is None:
+                        self._graph_chain = self._capture(lambda: [self._update_fused(i & 1) for i in range(CHAIN)])
+                        self._batch_stale = True
+                    graph = self._graph_chain
+                else:
+                    if getattr(self, '_graph_long', None) is None:
+                        self._graph_long = self._capture(lambda: [self._update_fused(i & 1) for i in range(LONG_CHAIN)])
+                        self._batch_stale = True
+                    graph = self._graph_long
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False
@@ -923,10 +931,10 @@ class DDPG(object):
 
     @staticmethod
     def _graph_allreduce():
-        """CURIOUS_GRAPH_ALLREDUCE=1: capture the RCCL all-reduce inside the update graph (one graph launch per update
-        or per chain instead of graph + eager collective + graph).  Opt-in: it could only be exercised against a
-        single-rank RCCL communicator on the 1-GPU development boxes."""
-        return os.environ.get('CURIOUS_GRAPH_ALLREDUCE', '0') == '1'
+        """Capture the RCCL all-reduce inside the update graph (one graph launch per chain of updates instead of graph +
+        eager collective + graph per update)?  Decided by curious_amd.dist.captured_allreduce_ok: forced by
+        CURIOUS_GRAPH_ALLREDUCE=0/1, otherwise by a collective self-test at the first use."""
+        return dist.captured_allreduce_ok()
 
     def _ranks_update(self):
         self._grads()

@@ -107,3 +107,53 @@ def broadcast_object(obj, root=0):
 def barrier():
     if is_distributed():
         td.barrier()
+
+
+_CAPTURED_OK = None
+
+
+def captured_allreduce_ok():
+    """May the gradient all-reduce be captured inside the update hipGraph (DDPG.train_batches)?  CURIOUS_GRAPH_ALLREDUCE
+    = 1 / 0 forces the answer; unset, the ranks find out together once per process: every rank captures a small RCCL
+    all-reduce in a graph, replays it three times and compares the result with the known sum; the ranks then agree on
+    the minimum of their verdicts (an eager all-reduce), so either all of them chain their updates or none does.  A
+    watchdog ends the process if the replayed collective never completes (a hang is not recoverable in-process)."""
+    global _CAPTURED_OK
+    env = os.environ.get('CURIOUS_GRAPH_ALLREDUCE', 'auto')
+    if env in ('0', '1'):
+        return env == '1'
+    if _CAPTURED_OK is not None:
+        return _CAPTURED_OK
+    if not is_distributed() or td.get_backend() != 'nccl':
+        _CAPTURED_OK = False
+        return False
+    import threading
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ws, rk = world_size(), rank()
+    watchdog = threading.Timer(120.0, lambda: os._exit(17))
+    watchdog.daemon = True
+    watchdog.start()
+    ok = False
+    try:
+        x = torch.full([4096], float(rk + 1), device=dev)
+        y = torch.empty_like(x)
+        y.copy_(x)
+        td.all_reduce(y)                                             # communicator warm-up outside any capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            y.copy_(x)
+            td.all_reduce(y)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        ok = bool((y == float(ws * (ws + 1) // 2)).all())
+        del g
+    except Exception:                                                # any failure: the eager collective is used
+        ok = False
+    finally:
+        watchdog.cancel()
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    td.all_reduce(flag, op=td.ReduceOp.MIN)
+    _CAPTURED_OK = bool(flag.item() == 1.0)
+    return _CAPTURED_OK

@@ -3,8 +3,8 @@
 The reference keeps one DDPG per task on shared replay buffers (train.py:285-291) and trains them one after the other,
 one expert per epoch (train.py:65-121); expert t_id samples its minibatch from buffer t_id + 1 and relabels to its own
 task (ddpg.py:302-318,335).  The experts are independent given the buffers, so here all N of them go through ONE launch
-sequence per update (curious_ddpg_update_experts: the 9 launches of a single-agent update with the expert on grid.z /
-grid.y) and -- with several ranks -- one all-reduce of the concatenated N x P gradient.
+sequence per update (curious_ddpg_update_experts: the 2 launches of a single-agent update with the expert on grid.z /
+grid.y).
 
 Layout: every expert's update state (parameters, target, gradient, Adam moments, step counter, step-size ring,
 workspace, the two staged batches, sampling tables, loss outputs) is carved, in the same order, out of row e of one
@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from curious_amd import _lib, dist, ops
-from curious_amd.ddpg import CAPTURE_MODE, CHAIN
+from curious_amd.ddpg import CAPTURE_MODE, CHAIN, LONG_CHAIN
 
 SEED_STRIDE_SAMPLER = 104729            # DDPG._refresh_device_tables: sampler key = seed * 104729 + ...
 
@@ -130,7 +130,7 @@ class ExpertBank:
         return g
 
     def _train(self, k):
-        """k updates of every expert (k = 1 or CHAIN)."""
+        """k updates of every expert (k = 1, CHAIN or LONG_CHAIN)."""
         if dist.is_distributed():
             raise NotImplementedError('the batched expert update runs on one rank per replica set; use '
                                       'experts_update=sequential with several ranks')
@@ -163,7 +163,9 @@ class ExpertBank:
             return [x.train_batches(n) for x in self.experts]
         try:
             while n > 0:
-                k = CHAIN if (self.use_graph and n >= CHAIN and self._cur == 0) else 1
+                k = 1
+                if self.use_graph and self._cur == 0 and n >= CHAIN:
+                    k = LONG_CHAIN if n >= LONG_CHAIN else CHAIN
                 self._train(k)
                 n -= k
         except _lib.CuriousHipError as err:

@@ -261,14 +261,14 @@ int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const f
                         const curious_adam_state_t* adam, const curious_next_batch_t* next, curious_stream_t stream);
 
 /* Batched task_experts update (BASELINE configs[4]): curious_ddpg_update for n_experts agents of identical shape in
- * ONE launch sequence (9 launches, grid.z / grid.y carry the expert).  The reference keeps one DDPG per task on shared
+ * ONE launch sequence (2 launches on the row-local route, grid.z / grid.y carry the expert).  The reference keeps one DDPG per task on shared
  * buffers and trains them one after the other (train.py:65-121; sampling rule ddpg.py:302-318,335).  Every per-expert
  * array -- theta_main, theta_target, batch, workspace, grad, out_losses, out_Q_pi, step_ctr, adam->m / v / alpha_tab,
  * next->batch and the sampling tables of next->rng (prop_prefix, cur_size, buf_alias, buf_task, step_ctr) -- is passed
  * for expert 0 and lives at the same offset of a per-expert slab; expert e's copy is expert_stride FLOATS (a multiple
  * of 64) further.  Shared: next->storage, the layouts, tasks, sampler parameters.  Expert e draws its batches with the
  * Philox key next->rng->seed + e * seed_stride.  Results per expert are bit-identical to curious_ddpg_update on that
- * expert alone.  Requires the lean route (hidden 256, >= 3 layers, dimu 4, B % 256 == 0, no input normalisation) and
+ * expert alone.  Requires the fast routes (modular nets, hidden 256, 2-3 layers, dimu 4, B % 256 == 0, no input normalisation) and
  * fails with an error otherwise (the caller then updates the experts one by one). */
 int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                 uint64_t seed_stride, float* theta_main, const float* theta_target,
@@ -315,7 +315,8 @@ int curious_counter_add(int64_t* p, int64_t delta, curious_stream_t stream);
 
 /* Fused acting step of the batched rollout: actor forward on the envs' current (o, g, td), output layer + noise +
  * clip + eps-greedy (device Philox, as curious_action_noise in throughput mode) and ONE env step, i.e.
- * policy.get_actions + env.step of rollout.py:226-263 for all n envs in 4 launches instead of 6.  u_out receives the
+ * policy.get_actions + env.step of rollout.py:226-263 for all n envs in ONE launch on the row-local route (n % 4 == 0,
+ * hidden 256; 3-4 launches otherwise).  u_out receives the
  * actions.  Same results, bit for bit, as curious_policy_forward + curious_action_noise + curious_env_step.
  * The Philox noise counter is counter + *counter_base (counter_base: optional device int64, so that a T-step rollout
  * captured once in a hipGraph draws fresh noise on every replay). */

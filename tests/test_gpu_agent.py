@@ -284,19 +284,24 @@ def test_rank_paths_match_single_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
-    for extra in ({}, {'CURIOUS_FORCE_DIST': '1'}, {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '1'}):
+    # eager collective forced, captured collective forced, and the default: decided by the collective self-test of
+    # curious_amd.dist.captured_allreduce_ok
+    for extra in ({}, {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '0'},
+                  {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '1'}, {'CURIOUS_FORCE_DIST': '1'}):
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), **extra)
+                   MASTER_PORT=str(port))
+        env.pop('CURIOUS_GRAPH_ALLREDUCE', None)
+        env.update(extra)
         out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rank_path_check.py')], env=env, cwd=root,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1].split()
         assert line[2] == '35'
         digests.append(line[1])
-    assert digests[0] == digests[1] == digests[2], digests
+    assert digests[0] == digests[1] == digests[2] == digests[3], digests
 
 
 def test_two_ranks_share_one_gpu_over_gloo():

@@ -24,7 +24,8 @@ def main():
         bench.cycle(policy, worker)
     torch.cuda.synchronize()
     h = hashlib.sha256(policy.theta.cpu().numpy().tobytes()).hexdigest()
-    line = 'DIGEST %s %d %r\n' % (h, int(policy._step_ctr), float(policy._losses[0]))
+    line = 'DIGEST %s %d %r captured=%s\n' % (h, int(policy._step_ctr), float(policy._losses[0]),
+                                              dist.captured_allreduce_ok() if dist.is_distributed() else None)
     out = os.environ.get('CURIOUS_RANK_CHECK_OUT')
     if out:                                     # one file per rank: ranks of one launcher share (and interleave on) stdout
         with open('%s.rank%d' % (out, dist.rank()), 'w') as f:

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
+#define ROWS_DEBUG 1
 #include "common.h"
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mlp_common.h"
@@ -34,7 +35,7 @@ int main() {
   CK(hipMalloc(&dth, th.size() * 4)); CK(hipMalloc(&dbatch, batch.size() * 4));
   const size_t BH = (size_t)B * H;
   CK(hipMalloc(&ws, (4 * nl * BH + 16 * B) * 4));
-  CK(hipMalloc(&dst, 64 * 8));
+  CK(hipMalloc(&dst, 1024 * 8)); CK(hipMemset(dst, 0, 1024 * 8));
   CK(hipMemcpy(dth, th.data(), th.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbatch, batch.data(), batch.size() * 4, hipMemcpyHostToDevice));
   auto mk = [&](const float* base, int S, int D) {
@@ -91,6 +92,13 @@ int main() {
       printf("  %s side (shader cycles): ", ty ? "actor" : "critic");
       for (int k = 1; k < 10; ++k) printf("%s %llu | ", names[ty][k], st[ty * 32 + k] - st[ty * 32 + k - 1]);
       printf("total %llu\n", st[ty * 32 + 9] - st[ty * 32]);
+    }
+    {
+      unsigned long long d[256];
+      CK(hipMemcpy(d, dst + 64, sizeof(d), hipMemcpyDeviceToHost));
+      printf("  actor side, forward hidden layers (start | after chunk 0..3 | after finish), deltas: ");
+      for (int k = 1; k < 24 && d[k]; ++k) printf("%s%llu", (k % 6 == 0) ? " || " : " ", d[k] - d[k - 1]);
+      printf("\n");
     }
   }
   return 0;
