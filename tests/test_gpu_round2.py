@@ -452,3 +452,83 @@ def test_torch_custom_op_face_matches_the_ctypes_face():
     assert torch.equal(s1, s2)
     with pytest.raises(Exception):
         torch.ops.curious_hip.polyak_update(tgt.cpu(), agent.theta.cpu(), 0.95)      # no CPU implementation
+
+
+@pytest.mark.parametrize('name', ['arm4', 'arm8', 'arm4rand', 'expert2'])
+def test_store_episode_and_sample_batch_match_the_reference_class(name):
+    """curious_amd.DDPG.store_episode / sample_batch (numpy stream) against tests/golden/ddpg_host.npz = the outputs of the
+    reference's own DDPG.store_episode / sample_batch (ddpg.py:163-223, :251-360) on the same seeds: buffer routing
+    (incl. j < 5 and the aliased buffers 6..), the HER batch fed to the normalisers, proportions for three CP vectors and
+    the staged arrays ag, g, o, task_descr, u, o_2, g_2, r -- bit for bit."""
+    from conftest import load_golden, sub
+    from curious_amd.ddpg import DDPG
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    G = load_golden('ddpg_host')
+    cases = {'arm4': (4, 40, 'curious', 'replay_task_cp_buffer', None),
+             'arm8': (8, 52, 'curious', 'replay_task_cp_buffer', None),
+             'arm4rand': (4, 40, 'curious', 'replay_task_random_buffer', None),
+             'expert2': (4, 40, 'task_experts', 'replay_current_task_buffer', 2)}
+    Tg, B, cap = [int(x) for x in G['cfg']]
+    nb, dimo, structure, tr, t_id = cases[name]
+    Gd = 3 * nb
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=Gd, ag=Gd, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(Tg + 1, dimo), u=(Tg, 4), g=(Tg, Gd), ag=(Tg + 1, Gd), info_is_success=(Tg, 1),
+                  task_descr=(Tg, nb), change=(Tg, Gd))
+    sampler = make_sample_multi_task_her_transitions('her', 4, tr, sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    bufs = make_pooled_buffers(shapes, Tg * cap, Tg, sampler, nb + 1, alias_from=5)
+    gamma = 1. - 1. / Tg
+    agent = DDPG(input_dims=dims, hidden=64, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
+                 polyak=0.95, batch_size=B, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1.,
+                 clip_obs=200., scope='ddpg', T=Tg, rollout_batch_size=2, subtract_goals=None, relative_goals=False,
+                 clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False, sample_transitions=sampler,
+                 gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids, task_replay=tr, eps_task=0.4,
+                 structure=structure, t_id=t_id, rng_mode='numpy', seed=1)
+    ci = list(cases).index(name)
+    cps = [G['%s/sample%d/cp' % (name, k)] for k in range(3)]
+    for rnd in range(2):
+        ep = {k: v.copy() for k, v in sub(G, '%s/store%d/in/' % (name, rnd)).items()}
+        np.random.seed(100 * ci + rnd)
+        agent.store_episode(ep, cps[rnd], 12 * (rnd + 1))
+        np.testing.assert_array_equal([agent.buffer[i].current_size for i in range(nb + 1)],
+                                      G['%s/store%d/sizes' % (name, rnd)])
+        cols = agent._layout.batch_cols
+        sb = agent._stats_batch.cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(sb[:, cols['o'][0]:cols['o'][0] + dimo], G['%s/store%d/stats_o' % (name, rnd)])
+        np.testing.assert_array_equal(sb[:, cols['g'][0]:cols['g'][0] + Gd], G['%s/store%d/stats_g' % (name, rnd)])
+    for i in range(min(nb + 1, 6)):
+        n = agent.buffer[i].current_size
+        v = agent.buffer[i].buffers
+        np.testing.assert_array_equal(v['o'][:n].cpu().numpy().astype(np.float64), G['%s/buffer%d/o' % (name, i)])
+        np.testing.assert_array_equal(v['g'][:n].cpu().numpy().astype(np.float64), G['%s/buffer%d/g' % (name, i)])
+    for k, cp in enumerate(cps):
+        agent.cp = cp
+        np.random.seed(7000 + 10 * ci + k)
+        got = agent.sample_batch()
+        np.testing.assert_array_equal(agent.proportions, G['%s/sample%d/proportions' % (name, k)])
+        for key, arr in zip(['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r'], got):
+            np.testing.assert_array_equal(arr.cpu().numpy().astype(np.float64), G['%s/sample%d/%s' % (name, k, key)],
+                                          err_msg='%s sample %d %s' % (name, k, key))
+
+
+def test_action_noise_kernel_matches_the_reference_method():
+    """curious_action_noise (parity mode: host-drawn randn / binomial / uniform in the reference's order) against the
+    outputs of the reference's own DDPG.get_actions post-processing (tests/golden/get_actions.npz), bit for bit."""
+    from conftest import load_golden
+    from curious_amd import ops
+    G = load_golden('get_actions')
+    for n in [int(x) for x in G['ns']]:
+        for tag, ne, re in (('noisy', 0.2, 0.3), ('greedy', 0.0, 0.0)):
+            np.random.seed(1000 + n)
+            randn = np.random.randn(n, 4)                                  # ddpg.py:149
+            binom = np.random.binomial(1, re, n).astype(np.float64)       # ddpg.py:152
+            unif = np.random.uniform(low=-1.0, high=1.0, size=(n, 4))     # ddpg.py:114-115
+            assert float(np.random.uniform()) == float(G['n%d/%s/next_uniform' % (n, tag)])
+            u = torch.from_numpy(G['n%d/pi' % n].copy()).cuda()
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            ops.action_noise(u, n, 4, ne * 1.0, re, 1.0, d(randn.reshape(-1)), d(binom), d(unif.reshape(-1)))
+            np.testing.assert_array_equal(u.cpu().numpy().reshape(G['n%d/%s/u' % (n, tag)].shape),
+                                          G['n%d/%s/u' % (n, tag)])

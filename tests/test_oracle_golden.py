@@ -174,3 +174,78 @@ def test_sagg_riac_matches_reference():
     np.testing.assert_array_equal(np.array([len(r[0]) for r in sel.regions]), d['final_sizes'])
     assert sel.max_difference == float(d['max_difference'])
     assert np.random.uniform() == float(d['end_draw'])             # same amount of the stream consumed
+
+
+DDPG_HOST = load_golden('ddpg_host')
+HOST_CASES = {'arm4': (4, 40, 'curious', 'replay_task_cp_buffer', None),
+              'arm8': (8, 52, 'curious', 'replay_task_cp_buffer', None),
+              'arm4rand': (4, 40, 'curious', 'replay_task_random_buffer', None),
+              'expert2': (4, 40, 'task_experts', 'replay_current_task_buffer', 2)}
+
+
+class _Rec:
+    """Stands in for a normaliser: keeps what update() was given (the generator did the same to the reference)."""
+    def __init__(self): self.seen = []
+    def update(self, v): self.seen.append(np.array(v, dtype=np.float64, copy=True))
+    def recompute_stats(self): pass
+
+
+@pytest.mark.parametrize('name', [str(n) for n in DDPG_HOST['cases']])
+def test_ddpg_store_episode_and_sample_batch_match_the_reference_class(name):
+    """oracle.ddpg.OracleDDPG.store_episode / sample_batch against the outputs of the reference's OWN DDPG methods
+    (ddpg.py:163-223 and :251-360, executed by tools/gen_golden.py from an instance without graph or session): task
+    activity + routing incl. the j < 5 rule and the aliased distractor buffers, the batch fed to the normalisers, buffer
+    proportions for three CP vectors, per-buffer sampling, concat + shuffle, clip -- on the reference's random stream."""
+    from oracle.ddpg import OracleDDPG, STAGE_KEYS
+    from oracle.replay_buffer import ReplayBuffer as OBuf
+    G = DDPG_HOST
+    T, B, cap = [int(x) for x in G['cfg']]
+    nb, dimo, structure, tr, t_id = HOST_CASES[name]
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=3 * nb, ag=3 * nb, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, 3 * nb), ag=(T + 1, 3 * nb), task_descr=(T, nb),
+                  change=(T, 3 * nb), info_is_success=(T, 1))
+    sampler = oher.make_sample_multi_task_her_transitions('her', 4, tr, make_reward_fun(ag_ids, g_ids),
+                                                          tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    bufs = [OBuf(shapes, T * cap, T, sampler) for _ in range(nb + 1)]
+    agent = OracleDDPG(dims, T, bufs, sampler, ag_ids, g_ids, hidden=8, batch_size=B, task_replay=tr,
+                       structure=structure, t_id=t_id, weight_rng=np.random.RandomState(0))
+    agent.o_stats, agent.g_stats = _Rec(), _Rec()
+    ci = list(HOST_CASES).index(name)
+    cps = [G['%s/sample%d/cp' % (name, k)] for k in range(3)]
+    for rnd in range(2):
+        ep = {k: v.astype(np.float64) for k, v in sub(G, '%s/store%d/in/' % (name, rnd)).items()}
+        np.random.seed(100 * ci + rnd)
+        agent.store_episode(ep, cps[rnd], 12 * (rnd + 1))
+        np.testing.assert_array_equal([b.current_size for b in agent.buffer], G['%s/store%d/sizes' % (name, rnd)])
+        np.testing.assert_array_equal(agent.o_stats.seen[-1], G['%s/store%d/stats_o' % (name, rnd)])
+        np.testing.assert_array_equal(agent.g_stats.seen[-1], G['%s/store%d/stats_g' % (name, rnd)])
+    for i in range(min(nb + 1, 6)):
+        n = agent.buffer[i].current_size
+        np.testing.assert_array_equal(agent.buffer[i].buffers['o'][:n], G['%s/buffer%d/o' % (name, i)])
+        np.testing.assert_array_equal(agent.buffer[i].buffers['g'][:n], G['%s/buffer%d/g' % (name, i)])
+    for k, cp in enumerate(cps):
+        agent.cp = cp
+        np.random.seed(7000 + 10 * ci + k)
+        batch = agent.sample_batch()
+        np.testing.assert_array_equal(agent.proportions, G['%s/sample%d/proportions' % (name, k)])
+        for key, arr in zip(STAGE_KEYS, batch):
+            np.testing.assert_array_equal(np.asarray(arr, dtype=np.float64), G['%s/sample%d/%s' % (name, k, key)],
+                                          err_msg='%s sample %d %s' % (name, k, key))
+
+
+def test_action_postprocessing_matches_the_reference_method():
+    """oracle.ddpg.action_postprocess against DDPG.get_actions of the reference (ddpg.py:147-160, run by
+    tools/gen_golden.py with a session object that returns given float32 policy outputs): in-place float32 noise add,
+    clip, eps-greedy replacement; same amount of the NumPy stream consumed, also when both eps are 0."""
+    from oracle.ddpg import action_postprocess
+    G = load_golden('get_actions')
+    for n in [int(x) for x in G['ns']]:
+        for tag, ne, re in (('noisy', 0.2, 0.3), ('greedy', 0.0, 0.0)):
+            np.random.seed(1000 + n)
+            u = action_postprocess(G['n%d/pi' % n].copy(), np.random, ne, re, 1.0).astype(np.float32)
+            want = G['n%d/%s/u' % (n, tag)]
+            assert want.shape == ((4,) if n == 1 else (n, 4))            # ddpg.py:153-154
+            np.testing.assert_array_equal(u.reshape(want.shape), want)
+            assert float(np.random.uniform()) == float(G['n%d/%s/next_uniform' % (n, tag)])
+            np.testing.assert_array_equal(G['n%d/%s/Q' % (n, tag)], G['n%d/Qin' % n])

@@ -427,6 +427,118 @@ def gen_sagg_riac():
     save('sagg_riac', **arrs)
 
 
+def gen_ddpg_host():
+    """The NumPy halves of the reference's DDPG -- store_episode (ddpg.py:163-223: task-activity test, routing into the
+    per-task buffers, the HER-sampled batch fed to the normalisers) and sample_batch (ddpg.py:251-360: buffer
+    proportions, per-buffer sampling, concat + shuffle, clip) -- executed from the reference's own class.  The module
+    imports against the permissive tensorflow stub; an instance is made with object.__new__ and only the attributes
+    these two methods read are set (no graph, no session).  The normalisers are recorders."""
+    from collections import OrderedDict
+    if not hasattr(np, 'int'):
+        np.int = int                                    # the reference uses the alias NumPy removed in 1.24
+    from baselines.her import her as ref_her
+    from baselines.her.ddpg import DDPG
+    from baselines.her.replay_buffer import ReplayBuffer
+    from oracle.reward import make_reward_fun
+
+    class Rec:                                          # stands in for Normalizer: keeps what update() was given
+        def __init__(self): self.seen = []
+        def update(self, v): self.seen.append(np.array(v, dtype=np.float64, copy=True))
+        def recompute_stats(self): pass
+
+    def build(nb, dimo, T, structure, task_replay, t_id=None, batch_size=64, cap_eps=40):
+        ag_ids, g_ids = tables(nb)
+        G = 3 * nb
+        fn = ref_her.make_sample_multi_task_her_transitions('her', 4, task_replay, make_reward_fun(ag_ids, g_ids),
+                                                            tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+        shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), task_descr=(T, nb), change=(T, G),
+                      info_is_success=(T, 1))
+        d = object.__new__(DDPG)
+        d.structure, d.task_replay, d.nb_tasks, d.t_id = structure, task_replay, nb, t_id
+        d.tasks_ag_id, d.tasks_g_id, d.T, d.batch_size, d.eps_task = ag_ids, g_ids, T, batch_size, 0.4
+        d.relative_goals, d.clip_obs, d.dimg, d.dimag = False, 200., G, G
+        d.buffer = [ReplayBuffer(shapes, T * cap_eps, T, fn) for _ in range(nb + 1)]
+        if len(d.buffer) > 5:                           # ddpg.py:106-110
+            for i in range(6, len(d.buffer)):
+                d.buffer[i] = d.buffer[5]
+        d.sample_transitions = fn
+        d.o_stats, d.g_stats = Rec(), Rec()
+        d.stage_shapes = OrderedDict((k, None) for k in ['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r'])
+        return d
+
+    out = {}
+    cases = [('arm4', 4, 40, 'curious', 'replay_task_cp_buffer', None),
+             ('arm8', 8, 52, 'curious', 'replay_task_cp_buffer', None),
+             ('arm4rand', 4, 40, 'curious', 'replay_task_random_buffer', None),
+             ('expert2', 4, 40, 'task_experts', 'replay_current_task_buffer', 2)]
+    T = 10
+    for ci, (name, nb, dimo, structure, tr, t_id) in enumerate(cases):
+        d = build(nb, dimo, T, structure, tr, t_id)
+        rng = np.random.RandomState(900 + ci)
+        cps = [np.zeros(nb), np.linspace(0.5, 0.0, nb), np.array([0.3] + [0.0] * (nb - 1))]
+        for rnd in range(2):                            # two stores: the second one meets non-empty buffers
+            ep = synth_episodes(rng, 12, T, dimo, nb)
+            out.update(flat_dict('%s/store%d/in/' % (name, rnd), ep))
+            np.random.seed(100 * ci + rnd)
+            d.store_episode({k: v.astype(np.float64) for k, v in ep.items()}, cps[rnd], 12 * (rnd + 1))
+            out['%s/store%d/sizes' % (name, rnd)] = np.array([b.current_size for b in d.buffer])
+            out['%s/store%d/stats_o' % (name, rnd)] = d.o_stats.seen[-1]
+            out['%s/store%d/stats_g' % (name, rnd)] = d.g_stats.seen[-1]
+        for i in range(min(nb + 1, 6)):
+            out['%s/buffer%d/o' % (name, i)] = d.buffer[i].buffers['o'][:d.buffer[i].current_size].copy()
+            out['%s/buffer%d/g' % (name, i)] = d.buffer[i].buffers['g'][:d.buffer[i].current_size].copy()
+        for k, cp in enumerate(cps):
+            d.cp = cp
+            np.random.seed(7000 + 10 * ci + k)
+            batch = d.sample_batch()
+            out['%s/sample%d/cp' % (name, k)] = cp
+            out['%s/sample%d/proportions' % (name, k)] = np.asarray(d.proportions)
+            for key, arr in zip(d.stage_shapes.keys(), batch):
+                out['%s/sample%d/%s' % (name, k, key)] = np.asarray(arr)
+    out['cases'] = np.array([c[0] for c in cases])
+    out['cfg'] = np.array([T, 64, 40])
+    save('ddpg_host', **out)
+
+
+def gen_get_actions():
+    """The post-processing half of the reference's DDPG.get_actions (ddpg.py:147-160: in-place float32 noise add, clip,
+    eps-greedy replacement, 1-D result for a single row) executed from the reference's own method; the TensorFlow half
+    (sess.run of the policy) is replaced by a session object that returns given float32 policy outputs."""
+    from baselines.her.ddpg import DDPG
+
+    class Sess:
+        def __init__(self): self.out = None
+        def run(self, vals, feed_dict=None): return [a.copy() for a in self.out[:len(vals)]]
+
+    class Net:
+        pi_tf = 'pi'; Q_pi_tf = 'Qpi'; o_tf = 'o'; g_tf = 'g'; u_tf = 'u'; td_tf = 'td'
+
+    d = object.__new__(DDPG)
+    d.structure, d.relative_goals, d.clip_obs, d.max_u = 'curious', False, 200., 1.
+    d.dimo, d.dimg, d.dimag, d.dimu, d.dimtd = 40, 12, 12, 4, 4
+    d.main = d.target = Net()
+    d.sess = Sess()
+    out = {}
+    rng = np.random.RandomState(31)
+    ns = [1, 2, 17, 256]
+    for n in ns:
+        pi = rng.uniform(-1.2, 1.2, [n, 4]).astype(np.float32)
+        Q = rng.randn(n, 1).astype(np.float32)
+        o = rng.randn(n, 40).astype(np.float32); g = rng.randn(n, 12).astype(np.float32)
+        td = np.eye(4, dtype=np.float32)[rng.randint(4, size=n)]
+        for tag, ne, re in (('noisy', 0.2, 0.3), ('greedy', 0.0, 0.0)):
+            d.sess.out = [pi, Q]
+            np.random.seed(1000 + n)
+            u, q = d.get_actions(o, o[:, :12], g, task_descr=td, noise_eps=ne, random_eps=re, compute_Q=True)
+            out['n%d/%s/u' % (n, tag)] = np.asarray(u)
+            out['n%d/%s/Q' % (n, tag)] = np.asarray(q)
+            out['n%d/%s/next_uniform' % (n, tag)] = np.array(np.random.uniform())
+        out['n%d/pi' % n] = pi
+        out['n%d/Qin' % n] = Q
+    out['ns'] = np.array(ns)
+    save('get_actions', **out)
+
+
 if __name__ == '__main__':
     install_stubs()
     gen_sagg_riac()
@@ -437,3 +549,5 @@ if __name__ == '__main__':
     gen_adam()
     gen_normalizer()
     gen_mpi_moments()
+    gen_ddpg_host()
+    gen_get_actions()
