@@ -268,6 +268,8 @@ class RolloutWorker:
                 u = out
             env.step_all(u, t)
         # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
+        if not self.eval and hasattr(self.policy, 'prefetch_activity'):
+            self.policy.prefetch_activity(env.episode_views())     # arrives with the flags: one host sync per cycle
         successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
         if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
