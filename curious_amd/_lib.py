@@ -141,17 +141,19 @@ def lib():
     """The loaded library.  Raises (loudly) when it is missing -- there is no fallback path."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        override = os.environ.get('CURIOUS_LIB')        # e.g. the ASan / UBSan host build of tools/sanitize_cpu.sh
+        path = override or LIB_PATH
+        if not os.path.exists(path):
             raise CuriousHipError(
                 'libcurious_hip.so is not built (%s). Run `python -m curious_amd.build` '
-                '(hipcc --offload-arch=gfx950); curious_amd has no CPU fallback.' % LIB_PATH)
+                '(hipcc --offload-arch=gfx950); curious_amd has no CPU fallback.' % path)
         # PyTorch-ROCm bundles its own libamdhip64; the library must bind to THAT runtime instance (device pointers
         # and streams are shared with torch), so torch is imported -- and its HIP runtime loaded -- first.
         import torch  # noqa: F401
         hip = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
         if os.path.exists(hip):
             C.CDLL(hip, mode=C.RTLD_GLOBAL)
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)            # AttributeError here = header / library mismatch
             fn.restype = res
@@ -161,7 +163,7 @@ def lib():
                                   '`python -m curious_amd.build`' % (L.curious_abi_version(), ABI_VERSION))
         from curious_amd.build import source_digest
         built = L.curious_build_digest().decode()
-        if built != source_digest():
+        if not override and built != source_digest():
             raise CuriousHipError('libcurious_hip.so was built from other sources than the ones in curious_amd/csrc '
                                   '(digest %s...): rebuild with `python -m curious_amd.build`' % built[:12])
         _lib = L

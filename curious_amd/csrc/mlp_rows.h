@@ -17,9 +17,10 @@
 //   forward  (h . W):   lane l supplies A = h[l & 3][k] and B = W[k][4 l + e]; accumulator e holds columns {4 l + e}
 //                       of the 4 rows; the 4 waves split k (64 each) and meet in LDS.  One 16-byte load of W[k][4l..]
 //                       feeds 4 instructions; a wave instruction reads one contiguous 1 KB row.
-//   backward (dY . W^T): lane l = (bn, bk, j) supplies B = W[64 w + 16 a + 4 bk + j][n] for n = 16 c + 4 bn + s: wave w
-//                       owns output columns 64 w .. 64 w + 63 over all n, the four bn classes split n inside the wave
-//                       (their partial sums meet in LDS); a wave instruction reads 16 weight rows x 64 contiguous bytes.
+//   backward (dY . W^T): lane l supplies B = W[64 w + l][n]: wave w owns output columns 64 w .. 64 w + 63 over all n (no
+//                       partial sums between waves).  The lanes run along ROWS of W, so the wave's 64 weight rows are
+//                       staged through a private LDS tile (rows_big_bwd): coalesced 8 rows x 128 B loads in, one
+//                       ds_read_b128 of its own row per lane out (= the B operands of four instructions).
 #pragma once
 
 #define ROWS_MAXL 4          // layers per network on this route (layer 0 + up to 3 hidden layers)
@@ -63,7 +64,7 @@ struct RCtx {
 };
 #define SLD 36               // LDS row stride of a staged 32-wide weight-row chunk (36 l mod 64 hits 16 distinct bank quads)
 
-// ---- weight fragments of one 16-deep chunk (forward) / one 64-wide n super-chunk (backward)
+// ---- weight fragments of one 16-deep k-chunk (forward) / one 32-wide n-chunk of the wave's 64 rows (backward)
 __device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int wave, int lane, int c) {
   const float* p = W + (int64_t)(64 * wave + 16 * c) * 256 + 4 * lane;
 #pragma unroll

@@ -259,3 +259,26 @@ def test_exchange_steps_at_world_4_and_8(world):
     s = np.mean([out[r]['rows'].astype(np.float32).sum(axis=0) for r in range(world)], axis=0)
     np.testing.assert_allclose(out[0]['mean'], s / out[0]['count'], rtol=1e-5, atol=1e-6)
     assert sum(out[0]['qsizes']) > 0
+
+
+# ------------------------------------------------------------------ bench.py's multi-process CPU baseline leg
+def test_cpu_baseline_ranks_leg_of_bench():
+    """bench.py cpu_baseline_ranks (SURVEY 8d ii): R single-threaded oracle processes, gradients summed over gloo."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.cpu_baseline_ranks(2, budget_s=2.0)
+    assert 'error' not in out, out
+    assert out['cores'] == 2 and out['kind'] == 'port' and out['value'] > 0 and out['env_steps_per_sec'] > 0
+    assert 'gloo' in out['sample']
+
+
+def test_captured_allreduce_is_off_without_rccl(monkeypatch):
+    """dist.captured_allreduce_ok: forced by the environment, otherwise False unless an RCCL process group exists."""
+    from curious_amd import dist
+    monkeypatch.setenv('CURIOUS_GRAPH_ALLREDUCE', '1')
+    assert dist.captured_allreduce_ok() is True
+    monkeypatch.setenv('CURIOUS_GRAPH_ALLREDUCE', '0')
+    assert dist.captured_allreduce_ok() is False
+    monkeypatch.delenv('CURIOUS_GRAPH_ALLREDUCE')
+    monkeypatch.setattr(dist, '_CAPTURED_OK', None)
+    assert dist.captured_allreduce_ok() is False                   # no process group in this process

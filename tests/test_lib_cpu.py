@@ -56,3 +56,37 @@ def test_product_refuses_cpu_tensors():
     from curious_amd import ops, _lib
     with pytest.raises(_lib.CuriousHipError):
         ops.polyak_update(torch.zeros(4), torch.zeros(4), 0.95)
+
+
+def test_host_descriptor_code_runs_up_to_the_launch_without_gpu():
+    """On a machine without a GPU the entry points still run all of their host code -- layout arithmetic, workspace carving,
+    problem descriptors, route selection -- and fail only at the kernel launch.  Run under tools/sanitize_cpu.sh this is
+    the AddressSanitizer / UBSan coverage of the host side."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('would launch kernels on fake pointers')
+    from curious_amd import _lib
+    L = _lib.lib()
+    for dims in ((40, 12, 4, 3), (52, 24, 8, 3), (40, 12, 4, 2), (37, 12, 4, 3)):     # rows route, Arm8, 2 layers, generic
+        cfg = _lib.NetCfg()
+        cfg.dimo, cfg.dimg, cfg.dimtd, cfg.layers = dims
+        cfg.dimu, cfg.hidden, cfg.modular = 4, 256, 1
+        cfg.max_u, cfg.gamma, cfg.clip_return, cfg.action_l2, cfg.clip_pos_returns = 1.0, 0.98, 50.0, 1.0, 1
+        ws = L.curious_workspace_floats(C.byref(cfg), 256)
+        assert ws > 0 and L.curious_param_total(C.byref(cfg)) > L.curious_param_offset_pi(C.byref(cfg)) > 0
+        BL = _lib.BatchLayout()
+        BL.off_o, BL.off_td, BL.off_u, BL.off_g, BL.off_o2, BL.off_g2, BL.off_r = 0, 56, 64, 68, 92, 148, 172
+        BL.off_ag, BL.off_ag2, BL.off_extra, BL.stride = 176, 200, 224, 256
+        fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(8)]          # never dereferenced on the host
+        rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
+                                  fake[5], fake[6], None, None)
+        assert rc != 0 and b'launch failed' in L.curious_last_error()
+        st = _lib.AdamState()
+        st.m, st.v = fake[6].value, fake[7].value
+        rc = L.curious_ddpg_update(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
+                                   fake[5], fake[6], None, C.byref(st), None, None)
+        assert rc != 0 and b'launch failed' in L.curious_last_error()
+        rc = L.curious_policy_forward(C.byref(cfg), fake[0], fake[1], cfg.dimo, None, 0, fake[2], cfg.dimg, fake[3],
+                                      cfg.dimtd, 64, 200.0, 0, None, None, fake[4], fake[5], fake[6], None)
+        assert rc != 0 and b'launch failed' in L.curious_last_error()
