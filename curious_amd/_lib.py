@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 2          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 3          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -65,7 +65,7 @@ class AdamState(C.Structure):
     _fields_ = [('m', C.c_void_p), ('v', C.c_void_p), ('alpha_tab', C.c_void_p), ('tab_base', C.c_int64),
                 ('tab_len', C.c_int32), ('alpha_Q', C.c_float), ('alpha_pi', C.c_float), ('beta1', C.c_float),
                 ('one_minus_beta1', C.c_float), ('beta2', C.c_float), ('one_minus_beta2', C.c_float),
-                ('epsilon', C.c_float)]
+                ('epsilon', C.c_float), ('params_unchanged', C.c_int32)]
 
 
 class NextBatch(C.Structure):

@@ -101,6 +101,8 @@ struct Ws {   // workspace carve-up
   float *pi_t, *pi, *dQ, *dz, *rows;
   float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
   float* part[6];              // dot-epilogue partials [4 tiles][B][<=4]: pi_target, pi, Q, Q_target, Q_pi, dz
+  float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h);
+                               // the ONLY part of the workspace that carries state from one update call to the next
   int64_t total;
 };
 
@@ -125,6 +127,8 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.zp[0] = take(BH);
   w.zp[1] = take(BH);
   for (int i = 0; i < 6; ++i) w.part[i] = take(16 * (int64_t)B);
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < c->layers; ++l) w.wT[net][l] = (l >= 1) ? take((int64_t)c->hidden * c->hidden) : nullptr;
   w.total = off;
   return w;
 }
@@ -582,7 +586,9 @@ struct DdpgPass {
 
   int setup(curious_stream_t stream);
   bool rows_route() const;
-  int rows_pass();
+  bool keeps_copies(const UpdateTail* tail) const;
+  int rows_pass(bool refresh, bool maintained);
+  bool copies_kept = false;   // this pass's optimiser tail has to write the transposed copies next to the parameters
   int forward();
   int critic_backward();
   int actor_backward();
@@ -626,7 +632,27 @@ bool DdpgPass::rows_route() const {
          ((cfg->dimo + cfg->dimtd) % 4 == 0) && (cfg->dimg % 4 == 0);
 }
 
-int DdpgPass::rows_pass() {
+// The backward layers of the row-local pass run on transposed copies of the main networks' hidden matrices (workspace
+// w.wT).  The fused optimiser tail on the lean weight-gradient tiles keeps them current (weight_grads checks that it
+// really ran); on every other route they are rebuilt from the parameters at the head of the pass.
+bool DdpgPass::keeps_copies(const UpdateTail* tail) const {
+  return tail && (B % 256 == 0) && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64);
+}
+
+int DdpgPass::rows_pass(bool refresh, bool maintained) {
+  const Ex ex = make_ex(xd, 1);
+  if (refresh) {
+    RowsTransposeArgs t;
+    memset(&t, 0, sizeof(t));
+    int n = 0;
+    for (int l = 1; l < nl; ++l) { t.src[n] = thQ + offQ.W[l]; t.dst[n++] = w.wT[0][l]; }
+    for (int l = 1; l < nl; ++l) { t.src[n] = thPi + offPi.W[l]; t.dst[n++] = w.wT[1][l]; }
+    { ProfScope ps__(CK_ROWS_T, st);
+      if (xd.nex > 1) hipLaunchKernelGGL((rows_transpose_kernel<true>), dim3(16, n, xd.nex), dim3(256), 0, st, t, ex);
+      else hipLaunchKernelGGL((rows_transpose_kernel<false>), dim3(16, n, 1), dim3(256), 0, st, t, ex); }
+    CURIOUS_LAUNCH_CHECK("rows_transpose_kernel");
+  }
+  copies_kept = maintained;
   RowsArgs a;
   memset(&a, 0, sizeof(a));
   a.tQ = rows_net(ttQ, offQ, nl); a.tPi = rows_net(ttPi, offPi, nl);
@@ -637,13 +663,13 @@ int DdpgPass::rows_pass() {
   for (int l = 0; l < nl; ++l) {
     a.actc[l] = w.act[1][l]; a.dactc[l] = w.dact[0][l];
     a.acta[l] = w.act[2][l]; a.dacta[l] = w.dact[2][l];
+    a.wTq[l] = w.wT[0][l]; a.wTpi[l] = w.wT[1][l];
   }
   a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
   a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
-  const Ex ex = make_ex(xd, 1);
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
@@ -936,6 +962,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       GemmHot& p = hw.p[nh];
       p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
       p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
+      p.dot_out = copies_kept ? w.wT[critic ? 0 : 1][l] : nullptr;
       tiles += (H / 16) * (H / 64);
       ++nh;
     }
@@ -978,10 +1005,12 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       return 0;
     }
     CURIOUS_CHECK(xd.nex == 1, "batched experts need the fused update tail");
+    CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
       hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1), dim3(256), 0, st, dwAll); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
+    CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     // generic path: every weight/bias gradient + the loss finalisation in one grouped launch
     DwArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -1044,7 +1073,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
                            const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
                            const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
                            int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail,
-                           const ExDim& xd = ExDim(), uint64_t seed_stride = 0) {
+                           const ExDim& xd = ExDim(), uint64_t seed_stride = 0, bool params_unchanged = false) {
   DdpgPass p;
   p.xd = xd; p.seed_stride = seed_stride;
   p.cfg = cfg; p.theta_main = theta_main; p.theta_target = theta_target; p.batch = batch; p.BL = BL; p.B = B;
@@ -1052,7 +1081,8 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
   int rc = p.setup(stream);
   if (!rc && p.rows_route()) {
-    rc = p.rows_pass();
+    const bool maintained = p.keeps_copies(tail);
+    rc = p.rows_pass(!(maintained && params_unchanged), maintained);
   } else {
     if (!rc) rc = p.forward();
     if (!rc) rc = p.critic_backward();
@@ -1096,7 +1126,7 @@ static int ddpg_update_impl(const curious_net_cfg_t* cfg, float* theta_main, con
     t.her = true;
   }
   return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
-                         out_Q_pi, step_ctr, stream, &t, xd, seed_stride);
+                         out_Q_pi, step_ctr, stream, &t, xd, seed_stride, adam->params_unchanged != 0);
 }
 
 extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,

@@ -64,6 +64,8 @@ __device__ inline void adam_apply1(const AdamFuse& A, float na, int64_t i, float
 struct GemmHot {
   const float* A; const float* B; const float* aux; float* C; float* aux_out;
   int32_t lda, ldb, ldc, M, N, K;
+  // (weight-gradient tiles with the optimiser epilogue: dot_out = where the TRANSPOSED copy of the updated matrix is
+  //  kept, [N][K], or NULL)
   // optional epilogue (DOT kernels): partial products of the output tile with a narrow matrix that the NEXT launch
   // would otherwise have to contract over whole rows (output layers, the critic's action rows):
   //   dot_out[tile][m][d] = sum_{c in this 64-column tile} C[m][c] * w(c, d)
@@ -268,7 +270,15 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   *reinterpret_cast<f32x4*>(dst) = v;
-  if (ADAM) adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
+  if (ADAM) {
+    adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
+    // transposed copy of the updated tile for the row-local backward layers (mlp_rows.h): WT[n][k] = W[k][n]
+    if (P.dot_out) {
+      float* t = P.dot_out + eo + (int64_t)(n0 + 4 * (tid & 15)) * P.K + k0 + (tid >> 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[(int64_t)e * P.K] = pre.th[e];
+    }
+  }
   if (by == 0) {
     // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
     __syncthreads();

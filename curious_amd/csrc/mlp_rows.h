@@ -17,10 +17,13 @@
 //   forward  (h . W):   lane l supplies A = h[l & 3][k] and B = W[k][4 l + e]; accumulator e holds columns {4 l + e}
 //                       of the 4 rows; the 4 waves split k (64 each) and meet in LDS.  One 16-byte load of W[k][4l..]
 //                       feeds 4 instructions; a wave instruction reads one contiguous 1 KB row.
-//   backward (dY . W^T): lane l supplies B = W[64 w + l][n]: wave w owns output columns 64 w .. 64 w + 63 over all n (no
-//                       partial sums between waves).  The lanes run along ROWS of W, so the wave's 64 weight rows are
-//                       staged through a private LDS tile (rows_big_bwd): coalesced 8 rows x 128 B loads in, one
-//                       ds_read_b128 of its own row per lane out (= the B operands of four instructions).
+//   backward (dY . W^T): the matrix instruction wants lane l to supply W[k_l][n] for ONE n per instruction, memory offers
+//                       W[k][n .. n+3] contiguously (a direct 16-byte load per lane makes every quad of lanes touch 4
+//                       different rows: 2.5x the forward layer's time; staging the rows through LDS: 1.2x).  So the
+//                       library keeps TRANSPOSED copies of the main networks' hidden matrices in the workspace --
+//                       written by the optimiser epilogue of dw_adam_her_kernel next to the parameters it updates,
+//                       rebuilt by rows_transpose_kernel otherwise -- and dY . W^T is the forward product on W^T
+//                       (rows_big_bwdT): a backward layer costs what a forward layer costs.
 #pragma once
 
 #define ROWS_MAXL 4          // layers per network on this route (layer 0 + up to 3 hidden layers)
@@ -41,6 +44,7 @@ struct RowsArgs {
   float* actc[ROWS_MAXL]; float* dactc[ROWS_MAXL];     // main critic(u): layer outputs, masked output gradients [B,H]
   float* acta[ROWS_MAXL]; float* dacta[ROWS_MAXL];     // main actor
   float* dQ; float* dz; float* rows; float* out_Qpi;
+  const float* wTq[ROWS_MAXL]; const float* wTpi[ROWS_MAXL];   // transposed hidden matrices of main critic / actor
   int64_t* step_ctr;
   int32_t B, nl, dimo, dimtd, dimg;
   float gamma, clip_lo, clip_hi, max_u, l2c;
@@ -59,28 +63,18 @@ struct RowsArgs {
 struct RCtx {
   mutable unsigned long long* dbg;
   float* hs; float* part; float* xin; float* sm; float* keep;
-  float* stage;              // this wave's private staging area of the backward layers: [2][64 rows][SLD]
   int tid, wave, lane, r0;
 };
-#define SLD 36               // LDS row stride of a staged 32-wide weight-row chunk (36 l mod 64 hits 16 distinct bank quads)
 
-// ---- weight fragments of one 16-deep k-chunk (forward) / one 32-wide n-chunk of the wave's 64 rows (backward)
+// ---- weight fragments of one 16-deep k-chunk
 __device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int wave, int lane, int c) {
   const float* p = W + (int64_t)(64 * wave + 16 * c) * 256 + 4 * lane;
 #pragma unroll
   for (int i = 0; i < 16; ++i) b[i] = ldv(p + (int64_t)i * 256);
 }
-// backward chunk c (n = 32 c .. 32 c + 31) of this wave's 64 weight rows: instruction r8 fetches rows 8 r8 .. 8 r8 + 7,
-// 8 lanes x 16 bytes = 128 contiguous bytes per row
-__device__ __forceinline__ void rows_bw_load(f32x4* g /*[8]*/, const float* W, int wave, int lane, int c) {
-  const float* p = W + (int64_t)(64 * wave + (lane >> 3)) * 256 + 32 * c + 4 * (lane & 7);
-#pragma unroll
-  for (int r8 = 0; r8 < 8; ++r8) g[r8] = ldv(p + (int64_t)(8 * r8) * 256);
-}
-
 // ---- what a layer routine loads ahead for its successor (weights do not depend on activations): the successor's
 // first chunk lands in wb[0] while this layer's last chunk is multiplied / its epilogue runs
-enum { RN_NONE = 0, RN_FWD = 1, RN_BWD = 2, RN_L0 = 3 };
+enum { RN_NONE = 0, RN_FWD = 1, RN_L0 = 3 };
 struct RNext { int kind; const float* W; int S; const float* Wg; int nk; };     // RN_L0: W = W0
 __device__ __forceinline__ RNext rnext(int kind, const float* W, int S = 0, const float* Wg = nullptr, int nk = 0) {
   RNext n;
@@ -100,7 +94,6 @@ __device__ __forceinline__ void rows_l0_load(f32x4 (&b)[16], const float* W0, in
 }
 __device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, int wave, int lane) {
   if (n.kind == RN_FWD) rows_fw_load(b, n.W, wave, lane, 0);
-  else if (n.kind == RN_BWD) { rows_bw_load(&b[0], n.W, wave, lane, 0); rows_bw_load(&b[8], n.W, wave, lane, 1); }
   else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
 }
 __device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c,
@@ -154,48 +147,31 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
   rows_fw_finish(x, acc, bv, keep, gout);
   ROWS_DBG(x);
 }
-// ---- one 256 x 256 hidden layer, backward: hs <- (hs . W^T) * relu'(mask).
-// dX[i][k] = sum_n dY[i][n] W[k][n]: the matrix instruction wants lane l to supply W[k_l][n] for ONE n per instruction,
-// memory offers W[k][n .. n+3] contiguously -- a direct 16-byte load per lane makes every quad of lanes touch 4
-// different rows (measured: 2.5x the forward layer's time).  So the wave's 64 weight rows (= its 64 output columns, over
-// ALL n: no partial sums between waves) are staged through a private LDS tile: coalesced global loads (8 rows x 128 B
-// per instruction) -> ds_write_b128 rows of SLD floats -> every lane reads back ITS row (conflict free), one
-// ds_read_b128 = the B operands of four instructions.  Four accumulators take n mod 4 so that no instruction waits on
-// its predecessor.  (RN_BWD prefetch = chunks 0 and 1 in wb[0][0..7] / wb[0][8..15].)
-__device__ __forceinline__ void rows_big_bwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* mask,
-                                             float* gout, const RNext& next) {
+// ---- one 256 x 256 hidden layer, backward on the TRANSPOSED matrix: hs <- (hs . WT) * relu'(mask), WT[n][k] = W[k][n].
+// The forward product with another epilogue (no bias; the kept activation of the layer below gates the gradient).
+__device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const float* mask,
+                                              float* gout, const RNext& next) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  float* const st = x.stage;
-  const int wrow = (x.lane >> 3) * SLD + 4 * (x.lane & 7);           // where this lane's 16 bytes of a fetched row go
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    f32x4* g = &wb[0][8 * (c & 1)];
-    float* buf = st + (c & 1) * 64 * SLD;
-#pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<f32x4*>(buf + 8 * r8 * SLD + wrow) = g[r8];
-    if (c + 2 < 8) rows_bw_load(g, W, x.wave, x.lane, c + 2);
-    else if (c == 7) rows_prefetch(wb[0], next, x.wave, x.lane);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(buf + x.lane * SLD + 4 * q);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(x.hs + (x.lane & 3) * RLD + 32 * c + 4 * q);
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc[s2] = MFMA4(a[s2], b[s2], acc[s2]);
-    }
+  for (int c = 0; c < 4; ++c) {
+    if (c < 3) rows_fw_load(wb[(c + 1) & 1], WT, x.wave, x.lane, c + 1);
+    else rows_prefetch(wb[0], next, x.wave, x.lane);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
   }
-  // lane l owns column 64 wave + l of the 4 rows
-  const int col = 64 * x.wave + x.lane;
-  float o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float v = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
-    o[i] = (mask[i * 256 + col] > 0.f) ? v : 0.f;
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    *reinterpret_cast<f32x4*>(x.part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
   }
-  __syncthreads();                                           // every wave has read its dY operands out of hs
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    x.hs[i * RLD + col] = o[i];
-    if (gout) gout[(int64_t)(x.r0 + i) * 256 + col] = o[i];
+  for (int r = 0; r < 4; ++r) {
+    float s = (x.part[(0 * 4 + r) * 256 + x.tid] + x.part[(1 * 4 + r) * 256 + x.tid]) +
+              (x.part[(2 * 4 + r) * 256 + x.tid] + x.part[(3 * 4 + r) * 256 + x.tid]);
+    s = (mask[r * 256 + x.tid] > 0.f) ? s : 0.f;
+    x.hs[r * RLD + x.tid] = s;
+    if (gout) gout[(int64_t)(x.r0 + r) * 256 + x.tid] = s;
   }
   __syncthreads();
 }
@@ -283,21 +259,26 @@ __device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16
     rows_big_fwd(x, wb, th + N.W[l], th + N.b[l], keep0 ? keep0 + l * 1024 : nullptr, g, nx);
   }
 }
-// hidden layers nl-1 .. 1 of a network, backward; which: 0 nothing stored, 1 -> a.dactc[l-1], 2 -> a.dacta[l-1]
-__device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
-                                                const float* th, const float* keep0, int which, int64_t eo,
-                                                const RNext& after) {
+// hidden layers nl-1 .. 1 of a network, backward on the transposed copies; which: 0 critic, nothing stored,
+// 1 critic -> a.dactc[l-1], 2 actor -> a.dacta[l-1]
+__device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a,
+                                                const float* keep0, int which, int64_t eo, const RNext& after) {
   for (int l = a.nl - 1; l >= 1; --l) {
     float* g = (which == 1) ? a.dactc[l - 1] + eo : (which == 2) ? a.dacta[l - 1] + eo : nullptr;
-    const RNext nx = (l > 1) ? rnext(RN_BWD, th + N.W[l - 1]) : after;
-    rows_big_bwd(x, wb, th + N.W[l], keep0 + (l - 1) * 1024, g, nx);
+    const float* wt = ((which == 2) ? a.wTpi[l] : a.wTq[l]) + eo;
+    const RNext nx = (l > 1) ? rnext(RN_FWD, ((which == 2) ? a.wTpi[l - 1] : a.wTq[l - 1]) + eo) : after;
+    rows_big_bwdT(x, wb, wt, keep0 + (l - 1) * 1024, g, nx);
   }
+}
+// what the layer in front of a network's backward pass loads ahead: the first chunk of its top hidden matrix
+__device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, int64_t eo) {
+  return rnext(RN_FWD, (actor ? a.wTpi[a.nl - 1] : a.wTq[a.nl - 1]) + eo);
 }
 
 // ================================================================== the kernel
 // grid (2 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
-  return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256 + 4 * 2 * 64 * SLD;
+  return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;
 }
 
 template <bool EX>
@@ -311,7 +292,6 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   x.sm = x.xin + 4 * XLD;
   x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
-  x.stage = x.keep + 2 * a.nl * 4 * 256 + x.wave * (2 * 64 * SLD);
   // Workgroups are dealt round-robin over the 8 XCDs in block-id order: block b lands on XCD b % 8 (speed only).  XCDs
   // 0-3 take the critic-side workgroups, 4-7 the actor-side ones, so that an XCD's L2 pulls in only the weights of
   // its side (3 resp. 2 of the 4 networks) instead of all of them.  grid.x = 2 * B / 4.
@@ -383,7 +363,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     ROWS_STAMP(6);
     rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, x.keep, a.actc[0] + eo,
                 rnext(RN_FWD, mq + a.mQ.W[1]));
-    rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
+    rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rows_bwd_first(a, false, eo));
     ROWS_STAMP(7);
     {
       const float Q = rows_head1(x, wq_m) + bq_m;
@@ -412,7 +392,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     }
     __syncthreads();
     ROWS_STAMP(8);
-    rows_hidden_bwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rnext(RN_NONE, nullptr));
+    rows_hidden_bwd(x, wb, a, x.keep, 1, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(9);
     return;
   }
@@ -463,7 +443,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   // ---- main critic on (o, g, pi) -> Q_pi
   rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, keepD, nullptr,
               rnext(RN_FWD, mq + a.mQ.W[1]));
-  rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mq + a.mQ.W[nl - 1]));
+  rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
   ROWS_STAMP(5);
   {
     const float Qpi = rows_head1(x, wq_m) + bq_m;
@@ -489,7 +469,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     for (int d = 0; d < 4; ++d) wu[d] = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
   }
   const f32x4 wpi_row = ldv(mp + a.mPi.Wout + 4 * x.tid);
-  rows_hidden_bwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rnext(RN_BWD, mp + a.mPi.W[nl - 1]));
+  rows_hidden_bwd(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
   ROWS_STAMP(7);
   {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
@@ -528,6 +508,25 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   }
   __syncthreads();
   ROWS_STAMP(8);
-  rows_hidden_bwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_NONE, nullptr));
+  rows_hidden_bwd(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
   ROWS_STAMP(9);
+}
+
+// ---- (re)build the transposed copies from the parameters: dst[j][n][k] = src[j][k][n], 256 x 256 each.
+// grid (16 tiles of 64 x 64, matrices, n_experts)
+struct RowsTransposeArgs { const float* src[2 * ROWS_MAXL]; float* dst[2 * ROWS_MAXL]; };
+template <bool EX>
+__global__ __launch_bounds__(256) void rows_transpose_kernel(RowsTransposeArgs a, Ex ex) {
+  __shared__ float tile[64][65];
+  int64_t eo;
+  (void)ex_decode<EX>(ex, blockIdx.z, eo);
+  const float* src = a.src[blockIdx.y] + eo;
+  float* dst = a.dst[blockIdx.y] + eo;
+  const int k0 = (blockIdx.x >> 2) * 64, n0 = (blockIdx.x & 3) * 64;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[4 * i + r4][c] = src[(int64_t)(k0 + 4 * i + r4) * 256 + n0 + c];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dst[(int64_t)(n0 + 4 * i + r4) * 256 + k0 + c] = tile[c][4 * i + r4];
 }

@@ -932,12 +932,13 @@ class DDPG(object):
                 assert k in (CHAIN, LONG_CHAIN) and k % 2 == 0 and self._cur == 0
                 if k == CHAIN:
                     if self._graph_chain is None:
-                        self._graph_chain = self._capture(lambda: [self._update_fused(i & 1) for i in range(CHAIN)])
+                        self._graph_chain = self._capture(lambda: [self._update_fused(i & 1, i > 0) for i in range(CHAIN)])
                         self._batch_stale = True
                     graph = self._graph_chain
                 else:
                     if getattr(self, '_graph_long', None) is None:
-                        self._graph_long = self._capture(lambda: [self._update_fused(i & 1) for i in range(LONG_CHAIN)])
+                        self._graph_long = self._capture(
+                            lambda: [self._update_fused(i & 1, i > 0) for i in range(LONG_CHAIN)])
                         self._batch_stale = True
                     graph = self._graph_long
         if self._batch_stale:
@@ -947,8 +948,8 @@ class DDPG(object):
             graph.replay()
             self._cur ^= (k & 1)
         else:
-            for _ in range(k):
-                self._update_fused(self._cur)
+            for i in range(k):
+                self._update_fused(self._cur, i > 0)
                 self._cur ^= 1
         self._staged = self._pp[self._cur]
         self.Q_adam.t += k
@@ -1012,7 +1013,10 @@ class DDPG(object):
         self.pi_adam.t += k
         return self._losses[0], self._Q_pi
 
-    def _update_fused(self, p):
+    def _update_fused(self, p, chained=False):
+        """chained: the previous launch on this stream was this very update (inside a captured chain) -- the only case in
+        which the library may trust the transposed copies it keeps in the workspace; everything else (a single update, the
+        head of a chain) has them rebuilt from theta first."""
         S = self.sample_transitions
         ops.ddpg_update(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self.batch_size,
                         self._workspace, self.grad, self._losses, self._Q_pi, self._m, self._v,
@@ -1020,7 +1024,8 @@ class DDPG(object):
                         o_stats=self.o_stats.state if self.normalize_obs else None,
                         g_stats=self.g_stats.state if self.normalize_obs else None,
                         next_batch=self._pp[p ^ 1], storage=self._pool.storage, buf_stride=self._pool.buf_stride,
-                        tasks=S.tasks, params=S.params(self.clip_obs, self.relative_goals), rng=self._rng_desc)
+                        tasks=S.tasks, params=S.params(self.clip_obs, self.relative_goals), rng=self._rng_desc,
+                        params_unchanged=chained)
 
     def _adam_and_sample(self):
         S = self.sample_transitions

@@ -105,14 +105,14 @@ class ExpertBank:
                 x._sample_packed()
                 x._batch_stale = False
 
-    def _update_all(self, p):
+    def _update_all(self, p, chained=False):
         x0 = self.experts[0]
         S = x0.sample_transitions
         ops.ddpg_update_experts(x0.net_cfg, self.n, self.stride, SEED_STRIDE_SAMPLER, x0.theta, x0.theta_target,
                                 x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi,
                                 x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base, x0._pp[p ^ 1],
                                 x0._pool.storage, x0._pool.buf_stride, S.tasks,
-                                S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc)
+                                S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, params_unchanged=chained)
 
     def _capture(self, fn):
         """Capture `fn` after one eager warm-up; the slab (all experts' state) is restored afterwards."""
@@ -139,13 +139,13 @@ class ExpertBank:
         if self.use_graph:
             key = (k, p0)
             if key not in self._graphs:
-                self._graphs[key] = self._capture(lambda: [self._update_all((p0 + i) & 1) for i in range(k)])
+                self._graphs[key] = self._capture(lambda: [self._update_all((p0 + i) & 1, i > 0) for i in range(k)])
                 for x in self.experts:                       # the warm-up overwrote the staged batches
                     x._sample_packed()
             self._graphs[key].replay()
         else:
             for i in range(k):
-                self._update_all((p0 + i) & 1)
+                self._update_all((p0 + i) & 1, i > 0)
         self._cur ^= (k & 1)
         for x in self.experts:
             x._cur = self._cur

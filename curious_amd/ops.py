@@ -148,19 +148,13 @@ def ddpg_grads(cfg, theta_main, theta_target, batch, layout, B, workspace, grad,
 def ddpg_update(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi, m, v,
                 step_ctr=None, alpha_tab=None, tab_base=0, alpha_Q=0.0, alpha_pi=0.0, beta1=0.9, beta2=0.999,
                 epsilon=1e-08, o_stats=None, g_stats=None, next_batch=None, storage=None, buf_stride=0, tasks=None,
-                params=None, rng=None):
+                params=None, rng=None, params_unchanged=False):
     """One whole single-rank update (curious_ddpg_update): gradients with Adam applied in the weight-gradient launch;
-    with `next_batch` (a staging tensor other than `batch`) the device-drawn HER gather of the next update rides along."""
-    f = np.float32
+    with `next_batch` (a staging tensor other than `batch`) the device-drawn HER gather of the next update rides along.
+    params_unchanged: nothing but the previous call of this op on this workspace has written theta_main since (the
+    library then skips rebuilding the transposed copies it keeps in the workspace)."""
     BL = layout.c_batch_layout()
-    A = _lib.AdamState()
-    A.m, A.v = ptr(_dev(m, 'm')), ptr(_dev(v, 'v'))
-    A.alpha_tab = ptr(alpha_tab)
-    A.tab_base, A.tab_len = int(tab_base), int(alpha_tab.shape[0]) if alpha_tab is not None else 0
-    A.alpha_Q, A.alpha_pi = float(alpha_Q), float(alpha_pi)
-    A.beta1, A.one_minus_beta1 = float(f(beta1)), float(f(1 - beta1))
-    A.beta2, A.one_minus_beta2 = float(f(beta2)), float(f(1 - beta2))
-    A.epsilon = float(f(epsilon))
+    A = _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsilon, params_unchanged)
     nb = None
     if next_batch is not None:
         L = layout.c_layout()
@@ -175,7 +169,7 @@ def ddpg_update(cfg, theta_main, theta_target, batch, layout, B, workspace, grad
                                     C.byref(A), nb, current_stream()), 'curious_ddpg_update')
 
 
-def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsilon):
+def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsilon, params_unchanged=False):
     f = np.float32
     A = _lib.AdamState()
     A.m, A.v = ptr(_dev(m, 'm')), ptr(_dev(v, 'v'))
@@ -185,16 +179,17 @@ def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsi
     A.beta1, A.one_minus_beta1 = float(f(beta1)), float(f(1 - beta1))
     A.beta2, A.one_minus_beta2 = float(f(beta2)), float(f(1 - beta2))
     A.epsilon = float(f(epsilon))
+    A.params_unchanged = int(bool(params_unchanged))
     return A
 
 
 def ddpg_update_experts(cfg, n_experts, expert_stride, seed_stride, theta_main, theta_target, batch, layout, B,
                         workspace, grad, out_losses, out_Q_pi, m, v, step_ctr, alpha_tab, tab_base, next_batch, storage,
-                        buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08):
+                        buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08, params_unchanged=False):
     """One update of n_experts agents in one launch sequence (curious_ddpg_update_experts).  Every tensor is expert
     0's view of a slab [n_experts, expert_stride]; `rng` is expert 0's sampler description."""
     BL = layout.c_batch_layout()
-    A = _adam_state(m, v, alpha_tab, tab_base, 0.0, 0.0, beta1, beta2, epsilon)
+    A = _adam_state(m, v, alpha_tab, tab_base, 0.0, 0.0, beta1, beta2, epsilon, params_unchanged)
     L = layout.c_layout()
     N = _lib.NextBatch()
     N.storage, N.buf_stride = ptr(_dev(storage, 'storage')), int(buf_stride)

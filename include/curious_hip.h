@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 2      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 3      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -245,6 +245,11 @@ typedef struct curious_adam_state {
   int32_t tab_len;
   float alpha_Q, alpha_pi;             /* step sizes when alpha_tab == NULL */
   float beta1, one_minus_beta1, beta2, one_minus_beta2, epsilon;
+  int32_t params_unchanged;            /* non-zero: since the previous curious_ddpg_update* call on THIS workspace returned,
+                                        * nothing else has written theta_main (and the workspace was left alone).  The
+                                        * library keeps transposed copies of the main networks' hidden matrices in the
+                                        * workspace for its backward layers; the optimiser epilogue keeps them current,
+                                        * and with 0 (always safe, +1 launch) they are rebuilt from theta_main first. */
 } curious_adam_state_t;
 
 typedef struct curious_next_batch {

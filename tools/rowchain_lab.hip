@@ -23,7 +23,10 @@ __device__ inline f32x4 ldv(const float* p) { return *reinterpret_cast<const f32
 __device__ inline f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // R = rows per workgroup (4 or 8).  grid (B / R, nchains).  W: [nchains][L][256][256], bias: [nchains][L][256].
-template <int R>
+// MODE 0: all 16 loads of the next chunk are issued before the current chunk's matrix instructions;
+// MODE 1: they are issued 4 at a time between the 4 k-steps of the current chunk (a wave issues in order: a vector-memory
+//         instruction the texture path cannot accept yet holds back the matrix instructions behind it)
+template <int R, int MODE>
 __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, const float* __restrict__ W,
                                                 const float* __restrict__ bias, float* __restrict__ Y, int L, int B) {
   constexpr int G = R / 4;                                  // row groups of 4
@@ -56,13 +59,19 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
     for (int c = 0; c < 4; ++c) {
       // prefetch the next 16-deep chunk (of the next layer after the last chunk: weights do not depend on activations)
       const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
-      if (c < 3 || l + 1 < L) {
+      const bool more = (c < 3 || l + 1 < L) && MODE != 3;      // MODE 3: matrix work only (stale weights)
+      if ((MODE == 0 || MODE >= 2) && more) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) b[(c + 1) & 1][i] = ldv(nx + (size_t)i * H);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
+        if (MODE == 1 && more) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b[(c + 1) & 1][4 * kq + i] = ldv(nx + (size_t)(4 * kq + i) * H);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         f32x4 a[G];
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -72,7 +81,11 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g][e] = MFMA4(a[g][s], b[c & 1][4 * kq + s][e], acc[g][e]);
+            for (int g = 0; g < G; ++g) {
+              if (MODE == 2) acc[g][e] += b[c & 1][4 * kq + s] * a[g][s];      // MODE 2: streaming only (4 VALU FMAs)
+              else acc[g][e] = MFMA4(a[g][s], b[c & 1][4 * kq + s][e], acc[g][e]);
+            }
+        if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     wl += (size_t)H * H;
@@ -112,14 +125,14 @@ static void cpu_chain(const std::vector<float>& X, const std::vector<float>& W, 
   Y.assign(h.begin(), h.end());
 }
 
-template <int R>
+template <int R, int MODE>
 static float run(const float* X, const float* W, const float* b, float* Y, int L, int B, int nch, int iters) {
   dim3 grid(B / R, nch);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(rowchain<R>, grid, dim3(256), 0, 0, X, W, b, Y, L, B);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((rowchain<R, MODE>), grid, dim3(256), 0, 0, X, W, b, Y, L, B);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(rowchain<R>, grid, dim3(256), 0, 0, X, W, b, Y, L, B);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((rowchain<R, MODE>), grid, dim3(256), 0, 0, X, W, b, Y, L, B);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -148,8 +161,8 @@ int main() {
     cpu_chain(hX, hW, hb, ref, L, B);
     for (int R : {4, 8}) {
       CK(hipMemset(Y, 0, hX.size() * 4));
-      if (R == 4) hipLaunchKernelGGL(rowchain<4>, dim3(B / 4, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
-      else hipLaunchKernelGGL(rowchain<8>, dim3(B / 8, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
+      if (R == 4) hipLaunchKernelGGL((rowchain<4, 1>), dim3(B / 4, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
+      else hipLaunchKernelGGL((rowchain<8, 1>), dim3(B / 8, 1), dim3(256), 0, 0, X, W, b, Y, L, B);
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(got.data(), Y, got.size() * 4, hipMemcpyDeviceToHost));
       double maxerr = 0, maxref = 0;
@@ -161,14 +174,20 @@ int main() {
     }
   }
   // ---- timing: per launch for L layers; the slope over L is the per-layer cost without the launch floor
-  for (int nch : {1, 3}) {
-    for (int R : {4, 8}) {
-      float t[3];
-      const int Ls[3] = {2, 8, 14};
-      for (int i = 0; i < 3; ++i)
-        t[i] = (R == 4) ? run<4>(X, W, b, Y, Ls[i], B, nch, 300) : run<8>(X, W, b, Y, Ls[i], B, nch, 300);
-      printf("rowchain R=%d chains=%d (%3d WGs): L=2 %.2f us, L=8 %.2f us, L=14 %.2f us -> %.2f us per layer\n", R, nch,
-             B / R * nch, t[0], t[1], t[2], (t[2] - t[0]) / 12.f);
+  for (int mode : {0, 1, 2, 3}) {
+    for (int nch : {1, 3}) {
+      for (int R : {4, 8}) {
+        float t[3];
+        const int Ls[3] = {2, 8, 14};
+        for (int i = 0; i < 3; ++i) {
+          if (mode == 0) t[i] = (R == 4) ? run<4, 0>(X, W, b, Y, Ls[i], B, nch, 300) : run<8, 0>(X, W, b, Y, Ls[i], B, nch, 300);
+          else if (mode == 2) t[i] = (R == 4) ? run<4, 2>(X, W, b, Y, Ls[i], B, nch, 300) : run<8, 2>(X, W, b, Y, Ls[i], B, nch, 300);
+          else if (mode == 3) t[i] = (R == 4) ? run<4, 3>(X, W, b, Y, Ls[i], B, nch, 300) : run<8, 3>(X, W, b, Y, Ls[i], B, nch, 300);
+          else t[i] = (R == 4) ? run<4, 1>(X, W, b, Y, Ls[i], B, nch, 300) : run<8, 1>(X, W, b, Y, Ls[i], B, nch, 300);
+        }
+        printf("rowchain %s R=%d chains=%d (%3d WGs): L=2 %.2f us, L=8 %.2f us, L=14 %.2f us -> %.2f us per layer\n",
+               mode == 0 ? "loads first      " : mode == 1 ? "loads interleaved" : mode == 2 ? "no matrix instr. " : "no weight loads  ", R, nch, B / R * nch, t[0], t[1], t[2], (t[2] - t[0]) / 12.f);
+      }
     }
   }
   return 0;

@@ -34,7 +34,7 @@ int main() {
   unsigned long long* dst;
   CK(hipMalloc(&dth, th.size() * 4)); CK(hipMalloc(&dbatch, batch.size() * 4));
   const size_t BH = (size_t)B * H;
-  CK(hipMalloc(&ws, (4 * nl * BH + 16 * B) * 4));
+  CK(hipMalloc(&ws, (4 * nl * BH + 16 * B + 4 * (size_t)H * H) * 4));
   CK(hipMalloc(&dst, 1024 * 8)); CK(hipMemset(dst, 0, 1024 * 8));
   CK(hipMemcpy(dth, th.data(), th.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbatch, batch.data(), batch.size() * 4, hipMemcpyHostToDevice));
@@ -61,6 +61,15 @@ int main() {
   a.gamma = 0.98f; a.clip_lo = -50.f; a.clip_hi = 0.f; a.max_u = 1.f; a.l2c = 2.0f / (B * U);
   a.stamps = dst;
   Ex ex; ex.stride = 0; ex.nprob = 1; ex.zmul = 0;
+  {                                                          // transposed copies of the main networks' hidden matrices
+    RowsTransposeArgs t; memset(&t, 0, sizeof(t));
+    float* wt = tail + 16 * B;
+    int n = 0;
+    for (int l = 1; l < nl; ++l) { t.src[n] = a.mQ.th + a.mQ.W[l]; t.dst[n] = wt + (size_t)n * H * H; a.wTq[l] = t.dst[n]; ++n; }
+    for (int l = 1; l < nl; ++l) { t.src[n] = a.mPi.th + a.mPi.W[l]; t.dst[n] = wt + (size_t)n * H * H; a.wTpi[l] = t.dst[n]; ++n; }
+    hipLaunchKernelGGL((rows_transpose_kernel<false>), dim3(16, n, 1), dim3(256), 0, 0, t, ex);
+    CK(hipDeviceSynchronize());
+  }
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
