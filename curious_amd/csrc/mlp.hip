@@ -101,6 +101,7 @@ struct Ws {   // workspace carve-up
   float *pi_t, *pi, *dQ, *dz, *rows;
   float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
   float* part[6];              // dot-epilogue partials [4 tiles][B][<=4]: pi_target, pi, Q, Q_target, Q_pi, dz
+  float* qt;                   // hand-off words of the row-local pass (mlp_rows.h): [B] x 64 bit
   float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h);
                                // the ONLY part of the workspace that carries state from one update call to the next
   int64_t total;
@@ -127,6 +128,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.zp[0] = take(BH);
   w.zp[1] = take(BH);
   for (int i = 0; i < 6; ++i) w.part[i] = take(16 * (int64_t)B);
+  w.qt = take(2 * (int64_t)B);
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l < c->layers; ++l) w.wT[net][l] = (l >= 1) ? take((int64_t)c->hidden * c->hidden) : nullptr;
   w.total = off;
@@ -666,6 +668,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
     a.wTq[l] = w.wT[0][l]; a.wTpi[l] = w.wT[1][l];
   }
   a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
+  a.qt = reinterpret_cast<unsigned long long*>(w.qt);
   a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
@@ -679,7 +682,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     lds_set = true;
   }
-  dim3 grid(2 * (B / ROWS_R), 1, xd.nex);
+  dim3 grid(3 * (B / ROWS_R), 1, xd.nex);
   { ProfScope ps__(CK_ROWS, st);
     if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
     else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }

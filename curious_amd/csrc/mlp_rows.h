@@ -5,10 +5,16 @@
 // (1.5 us) plus a cold start (~3 us) per layer.  Here a workgroup owns FOUR batch rows and walks all layers of its
 // networks by itself: activations never leave the CU (LDS), nothing is exchanged between workgroups, and the only
 // per-layer cost is streaming the layer's 256 KB of weights L2 -> CU (tools/rowchain_lab.hip: 2.3-2.9 us per layer).
-// Two kinds of workgroup per row group, both 2 * (layers - 1) hidden-layer applications deep forward + backward:
-//   critic side: target actor -> target critic(pi') -> Q';  main critic(u) -> Q, loss terms, dQ;  backward of critic(u)
+// Three kinds of workgroup per row group (grid.x = 3 * B / 4; block ids: all actor-side groups first -- the longest
+// chain --, then the target groups, then the main-critic groups, which consume what the target groups produce):
 //   actor side:  main actor -> pi;  main critic(pi) -> Q_pi;  backward through critic(pi) into the action slot -> dz;
 //                backward of the actor
+//   target:      target actor -> target critic(pi') -> Q'                      (handed to the main-critic group)
+//   main critic: main critic(u) -> Q;  waits for Q';  loss terms, dQ;  backward of critic(u)
+// The one dependency between workgroups -- Q' of a batch row -- travels as a single 64-bit word per row (tag | value)
+// written with one agent-scope atomic store and polled by the consumer, which clears it after reading: no fences, no
+// separate flag, nothing to initialise (a word without the tag is "not yet").  Producers never wait and are dispatched
+// before their consumers, so the kernel cannot deadlock whatever number of workgroups is resident.
 // (ddpg.py:419-449 for the graph, actor_critic.py:51-98 / util.py:73-107 for the networks.)  Everything the weight-
 // gradient launch needs -- layer inputs, masked output gradients, dQ, dz, per-row loss terms -- is written to the same
 // workspace arrays the tiled kernels fill, so dw_adam_her_kernel / dw_all_kernel run unchanged afterwards.
@@ -44,16 +50,19 @@ struct RowsArgs {
   float* actc[ROWS_MAXL]; float* dactc[ROWS_MAXL];     // main critic(u): layer outputs, masked output gradients [B,H]
   float* acta[ROWS_MAXL]; float* dacta[ROWS_MAXL];     // main actor
   float* dQ; float* dz; float* rows; float* out_Qpi;
+  unsigned long long* qt;         // [B] hand-off words target group -> main-critic group: (ROWS_QT_TAG << 32) | bits(Q')
   const float* wTq[ROWS_MAXL]; const float* wTpi[ROWS_MAXL];   // transposed hidden matrices of main critic / actor
   int64_t* step_ctr;
   int32_t B, nl, dimo, dimtd, dimg;
   float gamma, clip_lo, clip_hi, max_u, l2c;
-  unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [2][32] s_memtime stamps of row group 0, else NULL
+  unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [3][32] s_memtime stamps of row group 0, else NULL
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
-    if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[side * 32 + (k)] = __builtin_readcyclecounter(); \
+    if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[kind * 32 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
+#define ROWS_QT_TAG 0x51C0FFEEull
+#define ROWS_QT_SPINS (1 << 22)   // polls before a consumer gives up (~ seconds): the loss turns NaN instead of a hang
 
 #ifdef ROWS_DEBUG           // tools/rows_lab.hip: fine-grained stamps inside the layer routines
 #define ROWS_DBG(x) do { if ((x).dbg && (x).tid == 0) *(x).dbg++ = __builtin_readcyclecounter(); } while (0)
@@ -276,7 +285,7 @@ __device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, i
 }
 
 // ================================================================== the kernel
-// grid (2 * B / 4, 1, n_experts); B % 16 == 0.
+// grid (3 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
   return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;
 }
@@ -292,14 +301,14 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   x.sm = x.xin + 4 * XLD;
   x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
-  // Workgroups are dealt round-robin over the 8 XCDs in block-id order: block b lands on XCD b % 8 (speed only).  XCDs
-  // 0-3 take the critic-side workgroups, 4-7 the actor-side ones, so that an XCD's L2 pulls in only the weights of
-  // its side (3 resp. 2 of the 4 networks) instead of all of them.  grid.x = 2 * B / 4.
-  const int side = (blockIdx.x >> 2) & 1;
-  const int rgrp = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+  // kind of workgroup from the block id: [0, nrg) actor side, [nrg, 2 nrg) target, [2 nrg, 3 nrg) main critic.
+  // (Workgroups are dealt round-robin over the 8 XCDs in block-id order; every XCD gets an equal share of each kind.)
+  const int nrg = a.B / ROWS_R;
+  const int kind = ((int)blockIdx.x >= 2 * nrg) ? 2 : ((int)blockIdx.x >= nrg) ? 1 : 0;
+  const int rgrp = (int)blockIdx.x - kind * nrg;
   x.r0 = rgrp * ROWS_R;
 #ifdef ROWS_DEBUG
-  if (a.stamps && rgrp == 0 && side == 1) x.dbg = a.stamps + 64;
+  if (a.stamps && rgrp == 0 && kind == 0) x.dbg = a.stamps + 96;
 #endif
   int64_t eo;
   (void)ex_decode<EX>(ex, blockIdx.z, eo);                  // one problem per expert: blockIdx.z = expert
@@ -309,15 +318,13 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   const float invB = 1.0f / (float)a.B;
   float* sm_s = x.sm;                                       // [4] per-row scalar handed from wave i to the column threads
   float* sm_v = x.sm + 16;                                  // [4][4] per-row 4-vectors (pi, dz)
+  unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + m;
   f32x4 wb[2][16];
 
-  if (side == 0) {
-    // ================================================= critic side
-    if (rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+  if (kind == 1) {
+    // ================================================= target group: pi' = target actor(o_2, g_2), Q' = target critic
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
-    const float* mq = a.mQ.th + eo;
-    // ---- target actor on (o_2, g_2): pi' = max_u tanh(.)                                  (ddpg.py:427-431)
     ROWS_STAMP(0);
     rows_l0_load(wb[0], tp + a.tPi.W0, Sa, tp + a.tPi.Wg, Sa + G, x.wave, x.lane, 0);
     rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false);
@@ -345,28 +352,51 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     }
     __syncthreads();
     ROWS_STAMP(4);
-    // ---- target critic on (o_2, g_2, pi') -> Q'
     rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, tq + a.tQ.b0, nullptr, nullptr,
                 rnext(RN_FWD, tq + a.tQ.W[1]));
-    rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
+    rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
-    const float Qt = rows_head1(x, wq_t) + bq_t;
-    // operands of the main critic's head / loss / first backward step, fetched ahead of its hidden layers
+    const float Qt = rows_head1(x, wq_t) + bq_t;                                           // ddpg.py:427-431
+    if (x.lane == 0)
+      __hip_atomic_store(qt, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    ROWS_STAMP(6);
+    return;
+  }
+
+  if (kind == 2) {
+    // ================================================= main-critic group: critic(o, g, u), loss, backward
+    if (rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+    const float* mq = a.mQ.th + eo;
+    ROWS_STAMP(0);
+    rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
+    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
+    __syncthreads();
+    ROWS_STAMP(1);
+    // operands of the head / loss / first backward step, fetched ahead of the hidden layers
     const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
     const float bq_m = mq[a.mQ.bout];
     const float wq_col = mq[a.mQ.Wout + x.tid];
     const float rew = batch[(int64_t)m * a.ld + a.off_r];
-    // ---- main critic on (o, g, u): activations kept for the backward pass and the weight gradients
-    __syncthreads();                                         // every wave is done with hs / xin of the target pass
-    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
-    __syncthreads();
-    ROWS_STAMP(6);
+    // activations kept for the backward pass and the weight gradients
     rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, x.keep, a.actc[0] + eo,
                 rnext(RN_FWD, mq + a.mQ.W[1]));
+    ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rows_bwd_first(a, false, eo));
-    ROWS_STAMP(7);
+    ROWS_STAMP(3);
     {
       const float Q = rows_head1(x, wq_m) + bq_m;
+      // Q' of this wave's row from the target group (every lane polls the same word: one request per poll)
+      unsigned long long word = 0;
+      int spins = 0;
+      for (;;) {
+        word = __hip_atomic_load(qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((word >> 32) == ROWS_QT_TAG || ++spins > ROWS_QT_SPINS) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      ROWS_STAMP(4);
+      const float Qt = ((word >> 32) == ROWS_QT_TAG) ? __uint_as_float((unsigned)(word & 0xffffffffull)) : NAN;
+      if (x.lane == 0) __hip_atomic_store(qt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed
       const float target = fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi);                // ddpg.py:437-438
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
@@ -391,9 +421,9 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
       }
     }
     __syncthreads();
-    ROWS_STAMP(8);
+    ROWS_STAMP(5);
     rows_hidden_bwd(x, wb, a, x.keep, 1, eo, rnext(RN_NONE, nullptr));
-    ROWS_STAMP(9);
+    ROWS_STAMP(6);
     return;
   }
 

@@ -35,6 +35,7 @@ int main() {
   CK(hipMalloc(&dth, th.size() * 4)); CK(hipMalloc(&dbatch, batch.size() * 4));
   const size_t BH = (size_t)B * H;
   CK(hipMalloc(&ws, (4 * nl * BH + 16 * B + 4 * (size_t)H * H) * 4));
+  CK(hipMemset(ws, 0xff, (4 * nl * BH + 16 * B) * 4));      // the hand-off words need no initialisation: start from garbage
   CK(hipMalloc(&dst, 1024 * 8)); CK(hipMemset(dst, 0, 1024 * 8));
   CK(hipMemcpy(dth, th.data(), th.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbatch, batch.data(), batch.size() * 4, hipMemcpyHostToDevice));
@@ -57,6 +58,7 @@ int main() {
   }
   float* tail = ws + 4 * nl * BH;
   a.dQ = tail; a.dz = tail + B; a.rows = tail + 5 * B; a.out_Qpi = tail + 8 * B;
+  a.qt = reinterpret_cast<unsigned long long*>(tail + 10 * B);
   a.B = B; a.nl = nl; a.dimo = O; a.dimtd = N; a.dimg = G;
   a.gamma = 0.98f; a.clip_lo = -50.f; a.clip_hi = 0.f; a.max_u = 1.f; a.l2c = 2.0f / (B * U);
   a.stamps = dst;
@@ -73,7 +75,7 @@ int main() {
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  dim3 grid(2 * (B / ROWS_R), 1, 1);
+  dim3 grid(3 * (B / ROWS_R), 1, 1);
   auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
@@ -91,20 +93,24 @@ int main() {
       tot += ms;
     }
     printf("%s weights: %.2f us per launch (event pair around one launch)\n", cold ? "rewritten" : "warm", tot * 1000.f / it);
-    unsigned long long st[64];
+    unsigned long long st[96];
     CK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
-    const char* names[2][10] = {{"start", "inputs", "L0 tpi", "hidden tpi", "head pi'", "L0+hidden tQ", "head Q' + inputs",
-                                 "L0+hidden mQ", "head Q + dY", "bwd mQ"},
-                                {"start", "inputs", "L0 pi", "hidden pi", "head pi", "L0+hidden Q(pi)", "head + dY",
-                                 "bwd Q(pi)", "dz + dY", "bwd pi"}};
-    for (int ty = 0; ty < 2; ++ty) {
-      printf("  %s side (shader cycles): ", ty ? "actor" : "critic");
-      for (int k = 1; k < 10; ++k) printf("%s %llu | ", names[ty][k], st[ty * 32 + k] - st[ty * 32 + k - 1]);
-      printf("total %llu\n", st[ty * 32 + 9] - st[ty * 32]);
+    const char* names[3][10] = {{"start", "inputs", "L0 pi", "hidden pi", "head pi", "L0+hidden Q(pi)", "head + dY",
+                                 "bwd Q(pi)", "dz + dY", "bwd pi"},
+                                {"start", "inputs", "L0 tpi", "hidden tpi", "head pi'", "L0+hidden tQ", "head Q' + publish",
+                                 "", "", ""},
+                                {"start", "inputs", "L0 mQ", "hidden mQ", "head Q + wait for Q'", "loss + dY", "bwd mQ",
+                                 "", "", ""}};
+    const int nst[3] = {10, 7, 7};
+    const char* kinds[3] = {"actor side ", "target     ", "main critic"};
+    for (int ty = 0; ty < 3; ++ty) {
+      printf("  %s (shader cycles, from the actor group's start: %lld): ", kinds[ty], (long long)(st[ty * 32] - st[0]));
+      for (int k = 1; k < nst[ty]; ++k) printf("%s %llu | ", names[ty][k], st[ty * 32 + k] - st[ty * 32 + k - 1]);
+      printf("total %llu\n", st[ty * 32 + nst[ty] - 1] - st[ty * 32]);
     }
     {
       unsigned long long d[256];
-      CK(hipMemcpy(d, dst + 64, sizeof(d), hipMemcpyDeviceToHost));
+      CK(hipMemcpy(d, dst + 96, sizeof(d), hipMemcpyDeviceToHost));
       printf("  actor side, forward hidden layers (start | after chunk 0..3 | after finish), deltas: ");
       for (int k = 1; k < 24 && d[k]; ++k) printf("%s%llu", (k % 6 == 0) ? " || " : " ", d[k] - d[k - 1]);
       printf("\n");
