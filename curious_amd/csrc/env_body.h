@@ -14,7 +14,10 @@ __device__ inline void env_step_body(const curious_env_cfg_t& E, const curious_l
                                      float* __restrict__ o, float* __restrict__ ag, const float* __restrict__ g,
                                      const float* __restrict__ td, float* __restrict__ staging, int32_t off_change,
                                      int32_t off_success, double reward_eps, const int e, const int lane,
-                                     float* __restrict__ flags = nullptr, const int n = 0) {
+                                     float* __restrict__ flags = nullptr, const int n = 0,
+                                     float* next_in = nullptr /* LDS: receives clip(new o, +-in_clip), the policy's next
+                                                                 input row (multi-step rollout kernel) */,
+                                     const float in_clip = 0.f) {
   const int AG = 3 * E.ntasks;
   float* oe = o + (int64_t)e * E.dimo;
   float* ep0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
@@ -67,6 +70,7 @@ __device__ inline void env_step_body(const curious_env_cfg_t& E, const curious_l
     // entries >= 64 are beyond AG + 3 and unchanged)
     oe[i] = nv;
     nxt[L.off_o + i] = nv;
+    if (next_in) next_in[i] = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
     if (i < AG) {
       ag[(int64_t)e * AG + i] = nv;
       nxt[L.off_ag + i] = nv;

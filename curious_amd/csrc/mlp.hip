@@ -492,14 +492,14 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   return 0;
 }
 
-extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
-                                           float* workspace, double noise_scale, double random_eps, uint64_t seed,
-                                           uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
-                                           const curious_env_cfg_t* E,
-                                           const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
-                                           const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
-                                           const float* td, float* staging, int32_t off_change, int32_t off_success,
-                                           double reward_eps, float* flags, curious_stream_t stream) {
+// steps t .. t + nsteps - 1 of every env: one launch on the row-local route, else nsteps x (forward chain + act_step)
+static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                const int32_t* episode, const int32_t* tasks, int32_t t, int32_t nsteps, float* o,
+                                float* ag, const float* g, const float* td, float* staging, int32_t off_change,
+                                int32_t off_success, double reward_eps, float* flags, curious_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
                 "curious_policy_act_env_step: NULL argument");
@@ -507,7 +507,7 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
                                                      "normalisation only (use curious_policy_forward otherwise)");
   CURIOUS_CHECK(cfg->dimu == 4 && L->dimu == 4 && cfg->dimo == E->dimo && cfg->dimtd == E->ntasks &&
                     cfg->dimg == 3 * E->ntasks, "curious_policy_act_env_step: network / env dimensions differ");
-  CURIOUS_CHECK(t >= 0 && t < L->T, "curious_policy_act_env_step: t out of range");
+  CURIOUS_CHECK(t >= 0 && nsteps >= 1 && t + nsteps <= L->T, "curious_policy_act_env_step: t out of range");
   if (n <= 0) return 0;
   hipStream_t st = as_stream(stream);
   Ws w = carve(cfg, n, workspace);
@@ -523,10 +523,20 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
     a.fused = 1;
     a.noise_scale = noise_scale; a.random_eps = random_eps; a.max_u_d = (double)cfg->max_u;
     a.seed = seed; a.counter = counter; a.counter_base = counter_base; a.u_out = u_out; a.ldu = ldu;
-    a.E = *E; a.L = *L; a.env_id0 = env_id0; a.t = t; a.off_change = off_change; a.off_success = off_success;
+    a.E = *E; a.L = *L; a.env_id0 = env_id0; a.t = t; a.nsteps = nsteps; a.off_change = off_change;
+    a.off_success = off_success;
     a.episode = episode; a.tasks = tasks; a.eo = o; a.eag = ag; a.staging = staging; a.reward_eps = reward_eps;
     a.flags = flags;
     return launch_policy_rows(a, n, st);
+  }
+  if (nsteps > 1) {
+    for (int s = 0; s < nsteps; ++s) {
+      const int rc = policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter + s,
+                                          counter_base, u_out, ldu, E, L, env_id0, episode, tasks, t + s, 1, o, ag, g, td,
+                                          staging, off_change, off_success, reward_eps, flags, stream);
+      if (rc) return rc;
+    }
+    return 0;
   }
   ObsIn in;
   memset(&in, 0, sizeof(in));
@@ -555,6 +565,32 @@ extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const f
     else hipLaunchKernelGGL(act_step_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, k); }
   CURIOUS_LAUNCH_CHECK("act_step_kernel");
   return 0;
+}
+
+extern "C" int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                           float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                           uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                           const curious_env_cfg_t* E,
+                                           const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
+                                           const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
+                                           const float* td, float* staging, int32_t off_change, int32_t off_success,
+                                           double reward_eps, float* flags, curious_stream_t stream) {
+  return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
+                              u_out, ldu, E, L, env_id0, episode, tasks, t, 1, o, ag, g, td, staging, off_change,
+                              off_success, reward_eps, flags, stream);
+}
+
+extern "C" int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                      float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                      uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                      const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                      const int32_t* episode, const int32_t* tasks, int32_t t0, int32_t nsteps, float* o,
+                                      float* ag, const float* g, const float* td, float* staging, int32_t off_change,
+                                      int32_t off_success, double reward_eps, float* flags, curious_stream_t stream) {
+  CURIOUS_CHECK(nsteps >= 1, "curious_policy_rollout: nsteps must be positive");
+  return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
+                              u_out, ldu, E, L, env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, off_change,
+                              off_success, reward_eps, flags, stream);
 }
 
 // What follows the gradients in curious_ddpg_update: Adam (+ the gather of the next batch).

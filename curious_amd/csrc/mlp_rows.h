@@ -144,17 +144,15 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
                                              float* keep, float* gout, const RNext& next) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const float bv = bias[x.tid];
-  ROWS_DBG(x);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c < 3) rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
     else rows_prefetch(wb[0], next, x.wave, x.lane);
     __builtin_amdgcn_sched_barrier(0);
     rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
-    ROWS_DBG(x);
   }
   rows_fw_finish(x, acc, bv, keep, gout);
-  ROWS_DBG(x);
+  ROWS_DBG(x);                                               // (one stamp per layer: finer ones slow the measured group down)
 }
 // ---- one 256 x 256 hidden layer, backward on the TRANSPOSED matrix: hs <- (hs . WT) * relu'(mask), WT[n][k] = W[k][n].
 // The forward product with another epilogue (no bias; the kept activation of the layer below gates the gradient).

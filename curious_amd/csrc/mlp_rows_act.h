@@ -4,7 +4,8 @@
 // Replaces, per env step of a batched rollout (rollout.py:226-263 for every env), the 3 launches fwd_l01 -> fwd_hot<DOT>
 // -> act_step of the tiled route; and, for DDPG.get_actions (ddpg.py:129-146), fwd_l01 / fwd_hot / head_fwd (+ the same
 // again for Q).  Both entry points share this kernel, so the fused acting step stays bit-identical to
-// curious_policy_forward + curious_action_noise + curious_env_step.
+// curious_policy_forward + curious_action_noise + curious_env_step.  curious_policy_rollout runs ALL steps of a
+// rollout in one launch of it (the envs of a workgroup do not depend on any other env).
 #pragma once
 
 struct ActRowsArgs {
@@ -22,7 +23,7 @@ struct ActRowsArgs {
   const int64_t* counter_base;
   float* u_out; int32_t ldu;
   curious_env_cfg_t E; curious_layout_t L;
-  int32_t env_id0, t, off_change, off_success;
+  int32_t env_id0, t, nsteps, off_change, off_success;   // steps t .. t + nsteps - 1 of the episode in this launch
   const int32_t* episode; const int32_t* tasks;
   float* eo; float* eag; float* staging;          // env state (o is also the network input `o`), episode records
   double reward_eps;
@@ -63,12 +64,51 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       x.xin[i * XLD + k] = v;
     }
   }
-  // the exploration noise does not depend on the policy output: draw it now, while the first loads are in flight
-  NoiseDraw nd;
-  nd.z = nd.b = nd.ru = 0.0;
-  if (a.fused && x.lane < 4) {
-    const uint64_t ctr = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
-    nd = noise_draw(m * 4 + x.lane, m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed, ctr);
+  if (a.fused) {
+    // ---- acting steps t .. t + nsteps - 1 of the workgroup's 4 envs (rollout.py:226-303 per env): the envs are
+    // independent of each other, so the whole T-step loop of a rollout runs inside one launch -- the new observation
+    // goes straight from the env step into the policy's LDS input row, the layer-0 weights of the next step are fetched
+    // while the env steps.  Same numbers as nsteps launches with one step each.
+    const uint64_t ctr0 = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
+    for (int s = 0; s < a.nsteps; ++s) {
+      // the exploration noise does not depend on the policy output: draw it while the first loads are in flight
+      NoiseDraw nd;
+      nd.z = nd.b = nd.ru = 0.0;
+      if (x.lane < 4)
+        nd = noise_draw(m * 4 + x.lane, m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed, ctr0 + (uint64_t)s);
+      __syncthreads();                                       // input rows of all 4 envs are in LDS
+      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, nullptr, nullptr,
+                  rnext(RN_FWD, pp + a.pi.W[1]));
+      const RNext again = (s + 1 < a.nsteps) ? rnext(RN_L0, pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G)
+                                             : rnext(RN_NONE, nullptr);
+      for (int l = 1; l < a.nl; ++l)
+        rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], nullptr, nullptr,
+                     (l + 1 < a.nl) ? rnext(RN_FWD, pp + a.pi.W[l + 1]) : again);
+      float z[4];
+      rows_head4(x, wpi, z);
+      float v = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) v = ((x.lane & 3) == d) ? z[d] : v;
+      v = a.max_u * tanhf(v + bpi);                                                          // actor_critic.py:89
+      // exploration noise, clip, eps-greedy (ddpg.py:149-152) and one env step, one wavefront per env
+      float* s_u = x.sm + 8 * x.wave;
+      if (x.lane < 4) {
+        v = noise_mix(v, nd, a.noise_scale, a.max_u_d);
+        s_u[x.lane] = v;
+        a.u_out[(int64_t)m * a.ldu + x.lane] = v;
+      }
+      // (the network inputs were copied to LDS before layer 0: the env arrays they came from may be overwritten now)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u, a.t + s, a.eo, a.eag, a.g, a.td, a.staging,
+                    a.off_change, a.off_success, a.reward_eps, m, x.lane, a.flags, a.n,
+                    (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip);
+      // the env state this wave reads back in its next step was written by this wave
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    return;
   }
   __syncthreads();
   rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, nullptr, nullptr,
@@ -84,22 +124,6 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) v = ((x.lane & 3) == d) ? z[d] : v;
   v = a.max_u * tanhf(v + bpi);                                                            // actor_critic.py:89
-  if (a.fused) {
-    // exploration noise, clip, eps-greedy (ddpg.py:149-152) and one env step, one wavefront per env
-    float* s_u = x.sm + 8 * x.wave;
-    if (x.lane < 4) {
-      v = noise_mix(v, nd, a.noise_scale, a.max_u_d);
-      s_u[x.lane] = v;
-      a.u_out[(int64_t)m * a.ldu + x.lane] = v;
-    }
-    // (the network inputs were copied to LDS before layer 0: the env arrays they came from may be overwritten now)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u, a.t, a.eo, a.eag, a.g, a.td, a.staging, a.off_change,
-                  a.off_success, a.reward_eps, m, x.lane, a.flags, a.n);
-    return;
-  }
   if (x.lane < 4) {
     a.out_pi[(int64_t)m * a.ldpi + x.lane] = v;
     x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                  // actor_critic.py:93

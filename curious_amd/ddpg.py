@@ -291,11 +291,10 @@ class DDPG(object):
         return self._act_u
 
     def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
-        """The T-step acting loop of a batched rollout (rollout.py:226-303 for every env): T x act_and_step.  With
-        use_graph the 4*T launches are captured once per (env, noise setting) and replayed as one hipGraph -- the eager
-        loop is bound by host launch overhead (~29 us per step against ~19 us of kernels); the Philox noise counter is
-        (t + 1) + a device-resident base that advances by T per rollout, so replays draw fresh noise and the eager loop
-        draws the same numbers."""
+        """The T-step acting loop of a batched rollout (rollout.py:226-303 for every env): T x act_and_step, as ONE
+        launch (curious_policy_rollout) where the row-local route applies.  With use_graph the launches are captured once
+        per (env, noise setting) and replayed; the Philox noise counter is (t + 1) + a device-resident base that advances
+        by T per rollout, so replays draw fresh noise and the eager loop draws the same numbers."""
         from curious_amd.envs import REWARD_EPS
         n = env.n
         theta = self.theta_target if use_target_net else self.theta
@@ -320,11 +319,11 @@ class DDPG(object):
         u_out = self._act_u
 
         def steps():
-            for t in range(T):
-                ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
-                                        seed, t + 1, u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks,
-                                        t, env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS,
-                                        counter_base=self._noise_base, flags=getattr(env, 'flags', None))
+            # T x policy_act_env_step (noise counters 1 .. T on top of the base): one launch on the row-local route
+            ops.policy_rollout(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps, seed, 1,
+                               u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T, env.o, env.ag,
+                               env.g, env.td, env.staging, REWARD_EPS, counter_base=self._noise_base,
+                               flags=getattr(env, 'flags', None))
             ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T

@@ -296,6 +296,20 @@ def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_
           'curious_policy_act_env_step')
 
 
+def policy_rollout(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
+                   env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, reward_eps, counter_base=None, flags=None):
+    """nsteps x policy_act_env_step (steps t0 .. t0 + nsteps - 1, noise counters counter, counter + 1, ...); one launch
+    on the row-local route."""
+    L = layout.c_layout()
+    check(lib().curious_policy_rollout(C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs),
+                                       ptr(workspace), float(noise_scale), float(random_eps),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(counter_base), ptr(u_out),
+                                       int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode),
+                                       ptr(tasks), int(t0), int(nsteps), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
+                                       int(layout.off['change']), int(layout.off['info_is_success']),
+                                       float(reward_eps), ptr(flags), current_stream()), 'curious_policy_rollout')
+
+
 def env_step(ecfg, layout, env_id0, episode, tasks, u, t, n, o, ag, g, td, staging, reward_eps, flags=None):
     L = layout.c_layout()
     check(lib().curious_env_step(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), ptr(u),

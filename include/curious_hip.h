@@ -334,6 +334,19 @@ int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta
                                 float* staging, int32_t off_change, int32_t off_success, double reward_eps,
                                 float* flags, curious_stream_t stream);
 
+/* The acting loop of a batched rollout (rollout.py:226-303 for every env): steps t0 .. t0 + nsteps - 1, i.e. nsteps x
+ * curious_policy_act_env_step with noise counters counter, counter + 1, ... -- same results bit for bit.  The envs do
+ * not depend on each other, so on the row-local route (n % 4 == 0, hidden 256) the whole loop is ONE launch: a
+ * workgroup walks its 4 envs through all steps, the new observation goes from the env step straight into the
+ * policy's input row in LDS.  Other shapes: the launches of the single-step entry point, nsteps times. */
+int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                           float* workspace, double noise_scale, double random_eps, uint64_t seed, uint64_t counter,
+                           const int64_t* counter_base, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                           const curious_layout_t* L, int32_t env_id0, const int32_t* episode, const int32_t* tasks,
+                           int32_t t0, int32_t nsteps, float* o, float* ag, const float* g, const float* td,
+                           float* staging, int32_t off_change, int32_t off_success, double reward_eps, float* flags,
+                           curious_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,8 +111,8 @@ int main() {
     {
       unsigned long long d[256];
       CK(hipMemcpy(d, dst + 96, sizeof(d), hipMemcpyDeviceToHost));
-      printf("  actor side, forward hidden layers (start | after chunk 0..3 | after finish), deltas: ");
-      for (int k = 1; k < 24 && d[k]; ++k) printf("%s%llu", (k % 6 == 0) ? " || " : " ", d[k] - d[k - 1]);
+      printf("  actor side, end of each forward hidden layer, deltas: ");
+      for (int k = 1; k < 8 && d[k]; ++k) printf(" %llu", d[k] - d[k - 1]);
       printf("\n");
     }
   }
