@@ -427,8 +427,18 @@ static bool act_rows_ok(const curious_net_cfg_t* c, int n, bool relative, const 
 }
 
 static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
+  const int nsteps = a.fused ? a.nsteps : 1;
+  size_t lds = act_rows_lds_floats(nsteps) * sizeof(float);
+  a.noise_lds = (nsteps > 1 && lds <= 150 * 1024) ? 1 : 0;
+  if (!a.noise_lds) lds = act_rows_lds_floats(1) * sizeof(float);
+  static bool lds_set = false;
+  if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_rows_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_set = true;
+  }
   { ProfScope ps__(CK_ACT_ROWS, st);
-    hipLaunchKernelGGL(policy_rows_kernel, dim3(n / ROWS_R), dim3(256), act_rows_lds_floats() * sizeof(float), st, a); }
+    hipLaunchKernelGGL(policy_rows_kernel, dim3(n / ROWS_R), dim3(256), lds, st, a); }
   CURIOUS_LAUNCH_CHECK("policy_rows_kernel");
   return 0;
 }

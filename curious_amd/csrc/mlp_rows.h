@@ -200,11 +200,12 @@ __device__ __forceinline__ void rows_l0_mac(const RCtx& x, const f32x4 (&b)[16],
   }
 }
 // (rows t < 16 are already in flight into wb[0]; a second pass covers inputs wider than 64)
+// bv = bias[tid], loaded by the caller ahead of the layer (for a group's first layer: together with its inputs -- the
+// parameters were just rewritten by the optimiser, a load issued here would be a second cold round trip)
 __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W0, int S, const float* Wg,
-                                            int G, int gofs, const float* bias, float* keep, float* gout,
+                                            int G, int gofs, const float bv, float* keep, float* gout,
                                             const RNext& next) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  const float bv = bias[x.tid];
   const int nk = S + G;
   const bool two = nk > 64;
   if (two) rows_l0_load(wb[1], W0, S, Wg, nk, x.wave, x.lane, 16);
@@ -325,12 +326,14 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     const float* tq = a.tQ.th + eo;
     ROWS_STAMP(0);
     rows_l0_load(wb[0], tp + a.tPi.W0, Sa, tp + a.tPi.Wg, Sa + G, x.wave, x.lane, 0);
+    const float b0_tp = tp[a.tPi.b0 + x.tid];
     rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false);
     __syncthreads();
     ROWS_STAMP(1);
     const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
     const float bpi_t = tp[a.tPi.bout + (x.lane & 3)];
-    rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, tp + a.tPi.b0, nullptr, nullptr,
+    const float b0_tq = tq[a.tQ.b0 + x.tid];
+    rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, nullptr, nullptr,
                 rnext(RN_FWD, tp + a.tPi.W[1]));
     ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.tPi, tp, nullptr, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     }
     __syncthreads();
     ROWS_STAMP(4);
-    rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, tq + a.tQ.b0, nullptr, nullptr,
+    rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, nullptr, nullptr,
                 rnext(RN_FWD, tq + a.tQ.W[1]));
     rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     const float* mq = a.mQ.th + eo;
     ROWS_STAMP(0);
     rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
+    const float b0_mq = mq[a.mQ.b0 + x.tid];
     rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
     __syncthreads();
     ROWS_STAMP(1);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     const float wq_col = mq[a.mQ.Wout + x.tid];
     const float rew = batch[(int64_t)m * a.ld + a.off_r];
     // activations kept for the backward pass and the weight gradients
-    rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, x.keep, a.actc[0] + eo,
+    rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, x.keep, a.actc[0] + eo,
                 rnext(RN_FWD, mq + a.mQ.W[1]));
     ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rows_bwd_first(a, false, eo));
@@ -432,12 +436,14 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   float* keepD = x.keep + nl * 1024;                        // critic(pi) activations
   ROWS_STAMP(0);
   rows_l0_load(wb[0], mp + a.mPi.W0, Sa, mp + a.mPi.Wg, Sa + G, x.wave, x.lane, 0);
+  const float b0_mp = mp[a.mPi.b0 + x.tid];
   rows_load_inputs(x, a, batch, a.off_o, a.off_g, false);
   __syncthreads();
   ROWS_STAMP(1);
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);
   const f32x4 bpi = ldv(mp + a.mPi.bout);
-  rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, mp + a.mPi.b0, keepA, a.acta[0] + eo,
+  const float b0_mq = mq[a.mQ.b0 + x.tid];
+  rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, keepA, a.acta[0] + eo,
               rnext(RN_FWD, mp + a.mPi.W[1]));
   ROWS_STAMP(2);
   rows_hidden_fwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   const float bq_m = mq[a.mQ.bout];
   const float wq_col = mq[a.mQ.Wout + x.tid];
   // ---- main critic on (o, g, pi) -> Q_pi
-  rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, mq + a.mQ.b0, keepD, nullptr,
+  rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, keepD, nullptr,
               rnext(RN_FWD, mq + a.mQ.W[1]));
   rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
   ROWS_STAMP(5);

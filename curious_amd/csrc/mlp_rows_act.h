@@ -28,9 +28,13 @@ struct ActRowsArgs {
   float* eo; float* eag; float* staging;          // env state (o is also the network input `o`), episode records
   double reward_eps;
   float* flags;                                   // optional rollout flags (env_step_body)
+  int32_t noise_lds;                              // != 0: the launch has the LDS area for pre-drawn noise
 };
 
-static inline size_t act_rows_lds_floats() { return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64; }
+// + the pre-drawn exploration noise of a multi-step launch: 4 envs x nsteps x 4 components x (z, coin, uniform) doubles
+static inline size_t act_rows_lds_floats(int nsteps = 1) {
+  return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (nsteps > 1 ? (size_t)4 * nsteps * 4 * 3 * 2 : 0);
+}
 
 __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   rows_l0_load(wb[0], pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G, x.wave, x.lane, 0);
   const HeadW4 wpi = rows_head4_w(pp + a.pi.Wout, x.lane);
   const float bpi = pp[a.pi.bout + (x.lane & 3)];
+  const float b0_pi = pp[a.pi.b0 + x.tid];
   // ---- inputs: xin[i] = [clip(o) | td | action slot | clip(g)]
   {
     const int tot = Sc + G;
@@ -70,14 +75,29 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
     // goes straight from the env step into the policy's LDS input row, the layer-0 weights of the next step are fetched
     // while the env steps.  Same numbers as nsteps launches with one step each.
     const uint64_t ctr0 = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
+    // what does not change during the episode, and the env's observation (lane l: entry l) carried in a register
+    const EnvConsts ec = env_consts(a.E, a.L, a.episode, a.tasks, a.eo, a.g, a.td, a.staging, m, x.lane);
+    float ov = (x.lane < a.E.dimo) ? a.eo[(int64_t)m * a.E.dimo + x.lane] : 0.f;
+    // The exploration noise does not depend on the policy output.  Drawing it inside the step would occupy the wave with
+    // 4 active lanes (Philox + float64 Box-Muller) once per step; instead all 64 lanes draw the noise of ALL steps of
+    // this wave's env up front -- draw q = 4 s + d: step s, action component d -- into LDS.  (Same (index, counter)
+    // pairs, same numbers.)  Too many steps for the LDS area: drawn per step as before.
+    double* nz = reinterpret_cast<double*>(x.sm + 64) + (size_t)x.wave * 3 * 4 * a.nsteps;
+    const bool predrawn = a.nsteps > 1 && a.noise_lds;
+    if (predrawn) {
+      for (int q = x.lane; q < 4 * a.nsteps; q += 64) {
+        const NoiseDraw d = noise_draw(m * 4 + (q & 3), m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed,
+                                       ctr0 + (uint64_t)(q >> 2));
+        nz[3 * q] = d.z; nz[3 * q + 1] = d.b; nz[3 * q + 2] = d.ru;
+      }
+    }
     for (int s = 0; s < a.nsteps; ++s) {
-      // the exploration noise does not depend on the policy output: draw it while the first loads are in flight
       NoiseDraw nd;
       nd.z = nd.b = nd.ru = 0.0;
-      if (x.lane < 4)
+      if (!predrawn && x.lane < 4)
         nd = noise_draw(m * 4 + x.lane, m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed, ctr0 + (uint64_t)s);
       __syncthreads();                                       // input rows of all 4 envs are in LDS
-      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, nullptr, nullptr,
+      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr,
                   rnext(RN_FWD, pp + a.pi.W[1]));
       const RNext again = (s + 1 < a.nsteps) ? rnext(RN_L0, pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G)
                                              : rnext(RN_NONE, nullptr);
@@ -93,6 +113,10 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       // exploration noise, clip, eps-greedy (ddpg.py:149-152) and one env step, one wavefront per env
       float* s_u = x.sm + 8 * x.wave;
       if (x.lane < 4) {
+        if (predrawn) {
+          const int q = 4 * s + x.lane;
+          nd.z = nz[3 * q]; nd.b = nz[3 * q + 1]; nd.ru = nz[3 * q + 2];
+        }
         v = noise_mix(v, nd, a.noise_scale, a.max_u_d);
         s_u[x.lane] = v;
         a.u_out[(int64_t)m * a.ldu + x.lane] = v;
@@ -101,17 +125,14 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      env_step_body(a.E, a.L, a.env_id0, a.episode, a.tasks, s_u, a.t + s, a.eo, a.eag, a.g, a.td, a.staging,
-                    a.off_change, a.off_success, a.reward_eps, m, x.lane, a.flags, a.n,
-                    (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip);
-      // the env state this wave reads back in its next step was written by this wave
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ov = env_step_core(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
+                         a.off_success, a.reward_eps, m, x.lane, a.flags, a.n,
+                         (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip);
     }
     return;
   }
   __syncthreads();
-  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, nullptr, nullptr,
+  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr,
               rnext(RN_FWD, pp + a.pi.W[1]));
   const float* qp = a.q.th;
   const RNext after = a.out_Q ? rnext(RN_L0, qp + a.q.W0, Sc, qp + a.q.Wg, Sc + G) : rnext(RN_NONE, nullptr);
@@ -132,7 +153,8 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   const f32x4 wq = ldv(qp + a.q.Wout + 4 * x.lane);
   const float bq = qp[a.q.bout];
   __syncthreads();
-  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp + a.q.b0, nullptr, nullptr, rnext(RN_FWD, qp + a.q.W[1]));
+  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp[a.q.b0 + x.tid], nullptr, nullptr,
+              rnext(RN_FWD, qp + a.q.W[1]));
   for (int l = 1; l < a.nl; ++l)
     rows_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], nullptr, nullptr,
                  (l + 1 < a.nl) ? rnext(RN_FWD, qp + a.q.W[l + 1]) : rnext(RN_NONE, nullptr));

@@ -1,0 +1,54 @@
+"""Probe: where one bench cycle spends its wall-clock time -- host stamps at the phase boundaries of bench.cycle and GPU
+event stamps around the rollout, the store and the updates (is the GPU waiting for Python between the phases?)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    np.random.seed(1)
+    params, dims, policy, worker = bench.build_job(use_graph=True)
+    bench.prefill(policy, 2048, seed=0)
+    for _ in range(5):
+        bench.cycle(policy, worker)
+    torch.cuda.synchronize()
+    n = 30
+    host = np.zeros([n, 5])
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
+    t00 = time.perf_counter()
+    for c in range(n):
+        ev[c][0].record()
+        host[c, 0] = time.perf_counter()
+        episode, cp, n_ep = worker.generate_rollouts()
+        ev[c][1].record()
+        host[c, 1] = time.perf_counter()
+        policy.store_episode(episode, cp, n_ep)
+        ev[c][2].record()
+        host[c, 2] = time.perf_counter()
+        policy.train_batches(bench.N_BATCHES)
+        ev[c][3].record()
+        host[c, 3] = time.perf_counter()
+        policy.update_target_net()
+        ev[c][4].record()
+        host[c, 4] = time.perf_counter()
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t00) / n * 1e3
+    h = np.diff(host, axis=1).mean(axis=0) * 1e3
+    nxt = (host[1:, 0] - host[:-1, 4]).mean() * 1e3
+    g = np.array([[ev[c][i].elapsed_time(ev[c][i + 1]) for i in range(4)] for c in range(n)]).mean(axis=0)
+    gap = np.mean([ev[c][4].elapsed_time(ev[c + 1][0]) for c in range(n - 1)])
+    print('cycle %.3f ms' % total)
+    print('host  ms: rollout (incl. the flag sync) %.3f | store %.3f | train_batches (enqueue) %.3f | target %.3f | loop %.3f'
+          % (h[0], h[1], h[2], h[3], nxt))
+    print('GPU   ms between event stamps: rollout %.3f | store %.3f | updates %.3f | target %.3f | to next cycle %.3f'
+          % (g[0], g[1], g[2], g[3], gap))
+
+
+if __name__ == '__main__':
+    main()

@@ -110,6 +110,116 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
   }
 }
 
+
+// ---- the same chain with every layer split over a PAIR of workgroups on one XCD (block ids b, b + 8): workgroup p of
+// the pair streams only columns [128 p, 128 p + 128) of each weight matrix (128 KB per layer instead of 256 KB) for the
+// pair's 4 G rows and hands its half of the activations to the partner through the L2 -- as tagged 64-bit words
+// (value | tag), 16 bytes per store / load, polled by the reader, cleared after reading: no flag, no fence.  Each layer
+// starts with the k-half the workgroup produced itself; the partner's half is awaited in the middle of the layer.
+#define XTAG 0x51C0FFEEu
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int G>
+__global__ __launch_bounds__(256) void rowchain_pair(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ Y,
+                                                     u32x4* xbuf, int L, int B) {
+  constexpr int R = 4 * G;
+  __shared__ __attribute__((aligned(16))) float hs[R * HLD];
+  __shared__ __attribute__((aligned(16))) float part[8 * R * 128];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 5, c4 = lane & 31;
+  const int p = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  const int r0 = pair * R;
+  for (int i = tid; i < R * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(X + (size_t)(r0 + r) * H + c);
+  }
+  // weight rows of (layer, k-half kh) for this lane: k = 128 kh + 32 wave + 16 kk + t, t = 0..15; columns 128 p + 4 c4 ..
+  auto wrow = [&](int l, int kh) { return W + ((size_t)l * H + 128 * kh + 32 * wave + 16 * kk) * H + 128 * p + 4 * c4; };
+  f32x4 b[2][16];
+  {
+    const float* w0 = wrow(0, p);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) b[0][t] = ldv(w0 + (size_t)t * H);
+  }
+  const int orow = tid >> 5, ocq = tid & 31;                     // the output elements this thread finishes (R == 8)
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    f32x4 acc[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[g][e] = zero4();
+    const f32x4 bv = ldv(bias + (size_t)l * H + 128 * p + 4 * ocq);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int kh = ph ? (p ^ 1) : p;
+      if (ph == 1 && l > 0) {
+        // the partner's half of this layer's input: slot of step l - 1, written by the partner's epilogue
+        if (orow < R) {
+          u32x4* src = xbuf + ((((size_t)pair * 2 + (p ^ 1)) * L + (l - 1)) * R * 128 + orow * 128 + 4 * ocq) / 2;
+          u32x4 v0, v1;
+          for (;;) {
+            v0 = __builtin_nontemporal_load(src);
+            v1 = __builtin_nontemporal_load(src + 1);
+            if (v0[1] == XTAG && v0[3] == XTAG && v1[1] == XTAG && v1[3] == XTAG) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          const f32x4 hv = {__uint_as_float(v0[0]), __uint_as_float(v0[2]), __uint_as_float(v1[0]), __uint_as_float(v1[2])};
+          *reinterpret_cast<f32x4*>(hs + orow * HLD + 128 * (p ^ 1) + 4 * ocq) = hv;
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          src[0] = z; src[1] = z;                                  // consumed (the next launch starts from "not yet")
+        }
+        __syncthreads();
+      }
+      // prefetch: the other half of this layer, or the own half of the next layer
+      const float* nx = (ph == 0) ? wrow(l, p ^ 1) : wrow(l + 1, p);
+      if (ph == 0 || l + 1 < L) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) b[ph ^ 1][t] = ldv(nx + (size_t)t * H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        f32x4 a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          a[g] = *reinterpret_cast<const f32x4*>(hs + (4 * g + (lane & 3)) * HLD + 128 * kh + 32 * wave + 16 * kk + 4 * tq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][e] = MFMA4(a[g][s], b[ph][4 * tq + s][e], acc[g][e]);
+      }
+    }
+    // partials -> LDS: acc[g][e][r] = partial of out[row 4g + r][col 128 p + 4 c4 + e] over (wave, kk)'s k subset
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = {acc[g][0][r], acc[g][1][r], acc[g][2][r], acc[g][3][r]};
+        *reinterpret_cast<f32x4*>(part + ((wave * 2 + kk) * R + 4 * g + r) * 128 + 4 * c4) = v;
+      }
+    __syncthreads();
+    if (orow < R) {
+      f32x4 sum = bv;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) sum += *reinterpret_cast<const f32x4*>(part + (s8 * R + orow) * 128 + 4 * ocq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.f);
+      *reinterpret_cast<f32x4*>(hs + orow * HLD + 128 * p + 4 * ocq) = sum;
+      if (l + 1 < L) {
+        u32x4* dst = xbuf + ((((size_t)pair * 2 + p) * L + l) * R * 128 + orow * 128 + 4 * ocq) / 2;
+        const u32x4 v0 = {__float_as_uint(sum[0]), XTAG, __float_as_uint(sum[1]), XTAG};
+        const u32x4 v1 = {__float_as_uint(sum[2]), XTAG, __float_as_uint(sum[3]), XTAG};
+        dst[0] = v0; dst[1] = v1;
+      } else {
+        *reinterpret_cast<f32x4*>(Y + (size_t)(r0 + orow) * H + 128 * p + 4 * ocq) = sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static void cpu_chain(const std::vector<float>& X, const std::vector<float>& W, const std::vector<float>& b,
                       std::vector<float>& Y, int L, int B) {
   std::vector<double> h(X.begin(), X.begin() + (size_t)B * H), n((size_t)B * H);
@@ -173,8 +283,52 @@ int main() {
       printf("check R=%d L=%d: max abs err %.3e (max |ref| %.3f)\n", R, L, maxerr, maxref);
     }
   }
+  // ---- the pair-split chain: correctness (single chain, weights of chain 0) and timing
+  {
+    u32x4* xb;
+    const size_t xbytes = (size_t)(B / 4) * 2 * 16 * 8 * 128 * 8;
+    CK(hipMalloc(&xb, xbytes));
+    CK(hipMemset(xb, 0xff, xbytes));                             // garbage, not zeros: nothing needs initialising
+    std::vector<float> ref, got((size_t)B * H);
+    cpu_chain(hX, hW, hb, ref, 3, B);
+    for (int G : {1, 2}) {
+      CK(hipMemset(Y, 0, hX.size() * 4));
+      for (int rep = 0; rep < 2; ++rep) {
+        if (G == 1) hipLaunchKernelGGL(rowchain_pair<1>, dim3(2 * B / 4), dim3(256), 0, 0, X, W, b, Y, xb, 3, B);
+        else hipLaunchKernelGGL(rowchain_pair<2>, dim3(2 * B / 8), dim3(256), 0, 0, X, W, b, Y, xb, 3, B);
+      }
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(got.data(), Y, got.size() * 4, hipMemcpyDeviceToHost));
+      double maxerr = 0;
+      for (size_t i = 0; i < got.size(); ++i) maxerr = fmax(maxerr, fabs(got[i] - ref[i]));
+      printf("check pair chain, %d rows per pair, L=3: max abs err %.3e\n", 4 * G, maxerr);
+    }
+    for (int G : {1, 2}) {
+      float t[3];
+      const int Ls[3] = {2, 8, 14};
+      for (int i = 0; i < 3; ++i) {
+        const int L = Ls[i];
+        auto launch = [&]() {
+          if (G == 1) hipLaunchKernelGGL(rowchain_pair<1>, dim3(2 * B / 4), dim3(256), 0, 0, X, W, b, Y, xb, L, B);
+          else hipLaunchKernelGGL(rowchain_pair<2>, dim3(2 * B / 8), dim3(256), 0, 0, X, W, b, Y, xb, L, B);
+        };
+        for (int k = 0; k < 5; ++k) launch();
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int k = 0; k < 300; ++k) launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t[i] = ms * 1000.f / 300;
+      }
+      printf("pair chain, %d rows per pair (%3d WGs): L=2 %.2f us, L=8 %.2f us, L=14 %.2f us -> %.2f us per layer\n", 4 * G,
+             2 * B / (4 * G), t[0], t[1], t[2], (t[2] - t[0]) / 12.f);
+    }
+  }
   // ---- timing: per launch for L layers; the slope over L is the per-layer cost without the launch floor
-  for (int mode : {0, 1, 2, 3}) {
+  for (int mode : {0, 1}) {
     for (int nch : {1, 3}) {
       for (int R : {4, 8}) {
         float t[3];
