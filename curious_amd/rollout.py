@@ -321,6 +321,13 @@ class RolloutWorker:
         self.n_episodes += B * self.nb_cpu
         if self.structure not in ('curious', 'task_experts'):
             return
+        if not self.exploit and not dist.is_distributed() and self.goal_selection != 'active':
+            # Only exploit rollouts count (rollout.py:318-330): with one rank and no exploit rollout nothing valid
+            # arrives, the competence queues see empty lists and C, CP and the task probabilities come out as they went
+            # in.  Skipped: this sits between the end of a rollout and the launch of the updates that wait for it.
+            self.task_history.extend(list(self.tasks))
+            self.goal_history.extend(list(self.goals))
+            return
         # C9: gather (task, success, valid) of every rank; only exploit rollouts count (rollout.py:318-330)
         rec = np.zeros([B, 3], np.float64)
         rec[:, 0] = tasks_now

@@ -25,7 +25,7 @@ def main():
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)
-    st.sort_stats('cumulative').print_stats(45)
+    st.sort_stats('tottime').print_stats(50)
 
 
 if __name__ == '__main__':
