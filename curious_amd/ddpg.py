@@ -515,7 +515,6 @@ class DDPG(object):
     def _update_stats(self, staging, batch_size):
         """HER-sample batch_size * T transitions from the fresh episodes and feed both normalisers (ddpg.py:207-223)."""
         layout = self._layout
-        views = EpisodeViews(staging, layout)
         n = batch_size * self.T
         if self.rng_mode == 'numpy':
             ep, t, u_her, u_off, given = self.sample_transitions.draw(batch_size, self.T, n)
@@ -527,7 +526,7 @@ class DDPG(object):
             self._stats_batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
         batch = self._stats_batch
         P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
-        ops.her_sample(views.records, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
+        ops.her_sample(staging, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
         cols = layout.batch_cols
         # both normalisers from the one batch in two launches; on a single rank the second one also recomputes the
         # statistics, with several ranks the (packed) accumulators are all-reduced first (normalizer.py:84-94)

@@ -173,7 +173,10 @@ class BatchedSyntheticArm(ArmSpec):
         return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
 
     def episode_views(self):
-        return EpisodeViews(self.staging, self.layout, with_next=False)
+        # the staging block is allocated once: so are the views cut from it
+        if getattr(self, '_views', None) is None:
+            self._views = EpisodeViews(self.staging, self.layout, with_next=False)
+        return self._views
 
     def last_success(self):
         """is_success of the final step, [n] float32 on the GPU."""

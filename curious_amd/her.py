@@ -102,6 +102,9 @@ class HerSampler:
         return ep, t, u_her, u_off, given
 
     def params(self, clip_obs=np.inf, relative_goals=False):
+        key = (float(clip_obs), bool(relative_goals), float(self.future_p), self.reward_eps, self.mode, bool(self.flat))
+        if getattr(self, '_params_cache', (None, None))[0] == key:
+            return self._params_cache[1]
         P = _lib.SampleParams()
         P.future_p = float(self.future_p)
         P.reward_eps = self.reward_eps
@@ -109,6 +112,7 @@ class HerSampler:
         P.relative_goals = int(bool(relative_goals))
         P.relabel_mode = self.mode
         P.flat_reward = int(self.flat)
+        self._params_cache = (key, P)
         return P
 
     def apply_host_reward(self, batch, layout):

@@ -68,22 +68,32 @@ class RecordLayout:
         self.batch_cols = b
         self.batch_stride = _pad4(boff)
 
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ('_c_layout', '_c_batch_layout')}   # ctypes structs
+
     # ---------------------------------------------------------------- C structs
     def c_layout(self):
+        """curious_layout_t of this layout (built once: the layout is immutable and the library only reads it)."""
+        if getattr(self, '_c_layout', None) is not None:
+            return self._c_layout
         L = _lib.Layout()
         L.T = self.T
         L.dimo, L.dimag, L.dimg, L.dimu = self.dims['o'], self.dims['ag'], self.dims['g'], self.dims['u']
         L.dimtd, L.dimextra = self.dims['task_descr'], self.dimextra
         L.off_o, L.off_ag, L.off_g, L.off_u = self.off['o'], self.off['ag'], self.off['g'], self.off['u']
         L.off_td, L.off_extra, L.row_stride = self.off['task_descr'], self.off_extra, self.row_stride
+        self._c_layout = L
         return L
 
     def c_batch_layout(self):
+        if getattr(self, '_c_batch_layout', None) is not None:
+            return self._c_batch_layout
         B = _lib.BatchLayout()
         c = self.batch_cols
         B.off_o, B.off_td, B.off_u, B.off_g = c['o'][0], c['task_descr'][0], c['u'][0], c['g'][0]
         B.off_o2, B.off_g2, B.off_r = c['o_2'][0], c['g_2'][0], c['r'][0]
         B.off_ag, B.off_ag2, B.off_extra, B.stride = c['ag'][0], c['ag_2'][0], self.boff_extra, self.batch_stride
+        self._c_batch_layout = B
         return B
 
     # ---------------------------------------------------------------- views
