@@ -716,6 +716,11 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
   a.qt = reinterpret_cast<unsigned long long*>(w.qt);
   a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
+  {
+    static int xm = -1;                                      // CURIOUS_ROWS_XCD=0: the plain block-id order (A/B)
+    if (xm < 0) { const char* e = getenv("CURIOUS_ROWS_XCD"); xm = (e && atoi(e) == 0) ? 0 : 1; }
+    a.xmap = xm;
+  }
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
@@ -728,7 +733,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     lds_set = true;
   }
-  dim3 grid(3 * (B / ROWS_R), 1, xd.nex);
+  dim3 grid(4 * (B / ROWS_R), 1, xd.nex);
   { ProfScope ps__(CK_ROWS, st);
     if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
     else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }

@@ -5,8 +5,9 @@
 // (1.5 us) plus a cold start (~3 us) per layer.  Here a workgroup owns FOUR batch rows and walks all layers of its
 // networks by itself: activations never leave the CU (LDS), nothing is exchanged between workgroups, and the only
 // per-layer cost is streaming the layer's 256 KB of weights L2 -> CU (tools/rowchain_lab.hip: 2.3-2.9 us per layer).
-// Three kinds of workgroup per row group (grid.x = 3 * B / 4; block ids: all actor-side groups first -- the longest
-// chain --, then the target groups, then the main-critic groups, which consume what the target groups produce):
+// Three kinds of workgroup per row group (grid.x = 4 * B / 4, a quarter of them exit at once: see the block-id map in the
+// kernel; actor-side groups -- the longest chain -- and target groups are dispatched first, then the main-critic groups,
+// which consume what the target groups produce):
 //   actor side:  main actor -> pi;  main critic(pi) -> Q_pi;  backward through critic(pi) into the action slot -> dz;
 //                backward of the actor
 //   target:      target actor -> target critic(pi') -> Q'                      (handed to the main-critic group)
@@ -53,7 +54,7 @@ struct RowsArgs {
   unsigned long long* qt;         // [B] hand-off words target group -> main-critic group: (ROWS_QT_TAG << 32) | bits(Q')
   const float* wTq[ROWS_MAXL]; const float* wTpi[ROWS_MAXL];   // transposed hidden matrices of main critic / actor
   int64_t* step_ctr;
-  int32_t B, nl, dimo, dimtd, dimg;
+  int32_t B, nl, dimo, dimtd, dimg, xmap;
   float gamma, clip_lo, clip_hi, max_u, l2c;
   unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [3][32] s_memtime stamps of row group 0, else NULL
 };
@@ -284,7 +285,7 @@ __device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, i
 }
 
 // ================================================================== the kernel
-// grid (3 * B / 4, 1, n_experts); B % 16 == 0.
+// grid (4 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
   return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;
 }
@@ -300,11 +301,25 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   x.sm = x.xin + 4 * XLD;
   x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
-  // kind of workgroup from the block id: [0, nrg) actor side, [nrg, 2 nrg) target, [2 nrg, 3 nrg) main critic.
-  // (Workgroups are dealt round-robin over the 8 XCDs in block-id order; every XCD gets an equal share of each kind.)
-  const int nrg = a.B / ROWS_R;
-  const int kind = ((int)blockIdx.x >= 2 * nrg) ? 2 : ((int)blockIdx.x >= nrg) ? 1 : 0;
-  const int rgrp = (int)blockIdx.x - kind * nrg;
+  // Kind of workgroup and row group from the block id.  Workgroups are dealt round-robin over the 8 XCDs in block-id
+  // order (block b lands on XCD b % 8; speed only, nothing depends on it for correctness).  A layer's time is set by
+  // how many workgroups stream weights out of one XCD's L2 at the same time (24 per XCD: 7.1 k cycles, 16: 5.9 k), and
+  // the actor-side chain is the longest: it gets XCDs 0-3 for itself, 16 workgroups per XCD at B = 256, while the target
+  // and main-critic groups share XCDs 4-7, 32 per XCD -- they have the slack.  grid.x = 4 * nrg: slot = b / 8;
+  //   XCD 0-3: slots [0, nrg/4) actor side, the rest exit;   XCD 4-7: slots [0, nrg/4) target, [nrg/4, nrg/2) main critic
+  // (lower block ids are dispatched first: the longest chain and the producers start before the consumers).
+  const int nrg = a.B / ROWS_R, per = nrg >> 2;
+  int kind, rgrp;
+  if (a.xmap) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    if (xcd < 4 && slot >= per) return;
+    kind = (xcd < 4) ? 0 : (slot < per) ? 1 : 2;
+    rgrp = (xcd & 3) * per + (slot < per ? slot : slot - per);
+  } else {                                                   // A/B: kinds in block-id order, every XCD gets all kinds
+    if ((int)blockIdx.x >= 3 * nrg) return;
+    kind = ((int)blockIdx.x >= 2 * nrg) ? 2 : ((int)blockIdx.x >= nrg) ? 1 : 0;
+    rgrp = (int)blockIdx.x - kind * nrg;
+  }
   x.r0 = rgrp * ROWS_R;
 #ifdef ROWS_DEBUG
   if (a.stamps && rgrp == 0 && kind == 0) x.dbg = a.stamps + 96;

@@ -59,7 +59,7 @@ int main() {
   float* tail = ws + 4 * nl * BH;
   a.dQ = tail; a.dz = tail + B; a.rows = tail + 5 * B; a.out_Qpi = tail + 8 * B;
   a.qt = reinterpret_cast<unsigned long long*>(tail + 10 * B);
-  a.B = B; a.nl = nl; a.dimo = O; a.dimtd = N; a.dimg = G;
+  a.xmap = 1; a.B = B; a.nl = nl; a.dimo = O; a.dimtd = N; a.dimg = G;
   a.gamma = 0.98f; a.clip_lo = -50.f; a.clip_hi = 0.f; a.max_u = 1.f; a.l2c = 2.0f / (B * U);
   a.stamps = dst;
   Ex ex; ex.stride = 0; ex.nprob = 1; ex.zmul = 0;
@@ -75,7 +75,7 @@ int main() {
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  dim3 grid(3 * (B / ROWS_R), 1, 1);
+  dim3 grid(4 * (B / ROWS_R), 1, 1);
   auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
