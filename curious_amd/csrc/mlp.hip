@@ -719,7 +719,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   {
     static int xm = -1;                                      // CURIOUS_ROWS_XCD=0: the plain block-id order (A/B)
     if (xm < 0) { const char* e = getenv("CURIOUS_ROWS_XCD"); xm = (e && atoi(e) == 0) ? 0 : 1; }
-    a.xmap = xm;
+    a.xmap = (xm && xd.nex == 1) ? 1 : 0;                    // batched experts fill the chip several times over: plain order
   }
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
@@ -733,7 +733,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     lds_set = true;
   }
-  dim3 grid(4 * (B / ROWS_R), 1, xd.nex);
+  dim3 grid((a.xmap ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
   { ProfScope ps__(CK_ROWS, st);
     if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
     else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }

@@ -309,23 +309,29 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   //   XCD 0-3: slots [0, nrg/4) actor side, the rest exit;   XCD 4-7: slots [0, nrg/4) target, [nrg/4, nrg/2) main critic
   // (lower block ids are dispatched first: the longest chain and the producers start before the consumers).
   const int nrg = a.B / ROWS_R, per = nrg >> 2;
-  int kind, rgrp;
-  if (a.xmap) {
+  int kind, rgrp, expert = 0;
+  if (a.xmap) {                                              // single agent, grid.x = 4 * nrg
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
     if (xcd < 4 && slot >= per) return;
     kind = (xcd < 4) ? 0 : (slot < per) ? 1 : 2;
     rgrp = (xcd & 3) * per + (slot < per ? slot : slot - per);
-  } else {                                                   // A/B: kinds in block-id order, every XCD gets all kinds
-    if ((int)blockIdx.x >= 3 * nrg) return;
-    kind = ((int)blockIdx.x >= 2 * nrg) ? 2 : ((int)blockIdx.x >= nrg) ? 1 : 0;
-    rgrp = (int)blockIdx.x - kind * nrg;
+  } else {
+    // grid (3 * nrg, 1, experts), kinds in dispatch order ACROSS the experts: the actor-side groups of all experts,
+    // then all target groups, then all main-critic groups.  Batched experts fill the chip several times over; a
+    // main-critic group that is dispatched while its target group still runs would hold a CU just to wait.
+    const int groups = nrg * (int)gridDim.z;
+    const int lin = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
+    kind = lin / groups;
+    const int rem = lin - kind * groups;
+    expert = rem / nrg;
+    rgrp = rem - expert * nrg;
   }
   x.r0 = rgrp * ROWS_R;
 #ifdef ROWS_DEBUG
   if (a.stamps && rgrp == 0 && kind == 0) x.dbg = a.stamps + 96;
 #endif
   int64_t eo;
-  (void)ex_decode<EX>(ex, blockIdx.z, eo);                  // one problem per expert: blockIdx.z = expert
+  (void)ex_decode<EX>(ex, expert, eo);                      // one problem per expert
   const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
   const float* batch = a.batch + eo;
   const int m = x.r0 + x.wave;                              // the batch row whose output layers this wave finishes

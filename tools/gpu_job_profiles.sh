@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 profiles: rocprofv3 kernel stats + PMC passes of bench.py, default bench line, one-rank RCCL path.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2e; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2i; mkdir -p $O
 cd $R && python -m curious_amd.build > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
@@ -22,3 +22,21 @@ RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 CURIOUS
 timeout 200 python bench.py --structure task_experts --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_experts.json 2> $O/bench_experts.err
 timeout 200 python bench.py --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_arm8_1024.json 2> $O/bench_arm8_1024.err
 head -c 600 $O/bench_kernel_stats.csv; cat $O/pmc_hbm.txt | tail -20; tail -n 2 $O/*.err
+# labs + learning curves on the final kernels
+timeout 100 tools/rows_lab > $O/rows_lab.txt 2>&1
+timeout 100 tools/rowchain_lab > $O/rowchain_lab.txt 2>&1
+timeout 100 tools/xchg_lab > $O/xchg_lab.txt 2>&1
+timeout 200 python tools/cycle_timeline.py > $O/cycle_timeline.txt 2>&1
+cd $O && export PYTHONPATH=$R
+( time timeout 600 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --n_epochs 150 --n_cycles 25 --n_batches 40 --rollout_batch_size 256 --seed 1 > learn_curious.log 2>&1 ) 2> time_curious.txt
+cp save/MultiTaskFetchArm4-v5/0/progress.csv learn_curious_progress.csv
+( time timeout 600 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --structure task_experts --task_selection random --task_replay replay_current_task_buffer --experts_update batched --n_epochs 80 --n_cycles 25 --n_batches 40 --rollout_batch_size 256 --seed 1 --trial_id 1 > learn_experts.log 2>&1 ) 2> time_experts.txt
+cp save/MultiTaskFetchArm4-v5/1/progress.csv learn_experts_progress.csv
+rm -rf save
+tail -n 3 time_curious.txt time_experts.txt
+python - <<'PY'
+import csv
+for f in ('learn_curious_progress.csv','learn_experts_progress.csv'):
+    rows=list(csv.DictReader(open(f)))
+    print(f, len(rows), [ (r['epoch'], r['test/success_rate']) for r in rows[::max(1,len(rows)//10)] ], rows[-1]['test/success_rate'])
+PY

@@ -220,6 +220,89 @@ __global__ __launch_bounds__(256) void rowchain_pair(const float* __restrict__ X
   }
 }
 
+
+// ---- the plain chain again with THREE chunk buffers: the loads of chunk c + 2 are issued while chunk c is multiplied
+// (twice the bytes in flight per wave).  12 chunks = 3 layers are unrolled so that the buffer index stays static.
+template <int R>
+__global__ __launch_bounds__(256) void rowchain_deep(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int L, int B) {
+  constexpr int G = R / 4;
+  __shared__ __attribute__((aligned(16))) float hs[R * HLD];
+  __shared__ __attribute__((aligned(16))) float part[4 * R * H];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = blockIdx.x * R, chain = blockIdx.y;
+  const float* Wc = W + (size_t)chain * L * H * H;
+  const float* bc = bias + (size_t)chain * L * H;
+  const float* Xc = X + (size_t)chain * B * H;
+  float* Yc = Y + (size_t)chain * B * H;
+  for (int i = tid; i < R * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(Xc + (size_t)(r0 + r) * H + c);
+  }
+  f32x4 b[3][16];
+  // global chunk g = 4 l + c lives at Wc + l H H + (64 wave + 16 c) H + 4 lane
+  auto chunk = [&](int g) { return Wc + (size_t)(g >> 2) * H * H + (size_t)(64 * wave + 16 * (g & 3)) * H + 4 * lane; };
+  const int nchunks = 4 * L;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b[0][i] = ldv(chunk(0) + (size_t)i * H);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b[1][i] = ldv(chunk(1) + (size_t)i * H);
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += 3) {
+#pragma unroll
+    for (int ll = 0; ll < 3; ++ll) {
+      const int l = l0 + ll;
+      f32x4 acc[G][4];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[g][e] = zero4();
+      const float bv = bc[(size_t)l * H + tid];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = 4 * ll + c;                               // 0..11: buffer gi % 3
+        const int gg = 4 * l + c + 2;
+        if (gg < nchunks) {
+          const float* nx = chunk(gg);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) b[(gi + 2) % 3][i] = ldv(nx + (size_t)i * H);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          f32x4 a[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            a[g] = *reinterpret_cast<const f32x4*>(hs + (4 * g + (lane & 3)) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int g = 0; g < G; ++g) acc[g][e] = MFMA4(a[g][s], b[gi % 3][4 * kq + s][e], acc[g][e]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x4 v = {acc[g][0][r], acc[g][1][r], acc[g][2][r], acc[g][3][r]};
+          *reinterpret_cast<f32x4*>(part + ((wave * R + 4 * g + r) * H + 4 * lane)) = v;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float s = (part[(0 * R + r) * H + tid] + part[(1 * R + r) * H + tid]) +
+                  (part[(2 * R + r) * H + tid] + part[(3 * R + r) * H + tid]);
+        s = fmaxf(s + bv, 0.f);
+        hs[r * HLD + tid] = s;
+        if (l == L - 1) Yc[(size_t)(r0 + r) * H + tid] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 static void cpu_chain(const std::vector<float>& X, const std::vector<float>& W, const std::vector<float>& b,
                       std::vector<float>& Y, int L, int B) {
   std::vector<double> h(X.begin(), X.begin() + (size_t)B * H), n((size_t)B * H);
@@ -251,7 +334,7 @@ static float run(const float* X, const float* W, const float* b, float* Y, int L
 }
 
 int main() {
-  const int B = 256, LMAX = 16, NCH = 3;
+  const int B = 256, LMAX = 16, NCH = 3;   // (weights: [chain][L of the launch][..])
   std::vector<float> hX((size_t)NCH * B * H), hW((size_t)NCH * LMAX * H * H), hb((size_t)NCH * LMAX * H);
   srand(1);
   for (auto& v : hX) v = (float)rand() / RAND_MAX - 0.5f;
@@ -281,6 +364,37 @@ int main() {
         maxref = fmax(maxref, fabs(ref[i]));
       }
       printf("check R=%d L=%d: max abs err %.3e (max |ref| %.3f)\n", R, L, maxerr, maxref);
+    }
+  }
+  // ---- three chunk buffers (L must be a multiple of 3)
+  {
+    std::vector<float> ref, got((size_t)B * H);
+    cpu_chain(hX, hW, hb, ref, 3, B);
+    CK(hipMemset(Y, 0, hX.size() * 4));
+    hipLaunchKernelGGL(rowchain_deep<4>, dim3(B / 4, 1), dim3(256), 0, 0, X, W, b, Y, 3, B);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(got.data(), Y, got.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (size_t i = 0; i < got.size(); ++i) maxerr = fmax(maxerr, fabs(got[i] - ref[i]));
+    printf("check three-buffer chain R=4 L=3: max abs err %.3e\n", maxerr);
+    for (int nch : {1, 3}) {
+      float t[2];
+      const int Ls[2] = {3, 15};
+      for (int i = 0; i < 2; ++i) {
+        const int L = Ls[i];
+        for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(rowchain_deep<4>, dim3(B / 4, nch), dim3(256), 0, 0, X, W, b, Y, L, B);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int k = 0; k < 300; ++k) hipLaunchKernelGGL(rowchain_deep<4>, dim3(B / 4, nch), dim3(256), 0, 0, X, W, b, Y, L, B);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t[i] = ms * 1000.f / 300;
+      }
+      printf("three chunk buffers R=4 chains=%d (%3d WGs): L=3 %.2f us, L=15 %.2f us -> %.2f us per layer\n", nch,
+             B / 4 * nch, t[0], t[1], (t[1] - t[0]) / 12.f);
     }
   }
   // ---- the pair-split chain: correctness (single chain, weights of chain 0) and timing
