@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 3          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 4          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -68,6 +68,10 @@ class AdamState(C.Structure):
                 ('epsilon', C.c_float), ('params_unchanged', C.c_int32)]
 
 
+class Transposed(C.Structure):
+    _fields_ = [('n', C.c_int32), ('dim', C.c_int32), ('src_off', C.c_int64 * 8), ('dst', C.c_void_p * 8)]
+
+
 class NextBatch(C.Structure):
     _fields_ = [('storage', C.c_void_p), ('buf_stride', C.c_int64), ('L', C.POINTER(Layout)),
                 ('tasks', C.POINTER(Tasks)), ('P', C.POINTER(SampleParams)), ('rng', C.POINTER(SampleRng)),
@@ -107,7 +111,8 @@ PROTOTYPES = {
     'curious_param_total': (_I64, [C.POINTER(NetCfg)]),
     'curious_workspace_floats': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_ddpg_grads': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
-                                     _P, _P, _P, _P]),
+                                     _P, _P, _P, _I32, _P]),
+    'curious_ddpg_transposed': (C.c_int, [C.POINTER(NetCfg), _I32, _P, C.POINTER(Transposed)]),
     'curious_ddpg_update': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
                                       _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
     'curious_ddpg_update_experts': (C.c_int, [C.POINTER(NetCfg), _I32, _I64, _U64, _P, _P, _P, C.POINTER(BatchLayout),
@@ -117,11 +122,11 @@ PROTOTYPES = {
                                          _I32, _P, _P, _P, _P, _P, _P]),
     'curious_action_noise': (C.c_int, [_P, _I32, _I32, _I32, _D, _D, _D, _P, _P, _P, _U64, _U64, _P]),
     'curious_adam_update': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, C.POINTER(C.c_float), _F, _F,
-                                      _F, _F, _F, _P]),
+                                      _F, _F, _F, C.POINTER(Transposed), _P]),
     'curious_adam_update_and_sample': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, C.POINTER(C.c_float),
                                                  _F, _F, _F, _F, _F, _P, _I64, C.POINTER(Layout), C.POINTER(Tasks),
                                                  C.POINTER(SampleParams), C.POINTER(SampleRng), _I32, _P,
-                                                 C.POINTER(BatchLayout), _P]),
+                                                 C.POINTER(BatchLayout), C.POINTER(Transposed), _P]),
     'curious_polyak_update': (C.c_int, [_P, _P, _I64, _F, _F, _P]),
     'curious_param_checksum': (C.c_int, [_P, _I64, _P, _P]),
     'curious_policy_act_env_step': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,

@@ -142,6 +142,23 @@ extern "C" int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+extern "C" int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, float* workspace,
+                                       curious_transposed_t* out) {
+  CURIOUS_CHECK(cfg && workspace && out && B > 0, "curious_ddpg_transposed: bad argument");
+  if (check_cfg(cfg)) return -1;
+  memset(out, 0, sizeof(*out));
+  if (cfg->hidden != 256 || cfg->layers < 2 || 2 * (cfg->layers - 1) > 8) return 0;    // nothing is kept for this shape
+  const Ws w = carve(cfg, B, workspace);
+  const NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
+  out->dim = cfg->hidden;
+  for (int l = 1; l < cfg->layers; ++l) { out->src_off[out->n] = offQ.W[l]; out->dst[out->n++] = w.wT[0][l]; }
+  for (int l = 1; l < cfg->layers; ++l) {
+    out->src_off[out->n] = pi_offset(cfg) + offPi.W[l];
+    out->dst[out->n++] = w.wT[1][l];
+  }
+  return 0;
+}
+
 static Seg make_seg(const float* x, int ld, int w, const float* W) {
   Seg s;
   memset(&s, 0, sizeof(s));
@@ -1114,11 +1131,11 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
                                             a->alpha_tab, step_ctr, a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah,
                                             a->beta1, a->one_minus_beta1, a->beta2, a->one_minus_beta2, a->epsilon,
                                             nx->storage, nx->buf_stride, nx->L, nx->tasks, nx->P, nx->rng, B, nx->batch,
-                                            BL, (curious_stream_t)st);
+                                            BL, nullptr, (curious_stream_t)st);
     }
     return curious_adam_update(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi, a->alpha_tab, step_ctr,
                                a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah, a->beta1, a->one_minus_beta1,
-                               a->beta2, a->one_minus_beta2, a->epsilon, (curious_stream_t)st);
+                               a->beta2, a->one_minus_beta2, a->epsilon, nullptr, (curious_stream_t)st);
   }
   return 0;
 }
@@ -1135,8 +1152,10 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
   int rc = p.setup(stream);
   if (!rc && p.rows_route()) {
+    // the copies are kept current by this pass's own optimiser tail (maintained), or -- without a tail -- by the
+    // caller's stand-alone optimiser call (curious_adam_update* with `keep`), as the caller asserts
     const bool maintained = p.keeps_copies(tail);
-    rc = p.rows_pass(!(maintained && params_unchanged), maintained);
+    rc = p.rows_pass(!((maintained || !tail) && params_unchanged), maintained);
   } else {
     if (!rc) rc = p.forward();
     if (!rc) rc = p.critic_backward();
@@ -1149,9 +1168,10 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
 extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                                   const float* batch, const curious_batch_layout_t* BL, int32_t B,
                                   const float* o_stats, const float* g_stats, float* workspace, float* grad,
-                                  float* out_losses, float* out_Q_pi, int64_t* step_ctr, curious_stream_t stream) {
+                                  float* out_losses, float* out_Q_pi, int64_t* step_ctr, int32_t params_unchanged,
+                                  curious_stream_t stream) {
   return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
-                         out_Q_pi, step_ctr, stream, nullptr);
+                         out_Q_pi, step_ctr, stream, nullptr, ExDim(), 0, params_unchanged != 0);
 }
 
 static int ddpg_update_impl(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,

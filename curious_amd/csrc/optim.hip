@@ -19,10 +19,11 @@ struct AdamArgs {
   int32_t tab_len;
   float a_Q, a_pi;
   float b1, omb1, b2, omb2, eps;
+  curious_transposed_t keep;      // square matrices whose transposed copies are kept current (keep.n == 0: none)
 };
 
-__device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks) {
-  float aQ = a.a_Q, aPi = a.a_pi;
+__device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi) {
+  aQ = a.a_Q; aPi = a.a_pi;
   if (a.alpha_tab) {
     // the step counter was advanced by ddpg_grads; the table is a ring refilled by the host every tab_len steps
     int64_t idx = ((*a.step_ctr) - 1 - a.tab_base) % a.tab_len;
@@ -30,35 +31,105 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
     aQ = a.alpha_tab[2 * idx];
     aPi = a.alpha_tab[2 * idx + 1];
   }
+}
+// the arithmetic of one element (mpi_adam.py:31-34); returns the new parameter
+__device__ __forceinline__ float adam_math(const AdamArgs& a, const float na, const float g, float& m, float& v,
+                                           const float th) {
+  m = __fadd_rn(__fmul_rn(a.b1, m), __fmul_rn(a.omb1, g));                          // mpi_adam.py:31
+  v = __fadd_rn(__fmul_rn(a.b2, v), __fmul_rn(a.omb2, __fmul_rn(g, g)));            // mpi_adam.py:32
+  const float step = fdiv(__fmul_rn(na, m), __fadd_rn(sqrtf(v), a.eps));            // mpi_adam.py:33
+  return __fadd_rn(th, step);                                                       // mpi_adam.py:34
+}
+__device__ __forceinline__ void adam_one(const AdamArgs& a, const int64_t i, const float aQ, const float aPi) {
+  float m = a.m[i], v = a.v[i];
+  const float th = adam_math(a, (i < a.n_Q) ? -aQ : -aPi, a.grad[i], m, v, a.theta[i]);
+  a.m[i] = m;
+  a.v[i] = v;
+  a.theta[i] = th;
+}
+
+__device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks) {
+  float aQ, aPi;
+  adam_alphas(a, aQ, aPi);
+  const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
   for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.n; i += (int64_t)nblocks * 256) {
-    float g = a.grad[i];
-    float m = __fadd_rn(__fmul_rn(a.b1, a.m[i]), __fmul_rn(a.omb1, g));              // mpi_adam.py:31
-    float v = __fadd_rn(__fmul_rn(a.b2, a.v[i]), __fmul_rn(a.omb2, __fmul_rn(g, g)));  // mpi_adam.py:32
-    float na = (i < a.n_Q) ? -aQ : -aPi;
-    float step = fdiv(__fmul_rn(na, m), __fadd_rn(sqrtf(v), a.eps));        // mpi_adam.py:33
-    a.m[i] = m;
-    a.v[i] = v;
-    a.theta[i] = __fadd_rn(a.theta[i], step);                                          // mpi_adam.py:34
+    bool tiled = false;                                     // inside a matrix the tile blocks below take care of
+    for (int j = 0; j < a.keep.n; ++j) tiled |= (uint64_t)(i - a.keep.src_off[j]) < (uint64_t)msize;
+    if (!tiled) adam_one(a, i, aQ, aPi);
   }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) { adam_body(a, blockIdx.x, gridDim.x); }
+// One 64 x 64 tile of a matrix whose transposed copy is kept: the same arithmetic element by element, the updated tile
+// goes through LDS to the copy (WT[n][k] = W[k][n]), both sides in 256-byte row segments.
+#define ADAM_TILE 64
+__device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1]) {
+  float aQ, aPi;
+  adam_alphas(a, aQ, aPi);
+  const int dim = a.keep.dim, per = dim / ADAM_TILE;
+  const int j = tb / (per * per), t = tb - j * per * per;
+  const int k0 = (t / per) * ADAM_TILE, n0 = (t % per) * ADAM_TILE;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  const int64_t base = a.keep.src_off[j];
+  // all operands of the thread's 16 elements first (64 loads in flight), then the arithmetic and the stores: element
+  // by element the stores would fence the next element's loads and the tile would be 16 dependent round trips
+  constexpr int NE = ADAM_TILE / 4;
+  float g[NE], m[NE], v[NE], th[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int64_t e = base + (int64_t)(k0 + 4 * i + r4) * dim + n0 + c;
+    g[i] = a.grad[e]; m[i] = a.m[e]; v[i] = a.v[e]; th[i] = a.theta[e];
+  }
+  const float na = (base < a.n_Q) ? -aQ : -aPi;             // a matrix lies inside one network
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int64_t e = base + (int64_t)(k0 + 4 * i + r4) * dim + n0 + c;
+    th[i] = adam_math(a, na, g[i], m[i], v[i], th[i]);
+    a.m[e] = m[i]; a.v[e] = v[i]; a.theta[e] = th[i];
+    tile[4 * i + r4][c] = th[i];
+  }
+  __syncthreads();
+  float* dst = a.keep.dst[j];
+#pragma unroll 4
+  for (int i = 0; i < ADAM_TILE / 4; ++i) dst[(int64_t)(n0 + 4 * i + r4) * dim + k0 + c] = tile[c][4 * i + r4];
+}
+static inline int adam_tiles(const AdamArgs& a) {
+  const int per = a.keep.n ? a.keep.dim / ADAM_TILE : 0;
+  return a.keep.n * per * per;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int n_tile) {
+  __shared__ float tile[ADAM_TILE][ADAM_TILE + 1];
+  if ((int)blockIdx.x < n_tile) adam_tile_body(a, blockIdx.x, tile);
+  else adam_body(a, blockIdx.x - n_tile, gridDim.x - n_tile);
+}
 
 // Adam + the HER gather of the NEXT update in one launch: the gather does not depend on the parameters, so its
 // workgroups (the first n_her blocks) ride along with the optimiser's instead of being a dependent launch of their
 // own at the head of the next update (~7 us per update).  Stream order guarantees that every reader of the previous
 // staged batch (layer-0 forward, layer-0 weight gradients) has finished before this launch starts.
-__global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her) {
+__global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her, int n_tile) {
   extern __shared__ float lds[];
   if ((int)blockIdx.x < n_her) her_sample_body(h, blockIdx.x, lds);
-  else adam_body(a, blockIdx.x - n_her, gridDim.x - n_her);
+  else if ((int)blockIdx.x < n_her + n_tile)
+    adam_tile_body(a, blockIdx.x - n_her, reinterpret_cast<float(*)[ADAM_TILE + 1]>(lds));
+  else adam_body(a, blockIdx.x - n_her - n_tile, gridDim.x - n_her - n_tile);
 }
 
 static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
                      const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
                      const float* alpha_host, float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
-                     float epsilon) {
+                     float epsilon, const curious_transposed_t* keep) {
   CURIOUS_CHECK(theta && m && v && grad, "curious_adam_update: NULL argument");
+  memset(&a.keep, 0, sizeof(a.keep));
+  if (keep && keep->n > 0) {
+    CURIOUS_CHECK(keep->n <= 8 && keep->dim > 0 && keep->dim % ADAM_TILE == 0,
+                  "curious_adam_update: bad description of the transposed copies");
+    for (int j = 0; j < keep->n; ++j)
+      CURIOUS_CHECK(keep->dst[j] && keep->src_off[j] >= 0 &&
+                        keep->src_off[j] + (int64_t)keep->dim * keep->dim <= n_Q + n_pi,
+                    "curious_adam_update: bad description of the transposed copies");
+    a.keep = *keep;
+  }
   CURIOUS_CHECK((alpha_tab && step_ctr && tab_len > 0) || alpha_host, "curious_adam_update: no step size given");
   a.theta = theta; a.m = m; a.v = v; a.grad = grad;
   a.n_Q = n_Q; a.n = n_Q + n_pi;
@@ -76,19 +147,23 @@ extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, 
                                               const float* storage, int64_t buf_stride, const curious_layout_t* L,
                                               const curious_tasks_t* tasks, const curious_sample_params_t* P,
                                               const curious_sample_rng_t* rng, int32_t n, float* batch,
-                                              const curious_batch_layout_t* BL, curious_stream_t stream) {
+                                              const curious_batch_layout_t* BL, const curious_transposed_t* keep,
+                                              curious_stream_t stream) {
   AdamArgs a;
   if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
-                one_minus_beta1, beta2, one_minus_beta2, epsilon)) return -1;
+                one_minus_beta1, beta2, one_minus_beta2, epsilon, keep)) return -1;
   HerArgs h;
   if (her_fill_args(h, storage, buf_stride, L, tasks, P, nullptr, rng, n, batch, BL)) return -1;
   int n_her = (n + SPB - 1) / SPB;
   int blocks = (int)((a.n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
+  const int n_tile = adam_tiles(a);
+  size_t lds = her_lds_bytes(L);
+  if (n_tile && lds < sizeof(float) * ADAM_TILE * (ADAM_TILE + 1)) lds = sizeof(float) * ADAM_TILE * (ADAM_TILE + 1);
   { ProfScope ps__(CK_ADAM, as_stream(stream));
-    hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + blocks), dim3(256), her_lds_bytes(L), as_stream(stream), a, h,
-                       n_her); }
+    hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + n_tile + blocks), dim3(256), lds, as_stream(stream), a, h, n_her,
+                       n_tile); }
   CURIOUS_LAUNCH_CHECK("adam_her_kernel");
   return 0;
 }
@@ -96,15 +171,17 @@ extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, 
 extern "C" int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
                                    const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base,
                                    int32_t tab_len, const float* alpha_host, float beta1, float one_minus_beta1,
-                                   float beta2, float one_minus_beta2, float epsilon, curious_stream_t stream) {
+                                   float beta2, float one_minus_beta2, float epsilon,
+                                   const curious_transposed_t* keep, curious_stream_t stream) {
   AdamArgs a;
   if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
-                one_minus_beta1, beta2, one_minus_beta2, epsilon)) return -1;
+                one_minus_beta1, beta2, one_minus_beta2, epsilon, keep)) return -1;
   if (a.n <= 0) return 0;
   int blocks = (int)((a.n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  const int n_tile = adam_tiles(a);
   { ProfScope ps__(CK_ADAM, as_stream(stream));
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a); }
+    hipLaunchKernelGGL(adam_kernel, dim3(n_tile + blocks), dim3(256), 0, as_stream(stream), a, n_tile); }
   CURIOUS_LAUNCH_CHECK("adam_kernel");
   return 0;
 }

@@ -564,12 +564,15 @@ class DDPG(object):
     def _sync_optimizers(self):
         dist.broadcast_(self.theta, 0)                               # C3: one broadcast for both networks
 
-    def _grads(self):
+    def _grads(self, chained=False):
+        """chained: the launch in front of this one on the stream was _adam_and_sample (which keeps the transposed weight
+        copies of the workspace current) inside the same captured graph -- see _update_fused."""
         b = self._staged
         ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, b, self._layout_for_batch, self.batch_size,
                        self._workspace, self.grad, self._losses, self._Q_pi,
                        o_stats=self.o_stats.state if self.normalize_obs else None,
-                       g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr)
+                       g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr,
+                       params_unchanged=chained)
         return self._losses[0], self._Q_pi, self.grad[:self.P_Q], self.grad[self.off_pi:self.off_pi + self.P_pi]
 
     def _update(self, Q_grad=None, pi_grad=None, use_table=False):
@@ -850,7 +853,7 @@ class DDPG(object):
             self._graph_b = self._capture(self._adam_and_sample)
             self._batch_stale = True
         if self._graph_ba is None:
-            self._graph_ba = self._capture(lambda: (self._adam_and_sample(), self._grads()))
+            self._graph_ba = self._capture(lambda: (self._adam_and_sample(), self._grads(True)))
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
@@ -961,8 +964,8 @@ class DDPG(object):
         CURIOUS_GRAPH_ALLREDUCE=0/1, otherwise by a collective self-test at the first use."""
         return dist.captured_allreduce_ok()
 
-    def _ranks_update(self):
-        self._grads()
+    def _ranks_update(self, chained=False):
+        self._grads(chained)
         dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
         self._adam_and_sample()
 
@@ -992,7 +995,7 @@ class DDPG(object):
             self._graphs[0] = self._capture(self._ranks_update)
             self._batch_stale = True
         if one_graph and k > 1 and self._graph_chain is None:
-            self._graph_chain = self._capture(lambda: [self._ranks_update() for _ in range(CHAIN)])
+            self._graph_chain = self._capture(lambda: [self._ranks_update(i > 0) for i in range(CHAIN)])
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
@@ -1031,7 +1034,14 @@ class DDPG(object):
                                    self._alpha_tab, self._step_ctr, self._alpha_base, self._pool.storage,
                                    self._pool.buf_stride, self._layout, S.tasks,
                                    S.params(self.clip_obs, self.relative_goals), self._rng_desc, self.batch_size,
-                                   self._staged)
+                                   self._staged, keep=self._kept_copies())
+
+    def _kept_copies(self):
+        """curious_transposed_t of this agent's workspace: handed to the stand-alone optimiser launch of the multi-rank
+        path so that the gradient launch that follows it inside the same graph need not rebuild the copies."""
+        if getattr(self, '_kept', None) is None:
+            self._kept = ops.ddpg_transposed(self.net_cfg, self.batch_size, self._workspace)
+        return self._kept
 
     def _capture(self, fn):
         """Capture `fn`'s kernel launches into a hipGraph (after one eager warm-up on a side stream)."""

@@ -137,12 +137,22 @@ def workspace_floats(cfg, B):
 
 
 def ddpg_grads(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi,
-               o_stats=None, g_stats=None, step_ctr=None):
+               o_stats=None, g_stats=None, step_ctr=None, params_unchanged=False):
+    """params_unchanged: since the previous call on this workspace only an optimiser call that was given
+    ddpg_transposed(cfg, B, workspace) has written theta_main (the transposed weight copies in the workspace are current)."""
     BL = layout.c_batch_layout()
     check(lib().curious_ddpg_grads(C.byref(cfg), ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
                                    ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
                                    ptr(workspace), ptr(grad), ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr),
-                                   current_stream()), 'curious_ddpg_grads')
+                                   int(bool(params_unchanged)), current_stream()), 'curious_ddpg_grads')
+
+
+def ddpg_transposed(cfg, B, workspace):
+    """curious_transposed_t of the weight copies the gradient pass keeps in `workspace` (n == 0: none for this shape)."""
+    T = _lib.Transposed()
+    check(lib().curious_ddpg_transposed(C.byref(cfg), int(B), ptr(_dev(workspace, 'workspace')), C.byref(T)),
+          'curious_ddpg_transposed')
+    return T
 
 
 def ddpg_update(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi, m, v,
@@ -226,7 +236,7 @@ def adam_alpha(stepsize, t, beta1=0.9, beta2=0.999):
 
 
 def adam_update(theta, m, v, grad, n_Q, n_pi, alpha_Q=None, alpha_pi=None, beta1=0.9, beta2=0.999, epsilon=1e-08,
-                alpha_tab=None, step_ctr=None, tab_base=0):
+                alpha_tab=None, step_ctr=None, tab_base=0, keep=None):
     f = np.float32
     ah = None
     if alpha_tab is None:
@@ -235,12 +245,14 @@ def adam_update(theta, m, v, grad, n_Q, n_pi, alpha_Q=None, alpha_pi=None, beta1
                                     ptr(alpha_tab), ptr(step_ctr), int(tab_base),
                                     int(alpha_tab.shape[0]) if alpha_tab is not None else 0, ah,
                                     float(f(beta1)), float(f(1 - beta1)), float(f(beta2)), float(f(1 - beta2)),
-                                    float(f(epsilon)), current_stream()), 'curious_adam_update')
+                                    float(f(epsilon)), C.byref(keep) if keep is not None else None, current_stream()),
+          'curious_adam_update')
 
 
 def adam_update_and_sample(theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, storage, buf_stride, layout,
-                           tasks, params, rng, n, batch, beta1=0.9, beta2=0.999, epsilon=1e-08):
-    """Fused Adam (table-driven step sizes) + device-drawn HER gather of the next update."""
+                           tasks, params, rng, n, batch, beta1=0.9, beta2=0.999, epsilon=1e-08, keep=None):
+    """Fused Adam (table-driven step sizes) + device-drawn HER gather of the next update.  keep: ddpg_transposed(...) of
+    the workspace whose transposed weight copies this call keeps current."""
     f = np.float32
     L = layout.c_layout()
     BL = layout.c_batch_layout()
@@ -248,8 +260,8 @@ def adam_update_and_sample(theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, ta
         ptr(_dev(theta, 'theta')), ptr(m), ptr(v), ptr(grad), int(n_Q), int(n_pi), ptr(alpha_tab), ptr(step_ctr),
         int(tab_base), int(alpha_tab.shape[0]), None, float(f(beta1)), float(f(1 - beta1)), float(f(beta2)),
         float(f(1 - beta2)), float(f(epsilon)), ptr(_dev(storage, 'storage')), int(buf_stride), C.byref(L),
-        C.byref(tasks), C.byref(params), C.byref(rng), int(n), ptr(batch), C.byref(BL), current_stream()),
-        'curious_adam_update_and_sample')
+        C.byref(tasks), C.byref(params), C.byref(rng), int(n), ptr(batch), C.byref(BL),
+        C.byref(keep) if keep is not None else None, current_stream()), 'curious_adam_update_and_sample')
 
 
 def polyak_update(target, main, polyak):

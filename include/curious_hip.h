@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 3      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 4      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -188,11 +188,14 @@ int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
  * batch rows as written by curious_her_sample.  o_stats/g_stats = normaliser state vectors (may be
  * NULL when normalize_obs = 0).  out_losses = [Q_loss, pi_loss]; out_Q_pi[B] = main.Q_pi_tf (the
  * "actor_loss" returned by DDPG.train, ddpg.py:237-243); grad = [Q_grad | pad | pi_grad | pad] (pads untouched).
- * If step_ctr != NULL, *step_ctr is incremented once (device-side step counter for RNG / Adam). */
+ * If step_ctr != NULL, *step_ctr is incremented once (device-side step counter for RNG / Adam).
+ * params_unchanged != 0: since the previous call on THIS workspace (same cfg and B) nothing has written theta_main
+ * except an optimiser call that was given curious_ddpg_transposed() of this workspace (`keep`), and the workspace was
+ * left alone -- the library then trusts the transposed weight copies it keeps there (0: always safe, +1 launch). */
 int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                        const float* batch, const curious_batch_layout_t* BL, int32_t B,
                        const float* o_stats, const float* g_stats, float* workspace, float* grad,
-                       float* out_losses, float* out_Q_pi, int64_t* step_ctr, curious_stream_t stream);
+                       float* out_losses, float* out_Q_pi, int64_t* step_ctr, int32_t params_unchanged, curious_stream_t stream);
 
 /* Actor (and optionally critic) forward for acting: pi = max_u*tanh(net(o,td,g)), Q = critic(o,td,pi,g)
  * (ddpg.py:129-146, actor_critic.py:87-94).  Inputs are separate row matrices with their strides;
@@ -215,10 +218,23 @@ int curious_action_noise(float* u, int32_t ldu, int32_t n, int32_t dimu, double 
  * the two optimisers keep separate step sizes a_Q / a_pi = lr*sqrt(1-b2^t)/(1-b1^t), rounded to float32.
  * alpha_tab (device, [tab_len][2]) is a ring indexed by (*step_ctr - 1 - tab_base) mod tab_len when non-NULL, else
  * alpha_host is used. */
+/* The transposed copies of square parameter matrices that the row-local gradient pass keeps in its workspace
+ * (curious_ddpg_grads / curious_ddpg_update*; mlp_rows.h): matrix i is the dim x dim block at parameter index
+ * src_off[i] of theta, its transpose lives at dst[i].  An optimiser call that is handed this description (`keep`)
+ * writes WT next to the W it updates, so the next gradient pass may be told params_unchanged. */
+typedef struct curious_transposed {
+  int32_t n;                           /* number of matrices, 0 = none kept for this (cfg, B) */
+  int32_t dim;
+  int64_t src_off[8];
+  float* dst[8];
+} curious_transposed_t;
+int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, float* workspace, curious_transposed_t* out);
+
 int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
                         const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
                         const float* alpha_host, float beta1, float one_minus_beta1, float beta2,
-                        float one_minus_beta2, float epsilon, curious_stream_t stream);
+                        float one_minus_beta2, float epsilon, const curious_transposed_t* keep /* may be NULL */,
+                        curious_stream_t stream);
 
 /* curious_adam_update + the device-drawn HER gather of the NEXT update (curious_her_sample with `rng`) in ONE launch:
  * the gather does not depend on the parameters, so it rides along with the optimiser instead of heading the next
@@ -230,7 +246,8 @@ int curious_adam_update_and_sample(float* theta, float* m, float* v, const float
                                    float one_minus_beta2, float epsilon, const float* storage, int64_t buf_stride,
                                    const curious_layout_t* L, const curious_tasks_t* tasks,
                                    const curious_sample_params_t* P, const curious_sample_rng_t* rng, int32_t n,
-                                   float* batch, const curious_batch_layout_t* BL, curious_stream_t stream);
+                                   float* batch, const curious_batch_layout_t* BL,
+                                   const curious_transposed_t* keep /* may be NULL */, curious_stream_t stream);
 
 /* One whole single-rank update: DDPG._grads + both MpiAdam.update calls (ddpg.py:235-248, mpi_adam.py:29-35 with no
  * ranks to reduce over) with the optimiser applied in the epilogue of the weight-gradient launch, and optionally the

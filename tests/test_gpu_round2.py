@@ -532,3 +532,42 @@ def test_action_noise_kernel_matches_the_reference_method():
             ops.action_noise(u, n, 4, ne * 1.0, re, 1.0, d(randn.reshape(-1)), d(binom), d(unif.reshape(-1)))
             np.testing.assert_array_equal(u.cpu().numpy().reshape(G['n%d/%s/u' % (n, tag)].shape),
                                           G['n%d/%s/u' % (n, tag)])
+
+
+@pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 64), ('MultiTaskFetchArm8-v5', 8, 52, 64),
+                                                 ('MultiTaskFetchArm4-v5', 4, 40, 30)])
+def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B):
+    """curious_policy_rollout (all T steps in one launch on the row-local route, B % 4 == 0; the launches of the
+    single-step entry point otherwise) == T x curious_policy_act_env_step, bit for bit: episode records, last actions,
+    success / NaN flags, final env state -- over two consecutive episodes (the episode counter feeds the env's streams)."""
+    from curious_amd import ops
+    from curious_amd.envs import EnvFactory, REWARD_EPS
+    outs = []
+    for mode in ('rollout', 'steps'):
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False)
+        env = EnvFactory(env_name).make_batched(B)
+        env.seed(11)
+        rs = np.random.RandomState(3)
+        ws = torch.empty(ops.workspace_floats(agent.net_cfg, B), dtype=torch.float32, device='cuda')
+        u = torch.zeros([B, 4], dtype=torch.float32, device='cuda')
+        seed, recs = 12345, []
+        for ep in range(2):
+            env.reset_all(rs.randint(0, nb, B), rs.uniform(-1, 1, (B, 3)).astype(np.float32))
+            args = (agent.net_cfg, agent.theta, B, agent.clip_obs, ws, 0.2, 0.3, seed)
+            tail = (env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS)
+            if mode == 'rollout':
+                ops.policy_rollout(*args, 1 + ep * T, u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T,
+                                   *tail, flags=env.flags)
+            else:
+                for t in range(T):
+                    ops.policy_act_env_step(*args, 1 + ep * T + t, u, env._cfg, env.layout, env.env_id0, env.episode,
+                                            env.tasks, t, *tail, flags=env.flags)
+            torch.cuda.synchronize()
+            recs.append((env.staging.clone(), u.clone(), env.flags.clone(), env.o.clone(), env.ag.clone()))
+        outs.append(recs)
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    off_u = env.layout.off['u']
+    acts = outs[0][1][0][:, :T, off_u:off_u + 4]
+    assert float(acts.abs().max()) <= 1.0 and float(acts.abs().sum()) > 0
