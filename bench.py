@@ -68,7 +68,8 @@ def build_job(use_graph, seed=0, env=None, b_r=B_R):
     params.update(env_name=env or ENV, task_selection='active_competence_progress', goal_selection='random',
                   task_replay='replay_task_cp_buffer', goal_replay='her', structure='curious', normalize_obs=False,
                   num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=b_r,
-                  n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
+                  n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph,
+                  async_store=os.environ.get('CURIOUS_ASYNC_STORE', '1') != '0')
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = False
     params['ddpg_params']['seed'] = seed

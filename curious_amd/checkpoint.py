@@ -93,6 +93,11 @@ def load_worker_state(w, st):
 
 
 def save_training_state(path, policy, workers=()):
+    for w in workers:                                                # async_store: flags / routing the host has not
+        if hasattr(w, 'settle'):                                     # mirrored yet
+            w.settle()
+    if hasattr(policy, 'settle'):
+        policy.settle()
     torch.cuda.synchronize()
     torch.save(dict(policy=policy_state(policy), workers=[worker_state(w) for w in workers],
                     numpy_rng=np.random.get_state()), path)

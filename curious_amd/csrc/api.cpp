@@ -68,7 +68,7 @@ static const char* k_names[CK_COUNT] = {
     "norm_final_kernel", "norm_recompute_kernel", "fwd_l0_kernel", "fwd_hot_kernel", "dx_hot_kernel", "dw_all_kernel",
     "dw_kernel", "head_fwd_kernel",
     "dx_crit_kernel", "dx_actor_kernel", "adam_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel",
-    "env_step_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel", "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel"};
+    "env_step_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel", "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel"};
 
 extern "C" int curious_prof_kernel_count(void) { return CK_COUNT; }
 extern "C" const char* curious_prof_kernel_name(int kid) { return (kid >= 0 && kid < CK_COUNT) ? k_names[kid] : ""; }

@@ -72,7 +72,7 @@ static inline hipStream_t as_stream(curious_stream_t s) { return (hipStream_t)s;
 // ---------------------------------------------------------------- per-kernel HIP-event timing (bench.py roofline)
 enum {
   CK_HER_SAMPLE = 0, CK_STORE, CK_ACTIVITY, CK_NORM_PARTIAL, CK_NORM_FINAL, CK_NORM_RECOMPUTE, CK_FWD_LAYER0,
-  CK_FWD_LAYER, CK_DX, CK_DW, CK_DW_SMALL, CK_HEAD_FWD, CK_CRITIC_HEAD, CK_ACTOR_DZ, CK_ADAM, CK_POLYAK, CK_CHECKSUM, CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS, CK_ACT_ROWS, CK_ROWS_T, CK_COUNT
+  CK_FWD_LAYER, CK_DX, CK_DW, CK_DW_SMALL, CK_HEAD_FWD, CK_CRITIC_HEAD, CK_ACTOR_DZ, CK_ADAM, CK_POLYAK, CK_CHECKSUM, CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS, CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_COUNT
 };
 extern int g_curious_prof_on;
 void curious_prof_push(int kid, hipStream_t st, bool start);

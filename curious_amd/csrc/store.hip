@@ -6,12 +6,15 @@
 // stays on the host.
 #include "common.h"
 
+// n_pairs_dev != NULL: the pair list was made on the device (route_episodes_kernel); the grid covers the largest
+// possible list and the blocks beyond the real one leave
 __global__ __launch_bounds__(256) void store_episodes_kernel(float* __restrict__ storage,
                                                             const float* __restrict__ staging,
                                                             const int32_t* __restrict__ pair_src,
                                                             const int64_t* __restrict__ pair_dst, int64_t rec_floats,
-                                                            int32_t vec_ok) {
+                                                            int32_t vec_ok, const int32_t* __restrict__ n_pairs_dev) {
   const int pair = blockIdx.y;
+  if (n_pairs_dev && pair >= *n_pairs_dev) return;
   const float* src = staging + (int64_t)pair_src[pair] * rec_floats;
   float* dst = storage + pair_dst[pair] * rec_floats;
   if (vec_ok) {
@@ -39,7 +42,83 @@ extern "C" int curious_store_episodes(float* storage, const float* staging, cons
   if (bx > 16) bx = 16;
   if (bx < 1) bx = 1;
   { ProfScope ps__(CK_STORE, as_stream(stream)); hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_pairs), dim3(256), 0, as_stream(stream), storage, staging,
-                     pair_src, pair_dst, rec, vec_ok); }
+                     pair_src, pair_dst, rec, vec_ok, (const int32_t*)nullptr); }
+  CURIOUS_LAUNCH_CHECK("store_episodes_kernel");
+  return 0;
+}
+
+// Routing of DDPG.store_episode (ddpg.py:178-197) on the device, for batches that cannot overflow a buffer: one block;
+// task by task, the episodes whose activity flag is set get consecutive slots behind the buffer's current size, in
+// ascending episode order (the order of the reference's loop).  Writes the (src, dst) pair list, its length, and the new
+// sizes into the sampler's table.
+__global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __restrict__ active, int32_t ntasks,
+                                                            int32_t n_route, int32_t n_episodes,
+                                                            int32_t* __restrict__ cur_size,
+                                                            const int32_t* __restrict__ buf_alias, int64_t capacity,
+                                                            const float* __restrict__ skip,
+                                                            int32_t* __restrict__ pair_src,
+                                                            int64_t* __restrict__ pair_dst,
+                                                            int32_t* __restrict__ n_pairs) {
+  __shared__ int wave_cnt[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (skip && *skip != 0.0f) {                               // the rollout produced a NaN observation: keep nothing
+    if (tid == 0) *n_pairs = 0;
+    return;
+  }
+  int out = 0;                                               // pairs written so far (uniform)
+  for (int j = 0; j < n_route; ++j) {
+    int cur = cur_size[1 + j];                               // logical buffer 1 + j belongs to task j (ddpg.py:185)
+    const int64_t pool = (int64_t)buf_alias[1 + j] * capacity;
+    for (int b0 = 0; b0 < n_episodes; b0 += 256) {
+      const int b = b0 + tid;
+      const bool on = b < n_episodes && active[(int64_t)b * ntasks + j] != 0;
+      const unsigned long long m = __ballot(on);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        off += (w < wave) ? wave_cnt[w] : 0;
+        total += wave_cnt[w];
+      }
+      if (on) {
+        pair_src[out + off + before] = b;
+        pair_dst[out + off + before] = pool + cur + off + before;
+      }
+      out += total;
+      cur += total;
+      __syncthreads();
+    }
+    if (tid == 0) cur_size[1 + j] = cur;
+  }
+  if (tid == 0) *n_pairs = out;
+}
+
+extern "C" int curious_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
+                                            const int32_t* active, int32_t ntasks, int32_t n_route,
+                                            int32_t n_episodes, int32_t* cur_size, const int32_t* buf_alias,
+                                            int64_t capacity, const float* skip, int32_t* pair_src, int64_t* pair_dst,
+                                            int32_t* n_pairs, curious_stream_t stream) {
+  CURIOUS_CHECK(storage && staging && L && active && cur_size && buf_alias && pair_src && pair_dst && n_pairs,
+                "curious_route_store_episodes: NULL argument");
+  CURIOUS_CHECK(ntasks >= 1 && n_route >= 0 && n_route <= ntasks && capacity > 0,
+                "curious_route_store_episodes: bad task / capacity arguments");
+  if (n_episodes <= 0 || n_route == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  { ProfScope ps__(CK_ROUTE, st);
+    hipLaunchKernelGGL(route_episodes_kernel, dim3(1), dim3(256), 0, st, active, ntasks, n_route, n_episodes, cur_size,
+                       buf_alias, capacity, skip, pair_src, pair_dst, n_pairs); }
+  CURIOUS_LAUNCH_CHECK("route_episodes_kernel");
+  int64_t rec = (int64_t)(L->T + 1) * L->row_stride;
+  int vec_ok = (rec % 4 == 0) && (((uintptr_t)storage | (uintptr_t)staging) % 16 == 0);
+  int64_t work = vec_ok ? rec / 4 : rec;
+  int bx = (int)((work + 255) / 256);
+  if (bx > 16) bx = 16;
+  if (bx < 1) bx = 1;
+  { ProfScope ps__(CK_STORE, st);
+    hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_episodes * n_route), dim3(256), 0, st, storage, staging,
+                       (const int32_t*)pair_src, (const int64_t*)pair_dst, rec, vec_ok, (const int32_t*)n_pairs); }
   CURIOUS_LAUNCH_CHECK("store_episodes_kernel");
   return 0;
 }

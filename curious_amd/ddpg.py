@@ -47,8 +47,8 @@ class DDPG(object):
                  rollout_batch_size, subtract_goals, relative_goals, clip_pos_returns, clip_return,
                  normalize_obs, sample_transitions, gamma, buffers=None, reuse=False, tasks_ag_id=None,
                  tasks_g_id=None, task_replay='', t_id=None, eps_task=None, structure='curious',
-                 rng_mode='numpy', seed=0, use_graph=False, **kwargs):
-        """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph."""
+                 rng_mode='numpy', seed=0, use_graph=False, async_store=False, **kwargs):
+        """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph / async_store."""
         if self.clip_return is None:
             self.clip_return = np.inf
         # e.g. info, use_mpi: stored by store_args, pickled with the policy; names with a leading underscore are
@@ -100,6 +100,8 @@ class DDPG(object):
         self._graphs = [None, None]
         self._tables_dirty = True
         self._batch_stale = True
+        self._store_pending = None                                   # async_store: routing the host has not mirrored yet
+        self._async_batch = None
 
     # ------------------------------------------------------------------ construction
     def _new(self, shape, dtype=torch.float32):
@@ -393,11 +395,15 @@ class DDPG(object):
     def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
         block produced by the batched RolloutWorker (ddpg.py:163-223)."""
+        self.settle()
         self.cp = cp
         self.n_episodes = n_ep
         layout = self._layout
         staging = as_records(episode_batch, layout)
         batch_size = staging.shape[0]
+        marked, self._async_batch = self._async_batch, None
+        if marked is not None and marked[:2] == (staging.data_ptr(), batch_size) and update_stats:
+            return self._store_episode_async(staging, batch_size, marked[2])
         if self.structure in ('curious', 'task_experts'):
             if 'buffer' in self.task_replay or self.task_replay == 'hand_designed':
                 na = batch_size * self.nb_tasks
@@ -491,6 +497,74 @@ class DDPG(object):
         if update_stats:                                             # ddpg.py:207-223
             self._update_stats(staging, batch_size)
 
+    # ------------------------------------------------------------------ storing without waiting for the host (opt-in)
+    def can_store_async(self, batch_size):
+        """The device can route the episodes of the coming rollout itself (curious_route_store_episodes) and nothing the
+        host would compute from the rollout's flags is needed before the updates: every routed buffer is non-empty (the
+        replay proportions, ddpg.py:255-286, then depend on the competence progress only) and none can overflow (no
+        random slot, replay_buffer.py:94-109).  Single agent on its own buffers, single rank, device RNG."""
+        if not (self.async_store and self.structure == 'curious' and self._multi_buffer() and self.rng_mode == 'device'
+                and not dist.is_distributed() and isinstance(self.buffer, list)):
+            return False
+        self.settle()
+        nr = min(self.nb_tasks, 5)
+        bufs = [self.buffer[j + 1] for j in range(nr)]
+        return len({id(b) for b in bufs}) == nr and \
+            all(b.current_size > 0 and b.current_size + batch_size <= b.size for b in bufs)
+
+    def expect_async_store(self, episode_batch, skip):
+        """Called by the batched RolloutWorker when it returns WITHOUT having waited for the rollout's flags: the next
+        store_episode of exactly this batch takes the device-routed form.  skip: the rollout's NaN word (device)."""
+        staging = as_records(episode_batch, self._layout)
+        self._async_batch = (staging.data_ptr(), staging.shape[0], skip)
+
+    def _store_episode_async(self, staging, batch_size, skip):
+        """store_episode (ddpg.py:163-223) with the routing decided on the device: same slots, same table, same stats
+        as the host-routed form; the host's mirror of the buffer sizes follows in settle()."""
+        layout = self._layout
+        na = batch_size * self.nb_tasks
+        assert getattr(self, '_activity_prefetched', None) == (staging.data_ptr(), batch_size)
+        self._activity_prefetched = None
+        self._update_stats(staging, batch_size)
+        if self._tables_stale() or getattr(self, '_tables', None) is None:
+            self._refresh_device_tables()                            # from the host's (settled) sizes
+        nb1 = self.nb_tasks + 1
+        n0 = nb1 + 1
+        if getattr(self, '_route_count', None) is None:
+            self._route_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._nan_pin = torch.zeros(1, dtype=torch.float32).pin_memory()
+        src_d, dst_d = self._route_bufs[4][:na], self._route_bufs[5][:na]
+        ops.route_store_episodes(self._pool.storage, staging, layout, self._route_bufs[0][:na], self.nb_tasks,
+                                 min(self.nb_tasks, 5), batch_size, self._tables[n0 + 2 * nb1:],
+                                 self._tables[n0:n0 + nb1], self._pool.capacity, skip, src_d, dst_d, self._route_count)
+        self._nan_pin.copy_(skip, non_blocking=True)
+        arrived = torch.cuda.Event()
+        arrived.record()                                             # behind the activity flags' D2H (prefetch_activity)
+        self._pool.version += 1
+        self._tables_dirty = False
+        self._tables_sizes = self._sizes_key()                       # the device table is ahead of the host's sizes
+        self._batch_stale = True                                     # until settle(); the next batch is drawn from it
+        self._store_pending = (self._route_bufs[1][:na], batch_size, arrived)
+
+    def settle(self):
+        """Bring the host's mirror of the buffer sizes up to date with a device-routed store (async_store)."""
+        p, self._store_pending = self._store_pending, None
+        if p is None:
+            return
+        active_host, batch_size, arrived = p
+        arrived.synchronize()
+        if float(self._nan_pin[0]) == 0.0:                           # (a NaN rollout was dropped on the device as well)
+            routed = active_host.numpy().reshape(batch_size, self.nb_tasks).astype(bool)
+            if self.nb_tasks >= 5:
+                routed[:, 5:] = False                                # only tasks j < 5 are routed (ddpg.py:183)
+            counts = routed.sum(axis=0)
+            for j in range(self.nb_tasks):
+                if counts[j]:
+                    buf = self.buffer[j + 1]
+                    buf.current_size += int(counts[j])
+                    buf.n_transitions_stored += int(counts[j]) * self.T
+        self._tables_sizes = self._sizes_key()
+
     def prefetch_activity(self, episode_batch):
         """Called by the batched RolloutWorker right after it enqueued a rollout: the task-activity test of the coming
         store_episode (ddpg.py:179-184) and its D2H copy are enqueued now, so that they arrive with the rollout flags
@@ -558,6 +632,7 @@ class DDPG(object):
         return r
 
     def get_current_buffer_size(self):
+        self.settle()
         return sum([self.buffer[i].get_current_size() for i in range(self.nb_tasks)])
 
     # ------------------------------------------------------------------ optimiser plumbing
@@ -657,6 +732,7 @@ class DDPG(object):
             self._tables_host = torch.zeros(n, dtype=torch.int32).pin_memory()
 
     def _refresh_device_tables(self):
+        self.settle()
         nb1 = self.nb_tasks + 1
         self.proportions = self._proportions()
         assert self.proportions.sum() == self.batch_size             # ddpg.py:323
@@ -1068,6 +1144,7 @@ class DDPG(object):
         ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
 
     def clear_buffer(self):
+        self.settle()
         for i in range(self.nb_tasks):
             self.buffer[i].clear_buffer()
         self._tables_dirty = True

@@ -164,13 +164,20 @@ class BatchedSyntheticArm(ArmSpec):
         ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,
                      self.g, self.td, self.staging, REWARD_EPS, flags=self.flags)
 
-    def fetch_flags(self):
-        """(is_success of the final step per env [n], any observation NaN) -- the one D2H sync of a rollout."""
+    def request_flags(self):
+        """Enqueue the D2H copy of the rollout flags (no wait)."""
         self._flags_pin.copy_(self.flags, non_blocking=True)
         self._flags_ready.record()
+
+    def wait_flags(self):
         self._flags_ready.synchronize()
         host = self._flags_pin.numpy()
         return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
+
+    def fetch_flags(self):
+        """(is_success of the final step per env [n], any observation NaN) -- the one D2H sync of a rollout."""
+        self.request_flags()
+        return self.wait_flags()
 
     def episode_views(self):
         # the staging block is allocated once: so are the views cut from it

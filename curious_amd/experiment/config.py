@@ -78,7 +78,7 @@ def prepare_params(kwargs):
         ddpg_params[name] = kwargs[name]
         kwargs['_' + name] = kwargs[name]
         del kwargs[name]
-    for name in ['rng_mode', 'use_graph', 'seed']:                  # MI355X-side knobs (not in the reference)
+    for name in ['rng_mode', 'use_graph', 'seed', 'async_store']:   # MI355X-side knobs (not in the reference)
         if name in kwargs:
             ddpg_params[name] = kwargs[name]
     kwargs['ddpg_params'] = ddpg_params

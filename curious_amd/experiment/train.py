@@ -273,12 +273,16 @@ def main(argv=None):
     parser.add_argument('--rollout_batch_size', type=int, default=None)
     parser.add_argument('--rng_mode', type=str, default='device', choices=['numpy', 'device'])
     parser.add_argument('--use_graph', type=int, default=1)
+    parser.add_argument('--async_store', type=int, default=1,
+                        help='single rank, device RNG: let the device route the episodes of a rollout (no host wait '
+                             'between a rollout and its updates); 0 = always wait for the rollout flags first')
     parser.add_argument('--n_cycles', type=int, default=None)
     parser.add_argument('--n_batches', type=int, default=None)
     parser.add_argument('--experts_update', type=str, default='sequential', choices=['sequential', 'batched'],
                         help="task_experts: 'batched' updates all experts in one launch sequence per update")
     args = vars(parser.parse_args(argv))
     over = {'rng_mode': args.pop('rng_mode'), 'use_graph': bool(args.pop('use_graph')),
+            'async_store': bool(args.pop('async_store')),
             'experts_update': args.pop('experts_update')}
     for k in ('rollout_batch_size', 'n_cycles', 'n_batches'):
         v = args.pop(k)

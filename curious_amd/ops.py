@@ -60,6 +60,16 @@ def store_episodes(storage, staging, layout, pair_src, pair_dst):
                                        int(pair_src.numel()), current_stream()), 'curious_store_episodes')
 
 
+def route_store_episodes(storage, staging, layout, active, ntasks, n_route, n_episodes, cur_size, buf_alias, capacity,
+                         skip, pair_src, pair_dst, n_pairs):
+    """Device-side routing + copy of a batch of episodes that cannot overflow a buffer (curious_route_store_episodes)."""
+    L = layout.c_layout()
+    check(lib().curious_route_store_episodes(ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L),
+                                             ptr(active), int(ntasks), int(n_route), int(n_episodes), ptr(cur_size),
+                                             ptr(buf_alias), int(capacity), ptr(skip), ptr(pair_src), ptr(pair_dst),
+                                             ptr(n_pairs), current_stream()), 'curious_route_store_episodes')
+
+
 def episode_activity(staging, layout, tasks, n_episodes, active):
     L = layout.c_layout()
     check(lib().curious_episode_activity(ptr(_dev(staging, 'staging')), C.byref(L), C.byref(tasks),

@@ -216,7 +216,37 @@ class RolloutWorker:
         return convert_episode_to_batch_major(episode), self.CP, self.n_episodes
 
     # ================================================================== batched path (GPU-resident envs)
+    # ------------------------------------------------------------------ rollouts whose flags the host reads late
+    def _async_ok(self, env, fused):
+        """Nothing the host would compute from this rollout's flags is needed before its updates are enqueued: no exploit
+        rollout (competence queues, CP and task probabilities stay as they are, rollout.py:318-330), no Q statistics, no
+        SAGG-RIAC update, one rank, and a policy that can route the episodes on the device (DDPG.can_store_async)."""
+        return (fused and not self.eval and not self.exploit and not self.compute_Q and self.structure == 'curious'
+                and self.goal_selection != 'active' and not dist.is_distributed()
+                and hasattr(self.policy, 'can_store_async')
+                and self.policy.can_store_async(self.rollout_batch_size))
+
+    def settle(self):
+        """Process the flags of a rollout that was returned without waiting for them (async_store)."""
+        p, self._pending = getattr(self, '_pending', None), None
+        if p is None:
+            return
+        successful, o_has_nan = self.benv.wait_flags()
+        if np.isnan(successful).any() or o_has_nan:
+            # the sync path would have generated the rollout again (rollout.py:268-271); here its updates are already
+            # enqueued: the device dropped the episodes instead of storing them
+            self.logger.warning('NaN caught during rollout generation. Its episodes were not stored.')
+            successful = np.nan_to_num(successful)
+        exploit, self.exploit = self.exploit, False
+        self.tasks, self.goals = p['tasks'], p['goals']
+        self.n_episodes -= self.rollout_batch_size * self.nb_cpu     # counted when the rollout was returned
+        self._finish_rollout(successful, successful - 1.0, None, p['task_list'], None)
+        self.exploit = exploit
+
     def _generate_rollouts_batched(self):
+        self.settle()
+        if hasattr(self.policy, 'settle'):
+            self.policy.settle()
         self._decide_exploit()
         B, env = self.rollout_batch_size, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
@@ -270,6 +300,17 @@ class RolloutWorker:
         # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
         if not self.eval and hasattr(self.policy, 'prefetch_activity'):
             self.policy.prefetch_activity(env.episode_views())     # arrives with the flags: one host sync per cycle
+        if self._async_ok(env, fused and hasattr(self.policy, 'act_rollout')):
+            # return without waiting: the policy routes the episodes on the device, the flags are read in settle()
+            env.request_flags()
+            task_list = tasks.tolist()
+            tk = [[] for _ in range(self.nb_goals_per_rollout)]
+            tk[self.rank * B:(self.rank + 1) * B] = task_list
+            self._pending = dict(tasks=tk, goals=[[] for _ in range(self.nb_goals_per_rollout)], task_list=task_list)
+            self.n_episodes += B * self.nb_cpu
+            views = env.episode_views()
+            self.policy.expect_async_store(views, env.flags[env.n:env.n + 1])
+            return views, self.CP, self.n_episodes
         successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
         if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
@@ -361,6 +402,7 @@ class RolloutWorker:
                 self.p[self.unique_task] = 1
 
     def clear_history(self):
+        self.settle()
         self.success_history.clear()
         self.reward_history.clear()
         self.Q_history.clear()
@@ -370,6 +412,7 @@ class RolloutWorker:
             self.competence_computers[i].clear_queue()
 
     def current_success_rate(self):
+        self.settle()
         return np.mean(self.success_history)
 
     def current_mean_Q(self):
@@ -391,6 +434,7 @@ class RolloutWorker:
         pass                                                          # rollout.py:437-449 (commented out upstream)
 
     def logs(self, prefix='worker'):
+        self.settle()
         logs = []
         logs += [('success_rate', np.mean(self.success_history))]
         logs += [('avg_reward', np.mean(self.reward_history))]
@@ -402,6 +446,7 @@ class RolloutWorker:
         return logs
 
     def additional_logs(self, prefix='worker'):
+        self.settle()
         logs = []
         if self.structure in ('curious', 'task_experts'):
             for i in range(self.nb_tasks):

@@ -571,3 +571,102 @@ def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B):
     off_u = env.layout.off['u']
     acts = outs[0][1][0][:, :T, off_u:off_u + 4]
     assert float(acts.abs().max()) <= 1.0 and float(acts.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_async_store_equals_the_host_routed_cycle(use_graph):
+    """async_store: the cycle rollout -> store_episode -> train_batches with the episodes routed on the device and the
+    rollout flags read one cycle late == the cycle that waits for the flags and routes on the host, bit for bit -- replay
+    storage, buffer sizes, sampling tables, parameters, competence state -- through the phases in which the async form
+    does not apply (task buffers still empty, exploit rollouts, buffers about to overflow) and the ones in which it does."""
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd import logger
+    nb, dimo, B = 4, 40, 16
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    res, used = [], []
+    for async_store in (False, True):
+        agent, _ = build_pair(nb, dimo, cap_eps=120, rng_mode='device', use_graph=use_graph)
+        agent.async_store = async_store
+        w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                          noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='active_competence_progress',
+                          queue_length=6, eval=False)
+        w.seed(5)
+        np.random.seed(8)
+        snaps, n_async = [], 0
+        for c in range(14):
+            if c == 3:                                               # from here on every task buffer holds episodes
+                agent.store_episode(synth_episodes(np.random.RandomState(21), 24, nb, dimo), w.CP, w.n_episodes)
+            ep, cp, n_ep = w.generate_rollouts()
+            n_async += int(getattr(w, '_pending', None) is not None)
+            agent.store_episode(ep, cp, n_ep)
+            agent.train_batches(12)
+            agent.update_target_net()
+            if c in (3, 7, 13):
+                w.settle()
+                agent.settle()
+                torch.cuda.synchronize()
+                nb1 = nb + 1
+                snaps.append(dict(sizes=[agent.buffer[i].current_size for i in range(nb1)],
+                                  stored=[agent.buffer[i].n_transitions_stored for i in range(nb1)],
+                                  storage=[agent._pool.storage[agent.buffer[i].pool_index, :agent.buffer[i].current_size]
+                                           .clone() for i in range(nb1)], theta=agent.theta.clone(),
+                                  target=agent.theta_target.clone(), tables=agent._tables.clone(),
+                                  cp=np.asarray(w.CP).copy(), p=np.asarray(w.p).copy(), n_ep=w.n_episodes,
+                                  succ=list(w.success_history), tasks=list(w.task_history),
+                                  o_stats=agent.o_stats.state.clone()))
+        res.append(snaps)
+        used.append(n_async)
+    assert used[0] == 0 and 3 <= used[1] <= 12                   # the async form ran, and not in every cycle
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        assert a['sizes'] == b['sizes'] and a['stored'] == b['stored'] and a['n_ep'] == b['n_ep'], i
+        assert a['succ'] == b['succ'] and a['tasks'] == b['tasks'], i
+        assert np.array_equal(a['cp'], b['cp']) and np.array_equal(a['p'], b['p']), i
+        for k in ('theta', 'target', 'tables', 'o_stats'):
+            assert torch.equal(a[k], b[k]), (i, k)
+        assert all(torch.equal(x, y) for x, y in zip(a['storage'], b['storage'])), i     # the filled slots
+    assert max(res[1][-1]['sizes'][1:]) > 100                    # ran into the "could overflow" fallback at the end
+
+
+def test_route_store_kernel_matches_the_host_routing():
+    """curious_route_store_episodes against the host routing of DDPG.store_episode (fits case) for random activity
+    patterns: pair list, new sizes, stored records; 8 tasks (only the first 5 are routed), 300 episodes (two scan passes);
+    and the NaN word that makes it store nothing."""
+    from curious_amd import ops
+    from curious_amd.layout import RecordLayout
+    rng = np.random.RandomState(4)
+    nb, E, cap, Tn = 8, 300, 400, 5
+    shapes = dict(o=(Tn + 1, 6), u=(Tn, 4), g=(Tn, 3), ag=(Tn + 1, 3), info_is_success=(Tn, 1), task_descr=(Tn, nb),
+                  change=(Tn, 3))
+    lay = RecordLayout(shapes, Tn)
+    dev = torch.device('cuda', 0)
+    staging = torch.randn([E, Tn + 1, lay.row_stride], device=dev)
+    active = torch.from_numpy((rng.rand(E, nb) < 0.4).astype(np.int32)).to(dev)
+    alias = torch.tensor([0, 1, 2, 3, 4, 5, 5, 5, 5], dtype=torch.int32, device=dev)
+    for skip_val in (0.0, 1.0):
+        storage = torch.zeros([6, cap, Tn + 1, lay.row_stride], device=dev)
+        cur0 = rng.randint(1, 50, nb + 1).astype(np.int32)
+        cur = torch.from_numpy(cur0.copy()).to(dev)
+        src = torch.zeros(E * 5, dtype=torch.int32, device=dev)
+        dst = torch.zeros(E * 5, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        skip = torch.tensor([skip_val], device=dev)
+        ops.route_store_episodes(storage, staging, lay, active.reshape(-1), nb, 5, E, cur, alias, cap, skip, src, dst, cnt)
+        torch.cuda.synchronize()
+        a = active.cpu().numpy().astype(bool)
+        want_src, want_dst, want_cur = [], [], cur0.copy()
+        if skip_val == 0.0:
+            for j in range(5):
+                eps = np.nonzero(a[:, j])[0]
+                want_src += eps.tolist()
+                want_dst += (np.arange(cur0[1 + j], cur0[1 + j] + eps.size) + int(alias[1 + j]) * cap).tolist()
+                want_cur[1 + j] += eps.size
+        k = int(cnt)
+        assert k == len(want_src)
+        assert src[:k].cpu().tolist() == want_src and dst[:k].cpu().tolist() == want_dst
+        assert cur.cpu().numpy().tolist() == want_cur.tolist()
+        flat = storage.reshape(6 * cap, Tn + 1, lay.row_stride)
+        ref = torch.zeros_like(flat)
+        if k:
+            ref[torch.tensor(want_dst, device=dev)] = staging[torch.tensor(want_src, device=dev)]
+        assert torch.equal(flat, ref)

@@ -303,6 +303,79 @@ __global__ __launch_bounds__(256) void rowchain_deep(const float* __restrict__ X
   }
 }
 
+
+// ---- the plain chain with the four waves splitting N instead of K: wave w owns output columns 64 w .. 64 w + 63 over
+// ALL k, so no partial sums cross waves.  Lane l = (q = l >> 4, c = l & 15): B = W[k(q)][64 w + 4 c + e], the four lane
+// groups q take k = 16 t + 4 q + s; their partial sums are combined with a reduce-scatter over the lane groups (12
+// cross-lane moves) that leaves lane group q with batch row q.  One barrier per layer (activations ping-pong in LDS).
+__global__ __launch_bounds__(256) void rowchain_nsplit(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, int L, int B) {
+  __shared__ __attribute__((aligned(16))) float hs[2][4 * HLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const int r0 = blockIdx.x * 4, chain = blockIdx.y;
+  const float* Wc = W + (size_t)chain * L * H * H;
+  const float* bc = bias + (size_t)chain * L * H;
+  const float* Xc = X + (size_t)chain * B * H;
+  float* Yc = Y + (size_t)chain * B * H;
+  for (int i = tid; i < 4 * H / 4; i += 256) {
+    const int r = i / (H / 4), cc = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs[0] + r * HLD + cc) = ldv(Xc + (size_t)(r0 + r) * H + cc);
+  }
+  f32x4 b[2][16];
+  const float* wl = Wc + (size_t)(4 * q) * H + 64 * wave + 4 * c;      // + (64 cc + 16 t + s) rows
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[0][4 * t + s] = ldv(wl + (size_t)(16 * t + s) * H);
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    const float* cur = hs[l & 1];
+    float* nxt = hs[(l + 1) & 1];
+    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    const f32x4 bv = ldv(bc + (size_t)l * H + 64 * wave + 4 * c);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const float* nx = (cc < 3) ? wl + (size_t)(64 * (cc + 1)) * H : wl + (size_t)H * H;
+      if (cc < 3 || l + 1 < L) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[(cc + 1) & 1][4 * t + s] = ldv(nx + (size_t)(16 * t + s) * H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cur + (lane & 3) * HLD + 64 * cc + 16 * t + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA4(a[s], b[cc & 1][4 * t + s][e], acc[e]);
+      }
+    }
+    wl += (size_t)H * H;
+    // reduce-scatter over the lane groups: acc[e][r] = partial of out[row r][col 4 c + e] over this group's k's
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float keep[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                           // step 1: partner q ^ 1 keeps the rows of the other parity
+        const float mine = (q & 1) ? acc[e][2 * i + 1] : acc[e][2 * i];
+        const float send = (q & 1) ? acc[e][2 * i] : acc[e][2 * i + 1];
+        keep[i] = mine + __shfl_xor(send, 16);
+      }
+      const float mine = (q & 2) ? keep[1] : keep[0];         // step 2: partner q ^ 2, this group ends with row q
+      const float send = (q & 2) ? keep[0] : keep[1];
+      out[e] = mine + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = fmaxf(out[e] + bv[e], 0.f);
+    *reinterpret_cast<f32x4*>(nxt + q * HLD + 64 * wave + 4 * c) = out;
+    if (l == L - 1) *reinterpret_cast<f32x4*>(Yc + (size_t)(r0 + q) * H + 64 * wave + 4 * c) = out;
+    __syncthreads();
+  }
+}
+
 static void cpu_chain(const std::vector<float>& X, const std::vector<float>& W, const std::vector<float>& b,
                       std::vector<float>& Y, int L, int B) {
   std::vector<double> h(X.begin(), X.begin() + (size_t)B * H), n((size_t)B * H);
@@ -364,6 +437,37 @@ int main() {
         maxref = fmax(maxref, fabs(ref[i]));
       }
       printf("check R=%d L=%d: max abs err %.3e (max |ref| %.3f)\n", R, L, maxerr, maxref);
+    }
+  }
+  // ---- waves split N
+  {
+    std::vector<float> ref, got((size_t)B * H);
+    cpu_chain(hX, hW, hb, ref, 3, B);
+    CK(hipMemset(Y, 0, hX.size() * 4));
+    hipLaunchKernelGGL(rowchain_nsplit, dim3(B / 4, 1), dim3(256), 0, 0, X, W, b, Y, 3, B);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(got.data(), Y, got.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (size_t i = 0; i < got.size(); ++i) maxerr = fmax(maxerr, fabs(got[i] - ref[i]));
+    printf("check N-split waves R=4 L=3: max abs err %.3e\n", maxerr);
+    for (int nch : {1, 3}) {
+      float t[3];
+      const int Ls[3] = {2, 8, 14};
+      for (int i = 0; i < 3; ++i) {
+        const int L = Ls[i];
+        for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(rowchain_nsplit, dim3(B / 4, nch), dim3(256), 0, 0, X, W, b, Y, L, B);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int k = 0; k < 300; ++k) hipLaunchKernelGGL(rowchain_nsplit, dim3(B / 4, nch), dim3(256), 0, 0, X, W, b, Y, L, B);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t[i] = ms * 1000.f / 300;
+      }
+      printf("waves split N      R=4 chains=%d (%3d WGs): L=2 %.2f us, L=8 %.2f us, L=14 %.2f us -> %.2f us per layer\n", nch,
+             B / 4 * nch, t[0], t[1], t[2], (t[2] - t[0]) / 12.f);
     }
   }
   // ---- three chunk buffers (L must be a multiple of 3)
