@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void store_episodes_kernel(float* __restrict__
                                                             int32_t vec_ok, const int32_t* __restrict__ n_pairs_dev) {
   const int pair = blockIdx.y;
   if (n_pairs_dev && pair >= *n_pairs_dev) return;
+  if (pair_src[pair] < 0) return;                            // a later episode of the batch drew the same slot
   const float* src = staging + (int64_t)pair_src[pair] * rec_floats;
   float* dst = storage + pair_dst[pair] * rec_floats;
   if (vec_ok) {
@@ -47,19 +48,34 @@ extern "C" int curious_store_episodes(float* storage, const float* staging, cons
   return 0;
 }
 
-// Routing of DDPG.store_episode (ddpg.py:178-197) on the device, for batches that cannot overflow a buffer: one block;
-// task by task, the episodes whose activity flag is set get consecutive slots behind the buffer's current size, in
-// ascending episode order (the order of the reference's loop).  Writes the (src, dst) pair list, its length, and the new
+// Slot of a stored episode once its buffer is full (replay_buffer.py:101-102: np.random.randint(0, size)): in device
+// RNG mode a Philox draw keyed by (seed, store call, episode, task), the same on the host (curious_store_slots_host)
+// and on the device.
+#define STREAM_STORE_SLOT 31u
+__host__ __device__ inline int64_t store_random_slot(uint64_t seed, uint64_t call, int b, int j, int64_t size) {
+  const Philox4 r = philox4x32((uint32_t)b, (uint32_t)j, (uint32_t)call, STREAM_STORE_SLOT, (uint32_t)seed,
+                               (uint32_t)(seed >> 32));
+  return (int64_t)(((uint64_t)r.x * (uint64_t)size) >> 32);
+}
+
+// Routing of DDPG.store_episode (ddpg.py:178-197) on the device: one block; task by task, the episodes whose activity
+// flag is set get slots in ascending episode order (the order of the reference's loop): consecutive slots behind the
+// buffer's current size while it has room (replay_buffer.py:94-95), a random slot each once it is full
+// (replay_buffer.py:101-102); when two episodes of the batch end up on one slot the later one wins (sequential
+// semantics) and the earlier pair is marked dead (src = -1).  Writes the (src, dst) pair list, its length, and the new
 // sizes into the sampler's table.
+#define ROUTE_MAX_EPISODES 2048
 __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __restrict__ active, int32_t ntasks,
                                                             int32_t n_route, int32_t n_episodes,
                                                             int32_t* __restrict__ cur_size,
                                                             const int32_t* __restrict__ buf_alias, int64_t capacity,
+                                                            uint64_t seed, uint64_t call,
                                                             const float* __restrict__ skip,
                                                             int32_t* __restrict__ pair_src,
                                                             int64_t* __restrict__ pair_dst,
                                                             int32_t* __restrict__ n_pairs) {
   __shared__ int wave_cnt[4];
+  __shared__ int slot_of[ROUTE_MAX_EPISODES];                // this task's slot per episode, -1: not routed
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (skip && *skip != 0.0f) {                               // the rollout produced a NaN observation: keep nothing
     if (tid == 0) *n_pairs = 0;
@@ -67,8 +83,10 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
   }
   int out = 0;                                               // pairs written so far (uniform)
   for (int j = 0; j < n_route; ++j) {
-    int cur = cur_size[1 + j];                               // logical buffer 1 + j belongs to task j (ddpg.py:185)
+    const int cur0 = cur_size[1 + j];                        // logical buffer 1 + j belongs to task j (ddpg.py:185)
     const int64_t pool = (int64_t)buf_alias[1 + j] * capacity;
+    const int out0 = out;
+    int routed = 0;
     for (int b0 = 0; b0 < n_episodes; b0 += 256) {
       const int b = b0 + tid;
       const bool on = b < n_episodes && active[(int64_t)b * ntasks + j] != 0;
@@ -82,33 +100,68 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
         off += (w < wave) ? wave_cnt[w] : 0;
         total += wave_cnt[w];
       }
-      if (on) {
-        pair_src[out + off + before] = b;
-        pair_dst[out + off + before] = pool + cur + off + before;
+      if (b < n_episodes) {
+        int slot = -1;
+        if (on) {
+          const int rank = routed + off + before;
+          slot = (cur0 + rank < capacity) ? cur0 + rank : (int)store_random_slot(seed, call, b, j, capacity);
+          pair_src[out0 + rank] = b;
+          pair_dst[out0 + rank] = pool + slot;
+        }
+        slot_of[b] = slot;
       }
-      out += total;
-      cur += total;
+      routed += total;
       __syncthreads();
     }
-    if (tid == 0) cur_size[1 + j] = cur;
+    if (cur0 + routed > capacity) {
+      // random slots were drawn: an episode loses its slot to any later episode of the batch on the same slot
+      for (int b0 = 0; b0 < n_episodes; b0 += 256) {
+        const int b = b0 + tid;
+        const int mine = (b < n_episodes) ? slot_of[b] : -1;
+        if (mine >= 0) {
+          bool dead = false;
+          int rank = 0;                                      // this episode's position in the pair list
+          for (int c = 0; c < n_episodes; ++c) {
+            const int s = slot_of[c];
+            rank += (c < b && s >= 0);
+            dead |= (c > b && s == mine);
+          }
+          if (dead) pair_src[out0 + rank] = -1;
+        }
+      }
+      __syncthreads();
+    }
+    out += routed;
+    if (tid == 0) cur_size[1 + j] = (cur0 + routed < capacity) ? cur0 + routed : (int)capacity;
   }
   if (tid == 0) *n_pairs = out;
+}
+
+// the same slots for the host-routed form of a store in device RNG mode: out[i] for episode episodes[i] of task j
+extern "C" int curious_store_slots_host(uint64_t seed, uint64_t call, int32_t task, int64_t size, int32_t n,
+                                        const int32_t* episodes, int64_t* out) {
+  CURIOUS_CHECK(size > 0 && (n == 0 || (episodes && out)), "curious_store_slots_host: bad argument");
+  for (int i = 0; i < n; ++i) out[i] = store_random_slot(seed, call, episodes[i], task, size);
+  return 0;
 }
 
 extern "C" int curious_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
                                             const int32_t* active, int32_t ntasks, int32_t n_route,
                                             int32_t n_episodes, int32_t* cur_size, const int32_t* buf_alias,
-                                            int64_t capacity, const float* skip, int32_t* pair_src, int64_t* pair_dst,
-                                            int32_t* n_pairs, curious_stream_t stream) {
+                                            int64_t capacity, uint64_t seed, uint64_t call, const float* skip,
+                                            int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
+                                            curious_stream_t stream) {
   CURIOUS_CHECK(storage && staging && L && active && cur_size && buf_alias && pair_src && pair_dst && n_pairs,
                 "curious_route_store_episodes: NULL argument");
-  CURIOUS_CHECK(ntasks >= 1 && n_route >= 0 && n_route <= ntasks && capacity > 0,
+  CURIOUS_CHECK(ntasks >= 1 && n_route >= 0 && n_route <= ntasks && capacity > 0 && capacity < (1ll << 31),
                 "curious_route_store_episodes: bad task / capacity arguments");
+  CURIOUS_CHECK(n_episodes <= ROUTE_MAX_EPISODES, "curious_route_store_episodes: at most %d episodes per call",
+                ROUTE_MAX_EPISODES);
   if (n_episodes <= 0 || n_route == 0) return 0;
   hipStream_t st = as_stream(stream);
   { ProfScope ps__(CK_ROUTE, st);
     hipLaunchKernelGGL(route_episodes_kernel, dim3(1), dim3(256), 0, st, active, ntasks, n_route, n_episodes, cur_size,
-                       buf_alias, capacity, skip, pair_src, pair_dst, n_pairs); }
+                       buf_alias, capacity, seed, call, skip, pair_src, pair_dst, n_pairs); }
   CURIOUS_LAUNCH_CHECK("route_episodes_kernel");
   int64_t rec = (int64_t)(L->T + 1) * L->row_stride;
   int vec_ok = (rec % 4 == 0) && (((uintptr_t)storage | (uintptr_t)staging) % 16 == 0);

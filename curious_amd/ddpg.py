@@ -440,8 +440,31 @@ class DDPG(object):
                 counts = routed.sum(axis=0)
                 fits = all(self.buffer[j + 1].current_size + int(counts[j]) <= self.buffer[j + 1].size
                            for j in range(self.nb_tasks) if counts[j])
-                if fits and len({id(self.buffer[j + 1]) for j in range(self.nb_tasks) if counts[j]}) == \
-                        int((counts > 0).sum()):
+                distinct = len({id(self.buffer[j + 1]) for j in range(self.nb_tasks) if counts[j]}) == \
+                    int((counts > 0).sum())
+                if self.rng_mode == 'device' and distinct:
+                    # device RNG mode: the rule of replay_buffer.py:90-109 per episode -- consecutive slots while the
+                    # buffer has room, then a random slot -- with the random slots drawn from the Philox stream the
+                    # device-routed form uses (curious_route_store_episodes), so both forms store the same thing
+                    call = self._next_store_call()
+                    for j in range(self.nb_tasks):
+                        if counts[j]:
+                            buf = self.buffer[j + 1]
+                            eps = np.nonzero(routed[:, j])[0]
+                            free = max(0, buf.size - buf.current_size)
+                            slots = np.arange(buf.current_size, buf.current_size + min(eps.size, free), dtype=np.int64)
+                            buf.current_size = min(buf.size, buf.current_size + eps.size)
+                            buf.n_transitions_stored += eps.size * self.T
+                            if eps.size > free:
+                                slots = np.concatenate([slots, ops.store_slots_host(self._store_seed(), call, j, buf.size,
+                                                                                    eps[free:])])
+                                # of two episodes on one slot the later one wins (sequential semantics)
+                                _, first_rev = np.unique(slots[::-1], return_index=True)
+                                keep = np.sort(eps.size - 1 - first_rev)
+                                eps, slots = eps[keep], slots[keep]
+                            fast_src.append(eps.astype(np.int32))
+                            fast_dst.append(slots.astype(np.int64) + buf.pool_index * buf.pool.capacity)
+                elif fits and distinct:
                     # no buffer overflows within this batch -> slots are consecutive and no random number is drawn
                     # (replay_buffer.py:94-95): same result as the per-episode loop below, without the loop
                     for j in range(self.nb_tasks):
@@ -501,16 +524,22 @@ class DDPG(object):
     def can_store_async(self, batch_size):
         """The device can route the episodes of the coming rollout itself (curious_route_store_episodes) and nothing the
         host would compute from the rollout's flags is needed before the updates: every routed buffer is non-empty (the
-        replay proportions, ddpg.py:255-286, then depend on the competence progress only) and none can overflow (no
-        random slot, replay_buffer.py:94-109).  Single agent on its own buffers, single rank, device RNG."""
+        replay proportions, ddpg.py:255-286, then depend on the competence progress only).  Single agent on its own
+        buffers, single rank, device RNG (the random slots of full buffers are Philox draws in that mode)."""
         if not (self.async_store and self.structure == 'curious' and self._multi_buffer() and self.rng_mode == 'device'
                 and not dist.is_distributed() and isinstance(self.buffer, list)):
             return False
         self.settle()
         nr = min(self.nb_tasks, 5)
         bufs = [self.buffer[j + 1] for j in range(nr)]
-        return len({id(b) for b in bufs}) == nr and \
-            all(b.current_size > 0 and b.current_size + batch_size <= b.size for b in bufs)
+        return len({id(b) for b in bufs}) == nr and batch_size <= 2048 and all(b.current_size > 0 for b in bufs)
+
+    def _store_seed(self):
+        return (self.seed * 6700417 + 29 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+
+    def _next_store_call(self):
+        self._store_calls = getattr(self, '_store_calls', 0) + 1
+        return self._store_calls
 
     def expect_async_store(self, episode_batch, skip):
         """Called by the batched RolloutWorker when it returns WITHOUT having waited for the rollout's flags: the next
@@ -536,7 +565,8 @@ class DDPG(object):
         src_d, dst_d = self._route_bufs[4][:na], self._route_bufs[5][:na]
         ops.route_store_episodes(self._pool.storage, staging, layout, self._route_bufs[0][:na], self.nb_tasks,
                                  min(self.nb_tasks, 5), batch_size, self._tables[n0 + 2 * nb1:],
-                                 self._tables[n0:n0 + nb1], self._pool.capacity, skip, src_d, dst_d, self._route_count)
+                                 self._tables[n0:n0 + nb1], self._pool.capacity, self._store_seed(),
+                                 self._next_store_call(), skip, src_d, dst_d, self._route_count)
         self._nan_pin.copy_(skip, non_blocking=True)
         arrived = torch.cuda.Event()
         arrived.record()                                             # behind the activity flags' D2H (prefetch_activity)
@@ -561,7 +591,7 @@ class DDPG(object):
             for j in range(self.nb_tasks):
                 if counts[j]:
                     buf = self.buffer[j + 1]
-                    buf.current_size += int(counts[j])
+                    buf.current_size = min(buf.size, buf.current_size + int(counts[j]))
                     buf.n_transitions_stored += int(counts[j]) * self.T
         self._tables_sizes = self._sizes_key()
 

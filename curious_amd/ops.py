@@ -61,13 +61,24 @@ def store_episodes(storage, staging, layout, pair_src, pair_dst):
 
 
 def route_store_episodes(storage, staging, layout, active, ntasks, n_route, n_episodes, cur_size, buf_alias, capacity,
-                         skip, pair_src, pair_dst, n_pairs):
-    """Device-side routing + copy of a batch of episodes that cannot overflow a buffer (curious_route_store_episodes)."""
+                         seed, call, skip, pair_src, pair_dst, n_pairs):
+    """Device-side routing + copy of a batch of episodes (curious_route_store_episodes)."""
     L = layout.c_layout()
     check(lib().curious_route_store_episodes(ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L),
                                              ptr(active), int(ntasks), int(n_route), int(n_episodes), ptr(cur_size),
-                                             ptr(buf_alias), int(capacity), ptr(skip), ptr(pair_src), ptr(pair_dst),
-                                             ptr(n_pairs), current_stream()), 'curious_route_store_episodes')
+                                             ptr(buf_alias), int(capacity), int(seed) & 0xFFFFFFFFFFFFFFFF, int(call),
+                                             ptr(skip), ptr(pair_src), ptr(pair_dst), ptr(n_pairs), current_stream()),
+          'curious_route_store_episodes')
+
+
+def store_slots_host(seed, call, task, size, episodes):
+    """The random slots curious_route_store_episodes draws for `episodes` of `task` once the buffer is full (host)."""
+    ep = np.ascontiguousarray(episodes, dtype=np.int32)
+    out = np.empty(ep.size, np.int64)
+    check(lib().curious_store_slots_host(int(seed) & 0xFFFFFFFFFFFFFFFF, int(call), int(task), int(size), int(ep.size),
+                                         C.c_void_p(ep.ctypes.data), C.c_void_p(out.ctypes.data)),
+          'curious_store_slots_host')
+    return out
 
 
 def episode_activity(staging, layout, tasks, n_episodes, active):

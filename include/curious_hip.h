@@ -131,19 +131,25 @@ int curious_store_episodes(float* storage, const float* staging, const curious_l
                            const int32_t* pair_src, const int64_t* pair_dst, int32_t n_pairs,
                            curious_stream_t stream);
 
-/* The routing of DDPG.store_episode (ddpg.py:178-197) decided ON THE DEVICE + the copy, for a batch that cannot
- * overflow a buffer (the caller checked size + n_episodes <= capacity for the buffers of tasks 0 .. n_route-1): episode b
- * goes to logical buffer 1 + j of every task j < n_route whose flag active[b * ntasks + j] is set (curious_episode_activity),
- * into consecutive slots from cur_size[1 + j] on, episodes in ascending order -- the order of the reference's loop --,
- * and cur_size[1 + j] (device int32: the `cur_size` table of curious_sample_rng_t) advances accordingly.  buf_alias[i] =
- * pool slot of logical buffer i; capacity in episodes.  Nothing is stored when skip != NULL and *skip != 0 (the NaN
- * word of the rollout flags).  pair_src / pair_dst / n_pairs: device scratch of n_episodes * n_route entries / 1 entry;
- * they hold the routing afterwards.  The host never has to wait for the activity flags before the updates can be
- * enqueued. */
+/* The routing of DDPG.store_episode (ddpg.py:178-197) decided ON THE DEVICE + the copy (device RNG mode): episode b goes
+ * to logical buffer 1 + j of every task j < n_route whose flag active[b * ntasks + j] is set (curious_episode_activity),
+ * episodes in ascending order -- the order of the reference's loop: consecutive slots from cur_size[1 + j] on while the
+ * buffer has room (replay_buffer.py:94-95), a random slot each once it is full (replay_buffer.py:101-102: a Philox draw
+ * keyed by (seed, call, episode, task) instead of np.random.randint; curious_store_slots_host gives the same numbers on
+ * the host); of two episodes of the batch on one slot the later one wins.  cur_size[1 + j] (device int32: the `cur_size`
+ * table of curious_sample_rng_t) advances accordingly, capped at capacity.  buf_alias[i] = pool slot of logical buffer
+ * i; capacity in episodes.  Nothing is stored when skip != NULL and *skip != 0 (the NaN word of the rollout flags).
+ * pair_src / pair_dst / n_pairs: device scratch of n_episodes * n_route entries / 1 entry; they hold the routing
+ * afterwards (src = -1: the pair lost its slot).  The host never has to wait for the activity flags before the updates
+ * can be enqueued. */
 int curious_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L, const int32_t* active,
                                  int32_t ntasks, int32_t n_route, int32_t n_episodes, int32_t* cur_size,
-                                 const int32_t* buf_alias, int64_t capacity, const float* skip, int32_t* pair_src,
-                                 int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream);
+                                 const int32_t* buf_alias, int64_t capacity, uint64_t seed, uint64_t call,
+                                 const float* skip, int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
+                                 curious_stream_t stream);
+/* Host-side twin of the random slots above (no GPU involved): out[i] = slot of episode episodes[i] routed to `task`. */
+int curious_store_slots_host(uint64_t seed, uint64_t call, int32_t task, int64_t size, int32_t n,
+                             const int32_t* episodes, int64_t* out);
 
 /* Per-episode task activity test any(change[b,-1,ids]) (ddpg.py:179-184).
  * `change` lives in the extra block at float offset off_change; active[b*ntasks+j] in {0,1}. */

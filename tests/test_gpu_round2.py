@@ -578,7 +578,8 @@ def test_async_store_equals_the_host_routed_cycle(use_graph):
     """async_store: the cycle rollout -> store_episode -> train_batches with the episodes routed on the device and the
     rollout flags read one cycle late == the cycle that waits for the flags and routes on the host, bit for bit -- replay
     storage, buffer sizes, sampling tables, parameters, competence state -- through the phases in which the async form
-    does not apply (task buffers still empty, exploit rollouts, buffers about to overflow) and the ones in which it does."""
+    does not apply (task buffers still empty, exploit rollouts) and the ones in which it does, full buffers included
+    (random slots: the same Philox draws on the host and on the device)."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker
     from curious_amd import logger
@@ -586,7 +587,7 @@ def test_async_store_equals_the_host_routed_cycle(use_graph):
     dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
     res, used = [], []
     for async_store in (False, True):
-        agent, _ = build_pair(nb, dimo, cap_eps=120, rng_mode='device', use_graph=use_graph)
+        agent, _ = build_pair(nb, dimo, cap_eps=100, rng_mode='device', use_graph=use_graph)
         agent.async_store = async_store
         w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
                           noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='active_competence_progress',
@@ -617,7 +618,7 @@ def test_async_store_equals_the_host_routed_cycle(use_graph):
                                   o_stats=agent.o_stats.state.clone()))
         res.append(snaps)
         used.append(n_async)
-    assert used[0] == 0 and 3 <= used[1] <= 12                   # the async form ran, and not in every cycle
+    assert used[0] == 0 and 5 <= used[1] <= 12                   # the async form ran, and not in every cycle
     for i, (a, b) in enumerate(zip(res[0], res[1])):
         assert a['sizes'] == b['sizes'] and a['stored'] == b['stored'] and a['n_ep'] == b['n_ep'], i
         assert a['succ'] == b['succ'] and a['tasks'] == b['tasks'], i
@@ -625,7 +626,7 @@ def test_async_store_equals_the_host_routed_cycle(use_graph):
         for k in ('theta', 'target', 'tables', 'o_stats'):
             assert torch.equal(a[k], b[k]), (i, k)
         assert all(torch.equal(x, y) for x, y in zip(a['storage'], b['storage'])), i     # the filled slots
-    assert max(res[1][-1]['sizes'][1:]) > 100                    # ran into the "could overflow" fallback at the end
+    assert max(res[1][-1]['sizes'][1:]) == 100                   # a full buffer: random slots, async and host-routed alike
 
 
 def test_route_store_kernel_matches_the_host_routing():
@@ -635,7 +636,7 @@ def test_route_store_kernel_matches_the_host_routing():
     from curious_amd import ops
     from curious_amd.layout import RecordLayout
     rng = np.random.RandomState(4)
-    nb, E, cap, Tn = 8, 300, 400, 5
+    nb, E, cap, Tn = 8, 300, 150, 5                               # 150 slots: ~120 routed episodes per task overflow it
     shapes = dict(o=(Tn + 1, 6), u=(Tn, 4), g=(Tn, 3), ag=(Tn + 1, 3), info_is_success=(Tn, 1), task_descr=(Tn, nb),
                   change=(Tn, 3))
     lay = RecordLayout(shapes, Tn)
@@ -651,22 +652,31 @@ def test_route_store_kernel_matches_the_host_routing():
         dst = torch.zeros(E * 5, dtype=torch.int64, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         skip = torch.tensor([skip_val], device=dev)
-        ops.route_store_episodes(storage, staging, lay, active.reshape(-1), nb, 5, E, cur, alias, cap, skip, src, dst, cnt)
+        ops.route_store_episodes(storage, staging, lay, active.reshape(-1), nb, 5, E, cur, alias, cap, 77, 3, skip, src,
+                                 dst, cnt)
         torch.cuda.synchronize()
         a = active.cpu().numpy().astype(bool)
-        want_src, want_dst, want_cur = [], [], cur0.copy()
+        want_src, want_dst, want_cur, overflowed = [], [], cur0.copy(), 0
+        ref = torch.zeros([6 * cap, Tn + 1, lay.row_stride], device=dev)
         if skip_val == 0.0:
             for j in range(5):
                 eps = np.nonzero(a[:, j])[0]
+                free = max(0, cap - cur0[1 + j])
+                slots = np.arange(cur0[1 + j], cur0[1 + j] + min(eps.size, free)).tolist()
+                if eps.size > free:                              # the rule of replay_buffer.py:90-109, episode by episode
+                    slots += ops.store_slots_host(77, 3, j, cap, eps[free:]).tolist()
+                    overflowed += 1
+                want_cur[1 + j] = min(cap, cur0[1 + j] + eps.size)
+                for e, sl in zip(eps.tolist(), slots):           # sequential: the later writer of a slot wins
+                    ref[sl + int(alias[1 + j]) * cap] = staging[e]
                 want_src += eps.tolist()
-                want_dst += (np.arange(cur0[1 + j], cur0[1 + j] + eps.size) + int(alias[1 + j]) * cap).tolist()
-                want_cur[1 + j] += eps.size
+                want_dst += [sl + int(alias[1 + j]) * cap for sl in slots]
+            assert overflowed >= 3
         k = int(cnt)
         assert k == len(want_src)
-        assert src[:k].cpu().tolist() == want_src and dst[:k].cpu().tolist() == want_dst
+        got_src, got_dst = src[:k].cpu().tolist(), dst[:k].cpu().tolist()
+        assert got_dst == want_dst and all(g in (w, -1) for g, w in zip(got_src, want_src))
+        alive = [d for g, d in zip(got_src, got_dst) if g >= 0]
+        assert len(alive) == len(set(alive)) == len(set(want_dst))         # one surviving pair per destination
         assert cur.cpu().numpy().tolist() == want_cur.tolist()
-        flat = storage.reshape(6 * cap, Tn + 1, lay.row_stride)
-        ref = torch.zeros_like(flat)
-        if k:
-            ref[torch.tensor(want_dst, device=dev)] = staging[torch.tensor(want_src, device=dev)]
-        assert torch.equal(flat, ref)
+        assert torch.equal(storage.reshape(6 * cap, Tn + 1, lay.row_stride), ref)
