@@ -22,13 +22,13 @@ def main():
     # finer host stamps on the path on which the GPU waits for Python: flag sync returns -> first update graph replays
     marks = {'sync': [], 'replay': []}
     env = worker.benv
-    orig_fetch = env.fetch_flags
+    orig_wait = env.wait_flags
 
-    def fetch():
-        out = orig_fetch()
+    def wait():
+        out = orig_wait()
         marks['sync'].append(time.perf_counter())
         return out
-    env.fetch_flags = fetch
+    env.wait_flags = wait
     orig_replay = torch.cuda.CUDAGraph.replay
 
     def replay(self):
@@ -59,13 +59,18 @@ def main():
     nxt = (host[1:, 0] - host[:-1, 4]).mean() * 1e3
     g = np.array([[ev[c][i].elapsed_time(ev[c][i + 1]) for i in range(4)] for c in range(n)]).mean(axis=0)
     gap = np.mean([ev[c][4].elapsed_time(ev[c + 1][0]) for c in range(n - 1)])
-    print('cycle %.3f ms' % total)
+    print('cycle %.3f ms (async_store %s)' % (total, 'on' if policy.async_store else 'off'))
     sync = np.array(marks['sync'][-n:])
     rep = np.array(marks['replay']).reshape(-1, 3)[-n:]           # per cycle: rollout graph, two update chains
-    print('host  ms after the flag sync returned: -> generate_rollouts returns %.3f | -> store_episode returns %.3f | '
-          '-> first update graph launched %.3f | -> second %.3f'
-          % (((host[:, 1] - sync).mean()) * 1e3, ((host[:, 2] - sync).mean()) * 1e3, ((rep[:, 1] - sync).mean()) * 1e3,
-             ((rep[:, 2] - sync).mean()) * 1e3))
+    if not policy.async_store:
+        print('host  ms after the flag sync returned: -> generate_rollouts returns %.3f | -> store_episode returns %.3f | '
+              '-> first update graph launched %.3f | -> second %.3f'
+              % (((host[:, 1] - sync).mean()) * 1e3, ((host[:, 2] - sync).mean()) * 1e3,
+                 ((rep[:, 1] - sync).mean()) * 1e3, ((rep[:, 2] - sync).mean()) * 1e3))
+    else:
+        print('host  ms: the flags of a rollout are read at the start of the next cycle (the wait returns %.3f ms after the '
+              'cycle started on the host); rollout graph -> first update graph launched %.3f'
+              % (((sync - host[:, 0]).mean()) * 1e3, ((rep[:, 1] - rep[:, 0]).mean()) * 1e3))
     print('host  ms: rollout (incl. the flag sync) %.3f | store %.3f | train_batches (enqueue) %.3f | target %.3f | loop %.3f'
           % (h[0], h[1], h[2], h[3], nxt))
     print('GPU   ms between event stamps: rollout %.3f | store %.3f | updates %.3f | target %.3f | to next cycle %.3f'
