@@ -90,3 +90,22 @@ def test_host_descriptor_code_runs_up_to_the_launch_without_gpu():
         rc = L.curious_policy_forward(C.byref(cfg), fake[0], fake[1], cfg.dimo, None, 0, fake[2], cfg.dimg, fake[3],
                                       cfg.dimtd, 64, 200.0, 0, None, None, fake[4], fake[5], fake[6], None)
         assert rc != 0 and b'launch failed' in L.curious_last_error()
+
+
+def test_store_slots_host_is_the_documented_philox_draw():
+    """curious_store_slots_host (no GPU involved): slot = (Philox4x32-10(ctr = (episode, task, call, 31), key = seed).x
+    * size) >> 32 -- checked against the oracle's NumPy Philox, plus range and determinism."""
+    import numpy as np
+    from curious_amd import ops
+    from oracle.env import philox4x32
+    seed, call, task, size = 0x1234567890ABCDEF, 7, 3, 20000
+    eps = np.arange(0, 300, 3, dtype=np.int32)
+    got = ops.store_slots_host(seed, call, task, size, eps)
+    n = eps.size
+    x, _, _, _ = philox4x32(eps.astype(np.uint32), np.full(n, task, np.uint32), np.full(n, call, np.uint32),
+                            np.full(n, 31, np.uint32), np.uint32(seed & 0xFFFFFFFF), np.uint32(seed >> 32))
+    want = (x.astype(np.uint64) * np.uint64(size)) >> np.uint64(32)
+    assert got.dtype == np.int64 and np.array_equal(got, want.astype(np.int64))
+    assert got.min() >= 0 and got.max() < size and len(set(got.tolist())) > 90
+    assert np.array_equal(got, ops.store_slots_host(seed, call, task, size, eps))
+    assert not np.array_equal(got, ops.store_slots_host(seed, call + 1, task, size, eps))
