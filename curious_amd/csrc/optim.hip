@@ -59,38 +59,39 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
   }
 }
 
-// One 64 x 64 tile of a matrix whose transposed copy is kept: the same arithmetic element by element, the updated tile
-// goes through LDS to the copy (WT[n][k] = W[k][n]), both sides in 256-byte row segments.
-#define ADAM_TILE 64
+// One 32 x 32 tile of a matrix whose transposed copy is kept: the same arithmetic element by element, the updated tile
+// goes through LDS to the copy (WT[n][k] = W[k][n]), both sides in 128-byte row segments.  (4 elements per thread: a
+// 64 x 64 tile made these 64 blocks the long pole of the launch, +3 us.)
+#define ADAM_TILE 32
 __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1]) {
   float aQ, aPi;
   adam_alphas(a, aQ, aPi);
   const int dim = a.keep.dim, per = dim / ADAM_TILE;
   const int j = tb / (per * per), t = tb - j * per * per;
   const int k0 = (t / per) * ADAM_TILE, n0 = (t % per) * ADAM_TILE;
-  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  const int c = threadIdx.x & 31, r8 = threadIdx.x >> 5;
   const int64_t base = a.keep.src_off[j];
-  // all operands of the thread's 16 elements first (64 loads in flight), then the arithmetic and the stores: element
-  // by element the stores would fence the next element's loads and the tile would be 16 dependent round trips
-  constexpr int NE = ADAM_TILE / 4;
+  // all operands of the thread's elements first, then the arithmetic and the stores: element by element the stores
+  // would fence the next element's loads
+  constexpr int NE = ADAM_TILE / 8;
   float g[NE], m[NE], v[NE], th[NE];
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int64_t e = base + (int64_t)(k0 + 4 * i + r4) * dim + n0 + c;
+    const int64_t e = base + (int64_t)(k0 + 8 * i + r8) * dim + n0 + c;
     g[i] = a.grad[e]; m[i] = a.m[e]; v[i] = a.v[e]; th[i] = a.theta[e];
   }
   const float na = (base < a.n_Q) ? -aQ : -aPi;             // a matrix lies inside one network
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int64_t e = base + (int64_t)(k0 + 4 * i + r4) * dim + n0 + c;
+    const int64_t e = base + (int64_t)(k0 + 8 * i + r8) * dim + n0 + c;
     th[i] = adam_math(a, na, g[i], m[i], v[i], th[i]);
     a.m[e] = m[i]; a.v[e] = v[i]; a.theta[e] = th[i];
-    tile[4 * i + r4][c] = th[i];
+    tile[8 * i + r8][c] = th[i];
   }
   __syncthreads();
   float* dst = a.keep.dst[j];
-#pragma unroll 4
-  for (int i = 0; i < ADAM_TILE / 4; ++i) dst[(int64_t)(n0 + 4 * i + r4) * dim + k0 + c] = tile[c][4 * i + r4];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) dst[(int64_t)(n0 + 8 * i + r8) * dim + k0 + c] = tile[c][8 * i + r8];
 }
 static inline int adam_tiles(const AdamArgs& a) {
   const int per = a.keep.n ? a.keep.dim / ADAM_TILE : 0;
