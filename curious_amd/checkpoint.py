@@ -28,6 +28,7 @@ def policy_state(policy):
         o_stats=policy.o_stats.state.cpu(), g_stats=policy.g_stats.state.cpu(), stats_acc=policy._stats_acc.cpu(),
         cp=None if policy.cp is None else np.asarray(policy.cp, dtype=np.float64).copy(),
         noise_counter=policy._noise_counter, stats_calls=getattr(policy, '_stats_calls', 0),
+        store_calls=getattr(policy, '_store_calls', 0),
         buffers=[])
     for i, b in _buffers_of(policy):
         st['buffers'].append(dict(index=i, current_size=b.current_size, n_transitions_stored=b.n_transitions_stored,
@@ -50,6 +51,7 @@ def load_policy_state(policy, st):
     if getattr(policy, '_noise_base', None) is not None:
         policy._noise_base_val = None
     policy._stats_calls = st['stats_calls']
+    policy._store_calls = st.get('store_calls', 0)             # index of the Philox slot draws (device RNG mode)
     by_index = {i: b for i, b in _buffers_of(policy)}
     for bs in st['buffers']:
         b = by_index[bs['index']]

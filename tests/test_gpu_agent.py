@@ -567,19 +567,22 @@ def test_training_state_checkpoint_resumes_bit_exactly(tmp_path):
             agent.update_target_net()
     a1, w1 = job()
     np.random.seed(123)
-    cycles(a1, w1, 3)
+    cycles(a1, w1, 6)                                                 # 48 episodes: the gripper task's buffer (64 slots) ...
     path = str(tmp_path / 'state.pt')
     save_training_state(path, a1, [w1])
-    cycles(a1, w1, 2)
-    a2, w2 = job()
+    cycles(a1, w1, 4)                                                 # ... overflows after the save: random slots, whose
+    a2, w2 = job()                                                    # Philox call index is part of the checkpoint
     np.random.seed(999)                                               # overwritten by the checkpoint
     load_training_state(path, a2, [w2])
-    cycles(a2, w2, 2)
+    cycles(a2, w2, 4)
+    for x in (w1, w2, a1, a2):
+        x.settle()
     torch.cuda.synchronize()
+    assert a1.buffer[1].current_size == a1.buffer[1].size == 64
     assert torch.equal(a1.theta, a2.theta) and torch.equal(a1.theta_target, a2.theta_target)
     assert torch.equal(a1._m, a2._m) and torch.equal(a1._v, a2._v)
     assert torch.equal(a1.o_stats.state, a2.o_stats.state)
-    assert a1.Q_adam.t == a2.Q_adam.t == 35 and w1.n_episodes == w2.n_episodes
+    assert a1.Q_adam.t == a2.Q_adam.t == 70 and w1.n_episodes == w2.n_episodes
     for b1, b2 in zip(a1.buffer[1:], a2.buffer[1:]):
         assert b1.current_size == b2.current_size
         assert torch.equal(b1.records[:b1.current_size], b2.records[:b2.current_size])
