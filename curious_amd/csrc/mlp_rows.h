@@ -3,8 +3,8 @@
 // Replaces the 8 dependent launches fwd_l01 -> fwd_hot -> fwd_pi -> fwd_hot -> dx_crit -> dx_hot -> dx_actor -> dx_hot
 // (DESIGN.md section 4).  Those kernels split every 256 x 256 layer over 64 workgroups and pay a kernel boundary
 // (1.5 us) plus a cold start (~3 us) per layer.  Here a workgroup owns FOUR batch rows and walks all layers of its
-// networks by itself: activations never leave the CU (LDS), nothing is exchanged between workgroups, and the only
-// per-layer cost is streaming the layer's 256 KB of weights L2 -> CU (tools/rowchain_lab.hip: 2.3-2.9 us per layer).
+// networks by itself: activations never leave the CU (LDS), workgroups exchange nothing but one scalar per batch row (Q',
+// below), and the only per-layer cost is streaming the layer's 256 KB of weights L2 -> CU (tools/rowchain_lab.hip: 2.3-2.9 us per layer).
 // Three kinds of workgroup per row group (grid.x = 4 * B / 4, a quarter of them exit at once: see the block-id map in the
 // kernel; actor-side groups -- the longest chain -- and target groups are dispatched first, then the main-critic groups,
 // which consume what the target groups produce):
@@ -28,8 +28,8 @@
 //                       W[k][n .. n+3] contiguously (a direct 16-byte load per lane makes every quad of lanes touch 4
 //                       different rows: 2.5x the forward layer's time; staging the rows through LDS: 1.2x).  So the
 //                       library keeps TRANSPOSED copies of the main networks' hidden matrices in the workspace --
-//                       written by the optimiser epilogue of dw_adam_her_kernel next to the parameters it updates,
-//                       rebuilt by rows_transpose_kernel otherwise -- and dY . W^T is the forward product on W^T
+//                       written by the optimiser (epilogue of dw_adam_her_kernel; tile blocks of the stand-alone
+//                       adam launch) next to the parameters it updates, rebuilt by rows_transpose_kernel otherwise -- and dY . W^T is the forward product on W^T
 //                       (rows_big_bwdT): a backward layer costs what a forward layer costs.
 #pragma once
 
