@@ -109,3 +109,37 @@ def test_store_slots_host_is_the_documented_philox_draw():
     assert got.min() >= 0 and got.max() < size and len(set(got.tolist())) > 90
     assert np.array_equal(got, ops.store_slots_host(seed, call, task, size, eps))
     assert not np.array_equal(got, ops.store_slots_host(seed, call + 1, task, size, eps))
+
+
+def test_transposed_copy_description_and_routing_entry_without_gpu():
+    """curious_ddpg_transposed is pure host code (workspace carve + parameter layout); curious_route_store_episodes
+    validates and then fails at its launch on a machine without a GPU (sanitizer coverage of both)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('would launch kernels on fake pointers')
+    from curious_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.NetCfg()
+    cfg.dimo, cfg.dimg, cfg.dimtd, cfg.layers, cfg.dimu, cfg.hidden, cfg.modular = 40, 12, 4, 3, 4, 256, 1
+    cfg.max_u, cfg.gamma, cfg.clip_return, cfg.action_l2, cfg.clip_pos_returns = 1.0, 0.98, 50.0, 1.0, 1
+    T = _lib.Transposed()
+    base = 0x40000000
+    assert L.curious_ddpg_transposed(C.byref(cfg), 256, C.c_void_p(base), C.byref(T)) == 0
+    assert T.n == 4 and T.dim == 256
+    offs, dsts = list(T.src_off)[:4], list(T.dst)[:4]
+    n_Q, total = L.curious_param_offset_pi(C.byref(cfg)), L.curious_param_total(C.byref(cfg))
+    assert offs[0] < offs[1] < n_Q <= offs[2] < offs[3] < total and all(o % 4 == 0 for o in offs)
+    ws_bytes = 4 * L.curious_workspace_floats(C.byref(cfg), 256)
+    assert all(base <= d and d + 4 * 256 * 256 <= base + ws_bytes for d in dsts) and len(set(dsts)) == 4
+    cfg.hidden = 64                                             # no copies are kept for shapes off the row-local route
+    assert L.curious_ddpg_transposed(C.byref(cfg), 256, C.c_void_p(base), C.byref(T)) == 0 and T.n == 0
+    lay = _lib.Layout()
+    lay.T, lay.row_stride = 50, 88
+    fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(8)]
+    rc = L.curious_route_store_episodes(fake[0], fake[1], C.byref(lay), fake[2], 4, 4, 4096, fake[3], fake[4], 20000, 1, 1,
+                                        None, fake[5], fake[6], fake[7], None)
+    assert rc != 0 and b'at most' in L.curious_last_error()
+    rc = L.curious_route_store_episodes(fake[0], fake[1], C.byref(lay), fake[2], 4, 4, 256, fake[3], fake[4], 20000, 1, 1,
+                                        None, fake[5], fake[6], fake[7], None)
+    assert rc != 0 and b'launch failed' in L.curious_last_error()
