@@ -29,8 +29,11 @@ from curious_amd.util import import_function, store_args, transitions_in_episode
 
 ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
 CHAIN = 10              # updates per chained hipGraph launch in train_batches (even: the staging tensors alternate)
-LONG_CHAIN = 50         # single-rank path: a longer chain when that many updates are due (a graph launch leaves the GPU
-                        # idle for ~5 us; at 48 us per update that is 1 % per 10-update chain)
+LONG_CHAIN = 50         # batched experts: a longer chain when that many updates are due
+MAX_CHAIN = 100         # single-rank path: train_batches(n) replays ONE graph of min(n, 100) (even) updates -- every graph
+                        # launch leaves the GPU idle for ~5 us and its first update rebuilds the transposed weight copies
+                        # (3.6 us); the reference's n_batches = 40 is one launch instead of four
+MAX_CHAIN_GRAPHS = 4    # distinct chain lengths kept captured; further lengths fall back to chains of CHAIN
 # hipStreamCaptureModeThreadLocal: HIP calls of OTHER threads (the RCCL watchdog polling events) must not invalidate a
 # capture that only this thread's launches take part in
 CAPTURE_MODE = 'thread_local'
@@ -97,6 +100,7 @@ class DDPG(object):
         self._pp = None                                              # the two staging tensors of the device loop
         self._cur = 0
         self._graph = self._graph_b = self._graph_ba = self._graph_chain = self._graph_long = None
+        self._chains = None                                          # single rank: {length: graph of that many updates}
         self._graphs = [None, None]
         self._tables_dirty = True
         self._batch_stale = True
@@ -945,7 +949,12 @@ class DDPG(object):
             k = 1
             chainable = not dist.is_distributed() or (self._graph_allreduce() and self.Q_adam.t % CHAIN == 0)
             if self._device_loop() and self.use_graph and chainable and n >= CHAIN and self._cur == 0:
-                k = LONG_CHAIN if (n >= LONG_CHAIN and not dist.is_distributed()) else CHAIN
+                k = CHAIN
+                if not dist.is_distributed():
+                    want = min(n, MAX_CHAIN) & ~1
+                    chains = getattr(self, '_chains', None) or {}
+                    if want in chains or len(chains) < MAX_CHAIN_GRAPHS:
+                        k = want
             out = self._train_device(k) if self._device_loop() else self.train()
             n -= k
         return out
@@ -1036,18 +1045,13 @@ class DDPG(object):
                     self._batch_stale = True
                 graph = self._graphs[self._cur]
             else:
-                assert k in (CHAIN, LONG_CHAIN) and k % 2 == 0 and self._cur == 0
-                if k == CHAIN:
-                    if self._graph_chain is None:
-                        self._graph_chain = self._capture(lambda: [self._update_fused(i & 1, i > 0) for i in range(CHAIN)])
-                        self._batch_stale = True
-                    graph = self._graph_chain
-                else:
-                    if getattr(self, '_graph_long', None) is None:
-                        self._graph_long = self._capture(
-                            lambda: [self._update_fused(i & 1, i > 0) for i in range(LONG_CHAIN)])
-                        self._batch_stale = True
-                    graph = self._graph_long
+                assert CHAIN <= k <= MAX_CHAIN and k % 2 == 0 and self._cur == 0
+                if getattr(self, '_chains', None) is None:
+                    self._chains = {}
+                if k not in self._chains:
+                    self._chains[k] = self._capture(lambda: [self._update_fused(i & 1, i > 0) for i in range(k)])
+                    self._batch_stale = True
+                graph = self._chains[k]
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False

@@ -241,6 +241,7 @@ def shutdown(policies, expert_bank=None):
     for p in policies:
         p.finish_sync_checks()
         p._graph = p._graph_b = p._graph_ba = p._graph_chain = p._graph_long = None
+        p._chains = None
         p._graphs = [None, None]
         p._roll_graphs = {}
     if expert_bank is not None:

@@ -206,12 +206,12 @@ def test_device_rng_graph_equals_eager_and_learns():
         if first is None:
             first = float(le)
     # 7 single-update graphs (leaves the staging parity odd), then train_batches: one more single update to get back to
-    # parity 0, two chained graphs of CHAIN updates, two singles
+    # parity 0, then ONE chained graph of the 22 remaining updates
     for k in range(7):
         a_graph.train()
     lg, _ = a_graph.train_batches(23)
     torch.cuda.synchronize()
-    assert a_graph._graph_chain is not None and all(g is not None for g in a_graph._graphs)
+    assert list(a_graph._chains) == [22] and all(g is not None for g in a_graph._graphs)
     assert torch.equal(a_graph.theta, a_eager.theta)
     assert torch.equal(a_graph._m, a_eager._m) and torch.equal(a_graph._v, a_eager._v)
     assert torch.equal(a_graph._staged, a_eager._staged)             # the batch of update 31 is already staged
