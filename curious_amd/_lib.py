@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 4          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 5          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -69,7 +69,8 @@ class AdamState(C.Structure):
 
 
 class Transposed(C.Structure):
-    _fields_ = [('n', C.c_int32), ('dim', C.c_int32), ('src_off', C.c_int64 * 8), ('dst', C.c_void_p * 8)]
+    _fields_ = [('n', C.c_int32), ('dim', C.c_int32), ('src_off', C.c_int64 * 8), ('dst', C.c_void_p * 8),
+                ('fault', C.c_void_p)]
 
 
 class NextBatch(C.Structure):
@@ -95,6 +96,10 @@ PROTOTYPES = {
     'curious_prof_kernel_count': (C.c_int, []),
     'curious_prof_kernel_name': (C.c_char_p, [C.c_int]),
     'curious_prof_collect': (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    'curious_prof_launch_counts': (C.c_int, [C.POINTER(C.c_int64)]),
+    'curious_set_option': (C.c_int, [C.c_char_p, _I64]),
+    'curious_get_option': (_I64, [C.c_char_p]),
+    'curious_workspace_fault_offset': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
                                      C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
                                      _P]),
@@ -104,7 +109,8 @@ PROTOTYPES = {
     'curious_norm_scratch_doubles': (_I64, [_I32, _I32]),
     'curious_norm_recompute': (C.c_int, [_P, _P, _I32, _F, _F, _P]),
     'curious_norm_pair_scratch_doubles': (_I64, [_I32, _I32, _I32]),
-    'curious_norm_update_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F, _F, _P, _P]),
+    'curious_norm_update_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F, _F, _P, _P,
+                                           _P]),
     'curious_param_count_Q': (_I64, [C.POINTER(NetCfg)]),
     'curious_param_count_pi': (_I64, [C.POINTER(NetCfg)]),
     'curious_param_offset_pi': (_I64, [C.POINTER(NetCfg)]),
@@ -140,7 +146,7 @@ PROTOTYPES = {
     'curious_store_slots_host': (C.c_int, [_U64, _U64, _I32, _I64, _I32, _P, _P]),
     'curious_counter_add': (C.c_int, [_P, _I64, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,
-                                    _P, _P]),
+                                    _P, _P, _P]),
     'curious_env_step': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _I32, _I32, _P,
                                    _P, _P, _P, _P, _I32, _I32, _D, _P, _P]),
 }

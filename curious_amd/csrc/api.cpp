@@ -65,10 +65,62 @@ void curious_prof_push(int kid, hipStream_t st, bool start) {
 
 static const char* k_names[CK_COUNT] = {
     "her_sample_kernel", "store_episodes_kernel", "episode_activity_kernel", "norm_partial_kernel",
-    "norm_final_kernel", "norm_recompute_kernel", "fwd_l0_kernel", "fwd_hot_kernel", "dx_hot_kernel", "dw_all_kernel",
-    "dw_kernel", "head_fwd_kernel",
-    "dx_crit_kernel", "dx_actor_kernel", "adam_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel",
-    "env_step_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel", "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel"};
+    "norm_final_kernel", "norm_recompute_kernel", "norm_pair_partial_kernel", "norm_pair_final_kernel",
+    "fwd_l0_kernel", "fwd_layer_kernel", "fwd_hot_kernel", "dx_hot_kernel", "dx_kernel", "dw_all_kernel", "dw_kernel",
+    "head_fwd_kernel", "dx_crit_kernel", "critic_head_kernel", "dx_actor_kernel", "actor_dz_kernel", "adam_kernel",
+    "adam_her_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel", "env_step_kernel",
+    "counter_add_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel",
+    "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel"};
+int64_t g_curious_launches[CK_COUNT] = {0};
+
+// launches per kernel id since the library was loaded (counted whether or not event timing is enabled, also during
+// hipGraph capture -- a captured launch counts once, its replays do not)
+extern "C" int curious_prof_launch_counts(int64_t* counts_host) {
+  CURIOUS_CHECK(counts_host, "curious_prof_launch_counts: NULL argument");
+  for (int k = 0; k < CK_COUNT; ++k) counts_host[k] = g_curious_launches[k];
+  return 0;
+}
+
+// ------------------------------------------------------------------ run-time options
+#include <stdlib.h>
+CuriousOptions& curious_options() {
+  static CuriousOptions o;
+  static bool init = false;
+  if (!init) {
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    o.rows = env_int("CURIOUS_ROWS", 1) != 0;
+    o.rows_xcd = env_int("CURIOUS_ROWS_XCD", 1) != 0;
+    o.xcd_map = env_int("CURIOUS_XCD_MAP", 0);
+    if (o.xcd_map != 4 && o.xcd_map != 8) o.xcd_map = 0;
+    o.fault_inject = 0;
+    o.qt_spins = 1 << 22;
+    init = true;
+  }
+  return o;
+}
+static int* option_slot(const char* name) {
+  CuriousOptions& o = curious_options();
+  if (!name) return nullptr;
+  if (!strcmp(name, "rows")) return &o.rows;
+  if (!strcmp(name, "rows_xcd")) return &o.rows_xcd;
+  if (!strcmp(name, "xcd_map")) return &o.xcd_map;
+  if (!strcmp(name, "fault_inject")) return &o.fault_inject;
+  if (!strcmp(name, "qt_spins")) return &o.qt_spins;
+  return nullptr;
+}
+extern "C" int curious_set_option(const char* name, int64_t value) {
+  int* s = option_slot(name);
+  CURIOUS_CHECK(s, "curious_set_option: unknown option '%s'", name ? name : "(null)");
+  if (s == &curious_options().xcd_map) CURIOUS_CHECK(value == 0 || value == 4 || value == 8, "xcd_map must be 0, 4 or 8");
+  if (s == &curious_options().qt_spins) CURIOUS_CHECK(value >= 1 && value <= (1 << 30), "qt_spins out of range");
+  *s = (int)value;
+  return 0;
+}
+extern "C" int64_t curious_get_option(const char* name) {
+  int* s = option_slot(name);
+  if (!s) { curious_set_error("curious_get_option: unknown option '%s'", name ? name : "(null)"); return -1; }
+  return *s;
+}
 
 extern "C" int curious_prof_kernel_count(void) { return CK_COUNT; }
 extern "C" const char* curious_prof_kernel_name(int kid) { return (kid >= 0 && kid < CK_COUNT) ? k_names[kid] : ""; }

@@ -71,14 +71,34 @@ static inline hipStream_t as_stream(curious_stream_t s) { return (hipStream_t)s;
 
 // ---------------------------------------------------------------- per-kernel HIP-event timing (bench.py roofline)
 enum {
-  CK_HER_SAMPLE = 0, CK_STORE, CK_ACTIVITY, CK_NORM_PARTIAL, CK_NORM_FINAL, CK_NORM_RECOMPUTE, CK_FWD_LAYER0,
-  CK_FWD_LAYER, CK_DX, CK_DW, CK_DW_SMALL, CK_HEAD_FWD, CK_CRITIC_HEAD, CK_ACTOR_DZ, CK_ADAM, CK_POLYAK, CK_CHECKSUM, CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS, CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_COUNT
+  CK_HER_SAMPLE = 0, CK_STORE, CK_ACTIVITY, CK_NORM_PARTIAL, CK_NORM_FINAL, CK_NORM_RECOMPUTE, CK_NORM_PAIR_PARTIAL,
+  CK_NORM_PAIR_FINAL, CK_FWD_LAYER0, CK_FWD_GENERIC, CK_FWD_LAYER, CK_DX, CK_DX_GENERIC, CK_DW, CK_DW_SMALL, CK_HEAD_FWD,
+  CK_CRITIC_HEAD, CK_CRITIC_HEAD_GENERIC, CK_ACTOR_DZ, CK_ACTOR_DZ_GENERIC, CK_ADAM, CK_ADAM_HER, CK_POLYAK, CK_CHECKSUM,
+  CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_COUNTER_ADD, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS,
+  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_COUNT
 };
 extern int g_curious_prof_on;
+
+// ---------------------------------------------------------------- run-time options (curious_set_option)
+struct CuriousOptions {
+  int rows;            // 1: row-local routes (mlp_rows.h, mlp_rows_act.h); 0: tiled multi-launch routes      [CURIOUS_ROWS]
+  int rows_xcd;        // 1: kinds of ddpg_rows_kernel placed by XCD; 0: plain block-id order                 [CURIOUS_ROWS_XCD]
+  int xcd_map;         // 0 / 4 / 8: XCD-aware block placement of fwd_hot / dx_hot (tiled route)              [CURIOUS_XCD_MAP]
+  int fault_inject;    // > 0: the target group of row group (fault_inject - 1) never publishes Q' (tests)
+  int qt_spins;        // polls before a consumer of Q' gives up
+};
+CuriousOptions& curious_options();
+
 void curious_prof_push(int kid, hipStream_t st, bool start);
 // Brackets ONE kernel launch with a pair of events recorded on the launch stream (no-op unless profiling is on).
+// Every launch is also counted per kernel id (curious_prof_launch_counts: the GPU test session asserts that no kernel of
+// the library went unexercised).
+extern int64_t g_curious_launches[];
 struct ProfScope {
   int kid; hipStream_t st; bool on;
-  ProfScope(int k, hipStream_t s) : kid(k), st(s), on(g_curious_prof_on != 0) { if (on) curious_prof_push(kid, st, true); }
+  ProfScope(int k, hipStream_t s) : kid(k), st(s), on(g_curious_prof_on != 0) {
+    ++g_curious_launches[kid];
+    if (on) curious_prof_push(kid, st, true);
+  }
   ~ProfScope() { if (on) curious_prof_push(kid, st, false); }
 };

@@ -10,9 +10,10 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
                                  int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
                                  const float* __restrict__ goals_raw, int32_t n, float* __restrict__ o,
                                  float* __restrict__ ag, float* __restrict__ g, float* __restrict__ td,
-                                 float* __restrict__ staging) {
+                                 float* __restrict__ staging, float* __restrict__ flags) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
+  if (flags && e == 0) flags[n] = 0.0f;                     // the NaN word of the coming rollout (env_body.h)
   const int AG = 3 * E.ntasks;
   float* oe = o + (int64_t)e * E.dimo;
   float* row0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
@@ -44,16 +45,17 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
 
 extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                                  int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
-                                 float* o, float* ag, float* g, float* td, float* staging,
+                                 float* o, float* ag, float* g, float* td, float* staging, float* flags,
                                  curious_stream_t stream) {
   CURIOUS_CHECK(E && L && episode && tasks && goals_raw && o && ag && g && td && staging,
                 "curious_env_reset: NULL argument");
+  CURIOUS_CHECK(E->dimo <= 128, "curious_env_reset: the synthetic env handles observations of at most 128 floats");
   CURIOUS_CHECK(L->dimo == E->dimo && L->dimag == 3 * E->ntasks && L->dimg == 3 * E->ntasks &&
                     L->dimtd == E->ntasks && L->dimu == 4 && E->dimo >= 3 * E->ntasks + 4,
                 "curious_env_reset: layout does not match the synthetic env");
   if (n <= 0) return 0;
   { ProfScope ps__(CK_ENV_RESET, as_stream(stream)); hipLaunchKernelGGL(env_reset_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
-                     tasks, goals_raw, n, o, ag, g, td, staging); }
+                     tasks, goals_raw, n, o, ag, g, td, staging, flags); }
   CURIOUS_LAUNCH_CHECK("env_reset_kernel");
   return 0;
 }
@@ -79,6 +81,7 @@ extern "C" int curious_env_step(const curious_env_cfg_t* E, const curious_layout
                                 curious_stream_t stream) {
   CURIOUS_CHECK(E && L && episode && tasks && u && o && ag && g && td && staging, "curious_env_step: NULL argument");
   CURIOUS_CHECK(t >= 0 && t < L->T, "curious_env_step: t out of range");
+  CURIOUS_CHECK(E->dimo <= 128, "curious_env_step: the synthetic env handles observations of at most 128 floats");
   if (n <= 0) return 0;
   { ProfScope ps__(CK_ENV_STEP, as_stream(stream)); hipLaunchKernelGGL(env_step_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), *E, *L, env_id0, episode,
                      tasks, u, ldu, t, n, o, ag, g, td, staging, off_change, off_success, reward_eps, flags); }
@@ -91,7 +94,8 @@ __global__ void counter_add_kernel(int64_t* p, int64_t delta) { *p += delta; }
 
 extern "C" int curious_counter_add(int64_t* p, int64_t delta, curious_stream_t stream) {
   CURIOUS_CHECK(p, "curious_counter_add: NULL argument");
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), p, delta);
+  { ProfScope ps__(CK_COUNTER_ADD, as_stream(stream));
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), p, delta); }
   CURIOUS_LAUNCH_CHECK("counter_add_kernel");
   return 0;
 }

@@ -113,10 +113,10 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
   const float succ = (sqrt(d2) > reward_eps) ? 0.0f : 1.0f;
   if (lane == 0) row[off_success] = succ;
   // rollout flags (rollout.py:268-271,306): flags[e] = is_success of the final step, flags[n] = 1 when an observation
-  // of any env ended up NaN.  flags[n] is cleared by env 0 at t = 0 and only set (to the same value) at t = T - 1 --
-  // different launches of one stream (or program order inside the multi-step kernel), no ordering problem.
+  // of any env ended up NaN.  flags[n] is cleared by curious_env_reset -- a launch in front of the rollout: inside the
+  // multi-step kernel env 0's workgroup may well run after another workgroup has finished all its steps -- and only set
+  // (every writer stores the same value) at t = T - 1.
   if (flags) {
-    if (t == 0 && e == 0 && lane == 0) flags[n] = 0.0f;
     if (t == L.T - 1) {
       const bool bad = __any((i < E.dimo) && (nv != nv));
       if (lane == 0) {

@@ -102,8 +102,9 @@ struct Ws {   // workspace carve-up
   float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
   float* part[6];              // dot-epilogue partials [4 tiles][B][<=4]: pi_target, pi, Q, Q_target, Q_pi, dz
   float* qt;                   // hand-off words of the row-local pass (mlp_rows.h): [B] x 64 bit
-  float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h);
-                               // the ONLY part of the workspace that carries state from one update call to the next
+  float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h)
+  int32_t* fault;              // fault word (mlp_rows.h): consumers of Q' that gave up; sticky until the host clears it.
+                               // wT and fault are the ONLY parts of the workspace that carry state between calls
   int64_t total;
 };
 
@@ -131,6 +132,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.qt = take(2 * (int64_t)B);
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l < c->layers; ++l) w.wT[net][l] = (l >= 1) ? take((int64_t)c->hidden * c->hidden) : nullptr;
+  w.fault = reinterpret_cast<int32_t*>(take(64));
   w.total = off;
   return w;
 }
@@ -138,6 +140,11 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
 extern "C" int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B) {
   if (!cfg || B <= 0) return 0;
   return carve(cfg, B, nullptr).total;
+}
+extern "C" int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, int32_t B) {
+  if (!cfg || B <= 0) return -1;
+  static float dummy[1];
+  return (int64_t)(reinterpret_cast<float*>(carve(cfg, B, dummy).fault) - dummy);
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -147,8 +154,9 @@ extern "C" int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, 
   CURIOUS_CHECK(cfg && workspace && out && B > 0, "curious_ddpg_transposed: bad argument");
   if (check_cfg(cfg)) return -1;
   memset(out, 0, sizeof(*out));
-  if (cfg->hidden != 256 || cfg->layers < 2 || 2 * (cfg->layers - 1) > 8) return 0;    // nothing is kept for this shape
   const Ws w = carve(cfg, B, workspace);
+  out->fault = w.fault;
+  if (cfg->hidden != 256 || cfg->layers < 2 || 2 * (cfg->layers - 1) > 8) return 0;    // nothing is kept for this shape
   const NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
   out->dim = cfg->hidden;
   for (int l = 1; l < cfg->layers; ++l) { out->src_off[out->n] = offQ.W[l]; out->dst[out->n++] = w.wT[0][l]; }
@@ -236,15 +244,7 @@ static bool hot_ok(int M, int N, int K) { return (M % 16 == 0) && (N % 64 == 0) 
 
 // XCD-aware block placement of the 256 x 256 hidden-layer launches (mlp_lean_gemm.h tile_ids): rows-per-unit 0 (plain
 // grid), 4 or 8; CURIOUS_XCD_MAP overrides the default for A/B measurements.
-static int xcd_rows() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CURIOUS_XCD_MAP");
-    v = e ? atoi(e) : 0;
-    if (v != 4 && v != 8) v = 0;
-  }
-  return v;
-}
+static int xcd_rows() { return curious_options().xcd_map; }
 template <int XR> static dim3 xcd_grid(int nprob) { return dim3(8, 4 * XR, (nprob * (16 / XR) + 7) / 8); }
 
 // Batched experts (mlp_common.h "Ex"): nex agents per launch, slabs `stride` floats apart.
@@ -396,7 +396,7 @@ static int forward_chains(const curious_net_cfg_t* c, Chain* ch, int nch, int M,
       }
     }
     dim3 grid((H + 63) / 64, (M + 15) / 16, nch);
-    { ProfScope ps__(CK_FWD_LAYER0, st); hipLaunchKernelGGL(fwd_layer_kernel, grid, dim3(256), 0, st, a); }
+    { ProfScope ps__(CK_FWD_GENERIC, st); hipLaunchKernelGGL(fwd_layer_kernel, grid, dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("fwd_layer_kernel");
   }
   return 0;
@@ -417,16 +417,10 @@ static HeadFwdProb head_prob(const float* h, int H, const float* W, const float*
   return p;
 }
 
-// The row-local routes (mlp_rows.h, mlp_rows_act.h).  CURIOUS_ROWS=0 keeps the tiled multi-launch routes (A/B
-// measurements, and the reference point of parity checks between the two).
-static bool rows_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CURIOUS_ROWS");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0;
-}
+// The row-local routes (mlp_rows.h, mlp_rows_act.h).  Option "rows" = 0 (curious_set_option; initial value from
+// CURIOUS_ROWS) keeps the tiled multi-launch routes: A/B measurements, the reference point of the parity checks between
+// the two, and the route of shapes the row-local kernels refuse.  Read per call, so one process can run both.
+static bool rows_enabled() { return curious_options().rows != 0; }
 
 static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
   RowsNet n;
@@ -535,6 +529,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   CURIOUS_CHECK(cfg->dimu == 4 && L->dimu == 4 && cfg->dimo == E->dimo && cfg->dimtd == E->ntasks &&
                     cfg->dimg == 3 * E->ntasks, "curious_policy_act_env_step: network / env dimensions differ");
   CURIOUS_CHECK(t >= 0 && nsteps >= 1 && t + nsteps <= L->T, "curious_policy_act_env_step: t out of range");
+  CURIOUS_CHECK(E->dimo <= 128, "curious_policy_act_env_step: the synthetic env handles observations of at most 128 floats");
   if (n <= 0) return 0;
   hipStream_t st = as_stream(stream);
   Ws w = carve(cfg, n, workspace);
@@ -700,8 +695,13 @@ bool DdpgPass::rows_route() const {
 // The backward layers of the row-local pass run on transposed copies of the main networks' hidden matrices (workspace
 // w.wT).  The fused optimiser tail on the lean weight-gradient tiles keeps them current (weight_grads checks that it
 // really ran); on every other route they are rebuilt from the parameters at the head of the pass.
+// (the same conditions under which weight_grads() takes the fused dw_adam_her launch: lean tiles for at most 4 hidden
+//  matrices -- with 4 layers per network the generic gradient launch + the stand-alone optimiser run, which do not
+//  write the copies)
 bool DdpgPass::keeps_copies(const UpdateTail* tail) const {
-  return tail && (B % 256 == 0) && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64);
+  const bool dx_ok = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
+  return tail && dx_ok && (B % 256 == 0) && (nl - 1) <= 4 && 2 * (nl - 1) <= 4 && !cfg->normalize_obs &&
+         (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64);
 }
 
 int DdpgPass::rows_pass(bool refresh, bool maintained) {
@@ -733,11 +733,9 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
   a.qt = reinterpret_cast<unsigned long long*>(w.qt);
   a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
-  {
-    static int xm = -1;                                      // CURIOUS_ROWS_XCD=0: the plain block-id order (A/B)
-    if (xm < 0) { const char* e = getenv("CURIOUS_ROWS_XCD"); xm = (e && atoi(e) == 0) ? 0 : 1; }
-    a.xmap = (xm && xd.nex == 1) ? 1 : 0;                    // batched experts fill the chip several times over: plain order
-  }
+  // option "rows_xcd" = 0: the plain block-id order (A/B); batched experts fill the chip several times over: plain order
+  a.xmap = (curious_options().rows_xcd && xd.nex == 1) ? 1 : 0;
+  a.fault = w.fault; a.inject = curious_options().fault_inject; a.spins = curious_options().qt_spins;
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
@@ -885,7 +883,7 @@ int DdpgPass::critic_backward() {
     a.max_u = cfg->max_u;
     a.dc2 = w.dact[0][nl - 1]; a.dd2 = w.dact[1][nl - 1]; a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi;
     a.step_ctr = step_ctr;
-    { ProfScope ps__(CK_CRITIC_HEAD, st);
+    { ProfScope ps__(CK_CRITIC_HEAD_GENERIC, st);
       hipLaunchKernelGGL(critic_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("critic_head_kernel");
   }
@@ -934,7 +932,7 @@ int DdpgPass::critic_backward() {
       p.fast = p.vec && aligned16(p.dY) && H >= 4;
     }
     dim3 grid((H + 63) / 64, (B + 15) / 16, 2);
-    { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
+    { ProfScope ps__(CK_DX_GENERIC, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel");
   }
   return 0;
@@ -971,7 +969,7 @@ int DdpgPass::actor_backward() {
     a.a2 = w.act[2][nl - 1]; a.WoutPi = thPi + offPi.Wout; a.dz = w.dz; a.da2 = w.dact[2][nl - 1];
     a.B = B; a.H = H; a.U = U; a.max_u = cfg->max_u;
     a.l2c = l2c;
-    { ProfScope ps__(CK_ACTOR_DZ, st);
+    { ProfScope ps__(CK_ACTOR_DZ_GENERIC, st);
       hipLaunchKernelGGL(actor_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a); }
     CURIOUS_LAUNCH_CHECK("actor_dz_kernel");
   }
@@ -1002,7 +1000,7 @@ int DdpgPass::actor_backward() {
     p.M = B; p.N = H; p.K = H; p.vec = aligned16(p.W) ? 1 : 0;
     p.fast = p.vec && aligned16(p.dY) && H >= 4;
     dim3 grid((H + 63) / 64, (B + 15) / 16, 1);
-    { ProfScope ps__(CK_DX, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
+    { ProfScope ps__(CK_DX_GENERIC, st); hipLaunchKernelGGL(dx_kernel, grid, dim3(256), 0, st, da); }
     CURIOUS_LAUNCH_CHECK("dx_kernel(actor)");
   }
   return 0;
@@ -1125,17 +1123,20 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     const curious_adam_state_t* a = tail->st;
     const float ah[2] = {a->alpha_Q, a->alpha_pi};
     const int64_t n_Q = pi_offset(cfg);
+    curious_transposed_t kp;                                 // no copies kept on this route; the fault word still guards
+    memset(&kp, 0, sizeof(kp));
+    kp.fault = w.fault;
     if (tail->her) {
       const curious_next_batch_t* nx = tail->next;
       return curious_adam_update_and_sample(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi,
                                             a->alpha_tab, step_ctr, a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah,
                                             a->beta1, a->one_minus_beta1, a->beta2, a->one_minus_beta2, a->epsilon,
                                             nx->storage, nx->buf_stride, nx->L, nx->tasks, nx->P, nx->rng, B, nx->batch,
-                                            BL, nullptr, (curious_stream_t)st);
+                                            BL, &kp, (curious_stream_t)st);
     }
     return curious_adam_update(const_cast<float*>(theta_main), a->m, a->v, grad, n_Q, tail->n_pi, a->alpha_tab, step_ctr,
                                a->tab_base, a->tab_len, a->alpha_tab ? nullptr : ah, a->beta1, a->one_minus_beta1,
-                               a->beta2, a->one_minus_beta2, a->epsilon, nullptr, (curious_stream_t)st);
+                               a->beta2, a->one_minus_beta2, a->epsilon, &kp, (curious_stream_t)st);
   }
   return 0;
 }
@@ -1193,6 +1194,7 @@ static int ddpg_update_impl(const curious_net_cfg_t* cfg, float* theta_main, con
   A.a_Q = adam->alpha_Q; A.a_pi = adam->alpha_pi;
   A.b1 = adam->beta1; A.omb1 = adam->one_minus_beta1; A.b2 = adam->beta2; A.omb2 = adam->one_minus_beta2;
   A.eps = adam->epsilon;
+  A.fault = carve(cfg, B, workspace).fault;
   if (next) {
     CURIOUS_CHECK(next->batch && next->batch != batch, "curious_ddpg_update: the next batch needs its own staging buffer");
     if (her_fill_args(t.h, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,

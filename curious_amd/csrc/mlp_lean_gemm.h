@@ -12,7 +12,11 @@ struct AdamFuse {
   int64_t n_Q;
   const float* alpha_tab; const int64_t* step_ctr; int64_t tab_base; int32_t tab_len;
   float a_Q, a_pi, b1, omb1, b2, omb2, eps;
+  const int32_t* fault;           // fault word of the gradient workspace (mlp_rows.h) or NULL: non-zero = skip the optimiser
 };
+__device__ inline bool adam_faulted(const AdamFuse& A, int64_t eo) {
+  return A.fault && *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(A.fault) + eo) != 0;
+}
 
 // eo: slab offset of the expert this block works for (0 for a single agent); i / pidx / bidx below are indices into
 // the parameter vector, the moments and the parameters are addressed at index + eo
@@ -238,7 +242,9 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
   AdamPre4 pre;
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  bool faulted = false;
   if (ADAM) {
+    faulted = adam_faulted(A, eo);
     adam_alphas(A, aQ, aPi, eo);
     pre = adam_prefetch4(A, pidx + eo);
     if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
@@ -270,7 +276,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   *reinterpret_cast<f32x4*>(dst) = v;
-  if (ADAM) {
+  if (ADAM && !faulted) {
     adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
     // transposed copy of the updated tile for the row-local backward layers (mlp_rows.h): WT[n][k] = W[k][n]
     if (P.dot_out) {
@@ -289,7 +295,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
       P.aux_out[eo + n0 + tid] = gb;
-      if (ADAM) {
+      if (ADAM && !faulted) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
         A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
       }
@@ -334,7 +340,9 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
   AdamPre4 pre;
   pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
+  bool faulted = false;
   if (ADAM) {
+    faulted = adam_faulted(A, eo);
     adam_alphas(A, aQ, aPi, eo);
     if (YV) {
       pre = adam_prefetch4(A, (own ? pidx : 0) + eo);
@@ -389,10 +397,10 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
     const float na = (pidx < A.n_Q) ? -aQ : -aPi;
     if (YV) {
       *reinterpret_cast<f32x4*>(dst) = v;
-      if (ADAM) adam_apply4(A, na, pidx + eo, v, pre);
+      if (ADAM && !faulted) adam_apply4(A, na, pidx + eo, v, pre);
     } else {
       dst[0] = v[0];                                        // N == 1 (gcol == 0)
-      if (ADAM) {
+      if (ADAM && !faulted) {
         float m = pre.m[0], vv = pre.v[0];
         const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
         A.m[pidx + eo] = m; A.v[pidx + eo] = vv; A.theta[pidx + eo] = th;
@@ -408,7 +416,7 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
       P.db[eo + n0 + tid] = gb;
-      if (ADAM) {
+      if (ADAM && !faulted) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
         A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
       }
@@ -463,6 +471,7 @@ struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
 __global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   AdamFuse none;
+  none.fault = nullptr;
   if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red, 0);
   else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red, 0);
 }

@@ -58,13 +58,21 @@ struct RowsArgs {
   int32_t B, nl, dimo, dimtd, dimg, xmap;
   float gamma, clip_lo, clip_hi, max_u, l2c;
   unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [3][32] s_memtime stamps of row group 0, else NULL
+  int32_t* fault;                 // fault word of the workspace: incremented by every consumer wave that gave up on Q';
+                                  // the optimiser that follows leaves theta / m / v / the copies alone while it is set
+  int32_t inject, spins;          // inject > 0 (tests): the target group of row group inject - 1 never publishes;
+                                  // spins: polls before a consumer gives up
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
     if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[kind * 32 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
 #define ROWS_QT_TAG 0x51C0FFEEull
-#define ROWS_QT_SPINS (1 << 22)   // polls before a consumer gives up (~ seconds): the loss turns NaN instead of a hang
+// A consumer that has polled RowsArgs.spins times (default 2^22, ~ seconds) gives up: the loss turns NaN instead of a
+// hang, and the fault word of the workspace is incremented -- dw_adam_her_kernel / adam_kernel / adam_her_kernel then skip
+// the optimiser (theta, m, v and the transposed copies stay as they were) until the host has read and cleared the word
+// (DDPG.check_faults raises).  HIP does not promise block-id dispatch order, which is what makes the producers start
+// before their consumers: the guard turns a violated assumption into an error instead of silently poisoned parameters.
 
 #ifdef ROWS_DEBUG           // tools/rows_lab.hip: fine-grained stamps inside the layer routines
 #define ROWS_DBG(x) do { if ((x).dbg && (x).tid == 0) *(x).dbg++ = __builtin_readcyclecounter(); } while (0)
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
     const float Qt = rows_head1(x, wq_t) + bq_t;                                           // ddpg.py:427-431
-    if (x.lane == 0)
+    if (x.lane == 0 && !(a.inject > 0 && rgrp == a.inject - 1))
       __hip_atomic_store(qt, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     ROWS_STAMP(6);
@@ -413,14 +421,19 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
       // Q' of this wave's row from the target group (every lane polls the same word: one request per poll)
       unsigned long long word = 0;
       int spins = 0;
+      const int max_spins = a.spins > 0 ? a.spins : (1 << 22);
       for (;;) {
         word = __hip_atomic_load(qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((word >> 32) == ROWS_QT_TAG || ++spins > ROWS_QT_SPINS) break;
+        if ((word >> 32) == ROWS_QT_TAG || ++spins > max_spins) break;
         __builtin_amdgcn_s_sleep(1);
       }
       ROWS_STAMP(4);
-      const float Qt = ((word >> 32) == ROWS_QT_TAG) ? __uint_as_float((unsigned)(word & 0xffffffffull)) : NAN;
-      if (x.lane == 0) __hip_atomic_store(qt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed
+      const bool got = (word >> 32) == ROWS_QT_TAG;
+      const float Qt = got ? __uint_as_float((unsigned)(word & 0xffffffffull)) : NAN;
+      if (x.lane == 0) {
+        __hip_atomic_store(qt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // consumed
+        if (!got && a.fault) atomicAdd(reinterpret_cast<int32_t*>(reinterpret_cast<float*>(a.fault) + eo), 1);
+      }
       const float target = fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi);                // ddpg.py:437-438
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant

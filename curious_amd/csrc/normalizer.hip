@@ -211,7 +211,8 @@ __global__ __launch_bounds__(1024) void norm_pair_final_kernel(const double* __r
                                                               int32_t dim_a, int32_t dim_b, int32_t n_rows,
                                                               float* __restrict__ acc_a, float* __restrict__ acc_b,
                                                               float* __restrict__ state_a, float* __restrict__ state_b,
-                                                              float eps_a, float eps_b) {
+                                                              float eps_a, float eps_b, const float* __restrict__ skip) {
+  if (skip && *skip != 0.0f) return;                        // a NaN rollout (rollout.py:268-271) feeds no statistics
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ncol = dim_a + dim_b;
   for (int c = wave; c < 2 * ncol; c += 16) {
@@ -255,7 +256,7 @@ extern "C" int64_t curious_norm_pair_scratch_doubles(int32_t n_rows, int32_t dim
 
 extern "C" int curious_norm_update_pair(const float* rows, int32_t n_rows, int32_t stride, int32_t off_a, int32_t dim_a,
                                         int32_t off_b, int32_t dim_b, float* acc_a, float* acc_b, float* state_a,
-                                        float* state_b, float eps_a, float eps_b, double* scratch,
+                                        float* state_b, float eps_a, float eps_b, double* scratch, const float* skip,
                                         curious_stream_t stream) {
   CURIOUS_CHECK(rows && acc_a && acc_b && scratch, "curious_norm_update_pair: NULL argument");
   CURIOUS_CHECK((state_a == nullptr) == (state_b == nullptr), "curious_norm_update_pair: both states or none");
@@ -264,13 +265,13 @@ extern "C" int curious_norm_update_pair(const float* rows, int32_t n_rows, int32
   int cp = 1;
   while (cp < dim_a + dim_b) cp <<= 1;
   const int nb = (n_rows + NP_ROWS - 1) / NP_ROWS;
-  { ProfScope ps__(CK_NORM_PARTIAL, as_stream(stream));
+  { ProfScope ps__(CK_NORM_PAIR_PARTIAL, as_stream(stream));
     hipLaunchKernelGGL(norm_pair_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), rows, n_rows, stride, off_a,
                        dim_a, off_b, dim_b, cp, nb, scratch); }
   CURIOUS_LAUNCH_CHECK("norm_pair_partial_kernel");
-  { ProfScope ps__(CK_NORM_FINAL, as_stream(stream));
+  { ProfScope ps__(CK_NORM_PAIR_FINAL, as_stream(stream));
     hipLaunchKernelGGL(norm_pair_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scratch, nb, dim_a, dim_b,
-                       n_rows, acc_a, acc_b, state_a, state_b, eps_a, eps_b); }
+                       n_rows, acc_a, acc_b, state_a, state_b, eps_a, eps_b, skip); }
   CURIOUS_LAUNCH_CHECK("norm_pair_final_kernel");
   return 0;
 }

@@ -19,8 +19,11 @@ struct AdamArgs {
   int32_t tab_len;
   float a_Q, a_pi;
   float b1, omb1, b2, omb2, eps;
-  curious_transposed_t keep;      // square matrices whose transposed copies are kept current (keep.n == 0: none)
+  curious_transposed_t keep;      // square matrices whose transposed copies are kept current (keep.n == 0: none);
+                                  // keep.fault: fault word of the gradient workspace (non-zero = the launch leaves
+                                  // theta / m / v / the copies alone) or NULL
 };
+__device__ __forceinline__ bool adam_faulted(const AdamArgs& a) { return a.keep.fault && *a.keep.fault != 0; }
 
 __device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi) {
   aQ = a.a_Q; aPi = a.a_pi;
@@ -49,6 +52,7 @@ __device__ __forceinline__ void adam_one(const AdamArgs& a, const int64_t i, con
 }
 
 __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks) {
+  if (adam_faulted(a)) return;
   float aQ, aPi;
   adam_alphas(a, aQ, aPi);
   const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
@@ -64,6 +68,7 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
 // 64 x 64 tile made these 64 blocks the long pole of the launch, +3 us.)
 #define ADAM_TILE 32
 __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1]) {
+  if (adam_faulted(a)) return;
   float aQ, aPi;
   adam_alphas(a, aQ, aPi);
   const int dim = a.keep.dim, per = dim / ADAM_TILE;
@@ -122,6 +127,7 @@ static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float*
                      float epsilon, const curious_transposed_t* keep) {
   CURIOUS_CHECK(theta && m && v && grad, "curious_adam_update: NULL argument");
   memset(&a.keep, 0, sizeof(a.keep));
+  if (keep) a.keep.fault = keep->fault;
   if (keep && keep->n > 0) {
     CURIOUS_CHECK(keep->n <= 8 && keep->dim > 0 && keep->dim % ADAM_TILE == 0,
                   "curious_adam_update: bad description of the transposed copies");
@@ -162,7 +168,7 @@ extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, 
   const int n_tile = adam_tiles(a);
   size_t lds = her_lds_bytes(L);
   if (n_tile && lds < sizeof(float) * ADAM_TILE * (ADAM_TILE + 1)) lds = sizeof(float) * ADAM_TILE * (ADAM_TILE + 1);
-  { ProfScope ps__(CK_ADAM, as_stream(stream));
+  { ProfScope ps__(CK_ADAM_HER, as_stream(stream));
     hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + n_tile + blocks), dim3(256), lds, as_stream(stream), a, h, n_her,
                        n_tile); }
   CURIOUS_LAUNCH_CHECK("adam_her_kernel");

@@ -39,6 +39,12 @@ MAX_CHAIN_GRAPHS = 4    # distinct chain lengths kept captured; further lengths 
 CAPTURE_MODE = 'thread_local'
 
 
+class HandoffFault(_lib.CuriousHipError):
+    """A consumer of the in-kernel Q' hand-off of the row-local update gave up (include/curious_hip.h,
+    curious_workspace_fault_offset).  The optimiser skipped every update since: parameters, moments and target are those
+    of the last good update."""
+
+
 def dims_to_shapes(input_dims):
     return {key: tuple([val]) if val > 0 else tuple() for key, val in input_dims.items()}
 
@@ -400,6 +406,7 @@ class DDPG(object):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
         block produced by the batched RolloutWorker (ddpg.py:163-223)."""
         self.settle()
+        self.check_faults(wait=False)
         self.cp = cp
         self.n_episodes = n_ep
         layout = self._layout
@@ -536,7 +543,8 @@ class DDPG(object):
         self.settle()
         nr = min(self.nb_tasks, 5)
         bufs = [self.buffer[j + 1] for j in range(nr)]
-        return len({id(b) for b in bufs}) == nr and batch_size <= 2048 and all(b.current_size > 0 for b in bufs)
+        return len({id(b) for b in bufs}) == nr and batch_size <= 2048 and all(b.current_size > 0 for b in bufs) \
+            and self.dimo + self.dimg <= 256
 
     def _store_seed(self):
         return (self.seed * 6700417 + 29 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
@@ -558,7 +566,7 @@ class DDPG(object):
         na = batch_size * self.nb_tasks
         assert getattr(self, '_activity_prefetched', None) == (staging.data_ptr(), batch_size)
         self._activity_prefetched = None
-        self._update_stats(staging, batch_size)
+        self._update_stats(staging, batch_size, skip=skip)           # a NaN rollout feeds no statistics either
         if self._tables_stale() or getattr(self, '_tables', None) is None:
             self._refresh_device_tables()                            # from the host's (settled) sizes
         nb1 = self.nb_tasks + 1
@@ -620,8 +628,9 @@ class DDPG(object):
         self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
         self._activity_prefetched = (staging.data_ptr(), batch_size)
 
-    def _update_stats(self, staging, batch_size):
-        """HER-sample batch_size * T transitions from the fresh episodes and feed both normalisers (ddpg.py:207-223)."""
+    def _update_stats(self, staging, batch_size, skip=None):
+        """HER-sample batch_size * T transitions from the fresh episodes and feed both normalisers (ddpg.py:207-223).
+        skip: the NaN word of the rollout (device) on the device-routed path -- non-zero = nothing is accumulated."""
         layout = self._layout
         n = batch_size * self.T
         if self.rng_mode == 'numpy':
@@ -636,6 +645,13 @@ class DDPG(object):
         P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
         ops.her_sample(staging, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
         cols = layout.batch_cols
+        if self.dimo + self.dimg > 256:
+            # wider than the paired kernel's one workgroup: the two normalisers one after the other (ddpg.py:216-223)
+            assert skip is None
+            self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
+            self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
+            recompute_many([self.o_stats, self.g_stats])
+            return
         # both normalisers from the one batch in two launches; on a single rank the second one also recomputes the
         # statistics, with several ranks the (packed) accumulators are all-reduced first (normalizer.py:84-94)
         need = ops.norm_pair_scratch_doubles(n, self.dimo, self.dimg)
@@ -645,7 +661,7 @@ class DDPG(object):
         ops.norm_update_pair(batch, n, batch.stride(0), cols['o'][0], self.dimo, cols['g'][0], self.dimg,
                              self.o_stats.acc, self.g_stats.acc, self.o_stats.state if single else None,
                              self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
-                             self._stats_scratch)
+                             self._stats_scratch, skip=skip)
         if not single:
             recompute_many([self.o_stats, self.g_stats])
 
@@ -1020,8 +1036,9 @@ class DDPG(object):
         _, _, host, ev = self._sync_buf
         ev.synchronize()
         self._sync_pending = None
-        assert torch.equal(host[:2], host[2:]), \
-            'parameters diverged between ranks (rank %d, detected at update %d)' % (dist.rank(), t)
+        if not torch.equal(host[:2], host[2:]):                      # an exception, not an assert: survives python -O
+            raise dist.RankDivergence('parameters diverged between ranks (rank %d, detected at update %d)' %
+                                      (dist.rank(), t))
 
     def _train_device(self, k):
         """k updates of the device-resident loop.  Single rank: each update is curious_ddpg_update -- gradients, Adam in
@@ -1175,7 +1192,41 @@ class DDPG(object):
         ops.polyak_update(self.theta_target, self.theta, 0.0)        # ddpg.py:459-460
 
     def update_target_net(self):
+        self.check_faults(wait=False)                                # verdict of the previous cycle's copy (no stall)
         ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
+        self._enqueue_fault_check()                                  # once per cycle (train.py:154), behind the updates
+
+    # ------------------------------------------------------------------ guard of the in-kernel Q' hand-off
+    def _enqueue_fault_check(self):
+        """Asynchronous D2H copy of the workspace's fault word, stream-ordered behind everything enqueued so far."""
+        if getattr(self, '_fault', None) is None:
+            self._fault = ops.fault_word(self.net_cfg, self.batch_size, self._workspace)
+            self._fault_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._fault_ev = torch.cuda.Event()
+        self._fault_pin.copy_(self._fault, non_blocking=True)
+        self._fault_ev.record()
+        self._fault_pending = True
+
+    def check_faults(self, wait=True):
+        """Raises HandoffFault when a consumer of Q' gave up in an update since the last check.  wait=False looks only
+        at a copy that has already arrived (the training loop: the verdict of cycle c is read during cycle c + 1);
+        wait=True enqueues a fresh copy and waits for it.  The word is cleared before raising, so a caller that catches
+        the exception can go on training from the last good parameters."""
+        if wait:
+            self._enqueue_fault_check()
+        if not getattr(self, '_fault_pending', False):
+            return
+        if wait:
+            self._fault_ev.synchronize()
+        elif not self._fault_ev.query():
+            return
+        self._fault_pending = False
+        n = int(self._fault_pin[0])
+        if n:
+            self._fault.zero_()
+            raise HandoffFault("%d consumer wave(s) of the row-local update never received Q' from their target group "
+                               '(agent %s, rank %d): the optimiser was skipped from that update on' %
+                               (n, self.scope, dist.rank()))
 
     def clear_buffer(self):
         self.settle()

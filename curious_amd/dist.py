@@ -12,6 +12,10 @@ import torch
 import torch.distributed as td
 
 
+class RankDivergence(RuntimeError):
+    """MpiAdam.check_synced (mpi_adam.py:42-50): the ranks no longer hold bit-identical parameters."""
+
+
 def _forced():
     """CURIOUS_FORCE_DIST=1: take the multi-rank code paths (RCCL communicator, split update graphs, collectives) even
     with WORLD_SIZE=1 -- lets a single-GPU box exercise them against the real RCCL library."""

@@ -158,7 +158,8 @@ class BatchedSyntheticArm(ArmSpec):
         self.tasks.copy_(self._pin[:n].view(torch.int32), non_blocking=True)
         self._goals_dev.copy_(self._pin[n:].view(n, 3), non_blocking=True)
         ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
-                      self.o, self.ag, self.g, self.td, self.staging)      # also advances self.episode on the device
+                      self.o, self.ag, self.g, self.td, self.staging,      # also advances self.episode on the device
+                      flags=self.flags)                                    # and clears the NaN word of the coming rollout
 
     def step_all(self, u, t):
         ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,

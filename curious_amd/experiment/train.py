@@ -93,6 +93,8 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
             logger.info('Starting new epoch ', epoch, 'at time', time.time() - t0)
             t_ep = time.time()
             rollout_worker.clear_history()
+            if perturbation_study and epoch == 250:
+                perturb_envs(rollout_worker, evaluator)              # train.py:142-146
             for cyc in range(n_cycles):                               # train.py:148-155 -- the hot loop
                 episode, cp, n_ep = rollout_worker.generate_rollouts()
                 policy.store_episode(episode, cp, n_ep)
@@ -107,6 +109,23 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
                                      periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
                                      policy, rank, structure)
     return best_success_rate
+
+
+def perturb_envs(rollout_worker, evaluator, n=2):
+    """The perturbation study's switch (train.py:142-146): from epoch 250 on the first two envs of the training worker and
+    of the evaluator return biased observations (`env.unwrapped.bias = True`; what the bias does is the env's business --
+    gym_flowers upstream).  An env object without a `bias` attribute cannot honour it: refused, not ignored."""
+    for worker in (rollout_worker, evaluator):
+        envs = list(worker.envs)
+        if len(envs) < n:
+            raise NotImplementedError('--perturb needs a Python list of at least %d envs per worker (host envs); the '
+                                      'GPU-resident batched env of this build has no observation-bias model' % n)
+        for i in range(n):
+            env = envs[i].unwrapped
+            if not hasattr(env, 'bias'):
+                raise NotImplementedError('--perturb: %s has no `bias` switch (train.py:145-146 sets '
+                                          'env.unwrapped.bias = True)' % type(env).__name__)
+            env.bias = True
 
 
 def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, periodic_policy_path,
@@ -145,8 +164,8 @@ def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, 
     # ranks must hold different RNG streams (train.py:207-212, C13)
     local_uniform = np.random.uniform(size=(1,))
     root_uniform = dist.broadcast_object(float(local_uniform[0]), 0)
-    if rank != 0:
-        assert local_uniform[0] != root_uniform
+    if rank != 0 and local_uniform[0] == root_uniform:               # train.py:211-212 (an exception: survives python -O)
+        raise dist.RankDivergence('rank %d draws from the same NumPy stream as rank 0' % rank)
     return best_success_rate
 
 
@@ -163,6 +182,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         logger.configure(dir=save_dir)
     else:
         save_dir = None
+    if perturb and structure == 'task_experts':
+        raise NotImplementedError('--perturb applies to the curious / flat loop only (train.py:142-146)')
     rank_seed = seed + 1000000 * rank                                 # train.py:242-243
     np.random.seed(rank_seed)
     import random
@@ -261,7 +282,7 @@ def main(argv=None):
     parser.add_argument('--n_epochs', type=int, default=316)
     parser.add_argument('--num_cpu', type=int, default=NUM_CPU)
     parser.add_argument('--seed', type=int, default=int(np.random.randint(1e6)))
-    parser.add_argument('--policy_save_interval', type=int, default=20)
+    parser.add_argument('--policy_save_interval', type=int, default=50)
     parser.add_argument('--clip_return', type=int, default=1)
     parser.add_argument('--normalize_obs', type=lambda s: s.lower() in ('1', 'true', 'yes'), default=False)
     parser.add_argument('--structure', type=str, default=STRUCTURE)

@@ -178,3 +178,7 @@ class ExpertBank:
     def update_target_net(self):
         for x in self.experts:
             x.update_target_net()
+
+    def check_faults(self, wait=True):
+        for x in self.experts:
+            x.check_faults(wait)

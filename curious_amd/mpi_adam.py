@@ -58,4 +58,5 @@ class MpiAdam:
         ops.param_checksum(self.theta, out)
         mine = out.clone()
         dist.broadcast_(out, 0)
-        assert torch.equal(out, mine), 'parameters diverged between ranks (rank %d)' % dist.rank()
+        if not torch.equal(out, mine):                               # an exception, not an assert: survives python -O
+            raise dist.RankDivergence('parameters diverged between ranks (rank %d)' % dist.rank())

@@ -98,10 +98,11 @@ def norm_update(rows, n_rows, stride, col_off, dim, acc, scratch):
 
 
 def norm_update_pair(rows, n_rows, stride, off_a, dim_a, off_b, dim_b, acc_a, acc_b, state_a, state_b, eps_a, eps_b,
-                     scratch):
+                     scratch, skip=None):
+    """skip: device float; non-zero (the NaN word of a rollout) = accumulate nothing."""
     check(lib().curious_norm_update_pair(ptr(_dev(rows, 'rows')), int(n_rows), int(stride), int(off_a), int(dim_a),
                                          int(off_b), int(dim_b), ptr(acc_a), ptr(acc_b), ptr(state_a), ptr(state_b),
-                                         float(eps_a), float(eps_b), ptr(scratch), current_stream()),
+                                         float(eps_a), float(eps_b), ptr(scratch), ptr(skip), current_stream()),
           'curious_norm_update_pair')
 
 
@@ -303,10 +304,10 @@ def make_env_cfg(ntasks, dimo, T, seed):
     return e
 
 
-def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging):
+def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging, flags=None):
     L = layout.c_layout()
     check(lib().curious_env_reset(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks),
-                                  ptr(goals_raw), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
+                                  ptr(goals_raw), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging), ptr(flags),
                                   current_stream()), 'curious_env_reset')
 
 
@@ -362,3 +363,45 @@ def prof_collect():
     ms = (C.c_double * n)()
     check(lib().curious_prof_collect(counts, ms), 'curious_prof_collect')
     return {lib().curious_prof_kernel_name(k).decode(): (int(counts[k]), float(ms[k])) for k in range(n)}
+
+
+def prof_launch_counts():
+    """{kernel name: launches since the library was loaded} (counted with or without event timing; no sync)."""
+    n = lib().curious_prof_kernel_count()
+    counts = (C.c_int64 * n)()
+    check(lib().curious_prof_launch_counts(counts), 'curious_prof_launch_counts')
+    return {lib().curious_prof_kernel_name(k).decode(): int(counts[k]) for k in range(n)}
+
+
+def set_option(name, value):
+    """Run-time option of the library (include/curious_hip.h: rows, rows_xcd, xcd_map, fault_inject, qt_spins)."""
+    check(lib().curious_set_option(name.encode(), int(value)), 'curious_set_option')
+
+
+def get_option(name):
+    v = int(lib().curious_get_option(name.encode()))
+    if v < 0:
+        check(-1, 'curious_get_option')
+    return v
+
+
+class option:
+    """`with ops.option('rows', 0): ...` -- set an option for a block (tests: the tiled route, fault injection)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+
+
+def fault_word(cfg, B, workspace):
+    """int32 view (1 element) of the fault word inside a gradient workspace (curious_workspace_fault_offset)."""
+    off = int(lib().curious_workspace_fault_offset(C.byref(cfg), int(B)))
+    if off < 0:
+        raise _lib.CuriousHipError('curious_workspace_fault_offset: bad arguments')
+    return _dev(workspace, 'workspace')[off:off + 1].view(torch.int32)

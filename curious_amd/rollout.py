@@ -311,6 +311,8 @@ class RolloutWorker:
             views = env.episode_views()
             self.policy.expect_async_store(views, env.flags[env.n:env.n + 1])
             return views, self.CP, self.n_episodes
+        if getattr(self.policy, '_async_batch', None) is not None:
+            self.policy._async_batch = None                       # a marked rollout that was never stored: forget it
         successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
         if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')

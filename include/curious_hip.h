@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 4      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 5      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -114,6 +114,20 @@ int curious_prof_enable(int on);
 int curious_prof_kernel_count(void);
 const char* curious_prof_kernel_name(int kid);
 int curious_prof_collect(int64_t* counts_host, double* total_ms_host);
+/* launches per kernel id since the library was loaded ([curious_prof_kernel_count()] entries), counted whether or not
+ * event timing is on; a launch captured into a hipGraph counts once.  The GPU test session uses it to assert that no
+ * kernel of the library went unexercised. */
+int curious_prof_launch_counts(int64_t* counts_host);
+
+/* Run-time options, read at every call (so one process can run both routes).  Names:
+ *   "rows"         1 (default; env CURIOUS_ROWS): the row-local routes; 0: the tiled multi-launch routes
+ *   "rows_xcd"     1 (default; env CURIOUS_ROWS_XCD): workgroup kinds of the row-local update placed by XCD
+ *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
+ *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes (fault-path tests)
+ *   "qt_spins"     2^22 (default): polls before a consumer of Q' gives up and raises the workspace's fault word
+ * Options are baked into a launch when it is enqueued (also into captured graphs). */
+int curious_set_option(const char* name, int64_t value);
+int64_t curious_get_option(const char* name);     /* -1 + curious_last_error() for an unknown name */
 
 /* HER sample + goal/task relabel + reward + clip, written already permuted.
  * Replaces replay_buffer.py:37-55, her.py:99-183 (or :20-66), ddpg.py:326-353.
@@ -175,11 +189,14 @@ int curious_norm_recompute(float* acc, float* state, int32_t dim, float world_si
  * same HER-sampled batch, ddpg.py:216-223) in two launches: partial column sums over [a | b], then a finishing launch
  * (wavefront reductions, the accumulator update of normalizer.py:68-70).  With state_a / state_b given (single rank)
  * the finishing launch also runs recompute_stats (normalizer.py:96-118, world size 1) and zeroes the accumulators;
- * with several ranks pass NULL, all-reduce the accumulators and call curious_norm_recompute. */
+ * with several ranks pass NULL, all-reduce the accumulators and call curious_norm_recompute.
+ * skip (device, optional): when *skip != 0 -- the NaN word of the rollout flags -- nothing is accumulated (the reference
+ * discards a NaN rollout before store_episode ever sees it, rollout.py:268-271).  dim_a + dim_b <= 256. */
 int64_t curious_norm_pair_scratch_doubles(int32_t n_rows, int32_t dim_a, int32_t dim_b);
 int curious_norm_update_pair(const float* rows, int32_t n_rows, int32_t stride, int32_t off_a, int32_t dim_a,
                              int32_t off_b, int32_t dim_b, float* acc_a, float* acc_b, float* state_a, float* state_b,
-                             float eps_a, float eps_b, double* scratch, curious_stream_t stream);
+                             float eps_a, float eps_b, double* scratch, const float* skip /* may be NULL */,
+                             curious_stream_t stream);
 
 /* ---- networks ---------------------------------------------------------------------------------
  * Parameter vector of one agent = [theta_Q | pad | theta_pi | pad] (ddpg.py:456 main_vars order); theta_pi
@@ -203,6 +220,13 @@ int64_t curious_param_offset_pi(const curious_net_cfg_t* cfg);
 int64_t curious_param_total(const curious_net_cfg_t* cfg);
 /* workspace floats for curious_ddpg_grads / curious_policy_forward at batch size B */
 int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
+/* Float offset, inside that workspace, of its FAULT WORD (one int32; zero it together with the workspace).  The
+ * row-local update hands Q' of the target networks from one workgroup to another inside one launch; a consumer that
+ * never receives its value (HIP does not promise the dispatch order the hand-off relies on) gives up after "qt_spins"
+ * polls, turns the loss into NaN and increments this word.  While it is non-zero every optimiser of this library that
+ * knows the workspace (curious_ddpg_update*, curious_adam_update* given curious_ddpg_transposed()) leaves theta, m, v
+ * and the transposed copies untouched: the caller reads the word once per cycle, raises, and clears it. */
+int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, int32_t B);
 
 /* One DDPG._grads(): target/main forward, losses, flat gradients (ddpg.py:235-243,419-449).
  * batch rows as written by curious_her_sample.  o_stats/g_stats = normaliser state vectors (may be
@@ -247,6 +271,7 @@ typedef struct curious_transposed {
   int32_t dim;
   int64_t src_off[8];
   float* dst[8];
+  const int32_t* fault;                /* the workspace's fault word (curious_workspace_fault_offset); set even when n == 0 */
 } curious_transposed_t;
 int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, float* workspace, curious_transposed_t* out);
 
@@ -337,15 +362,18 @@ typedef struct curious_env_cfg {
 
 /* Reset n envs: o[n][dimo] from Philox stream (env_id0+i, episode[i]); episode[i] (episodes started so far) is
  * incremented afterwards, on the device; writes record row 0 of the
- * staging block (o, ag, g, td) and the working arrays o/ag/g/td. goals_raw[n][3] in [-1,1], tasks[n]. */
+ * staging block (o, ag, g, td) and the working arrays o/ag/g/td. goals_raw[n][3] in [-1,1], tasks[n].
+ * flags (optional, [n+1] floats, see curious_env_step): flags[n], the NaN word of the coming rollout, is cleared. */
 int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                       int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
-                      float* o, float* ag, float* g, float* td, float* staging, curious_stream_t stream);
+                      float* o, float* ag, float* g, float* td, float* staging, float* flags /* may be NULL */,
+                      curious_stream_t stream);
 
 /* One step of n envs with actions u[n][dimu]: updates o/ag in place, writes u, g, td, change, is_success
  * into staging row t and o, ag into row t+1 (the episode record of rollout.py:273-303).
  * flags (optional, [n+1] floats): at the last step t = T-1, flags[i] = is_success of env i and flags[n] = 1 if any
- * observation is NaN (flags[n] is cleared at t = 0) -- what rollout.py:268-271,306 reads, in one small D2H copy. */
+ * observation is NaN (flags[n] is cleared by curious_env_reset) -- what rollout.py:268-271,306 reads, in one small D2H
+ * copy.  dimo <= 128. */
 int curious_env_step(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                      const int32_t* episode, const int32_t* tasks, const float* u, int32_t ldu, int32_t t,
                      int32_t n, float* o, float* ag, const float* g, const float* td, float* staging,
