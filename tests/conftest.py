@@ -27,3 +27,12 @@ def sub(npz, prefix):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+@pytest.fixture(params=['rows', 'tiled'])
+def route(request):
+    """Runs a GPU test once per network route of the library: the row-local kernels (mlp_rows.h, the default) and the
+    tiled multi-launch kernels (option "rows" = 0), which remain the route of shapes the row-local kernels refuse."""
+    from curious_amd import ops
+    with ops.option('rows', 1 if request.param == 'rows' else 0):
+        yield request.param

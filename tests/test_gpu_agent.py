@@ -37,7 +37,7 @@ def synth_episodes(rng, E, nb, dimo):
     return dict(o=o, u=u, g=g, ag=ag, task_descr=td, change=change, info_is_success=succ)
 
 
-def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', use_graph=False, hidden=256):
+def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', use_graph=False, hidden=256, layers=3):
     """(product agent, oracle agent) with identical weights and empty buffers."""
     from curious_amd.ddpg import DDPG
     from curious_amd.envs import sparse_reward_fun
@@ -57,7 +57,7 @@ def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', u
                                                      tasks_ag_id=ag_ids, tasks_g_id=g_ids)
     bufs = make_pooled_buffers(shapes, T * cap_eps, T, sampler, nb + 1, alias_from=5)
     gamma = 1. - 1. / T
-    agent = DDPG(input_dims=dims, hidden=hidden, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
+    agent = DDPG(input_dims=dims, hidden=hidden, layers=layers, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
                  polyak=0.95, batch_size=batch_size, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1.,
                  action_l2=1., clip_obs=200., scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None,
                  relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
@@ -68,7 +68,7 @@ def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', u
                                                            make_reward_fun(ag_ids, g_ids), tasks_ag_id=ag_ids,
                                                            tasks_g_id=g_ids)
     obufs = [OBuf(shapes, T * cap_eps, T, osampler) for _ in range(nb + 1)]
-    oracle = OracleDDPG(dims, T, obufs, osampler, ag_ids, g_ids, hidden=hidden, batch_size=batch_size,
+    oracle = OracleDDPG(dims, T, obufs, osampler, ag_ids, g_ids, hidden=hidden, layers=layers, batch_size=batch_size,
                         weight_rng=np.random.RandomState(seed))
     return agent, oracle
 
@@ -226,11 +226,12 @@ def test_device_rng_graph_equals_eager_and_learns():
     assert np.all(td.sum(axis=1) == 1)
 
 
-@pytest.mark.parametrize('small', [False, True])
-def test_fused_update_equals_unfused_sequence(small):
+@pytest.mark.parametrize('shape', ['default', 'small', 'layers4', 'layers2'])
+def test_fused_update_equals_unfused_sequence(shape, route):
     """curious_ddpg_update (Adam in the weight-gradient launch + next gather riding along) against the three separate
-    launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit, lean kernels and generic fallback."""
-    kw = dict(batch_size=64, hidden=64) if small else {}
+    launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit: lean kernels, the generic fallback, and
+    4 layers per network (the row-local pass with the generic weight gradients + the stand-alone optimiser)."""
+    kw = dict(default={}, small=dict(batch_size=64, hidden=64), layers4=dict(layers=4), layers2=dict(layers=2))[shape]
     a_f, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
     a_u, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
     rng = np.random.RandomState(5)
@@ -331,7 +332,7 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert found[0][2] == found[1][2] == '235'
 
 
-def test_batched_rollout_matches_oracle():
+def test_batched_rollout_matches_oracle(route):
     """GPU-resident rollout (actor forward + noise + env step kernels) against the oracle env + oracle policy."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker
@@ -645,7 +646,7 @@ def test_evaluator_rollout_graph_equals_eager():
     assert qs[0] == qs[1] and len(qs[0]) == 3 and np.isfinite(qs[0]).all()
 
 
-def test_fused_act_and_step_equals_unfused():
+def test_fused_act_and_step_equals_unfused(route):
     """curious_policy_act_env_step == get_actions + env.step_all, bit for bit (throughput mode)."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker

@@ -42,7 +42,7 @@ def _expert_kit(nb=4, dimo=40, batch_size=256, hidden=256, cap_eps=64):
 
 
 @pytest.mark.parametrize('use_graph', [False, True])
-def test_batched_experts_equal_sequential_experts_and_oracle(use_graph):
+def test_batched_experts_equal_sequential_experts_and_oracle(use_graph, route):
     """curious_ddpg_update_experts: N = 4 experts in one launch sequence per update, bit-identical to 4 DDPG(t_id=i)
     objects updated one after the other (train.py:65-121, ddpg.py:302-318,335); every expert's loss within 1e-5 of the
     float64 oracle on the batch it drew."""
@@ -188,9 +188,10 @@ def test_launch_runs_every_structure_and_logs_the_reference_columns(tmp_path, st
 @pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 48),
                                                  ('MultiTaskFetchArm8-v5', 8, 52, 48),
                                                  ('MultiTaskFetchArm8-v5', 8, 52, 37)])
-def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B):
-    """curious_policy_act_env_step (fwd_l01<1|2> + fwd_hot<DOT> + act_step<PART> when B % 16 == 0, generic kernels
-    otherwise) == get_actions + env.step_all, bit for bit, eager and as a replayed hipGraph -- on both env sizes."""
+def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B, route):
+    """curious_policy_act_env_step == get_actions + env.step_all, bit for bit, eager and as a replayed hipGraph, on both
+    env sizes and both routes: `rows` = policy_rows_kernel when B % 4 == 0 (generic kernels for B = 37); `tiled` =
+    fwd_l01<1|2> + fwd_hot<DOT> + act_step<PART> when B % 16 == 0, generic kernels otherwise."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker
     from curious_amd import logger
@@ -536,7 +537,7 @@ def test_action_noise_kernel_matches_the_reference_method():
 
 @pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 64), ('MultiTaskFetchArm8-v5', 8, 52, 64),
                                                  ('MultiTaskFetchArm4-v5', 4, 40, 30)])
-def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B):
+def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B, route):
     """curious_policy_rollout (all T steps in one launch on the row-local route, B % 4 == 0; the launches of the
     single-step entry point otherwise) == T x curious_policy_act_env_step, bit for bit: episode records, last actions,
     success / NaN flags, final env state -- over two consecutive episodes (the episode counter feeds the env's streams)."""

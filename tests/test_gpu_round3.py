@@ -1,0 +1,201 @@
+"""Round-3 GPU tests: the guard on the in-kernel Q' hand-off (fault injection), NaN rollouts on the device-routed
+path, the wide-observation normaliser fallback, run-time options."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_agent import T, build_pair, synth_episodes
+from test_gpu_round2 import _expert_kit
+
+pytestmark = pytest.mark.gpu
+
+
+def _filled_agent(**kw):
+    agent, _ = build_pair(4, 40, rng_mode='device', **kw)
+    ep = synth_episodes(np.random.RandomState(5), 40, 4, 40)
+    np.random.seed(2)
+    agent.store_episode({k: v.copy() for k, v in ep.items()}, np.array([0.3, 0.0, 0.2, 0.1]), 40)
+    return agent, ep
+
+
+def test_options_are_read_per_call():
+    from curious_amd import _lib, ops
+    assert ops.get_option('rows') == 1 and ops.get_option('fault_inject') == 0 and ops.get_option('qt_spins') == 1 << 22
+    with ops.option('rows', 0):
+        assert ops.get_option('rows') == 0
+    assert ops.get_option('rows') == 1
+    with pytest.raises(_lib.CuriousHipError):
+        ops.set_option('no_such_option', 1)
+    with pytest.raises(_lib.CuriousHipError):
+        ops.set_option('xcd_map', 3)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_handoff_fault_is_detected_and_the_optimiser_skipped(use_graph):
+    """A target group that never publishes Q' (option fault_inject): the consumers give up after qt_spins polls, the
+    loss is NaN, the workspace's fault word counts the 4 waves, the optimiser of that update -- and of every later one
+    until the word is cleared -- leaves theta / m / v / the transposed copies alone; DDPG.check_faults raises and clears;
+    the next update is clean.  Eager launches and a captured graph (the option is baked into the capture)."""
+    from curious_amd import ops
+    from curious_amd.ddpg import HandoffFault
+    agent, ep = _filled_agent(use_graph=use_graph)
+    agent.train_batches(3)
+    agent.check_faults()                                             # nothing to report
+    torch.cuda.synchronize()
+    before = [x.clone() for x in (agent.theta, agent._m, agent._v, agent.theta_target)]
+    kept = ops.ddpg_transposed(agent.net_cfg, agent.batch_size, agent._workspace)
+    assert kept.n == 4 and kept.fault == ops.fault_word(agent.net_cfg, agent.batch_size, agent._workspace).data_ptr()
+    ws_before = agent._workspace.clone()
+    fault = ops.fault_word(agent.net_cfg, agent.batch_size, agent._workspace)
+    with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+        if use_graph:
+            agent._graphs = [None, None]                             # capture anew, with the injected fault baked in
+        loss, _ = agent.train()
+        torch.cuda.synchronize()
+    # the 4 waves (batch rows) of row group 2 -- twice with a graph: the eager warm-up of the capture, then the replay
+    assert int(fault) == (8 if use_graph else 4)
+    assert not np.isfinite(float(loss))
+    agent.train()                                                    # the word is sticky: this update is skipped as well
+    torch.cuda.synchronize()
+    if use_graph:
+        agent._graphs = [None, None]                                 # (drop the graphs that carry the injection)
+    for a, b in zip(before, (agent.theta, agent._m, agent._v, agent.theta_target)):
+        assert torch.equal(a, b)
+    off = (kept.dst[0] - agent._workspace.data_ptr()) // 4           # the transposed copies: untouched
+    n_copy = 4 * 256 * 256
+    assert torch.equal(ws_before[off:off + n_copy], agent._workspace[off:off + n_copy])
+    # the training loop's form of the check: enqueued by update_target_net, read by the next store_episode
+    agent.update_target_net()
+    torch.cuda.synchronize()
+    with pytest.raises(HandoffFault):
+        agent.store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(4), 80)
+    assert int(fault) == 0                                           # cleared by the check
+    agent.check_faults()
+    loss, _ = agent.train()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and not torch.equal(before[0], agent.theta)
+    agent.check_faults()
+
+
+def test_handoff_fault_with_batched_experts():
+    """N = 4 experts: 768 workgroups compete for 256 CUs; every expert's row group 5 loses its producer.  Every expert
+    reports, no expert's parameters move, the bank trains on afterwards."""
+    from curious_amd import ops
+    from curious_amd.ddpg import HandoffFault
+    from curious_amd.experts import ExpertBank
+    nb = 4
+    make, bufs, dims, shapes, ids, tr = _expert_kit()
+    bank = ExpertBank(lambda t, **h: make(t, **h), nb)
+    ep = synth_episodes(np.random.RandomState(2), 40, nb, 40)
+    np.random.seed(1)
+    bank[0].store_episode({k: v.copy() for k, v in ep.items()}, np.zeros(nb), 40)
+    bank.train_batches(2)
+    bank.check_faults()
+    torch.cuda.synchronize()
+    before = bank.slab.clone()
+    x0 = bank[0]
+    with ops.option('fault_inject', 6), ops.option('qt_spins', 50000):
+        bank.train_batches(1)
+        torch.cuda.synchronize()
+    assert bank.batched
+    for x in bank:
+        assert int(ops.fault_word(x.net_cfg, x.batch_size, x._workspace)) == 4
+        n = x.theta.numel()
+        for name in ('theta', '_m', '_v', 'theta_target'):
+            t = getattr(x, name)
+            off = (t.data_ptr() - bank.slab.data_ptr()) // 4
+            assert torch.equal(before.view(-1)[off:off + n], t), name
+        assert not np.isfinite(float(x._losses[0]))
+    n_raised = 0
+    for x in bank:
+        with pytest.raises(HandoffFault):
+            x.check_faults()
+        n_raised += 1
+    assert n_raised == nb
+    bank.check_faults()                                              # all cleared
+    bank.train_batches(3)
+    torch.cuda.synchronize()
+    bank.check_faults()
+    assert all(np.isfinite(float(x._losses[0])) for x in bank)
+    assert not torch.equal(before.view(-1)[:x0.theta.numel()], x0.theta)
+
+
+def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
+    """async_store: a rollout whose observations turn NaN is neither stored nor fed to the normalisers (the reference
+    regenerates it before store_episode ever sees it, rollout.py:268-271); the worker reports it a cycle late; the NaN
+    word is cleared by the next reset."""
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    nb, dimo, B = 4, 40, 16
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    agent, _ = build_pair(nb, dimo, cap_eps=100, rng_mode='device', use_graph=False)
+    agent.async_store = True
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                      noise_eps=0.2, random_eps=0.0, structure='curious', task_selection='random', queue_length=6,
+                      eval=False)
+    w.seed(5)
+    np.random.seed(8)
+    agent.store_episode(synth_episodes(np.random.RandomState(21), 24, nb, dimo), w.CP, 24)
+    ep, cp, n_ep = w.generate_rollouts()
+    assert getattr(w, '_pending', None) is not None                   # the async form applies
+    agent.store_episode(ep, cp, n_ep)
+    agent.train_batches(2)
+    w.settle(); agent.settle()
+    torch.cuda.synchronize()
+    sizes = [b.current_size for b in agent.buffer]
+    stats = (agent.o_stats.state.clone(), agent.g_stats.state.clone(), agent._stats_acc.clone())
+    reset_all = w.benv.reset_all
+
+    def poisoned_reset(tasks, goals):                                # one env starts from a NaN observation
+        reset_all(tasks, goals)
+        w.benv.o[3, 1] = float('nan')
+    w.benv.reset_all = poisoned_reset
+    ep, cp, n_ep = w.generate_rollouts()
+    w.benv.reset_all = reset_all
+    assert getattr(w, '_pending', None) is not None
+    agent.store_episode(ep, cp, n_ep)
+    torch.cuda.synchronize()
+    assert float(w.benv.flags[B]) == 1.0
+    w.settle(); agent.settle()
+    assert [b.current_size for b in agent.buffer] == sizes            # nothing stored
+    for a, b in zip(stats, (agent.o_stats.state, agent.g_stats.state, agent._stats_acc)):
+        assert torch.equal(a, b)                                      # nothing accumulated
+    assert torch.isfinite(agent.o_stats.state).all()
+    ep, cp, n_ep = w.generate_rollouts()                             # the next reset clears the NaN word
+    agent.store_episode(ep, cp, n_ep)
+    w.settle(); agent.settle()
+    torch.cuda.synchronize()
+    assert float(w.benv.flags[B]) == 0.0
+    assert sum(b.current_size for b in agent.buffer[1:nb + 1]) > sum(sizes[1:nb + 1])
+
+
+def test_wide_observations_take_the_per_normaliser_path():
+    """dimo + dimg > 256: store_episode feeds the two normalisers one after the other (curious_norm_update +
+    curious_norm_recompute) instead of the paired launch; same statistics as the oracle."""
+    nb, dimo = 4, 250
+    agent, oracle = build_pair(nb, dimo, rng_mode='numpy')
+    ep = synth_episodes(np.random.RandomState(7), 12, nb, dimo)
+    cp = np.zeros(nb)
+    np.random.seed(4)
+    agent.store_episode({k: v.copy() for k, v in ep.items()}, cp, 12)
+    np.random.seed(4)
+    oracle.store_episode({k: v.astype(np.float64) for k, v in ep.items()}, cp, 12)
+    for nz, onz in ((agent.o_stats, oracle.o_stats), (agent.g_stats, oracle.g_stats)):
+        np.testing.assert_allclose(nz.mean.cpu().numpy(), onz.mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nz.std.cpu().numpy(), onz.std, rtol=1e-5, atol=1e-6)
+
+
+def test_synthetic_env_refuses_observations_wider_than_its_step_kernel():
+    from curious_amd import _lib, ops
+    from curious_amd.layout import RecordLayout
+    nb, dimo, n, Tn = 4, 132, 4, 5
+    G = 3 * nb
+    shapes = dict(o=(Tn + 1, dimo), u=(Tn, 4), g=(Tn, G), ag=(Tn + 1, G), info_is_success=(Tn, 1),
+                  task_descr=(Tn, nb), change=(Tn, G))
+    lay = RecordLayout(shapes, Tn)
+    ecfg = ops.make_env_cfg(nb, dimo, Tn, 1)
+    z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device='cuda')
+    with pytest.raises(_lib.CuriousHipError, match='at most 128'):
+        ops.env_step(ecfg, lay, 0, z(n, dtype=torch.int32), z(n, dtype=torch.int32), z(n, 4), 0, n, z(n, dimo), z(n, G),
+                     z(n, G), z(n, nb), z(n, Tn + 1, lay.row_stride), 0.05)

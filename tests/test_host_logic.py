@@ -163,3 +163,26 @@ def test_record_layout_views_roundtrip():
         np.testing.assert_array_equal(views[k].numpy(), ep[k])
     assert set(L.batch_cols) == {'o', 'task_descr', 'u', 'g', 'o_2', 'g_2', 'r', 'ag', 'ag_2', 'change',
                                  'info_is_success'}
+
+
+def test_perturbation_switch_sets_bias_on_the_first_two_envs_or_refuses():
+    """train.py:142-146: at epoch 250 of a perturbation study env.unwrapped.bias = True on envs 0 and 1 of both workers."""
+    from curious_amd.experiment.train import perturb_envs
+
+    class Env:
+        def __init__(self, with_bias=True):
+            if with_bias:
+                self.bias = False
+        unwrapped = property(lambda self: self)
+
+    class Worker:
+        def __init__(self, envs):
+            self.envs = envs
+
+    a, b = Worker([Env() for _ in range(3)]), Worker([Env() for _ in range(2)])
+    perturb_envs(a, b)
+    assert [e.bias for e in a.envs] == [True, True, False] and [e.bias for e in b.envs] == [True, True]
+    with pytest.raises(NotImplementedError):                         # the GPU-resident batch is ONE env object
+        perturb_envs(Worker([Env()]), b)
+    with pytest.raises(NotImplementedError):                         # an env without the switch: refused, not ignored
+        perturb_envs(Worker([Env(False), Env(False)]), b)
