@@ -248,7 +248,8 @@ static int xcd_rows() { return curious_options().xcd_map; }
 template <int XR> static dim3 xcd_grid(int nprob) { return dim3(8, 4 * XR, (nprob * (16 / XR) + 7) / 8); }
 
 // Batched experts (mlp_common.h "Ex"): nex agents per launch, slabs `stride` floats apart.
-struct ExDim { int nex = 1; int64_t stride = 0; };
+// gstride: floats between the experts' GRADIENT vectors (they live in a contiguous [N, P] block of their own).
+struct ExDim { int nex = 1; int64_t stride = 0; int64_t gstride = 0; };
 static Ex make_ex(const ExDim& d, int nprob) {
   Ex e;
   e.stride = d.stride; e.nprob = nprob; e.zmul = (uint32_t)((65536 + nprob - 1) / nprob);
@@ -1058,7 +1059,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   int tAll = 0, stAll = 0;
   bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
   if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
-  CURIOUS_CHECK(xd.nex == 1 || (lean_dw && tail), "batched experts need the lean weight-gradient launch");
+  CURIOUS_CHECK(xd.nex == 1 || lean_dw, "batched experts need the lean weight-gradient launch");
   if (lean_dw) {
     smAll.fin = fin;
     dwAll.n_hot = tAll;
@@ -1069,14 +1070,14 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       { ProfScope ps__(CK_DW_ADAM_HER, st);
         hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll,
-                           tail->adam, tail->h, n_her, xd.stride, seed_stride); }
+                           tail->adam, tail->h, n_her, xd.stride, xd.gstride, seed_stride); }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
       return 0;
     }
-    CURIOUS_CHECK(xd.nex == 1, "batched experts need the fused update tail");
+    CURIOUS_CHECK(xd.nex == 1 || !tail, "batched experts need the fused update tail");
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
-      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1), dim3(256), 0, st, dwAll); }
+      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll, xd.stride, xd.gstride); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
@@ -1215,20 +1216,41 @@ extern "C" int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_ma
                           out_Q_pi, step_ctr, adam, next, stream, ExDim(), 0);
 }
 
-extern "C" int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
-                                           uint64_t seed_stride, float* theta_main, const float* theta_target,
-                                           const float* batch, const curious_batch_layout_t* BL, int32_t B,
-                                           float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                                           int64_t* step_ctr, const curious_adam_state_t* adam,
-                                           const curious_next_batch_t* next, curious_stream_t stream) {
-  CURIOUS_CHECK(n_experts >= 1 && n_experts <= 64, "curious_ddpg_update_experts: n_experts must be in 1..64");
+static int check_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride, int64_t grad_stride) {
+  CURIOUS_CHECK(n_experts >= 1 && n_experts <= 64, "batched experts: n_experts must be in 1..64");
   CURIOUS_CHECK(n_experts == 1 || (expert_stride > 0 && expert_stride % 64 == 0),
-                "curious_ddpg_update_experts: expert_stride must be a positive multiple of 64 floats");
+                "batched experts: expert_stride must be a positive multiple of 64 floats");
+  CURIOUS_CHECK(cfg && (n_experts == 1 || (grad_stride >= curious_param_total(cfg) && grad_stride % 64 == 0)),
+                "batched experts: grad_stride must be a multiple of 64 floats >= curious_param_total()");
+  return 0;
+}
+
+extern "C" int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
+                                          int64_t grad_stride, const float* theta_main, const float* theta_target,
+                                          const float* batch, const curious_batch_layout_t* BL, int32_t B,
+                                          float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                                          int64_t* step_ctr, int32_t params_unchanged, curious_stream_t stream) {
+  if (check_experts(cfg, n_experts, expert_stride, grad_stride)) return -1;
+  CURIOUS_CHECK(!cfg->normalize_obs, "curious_ddpg_grads_experts: input normalisation is not supported");
+  ExDim xd;
+  xd.nex = n_experts; xd.stride = expert_stride; xd.gstride = grad_stride;
+  return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
+                         out_Q_pi, step_ctr, stream, nullptr, xd, 0, params_unchanged != 0);
+}
+
+extern "C" int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
+                                           int64_t grad_stride, uint64_t seed_stride, float* theta_main,
+                                           const float* theta_target, const float* batch,
+                                           const curious_batch_layout_t* BL, int32_t B, float* workspace, float* grad,
+                                           float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                                           const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                                           curious_stream_t stream) {
+  if (check_experts(cfg, n_experts, expert_stride, grad_stride)) return -1;
   CURIOUS_CHECK(cfg && !cfg->normalize_obs, "curious_ddpg_update_experts: input normalisation is not supported");
   CURIOUS_CHECK(step_ctr && adam && adam->alpha_tab && next,
                 "curious_ddpg_update_experts: device step counter, step-size table and next batch are required");
   ExDim xd;
-  xd.nex = n_experts; xd.stride = expert_stride;
+  xd.nex = n_experts; xd.stride = expert_stride; xd.gstride = grad_stride;
   return ddpg_update_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
                           out_Q_pi, step_ctr, adam, next, stream, xd, seed_stride);
 }

@@ -19,7 +19,9 @@ __device__ inline bool adam_faulted(const AdamFuse& A, int64_t eo) {
 }
 
 // eo: slab offset of the expert this block works for (0 for a single agent); i / pidx / bidx below are indices into
-// the parameter vector, the moments and the parameters are addressed at index + eo
+// the parameter vector, the moments and the parameters are addressed at index + eo.  eg: the same for the GRADIENT
+// vectors, which the experts keep in a contiguous [N, P] block of their own (grad_stride = P) so that several ranks sum
+// all of them in ONE all-reduce (curious_ddpg_grads_experts); every pointer into a gradient vector is shifted by eg.
 __device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int64_t eo) {
   aQ = A.a_Q; aPi = A.a_pi;
   if (A.alpha_tab) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
 __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
-                                   const int64_t eo) {
+                                   const int64_t eo, const int64_t eg) {
   // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
   const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
   const GemmHot& P = args.p[pi];
@@ -237,7 +239,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0);
   // pidx / bidx = parameter indices (the same for every expert), addressed at index + eo
   const int64_t toff = (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
-  float* const dst = P.C + eo + toff;
+  float* const dst = P.C + eg + toff;
   const int64_t pidx = ADAM ? (int64_t)(P.C - A.grad) + toff : 0;
   const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
   AdamPre4 pre;
@@ -294,7 +296,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
       float gb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.aux_out[eo + n0 + tid] = gb;
+      P.aux_out[eg + n0 + tid] = gb;
       if (ADAM && !faulted) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
         A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
@@ -319,7 +321,7 @@ struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin f
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
 template <bool ADAM, bool YV>
 __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
-                                     const int64_t eo) {
+                                     const int64_t eo, const int64_t eg) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -333,8 +335,8 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   // optimiser operands of what this thread finishes, fetched with the first batch of loads
   const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
   const bool own = grow < P.w && gcol < P.N;
-  float* const dst = P.dW + eo + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
-  const int64_t pidx = ADAM ? (int64_t)(dst - eo - A.grad) : 0;      // parameter index, addressed at index + eo
+  float* const dst = P.dW + eg + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - eg - A.grad) : 0;      // parameter index, addressed at index + eo
   const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
   const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
@@ -415,7 +417,7 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
       float gb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.db[eo + n0 + tid] = gb;
+      P.db[eg + n0 + tid] = gb;
       if (ADAM && !faulted) {
         const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
         A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
@@ -426,7 +428,7 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
 
 template <bool ADAM>
 __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
-                                     const int64_t eo) {
+                                     const int64_t eo, const int64_t eg) {
   const int tid = threadIdx.x;
   // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
   // arithmetic, so the descriptor load does not wait for a search through the table
@@ -460,20 +462,22 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
   }
   const DwSmall& P = args.p[pi];
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo);
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg);
 }
 
 // Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
 // hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
 // launches only bought a second ~4.5 us dependent stage).
+// (batched experts: blockIdx.y = expert, as in dw_adam_her_kernel below)
 struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
-__global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
+__global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args, int64_t ex_stride, int64_t grad_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   AdamFuse none;
   none.fault = nullptr;
-  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red, 0);
-  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red, 0);
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
+  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red, eo, eg);
+  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red, eo, eg);
 }
 
 // The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
@@ -483,11 +487,11 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args) {
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
 __global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her,
-                                                          int64_t ex_stride, uint64_t seed_stride) {
+                                                          int64_t ex_stride, int64_t grad_stride, uint64_t seed_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const int bid = (int)blockIdx.x - n_her;
-  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
   if (bid < 0) her_sample_body(h, blockIdx.x, red, eo, (uint64_t)blockIdx.y * seed_stride);
-  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red, eo);
-  else dw_small_body<true>(args.small, A, bid - args.n_hot, red, eo);
+  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red, eo, eg);
+  else dw_small_body<true>(args.small, A, bid - args.n_hot, red, eo, eg);
 }

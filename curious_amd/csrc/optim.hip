@@ -23,16 +23,23 @@ struct AdamArgs {
                                   // keep.fault: fault word of the gradient workspace (non-zero = the launch leaves
                                   // theta / m / v / the copies alone) or NULL
 };
-__device__ __forceinline__ bool adam_faulted(const AdamArgs& a) { return a.keep.fault && *a.keep.fault != 0; }
+// Batched experts (curious_adam_update_and_sample_experts): blockIdx.y = expert; eo = its slab offset (parameters,
+// moments, step counter, step-size ring, transposed copies, fault word), eg = its offset in the contiguous gradient block.
+__device__ __forceinline__ const int64_t* opt_i64(const int64_t* p, int64_t eo) {
+  return reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(p) + eo);
+}
+__device__ __forceinline__ bool adam_faulted(const AdamArgs& a, const int64_t eo) {
+  return a.keep.fault && *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(a.keep.fault) + eo) != 0;
+}
 
-__device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi) {
+__device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi, const int64_t eo) {
   aQ = a.a_Q; aPi = a.a_pi;
   if (a.alpha_tab) {
     // the step counter was advanced by ddpg_grads; the table is a ring refilled by the host every tab_len steps
-    int64_t idx = ((*a.step_ctr) - 1 - a.tab_base) % a.tab_len;
+    int64_t idx = ((*opt_i64(a.step_ctr, eo)) - 1 - a.tab_base) % a.tab_len;
     if (idx < 0) idx += a.tab_len;
-    aQ = a.alpha_tab[2 * idx];
-    aPi = a.alpha_tab[2 * idx + 1];
+    aQ = a.alpha_tab[eo + 2 * idx];
+    aPi = a.alpha_tab[eo + 2 * idx + 1];
   }
 }
 // the arithmetic of one element (mpi_adam.py:31-34); returns the new parameter
@@ -43,23 +50,25 @@ __device__ __forceinline__ float adam_math(const AdamArgs& a, const float na, co
   const float step = fdiv(__fmul_rn(na, m), __fadd_rn(sqrtf(v), a.eps));            // mpi_adam.py:33
   return __fadd_rn(th, step);                                                       // mpi_adam.py:34
 }
-__device__ __forceinline__ void adam_one(const AdamArgs& a, const int64_t i, const float aQ, const float aPi) {
-  float m = a.m[i], v = a.v[i];
-  const float th = adam_math(a, (i < a.n_Q) ? -aQ : -aPi, a.grad[i], m, v, a.theta[i]);
-  a.m[i] = m;
-  a.v[i] = v;
-  a.theta[i] = th;
+__device__ __forceinline__ void adam_one(const AdamArgs& a, const int64_t i, const float aQ, const float aPi,
+                                         const int64_t eo, const int64_t eg) {
+  float m = a.m[i + eo], v = a.v[i + eo];
+  const float th = adam_math(a, (i < a.n_Q) ? -aQ : -aPi, a.grad[i + eg], m, v, a.theta[i + eo]);
+  a.m[i + eo] = m;
+  a.v[i + eo] = v;
+  a.theta[i + eo] = th;
 }
 
-__device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks) {
-  if (adam_faulted(a)) return;
+__device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks, const int64_t eo,
+                                          const int64_t eg) {
+  if (adam_faulted(a, eo)) return;
   float aQ, aPi;
-  adam_alphas(a, aQ, aPi);
+  adam_alphas(a, aQ, aPi, eo);
   const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
   for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.n; i += (int64_t)nblocks * 256) {
     bool tiled = false;                                     // inside a matrix the tile blocks below take care of
     for (int j = 0; j < a.keep.n; ++j) tiled |= (uint64_t)(i - a.keep.src_off[j]) < (uint64_t)msize;
-    if (!tiled) adam_one(a, i, aQ, aPi);
+    if (!tiled) adam_one(a, i, aQ, aPi, eo, eg);
   }
 }
 
@@ -67,10 +76,11 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
 // goes through LDS to the copy (WT[n][k] = W[k][n]), both sides in 128-byte row segments.  (4 elements per thread: a
 // 64 x 64 tile made these 64 blocks the long pole of the launch, +3 us.)
 #define ADAM_TILE 32
-__device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1]) {
-  if (adam_faulted(a)) return;
+__device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1],
+                                               const int64_t eo, const int64_t eg) {
+  if (adam_faulted(a, eo)) return;
   float aQ, aPi;
-  adam_alphas(a, aQ, aPi);
+  adam_alphas(a, aQ, aPi, eo);
   const int dim = a.keep.dim, per = dim / ADAM_TILE;
   const int j = tb / (per * per), t = tb - j * per * per;
   const int k0 = (t / per) * ADAM_TILE, n0 = (t % per) * ADAM_TILE;
@@ -83,18 +93,18 @@ __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, 
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int64_t e = base + (int64_t)(k0 + 8 * i + r8) * dim + n0 + c;
-    g[i] = a.grad[e]; m[i] = a.m[e]; v[i] = a.v[e]; th[i] = a.theta[e];
+    g[i] = a.grad[e + eg]; m[i] = a.m[e + eo]; v[i] = a.v[e + eo]; th[i] = a.theta[e + eo];
   }
   const float na = (base < a.n_Q) ? -aQ : -aPi;             // a matrix lies inside one network
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int64_t e = base + (int64_t)(k0 + 8 * i + r8) * dim + n0 + c;
     th[i] = adam_math(a, na, g[i], m[i], v[i], th[i]);
-    a.m[e] = m[i]; a.v[e] = v[i]; a.theta[e] = th[i];
+    a.m[e + eo] = m[i]; a.v[e + eo] = v[i]; a.theta[e + eo] = th[i];
     tile[8 * i + r8][c] = th[i];
   }
   __syncthreads();
-  float* dst = a.keep.dst[j];
+  float* dst = a.keep.dst[j] + eo;
 #pragma unroll
   for (int i = 0; i < NE; ++i) dst[(int64_t)(n0 + 8 * i + r8) * dim + k0 + c] = tile[c][8 * i + r8];
 }
@@ -105,20 +115,23 @@ static inline int adam_tiles(const AdamArgs& a) {
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int n_tile) {
   __shared__ float tile[ADAM_TILE][ADAM_TILE + 1];
-  if ((int)blockIdx.x < n_tile) adam_tile_body(a, blockIdx.x, tile);
-  else adam_body(a, blockIdx.x - n_tile, gridDim.x - n_tile);
+  if ((int)blockIdx.x < n_tile) adam_tile_body(a, blockIdx.x, tile, 0, 0);
+  else adam_body(a, blockIdx.x - n_tile, gridDim.x - n_tile, 0, 0);
 }
 
 // Adam + the HER gather of the NEXT update in one launch: the gather does not depend on the parameters, so its
 // workgroups (the first n_her blocks) ride along with the optimiser's instead of being a dependent launch of their
 // own at the head of the next update (~7 us per update).  Stream order guarantees that every reader of the previous
 // staged batch (layer-0 forward, layer-0 weight gradients) has finished before this launch starts.
-__global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her, int n_tile) {
+// (batched experts: grid.y = expert)
+__global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her, int n_tile, int64_t ex_stride,
+                                                       int64_t grad_stride, uint64_t seed_stride) {
   extern __shared__ float lds[];
-  if ((int)blockIdx.x < n_her) her_sample_body(h, blockIdx.x, lds);
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
+  if ((int)blockIdx.x < n_her) her_sample_body(h, blockIdx.x, lds, eo, (uint64_t)blockIdx.y * seed_stride);
   else if ((int)blockIdx.x < n_her + n_tile)
-    adam_tile_body(a, blockIdx.x - n_her, reinterpret_cast<float(*)[ADAM_TILE + 1]>(lds));
-  else adam_body(a, blockIdx.x - n_her - n_tile, gridDim.x - n_her - n_tile);
+    adam_tile_body(a, blockIdx.x - n_her, reinterpret_cast<float(*)[ADAM_TILE + 1]>(lds), eo, eg);
+  else adam_body(a, blockIdx.x - n_her - n_tile, gridDim.x - n_her - n_tile, eo, eg);
 }
 
 static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
@@ -147,15 +160,14 @@ static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float*
   return 0;
 }
 
-extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, const float* grad, int64_t n_Q,
-                                              int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,
-                                              int64_t tab_base, int32_t tab_len, const float* alpha_host, float beta1,
-                                              float one_minus_beta1, float beta2, float one_minus_beta2, float epsilon,
-                                              const float* storage, int64_t buf_stride, const curious_layout_t* L,
-                                              const curious_tasks_t* tasks, const curious_sample_params_t* P,
-                                              const curious_sample_rng_t* rng, int32_t n, float* batch,
-                                              const curious_batch_layout_t* BL, const curious_transposed_t* keep,
-                                              curious_stream_t stream) {
+static int adam_and_sample(int32_t n_experts, int64_t expert_stride, int64_t grad_stride, uint64_t seed_stride,
+                           float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
+                           const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
+                           const float* alpha_host, float beta1, float one_minus_beta1, float beta2,
+                           float one_minus_beta2, float epsilon, const float* storage, int64_t buf_stride,
+                           const curious_layout_t* L, const curious_tasks_t* tasks, const curious_sample_params_t* P,
+                           const curious_sample_rng_t* rng, int32_t n, float* batch, const curious_batch_layout_t* BL,
+                           const curious_transposed_t* keep, curious_stream_t stream) {
   AdamArgs a;
   if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
                 one_minus_beta1, beta2, one_minus_beta2, epsilon, keep)) return -1;
@@ -169,10 +181,45 @@ extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, 
   size_t lds = her_lds_bytes(L);
   if (n_tile && lds < sizeof(float) * ADAM_TILE * (ADAM_TILE + 1)) lds = sizeof(float) * ADAM_TILE * (ADAM_TILE + 1);
   { ProfScope ps__(CK_ADAM_HER, as_stream(stream));
-    hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + n_tile + blocks), dim3(256), lds, as_stream(stream), a, h, n_her,
-                       n_tile); }
+    hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + n_tile + blocks, n_experts), dim3(256), lds, as_stream(stream), a,
+                       h, n_her, n_tile, expert_stride, grad_stride, seed_stride); }
   CURIOUS_LAUNCH_CHECK("adam_her_kernel");
   return 0;
+}
+
+extern "C" int curious_adam_update_and_sample(float* theta, float* m, float* v, const float* grad, int64_t n_Q,
+                                              int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,
+                                              int64_t tab_base, int32_t tab_len, const float* alpha_host, float beta1,
+                                              float one_minus_beta1, float beta2, float one_minus_beta2, float epsilon,
+                                              const float* storage, int64_t buf_stride, const curious_layout_t* L,
+                                              const curious_tasks_t* tasks, const curious_sample_params_t* P,
+                                              const curious_sample_rng_t* rng, int32_t n, float* batch,
+                                              const curious_batch_layout_t* BL, const curious_transposed_t* keep,
+                                              curious_stream_t stream) {
+  return adam_and_sample(1, 0, 0, 0, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host,
+                         beta1, one_minus_beta1, beta2, one_minus_beta2, epsilon, storage, buf_stride, L, tasks, P, rng, n,
+                         batch, BL, keep, stream);
+}
+
+extern "C" int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_stride, int64_t grad_stride,
+                                                      uint64_t seed_stride, float* theta, float* m, float* v,
+                                                      const float* grad, int64_t n_Q, int64_t n_pi,
+                                                      const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base,
+                                                      int32_t tab_len, float beta1, float one_minus_beta1, float beta2,
+                                                      float one_minus_beta2, float epsilon, const float* storage,
+                                                      int64_t buf_stride, const curious_layout_t* L,
+                                                      const curious_tasks_t* tasks, const curious_sample_params_t* P,
+                                                      const curious_sample_rng_t* rng, int32_t n, float* batch,
+                                                      const curious_batch_layout_t* BL, const curious_transposed_t* keep,
+                                                      curious_stream_t stream) {
+  CURIOUS_CHECK(n_experts >= 1 && n_experts <= 64, "curious_adam_update_and_sample_experts: n_experts must be in 1..64");
+  CURIOUS_CHECK(n_experts == 1 || (expert_stride > 0 && expert_stride % 64 == 0 && grad_stride >= n_Q + n_pi),
+                "curious_adam_update_and_sample_experts: bad strides");
+  CURIOUS_CHECK(alpha_tab && step_ctr, "curious_adam_update_and_sample_experts: device step counter and step-size "
+                                       "table are required");
+  return adam_and_sample(n_experts, expert_stride, grad_stride, seed_stride, theta, m, v, grad, n_Q, n_pi, alpha_tab,
+                         step_ctr, tab_base, tab_len, nullptr, beta1, one_minus_beta1, beta2, one_minus_beta2, epsilon,
+                         storage, buf_stride, L, tasks, P, rng, n, batch, BL, keep, stream);
 }
 
 extern "C" int curious_adam_update(float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,

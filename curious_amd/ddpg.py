@@ -114,11 +114,12 @@ class DDPG(object):
         self._async_batch = None
 
     # ------------------------------------------------------------------ construction
-    def _new(self, shape, dtype=torch.float32):
+    def _new(self, shape, dtype=torch.float32, name=None):
         """Zero-filled device tensor holding per-agent update state.  An ExpertBank passes an allocator that carves these
-        tensors out of the agent's slab (same order and sizes for every expert -> same offsets)."""
+        tensors out of the agent's slab (same order and sizes for every expert -> same offsets; `name` lets it place the
+        gradient vector in the bank's contiguous gradient block instead)."""
         if self._alloc is not None:
-            return self._alloc(shape, dtype)
+            return self._alloc(shape, dtype, name)
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def _create_network(self, reuse=False):
@@ -139,7 +140,7 @@ class DDPG(object):
         self.theta = self._new([self.P_total])
         self.theta.copy_(torch.from_numpy(ops.pad_params(cfg, flat)))
         self.theta_target = self._new([self.P_total])
-        self.grad = self._new([self.P_total])
+        self.grad = self._new([self.P_total], name='grad')
         self._m = self._new([self.P_total])
         self._v = self._new([self.P_total])
         self.Q_adam = MpiAdam(self.theta[:self.off_pi], scale_grad_by_procs=False)       # ddpg.py:452-453

@@ -21,13 +21,21 @@ SEED_STRIDE_SAMPLER = 104729            # DDPG._refresh_device_tables: sampler k
 
 class _Carver:
     """Allocator handed to DDPG(_alloc=...): consecutive 256-byte aligned pieces of one slab row (or, in measuring mode,
-    stand-alone tensors while the total is added up)."""
+    stand-alone tensors while the total is added up).  The piece named 'grad' comes from `grad_row` instead: the
+    experts' gradient vectors form one contiguous [N, P] block, so that several ranks sum all of them in ONE all-reduce."""
 
-    def __init__(self, device, row=None):
-        self.device, self.row, self.off = device, row, 0
+    def __init__(self, device, row=None, grad_row=None):
+        self.device, self.row, self.grad_row, self.off = device, row, grad_row, 0
 
-    def __call__(self, shape, dtype):
+    def __call__(self, shape, dtype, name=None):
         n = int(np.prod(shape))
+        if name == 'grad' and dtype == torch.float32:
+            if self.row is None:
+                return torch.zeros(shape, dtype=dtype, device=self.device)
+            assert n <= self.grad_row.numel()
+            piece = self.grad_row[:n]
+            piece.zero_()
+            return piece.view(*shape)
         words = n * (2 if dtype == torch.int64 else 1)
         start = self.off
         self.off += (words + 63) & ~63
@@ -48,6 +56,11 @@ class ExpertBank:
     `make_expert(t_id, **hooks)` must build the DDPG of expert t_id (config.configure_ddpg with t_id) forwarding the
     hook keyword arguments to the DDPG constructor.  Expert seeds must be consecutive (seed_0 + t_id): the batched
     launch derives expert e's sampler key from expert 0's.
+
+    Several ranks (one process per GPU): every rank holds all N experts, its own buffers and RNG streams; per update the
+    experts' gradients -- one contiguous [N, P] block -- are summed over the ranks by ONE all-reduce between the gradient
+    launches and the optimiser launch (the reference: 2 N MpiAdam.update Allreduces per round of updates,
+    train.py:65-121, mpi_adam.py:21-35).
     """
 
     def __init__(self, make_expert, n_experts):
@@ -57,11 +70,13 @@ class ExpertBank:
         probe = make_expert(0, _alloc=probe_alloc)
         probe._prealloc_device_loop()
         self.stride = (probe_alloc.off + 63) & ~63
+        self.grad_stride = (probe.P_total + 63) & ~63
         del probe
         self.slab = torch.zeros([self.n, self.stride], dtype=torch.float32, device=dev)
+        self.grads = torch.zeros([self.n, self.grad_stride], dtype=torch.float32, device=dev)
         self.experts = []
         for e in range(self.n):
-            x = make_expert(e, _alloc=_Carver(dev, self.slab[e]))
+            x = make_expert(e, _alloc=_Carver(dev, self.slab[e], self.grads[e]))
             x._prealloc_device_loop()
             self.experts.append(x)
         x0 = self.experts[0]
@@ -70,10 +85,11 @@ class ExpertBank:
                 raise ValueError('expert seeds must be consecutive (seed_0 + t_id)')
             if not x._device_loop() or x.normalize_obs:
                 raise ValueError("the batched update needs rng_mode='device', per-task buffers and normalize_obs=False")
-            for name in ('theta', 'theta_target', 'grad', '_m', '_v', '_workspace', '_losses', '_Q_pi', '_step_ctr',
+            for name in ('theta', 'theta_target', '_m', '_v', '_workspace', '_losses', '_Q_pi', '_step_ctr',
                          '_alpha_tab', '_tables'):
                 a, b = getattr(x, name), getattr(x0, name)
                 assert a.data_ptr() - b.data_ptr() == 4 * e * self.stride, name
+            assert x.grad.data_ptr() - x0.grad.data_ptr() == 4 * e * self.grad_stride
         self.use_graph = bool(x0.use_graph)
         self._graphs = {}
         self._cur = 0
@@ -108,11 +124,37 @@ class ExpertBank:
     def _update_all(self, p, chained=False):
         x0 = self.experts[0]
         S = x0.sample_transitions
-        ops.ddpg_update_experts(x0.net_cfg, self.n, self.stride, SEED_STRIDE_SAMPLER, x0.theta, x0.theta_target,
-                                x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi,
-                                x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base, x0._pp[p ^ 1],
-                                x0._pool.storage, x0._pool.buf_stride, S.tasks,
+        ops.ddpg_update_experts(x0.net_cfg, self.n, self.stride, self.grad_stride, SEED_STRIDE_SAMPLER, x0.theta,
+                                x0.theta_target, x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad,
+                                x0._losses, x0._Q_pi, x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base,
+                                x0._pp[p ^ 1], x0._pool.storage, x0._pool.buf_stride, S.tasks,
                                 S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, params_unchanged=chained)
+
+    # the two halves of an update on several ranks: the all-reduce of the gradient block sits between them
+    def _grads_all(self, p, chained=False):
+        x0 = self.experts[0]
+        ops.ddpg_grads_experts(x0.net_cfg, self.n, self.stride, self.grad_stride, x0.theta, x0.theta_target, x0._pp[p],
+                               x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi, x0._step_ctr,
+                               params_unchanged=chained)
+
+    def _adam_all(self, p):
+        """Adam of every expert from the summed gradients + the gather of every expert's next batch into the SAME
+        staging tensor (the gradient launches that read it have finished: stream order)."""
+        x0 = self.experts[0]
+        S = x0.sample_transitions
+        ops.adam_update_and_sample_experts(self.n, self.stride, self.grad_stride, SEED_STRIDE_SAMPLER, x0.theta, x0._m,
+                                           x0._v, x0.grad, x0.off_pi, x0.P_total - x0.off_pi, x0._alpha_tab,
+                                           x0._step_ctr, x0._alpha_base, x0._pool.storage, x0._pool.buf_stride,
+                                           x0._layout, S.tasks, S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc,
+                                           x0.batch_size, x0._pp[p], keep=x0._kept_copies())
+
+    def _allreduce(self):
+        dist.allreduce_sum_(self.grads)                      # ONE collective: N x P floats, SUM (mpi_adam.py:26)
+
+    def _ranks_update_all(self, p, chained=False):
+        self._grads_all(p, chained)
+        self._allreduce()
+        self._adam_all(p)
 
     def _capture(self, fn):
         """Capture `fn` after one eager warm-up; the slab (all experts' state) is restored afterwards."""
@@ -129,29 +171,60 @@ class ExpertBank:
         self.slab.copy_(saved)
         return g
 
+    def _graph(self, key, fn):
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(fn)
+            for x in self.experts:                           # the warm-up overwrote the staged batches
+                x._sample_packed()
+        return self._graphs[key]
+
     def _train(self, k):
         """k updates of every expert (k = 1, CHAIN or LONG_CHAIN)."""
         if dist.is_distributed():
-            raise NotImplementedError('the batched expert update runs on one rank per replica set; use '
-                                      'experts_update=sequential with several ranks')
+            return self._train_ranks(k)
         self._prologue(k)
         p0 = self._cur
         if self.use_graph:
-            key = (k, p0)
-            if key not in self._graphs:
-                self._graphs[key] = self._capture(lambda: [self._update_all((p0 + i) & 1, i > 0) for i in range(k)])
-                for x in self.experts:                       # the warm-up overwrote the staged batches
-                    x._sample_packed()
-            self._graphs[key].replay()
+            self._graph((k, p0), lambda: [self._update_all((p0 + i) & 1, i > 0) for i in range(k)]).replay()
         else:
             for i in range(k):
                 self._update_all((p0 + i) & 1, i > 0)
         self._cur ^= (k & 1)
+        self._advance(k)
+
+    def _advance(self, k):
         for x in self.experts:
             x._cur = self._cur
             x._staged = x._pp[x._cur]
             x.Q_adam.t += k
             x.pi_adam.t += k
+
+    def _train_ranks(self, k):
+        """k updates of every expert on several ranks.  One staging tensor (parity never flips).  With the collective
+        captured (dist.captured_allreduce_ok) a chain of k updates is ONE graph launch; otherwise the eager all-reduce
+        separates graph A (gradients) from graph B (optimiser + next gather), software-pipelined as B(i) + A(i + 1)."""
+        self._prologue(k)
+        p = self._cur
+        x0 = self.experts[0]
+        if x0.Q_adam.t % 100 == 0:                           # C4 (mpi_adam.py:42-50): every 100 updates, parameters at
+            for x in self.experts:                           # rest (chains start on multiples of their length)
+                x._check_synced()
+        if not self.use_graph:
+            for i in range(k):
+                self._ranks_update_all(p, i > 0)
+        elif dist.captured_allreduce_ok():
+            self._graph(('ranks', k, p), lambda: [self._ranks_update_all(p, i > 0) for i in range(k)]).replay()
+        else:
+            ga = self._graph(('A', p), lambda: self._grads_all(p))
+            gb = self._graph(('B', p), lambda: self._adam_all(p))
+            gba = self._graph(('BA', p), lambda: (self._adam_all(p), self._grads_all(p, True)))
+            ga.replay()
+            for i in range(1, k):
+                self._allreduce()
+                gba.replay()
+            self._allreduce()
+            gb.replay()
+        self._advance(k)
 
     def train(self):
         """One update of every expert.  Returns [(critic_loss, Q_pi)] per expert (GPU tensors)."""
@@ -166,6 +239,10 @@ class ExpertBank:
                 k = 1
                 if self.use_graph and self._cur == 0 and n >= CHAIN:
                     k = LONG_CHAIN if n >= LONG_CHAIN else CHAIN
+                if dist.is_distributed() and k > 1:
+                    # chains start on multiples of their length so that the every-100 check falls on a chain head
+                    t = self.experts[0].Q_adam.t
+                    k = LONG_CHAIN if (n >= LONG_CHAIN and t % LONG_CHAIN == 0) else CHAIN if t % CHAIN == 0 else 1
                 self._train(k)
                 n -= k
         except _lib.CuriousHipError as err:

@@ -215,11 +215,41 @@ def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsi
     return A
 
 
-def ddpg_update_experts(cfg, n_experts, expert_stride, seed_stride, theta_main, theta_target, batch, layout, B,
-                        workspace, grad, out_losses, out_Q_pi, m, v, step_ctr, alpha_tab, tab_base, next_batch, storage,
-                        buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08, params_unchanged=False):
+def ddpg_grads_experts(cfg, n_experts, expert_stride, grad_stride, theta_main, theta_target, batch, layout, B, workspace,
+                       grad, out_losses, out_Q_pi, step_ctr, params_unchanged=False):
+    """curious_ddpg_grads for n_experts agents in one launch sequence (the first half of a data-parallel batched
+    update); tensors as in ddpg_update_experts."""
+    BL = layout.c_batch_layout()
+    check(lib().curious_ddpg_grads_experts(C.byref(cfg), int(n_experts), int(expert_stride), int(grad_stride),
+                                           ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
+                                           ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),
+                                           ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr), int(bool(params_unchanged)),
+                                           current_stream()), 'curious_ddpg_grads_experts')
+
+
+def adam_update_and_sample_experts(n_experts, expert_stride, grad_stride, seed_stride, theta, m, v, grad, n_Q, n_pi,
+                                   alpha_tab, step_ctr, tab_base, storage, buf_stride, layout, tasks, params, rng, n,
+                                   batch, beta1=0.9, beta2=0.999, epsilon=1e-08, keep=None):
+    """adam_update_and_sample for n_experts agents in one launch (the second half of a data-parallel batched update)."""
+    f = np.float32
+    L = layout.c_layout()
+    BL = layout.c_batch_layout()
+    check(lib().curious_adam_update_and_sample_experts(
+        int(n_experts), int(expert_stride), int(grad_stride), int(seed_stride) & 0xFFFFFFFFFFFFFFFF,
+        ptr(_dev(theta, 'theta')), ptr(m), ptr(v), ptr(grad), int(n_Q), int(n_pi), ptr(alpha_tab), ptr(step_ctr),
+        int(tab_base), int(alpha_tab.shape[0]), float(f(beta1)), float(f(1 - beta1)), float(f(beta2)),
+        float(f(1 - beta2)), float(f(epsilon)), ptr(_dev(storage, 'storage')), int(buf_stride), C.byref(L),
+        C.byref(tasks), C.byref(params), C.byref(rng), int(n), ptr(batch), C.byref(BL),
+        C.byref(keep) if keep is not None else None, current_stream()), 'curious_adam_update_and_sample_experts')
+
+
+def ddpg_update_experts(cfg, n_experts, expert_stride, grad_stride, seed_stride, theta_main, theta_target, batch, layout,
+                        B, workspace, grad, out_losses, out_Q_pi, m, v, step_ctr, alpha_tab, tab_base, next_batch,
+                        storage, buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08,
+                        params_unchanged=False):
     """One update of n_experts agents in one launch sequence (curious_ddpg_update_experts).  Every tensor is expert
-    0's view of a slab [n_experts, expert_stride]; `rng` is expert 0's sampler description."""
+    0's view of a slab [n_experts, expert_stride] (the gradients: of a block [n_experts, grad_stride]); `rng` is expert
+    0's sampler description."""
     BL = layout.c_batch_layout()
     A = _adam_state(m, v, alpha_tab, tab_base, 0.0, 0.0, beta1, beta2, epsilon, params_unchanged)
     L = layout.c_layout()
@@ -227,7 +257,7 @@ def ddpg_update_experts(cfg, n_experts, expert_stride, seed_stride, theta_main, 
     N.storage, N.buf_stride = ptr(_dev(storage, 'storage')), int(buf_stride)
     N.L, N.tasks, N.P, N.rng = C.pointer(L), C.pointer(tasks), C.pointer(params), C.pointer(rng)
     N.batch = ptr(_dev(next_batch, 'next_batch'))
-    check(lib().curious_ddpg_update_experts(C.byref(cfg), int(n_experts), int(expert_stride),
+    check(lib().curious_ddpg_update_experts(C.byref(cfg), int(n_experts), int(expert_stride), int(grad_stride),
                                             int(seed_stride) & 0xFFFFFFFFFFFFFFFF,
                                             ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
                                             ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),

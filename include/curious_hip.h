@@ -330,19 +330,47 @@ int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const f
 /* Batched task_experts update (BASELINE configs[4]): curious_ddpg_update for n_experts agents of identical shape in
  * ONE launch sequence (2 launches on the row-local route, grid.z / grid.y carry the expert).  The reference keeps one DDPG per task on shared
  * buffers and trains them one after the other (train.py:65-121; sampling rule ddpg.py:302-318,335).  Every per-expert
- * array -- theta_main, theta_target, batch, workspace, grad, out_losses, out_Q_pi, step_ctr, adam->m / v / alpha_tab,
+ * array -- theta_main, theta_target, batch, workspace, out_losses, out_Q_pi, step_ctr, adam->m / v / alpha_tab,
  * next->batch and the sampling tables of next->rng (prop_prefix, cur_size, buf_alias, buf_task, step_ctr) -- is passed
  * for expert 0 and lives at the same offset of a per-expert slab; expert e's copy is expert_stride FLOATS (a multiple
- * of 64) further.  Shared: next->storage, the layouts, tasks, sampler parameters.  Expert e draws its batches with the
+ * of 64) further.  The gradient vectors have a stride of their own (grad_stride floats, a multiple of 64 >=
+ * curious_param_total(): a contiguous [n_experts][grad_stride] block, see curious_ddpg_grads_experts).  Shared:
+ * next->storage, the layouts, tasks, sampler parameters.  Expert e draws its batches with the
  * Philox key next->rng->seed + e * seed_stride.  Results per expert are bit-identical to curious_ddpg_update on that
  * expert alone.  Requires the fast routes (modular nets, hidden 256, 2-3 layers, dimu 4, B % 256 == 0, no input normalisation) and
  * fails with an error otherwise (the caller then updates the experts one by one). */
 int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
-                                uint64_t seed_stride, float* theta_main, const float* theta_target,
-                                const float* batch, const curious_batch_layout_t* BL, int32_t B, float* workspace,
-                                float* grad, float* out_losses, float* out_Q_pi, int64_t* step_ctr,
-                                const curious_adam_state_t* adam, const curious_next_batch_t* next,
+                                int64_t grad_stride, uint64_t seed_stride, float* theta_main,
+                                const float* theta_target, const float* batch, const curious_batch_layout_t* BL,
+                                int32_t B, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                                int64_t* step_ctr, const curious_adam_state_t* adam, const curious_next_batch_t* next,
                                 curious_stream_t stream);
+
+/* The two halves of curious_ddpg_update_experts for DATA-PARALLEL batched experts (BASELINE configs[4] on several
+ * GPUs): the reference runs task_experts under MPI like everything else -- every expert's two MpiAdam instances sum
+ * their gradients over the ranks (train.py:65-121, mpi_adam.py:21-35) -- so between the halves the caller all-reduces
+ * (SUM) the experts' gradients.  They are kept in ONE contiguous block [n_experts][grad_stride] (`grad` = expert 0's
+ * vector), which makes that a single collective over n_experts * P floats (4.7 MB at 4 experts).
+ *   curious_ddpg_grads_experts: curious_ddpg_grads for every expert (row-local pass + one weight-gradient launch);
+ *   curious_adam_update_and_sample_experts: curious_adam_update_and_sample for every expert (grid.y = expert): Adam
+ *     from the summed gradients + the HER gather of every expert's next batch; `keep` = curious_ddpg_transposed() of
+ *     expert 0's workspace (copies and fault word of expert e: expert_stride floats further).
+ * Per expert the results are bit-identical to curious_ddpg_grads / curious_adam_update_and_sample on that expert alone,
+ * and -- with one rank -- to curious_ddpg_update_experts. */
+int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
+                               int64_t grad_stride, const float* theta_main, const float* theta_target,
+                               const float* batch, const curious_batch_layout_t* BL, int32_t B, float* workspace,
+                               float* grad, float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                               int32_t params_unchanged, curious_stream_t stream);
+int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_stride, int64_t grad_stride,
+                                           uint64_t seed_stride, float* theta, float* m, float* v, const float* grad,
+                                           int64_t n_Q, int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,
+                                           int64_t tab_base, int32_t tab_len, float beta1, float one_minus_beta1,
+                                           float beta2, float one_minus_beta2, float epsilon, const float* storage,
+                                           int64_t buf_stride, const curious_layout_t* L, const curious_tasks_t* tasks,
+                                           const curious_sample_params_t* P, const curious_sample_rng_t* rng, int32_t n,
+                                           float* batch, const curious_batch_layout_t* BL,
+                                           const curious_transposed_t* keep, curious_stream_t stream);
 
 /* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
  * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */

@@ -261,6 +261,67 @@ def test_exchange_steps_at_world_4_and_8(world):
     assert sum(out[0]['qsizes']) > 0
 
 
+# ------------------------------------------------------------------ data-parallel batched experts (configs[4] at N > 1)
+def _expert_block_sum(rank, world):
+    """N task experts per rank; the reference all-reduces every expert's Q and pi gradient on its own (2 N Allreduces per
+    round of updates: train.py:65-121, mpi_adam.py:21-35).  ExpertBank keeps the N gradient vectors in one [N, P] block
+    (padded like the device layout) and sums it over the ranks with ONE collective; both ways must give every expert
+    the same parameters, bit for bit."""
+    from curious_amd import dist
+    from oracle.ddpg import OracleDDPG, STAGE_KEYS
+    nb, dimo, B, Tn, hidden = 3, 10, 16, 5, 24
+    G = 3 * nb
+    ids = [[3 * j, 3 * j + 1, 3 * j + 2] for j in range(nb)]
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+
+    def allreduce(x):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        dist.allreduce_sum_(t)
+        return t.numpy()
+
+    def experts(hook):
+        return [OracleDDPG(dims, Tn, [None] * (nb + 1), None, ids, ids, hidden=hidden, layers=2, batch_size=B,
+                           structure='task_experts', t_id=e, task_replay='replay_current_task_buffer',
+                           weight_rng=np.random.RandomState(7 + e), allreduce_sum=hook) for e in range(nb)]
+    ref, blk = experts(allreduce), experts(None)
+    P_Q, P = ref[0].math.P_Q, ref[0].theta.shape[0]
+    off_pi = (P_Q + 63) & ~63
+    stride = off_pi + ((P - P_Q + 63) & ~63)                        # the padded device layout [Q | pad | pi | pad]
+    rng = np.random.RandomState(50 + rank)                            # rank-private data
+    n_collectives = [0]
+    for step in range(3):
+        block = np.zeros([nb, stride], np.float32)
+        outs = []
+        for e in range(nb):
+            shapes = dict(ag=G, g=G, o=dimo, task_descr=nb, u=4, o_2=dimo, g_2=G, r=1)
+            batch = [rng.randn(B, shapes[k]).astype(np.float32) for k in STAGE_KEYS]
+            ref[e].train([b.copy() for b in batch])                  # 2 all-reduces inside
+            out = blk[e].grads(batch)
+            block[e, :P_Q] = out['Q_grad']
+            block[e, off_pi:off_pi + P - P_Q] = out['pi_grad']
+            outs.append(out)
+        block = allreduce(block)                                     # ONE all-reduce of N x P
+        n_collectives[0] += 1
+        for e in range(nb):
+            blk[e]._allreduce_sum = None
+            g = dict(Q_grad=block[e, :P_Q], pi_grad=block[e, off_pi:off_pi + P - P_Q])
+            orig = blk[e].grads
+            blk[e].grads = lambda b, g=g, o=outs[e]: dict(o, **g)    # feed train() the summed gradients
+            blk[e].train([None] * len(STAGE_KEYS))
+            blk[e].grads = orig
+    return dict(ref=[x.theta.copy() for x in ref], blk=[x.theta.copy() for x in blk], pads=float(np.abs(
+        block[:, P_Q:off_pi]).sum()), n=n_collectives[0])
+
+
+def test_expert_gradient_block_is_summed_by_one_collective():
+    out = run2('_expert_block_sum')
+    for e in range(3):
+        np.testing.assert_array_equal(out[0]['ref'][e], out[0]['blk'][e])        # one N x P sum == 2 N separate sums
+        np.testing.assert_array_equal(out[0]['blk'][e], out[1]['blk'][e])        # and the replicas agree
+    assert not np.array_equal(out[0]['blk'][0], out[0]['blk'][1])                # experts stay distinct
+    assert out[0]['pads'] == 0.0 and out[0]['n'] == 3
+
+
 # ------------------------------------------------------------------ bench.py's multi-process CPU baseline leg
 def test_cpu_baseline_ranks_leg_of_bench():
     """bench.py cpu_baseline_ranks (SURVEY 8d ii): R single-threaded oracle processes, gradients summed over gloo."""

@@ -14,6 +14,8 @@ def main():
     from curious_amd import dist
     dist.init_from_env()
     torch.cuda.set_device(dist.local_device_index())
+    if os.environ.get('CURIOUS_RANK_CHECK_STRUCTURE') == 'task_experts':
+        return experts_main()
     params, dims, policy, worker = bench.build_job(use_graph=True)
     bench.prefill(policy, 256, seed=dist.rank())
     for _ in range(5):
@@ -35,6 +37,34 @@ def main():
     # clean shutdown: captured graphs are dropped before the process group is destroyed
     from curious_amd.experiment.train import shutdown
     shutdown([policy])
+
+
+def experts_main():
+    """The same for the batched task experts (BASELINE configs[4]): 4 experts, every update of all of them in one launch
+    sequence; with several ranks ONE all-reduce of the [4, P] gradient block per update."""
+    from curious_amd import dist
+    params, dims, bank, workers = bench.build_experts_job(use_graph=os.environ.get('CURIOUS_RANK_CHECK_GRAPH', '1') != '0')
+    bench.prefill(bank[0], 256, seed=dist.rank())
+    bank.train_batches(3)                                     # singles
+    bank.train_batches(32)                                    # chains of 10 + singles
+    for k in range(int(os.environ.get('CURIOUS_RANK_CHECK_CYCLES', '0'))):
+        bench.experts_cycle(bank, workers, k)
+    torch.cuda.synchronize()
+    bank.check_faults()
+    assert bank.batched
+    h = hashlib.sha256()
+    for x in bank:
+        h.update(x.theta.cpu().numpy().tobytes())
+    line = 'DIGEST %s %d %r captured=%s\n' % (h.hexdigest(), int(bank[0]._step_ctr), float(bank[3]._losses[0]),
+                                              dist.captured_allreduce_ok() if dist.is_distributed() else None)
+    out = os.environ.get('CURIOUS_RANK_CHECK_OUT')
+    if out:
+        with open('%s.rank%d' % (out, dist.rank()), 'w') as f:
+            f.write(line)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    from curious_amd.experiment.train import shutdown
+    shutdown(list(bank), bank)
 
 
 if __name__ == '__main__':
