@@ -434,7 +434,9 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
         __hip_atomic_store(qt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // consumed
         if (!got && a.fault) atomicAdd(reinterpret_cast<int32_t*>(reinterpret_cast<float*>(a.fault) + eo), 1);
       }
-      const float target = fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi);                // ddpg.py:437-438
+      // (fminf / fmaxf drop a NaN operand, so the clip alone would turn a missing Q' into the target clip_lo: the NaN is
+      //  re-injected behind it -- a faulted update reports a NaN loss as well as the fault word)
+      const float target = got ? fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi) : NAN;    // ddpg.py:437-438
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
       if (x.lane == 0) {

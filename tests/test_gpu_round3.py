@@ -136,6 +136,7 @@ def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
                       eval=False)
     w.seed(5)
     np.random.seed(8)
+    w._decide_exploit = lambda: None                                 # no exploit rollouts (they wait for the flags)
     agent.store_episode(synth_episodes(np.random.RandomState(21), 24, nb, dimo), w.CP, 24)
     ep, cp, n_ep = w.generate_rollouts()
     assert getattr(w, '_pending', None) is not None                   # the async form applies
@@ -149,7 +150,7 @@ def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
 
     def poisoned_reset(tasks, goals):                                # one env starts from a NaN observation
         reset_all(tasks, goals)
-        w.benv.o[3, 1] = float('nan')
+        w.benv.o[3, 20] = float("nan")                               # an entry the env carries along unchanged
     w.benv.reset_all = poisoned_reset
     ep, cp, n_ep = w.generate_rollouts()
     w.benv.reset_all = reset_all
