@@ -94,6 +94,7 @@ CuriousOptions& curious_options() {
     if (o.xcd_map != 4 && o.xcd_map != 8) o.xcd_map = 0;
     o.fault_inject = 0;
     o.qt_spins = 1 << 22;
+    o.lab_no_target = 0;
     init = true;
   }
   return o;
@@ -106,6 +107,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "xcd_map")) return &o.xcd_map;
   if (!strcmp(name, "fault_inject")) return &o.fault_inject;
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
+  if (!strcmp(name, "lab_no_target")) return &o.lab_no_target;
   return nullptr;
 }
 extern "C" int curious_set_option(const char* name, int64_t value) {

@@ -86,6 +86,8 @@ struct CuriousOptions {
   int xcd_map;         // 0 / 4 / 8: XCD-aware block placement of fwd_hot / dx_hot (tiled route)              [CURIOUS_XCD_MAP]
   int fault_inject;    // > 0: the target group of row group (fault_inject - 1) never publishes Q' (tests)
   int qt_spins;        // polls before a consumer of Q' gives up
+  int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
+                       // wrong numbers, right timing of an update whose targets were computed elsewhere
 };
 CuriousOptions& curious_options();
 

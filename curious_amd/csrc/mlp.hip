@@ -737,6 +737,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   // option "rows_xcd" = 0: the plain block-id order (A/B); batched experts fill the chip several times over: plain order
   a.xmap = (curious_options().rows_xcd && xd.nex == 1) ? 1 : 0;
   a.fault = w.fault; a.inject = curious_options().fault_inject; a.spins = curious_options().qt_spins;
+  a.lab_no_target = curious_options().lab_no_target;
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));

@@ -62,6 +62,7 @@ struct RowsArgs {
                                   // the optimiser that follows leaves theta / m / v / the copies alone while it is set
   int32_t inject, spins;          // inject > 0 (tests): the target group of row group inject - 1 never publishes;
                                   // spins: polls before a consumer gives up
+  int32_t lab_no_target;          // lab only: no target groups, Q' = 0 (timing of an update with precomputed targets)
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   f32x4 wb[2][16];
 
   if (kind == 1) {
+    if (a.lab_no_target) return;
     // ================================================= target group: pi' = target actor(o_2, g_2), Q' = target critic
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
       int spins = 0;
       const int max_spins = a.spins > 0 ? a.spins : (1 << 22);
       for (;;) {
+        if (a.lab_no_target) { word = ROWS_QT_TAG << 32; break; }
         word = __hip_atomic_load(qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((word >> 32) == ROWS_QT_TAG || ++spins > max_spins) break;
         __builtin_amdgcn_s_sleep(1);

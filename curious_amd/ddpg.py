@@ -537,9 +537,10 @@ class DDPG(object):
         """The device can route the episodes of the coming rollout itself (curious_route_store_episodes) and nothing the
         host would compute from the rollout's flags is needed before the updates: every routed buffer is non-empty (the
         replay proportions, ddpg.py:255-286, then depend on the competence progress only).  Single agent on its own
-        buffers, single rank, device RNG (the random slots of full buffers are Philox draws in that mode)."""
+        buffers, device RNG (the random slots of full buffers are Philox draws in that mode).  With several ranks the
+        normaliser all-reduce of the store is stream-ordered like everything else: nothing here needs the host either."""
         if not (self.async_store and self.structure == 'curious' and self._multi_buffer() and self.rng_mode == 'device'
-                and not dist.is_distributed() and isinstance(self.buffer, list)):
+                and isinstance(self.buffer, list)):
             return False
         self.settle()
         nr = min(self.nb_tasks, 5)

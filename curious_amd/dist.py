@@ -47,6 +47,28 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local_device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     td.init_process_group(backend=backend)
+    host_group()                                                     # (collective: every rank creates it here)
+
+
+_HOST_GROUP = None
+
+
+def host_group():
+    """Process group for the small HOST-side exchanges (competence records C9, exploit flags, log scalars C11, pickled
+    objects C12): gloo over TCP, CPU tensors.  With RCCL as the main backend these would otherwise be GPU collectives
+    whose results the host can only read after a stream synchronisation -- i.e. after every update already enqueued --
+    while the host-side form just blocks Python, which runs ahead of the GPU anyway.  None = use the default group (the
+    main backend is gloo already, or the side group could not be created)."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None and td.is_available() and td.is_initialized():
+        if td.get_backend() == 'gloo':
+            _HOST_GROUP = False
+        else:
+            try:
+                _HOST_GROUP = td.new_group(backend='gloo')
+            except Exception:                                        # no gloo in this build: GPU collectives it is
+                _HOST_GROUP = False
+    return _HOST_GROUP or None
 
 
 def local_device_index():
@@ -78,33 +100,47 @@ def allgather(t):
 
 
 def _comm_device():
-    if is_distributed() and td.get_backend() == 'nccl':
+    if is_distributed() and td.get_backend() == 'nccl' and host_group() is None:
         return torch.device('cuda', torch.cuda.current_device())
     return torch.device('cpu')
 
 
 def allreduce_sum_numpy(x):
-    """Small host arrays (log scalars, C11)."""
+    """Small host arrays (log scalars, C11): on the host-side group."""
     if not is_distributed():
         return x
     t = torch.as_tensor(np.asarray(x, dtype=np.float64)).to(_comm_device())
-    td.all_reduce(t, op=td.ReduceOp.SUM)
+    td.all_reduce(t, op=td.ReduceOp.SUM, group=host_group())
     return t.cpu().numpy()
 
 
 def allgather_numpy(x):
-    """[n, ...] host array per rank -> [world*n, ...] (C9)."""
+    """[n, ...] host array per rank -> [world*n, ...] (C9): on the host-side group."""
     if not is_distributed():
         return np.asarray(x)
     t = torch.as_tensor(np.ascontiguousarray(x)).to(_comm_device())
-    return allgather(t).cpu().numpy()
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    td.all_gather(out, t.contiguous(), group=host_group())
+    return torch.cat(out, dim=0).cpu().numpy()
+
+
+def host_any(flag):
+    """True on every rank iff `flag` is true on at least one rank (a host-side exchange: the GPU is not involved)."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32).to(_comm_device())
+    td.all_reduce(t, op=td.ReduceOp.MAX, group=host_group())
+    return bool(int(t.item()))
 
 
 def broadcast_object(obj, root=0):
     if not is_distributed():
         return obj
     box = [obj]
-    td.broadcast_object_list(box, src=root)
+    if host_group() is not None:
+        td.broadcast_object_list(box, src=root, group=host_group(), device=torch.device('cpu'))
+    else:
+        td.broadcast_object_list(box, src=root)
     return box[0]
 
 

@@ -219,11 +219,11 @@ class RolloutWorker:
     # ------------------------------------------------------------------ rollouts whose flags the host reads late
     def _async_ok(self, env, fused):
         """Nothing the host would compute from this rollout's flags is needed before its updates are enqueued: no exploit
-        rollout (competence queues, CP and task probabilities stay as they are, rollout.py:318-330), no Q statistics, no
-        SAGG-RIAC update, one rank, and a policy that can route the episodes on the device (DDPG.can_store_async)."""
-        return (fused and not self.eval and not self.exploit and not self.compute_Q and self.structure == 'curious'
-                and self.goal_selection != 'active' and not dist.is_distributed()
-                and hasattr(self.policy, 'can_store_async')
+        rollout ON ANY RANK (competence queues, CP and task probabilities stay as they are, rollout.py:318-330), no Q
+        statistics, no SAGG-RIAC update, and a policy that can route the episodes on the device (DDPG.can_store_async).
+        A rank-local decision: a cycle without exploit rollouts has no host-side collective (see _finish_rollout)."""
+        return (fused and not self.eval and not self._any_exploit and not self.compute_Q and self.structure == 'curious'
+                and self.goal_selection != 'active' and hasattr(self.policy, 'can_store_async')
                 and self.policy.can_store_async(self.rollout_batch_size))
 
     def settle(self):
@@ -238,16 +238,24 @@ class RolloutWorker:
             self.logger.warning('NaN caught during rollout generation. Its episodes were not stored.')
             successful = np.nan_to_num(successful)
         exploit, self.exploit = self.exploit, False
+        any_exploit, self._any_exploit = getattr(self, '_any_exploit', False), False
         self.tasks, self.goals = p['tasks'], p['goals']
         self.n_episodes -= self.rollout_batch_size * self.nb_cpu     # counted when the rollout was returned
         self._finish_rollout(successful, successful - 1.0, None, p['task_list'], None)
-        self.exploit = exploit
+        self.exploit, self._any_exploit = exploit, any_exploit
 
-    def _generate_rollouts_batched(self):
+    def _generate_rollouts_batched(self, retry=False):
         self.settle()
         if hasattr(self.policy, 'settle'):
             self.policy.settle()
-        self._decide_exploit()
+        if not retry:
+            self._decide_exploit()
+            # Does ANY rank exploit in this cycle?  Exploit rollouts are the only ones that feed the (replicated)
+            # competence queues, through an all-gather every rank has to take part in (C9, rollout.py:332-336) -- so the
+            # ranks agree here, on the host (gloo side group: Python blocks, the GPU keeps working on what is enqueued),
+            # whether this cycle has that exchange at all.  (A rollout regenerated after a NaN keeps the decision: the
+            # ranks' host-side exchanges have to stay paired.)
+            self._any_exploit = True if self.eval else dist.host_any(self.exploit)
         B, env = self.rollout_batch_size, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
         tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
@@ -316,7 +324,7 @@ class RolloutWorker:
         successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
         if np.isnan(successful).any() or o_has_nan:
             self.logger.warning('NaN caught during rollout generation. Trying again...')
-            return self._generate_rollouts_batched()
+            return self._generate_rollouts_batched(retry=True)
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
         task_list = tasks.tolist()
         self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
@@ -364,10 +372,11 @@ class RolloutWorker:
         self.n_episodes += B * self.nb_cpu
         if self.structure not in ('curious', 'task_experts'):
             return
-        if not self.exploit and not dist.is_distributed() and self.goal_selection != 'active':
-            # Only exploit rollouts count (rollout.py:318-330): with one rank and no exploit rollout nothing valid
-            # arrives, the competence queues see empty lists and C, CP and the task probabilities come out as they went
-            # in.  Skipped: this sits between the end of a rollout and the launch of the updates that wait for it.
+        if not getattr(self, '_any_exploit', self.exploit or dist.is_distributed()) and self.goal_selection != 'active':
+            # Only exploit rollouts count (rollout.py:318-330): when no rank had one, nothing valid would arrive, the
+            # competence queues would see empty lists and C, CP and the task probabilities come out as they went in.
+            # Skipped on every rank alike: this sits between the end of a rollout and the launch of the updates that
+            # wait for it.  (_any_exploit: agreed between the ranks at the start of the rollout.)
             self.task_history.extend(list(self.tasks))
             self.goal_history.extend(list(self.goals))
             return
