@@ -70,7 +70,8 @@ static const char* k_names[CK_COUNT] = {
     "head_fwd_kernel", "dx_crit_kernel", "critic_head_kernel", "dx_actor_kernel", "actor_dz_kernel", "adam_kernel",
     "adam_her_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel", "env_step_kernel",
     "counter_add_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel",
-    "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel"};
+    "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel",
+    "policy_resident_kernel"};
 int64_t g_curious_launches[CK_COUNT] = {0};
 
 // launches per kernel id since the library was loaded (counted whether or not event timing is enabled, also during
@@ -95,6 +96,8 @@ CuriousOptions& curious_options() {
     o.fault_inject = 0;
     o.qt_spins = 1 << 22;
     o.lab_no_target = 0;
+    o.resident = env_int("CURIOUS_RESIDENT", 1) != 0;
+    o.res_spins = 1 << 20;
     init = true;
   }
   return o;
@@ -108,6 +111,8 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "fault_inject")) return &o.fault_inject;
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
   if (!strcmp(name, "lab_no_target")) return &o.lab_no_target;
+  if (!strcmp(name, "resident")) return &o.resident;
+  if (!strcmp(name, "res_spins")) return &o.res_spins;
   return nullptr;
 }
 extern "C" int curious_set_option(const char* name, int64_t value) {

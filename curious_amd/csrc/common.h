@@ -75,7 +75,7 @@ enum {
   CK_NORM_PAIR_FINAL, CK_FWD_LAYER0, CK_FWD_GENERIC, CK_FWD_LAYER, CK_DX, CK_DX_GENERIC, CK_DW, CK_DW_SMALL, CK_HEAD_FWD,
   CK_CRITIC_HEAD, CK_CRITIC_HEAD_GENERIC, CK_ACTOR_DZ, CK_ACTOR_DZ_GENERIC, CK_ADAM, CK_ADAM_HER, CK_POLYAK, CK_CHECKSUM,
   CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_COUNTER_ADD, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS,
-  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_COUNT
+  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_ACT_RES, CK_COUNT
 };
 extern int g_curious_prof_on;
 
@@ -86,6 +86,9 @@ struct CuriousOptions {
   int xcd_map;         // 0 / 4 / 8: XCD-aware block placement of fwd_hot / dx_hot (tiled route)              [CURIOUS_XCD_MAP]
   int fault_inject;    // > 0: the target group of row group (fault_inject - 1) never publishes Q' (tests)
   int qt_spins;        // polls before a consumer of Q' gives up
+  int resident;        // 1: multi-step rollouts keep the actor's hidden matrices in LDS (mlp_rows_res.h) when the grid fits
+                       // the device; 0: policy_rows_kernel streams them every step                     [CURIOUS_RESIDENT]
+  int res_spins;       // polls before a member of a resident-rollout group gives up on a peer
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere
 };

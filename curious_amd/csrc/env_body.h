@@ -43,6 +43,9 @@ __device__ inline EnvConsts env_consts(const curious_env_cfg_t& E, const curious
 }
 
 // v: o[e][lane] before the step (lanes >= dimo: ignored).  Returns o[e][lane] after the step.
+// STORE = false: the step is computed (return value, `next_in`) but nothing is written to global memory -- the members of
+// a workgroup group that step the same envs redundantly (mlp_rows_res.h) leave the stores to one of them.
+template <bool STORE = true>
 __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_layout_t& L, int32_t env_id0,
                                       const EnvConsts& C, const float* ue /* the env's 4 action values (global or LDS) */,
                                       int32_t t, const float v, float* __restrict__ o, float* __restrict__ ag,
@@ -90,9 +93,11 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
     } else if (i == AG + 3) {
       nv = uc[3];
     }
+    if (next_in) next_in[i] = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
+  }
+  if (STORE && i < E.dimo) {
     oe[i] = nv;
     nxt[L.off_o + i] = nv;
-    if (next_in) next_in[i] = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
     if (i < AG) {
       ag[(int64_t)e * AG + i] = nv;
       nxt[L.off_ag + i] = nv;
@@ -102,7 +107,7 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
     if (i < L.dimu) row[L.off_u + i] = ue[i];
     if (i < E.ntasks) row[L.off_td + i] = C.td_i;
   }
-  if (i + 64 < E.dimo) nxt[L.off_o + i + 64] = C.v_hi;        // entries beyond AG + 3: unchanged
+  if (STORE && i + 64 < E.dimo) nxt[L.off_o + i + 64] = C.v_hi;        // entries beyond AG + 3: unchanged
   // is_success for the env's own task: the new coordinates of the task's slots sit in lanes 3*task .. 3*task+2
   double d2 = 0.0;
 #pragma unroll
@@ -111,12 +116,12 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
     d2 = __dadd_rn(d2, __dmul_rn(d, d));
   }
   const float succ = (sqrt(d2) > reward_eps) ? 0.0f : 1.0f;
-  if (lane == 0) row[off_success] = succ;
+  if (STORE && lane == 0) row[off_success] = succ;
   // rollout flags (rollout.py:268-271,306): flags[e] = is_success of the final step, flags[n] = 1 when an observation
   // of any env ended up NaN.  flags[n] is cleared by curious_env_reset -- a launch in front of the rollout: inside the
   // multi-step kernel env 0's workgroup may well run after another workgroup has finished all its steps -- and only set
   // (every writer stores the same value) at t = T - 1.
-  if (flags) {
+  if (STORE && flags) {
     if (t == L.T - 1) {
       const bool bad = __any((i < E.dimo) && (nv != nv));
       if (lane == 0) {

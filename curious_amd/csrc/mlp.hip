@@ -40,6 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mlp_heads.h"
 #include "mlp_rows.h"
 #include "mlp_rows_act.h"
+#include "mlp_rows_res.h"
 
 // ================================================================== host side
 struct NetOff {
@@ -438,6 +439,42 @@ static bool act_rows_ok(const curious_net_cfg_t* c, int n, bool relative, const 
          aligned16(theta) && ((c->dimo + c->dimtd) % 4 == 0) && (c->dimg % 4 == 0);
 }
 
+static int device_cu_count() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+              ? prop.multiProcessorCount : 0;
+  }
+  return cus;
+}
+
+// Multi-step rollouts with the hidden matrices resident in LDS (mlp_rows_res.h): 4 workgroups per 4 envs that spin on
+// each other, so every workgroup of the launch must be resident at once -- one per CU (157 KB of LDS each).
+static bool resident_ok(const ActRowsArgs& a, int n, const float* workspace) {
+  return curious_options().resident && a.fused && a.nsteps >= 4 && (a.nl == 2 || a.nl == 3) && n >= 4 &&
+         n <= device_cu_count() && workspace != nullptr;
+}
+
+static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, hipStream_t st) {
+  ResX rx;
+  rx.xbuf = reinterpret_cast<unsigned long long*>(workspace);
+  rx.xmap = (n % 32 == 0) ? 1 : 0;
+  rx.spins = curious_options().res_spins;
+  const size_t lds = res_lds_floats(a.nl) * sizeof(float);
+  static bool lds_set = false;
+  if (!lds_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_resident_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_set = true;
+  }
+  { ProfScope ps__(CK_ACT_RES, st);
+    hipLaunchKernelGGL(policy_resident_kernel, dim3(n), dim3(256), lds, st, a, rx); }
+  CURIOUS_LAUNCH_CHECK("policy_resident_kernel");
+  return 0;
+}
+
 static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
   const int nsteps = a.fused ? a.nsteps : 1;
   size_t lds = act_rows_lds_floats(nsteps) * sizeof(float);
@@ -550,6 +587,10 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     a.off_success = off_success;
     a.episode = episode; a.tasks = tasks; a.eo = o; a.eag = ag; a.staging = staging; a.reward_eps = reward_eps;
     a.flags = flags;
+    // the exchange buffer of the resident form is the head of the workspace (the row-local routes use nothing else of it)
+    if (resident_ok(a, n, workspace) &&
+        (int64_t)res_xbuf_floats(n) <= curious_workspace_floats(cfg, n) && aligned16(workspace))
+      return launch_policy_resident(a, n, workspace, st);
     return launch_policy_rows(a, n, st);
   }
   if (nsteps > 1) {

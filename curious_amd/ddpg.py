@@ -227,7 +227,7 @@ class DDPG(object):
         theta = self.theta_target if use_target_net else self.theta
         ws = self._act_ws.get(n)
         if ws is None:
-            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=dev)
+            ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=dev)
             self._act_ws[n] = ws
         u = torch.empty([n, self.dimu], dtype=torch.float32, device=dev)
         Q = torch.empty([n, 1], dtype=torch.float32, device=dev) if compute_Q else None
@@ -291,7 +291,7 @@ class DDPG(object):
         theta = self.theta_target if use_target_net else self.theta
         ws = self._act_ws.get(n)
         if ws is None:
-            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+            ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
             self._act_ws[n] = ws
         if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
             self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
@@ -313,7 +313,7 @@ class DDPG(object):
         theta = self.theta_target if use_target_net else self.theta
         ws = self._act_ws.get(n)
         if ws is None:
-            ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+            ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
             self._act_ws[n] = ws
         if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
             self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
@@ -375,7 +375,7 @@ class DDPG(object):
         if entry is None:
             ws = self._act_ws.get(n)
             if ws is None:
-                ws = torch.empty(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
+                ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
                 self._act_ws[n] = ws
             u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
             Q = torch.empty([n, 1], dtype=torch.float32, device=self.device) if compute_Q else None

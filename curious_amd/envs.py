@@ -13,7 +13,7 @@ oracle/env.py; kernels: curious_amd/csrc/env.hip).  Two front-ends share those k
 import numpy as np
 import torch
 
-from curious_amd import ops
+from curious_amd import _lib, ops
 from curious_amd.layout import RecordLayout
 from curious_amd.replay_buffer import EpisodeViews
 
@@ -173,6 +173,11 @@ class BatchedSyntheticArm(ArmSpec):
     def wait_flags(self):
         self._flags_ready.synchronize()
         host = self._flags_pin.numpy()
+        if host[self.n] == 2.0:
+            # include/curious_hip.h, curious_policy_rollout: a workgroup of the resident-weights rollout never got an
+            # answer from a peer of its group (the launch was not fully resident) -- the rollout is void
+            raise _lib.CuriousHipError('curious_policy_rollout: a member of a workgroup group gave up waiting for its '
+                                       "peers; rerun with CURIOUS_RESIDENT=0 (option 'resident')")
         return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
 
     def fetch_flags(self):

@@ -125,6 +125,10 @@ int curious_prof_launch_counts(int64_t* counts_host);
  *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
  *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes (fault-path tests)
  *   "qt_spins"     2^22 (default): polls before a consumer of Q' gives up and raises the workspace's fault word
+ *   "resident"     1 (default; env CURIOUS_RESIDENT): curious_policy_rollout keeps the actor's hidden matrices in LDS for
+ *                  the whole episode (groups of 4 workgroups per 4 envs) when n <= the device's CU count; 0: every
+ *                  workgroup streams them at every step
+ *   "res_spins"    2^20 (default): polls before a member of such a group gives up on a peer (flags[n] = 2)
  * Options are baked into a launch when it is enqueued (also into captured graphs). */
 int curious_set_option(const char* name, int64_t value);
 int64_t curious_get_option(const char* name);     /* -1 + curious_last_error() for an unknown name */
@@ -431,7 +435,12 @@ int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta
  * curious_policy_act_env_step with noise counters counter, counter + 1, ... -- same results bit for bit.  The envs do
  * not depend on each other, so on the row-local route (n % 4 == 0, hidden 256) the whole loop is ONE launch: a
  * workgroup walks its 4 envs through all steps, the new observation goes from the env step straight into the
- * policy's input row in LDS.  Other shapes: the launches of the single-step entry point, nsteps times. */
+ * policy's input row in LDS.  Other shapes: the launches of the single-step entry point, nsteps times.
+ * With nsteps >= 4, 2-3 layers and n <= the device's CU count (option "resident") the 4 envs get FOUR workgroups that
+ * keep a quarter of every hidden matrix each in LDS for the whole launch and exchange activations through the first
+ * n * 1024 floats of `workspace` -- which must then not be shared with a launch running concurrently, and whose
+ * (seed, counter) pairs must not repeat (they tag the exchanged words).  The members wait for each other: should one
+ * never be scheduled the others give up after "res_spins" polls and flags[n] is set to 2 (the rollout is void). */
 int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                            float* workspace, double noise_scale, double random_eps, uint64_t seed, uint64_t counter,
                            const int64_t* counter_base, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
