@@ -117,7 +117,7 @@ PROTOTYPES = {
     'curious_param_total': (_I64, [C.POINTER(NetCfg)]),
     'curious_workspace_floats': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_ddpg_grads': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
-                                     _P, _P, _P, _I32, _P]),
+                                     _P, _P, _P, _I32, C.POINTER(NextBatch), _P]),
     'curious_ddpg_transposed': (C.c_int, [C.POINTER(NetCfg), _I32, _P, C.POINTER(Transposed)]),
     'curious_ddpg_update': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
                                       _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
@@ -125,7 +125,7 @@ PROTOTYPES = {
                                               C.POINTER(BatchLayout), _I32, _P, _P, _P, _P, _P, C.POINTER(AdamState),
                                               C.POINTER(NextBatch), _P]),
     'curious_ddpg_grads_experts': (C.c_int, [C.POINTER(NetCfg), _I32, _I64, _I64, _P, _P, _P, C.POINTER(BatchLayout),
-                                             _I32, _P, _P, _P, _P, _P, _I32, _P]),
+                                             _I32, _P, _P, _P, _P, _P, _I32, _U64, C.POINTER(NextBatch), _P]),
     'curious_adam_update_and_sample_experts': (C.c_int, [_I32, _I64, _I64, _U64, _P, _P, _P, _P, _I64, _I64, _P, _P,
                                                          _I64, _I32, _F, _F, _F, _F, _F, _P, _I64, C.POINTER(Layout),
                                                          C.POINTER(Tasks), C.POINTER(SampleParams),

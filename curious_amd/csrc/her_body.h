@@ -29,8 +29,10 @@ struct HerArgs {
 // transition.  Relabelling, reward and clipping then run out of LDS / registers.
 // eo / seed_add: batched experts (mlp_common.h "Ex"): the staged batch, the sampling tables and the step counter of
 // expert e live eo floats behind expert 0's, its Philox key is seed + seed_add; the replay storage is shared.
+// step_add: added to the step counter read from memory (the gather that rides in ddpg_rows_kernel runs BEFORE the
+// update's increment of the counter, mlp_rows.h: + 1 gives the key the gather after it would have used).
 __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int block, float* lds, const int64_t eo = 0,
-                                                const uint64_t seed_add = 0) {
+                                                const uint64_t seed_add = 0, const int64_t step_add = 0) {
   __shared__ int32_t s_tab[TAB_INTS];
   const curious_layout_t& L = a.L;
   const curious_batch_layout_t& BL = a.BL;
@@ -73,8 +75,8 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     const int al = R.buf_alias ? R.buf_alias[eo + b] : b;
     const int tk = R.buf_task ? R.buf_task[eo + b] : -1;
     const int cs = R.cur_size[eo + b];
-    const int64_t step = R.step_ctr
-        ? *reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(R.step_ctr) + eo) : R.step_host;
+    const int64_t step = (R.step_ctr
+        ? *reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(R.step_ctr) + eo) : R.step_host) + step_add;
     const uint64_t seed = R.seed + seed_add;
     const unsigned long long beyond = __ballot(lane < R.nbuf && gic >= pe);
     int lb = __popcll(beyond);

@@ -467,6 +467,7 @@ static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, hipSt
   if (!lds_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_resident_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
     lds_set = true;
   }
   { ProfScope ps__(CK_ACT_RES, st);
@@ -484,6 +485,7 @@ static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_rows_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
     lds_set = true;
   }
   { ProfScope ps__(CK_ACT_ROWS, st);
@@ -691,6 +693,10 @@ struct DdpgPass {
   bool keeps_copies(const UpdateTail* tail) const;
   int rows_pass(bool refresh, bool maintained);
   bool copies_kept = false;   // this pass's optimiser tail has to write the transposed copies next to the parameters
+  // curious_ddpg_grads* with a `next` batch: its HER gather rides in the row-local launch (spare workgroups), the step
+  // counter's increment moves to the weight-gradient launch (mlp_rows.h RowsArgs.n_her)
+  bool gather_in_rows = false;
+  HerArgs her_rows;
   int forward();
   int critic_backward();
   int actor_backward();
@@ -785,16 +791,30 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
+    // (the kernel also has ~1 KB of static LDS -- the task tables of its gather blocks: dynamic + static must stay <= 160 KB)
+    const int max_dyn = (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    (void)hipGetLastError();                                 // a refusal here must not be mistaken for a failed launch
     lds_set = true;
   }
-  dim3 grid((a.xmap ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
-  { ProfScope ps__(CK_ROWS, st);
+  a.n_her = gather_in_rows ? B / ROWS_R : 0;                 // (SPB == ROWS_R: as many gather blocks as row groups)
+  dim3 grid((a.xmap || gather_in_rows ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
+  if (gather_in_rows) {
+    ProfScope ps__(CK_ROWS_HER, st);
+    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_her_kernel<true>), grid, dim3(256), lds, st, a, ex, her_rows, seed_stride);
+    else hipLaunchKernelGGL((ddpg_rows_her_kernel<false>), grid, dim3(256), lds, st, a, ex, her_rows, seed_stride);
+  } else {
+    ProfScope ps__(CK_ROWS, st);
     if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
-    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex); }
+    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex);
+  }
   CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");
   // what weight_grads() reads of the tiled route's state
   dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
@@ -1054,6 +1074,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && !cfg->normalize_obs;
   LossFin fin;
   fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
+  fin.step_ctr = gather_in_rows ? step_ctr : nullptr;
   auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
     int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
     bool ok = true;
@@ -1184,17 +1205,30 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   return 0;
 }
 
+// next (without a tail only): the device-drawn HER gather of the NEXT update's batch as part of this call -- inside the
+// row-local launch where that route applies, as a launch of its own behind the gradients otherwise.
 static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                            const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
                            const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
                            int64_t* step_ctr, curious_stream_t stream, const UpdateTail* tail,
-                           const ExDim& xd = ExDim(), uint64_t seed_stride = 0, bool params_unchanged = false) {
+                           const ExDim& xd = ExDim(), uint64_t seed_stride = 0, bool params_unchanged = false,
+                           const curious_next_batch_t* next = nullptr) {
   DdpgPass p;
   p.xd = xd; p.seed_stride = seed_stride;
   p.cfg = cfg; p.theta_main = theta_main; p.theta_target = theta_target; p.batch = batch; p.BL = BL; p.B = B;
   p.o_stats = o_stats; p.g_stats = g_stats; p.workspace = workspace; p.grad = grad; p.out_losses = out_losses;
   p.out_Q_pi = out_Q_pi; p.step_ctr = step_ctr;
   int rc = p.setup(stream);
+  if (!rc && next) {
+    CURIOUS_CHECK(!tail, "internal: a fused update carries its own gather");
+    CURIOUS_CHECK(next->batch && next->batch != batch, "curious_ddpg_grads: the next batch needs its own staging buffer");
+    CURIOUS_CHECK(next->rng && next->rng->step_ctr == step_ctr && step_ctr,
+                  "curious_ddpg_grads: the next batch must be keyed by this call's step counter");
+    if (her_fill_args(p.her_rows, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
+                      next->batch, BL)) return -1;
+    p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(cfg->layers) * sizeof(float) &&
+                       (B % (ROWS_R * 4) == 0) && SPB == ROWS_R;
+  }
   if (!rc && p.rows_route()) {
     // the copies are kept current by this pass's own optimiser tail (maintained), or -- without a tail -- by the
     // caller's stand-alone optimiser call (curious_adam_update* with `keep`), as the caller asserts
@@ -1206,6 +1240,11 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     if (!rc) rc = p.actor_backward();
   }
   if (!rc) rc = p.weight_grads(tail);
+  if (!rc && next && !p.gather_in_rows) {
+    if (xd.nex > 1) { curious_set_error("batched experts need the row-local route for the gather of the next batch"); return -1; }
+    rc = curious_her_sample(next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
+                            next->batch, BL, stream);
+  }
   return rc;
 }
 
@@ -1213,9 +1252,9 @@ extern "C" int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* the
                                   const float* batch, const curious_batch_layout_t* BL, int32_t B,
                                   const float* o_stats, const float* g_stats, float* workspace, float* grad,
                                   float* out_losses, float* out_Q_pi, int64_t* step_ctr, int32_t params_unchanged,
-                                  curious_stream_t stream) {
+                                  const curious_next_batch_t* next, curious_stream_t stream) {
   return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
-                         out_Q_pi, step_ctr, stream, nullptr, ExDim(), 0, params_unchanged != 0);
+                         out_Q_pi, step_ctr, stream, nullptr, ExDim(), 0, params_unchanged != 0, next);
 }
 
 static int ddpg_update_impl(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
@@ -1271,13 +1310,14 @@ extern "C" int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t 
                                           int64_t grad_stride, const float* theta_main, const float* theta_target,
                                           const float* batch, const curious_batch_layout_t* BL, int32_t B,
                                           float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                                          int64_t* step_ctr, int32_t params_unchanged, curious_stream_t stream) {
+                                          int64_t* step_ctr, int32_t params_unchanged, uint64_t seed_stride,
+                                          const curious_next_batch_t* next, curious_stream_t stream) {
   if (check_experts(cfg, n_experts, expert_stride, grad_stride)) return -1;
   CURIOUS_CHECK(!cfg->normalize_obs, "curious_ddpg_grads_experts: input normalisation is not supported");
   ExDim xd;
   xd.nex = n_experts; xd.stride = expert_stride; xd.gstride = grad_stride;
   return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
-                         out_Q_pi, step_ctr, stream, nullptr, xd, 0, params_unchanged != 0);
+                         out_Q_pi, step_ctr, stream, nullptr, xd, seed_stride, params_unchanged != 0, next);
 }
 
 extern "C" int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,

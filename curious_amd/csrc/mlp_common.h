@@ -60,6 +60,8 @@ struct LossFin {         // final, fixed-order reduction of the per-row loss ter
   float* out;            // [2]: Q_loss, pi_loss
   int32_t B, U;
   float action_l2;
+  int64_t* step_ctr;     // non-NULL: the update's increment of the step counter happens HERE (deferred from the gradient
+                         // launch, whose gather blocks read the counter: mlp_rows.h)
 };
 struct DwArgs { DwProb p[MAX_DW]; int32_t nprob; LossFin fin; };
 

@@ -455,6 +455,7 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
     }
     if (tid == 0) {
       const float invB = 1.0f / (float)F.B;
+      if (F.step_ctr) *ex_i64(F.step_ctr, eo) += 1;
       F.out[eo + 0] = red[0] * invB;
       F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
     }

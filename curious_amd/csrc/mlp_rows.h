@@ -63,6 +63,10 @@ struct RowsArgs {
   int32_t inject, spins;          // inject > 0 (tests): the target group of row group inject - 1 never publishes;
                                   // spins: polls before a consumer gives up
   int32_t lab_no_target;          // lab only: no target groups, Q' = 0 (timing of an update with precomputed targets)
+  int32_t n_her;                  // > 0: B / 4 spare workgroups of this launch run the HER gather of the NEXT update's
+                                  // batch (her_body.h) -- on CUs the three kinds leave idle, hidden behind the chains.
+                                  // The step counter is then NOT incremented here (the gather keys its Philox stream on
+                                  // it: counter + 1) but by the weight-gradient launch that follows (LossFin.step_ctr).
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
@@ -300,8 +304,11 @@ static inline size_t rows_lds_floats(int nl) {
   return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;
 }
 
-template <bool EX>
-__global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
+// HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
+// form keeps its 632-byte kernarg -- HerArgs adds 1.4 KB)
+template <bool EX, bool HER>
+__device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
+                                               const uint64_t seed_stride) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
   x.dbg = nullptr;
@@ -322,7 +329,11 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   int kind, rgrp, expert = 0;
   if (a.xmap) {                                              // single agent, grid.x = 4 * nrg
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    if (xcd < 4 && slot >= per) return;
+    if (xcd < 4 && slot >= per) {                            // the spare quarter of the grid: the gather, or nothing
+      const int idx = xcd * per + (slot - per);
+      if (HER && idx < a.n_her) her_sample_body(*her, idx, rows_lds, 0, 0, 1);
+      return;
+    }
     kind = (xcd < 4) ? 0 : (slot < per) ? 1 : 2;
     rgrp = (xcd & 3) * per + (slot < per ? slot : slot - per);
   } else {
@@ -335,6 +346,12 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
     const int rem = lin - kind * groups;
     expert = rem / nrg;
     rgrp = rem - expert * nrg;
+    if (kind == 3) {                                         // (grid.x = 4 * nrg only with n_her > 0) the gather blocks
+      int64_t ge;
+      (void)ex_decode<EX>(ex, expert, ge);
+      if (HER && rgrp < a.n_her) her_sample_body(*her, rgrp, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
+      return;
+    }
   }
   x.r0 = rgrp * ROWS_R;
 #ifdef ROWS_DEBUG
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
 
   if (kind == 2) {
     // ================================================= main-critic group: critic(o, g, u), loss, backward
-    if (rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
+    if (!HER && rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
     const float* mq = a.mQ.th + eo;
     ROWS_STAMP(0);
     rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
@@ -584,6 +601,15 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   ROWS_STAMP(8);
   rows_hidden_bwd(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
   ROWS_STAMP(9);
+}
+
+template <bool EX>
+__global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
+  ddpg_rows_body<EX, false>(a, ex, nullptr, 0);
+}
+template <bool EX>
+__global__ __launch_bounds__(256) void ddpg_rows_her_kernel(RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
+  ddpg_rows_body<EX, true>(a, ex, &her, seed_stride);
 }
 
 // ---- (re)build the transposed copies from the parameters: dst[j][n][k] = src[j][k][n], 256 x 256 each.

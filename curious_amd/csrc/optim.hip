@@ -59,17 +59,47 @@ __device__ __forceinline__ void adam_one(const AdamArgs& a, const int64_t i, con
   a.theta[i + eo] = th;
 }
 
+typedef float f32x4_o __attribute__((ext_vector_type(4)));
+// vec4: n, n_Q, the matrices of `keep` and the four vectors all start on 16-byte boundaries (the padded parameter
+// layout of curious_param_total) -- one thread then takes 4 consecutive elements with 16-byte loads and stores
 __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks, const int64_t eo,
-                                          const int64_t eg) {
+                                          const int64_t eg, const bool vec4) {
   if (adam_faulted(a, eo)) return;
   float aQ, aPi;
   adam_alphas(a, aQ, aPi, eo);
   const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
+  if (vec4) {
+    for (int64_t i = ((int64_t)block * 256 + threadIdx.x) * 4; i < a.n; i += (int64_t)nblocks * 1024) {
+      bool tiled = false;                                   // inside a matrix the tile blocks below take care of
+      for (int j = 0; j < a.keep.n; ++j) tiled |= (uint64_t)(i - a.keep.src_off[j]) < (uint64_t)msize;
+      if (tiled) continue;
+      const f32x4_o g = *reinterpret_cast<const f32x4_o*>(a.grad + i + eg);
+      f32x4_o m = *reinterpret_cast<const f32x4_o*>(a.m + i + eo), v = *reinterpret_cast<const f32x4_o*>(a.v + i + eo);
+      f32x4_o th = *reinterpret_cast<const f32x4_o*>(a.theta + i + eo);
+      const float na = (i < a.n_Q) ? -aQ : -aPi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float me = m[e], ve = v[e];
+        th[e] = adam_math(a, na, g[e], me, ve, th[e]);
+        m[e] = me; v[e] = ve;
+      }
+      *reinterpret_cast<f32x4_o*>(a.m + i + eo) = m;
+      *reinterpret_cast<f32x4_o*>(a.v + i + eo) = v;
+      *reinterpret_cast<f32x4_o*>(a.theta + i + eo) = th;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.n; i += (int64_t)nblocks * 256) {
-    bool tiled = false;                                     // inside a matrix the tile blocks below take care of
+    bool tiled = false;
     for (int j = 0; j < a.keep.n; ++j) tiled |= (uint64_t)(i - a.keep.src_off[j]) < (uint64_t)msize;
     if (!tiled) adam_one(a, i, aQ, aPi, eo, eg);
   }
+}
+static inline bool adam_vec4(const AdamArgs& a, int64_t expert_stride, int64_t grad_stride) {
+  bool ok = (a.n % 4 == 0) && (a.n_Q % 4 == 0) && (expert_stride % 4 == 0) && (grad_stride % 4 == 0) &&
+            (((uintptr_t)a.theta | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)a.grad) & 15) == 0;
+  for (int j = 0; j < a.keep.n; ++j) ok = ok && (a.keep.src_off[j] % 4 == 0);
+  return ok && (((int64_t)a.keep.dim * a.keep.dim) % 4 == 0);
 }
 
 // One 32 x 32 tile of a matrix whose transposed copy is kept: the same arithmetic element by element, the updated tile
@@ -113,10 +143,10 @@ static inline int adam_tiles(const AdamArgs& a) {
   return a.keep.n * per * per;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int n_tile) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int n_tile, int vec4) {
   __shared__ float tile[ADAM_TILE][ADAM_TILE + 1];
   if ((int)blockIdx.x < n_tile) adam_tile_body(a, blockIdx.x, tile, 0, 0);
-  else adam_body(a, blockIdx.x - n_tile, gridDim.x - n_tile, 0, 0);
+  else adam_body(a, blockIdx.x - n_tile, gridDim.x - n_tile, 0, 0, vec4 != 0);
 }
 
 // Adam + the HER gather of the NEXT update in one launch: the gather does not depend on the parameters, so its
@@ -125,13 +155,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int n_tile) {
 // staged batch (layer-0 forward, layer-0 weight gradients) has finished before this launch starts.
 // (batched experts: grid.y = expert)
 __global__ __launch_bounds__(256) void adam_her_kernel(AdamArgs a, HerArgs h, int n_her, int n_tile, int64_t ex_stride,
-                                                       int64_t grad_stride, uint64_t seed_stride) {
+                                                       int64_t grad_stride, uint64_t seed_stride, int vec4) {
   extern __shared__ float lds[];
   const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
   if ((int)blockIdx.x < n_her) her_sample_body(h, blockIdx.x, lds, eo, (uint64_t)blockIdx.y * seed_stride);
   else if ((int)blockIdx.x < n_her + n_tile)
     adam_tile_body(a, blockIdx.x - n_her, reinterpret_cast<float(*)[ADAM_TILE + 1]>(lds), eo, eg);
-  else adam_body(a, blockIdx.x - n_her - n_tile, gridDim.x - n_her - n_tile, eo, eg);
+  else adam_body(a, blockIdx.x - n_her - n_tile, gridDim.x - n_her - n_tile, eo, eg, vec4 != 0);
 }
 
 static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float* grad, int64_t n_Q, int64_t n_pi,
@@ -171,18 +201,21 @@ static int adam_and_sample(int32_t n_experts, int64_t expert_stride, int64_t gra
   AdamArgs a;
   if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
                 one_minus_beta1, beta2, one_minus_beta2, epsilon, keep)) return -1;
+  // storage == NULL: no gather rides along (the caller had it done in the gradient launch, curious_ddpg_grads* `next`)
   HerArgs h;
-  if (her_fill_args(h, storage, buf_stride, L, tasks, P, nullptr, rng, n, batch, BL)) return -1;
-  int n_her = (n + SPB - 1) / SPB;
-  int blocks = (int)((a.n + 255) / 256);
+  memset(&h, 0, sizeof(h));
+  if (storage && her_fill_args(h, storage, buf_stride, L, tasks, P, nullptr, rng, n, batch, BL)) return -1;
+  int n_her = storage ? (n + SPB - 1) / SPB : 0;
+  const bool vec4 = adam_vec4(a, expert_stride, grad_stride);
+  int blocks = (int)((a.n + (vec4 ? 1023 : 255)) / (vec4 ? 1024 : 256));
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const int n_tile = adam_tiles(a);
-  size_t lds = her_lds_bytes(L);
+  size_t lds = storage ? her_lds_bytes(L) : 0;
   if (n_tile && lds < sizeof(float) * ADAM_TILE * (ADAM_TILE + 1)) lds = sizeof(float) * ADAM_TILE * (ADAM_TILE + 1);
   { ProfScope ps__(CK_ADAM_HER, as_stream(stream));
     hipLaunchKernelGGL(adam_her_kernel, dim3(n_her + n_tile + blocks, n_experts), dim3(256), lds, as_stream(stream), a,
-                       h, n_her, n_tile, expert_stride, grad_stride, seed_stride); }
+                       h, n_her, n_tile, expert_stride, grad_stride, seed_stride, vec4 ? 1 : 0); }
   CURIOUS_LAUNCH_CHECK("adam_her_kernel");
   return 0;
 }
@@ -231,11 +264,12 @@ extern "C" int curious_adam_update(float* theta, float* m, float* v, const float
   if (fill_adam(a, theta, m, v, grad, n_Q, n_pi, alpha_tab, step_ctr, tab_base, tab_len, alpha_host, beta1,
                 one_minus_beta1, beta2, one_minus_beta2, epsilon, keep)) return -1;
   if (a.n <= 0) return 0;
-  int blocks = (int)((a.n + 255) / 256);
+  const bool vec4 = adam_vec4(a, 0, 0);
+  int blocks = (int)((a.n + (vec4 ? 1023 : 255)) / (vec4 ? 1024 : 256));
   if (blocks > 2048) blocks = 2048;
   const int n_tile = adam_tiles(a);
   { ProfScope ps__(CK_ADAM, as_stream(stream));
-    hipLaunchKernelGGL(adam_kernel, dim3(n_tile + blocks), dim3(256), 0, as_stream(stream), a, n_tile); }
+    hipLaunchKernelGGL(adam_kernel, dim3(n_tile + blocks), dim3(256), 0, as_stream(stream), a, n_tile, vec4 ? 1 : 0); }
   CURIOUS_LAUNCH_CHECK("adam_kernel");
   return 0;
 }

@@ -105,7 +105,7 @@ class DDPG(object):
         self._staged = None
         self._pp = None                                              # the two staging tensors of the device loop
         self._cur = 0
-        self._graph = self._graph_b = self._graph_ba = self._graph_chain = self._graph_long = None
+        self._graph = self._graph_a = self._graph_b = self._graph_ba = self._graph_chain = self._graph_long = None
         self._chains = None                                          # single rank: {length: graph of that many updates}
         self._graphs = [None, None]
         self._tables_dirty = True
@@ -981,33 +981,40 @@ class DDPG(object):
         """n updates on several ranks: A(0); [all-reduce; B(k)+A(k+1)] x (n-1); all-reduce; B(n-1), where A = the 8
         gradient launches and B = Adam + the gather of the next batch.  Same launches in the same order as n x train()."""
         self._train_device_prologue(n)
-        if self._graph is None:
-            self._graph = self._capture(self._grads)
-            self._graph_b = self._capture(self._adam_and_sample)
-            self._batch_stale = True
-        if self._graph_ba is None:
-            self._graph_ba = self._capture(lambda: (self._adam_and_sample(), self._grads(True)))
-            self._batch_stale = True
+        self._rank_graphs()
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False
         t = self.Q_adam.t
         if t % 100 == 0:
             self._check_synced()
-        self._graph.replay()
+        p = self._cur
+        self._graph_a[p].replay()
         for i in range(1, n):
             dist.allreduce_sum_(self.grad)                           # C1+C2 fused; SUM, not mean (ddpg.py:452)
+            p ^= 1                                                   # the gradient launch drew the next batch
             if (t + i) % 100 == 0:                                   # C4 between the two halves, parameters at rest
                 self._graph_b.replay()
                 self._check_synced()
-                self._graph.replay()
+                self._graph_a[p].replay()
             else:
-                self._graph_ba.replay()
+                self._graph_ba[p].replay()
         dist.allreduce_sum_(self.grad)
         self._graph_b.replay()
+        self._cur = p ^ 1
+        self._staged = self._pp[self._cur]
         self.Q_adam.t += n
         self.pi_adam.t += n
         return self._losses[0], self._Q_pi
+
+    def _rank_graphs(self):
+        """The split update graphs of the several-rank path with an eager collective: A[p] = gradients of the batch in
+        staging tensor p (+ the gather of the next batch into the other one), B = the optimiser, BA[p] = B then A[p]."""
+        if getattr(self, '_graph_a', None) is None:
+            self._graph_a = [self._capture(lambda p=p: self._grads_next(p)) for p in (0, 1)]
+            self._graph_b = self._capture(self._adam_only)
+            self._graph_ba = [self._capture(lambda p=p: (self._adam_only(), self._grads_next(p, True))) for p in (0, 1)]
+            self._batch_stale = True
 
     def _check_synced(self, wait=False):
         """mpi_adam.py:42-50 (every 100 updates) off the critical path: a 128-bit checksum of the fused parameter vector
@@ -1093,10 +1100,27 @@ class DDPG(object):
         CURIOUS_GRAPH_ALLREDUCE=0/1, otherwise by a collective self-test at the first use."""
         return dist.captured_allreduce_ok()
 
-    def _ranks_update(self, chained=False):
-        self._grads(chained)
+    def _ranks_update(self, p, chained=False):
+        """One update on several ranks: gradients of the batch staged in tensor p -- the HER gather of the next batch into
+        tensor p ^ 1 rides in that launch --, the all-reduce, the optimiser."""
+        self._grads_next(p, chained)
         dist.allreduce_sum_(self.grad)                               # C1+C2 fused; SUM, not mean (ddpg.py:452)
-        self._adam_and_sample()
+        self._adam_only()
+
+    def _grads_next(self, p, chained=False):
+        S = self.sample_transitions
+        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self.batch_size,
+                       self._workspace, self.grad, self._losses, self._Q_pi,
+                       o_stats=self.o_stats.state if self.normalize_obs else None,
+                       g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr,
+                       params_unchanged=chained, next_batch=self._pp[p ^ 1], storage=self._pool.storage,
+                       buf_stride=self._pool.buf_stride, tasks=S.tasks,
+                       params=S.params(self.clip_obs, self.relative_goals), rng=self._rng_desc)
+
+    def _adam_only(self):
+        ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
+                        alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base,
+                        keep=self._kept_copies())
 
     def _train_device_prologue(self, k):
         if self._tables_stale():
@@ -1115,16 +1139,18 @@ class DDPG(object):
         self._layout_for_batch = self._layout
 
     def _train_device_ranks(self, k=1):
+        """k = 1: one update from the staging tensor of the current parity (which flips: the gradient launch draws the
+        next batch into the other tensor); k = CHAIN (even, parity 0): one graph of CHAIN updates, collective captured."""
         one_graph = self.use_graph and self._graph_allreduce()
-        if self.use_graph and not one_graph and self._graph is None:
-            self._graph = self._capture(self._grads)
-            self._graph_b = self._capture(self._adam_and_sample)
-            self._batch_stale = True
-        if one_graph and k == 1 and self._graphs[0] is None:
-            self._graphs[0] = self._capture(self._ranks_update)
+        p = self._cur
+        if self.use_graph and not one_graph:
+            self._rank_graphs()
+        if one_graph and k == 1 and self._graphs[p] is None:
+            self._graphs[p] = self._capture(lambda: self._ranks_update(p))
             self._batch_stale = True
         if one_graph and k > 1 and self._graph_chain is None:
-            self._graph_chain = self._capture(lambda: [self._ranks_update(i > 0) for i in range(CHAIN)])
+            assert p == 0 and k % 2 == 0
+            self._graph_chain = self._capture(lambda: [self._ranks_update(i & 1, i > 0) for i in range(CHAIN)])
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
@@ -1132,13 +1158,15 @@ class DDPG(object):
         if self.Q_adam.t % 100 == 0:
             self._check_synced()
         if one_graph:
-            (self._graph_chain if k > 1 else self._graphs[0]).replay()
+            (self._graph_chain if k > 1 else self._graphs[p]).replay()
         elif self.use_graph:
-            self._graph.replay()
+            self._graph_a[p].replay()
             dist.allreduce_sum_(self.grad)
             self._graph_b.replay()
         else:
-            self._ranks_update()
+            self._ranks_update(p)
+        self._cur ^= (k & 1)
+        self._staged = self._pp[self._cur]
         self.Q_adam.t += k
         self.pi_adam.t += k
         return self._losses[0], self._Q_pi

@@ -132,21 +132,25 @@ class ExpertBank:
 
     # the two halves of an update on several ranks: the all-reduce of the gradient block sits between them
     def _grads_all(self, p, chained=False):
+        """Gradients of every expert from the batches staged in tensor p; the HER gather of every expert's NEXT batch
+        into tensor p ^ 1 rides in spare workgroups of the row-local launch."""
         x0 = self.experts[0]
+        S = x0.sample_transitions
         ops.ddpg_grads_experts(x0.net_cfg, self.n, self.stride, self.grad_stride, x0.theta, x0.theta_target, x0._pp[p],
                                x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi, x0._step_ctr,
-                               params_unchanged=chained)
+                               params_unchanged=chained, seed_stride=SEED_STRIDE_SAMPLER, next_batch=x0._pp[p ^ 1],
+                               storage=x0._pool.storage, buf_stride=x0._pool.buf_stride, tasks=S.tasks,
+                               params=S.params(x0.clip_obs, x0.relative_goals), rng=x0._rng_desc)
 
-    def _adam_all(self, p):
-        """Adam of every expert from the summed gradients + the gather of every expert's next batch into the SAME
-        staging tensor (the gradient launches that read it have finished: stream order)."""
+    def _adam_all(self):
+        """Adam of every expert from the summed gradients (one launch, grid.y = expert)."""
         x0 = self.experts[0]
         S = x0.sample_transitions
         ops.adam_update_and_sample_experts(self.n, self.stride, self.grad_stride, SEED_STRIDE_SAMPLER, x0.theta, x0._m,
                                            x0._v, x0.grad, x0.off_pi, x0.P_total - x0.off_pi, x0._alpha_tab,
-                                           x0._step_ctr, x0._alpha_base, x0._pool.storage, x0._pool.buf_stride,
-                                           x0._layout, S.tasks, S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc,
-                                           x0.batch_size, x0._pp[p], keep=x0._kept_copies())
+                                           x0._step_ctr, x0._alpha_base, None, 0, x0._layout, S.tasks,
+                                           S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, x0.batch_size, None,
+                                           keep=x0._kept_copies())
 
     def _allreduce(self):
         dist.allreduce_sum_(self.grads)                      # ONE collective: N x P floats, SUM (mpi_adam.py:26)
@@ -154,7 +158,7 @@ class ExpertBank:
     def _ranks_update_all(self, p, chained=False):
         self._grads_all(p, chained)
         self._allreduce()
-        self._adam_all(p)
+        self._adam_all()
 
     def _capture(self, fn):
         """Capture `fn` after one eager warm-up; the slab (all experts' state) is restored afterwards."""
@@ -200,9 +204,10 @@ class ExpertBank:
             x.pi_adam.t += k
 
     def _train_ranks(self, k):
-        """k updates of every expert on several ranks.  One staging tensor (parity never flips).  With the collective
-        captured (dist.captured_allreduce_ok) a chain of k updates is ONE graph launch; otherwise the eager all-reduce
-        separates graph A (gradients) from graph B (optimiser + next gather), software-pipelined as B(i) + A(i + 1)."""
+        """k updates of every expert on several ranks (the staging tensors alternate like on one rank: the gradient
+        launch of an update draws the next batch).  With the collective captured (dist.captured_allreduce_ok) a chain of
+        k updates is ONE graph launch; otherwise the eager all-reduce separates graph A (gradients + next gather) from
+        graph B (optimiser), software-pipelined as B(i) + A(i + 1)."""
         self._prologue(k)
         p = self._cur
         x0 = self.experts[0]
@@ -211,19 +216,20 @@ class ExpertBank:
                 x._check_synced()
         if not self.use_graph:
             for i in range(k):
-                self._ranks_update_all(p, i > 0)
+                self._ranks_update_all((p + i) & 1, i > 0)
         elif dist.captured_allreduce_ok():
-            self._graph(('ranks', k, p), lambda: [self._ranks_update_all(p, i > 0) for i in range(k)]).replay()
+            self._graph(('ranks', k, p), lambda: [self._ranks_update_all((p + i) & 1, i > 0) for i in range(k)]).replay()
         else:
-            ga = self._graph(('A', p), lambda: self._grads_all(p))
-            gb = self._graph(('B', p), lambda: self._adam_all(p))
-            gba = self._graph(('BA', p), lambda: (self._adam_all(p), self._grads_all(p, True)))
-            ga.replay()
+            ga = [self._graph(('A', q), lambda q=q: self._grads_all(q)) for q in (0, 1)]
+            gb = self._graph(('B',), self._adam_all)
+            gba = [self._graph(('BA', q), lambda q=q: (self._adam_all(), self._grads_all(q, True))) for q in (0, 1)]
+            ga[p].replay()
             for i in range(1, k):
                 self._allreduce()
-                gba.replay()
+                gba[(p + i) & 1].replay()
             self._allreduce()
             gb.replay()
+        self._cur ^= (k & 1)
         self._advance(k)
 
     def train(self):

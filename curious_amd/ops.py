@@ -158,15 +158,33 @@ def workspace_floats(cfg, B):
     return int(lib().curious_workspace_floats(C.byref(cfg), int(B)))
 
 
+def _next_batch(layout, next_batch, storage, buf_stride, tasks, params, rng):
+    """curious_next_batch_t (None without a next batch); the ctypes objects it points to stay referenced on it."""
+    if next_batch is None:
+        return None
+    L = layout.c_layout()
+    N = _lib.NextBatch()
+    N.storage, N.buf_stride = ptr(_dev(storage, 'storage')), int(buf_stride)
+    N.L, N.tasks, N.P, N.rng = C.pointer(L), C.pointer(tasks), C.pointer(params), C.pointer(rng)
+    N.batch = ptr(_dev(next_batch, 'next_batch'))
+    N._keep = (L, tasks, params, rng)
+    return N
+
+
 def ddpg_grads(cfg, theta_main, theta_target, batch, layout, B, workspace, grad, out_losses, out_Q_pi,
-               o_stats=None, g_stats=None, step_ctr=None, params_unchanged=False):
+               o_stats=None, g_stats=None, step_ctr=None, params_unchanged=False, next_batch=None, storage=None,
+               buf_stride=0, tasks=None, params=None, rng=None):
     """params_unchanged: since the previous call on this workspace only an optimiser call that was given
-    ddpg_transposed(cfg, B, workspace) has written theta_main (the transposed weight copies in the workspace are current)."""
+    ddpg_transposed(cfg, B, workspace) has written theta_main (the transposed weight copies in the workspace are current).
+    next_batch (+ storage, buf_stride, tasks, params, rng): the device-drawn gather of the next update's batch as part of
+    the call (multi-rank path: in spare workgroups of the row-local launch)."""
     BL = layout.c_batch_layout()
+    N = _next_batch(layout, next_batch, storage, buf_stride, tasks, params, rng)
     check(lib().curious_ddpg_grads(C.byref(cfg), ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
                                    ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
                                    ptr(workspace), ptr(grad), ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr),
-                                   int(bool(params_unchanged)), current_stream()), 'curious_ddpg_grads')
+                                   int(bool(params_unchanged)), C.byref(N) if N is not None else None,
+                                   current_stream()), 'curious_ddpg_grads')
 
 
 def ddpg_transposed(cfg, B, workspace):
@@ -216,14 +234,17 @@ def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsi
 
 
 def ddpg_grads_experts(cfg, n_experts, expert_stride, grad_stride, theta_main, theta_target, batch, layout, B, workspace,
-                       grad, out_losses, out_Q_pi, step_ctr, params_unchanged=False):
+                       grad, out_losses, out_Q_pi, step_ctr, params_unchanged=False, seed_stride=0, next_batch=None,
+                       storage=None, buf_stride=0, tasks=None, params=None, rng=None):
     """curious_ddpg_grads for n_experts agents in one launch sequence (the first half of a data-parallel batched
-    update); tensors as in ddpg_update_experts."""
+    update); tensors as in ddpg_update_experts.  next_batch: every expert's next batch is gathered in the same launch."""
     BL = layout.c_batch_layout()
+    N = _next_batch(layout, next_batch, storage, buf_stride, tasks, params, rng)
     check(lib().curious_ddpg_grads_experts(C.byref(cfg), int(n_experts), int(expert_stride), int(grad_stride),
                                            ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
                                            ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),
                                            ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr), int(bool(params_unchanged)),
+                                           int(seed_stride) & 0xFFFFFFFFFFFFFFFF, C.byref(N) if N is not None else None,
                                            current_stream()), 'curious_ddpg_grads_experts')
 
 
@@ -238,7 +259,7 @@ def adam_update_and_sample_experts(n_experts, expert_stride, grad_stride, seed_s
         int(n_experts), int(expert_stride), int(grad_stride), int(seed_stride) & 0xFFFFFFFFFFFFFFFF,
         ptr(_dev(theta, 'theta')), ptr(m), ptr(v), ptr(grad), int(n_Q), int(n_pi), ptr(alpha_tab), ptr(step_ctr),
         int(tab_base), int(alpha_tab.shape[0]), float(f(beta1)), float(f(1 - beta1)), float(f(beta2)),
-        float(f(1 - beta2)), float(f(epsilon)), ptr(_dev(storage, 'storage')), int(buf_stride), C.byref(L),
+        float(f(1 - beta2)), float(f(epsilon)), ptr(storage), int(buf_stride), C.byref(L),
         C.byref(tasks), C.byref(params), C.byref(rng), int(n), ptr(batch), C.byref(BL),
         C.byref(keep) if keep is not None else None, current_stream()), 'curious_adam_update_and_sample_experts')
 

@@ -103,11 +103,12 @@ def ddpg_grads(cfg_i: list[int], cfg_f: list[float], theta: torch.Tensor, theta_
     BL = _lib.BatchLayout()
     for name, val in zip([f[0] for f in _lib.BatchLayout._fields_], batch_layout):
         setattr(BL, name, int(val))
-    ws = torch.empty(ops.workspace_floats(cfg, B), dtype=torch.float32, device=batch.device)
+    ws = torch.zeros(ops.workspace_floats(cfg, B), dtype=torch.float32, device=batch.device)   # (holds the fault word)
     losses = torch.zeros(2, dtype=torch.float32, device=batch.device)
     Q_pi = torch.zeros([B, 1], dtype=torch.float32, device=batch.device)
     check(lib().curious_ddpg_grads(C.byref(cfg), ptr(theta), ptr(theta_target), ptr(batch), C.byref(BL), int(B), None,
-                                   None, ptr(ws), ptr(grad), ptr(losses), ptr(Q_pi), None, 0, _lib.current_stream()),
+                                   None, ptr(ws), ptr(grad), ptr(losses), ptr(Q_pi), None, 0, None,
+                                   _lib.current_stream()),
           'curious_ddpg_grads')
     return losses, Q_pi
 

@@ -232,6 +232,15 @@ int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
  * and the transposed copies untouched: the caller reads the word once per cycle, raises, and clears it. */
 int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, int32_t B);
 
+/* Where the device-drawn HER gather of the NEXT update's batch goes (curious_her_sample with `rng`) when it rides along
+ * with another call: replay storage + layouts + sampler description + the staging tensor to fill. */
+typedef struct curious_next_batch {
+  const float* storage; int64_t buf_stride;
+  const curious_layout_t* L; const curious_tasks_t* tasks; const curious_sample_params_t* P;
+  const curious_sample_rng_t* rng;
+  float* batch;
+} curious_next_batch_t;
+
 /* One DDPG._grads(): target/main forward, losses, flat gradients (ddpg.py:235-243,419-449).
  * batch rows as written by curious_her_sample.  o_stats/g_stats = normaliser state vectors (may be
  * NULL when normalize_obs = 0).  out_losses = [Q_loss, pi_loss]; out_Q_pi[B] = main.Q_pi_tf (the
@@ -239,11 +248,17 @@ int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, int32_t B);
  * If step_ctr != NULL, *step_ctr is incremented once (device-side step counter for RNG / Adam).
  * params_unchanged != 0: since the previous call on THIS workspace (same cfg and B) nothing has written theta_main
  * except an optimiser call that was given curious_ddpg_transposed() of this workspace (`keep`), and the workspace was
- * left alone -- the library then trusts the transposed weight copies it keeps there (0: always safe, +1 launch). */
+ * left alone -- the library then trusts the transposed weight copies it keeps there (0: always safe, +1 launch).
+ * next (may be NULL; multi-rank training, where the optimiser is a launch of its own behind the all-reduce): the gather
+ * of the NEXT update's batch (ddpg.py:251-360, device-drawn plan keyed by THIS call's step_ctr: next->rng->step_ctr ==
+ * step_ctr) is part of this call -- on the row-local route it runs in spare workgroups of the gradient launch, hidden
+ * behind the layer chains (elsewhere: a launch behind the gradients).  Same batch as curious_her_sample called right
+ * after this call; next->batch must not alias `batch`. */
 int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                        const float* batch, const curious_batch_layout_t* BL, int32_t B,
                        const float* o_stats, const float* g_stats, float* workspace, float* grad,
-                       float* out_losses, float* out_Q_pi, int64_t* step_ctr, int32_t params_unchanged, curious_stream_t stream);
+                       float* out_losses, float* out_Q_pi, int64_t* step_ctr, int32_t params_unchanged,
+                       const curious_next_batch_t* next, curious_stream_t stream);
 
 /* Actor (and optionally critic) forward for acting: pi = max_u*tanh(net(o,td,g)), Q = critic(o,td,pi,g)
  * (ddpg.py:129-146, actor_critic.py:87-94).  Inputs are separate row matrices with their strides;
@@ -318,13 +333,6 @@ typedef struct curious_adam_state {
                                         * and with 0 (always safe, +1 launch) they are rebuilt from theta_main first. */
 } curious_adam_state_t;
 
-typedef struct curious_next_batch {
-  const float* storage; int64_t buf_stride;
-  const curious_layout_t* L; const curious_tasks_t* tasks; const curious_sample_params_t* P;
-  const curious_sample_rng_t* rng;
-  float* batch;
-} curious_next_batch_t;
-
 int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const float* theta_target,
                         const float* batch, const curious_batch_layout_t* BL, int32_t B,
                         const float* o_stats, const float* g_stats, float* workspace, float* grad,
@@ -355,17 +363,20 @@ int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts,
  * their gradients over the ranks (train.py:65-121, mpi_adam.py:21-35) -- so between the halves the caller all-reduces
  * (SUM) the experts' gradients.  They are kept in ONE contiguous block [n_experts][grad_stride] (`grad` = expert 0's
  * vector), which makes that a single collective over n_experts * P floats (4.7 MB at 4 experts).
- *   curious_ddpg_grads_experts: curious_ddpg_grads for every expert (row-local pass + one weight-gradient launch);
+ *   curious_ddpg_grads_experts: curious_ddpg_grads for every expert (row-local pass + one weight-gradient launch),
+ *     with `next` (expert e's sampler key = next->rng->seed + e * seed_stride) also every expert's next batch;
  *   curious_adam_update_and_sample_experts: curious_adam_update_and_sample for every expert (grid.y = expert): Adam
- *     from the summed gradients + the HER gather of every expert's next batch; `keep` = curious_ddpg_transposed() of
- *     expert 0's workspace (copies and fault word of expert e: expert_stride floats further).
+ *     from the summed gradients (+ the HER gather of every expert's next batch unless storage == NULL: it was part of
+ *     the gradient call); `keep` = curious_ddpg_transposed() of expert 0's workspace (copies and fault word of expert
+ *     e: expert_stride floats further).
  * Per expert the results are bit-identical to curious_ddpg_grads / curious_adam_update_and_sample on that expert alone,
  * and -- with one rank -- to curious_ddpg_update_experts. */
 int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                int64_t grad_stride, const float* theta_main, const float* theta_target,
                                const float* batch, const curious_batch_layout_t* BL, int32_t B, float* workspace,
                                float* grad, float* out_losses, float* out_Q_pi, int64_t* step_ctr,
-                               int32_t params_unchanged, curious_stream_t stream);
+                               int32_t params_unchanged, uint64_t seed_stride, const curious_next_batch_t* next,
+                               curious_stream_t stream);
 int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_stride, int64_t grad_stride,
                                            uint64_t seed_stride, float* theta, float* m, float* v, const float* grad,
                                            int64_t n_Q, int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,

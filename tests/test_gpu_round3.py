@@ -252,3 +252,33 @@ def test_two_ranks_of_batched_experts_share_one_gpu_over_gloo():
                              'CURIOUS_RANK_CHECK_CYCLES': '2'}, nproc=2)
     assert found[0][1] == found[1][1] and len(found[0][1]) == 64, found
     assert found[0][2] == found[1][2] == '235'
+
+
+def test_gradients_with_the_next_gather_riding_along(route):
+    """curious_ddpg_grads(next): the HER gather of the next update's batch in spare workgroups of the row-local launch
+    (the step counter's increment deferred to the weight-gradient launch) == curious_ddpg_grads followed by
+    curious_her_sample, bit for bit: gradients, losses, counter, the gathered batch.  (The tiled route: the gather is a
+    launch behind the gradients.)"""
+    from curious_amd import ops
+    agent, _ = _filled_agent(use_graph=False)
+    agent._train_device_prologue(1)
+    agent._sample_packed()
+    S = agent.sample_transitions
+    kw = dict(storage=agent._pool.storage, buf_stride=agent._pool.buf_stride, tasks=S.tasks,
+              params=S.params(agent.clip_obs, agent.relative_goals), rng=agent._rng_desc)
+    outs = []
+    for riding in (True, False):
+        agent._step_ctr.fill_(7)
+        agent._pp[1].fill_(-3.0)
+        agent.grad.fill_(float('nan'))
+        ops.ddpg_grads(agent.net_cfg, agent.theta, agent.theta_target, agent._pp[0], agent._layout, agent.batch_size,
+                       agent._workspace, agent.grad, agent._losses, agent._Q_pi, step_ctr=agent._step_ctr,
+                       **(dict(next_batch=agent._pp[1], **kw) if riding else {}))
+        if not riding:
+            ops.her_sample(agent._pool.storage, agent._pool.buf_stride, agent._layout, S.tasks, kw['params'],
+                           agent.batch_size, agent._pp[1], rng=agent._rng_desc)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in (agent.grad, agent._losses, agent._Q_pi, agent._step_ctr, agent._pp[1])])
+    for a, b in zip(*outs):
+        assert torch.equal(a.nan_to_num(nan=12345.0), b.nan_to_num(nan=12345.0))     # (the pads of `grad` stay NaN)
+    assert int(outs[0][3]) == 8 and bool((outs[0][4][:, :40] != -3.0).all())  # counter advanced once, batch overwritten

@@ -80,7 +80,7 @@ def test_host_descriptor_code_runs_up_to_the_launch_without_gpu():
         BL.off_ag, BL.off_ag2, BL.off_extra, BL.stride = 176, 200, 224, 256
         fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(8)]          # never dereferenced on the host
         rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
-                                  fake[5], fake[6], None, 0, None)
+                                  fake[5], fake[6], None, 0, None, None)
         assert rc != 0 and b'launch failed' in L.curious_last_error()
         st = _lib.AdamState()
         st.m, st.v = fake[6].value, fake[7].value

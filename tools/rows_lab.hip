@@ -8,6 +8,7 @@
 #define ROWS_DEBUG 1
 #include "common.h"
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "her_body.h"
 #include "mlp_common.h"
 #include "mlp_rows.h"
 void curious_set_error(const char*, ...) {}
