@@ -187,8 +187,12 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     return dict(
         # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
         ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1),
+        ddpg_rows_her_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1),
         policy_rows_kernel=dict(bound='mfma', per_update=0, launches_update=0, per_env_step=2 * B_R * net(Sa, U),
                                 launches_env_step=1),
+        # the weights-resident rollout: layer 0 is computed by all 4 members of a group (x 4), the rest once
+        policy_resident_kernel=dict(bound='mfma', per_update=0, launches_update=0,
+                                    per_env_step=2 * B_R * (net(Sa, U) + 3 * (Sa + G) * H), launches_env_step=1),
         # layers 0 + 1 in one launch: level A's 3 chains (+ the 2 action-free pre-activations of level B) per update;
         # the actor chain per env step
         fwd_l01_kernel=dict(bound='mfma', per_update=3 * 2 * B * H * H + 2 * B * H * (Kc + 4 * Ka), launches_update=1,
@@ -253,9 +257,8 @@ def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
     the bytes of 16-byte-per-lane streaming reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    path = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic.json' % r) for r in (3, 2, 1))
+                 if os.path.exists(p)), '')
     try:
         with open(path) as f:
             table = json.load(f)
@@ -322,7 +325,7 @@ def cpu_baseline(seed=0, budget_s=20.0):
     bufs = [OBuf(shapes, cap, T, sampler) for _ in range(nb + 1)]
     agent = OracleDDPG(dims, T, bufs, sampler, ids, ids, batch_size=BATCH, weight_rng=np.random.RandomState(seed))
     envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=seed, env_id=i) for i in range(B_R)]
-    n_rollout_envs = 32   # the per-env Python loop is sampled on 32 envs and scaled (it is linear in the env count)
+    n_rollout_envs = B_R  # the whole 256-env rollout is timed (round 2 sampled 32 envs and scaled)
 
     def rollout():
         tasks = np.random.choice(range(nb), size=B_R)
@@ -371,9 +374,8 @@ def cpu_baseline(seed=0, budget_s=20.0):
         total = t_roll + t_store + t_train
     return dict(value=round(cycles * N_BATCHES * BATCH / total, 1), unit='HER grad transitions/s',
                 env_steps_per_sec=round(cycles * B_R * T / total, 1), cores=1, kind='port',
-                sample='%d full cycles of the NumPy oracle (256-env rollout [32 envs timed, x8] + store + 100 updates, '
-                       'batch 256) on 1 thread; %.1f s rollout, %.1f s store, %.1f s updates'
-                       % (cycles, t_roll, t_store, t_train))
+                sample='%d full cycles of the NumPy oracle (256-env x 50-step rollout + store + 100 updates, batch 256) '
+                       'on 1 thread; %.1f s rollout, %.1f s store, %.1f s updates' % (cycles, t_roll, t_store, t_train))
 
 
 def cpu_rank_worker(rank, world, port, budget_s):
