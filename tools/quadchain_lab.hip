@@ -1,0 +1,369 @@
+// Lab: a chain of dependent 256-wide layers where every row group is served by a QUAD of workgroups (4 CUs of one XCD),
+// member c streaming only columns [64 c, 64 c + 64) of each weight matrix (64 KB per layer instead of 256 KB) and the
+// members all-gathering their 64-column slices of the activations after every layer (tagged 64-bit words through the
+// L2, two buffers by parity -- the exchange of mlp_rows_res.h).  Unlike the rollout, the weights of an UPDATE change
+// every launch, so nothing can stay resident: the question is whether a quarter of the stream + an exchange beats the
+// full stream of the row-local update kernel (5.8 k cycles per hidden layer, 2.2-2.9 us bare: r02_rowchain_lab.txt),
+// in the presence of the other workgroup kinds that stream whole matrices next to it.
+// The k order of every accumulation is that of the row-local kernel (wave w: k in [64 w, 64 w + 64) ascending; partial
+// tiles added (p0 + p1) + (p2 + p3)), so a product kernel built this way would stay bit-identical to it: the B operand
+// is fetched with 4-byte loads, lane = column (one 256-byte row segment per wave instruction).
+//   hipcc --offload-arch=gfx950 -O3 tools/quadchain_lab.hip -o tools/quadchain_lab && tools/quadchain_lab
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#define H 256
+#define HLD 264
+#define SPIN_MAX (1 << 22)
+
+__device__ inline f32x4 ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ void put(unsigned long long* p, uint32_t tag, float v) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int N>
+__device__ __forceinline__ bool take_n(const unsigned long long* const (&p)[N], uint32_t tag, float (&out)[N]) {
+  unsigned long long w[N];
+  int spins = 0;
+  bool ok;
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __hip_atomic_load(p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && ((uint32_t)(w[i] >> 32) == tag);
+    if (ok || ++spins > SPIN_MAX) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = __uint_as_float((uint32_t)(w[i] & 0xffffffffull));
+  return ok;
+}
+
+struct Args {
+  const float* X; const float* W; const float* bias; float* Y;   // W [L][256][256]
+  unsigned long long* xbuf;                                      // [quads][2][4][R * 64]
+  unsigned long long* cyc; int* err;
+  int L, nquad_blocks, R;                                        // blocks [0, nquad_blocks): quad members; the rest: streamers
+};
+
+// quad member: R rows; streams its 64 columns with dword loads (lane = column)
+template <int R>
+__device__ __forceinline__ void quad_member(const Args& a, float* hs, float* part, int b) {
+  constexpr int G = R / 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int xcd = b & 7, slot = b >> 3, member = slot & 3;
+  const int quad = xcd * (a.nquad_blocks >> 5) + (slot >> 2);
+  const int r0 = quad * R;
+  unsigned long long* xg = a.xbuf + (size_t)quad * 2 * 4 * (R * 64);
+  for (int i = tid; i < R * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(a.X + (size_t)(r0 + r) * H + c);
+  }
+  // this wave's k quarter of my 64 columns, 16 k at a time: wv[i] = W[64 wave + 16 c + i][64 member + lane]
+  float wv[2][16];
+  const float* wl = a.W + (size_t)(64 * wave) * H + 64 * member + lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wv[0][i] = wl[(size_t)i * H];
+  __syncthreads();
+  uint32_t q = 1;
+  bool lost = false;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int l = 0; l < a.L; ++l) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = zero4();
+    const float bv = a.bias[(size_t)l * H + 64 * member + (tid & 63)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
+      if (c < 3 || l + 1 < a.L) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wv[(c + 1) & 1][i] = nx[(size_t)i * H];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(hs + (4 * g + (lane & 3)) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[g] = MFMA4(av[s], wv[c & 1][4 * kq + s], acc[g]);
+        }
+      }
+    }
+    wl += (size_t)H * H;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * R + 4 * g + r) * 64 + lane] = acc[g][r];
+    __syncthreads();
+    unsigned long long* mine = xg + ((q & 1) * 4 + member) * (R * 64);
+    for (int i = tid; i < R * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const float s = (part[(0 * R + r) * 64 + c] + part[(1 * R + r) * 64 + c]) +
+                      (part[(2 * R + r) * 64 + c] + part[(3 * R + r) * 64 + c]);
+      const float v = fmaxf(s + bv, 0.f);
+      put(mine + i, q, v);
+      hs[r * HLD + 64 * member + c] = v;
+      if (l == a.L - 1) a.Y[(size_t)(r0 + r) * H + 64 * member + c] = v;
+    }
+    for (int i = tid; i < R * 64; i += 256) {
+      const unsigned long long* ps[3];
+#pragma unroll
+      for (int p = 1; p < 4; ++p) ps[p - 1] = xg + ((q & 1) * 4 + ((member + p) & 3)) * (R * 64) + i;
+      float v[3];
+      if (!take_n<3>(ps, q, v)) lost = true;
+#pragma unroll
+      for (int p = 1; p < 4; ++p) hs[(i >> 6) * HLD + 64 * ((member + p) & 3) + (i & 63)] = v[p - 1];
+    }
+    ++q;
+    __syncthreads();
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) a.cyc[b] = t1 - t0;
+  if (lost) *a.err = 1;
+}
+
+// quad member, second form: the slice is fetched with 16-byte loads (lane: row k0 + lane / 16, columns 4 (lane % 16) ..) and
+// re-laid out through a wave-private LDS stage (row-major [16 k][64 + 4]) so that the matrix instructions still see
+// lane = column, k ascending -- a quarter of the load instructions of the 4-byte form
+template <int R>
+__device__ __forceinline__ void quad_member_lds(const Args& a, float* hs, float* part, float* stage_all, int b) {
+  constexpr int G = R / 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int xcd = b & 7, slot = b >> 3, member = slot & 3;
+  const int quad = xcd * (a.nquad_blocks >> 5) + (slot >> 2);
+  const int r0 = quad * R;
+  float* stage = stage_all + wave * (16 * 68);
+  unsigned long long* xg = a.xbuf + (size_t)quad * 2 * 4 * (R * 64);
+  for (int i = tid; i < R * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(a.X + (size_t)(r0 + r) * H + c);
+  }
+  // chunk of 16 k: lane fetches rows 4 i + lane / 16 (i = 0..3), columns 64 member + 4 (lane % 16) .. + 3
+  f32x4 wv[2][4];
+  const float* wl = a.W + (size_t)(64 * wave + (lane >> 4)) * H + 64 * member + 4 * (lane & 15);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wv[0][i] = ldv(wl + (size_t)(4 * i) * H);
+  __syncthreads();
+  uint32_t q = 1;
+  bool lost = false;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int l = 0; l < a.L; ++l) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = zero4();
+    const float bv = a.bias[(size_t)l * H + 64 * member + (tid & 63)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(stage + (4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)) = wv[c & 1][i];
+      const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
+      if (c < 3 || l + 1 < a.L) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[(c + 1) & 1][i] = ldv(nx + (size_t)(4 * i) * H);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float bk[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bk[k] = stage[k * 68 + lane];
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(hs + (4 * g + (lane & 3)) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[g] = MFMA4(av[s2], bk[4 * kq + s2], acc[g]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    wl += (size_t)H * H;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * R + 4 * g + r) * 64 + lane] = acc[g][r];
+    __syncthreads();
+    unsigned long long* mine = xg + ((q & 1) * 4 + member) * (R * 64);
+    for (int i = tid; i < R * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const float s = (part[(0 * R + r) * 64 + c] + part[(1 * R + r) * 64 + c]) +
+                      (part[(2 * R + r) * 64 + c] + part[(3 * R + r) * 64 + c]);
+      const float v = fmaxf(s + bv, 0.f);
+      put(mine + i, q, v);
+      hs[r * HLD + 64 * member + c] = v;
+      if (l == a.L - 1) a.Y[(size_t)(r0 + r) * H + 64 * member + c] = v;
+    }
+    for (int i = tid; i < R * 64; i += 256) {
+      const unsigned long long* ps[3];
+#pragma unroll
+      for (int p = 1; p < 4; ++p) ps[p - 1] = xg + ((q & 1) * 4 + ((member + p) & 3)) * (R * 64) + i;
+      float v[3];
+      if (!take_n<3>(ps, q, v)) lost = true;
+#pragma unroll
+      for (int p = 1; p < 4; ++p) hs[(i >> 6) * HLD + 64 * ((member + p) & 3) + (i & 63)] = v[p - 1];
+    }
+    ++q;
+    __syncthreads();
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) a.cyc[b] = t1 - t0;
+  if (lost) *a.err = 1;
+}
+
+// streamer: the classic row-local layer chain on 4 rows of its own (stands for the other workgroup kinds of the update)
+__device__ __forceinline__ void streamer(const Args& a, float* hs, float* part, int b) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 4 * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(a.X + (size_t)r * H + c);
+  }
+  f32x4 wb[2][16];
+  const float* wl = a.W + (size_t)(64 * wave) * H + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wb[0][i] = ldv(wl + (size_t)i * H);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int l = 0; l < a.L; ++l) {
+    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    const float bv = a.bias[(size_t)l * H + tid];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
+      if (c < 3 || l + 1 < a.L) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[(c + 1) & 1][i] = ldv(nx + (size_t)i * H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA4(av[s], wb[c & 1][4 * kq + s][e], acc[e]);
+      }
+    }
+    wl += (size_t)H * H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      *reinterpret_cast<f32x4*>(part + (wave * 4 + r) * 256 + 4 * lane) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = (part[(0 * 4 + r) * 256 + tid] + part[(1 * 4 + r) * 256 + tid]) +
+                      (part[(2 * 4 + r) * 256 + tid] + part[(3 * 4 + r) * 256 + tid]);
+      hs[r * HLD + tid] = fmaxf(s + bv, 0.f);
+    }
+    __syncthreads();
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) a.cyc[b] = t1 - t0;
+}
+
+template <int R, int FORM>
+__global__ __launch_bounds__(256) void quadchain(Args a) {
+  __shared__ __attribute__((aligned(16))) float hs[R * HLD];
+  __shared__ __attribute__((aligned(16))) float part[4 * 4 * 256];   // >= 4 * R * 64 for R <= 16
+  __shared__ __attribute__((aligned(16))) float stage[FORM ? 4 * 16 * 68 : 4];
+  const int b = blockIdx.x;
+  if (b < a.nquad_blocks) {
+    if (FORM) quad_member_lds<R>(a, hs, part, stage, b);
+    else quad_member<R>(a, hs, part, b);
+  } else streamer(a, hs, part, b);
+}
+
+template <int R, int FORM = 0>
+static void run(Args a, int quads, int streamers, int L) {
+  a.L = L; a.R = R; a.nquad_blocks = quads * 4;
+  const int grid = quads * 4 + streamers;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best[2] = {1e30f, 1e30f};
+  const int Ls[2] = {2, L};
+  std::vector<unsigned long long> cyc(grid);
+  for (int v = 0; v < 2; ++v) {
+    a.L = Ls[v];
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemset(a.xbuf, 0, (size_t)64 * 2 * 4 * 16 * 64 * 8));
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL((quadchain<R, FORM>), dim3(grid), dim3(256), 0, 0, a);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best[v]) best[v] = ms;
+    }
+  }
+  CK(hipMemcpy(cyc.data(), a.cyc, grid * 8, hipMemcpyDeviceToHost));
+  int err = 0;
+  CK(hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost));
+  double cq = 0, cs = 0;
+  for (int b = 0; b < quads * 4; ++b) cq += (double)cyc[b] / L;
+  for (int b = quads * 4; b < grid; ++b) cs += (double)cyc[b] / L;
+  printf("%s %3d quads x 4 (R = %2d rows, %3d rows) + %3d streamers: L=2 %.2f us, L=%d %.2f us -> %.2f us per layer; in-kernel "
+         "cycles per layer: quad members %.0f, streamers %.0f%s\n", FORM ? "[16 B loads + LDS stage]" : "[4 B loads]             ",
+         quads, R, quads * R, streamers, best[0] * 1e3f, L,
+         best[1] * 1e3f, (best[1] - best[0]) * 1e3f / (L - 2), quads ? cq / (quads * 4) : 0.0,
+         streamers ? cs / streamers : 0.0, err ? "  ** a wait timed out **" : "");
+}
+
+int main() {
+  const int L = 14, B = 1024;
+  std::vector<float> hW((size_t)L * H * H), hb((size_t)L * H), hX((size_t)B * H);
+  srand(3);
+  for (auto& v : hW) v = 0.11f * (2.f * rand() / (float)RAND_MAX - 1.f);
+  for (auto& v : hb) v = 0.01f;
+  for (auto& v : hX) v = (float)rand() / (float)RAND_MAX;
+  for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.05f + 0.001f * (float)(i % 97);
+  Args a;
+  float *W, *bias, *X, *Y;
+  CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&bias, hb.size() * 4)); CK(hipMalloc(&X, hX.size() * 4));
+  CK(hipMalloc(&Y, hX.size() * 4));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+  a.X = X; a.W = W; a.bias = bias; a.Y = Y;
+  CK(hipMalloc(&a.xbuf, (size_t)64 * 2 * 4 * 16 * 64 * 8));
+  CK(hipMalloc(&a.cyc, 1024 * 8));
+  CK(hipMalloc(&a.err, 4));
+  CK(hipMemset(a.err, 0, 4));
+  printf("row-local update kernel: 5.8 k cycles per hidden layer in-kernel (7.4 k while three kinds stream); bare chains: "
+         "2.2-2.3 us per layer (64 workgroups), 2.9 us (192)\n");
+  run<4>(a, 0, 64, L);          // reference: streamers only
+  run<4>(a, 0, 192, L);
+  run<4>(a, 64, 0, L);          // 256 rows as 64 quads of 4 rows: 256 workgroups
+  run<8>(a, 32, 0, L);          // 256 rows as 32 quads of 8 rows: 128 workgroups
+  run<16>(a, 16, 0, L);         // 256 rows as 16 quads of 16 rows: 64 workgroups
+  run<8>(a, 32, 128, L);        // the update's shape: actor side as quads of 8 rows + 128 whole-matrix streamers = 256 workgroups
+  run<4>(a, 64, 128, L);        // actor side as quads of 4 rows + 128 streamers = 384 workgroups (some CUs host two)
+  run<16>(a, 16, 128, L);
+  run<4, 1>(a, 64, 0, L);
+  run<8, 1>(a, 32, 0, L);
+  run<8, 1>(a, 32, 128, L);
+  run<4, 1>(a, 64, 128, L);
+  // correctness: the quad chain computes what the single-workgroup chain computes (same k order): compare Y of 64 x R=4
+  std::vector<float> y1((size_t)256 * H), y2((size_t)256 * H);
+  run<4>(a, 64, 0, 3);
+  CK(hipMemcpy(y1.data(), Y, y1.size() * 4, hipMemcpyDeviceToHost));
+  run<8, 1>(a, 32, 0, 3);
+  CK(hipMemcpy(y2.data(), Y, y2.size() * 4, hipMemcpyDeviceToHost));
+  double d = 0;
+  for (size_t i = 0; i < y1.size(); ++i) d = fmax(d, fabs((double)y1[i] - (double)y2[i]));
+  printf("Y after 3 layers, quads of 4 rows / 4-byte loads vs quads of 8 rows / staged 16-byte loads: max |diff| = %.3g (Y[0] = %.6f)\n", d, y1[0]);
+  return 0;
+}
