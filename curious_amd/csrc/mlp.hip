@@ -462,6 +462,7 @@ static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, hipSt
   rx.xbuf = reinterpret_cast<unsigned long long*>(workspace);
   rx.xmap = (n % 32 == 0) ? 1 : 0;
   rx.spins = curious_options().res_spins;
+  rx.inject = curious_options().fault_inject;
   const size_t lds = res_lds_floats(a.nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {

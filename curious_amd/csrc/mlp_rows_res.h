@@ -34,6 +34,8 @@ struct ResX {
   unsigned long long* xbuf;      // [groups][2][4 members][4 x 64] tagged words (the head of the acting workspace)
   int32_t xmap;                  // 1: grid % 32 == 0 -> the 4 members of a group share an XCD (block b lands on XCD b % 8)
   int32_t spins;
+  int32_t inject;                // > 0 (tests, option "fault_inject"): member 1 of group inject - 1 exits at once -- a
+                                 // workgroup that was never scheduled, as far as its peers can tell
 };
 
 static inline size_t res_lds_floats(int nl) {
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     group = (int)blockIdx.x >> 2;
     member = (int)blockIdx.x & 3;
   }
+  if (rx.inject > 0 && group == rx.inject - 1 && member == 1) return;
   x.r0 = group * ROWS_R;
   const int Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
   const int m = x.r0 + x.wave;                              // the env this wave finishes (every member: the same 4 envs)

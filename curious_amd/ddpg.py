@@ -28,6 +28,7 @@ from curious_amd.replay_buffer import EpisodeViews, ReplayBuffer, as_records
 from curious_amd.util import import_function, store_args, transitions_in_episode_batch
 
 ALPHA_TAB = 4096        # Adam step sizes precomputed per cycle for graph replay
+FAULT_CHECK_EVERY = 8   # cycles between asynchronous reads of the hand-off fault word (DDPG.update_target_net)
 CHAIN = 10              # updates per chained hipGraph launch in train_batches (even: the staging tensors alternate)
 LONG_CHAIN = 50         # batched experts: a longer chain when that many updates are due
 MAX_CHAIN = 100         # single-rank path: train_batches(n) replays ONE graph of min(n, 100) (even) updates -- every graph
@@ -415,7 +416,7 @@ class DDPG(object):
         batch_size = staging.shape[0]
         marked, self._async_batch = self._async_batch, None
         if marked is not None and marked[:2] == (staging.data_ptr(), batch_size) and update_stats:
-            return self._store_episode_async(staging, batch_size, marked[2])
+            return self._store_episode_async(staging, batch_size, marked[2], marked[3])
         if self.structure in ('curious', 'task_experts'):
             if 'buffer' in self.task_replay or self.task_replay == 'hand_designed':
                 na = batch_size * self.nb_tasks
@@ -555,13 +556,14 @@ class DDPG(object):
         self._store_calls = getattr(self, '_store_calls', 0) + 1
         return self._store_calls
 
-    def expect_async_store(self, episode_batch, skip):
+    def expect_async_store(self, episode_batch, skip, skip_host=None):
         """Called by the batched RolloutWorker when it returns WITHOUT having waited for the rollout's flags: the next
-        store_episode of exactly this batch takes the device-routed form.  skip: the rollout's NaN word (device)."""
+        store_episode of exactly this batch takes the device-routed form.  skip: the rollout's NaN word (device);
+        skip_host: where its value arrives on the host (pinned, the D2H copy already enqueued: the worker's flag copy)."""
         staging = as_records(episode_batch, self._layout)
-        self._async_batch = (staging.data_ptr(), staging.shape[0], skip)
+        self._async_batch = (staging.data_ptr(), staging.shape[0], skip, skip_host)
 
-    def _store_episode_async(self, staging, batch_size, skip):
+    def _store_episode_async(self, staging, batch_size, skip, skip_host=None):
         """store_episode (ddpg.py:163-223) with the routing decided on the device: same slots, same table, same stats
         as the host-routed form; the host's mirror of the buffer sizes follows in settle()."""
         layout = self._layout
@@ -581,23 +583,25 @@ class DDPG(object):
                                  min(self.nb_tasks, 5), batch_size, self._tables[n0 + 2 * nb1:],
                                  self._tables[n0:n0 + nb1], self._pool.capacity, self._store_seed(),
                                  self._next_store_call(), skip, src_d, dst_d, self._route_count)
-        self._nan_pin.copy_(skip, non_blocking=True)
+        if skip_host is None:
+            self._nan_pin.copy_(skip, non_blocking=True)
+            skip_host = self._nan_pin
         arrived = torch.cuda.Event()
-        arrived.record()                                             # behind the activity flags' D2H (prefetch_activity)
+        arrived.record()                                             # behind the D2H copies of the activity and rollout flags
         self._pool.version += 1
         self._tables_dirty = False
         self._tables_sizes = self._sizes_key()                       # the device table is ahead of the host's sizes
         self._batch_stale = True                                     # until settle(); the next batch is drawn from it
-        self._store_pending = (self._route_bufs[1][:na], batch_size, arrived)
+        self._store_pending = (self._route_bufs[1][:na], batch_size, arrived, skip_host)
 
     def settle(self):
         """Bring the host's mirror of the buffer sizes up to date with a device-routed store (async_store)."""
         p, self._store_pending = self._store_pending, None
         if p is None:
             return
-        active_host, batch_size, arrived = p
+        active_host, batch_size, arrived, skip_host = p
         arrived.synchronize()
-        if float(self._nan_pin[0]) == 0.0:                           # (a NaN rollout was dropped on the device as well)
+        if float(skip_host[0]) == 0.0:                               # (a NaN rollout was dropped on the device as well)
             routed = active_host.numpy().reshape(batch_size, self.nb_tasks).astype(bool)
             if self.nb_tasks >= 5:
                 routed[:, 5:] = False                                # only tasks j < 5 are routed (ddpg.py:183)
@@ -1222,9 +1226,13 @@ class DDPG(object):
         ops.polyak_update(self.theta_target, self.theta, 0.0)        # ddpg.py:459-460
 
     def update_target_net(self):
-        self.check_faults(wait=False)                                # verdict of the previous cycle's copy (no stall)
+        self.check_faults(wait=False)                                # verdict of an earlier copy that has arrived (no stall)
         ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
-        self._enqueue_fault_check()                                  # once per cycle (train.py:154), behind the updates
+        # the fault word travels to the host every FAULT_CHECK_EVERY-th cycle (train.py:154: once per cycle we are here):
+        # a faulted update freezes the parameters until the word is cleared, so a late report loses nothing
+        self._fault_tick = getattr(self, '_fault_tick', 0) + 1
+        if self._fault_tick % FAULT_CHECK_EVERY == 1:
+            self._enqueue_fault_check()
 
     # ------------------------------------------------------------------ guard of the in-kernel Q' hand-off
     def _enqueue_fault_check(self):

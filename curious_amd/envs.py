@@ -125,13 +125,15 @@ class BatchedSyntheticArm(ArmSpec):
         self.td = torch.zeros([n, self.nb_tasks], device=dev)
         self.staging = torch.zeros([n, self.T + 1, self.layout.row_stride], device=dev)
         self.episode = torch.zeros(n, dtype=torch.int32, device=dev)     # episodes started so far, per env
-        self.tasks = torch.zeros(n, dtype=torch.int32, device=dev)
+        # tasks (int32) and raw goals of a rollout live in one device block: ONE H2D copy per reset
+        self._tg_dev = torch.zeros(n * 4, dtype=torch.float32, device=dev)
+        self.tasks = self._tg_dev[:n].view(torch.int32)
         self.tasks_host = np.zeros(n, np.int32)
         self.goals_host = np.zeros([n, 3], np.float32)
         # pinned staging for the per-rollout task / goal upload: the copy is enqueued without blocking the host,
         # so the next rollout can be queued behind the previous cycle's updates
         self._pin = torch.empty(n * 4, dtype=torch.float32).pin_memory()
-        self._goals_dev = torch.zeros([n, 3], device=dev)
+        self._goals_dev = self._tg_dev[n:].view(n, 3)
         self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
         # rollout flags written by the last env step: is_success per env + one "an observation is NaN" word
         self.flags = torch.zeros(n + 1, dtype=torch.float32, device=dev)
@@ -155,8 +157,7 @@ class BatchedSyntheticArm(ArmSpec):
         # the previous use of the pinned block has completed: every rollout ends with a device->host sync
         self._pin[:n].view(torch.int32).copy_(torch.from_numpy(self.tasks_host))
         self._pin[n:].view(n, 3).copy_(torch.from_numpy(self.goals_host))
-        self.tasks.copy_(self._pin[:n].view(torch.int32), non_blocking=True)
-        self._goals_dev.copy_(self._pin[n:].view(n, 3), non_blocking=True)
+        self._tg_dev.copy_(self._pin, non_blocking=True)
         ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
                       self.o, self.ag, self.g, self.td, self.staging,      # also advances self.episode on the device
                       flags=self.flags)                                    # and clears the NaN word of the coming rollout

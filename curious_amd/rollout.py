@@ -317,7 +317,7 @@ class RolloutWorker:
             self._pending = dict(tasks=tk, goals=[[] for _ in range(self.nb_goals_per_rollout)], task_list=task_list)
             self.n_episodes += B * self.nb_cpu
             views = env.episode_views()
-            self.policy.expect_async_store(views, env.flags[env.n:env.n + 1])
+            self.policy.expect_async_store(views, env.flags[env.n:env.n + 1], env._flags_pin[env.n:env.n + 1])
             return views, self.CP, self.n_episodes
         if getattr(self.policy, '_async_batch', None) is not None:
             self.policy._async_batch = None                       # a marked rollout that was never stored: forget it

@@ -123,7 +123,8 @@ int curious_prof_launch_counts(int64_t* counts_host);
  *   "rows"         1 (default; env CURIOUS_ROWS): the row-local routes; 0: the tiled multi-launch routes
  *   "rows_xcd"     1 (default; env CURIOUS_ROWS_XCD): workgroup kinds of the row-local update placed by XCD
  *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
- *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes (fault-path tests)
+ *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes; a member of group k - 1 of
+ *                  the resident-weights rollout never shows up (fault-path tests)
  *   "qt_spins"     2^22 (default): polls before a consumer of Q' gives up and raises the workspace's fault word
  *   "resident"     1 (default; env CURIOUS_RESIDENT): curious_policy_rollout keeps the actor's hidden matrices in LDS for
  *                  the whole episode (groups of 4 workgroups per 4 envs) when n <= the device's CU count; 0: every

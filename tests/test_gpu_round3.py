@@ -282,3 +282,33 @@ def test_gradients_with_the_next_gather_riding_along(route):
     for a, b in zip(*outs):
         assert torch.equal(a.nan_to_num(nan=12345.0), b.nan_to_num(nan=12345.0))     # (the pads of `grad` stay NaN)
     assert int(outs[0][3]) == 8 and bool((outs[0][4][:, :40] != -3.0).all())  # counter advanced once, batch overwritten
+
+
+def test_resident_rollout_reports_a_member_that_never_shows_up():
+    """policy_resident_kernel: the 4 workgroups of a group wait for each other.  With one member missing (option
+    fault_inject: it exits at once, like a workgroup that was never scheduled) its peers give up after res_spins polls, the
+    launch ENDS (no hang), flags[n] = 2 and the worker's flag fetch raises; the next rollout is clean."""
+    from curious_amd import _lib, logger, ops
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    nb, dimo, B = 4, 40, 64
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False)
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                      noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='random', queue_length=6,
+                      eval=False)
+    w.seed(5)
+    np.random.seed(8)
+    before = ops.prof_launch_counts()['policy_resident_kernel']
+    ep, _, _ = w.generate_rollouts()
+    torch.cuda.synchronize()
+    assert ops.prof_launch_counts()['policy_resident_kernel'] == before + 1     # the resident route is the one taken
+    assert float(w.benv.flags[B]) == 0.0
+    with ops.option('fault_inject', 3), ops.option('res_spins', 20000):
+        with pytest.raises(_lib.CuriousHipError, match='gave up waiting'):
+            w.generate_rollouts()
+    torch.cuda.synchronize()
+    assert float(w.benv.flags[B]) == 2.0
+    ep, _, _ = w.generate_rollouts()                                   # (reset clears the word)
+    torch.cuda.synchronize()
+    assert float(w.benv.flags[B]) == 0.0 and bool(torch.isfinite(ep.records).all())
