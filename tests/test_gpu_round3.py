@@ -312,3 +312,24 @@ def test_resident_rollout_reports_a_member_that_never_shows_up():
     ep, _, _ = w.generate_rollouts()                                   # (reset clears the word)
     torch.cuda.synchronize()
     assert float(w.benv.flags[B]) == 0.0 and bool(torch.isfinite(ep.records).all())
+
+
+def test_ipc_allreduce_adam_prototype_two_processes_one_gpu(tmp_path):
+    """tools/ipc_allreduce_lab.hip ("next step"): reduce-scatter over IPC-mapped peer gradients + Adam on
+    the owned slice + all-gather of the new slices as ONE kernel per rank.  Two processes share this GPU and map each
+    other's buffers through hipIpc handles; every rank's parameters must equal the host model of SUM-in-rank-order + Adam
+    bit for bit, and each other.  (Functional only: on one device there is no wire to time.)"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    exe = str(tmp_path / 'ipc_allreduce_lab')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
+                    os.path.join(root, 'tools', 'ipc_allreduce_lab.hip'), '-o', exe], check=True, timeout=600)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([exe, '2'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith('OK'), (out.stdout[-1500:], out.stderr[-1500:])
+    assert 'bit for bit' in out.stdout and 'replicas identical' in out.stdout
