@@ -535,17 +535,21 @@ def test_action_noise_kernel_matches_the_reference_method():
                                           G['n%d/%s/u' % (n, tag)])
 
 
-@pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 64), ('MultiTaskFetchArm8-v5', 8, 52, 64),
-                                                 ('MultiTaskFetchArm4-v5', 4, 40, 30)])
-def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B, route):
-    """curious_policy_rollout (all T steps in one launch on the row-local route, B % 4 == 0; the launches of the
-    single-step entry point otherwise) == T x curious_policy_act_env_step, bit for bit: episode records, last actions,
-    success / NaN flags, final env state -- over two consecutive episodes (the episode counter feeds the env's streams)."""
+@pytest.mark.parametrize('env_name,nb,dimo,B,layers', [('MultiTaskFetchArm4-v5', 4, 40, 64, 3),
+                                                        ('MultiTaskFetchArm8-v5', 8, 52, 64, 3),
+                                                        ('MultiTaskFetchArm4-v5', 4, 40, 30, 3),
+                                                        ('MultiTaskFetchArm4-v5', 4, 40, 48, 2),   # one hidden matrix: no x2
+                                                        ('MultiTaskFetchArm4-v5', 4, 40, 64, 4)])  # 3 hidden: streaming kernel
+def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B, layers, route):
+    """curious_policy_rollout (all T steps in one launch on the row-local route, B % 4 == 0 -- with 2 or 3 layers the
+    weights-resident kernel, groups of 4 workgroups per 4 envs; the launches of the single-step entry point otherwise)
+    == T x curious_policy_act_env_step, bit for bit: episode records, last actions, success / NaN flags, final env state
+    -- over two consecutive episodes (the episode counter feeds the env's streams)."""
     from curious_amd import ops
     from curious_amd.envs import EnvFactory, REWARD_EPS
     outs = []
     for mode in ('rollout', 'steps'):
-        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False)
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, layers=layers)
         env = EnvFactory(env_name).make_batched(B)
         env.seed(11)
         rs = np.random.RandomState(3)
