@@ -972,6 +972,8 @@ class DDPG(object):
             chainable = not dist.is_distributed() or (self._graph_allreduce() and self.Q_adam.t % CHAIN == 0)
             if self._device_loop() and self.use_graph and chainable and n >= CHAIN and self._cur == 0:
                 k = CHAIN
+                if dist.is_distributed() and n >= MAX_CHAIN and self.Q_adam.t % MAX_CHAIN == 0:
+                    k = MAX_CHAIN                                    # (the every-100 check falls on the chain's head)
                 if not dist.is_distributed():
                     want = min(n, MAX_CHAIN) & ~1
                     chains = getattr(self, '_chains', None) or {}
@@ -1062,7 +1064,7 @@ class DDPG(object):
         changed since the last one, so every batch is still drawn after the latest store_episode."""
         self._train_device_prologue(k)
         if dist.is_distributed():
-            assert k == 1 or (k == CHAIN and self._graph_allreduce() and 100 % CHAIN == 0)
+            assert k == 1 or (k in (CHAIN, MAX_CHAIN) and self._graph_allreduce() and 100 % CHAIN == 0 and MAX_CHAIN == 100)
             return self._train_device_ranks(k)
         graph = None
         if self.use_graph:
@@ -1144,7 +1146,8 @@ class DDPG(object):
 
     def _train_device_ranks(self, k=1):
         """k = 1: one update from the staging tensor of the current parity (which flips: the gradient launch draws the
-        next batch into the other tensor); k = CHAIN (even, parity 0): one graph of CHAIN updates, collective captured."""
+        next batch into the other tensor); k = CHAIN or MAX_CHAIN (even, parity 0): one graph of k updates with the
+        collective captured inside."""
         one_graph = self.use_graph and self._graph_allreduce()
         p = self._cur
         if self.use_graph and not one_graph:
@@ -1152,9 +1155,10 @@ class DDPG(object):
         if one_graph and k == 1 and self._graphs[p] is None:
             self._graphs[p] = self._capture(lambda: self._ranks_update(p))
             self._batch_stale = True
-        if one_graph and k > 1 and self._graph_chain is None:
+        if one_graph and k > 1 and k not in (self._graph_chain or {}):
             assert p == 0 and k % 2 == 0
-            self._graph_chain = self._capture(lambda: [self._ranks_update(i & 1, i > 0) for i in range(CHAIN)])
+            self._graph_chain = dict(self._graph_chain or {})
+            self._graph_chain[k] = self._capture(lambda: [self._ranks_update(i & 1, i > 0) for i in range(k)])
             self._batch_stale = True
         if self._batch_stale:
             self._sample_packed()
@@ -1162,7 +1166,7 @@ class DDPG(object):
         if self.Q_adam.t % 100 == 0:
             self._check_synced()
         if one_graph:
-            (self._graph_chain if k > 1 else self._graphs[p]).replay()
+            (self._graph_chain[k] if k > 1 else self._graphs[p]).replay()
         elif self.use_graph:
             self._graph_a[p].replay()
             dist.allreduce_sum_(self.grad)

@@ -143,3 +143,77 @@ def test_transposed_copy_description_and_routing_entry_without_gpu():
     rc = L.curious_route_store_episodes(fake[0], fake[1], C.byref(lay), fake[2], 4, 4, 256, fake[3], fake[4], 20000, 1, 1,
                                         None, fake[5], fake[6], fake[7], None)
     assert rc != 0 and b'launch failed' in L.curious_last_error()
+
+
+def test_round3_entry_points_host_code_without_gpu():
+    """Options, the fault-word offset, the halves of the data-parallel expert update and the gradient call with a next
+    batch: validation + descriptor / grid arithmetic up to the failing launch (sanitizer coverage of their host side)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('would launch kernels on fake pointers')
+    from curious_amd import _lib
+    L = _lib.lib()
+    # options: read per call, unknown names refused
+    assert L.curious_get_option(b'rows') == 1 and L.curious_set_option(b'rows', 0) == 0 and L.curious_get_option(b'rows') == 0
+    assert L.curious_set_option(b'rows', 1) == 0
+    assert L.curious_set_option(b'nope', 1) != 0 and b'unknown option' in L.curious_last_error()
+    assert L.curious_set_option(b'xcd_map', 5) != 0 and L.curious_get_option(b'nope') == -1
+    assert L.curious_get_option(b'resident') == 1 and L.curious_get_option(b'res_spins') == 1 << 20
+    cfg = _lib.NetCfg()
+    cfg.dimo, cfg.dimg, cfg.dimtd, cfg.layers, cfg.dimu, cfg.hidden, cfg.modular = 40, 12, 4, 3, 4, 256, 1
+    cfg.max_u, cfg.gamma, cfg.clip_return, cfg.action_l2, cfg.clip_pos_returns = 1.0, 0.98, 50.0, 1.0, 1
+    ws = L.curious_workspace_floats(C.byref(cfg), 256)
+    off = L.curious_workspace_fault_offset(C.byref(cfg), 256)
+    assert 0 < off < ws and off % 64 == 0 and L.curious_workspace_fault_offset(C.byref(cfg), 0) == -1
+    T = _lib.Transposed()
+    base = 0x40000000
+    assert L.curious_ddpg_transposed(C.byref(cfg), 256, C.c_void_p(base), C.byref(T)) == 0
+    assert T.fault == base + 4 * off                           # the optimiser finds the fault word through `keep`
+    BL = _lib.BatchLayout()
+    BL.off_o, BL.off_td, BL.off_u, BL.off_g, BL.off_o2, BL.off_g2, BL.off_r = 0, 40, 44, 48, 60, 100, 112
+    BL.off_ag, BL.off_ag2, BL.off_extra, BL.stride = 113, 125, 137, 152
+    fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(12)]
+    P = L.curious_param_total(C.byref(cfg))
+    # strides are validated first
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1000, P, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
+                                      fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
+    assert rc != 0 and b'expert_stride' in L.curious_last_error()
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P - 64, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
+                                      fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
+    assert rc != 0 and b'grad_stride' in L.curious_last_error()
+    # a next batch must be keyed by the call's own step counter and must not alias the current batch
+    lay = _lib.Layout()
+    lay.T, lay.dimo, lay.dimag, lay.dimg, lay.dimu, lay.dimtd, lay.dimextra = 50, 40, 12, 12, 4, 4, 13
+    lay.off_o, lay.off_ag, lay.off_g, lay.off_u, lay.off_td, lay.off_extra, lay.row_stride = 0, 40, 52, 64, 68, 72, 88
+    tasks, sp, rng = _lib.Tasks(), _lib.SampleParams(), _lib.SampleRng()
+    tasks.ntasks = 4
+    rng.prop_prefix, rng.cur_size, rng.nbuf, rng.step_ctr = fake[8].value, fake[9].value, 5, fake[10].value
+    nb = _lib.NextBatch()
+    nb.storage, nb.L, nb.tasks, nb.P, nb.rng = fake[11].value, C.pointer(lay), C.pointer(tasks), C.pointer(sp), C.pointer(rng)
+    nb.batch = fake[2].value
+    rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
+                              fake[5], fake[6], fake[10], 0, C.byref(nb), None)
+    assert rc != 0 and b'staging' in L.curious_last_error()
+    nb.batch = fake[7].value
+    rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
+                              fake[5], fake[6], fake[9], 0, C.byref(nb), None)
+    assert rc != 0 and b'step counter' in L.curious_last_error()
+    # ... and with everything in order the call walks its host code to the launch (single agent, then 4 experts)
+    rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
+                              fake[5], fake[6], fake[10], 0, C.byref(nb), None)
+    assert rc != 0 and b'launch failed' in L.curious_last_error()
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
+                                      fake[4], fake[5], fake[6], fake[10], 1, 104729, C.byref(nb), None)
+    assert rc != 0 and b'launch failed' in L.curious_last_error()
+    # the optimiser half for the experts, without a gather (storage NULL)
+    rc = L.curious_adam_update_and_sample_experts(4, 1 << 22, P, 104729, fake[0], fake[1], fake[2], fake[3],
+                                                  L.curious_param_offset_pi(C.byref(cfg)),
+                                                  P - L.curious_param_offset_pi(C.byref(cfg)), fake[4], fake[10], 0, 4096,
+                                                  0.9, 0.1, 0.999, 0.001, 1e-8, None, 0, C.byref(lay), C.byref(tasks),
+                                                  C.byref(sp), C.byref(rng), 256, None, C.byref(BL), C.byref(T), None)
+    assert rc != 0 and b'launch failed' in L.curious_last_error()
+    rc = L.curious_adam_update_and_sample_experts(4, 100, P, 0, fake[0], fake[1], fake[2], fake[3], 64, 64, fake[4],
+                                                  fake[10], 0, 4096, 0.9, 0.1, 0.999, 0.001, 1e-8, None, 0, C.byref(lay),
+                                                  C.byref(tasks), C.byref(sp), C.byref(rng), 256, None, C.byref(BL), None, None)
+    assert rc != 0 and b'bad strides' in L.curious_last_error()
