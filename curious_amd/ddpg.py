@@ -106,7 +106,7 @@ class DDPG(object):
         self._staged = None
         self._pp = None                                              # the two staging tensors of the device loop
         self._cur = 0
-        self._graph = self._graph_a = self._graph_b = self._graph_ba = self._graph_chain = self._graph_long = None
+        self._graph_a = self._graph_b = self._graph_ba = self._graph_chain = None    # several ranks: split / chained graphs
         self._chains = None                                          # single rank: {length: graph of that many updates}
         self._graphs = [None, None]
         self._tables_dirty = True
@@ -696,8 +696,8 @@ class DDPG(object):
         dist.broadcast_(self.theta, 0)                               # C3: one broadcast for both networks
 
     def _grads(self, chained=False):
-        """chained: the launch in front of this one on the stream was _adam_and_sample (which keeps the transposed weight
-        copies of the workspace current) inside the same captured graph -- see _update_fused."""
+        """chained: the launch in front of this one on the stream was an optimiser call that keeps the transposed weight
+        copies of the workspace current (_adam_only) inside the same captured graph -- see _update_fused."""
         b = self._staged
         ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, b, self._layout_for_batch, self.batch_size,
                        self._workspace, self.grad, self._losses, self._Q_pi,
@@ -1192,14 +1192,6 @@ class DDPG(object):
                         next_batch=self._pp[p ^ 1], storage=self._pool.storage, buf_stride=self._pool.buf_stride,
                         tasks=S.tasks, params=S.params(self.clip_obs, self.relative_goals), rng=self._rng_desc,
                         params_unchanged=chained)
-
-    def _adam_and_sample(self):
-        S = self.sample_transitions
-        ops.adam_update_and_sample(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
-                                   self._alpha_tab, self._step_ctr, self._alpha_base, self._pool.storage,
-                                   self._pool.buf_stride, self._layout, S.tasks,
-                                   S.params(self.clip_obs, self.relative_goals), self._rng_desc, self.batch_size,
-                                   self._staged, keep=self._kept_copies())
 
     def _kept_copies(self):
         """curious_transposed_t of this agent's workspace: handed to the stand-alone optimiser launch of the multi-rank

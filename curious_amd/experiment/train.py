@@ -261,7 +261,7 @@ def shutdown(policies, expert_bank=None):
     import gc
     for p in policies:
         p.finish_sync_checks()
-        p._graph = p._graph_a = p._graph_b = p._graph_ba = p._graph_chain = p._graph_long = None
+        p._graph_a = p._graph_b = p._graph_ba = p._graph_chain = None
         p._chains = None
         p._graphs = [None, None]
         p._roll_graphs = {}
