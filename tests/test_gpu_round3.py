@@ -333,3 +333,28 @@ def test_ipc_allreduce_adam_prototype_two_processes_one_gpu(tmp_path):
     out = subprocess.run([exe, '2'], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and out.stdout.strip().endswith('OK'), (out.stdout[-1500:], out.stderr[-1500:])
     assert 'bit for bit' in out.stdout and 'replicas identical' in out.stdout
+
+
+def test_training_learns_the_synthetic_arm_and_reproduces_the_committed_curve(tmp_path):
+    """End to end: launch() with the throughput configuration (256 GPU-resident envs, device RNG, hipGraphs, async store,
+    resident rollout) for 70 epochs of 25 cycles x 40 updates.  The test success rate must follow the committed learning
+    curve (profiles/r03_learning_curve_arm4.csv, same seed: the run is deterministic) and end above 0.9 -- every kernel
+    of the cycle takes part, a silent numerical regression anywhere shows up here."""
+    import csv
+    import os
+    from curious_amd.experiment import config, train
+    config.CACHED_ENVS.clear()
+    over = dict(rollout_batch_size=256, n_cycles=25, n_batches=40, rng_mode='device', use_graph=True, async_store=True)
+    np.random.seed(0)
+    best = train.launch(env='MultiTaskFetchArm4-v5', trial_id=0, n_epochs=70, num_cpu=1, seed=1, policy_save_interval=0,
+                        clip_return=1, normalize_obs=False, structure='curious',
+                        task_selection='active_competence_progress', goal_selection='random', goal_replay='her',
+                        task_replay='replay_task_cp_buffer', save_policies=False, override_params=over,
+                        save_root=str(tmp_path) + '/')
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'MultiTaskFetchArm4-v5', '0', 'progress.csv'))))
+    got = [float(r['test/success_rate']) for r in rows]
+    assert len(got) == 71 and max(got) >= 0.95 and got[-1] >= 0.9, got[-5:]       # (`best` is only tracked when saving)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r03_learning_curve_arm4.csv'))))
+    want = [float(r['test/success_rate']) for r in ref[:71]]
+    assert got == want, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:5]
