@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
+L2_PEAK_TBS = 34.5              # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs; 135 GB/s per CU)
 
 ENV = 'MultiTaskFetchArm4-v5'
 B_R = 256                      # parallel rollouts per GPU (configs[1])
@@ -184,10 +185,19 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     net = lambda S, D: (S + G) * H + hid * H * H + H * D          # multiply-adds of one forward pass per row
     rows_fwd = 2 * net(Sa, U) + 3 * net(Sc, 1)                    # target actor, actor; target critic, critic(u), critic(pi)
     rows_bwd = (hid * H * H + H) + (hid * H * H + H + U * H) + (hid * H * H + H * U)
+    # bytes of weights the row-local update pulls L2 -> CU per launch: every workgroup (4 batch rows, one of three kinds)
+    # streams every matrix of its chain once (THIS is what bounds a layer, not MFMA and not HBM)
+    l0pi, l0q, hidw = (Sa + G) * H, (Sc + G) * H, hid * H * H
+    w_actor = l0pi + hidw + H * U + l0q + hidw + H + hidw + U * H + H * U + hidw
+    w_target = l0pi + hidw + H * U + l0q + hidw + H
+    w_critic = l0q + hidw + 2 * H + hidw
+    rows_l2_bytes = 4 * (w_actor + w_target + w_critic) * (B // 4)
     return dict(
         # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
-        ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1),
-        ddpg_rows_her_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1),
+        ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
+                              l2_stream_bytes=rows_l2_bytes),
+        ddpg_rows_her_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
+                                  l2_stream_bytes=rows_l2_bytes),
         policy_rows_kernel=dict(bound='mfma', per_update=0, launches_update=0, per_env_step=2 * B_R * net(Sa, U),
                                 launches_env_step=1),
         # the weights-resident rollout: layer 0 is computed by all 4 members of a group (x 4), the rest once
@@ -297,9 +307,16 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms):
         ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
     else:
         ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
-    return dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
-                frac=round(ach / peak, 5), traffic=pmc_traffic(dominant), algorithmic_per_launch=round(per_launch, 1),
-                avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3)), table
+    out = dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
+               frac=round(ach / peak, 5), traffic=pmc_traffic(dominant), algorithmic_per_launch=round(per_launch, 1),
+               avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3))
+    if 'l2_stream_bytes' in w:
+        # the resource that actually bounds this kernel: weight bytes streamed L2 -> CU (each CU's fill path), against the
+        # aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s over 256 CUs; the launch occupies 192 of them)
+        tb = w['l2_stream_bytes'] / avg_s / 1e12
+        out['l2_stream'] = dict(achieved=round(tb, 3), peak=L2_PEAK_TBS, unit='TB/s', frac=round(tb / L2_PEAK_TBS, 4),
+                                bytes_per_launch=int(w['l2_stream_bytes']))
+    return out, table
 
 
 def cpu_baseline(seed=0, budget_s=20.0):
