@@ -275,6 +275,66 @@ __device__ __forceinline__ void streamer(const Args& a, float* hs, float* part, 
   if (tid == 0) a.cyc[b] = t1 - t0;
 }
 
+// streamer with the SHIFTED two-buffer schedule: the loads of chunk c + 2 are issued right AFTER chunk c has been
+// multiplied (its buffer is free), so two chunks are always in flight -- also across the layer boundary, where the
+// classic schedule (loads of chunk c + 1 issued before chunk c is multiplied) leaves the CU's fill path idle for most of
+// the epilogue (partial tiles -> LDS -> barrier -> bias / relu -> barrier)
+__device__ __forceinline__ void streamer_shifted(const Args& a, float* hs, float* part, int b) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 4 * H / 4; i += 256) {
+    const int r = i / (H / 4), c = (i % (H / 4)) * 4;
+    *reinterpret_cast<f32x4*>(hs + r * HLD + c) = ldv(a.X + (size_t)r * H + c);
+  }
+  f32x4 wb[2][16];
+  const float* wl = a.W + (size_t)(64 * wave) * H + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wb[0][i] = ldv(wl + (size_t)i * H);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wb[1][i] = ldv(wl + (size_t)(16 + i) * H);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int l = 0; l < a.L; ++l) {
+    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    const float bv = a.bias[(size_t)l * H + tid];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * HLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA4(av[s], wb[c & 1][4 * kq + s][e], acc[e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // chunk c + 2: of this layer for c < 2, of the next layer otherwise
+      const float* nx = (c < 2) ? wl + (size_t)(16 * (c + 2)) * H : wl + (size_t)H * H + (size_t)(16 * (c - 2)) * H;
+      if (c < 2 || l + 1 < a.L) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[c & 1][i] = ldv(nx + (size_t)i * H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wl += (size_t)H * H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      *reinterpret_cast<f32x4*>(part + (wave * 4 + r) * 256 + 4 * lane) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = (part[(0 * 4 + r) * 256 + tid] + part[(1 * 4 + r) * 256 + tid]) +
+                      (part[(2 * 4 + r) * 256 + tid] + part[(3 * 4 + r) * 256 + tid]);
+      hs[r * HLD + tid] = fmaxf(s + bv, 0.f);
+      if (l == a.L - 1) a.Y[(size_t)((b & 63) * 4 + r) * H + tid] = hs[r * HLD + tid];
+    }
+    __syncthreads();
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) a.cyc[b] = t1 - t0;
+}
+
 template <int R, int FORM>
 __global__ __launch_bounds__(256) void quadchain(Args a) {
   __shared__ __attribute__((aligned(16))) float hs[R * HLD];
@@ -284,7 +344,8 @@ __global__ __launch_bounds__(256) void quadchain(Args a) {
   if (b < a.nquad_blocks) {
     if (FORM) quad_member_lds<R>(a, hs, part, stage, b);
     else quad_member<R>(a, hs, part, b);
-  } else streamer(a, hs, part, b);
+  } else if (FORM == 2) streamer_shifted(a, hs, part, b);
+  else streamer(a, hs, part, b);
 }
 
 template <int R, int FORM = 0>
@@ -316,7 +377,7 @@ static void run(Args a, int quads, int streamers, int L) {
   for (int b = 0; b < quads * 4; ++b) cq += (double)cyc[b] / L;
   for (int b = quads * 4; b < grid; ++b) cs += (double)cyc[b] / L;
   printf("%s %3d quads x 4 (R = %2d rows, %3d rows) + %3d streamers: L=2 %.2f us, L=%d %.2f us -> %.2f us per layer; in-kernel "
-         "cycles per layer: quad members %.0f, streamers %.0f%s\n", FORM ? "[16 B loads + LDS stage]" : "[4 B loads]             ",
+         "cycles per layer: quad members %.0f, streamers %.0f%s\n", FORM == 2 ? "[shifted schedule]      " : FORM ? "[16 B loads + LDS stage]" : "[4 B loads]             ",
          quads, R, quads * R, streamers, best[0] * 1e3f, L,
          best[1] * 1e3f, (best[1] - best[0]) * 1e3f / (L - 2), quads ? cq / (quads * 4) : 0.0,
          streamers ? cs / streamers : 0.0, err ? "  ** a wait timed out **" : "");
@@ -352,6 +413,8 @@ int main() {
   run<8>(a, 32, 128, L);        // the update's shape: actor side as quads of 8 rows + 128 whole-matrix streamers = 256 workgroups
   run<4>(a, 64, 128, L);        // actor side as quads of 4 rows + 128 streamers = 384 workgroups (some CUs host two)
   run<16>(a, 16, 128, L);
+  run<4, 2>(a, 0, 64, L);       // streamers only, shifted two-buffer schedule
+  run<4, 2>(a, 0, 192, L);
   run<4, 1>(a, 64, 0, L);
   run<8, 1>(a, 32, 0, L);
   run<8, 1>(a, 32, 128, L);
