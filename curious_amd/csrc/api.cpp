@@ -96,6 +96,7 @@ CuriousOptions& curious_options() {
     o.fault_inject = 0;
     o.qt_spins = 1 << 22;
     o.lab_no_target = 0;
+    o.lab_res_stamps = 0;
     o.resident = env_int("CURIOUS_RESIDENT", 1) != 0;
     o.res_spins = 1 << 20;
     init = true;
@@ -111,6 +112,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "fault_inject")) return &o.fault_inject;
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
   if (!strcmp(name, "lab_no_target")) return &o.lab_no_target;
+  if (!strcmp(name, "lab_res_stamps")) return &o.lab_res_stamps;
   if (!strcmp(name, "resident")) return &o.resident;
   if (!strcmp(name, "res_spins")) return &o.res_spins;
   return nullptr;

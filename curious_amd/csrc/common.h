@@ -89,6 +89,8 @@ struct CuriousOptions {
   int resident;        // 1: multi-step rollouts keep the actor's hidden matrices in LDS (mlp_rows_res.h) when the grid fits
                        // the device; 0: policy_rows_kernel streams them every step                     [CURIOUS_RESIDENT]
   int res_spins;       // polls before a member of a resident-rollout group gives up on a peer
+  int lab_res_stamps;  // LAB ONLY (tools/res_stamps.py): policy_resident_kernel adds per-phase cycle stamps of block 0 to 8
+                       // 64-bit words behind its exchange buffer in the workspace
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere
 };

@@ -463,6 +463,9 @@ static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, hipSt
   rx.xmap = (n % 32 == 0) ? 1 : 0;
   rx.spins = curious_options().res_spins;
   rx.inject = curious_options().fault_inject;
+  // lab: per-phase cycle stamps of block 0 behind the exchange buffer (the workspace has room: checked by the caller)
+  rx.stamps = curious_options().lab_res_stamps
+                  ? reinterpret_cast<unsigned long long*>(workspace + res_xbuf_floats(n)) : nullptr;
   const size_t lds = res_lds_floats(a.nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {

@@ -36,7 +36,16 @@ struct ResX {
   int32_t spins;
   int32_t inject;                // > 0 (tests, option "fault_inject"): member 1 of group inject - 1 exits at once -- a
                                  // workgroup that was never scheduled, as far as its peers can tell
+  unsigned long long* stamps;    // lab only (option "lab_res_stamps", tools/res_stamps.py): [8] summed cycles of block 0:
+                                 // layer 0 | slice 1 | x2 | slice 2 + h2s | output partials | x3 + noise | env step | steps
 };
+#define RES_STAMP(i)                                                                          \
+  do {                                                                                        \
+    if (rx.stamps && blockIdx.x == 0 && x.tid == 0) {                                         \
+      const unsigned long long n__ = __builtin_readcyclecounter();                            \
+      rx.stamps[i] += n__ - last_stamp; last_stamp = n__;                                     \
+    }                                                                                         \
+  } while (0)
 
 static inline size_t res_lds_floats(int nl) {
   return (size_t)(nl - 1) * 64 * 256 + 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + 4 * 64 + (size_t)4 * 3 * 4 * RES_NOISE_CH * 2;
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
   uint32_t q = (uint32_t)(2ull * ctr0) + 1u;                 // tag of the next exchange
   bool lost = false;
   int max_spins = rx.spins;                                  // (after a lost exchange: no more waiting, the rollout is void)
+  unsigned long long last_stamp = __builtin_readcyclecounter();
   for (int s = 0; s < a.nsteps; ++s) {
     if ((s % RES_NOISE_CH) == 0) {
       // exploration noise of the next RES_NOISE_CH steps of this wave's env, drawn by all 64 lanes (mlp_rows_act.h)
@@ -173,8 +183,11 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       }
     }
     __syncthreads();                                         // input rows (and, first step, the slices) are in LDS
+    if (rx.stamps && blockIdx.x == 0 && x.tid == 0) last_stamp = __builtin_readcyclecounter();
     rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr, rnext(RN_NONE, nullptr));
+    RES_STAMP(0);
     float v1 = res_slice(x, w1s, bias1);
+    RES_STAMP(1);
     if (nh > 1) {
       // x2: all-gather the slices of the first hidden layer into hs
       const int r = x.tid >> 6, c = x.tid & 63;
@@ -189,10 +202,12 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       for (int p = 1; p < 4; ++p) x.hs[r * RLD + 64 * ((member + p) & 3) + c] = pv[p - 1];
       ++q;
       __syncthreads();
+      RES_STAMP(2);
       v1 = res_slice(x, w2s, bias2);
     }
     h2s[x.tid] = v1;
     __syncthreads();
+    RES_STAMP(3);
     // output layer: the partial sums over this member's 64 hidden units = DPP row `member` of rows_head4's reduction
     {
       const f32x4 h4 = *reinterpret_cast<const f32x4*>(h2s + x.wave * 64 + 4 * (x.lane & 15));
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       }
       if (x.lane < 4) res_put(xg + ((q & 1) * 4 + member) * 256 + 4 * x.wave + x.lane, q, pd);
     }
+    RES_STAMP(4);
     // the next step's layer-0 weights: in flight while this member waits for the partials
     if (s + 1 < a.nsteps) rows_l0_load(wb[0], pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G, x.wave, x.lane, 0);
     float* s_u = x.sm + 8 * x.wave;
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       if (member == 0) a.u_out[(int64_t)m * a.ldu + x.lane] = v;
     }
     ++q;
+    RES_STAMP(5);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -233,6 +250,8 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     else
       ov = env_step_core<false>(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
                                 a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip);
+    RES_STAMP(6);
+    if (rx.stamps && blockIdx.x == 0 && x.tid == 0) rx.stamps[7] += 1;
   }
   // a member that gave up on a peer: the rollout is void, the host has to know
   if (__any(lost) && x.lane == 0 && a.flags) a.flags[a.n] = 2.0f;
