@@ -452,7 +452,9 @@ int curious_policy_act_env_step(const curious_net_cfg_t* cfg, const float* theta
  * keep a quarter of every hidden matrix each in LDS for the whole launch and exchange activations through the first
  * n * 1024 floats of `workspace` -- which must then not be shared with a launch running concurrently, and whose
  * (seed, counter) pairs must not repeat (they tag the exchanged words).  The members wait for each other: should one
- * never be scheduled the others give up after "res_spins" polls and flags[n] is set to 2 (the rollout is void). */
+ * never be scheduled the others give up after "res_spins" polls and flags[n] is set to 2 (the rollout is void).  The
+ * route assumes that the process has the device to itself (one process per GPU); several processes sharing one device
+ * set option "resident" = 0. */
 int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                            float* workspace, double noise_scale, double random_eps, uint64_t seed, uint64_t counter,
                            const int64_t* counter_base, float* u_out, int32_t ldu, const curious_env_cfg_t* E,

@@ -319,7 +319,10 @@ def test_two_ranks_share_one_gpu_over_gloo():
         port = sk.getsockname()[1]
     import tempfile
     prefix = os.path.join(tempfile.mkdtemp(), 'digest')
-    env = dict(os.environ, CURIOUS_DIST_BACKEND='gloo', CURIOUS_RANK_CHECK_CYCLES='2', CURIOUS_RANK_CHECK_OUT=prefix)
+    # (two processes on ONE device: the weights-resident rollout needs all CUs for one launch -- two such launches from two
+    #  processes can starve each other of CUs until they time out; one process per GPU, the deployment model, cannot)
+    env = dict(os.environ, CURIOUS_DIST_BACKEND='gloo', CURIOUS_RANK_CHECK_CYCLES='2', CURIOUS_RANK_CHECK_OUT=prefix,
+               CURIOUS_RESIDENT='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CURIOUS_FORCE_DIST', 'CURIOUS_GRAPH_ALLREDUCE'):
         env.pop(k, None)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',

@@ -224,6 +224,8 @@ def _run_rank_check(extra, nproc=1, timeout=900):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
                '--master-addr', '127.0.0.1', '--master-port', str(port), script]
     env.update(extra)
+    if nproc > 1:
+        env['CURIOUS_RESIDENT'] = '0'           # several processes on ONE device must not both claim every CU
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     return [open('%s.rank%d' % (prefix, r)).read().split() for r in range(nproc)]
