@@ -1245,7 +1245,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
   }
   if (!rc) rc = p.weight_grads(tail);
   if (!rc && next && !p.gather_in_rows) {
-    if (xd.nex > 1) { curious_set_error("batched experts need the row-local route for the gather of the next batch"); return -1; }
+    if (xd.nex > 1) { curious_set_error("batched experts need the lean route (row-local kernels) for the gather of the next batch"); return -1; }
     rc = curious_her_sample(next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
                             next->batch, BL, stream);
   }
