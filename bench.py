@@ -237,8 +237,7 @@ def profile_pass(policy, worker, n_cycles=1):
     policy.use_graph = False
 
     def updates():
-        for _ in range(N_BATCHES):
-            policy.train()
+        policy.train_batches(N_BATCHES)
     updates()                                                     # warm the eager path
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -528,6 +527,7 @@ def main():
     import numpy as np
     import torch
     from curious_amd import dist, ops
+    from curious_amd.util import freeze_setup_objects
     dist.init_from_env()
     rank, world = dist.rank(), dist.world_size()
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
@@ -553,6 +553,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    freeze_setup_objects()                                        # as experiment/train.py does before its epoch loop
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -206,6 +206,7 @@ __device__ inline void norm_recompute_elem(float* acc, float* state, int dim, in
   stdv[c] = sqrtf(fmaxf(__fmul_rn(eps, eps), var));
 }
 
+#define NF_COLS 6
 // one workgroup of 16 wavefronts: wave w finishes columns w, w + 16, ... of [sum_a | sum_b | sumsq_a | sumsq_b]
 __global__ __launch_bounds__(1024) void norm_pair_final_kernel(const double* __restrict__ partial, int32_t nb,
                                                               int32_t dim_a, int32_t dim_b, int32_t n_rows,
@@ -215,14 +216,32 @@ __global__ __launch_bounds__(1024) void norm_pair_final_kernel(const double* __r
   if (skip && *skip != 0.0f) return;                        // a NaN rollout (rollout.py:268-271) feeds no statistics
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ncol = dim_a + dim_b;
-  for (int c = wave; c < 2 * ncol; c += 16) {
-    double s = 0.0;
-    for (int b = lane; b < nb; b += 64) s = __dadd_rn(s, partial[(int64_t)c * nb + b]);
-    s = wave_sum_f64(s);
-    if (lane == 0) {
-      const int kind = c / ncol, vc = c - kind * ncol;
-      float* p = (vc < dim_a) ? acc_a + kind * dim_a + vc : acc_b + kind * dim_b + (vc - dim_a);
-      *p = (float)__dadd_rn((double)*p, s);                 // normalizer.py:68-69 (f32 += f64 array)
+  // NF_COLS columns of a wave at a time: their loads are independent, so NF_COLS of them are in flight per lane; the
+  // order of the additions of one column (lane-strided, then wave_sum_f64) does not depend on NF_COLS
+  for (int c0 = wave; c0 < 2 * ncol; c0 += 16 * NF_COLS) {
+    double s[NF_COLS];
+#pragma unroll
+    for (int u = 0; u < NF_COLS; ++u) s[u] = 0.0;
+    for (int b = lane; b < nb; b += 64) {
+      double v[NF_COLS];
+#pragma unroll
+      for (int u = 0; u < NF_COLS; ++u) {
+        const int c = c0 + 16 * u;
+        v[u] = (c < 2 * ncol) ? partial[(int64_t)c * nb + b] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < NF_COLS; ++u) s[u] = __dadd_rn(s[u], v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NF_COLS; ++u) {
+      const int c = c0 + 16 * u;
+      if (c >= 2 * ncol) break;
+      const double t = wave_sum_f64(s[u]);
+      if (lane == 0) {
+        const int kind = c / ncol, vc = c - kind * ncol;
+        float* p = (vc < dim_a) ? acc_a + kind * dim_a + vc : acc_b + kind * dim_b + (vc - dim_a);
+        *p = (float)__dadd_rn((double)*p, t);               // normalizer.py:68-69 (f32 += f64 array)
+      }
     }
   }
   if (threadIdx.x == 0) {

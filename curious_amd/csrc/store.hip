@@ -65,6 +65,8 @@ __host__ __device__ inline int64_t store_random_slot(uint64_t seed, uint64_t cal
 // semantics) and the earlier pair is marked dead (src = -1).  Writes the (src, dst) pair list, its length, and the new
 // sizes into the sampler's table.
 #define ROUTE_MAX_EPISODES 2048
+#define ROUTE_HASH 4096u                                     // >= 2 x ROUTE_MAX_EPISODES, a power of two
+__device__ inline unsigned route_hash(int slot) { return ((unsigned)slot * 2654435761u >> 16) & (ROUTE_HASH - 1u); }
 __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __restrict__ active, int32_t ntasks,
                                                             int32_t n_route, int32_t n_episodes,
                                                             int32_t* __restrict__ cur_size,
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
                                                             int32_t* __restrict__ n_pairs) {
   __shared__ int wave_cnt[4];
   __shared__ int slot_of[ROUTE_MAX_EPISODES];                // this task's slot per episode, -1: not routed
+  __shared__ int rank_of[ROUTE_MAX_EPISODES];                // its position in this task's part of the pair list
+  __shared__ int hkey[ROUTE_HASH], hval[ROUTE_HASH];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (skip && *skip != 0.0f) {                               // the rollout produced a NaN observation: keep nothing
     if (tid == 0) *n_pairs = 0;
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
           slot = (cur0 + rank < capacity) ? cur0 + rank : (int)store_random_slot(seed, call, b, j, capacity);
           pair_src[out0 + rank] = b;
           pair_dst[out0 + rank] = pool + slot;
+          rank_of[b] = rank;
         }
         slot_of[b] = slot;
       }
@@ -114,20 +119,32 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
       __syncthreads();
     }
     if (cur0 + routed > capacity) {
-      // random slots were drawn: an episode loses its slot to any later episode of the batch on the same slot
-      for (int b0 = 0; b0 < n_episodes; b0 += 256) {
-        const int b = b0 + tid;
-        const int mine = (b < n_episodes) ? slot_of[b] : -1;
-        if (mine >= 0) {
-          bool dead = false;
-          int rank = 0;                                      // this episode's position in the pair list
-          for (int c = 0; c < n_episodes; ++c) {
-            const int s = slot_of[c];
-            rank += (c < b && s >= 0);
-            dead |= (c > b && s == mine);
-          }
-          if (dead) pair_src[out0 + rank] = -1;
+      // random slots were drawn: an episode loses its slot to any later episode of the batch on the same slot.  The
+      // last episode per slot is found through an open-addressed table in LDS (key: slot, value: max episode index),
+      // O(episodes) instead of comparing every pair.
+      for (int h = tid; h < ROUTE_HASH; h += 256) {
+        hkey[h] = -1;
+        hval[h] = -1;
+      }
+      __syncthreads();
+      for (int b = tid; b < n_episodes; b += 256) {
+        const int mine = slot_of[b];
+        if (mine < 0) continue;
+        unsigned h = route_hash(mine);
+        for (;;) {
+          const int prev = atomicCAS(&hkey[h], -1, mine);
+          if (prev == -1 || prev == mine) break;
+          h = (h + 1u) & (ROUTE_HASH - 1u);
         }
+        atomicMax(&hval[h], b);
+      }
+      __syncthreads();
+      for (int b = tid; b < n_episodes; b += 256) {
+        const int mine = slot_of[b];
+        if (mine < 0) continue;
+        unsigned h = route_hash(mine);
+        while (hkey[h] != mine) h = (h + 1u) & (ROUTE_HASH - 1u);
+        if (hval[h] > b) pair_src[out0 + rank_of[b]] = -1;
       }
       __syncthreads();
     }

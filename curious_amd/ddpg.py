@@ -938,6 +938,13 @@ class DDPG(object):
         self._alpha_filled = t0 + n
         self._step_ctr.fill_(t0)
 
+    def _keep_alpha_ahead(self):
+        """Called right AFTER a run of updates was enqueued: refill the step-size ring while the GPU is busy with that
+        run (the refill is ~3 ms of host arithmetic; in front of a run, as _train_device_prologue does it when it has
+        to, the GPU waits for it)."""
+        if self.Q_adam.t + 2 * MAX_CHAIN > self._alpha_filled:
+            self._fill_alpha_table()
+
     def _device_loop(self):
         """The device-resident update loop applies: device-drawn batches from the pooled per-task buffers."""
         return self.rng_mode == 'device' and self._multi_buffer() and \
@@ -979,6 +986,8 @@ class DDPG(object):
                     chains = getattr(self, '_chains', None) or {}
                     if want in chains or len(chains) < MAX_CHAIN_GRAPHS:
                         k = want
+            elif self._device_loop() and not self.use_graph and not dist.is_distributed() and n >= 2:
+                k = min(n, MAX_CHAIN)                                # eager launches: one run, copies kept between updates
             out = self._train_device(k) if self._device_loop() else self.train()
             n -= k
         return out
@@ -1011,6 +1020,7 @@ class DDPG(object):
         self._staged = self._pp[self._cur]
         self.Q_adam.t += n
         self.pi_adam.t += n
+        self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
 
     def _rank_graphs(self):
@@ -1097,6 +1107,7 @@ class DDPG(object):
         self._staged = self._pp[self._cur]
         self.Q_adam.t += k
         self.pi_adam.t += k
+        self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
 
     @staticmethod
@@ -1177,6 +1188,7 @@ class DDPG(object):
         self._staged = self._pp[self._cur]
         self.Q_adam.t += k
         self.pi_adam.t += k
+        self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
 
     def _update_fused(self, p, chained=False):

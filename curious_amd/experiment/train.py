@@ -18,7 +18,7 @@ import torch
 from curious_amd import dist, logger
 from curious_amd.experiment import config
 from curious_amd.rollout import RolloutWorker
-from curious_amd.util import find_save_path, mpi_average
+from curious_amd.util import find_save_path, freeze_setup_objects, mpi_average
 
 ENV = 'MultiTaskFetchArm4-v5'
 NUM_CPU = 1
@@ -44,6 +44,7 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
         latest_policy_path = best_policy_path = periodic_policy_path = None
     best_success_rate = -1
     nb_tasks = params['nb_tasks']
+    freeze_setup_objects()
 
     if structure == 'task_experts':
         p = 1 / nb_tasks * np.ones([nb_tasks])

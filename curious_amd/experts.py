@@ -202,6 +202,7 @@ class ExpertBank:
             x._staged = x._pp[x._cur]
             x.Q_adam.t += k
             x.pi_adam.t += k
+            x._keep_alpha_ahead()
 
     def _train_ranks(self, k):
         """k updates of every expert on several ranks (the staging tensors alternate like on one rank: the gradient

@@ -274,6 +274,14 @@ def test_step_size_ring_refill_under_chained_graphs():
     assert a_graph.Q_adam.t == a_eager.Q_adam.t == 4200 == int(a_graph._step_ctr)
     assert torch.equal(a_graph.theta, a_eager.theta)
     assert torch.isfinite(a_graph.theta).all()
+    # the ring was refilled BEHIND a run of updates (DDPG._keep_alpha_ahead), never in front of one: the entries the last
+    # updates read are the float64 host formula rounded to float32
+    from curious_amd.ddpg import ALPHA_TAB
+    tab = a_graph._alpha_tab.cpu().numpy()
+    for t in (4097, 4150, 4200):
+        assert tab[(t - 1) % ALPHA_TAB, 0] == np.float32(a_graph.Q_adam.alpha(a_graph.Q_lr, t))
+        assert tab[(t - 1) % ALPHA_TAB, 1] == np.float32(a_graph.pi_adam.alpha(a_graph.pi_lr, t))
+    assert a_graph._alpha_filled >= 4200 + 100
 
 
 def test_rank_paths_match_single_rank():

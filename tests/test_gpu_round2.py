@@ -634,14 +634,16 @@ def test_async_store_equals_the_host_routed_cycle(use_graph):
     assert max(res[1][-1]['sizes'][1:]) == 100                   # a full buffer: random slots, async and host-routed alike
 
 
-def test_route_store_kernel_matches_the_host_routing():
+@pytest.mark.parametrize('E,cap', [(300, 150), (1500, 400), (2048, 5000)])
+def test_route_store_kernel_matches_the_host_routing(E, cap):
     """curious_route_store_episodes against the host routing of DDPG.store_episode (fits case) for random activity
-    patterns: pair list, new sizes, stored records; 8 tasks (only the first 5 are routed), 300 episodes (two scan passes);
-    and the NaN word that makes it store nothing."""
+    patterns: pair list, new sizes, stored records; 8 tasks (only the first 5 are routed), 300 episodes (two scan passes)
+    up to the 2048 the entry point accepts, buffers that overflow into random slots with many / few collisions inside the
+    batch; and the NaN word that makes it store nothing."""
     from curious_amd import ops
     from curious_amd.layout import RecordLayout
     rng = np.random.RandomState(4)
-    nb, E, cap, Tn = 8, 300, 150, 5                               # 150 slots: ~120 routed episodes per task overflow it
+    nb, Tn = 8, 5                                                 # 150 slots: ~120 routed episodes per task overflow it
     shapes = dict(o=(Tn + 1, 6), u=(Tn, 4), g=(Tn, 3), ag=(Tn + 1, 3), info_is_success=(Tn, 1), task_descr=(Tn, nb),
                   change=(Tn, 3))
     lay = RecordLayout(shapes, Tn)
@@ -651,7 +653,7 @@ def test_route_store_kernel_matches_the_host_routing():
     alias = torch.tensor([0, 1, 2, 3, 4, 5, 5, 5, 5], dtype=torch.int32, device=dev)
     for skip_val in (0.0, 1.0):
         storage = torch.zeros([6, cap, Tn + 1, lay.row_stride], device=dev)
-        cur0 = rng.randint(1, 50, nb + 1).astype(np.int32)
+        cur0 = rng.randint(cap - 149, cap - 100, nb + 1).astype(np.int32)
         cur = torch.from_numpy(cur0.copy()).to(dev)
         src = torch.zeros(E * 5, dtype=torch.int32, device=dev)
         dst = torch.zeros(E * 5, dtype=torch.int64, device=dev)
