@@ -701,6 +701,13 @@ struct DdpgPass {
   // counter's increment moves to the weight-gradient launch (mlp_rows.h RowsArgs.n_her)
   bool gather_in_rows = false;
   HerArgs her_rows;
+  // one-launch update (mlp_rows.h ddpg_step_kernel): rows_pass() only prepares the row-local launch, weight_grads()
+  // enqueues it together with its tiles -- or, should the tile lists not qualify, on its own first (launch_rows)
+  bool one_launch = false;
+  bool rows_pending = false;
+  RowsArgs ra;
+  size_t ra_lds = 0;
+  int launch_rows();
   int forward();
   int critic_backward();
   int actor_backward();
@@ -805,10 +812,28 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_step_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipGetLastError();                                 // a refusal here must not be mistaken for a failed launch
     lds_set = true;
   }
   a.n_her = gather_in_rows ? B / ROWS_R : 0;                 // (SPB == ROWS_R: as many gather blocks as row groups)
+  ra = a;
+  ra_lds = lds;
+  rows_pending = true;
+  if (!one_launch && launch_rows()) return -1;
+  // what weight_grads() reads of the tiled route's state
+  dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
+  fuse_pi = use_part = fuse_crit = false;
+  urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);
+  return 0;
+}
+
+int DdpgPass::launch_rows() {
+  const Ex ex = make_ex(xd, 1);
+  const RowsArgs& a = ra;
+  const size_t lds = ra_lds;
+  rows_pending = false;
   dim3 grid((a.xmap || gather_in_rows ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
   if (gather_in_rows) {
     ProfScope ps__(CK_ROWS_HER, st);
@@ -820,10 +845,6 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
     else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex);
   }
   CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");
-  // what weight_grads() reads of the tiled route's state
-  dx_hot = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
-  fuse_pi = use_part = fuse_crit = false;
-  urow = cfg->dimo + (cfg->modular ? cfg->dimtd : cfg->dimg);
   return 0;
 }
 
@@ -1125,7 +1146,12 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   DwSmallArgs& smAll = dwAll.small;
   int tAll = 0, stAll = 0;
   bool lean_dw = dw_hot && 2 * (nl - 1) <= 4;
-  if (lean_dw) lean_dw = build_net(true, hwAll, tAll, smAll, stAll) && build_net(false, hwAll, tAll, smAll, stAll);
+  int n_small_critic = 0;
+  if (lean_dw) {
+    lean_dw = build_net(true, hwAll, tAll, smAll, stAll);
+    n_small_critic = smAll.nprob;
+    lean_dw = lean_dw && build_net(false, hwAll, tAll, smAll, stAll);
+  }
   CURIOUS_CHECK(xd.nex == 1 || lean_dw, "batched experts need the lean weight-gradient launch");
   if (lean_dw) {
     smAll.fin = fin;
@@ -1133,6 +1159,35 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     hwAll.tiles_per = (H / 16) * (H / 64);
     smAll.slots = stAll > 0 ? stAll : 1;
     const int nsmall = smAll.nprob * smAll.slots;           // + 1 block for the loss finalisation
+    if (rows_pending && tail && copies_kept) {
+      // the whole update in one launch of 4 * nrg workgroups: row groups (the spare quarter gathers the next batch), each
+      // followed by its share of the tiles (mlp_rows.h ddpg_step_kernel)
+      RowsArgs a = ra;
+      const int nrg = B / ROWS_R;
+      a.n_her = tail->her ? nrg : 0;
+      a.sync = w.fault + STEP_SYNC_OFFSET;
+      a.n_tickets = 4 * nrg;
+      a.lab_step = curious_options().lab_step;
+      if (a.lab_step & 8) a.stamps = reinterpret_cast<unsigned long long*>(w.part[0]);   // lab: [256] 64-bit stamps
+      AdamFuse A = tail->adam;
+      A.step_add = 1;                                        // nothing advances the counter while the launch runs
+      smAll.fin.step_ctr = nullptr;                          // (the last ticket does)
+      StepPlan plan;
+      plan.hot_c = plan.hot_a = (nl - 1) * hwAll.tiles_per;  // build_net(critic) queued its hidden matrices first
+      smAll.tile0[0] = 0;
+      for (int i = 0; i < smAll.nprob; ++i)
+        smAll.tile0[i + 1] = smAll.tile0[i] + ((smAll.p[i].w + 15) / 16) * ((smAll.p[i].N + 63) / 64);
+      smAll.n_crit = n_small_critic;
+      plan.small_c = smAll.tile0[n_small_critic];
+      plan.small_a = smAll.tile0[smAll.nprob] - plan.small_c;
+      rows_pending = false;
+      { ProfScope ps__(CK_STEP, st);
+        hipLaunchKernelGGL(ddpg_step_kernel, dim3(4 * nrg), dim3(256), ra_lds, st, a, make_ex(xd, 1), dwAll, A, tail->h,
+                           plan); }
+      CURIOUS_LAUNCH_CHECK("ddpg_step_kernel");
+      return 0;
+    }
+    if (rows_pending && launch_rows()) return -1;
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       { ProfScope ps__(CK_DW_ADAM_HER, st);
@@ -1147,6 +1202,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll, xd.stride, xd.gstride); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
+    if (rows_pending && launch_rows()) return -1;
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     // generic path: every weight/bias gradient + the loss finalisation in one grouped launch
     DwArgs wa;
@@ -1237,6 +1293,13 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     // the copies are kept current by this pass's own optimiser tail (maintained), or -- without a tail -- by the
     // caller's stand-alone optimiser call (curious_adam_update* with `keep`), as the caller asserts
     const bool maintained = p.keeps_copies(tail);
+    // option "one_launch" (default 0: it measured slower): a fused single-agent update whose tile lists
+    // qualify (the conditions of keeps_copies) runs as ONE launch; the gather of the next batch then sits in the spare
+    // row-group slots
+    p.one_launch = tail && maintained && curious_options().one_launch && curious_options().rows_xcd && xd.nex == 1 &&
+                   B % (ROWS_R * 4) == 0 && SPB == ROWS_R && B <= device_cu_count() &&
+                   (!tail->her || (her_lds_bytes(&tail->h.L) <= rows_lds_floats(cfg->layers) * sizeof(float) &&
+                                   (!tail->next->rng->step_ctr || tail->next->rng->step_ctr == step_ctr)));
     rc = p.rows_pass(!((maintained || !tail) && params_unchanged), maintained);
   } else {
     if (!rc) rc = p.forward();

@@ -13,9 +13,14 @@ struct AdamFuse {
   const float* alpha_tab; const int64_t* step_ctr; int64_t tab_base; int32_t tab_len;
   float a_Q, a_pi, b1, omb1, b2, omb2, eps;
   const int32_t* fault;           // fault word of the gradient workspace (mlp_rows.h) or NULL: non-zero = skip the optimiser
+  int32_t step_add;               // 1: the step counter has not been advanced for this update yet (ddpg_step_kernel)
 };
 __device__ inline bool adam_faulted(const AdamFuse& A, int64_t eo) {
   return A.fault && *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(A.fault) + eo) != 0;
+}
+// the same word when it may have been written by another workgroup of this very launch (ddpg_step_kernel)
+__device__ inline bool adam_faulted_now(const AdamFuse& A) {
+  return A.fault && __hip_atomic_load(const_cast<int32_t*>(A.fault), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // eo: slab offset of the expert this block works for (0 for a single agent); i / pidx / bidx below are indices into
@@ -25,7 +30,7 @@ __device__ inline bool adam_faulted(const AdamFuse& A, int64_t eo) {
 __device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int64_t eo) {
   aQ = A.a_Q; aPi = A.a_pi;
   if (A.alpha_tab) {
-    int64_t idx = ((*ex_i64(A.step_ctr, eo)) - 1 - A.tab_base) % A.tab_len;
+    int64_t idx = ((*ex_i64(A.step_ctr, eo)) + A.step_add - 1 - A.tab_base) % A.tab_len;
     if (idx < 0) idx += A.tab_len;
     aQ = A.alpha_tab[eo + 2 * idx];
     aPi = A.alpha_tab[eo + 2 * idx + 1];
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
 __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
-                                   const int64_t eo, const int64_t eg) {
+                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr) {
   // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
   const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
   const GemmHot& P = args.p[pi];
@@ -251,6 +256,12 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
     pre = adam_prefetch4(A, pidx + eo);
     if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
+  if (S) {
+    // one-launch update: the optimiser operands above are in flight; the activations and gradients below exist once
+    // the row groups of this matrix's network have published (and nobody reads the matrix any more)
+    if (!step_wait(*S, ((int64_t)(P.C - A.grad) < A.n_Q) ? 3u : 4u)) return;
+    faulted = adam_faulted_now(A);
+  }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < P.M; mb += 256) {
@@ -261,6 +272,8 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
       const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        // (one-launch update: plain loads are enough for these [B, 256] matrices -- no workgroup on this XCD has
+        //  touched the rows of OTHER row groups since the launch began, so no stale line can sit in its L2 or L1)
         a[u][s] = xc[(int64_t)(mq + s) * P.lda];
         b[u][s] = ldv(yc + (int64_t)(mq + s) * P.ldb);
       }
@@ -275,6 +288,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
         for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
       }
   }
+  if (S && S->st && tid == 0) S->st[3] = __builtin_readcyclecounter();
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   *reinterpret_cast<f32x4*>(dst) = v;
@@ -314,14 +328,19 @@ struct DwSmall {
   float div;
 };
 #define MAX_DW_SMALL 12
-struct DwSmallArgs { DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin; };   // `slots` block ids per problem
+struct DwSmallArgs {
+  DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin;   // `slots` block ids per problem
+  // the same tiles as a compact list (ddpg_step_kernel): problem i owns tiles [tile0[i], tile0[i + 1]); the critic's
+  // problems come first, n_crit of them
+  int32_t tile0[MAX_DW_SMALL + 1]; int32_t n_crit;
+};
 
 // One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
 // layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
 template <bool ADAM, bool YV>
 __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
-                                     const int64_t eo, const int64_t eg) {
+                                     const int64_t eo, const int64_t eg, const StepSync* S) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -353,6 +372,13 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
     }
     if (own_b) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
+  if (S) {
+    if (!step_wait(*S, ((int64_t)(P.dW - A.grad) < A.n_Q) ? 3u : 4u)) return;
+    faulted = adam_faulted_now(A);
+  }
+  // dQ / dz: a 128-byte line holds the values of several row groups, written on different XCDs -> agent-coherent loads
+  const bool ycoh = S && P.lddy < 64;
+  const __amdgpu_buffer_rsrc_t ry = coh_rsrc(P.dY + eo);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < M; mb += 256) {
@@ -364,11 +390,20 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
-        if (YV) {
-          b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+        if (ycoh) {
+          if (YV) {
+            b[u][s] = coh_ld4(ry, ((mq + s) * P.lddy + colc) * 4);
+          } else {
+            b[u][s] = zero4();
+            b[u][s][0] = coh_ld1(ry, (mq + s) * P.lddy * 4);
+          }
         } else {
-          b[u][s] = zero4();
-          b[u][s][0] = yc[(int64_t)(mq + s) * P.lddy];
+          if (YV) {
+            b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+          } else {
+            b[u][s] = zero4();
+            b[u][s][0] = yc[(int64_t)(mq + s) * P.lddy];
+          }
         }
       }
     }
@@ -426,22 +461,23 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   }
 }
 
-template <bool ADAM>
-__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
-                                     const int64_t eo, const int64_t eg) {
+// losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
+__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const StepSync* S) {
   const int tid = threadIdx.x;
-  // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
-  // arithmetic, so the descriptor load does not wait for a search through the table
-  const int pi = bid / args.slots, t = bid - pi * args.slots;
-  if (pi >= args.nprob) {
-    // extra last block (only launched when fin.rows != NULL): losses (ddpg.py:439-441) from the per-row terms,
-    // summed in a fixed order
-    const LossFin& F = args.fin;
+  {
+    if (S && !step_wait(*S, 5u)) return;
     float lq = 0.f, lp = 0.f, ll = 0.f;
+    const __amdgpu_buffer_rsrc_t rr = coh_rsrc(F.rows + eo);
     for (int m = tid; m < F.B; m += 256) {
-      lq += F.rows[eo + m];
-      lp += F.rows[eo + F.B + m];
-      ll += F.rows[eo + 2 * F.B + m];
+      if (S) {
+        lq += coh_ld1(rr, m * 4);
+        lp += coh_ld1(rr, (F.B + m) * 4);
+        ll += coh_ld1(rr, (2 * F.B + m) * 4);
+      } else {
+        lq += F.rows[eo + m];
+        lp += F.rows[eo + F.B + m];
+        ll += F.rows[eo + 2 * F.B + m];
+      }
     }
     red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
     __syncthreads();
@@ -459,12 +495,36 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
       F.out[eo + 0] = red[0] * invB;
       F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
     }
+  }
+}
+
+template <bool ADAM>
+__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
+                                     const int64_t eo, const int64_t eg, const StepSync* S = nullptr) {
+  // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
+  // arithmetic, so the descriptor load does not wait for a search through the table
+  const int pi = bid / args.slots, t = bid - pi * args.slots;
+  if (pi >= args.nprob) {
+    // extra last block (only launched when fin.rows != NULL)
+    dw_loss_fin(args.fin, red, eo, S);
     return;
   }
   const DwSmall& P = args.p[pi];
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg);
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S);
+}
+
+// item `it` of the compact tile list (DwSmallArgs.tile0)
+template <bool ADAM>
+__device__ inline void dw_small_item(const DwSmallArgs& args, const AdamFuse& A, const int it, float* red,
+                                     const int64_t eo, const int64_t eg, const StepSync* S) {
+  int pi = 0;
+  while (pi + 1 < args.nprob && it >= args.tile0[pi + 1]) ++pi;
+  const DwSmall& P = args.p[pi];
+  const int t = it - args.tile0[pi];
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S);
 }
 
 // Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the

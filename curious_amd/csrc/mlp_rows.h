@@ -67,6 +67,9 @@ struct RowsArgs {
                                   // batch (her_body.h) -- on CUs the three kinds leave idle, hidden behind the chains.
                                   // The step counter is then NOT incremented here (the gather keys its Philox stream on
                                   // it: counter + 1) but by the weight-gradient launch that follows (LossFin.step_ctr).
+  int32_t* sync;                  // one-launch update (ddpg_step_kernel, mlp_common.h StepSync): the counters the row groups
+  int32_t n_tickets;              // publish on, and how many workgroups take a ticket; NULL / 0 in every other launch
+  int32_t lab_step;               // lab only (CuriousOptions.lab_step)
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
@@ -88,7 +91,13 @@ struct RCtx {
   mutable unsigned long long* dbg;
   float* hs; float* part; float* xin; float* sm; float* keep;
   int tid, wave, lane, r0;
+  bool pub;   // one-launch update: what the tiles of the same launch read is stored THROUGH the L2 (agent-coherent stores)
 };
+// a result other workgroups read: the weight-gradient launch that follows, or (pub) the tiles of this very launch
+__device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
+  if (x.pub) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 // ---- weight fragments of one 16-deep k-chunk
 __device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int wave, int lane, int c) {
@@ -149,7 +158,7 @@ __device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)
     s = fmaxf(s + bv, 0.f);
     x.hs[r * RLD + x.tid] = s;
     if (keep) keep[r * 256 + x.tid] = s;
-    if (gout) gout[(int64_t)(x.r0 + r) * 256 + x.tid] = s;
+    if (gout) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s);
   }
   __syncthreads();
 }
@@ -193,7 +202,7 @@ __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16],
               (x.part[(2 * 4 + r) * 256 + x.tid] + x.part[(3 * 4 + r) * 256 + x.tid]);
     s = (mask[r * 256 + x.tid] > 0.f) ? s : 0.f;
     x.hs[r * RLD + x.tid] = s;
-    if (gout) gout[(int64_t)(x.r0 + r) * 256 + x.tid] = s;
+    if (gout) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s);
   }
   __syncthreads();
 }
@@ -306,12 +315,16 @@ static inline size_t rows_lds_floats(int nl) {
 
 // HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
 // form keeps its 632-byte kernarg -- HerArgs adds 1.4 KB)
-template <bool EX, bool HER>
-__device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
-                                               const uint64_t seed_stride) {
+// Returns the workgroup's role as a worker index (ddpg_step_kernel hands out its tiles by it): spare blocks [0, nrg),
+// target groups nrg + row group, main-critic groups 2 nrg + row group, actor-side groups 3 nrg + row group.
+// STEP: the one-launch update -- results are published for the tiles of the same launch (mlp_common.h StepSync).
+template <bool EX, bool HER, bool STEP = false>
+__device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
+                                              const uint64_t seed_stride) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
   x.dbg = nullptr;
+  x.pub = STEP;
   x.hs = rows_lds;
   x.part = x.hs + 4 * RLD;
   x.xin = x.part + 4 * 4 * 256;
@@ -332,7 +345,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
     if (xcd < 4 && slot >= per) {                            // the spare quarter of the grid: the gather, or nothing
       const int idx = xcd * per + (slot - per);
       if (HER && idx < a.n_her) her_sample_body(*her, idx, rows_lds, 0, 0, 1);
-      return;
+      return idx;
     }
     kind = (xcd < 4) ? 0 : (slot < per) ? 1 : 2;
     rgrp = (xcd & 3) * per + (slot < per ? slot : slot - per);
@@ -350,7 +363,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       int64_t ge;
       (void)ex_decode<EX>(ex, expert, ge);
       if (HER && rgrp < a.n_her) her_sample_body(*her, rgrp, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
-      return;
+      return rgrp;
     }
   }
   x.r0 = rgrp * ROWS_R;
@@ -369,7 +382,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
   f32x4 wb[2][16];
 
   if (kind == 1) {
-    if (a.lab_no_target) return;
+    if (a.lab_no_target) return nrg + rgrp;
     // ================================================= target group: pi' = target actor(o_2, g_2), Q' = target critic
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
@@ -411,7 +424,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       __hip_atomic_store(qt, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     ROWS_STAMP(6);
-    return;
+    return nrg + rgrp;
   }
 
   if (kind == 2) {
@@ -460,8 +473,8 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
       if (x.lane == 0) {
-        a.rows[eo + m] = diff * diff;                        // ddpg.py:439
-        a.dQ[eo + m] = dq;
+        rows_gst(x, a.rows + eo + m, diff * diff);           // ddpg.py:439
+        rows_gst(x, a.dQ + eo + m, dq);
         sm_s[x.wave] = dq;
       }
     }
@@ -476,14 +489,15 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       for (int i = 0; i < 4; ++i) {
         const float v = (hk[i * 256 + x.tid] > 0.f) ? sm_s[i] * w : 0.f;
         x.hs[i * RLD + x.tid] = v;
-        g[(int64_t)(x.r0 + i) * 256 + x.tid] = v;
+        rows_gst(x, g + (int64_t)(x.r0 + i) * 256 + x.tid, v);
       }
     }
     __syncthreads();
     ROWS_STAMP(5);
     rows_hidden_bwd(x, wb, a, x.keep, 1, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(6);
-    return;
+    if (STEP) step_signal(a.sync, STEP_DONE_CRITIC, (a.lab_step & 1) ? 0 : 1);
+    return 2 * nrg + rgrp;
   }
 
   // =================================================== actor side
@@ -522,7 +536,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       for (int d = 0; d < 4; ++d) v = (x.lane == d) ? pi[d] : v;
       x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                // actor_critic.py:93
     }
-    if (x.lane == 0) a.rows[eo + 2 * a.B + m] = l2;
+    if (x.lane == 0) rows_gst(x, a.rows + eo + 2 * a.B + m, l2);
   }
   __syncthreads();
   ROWS_STAMP(4);
@@ -539,7 +553,7 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
   {
     const float Qpi = rows_head1(x, wq_m) + bq_m;
     if (x.lane == 0) {
-      a.rows[eo + a.B + m] = Qpi;                            // ddpg.py:440
+      rows_gst(x, a.rows + eo + a.B + m, Qpi);               // ddpg.py:440
       a.out_Qpi[eo + m] = Qpi;
     }
   }
@@ -562,6 +576,8 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
   const f32x4 wpi_row = ldv(mp + a.mPi.Wout + 4 * x.tid);
   rows_hidden_bwd(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
   ROWS_STAMP(7);
+  // (every operand that comes from the critic's parameters is in registers or consumed by now: wu, wq_col above)
+  if (STEP) step_signal(a.sync, STEP_PAST_CRITIC, 0);
   {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
     // pi = max_u tanh(z) and the l2 term (ddpg.py:440-441)
@@ -577,7 +593,12 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
     }
     if (x.lane == 0) {
       const f32x4 o = {dz[0], dz[1], dz[2], dz[3]};
-      *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
+      if (STEP) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) rows_gst(x, a.dz + eo + (int64_t)m * 4 + d, dz[d]);
+      } else {
+        *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
+      }
       *reinterpret_cast<f32x4*>(sm_v + 4 * x.wave) = o;
     }
   }
@@ -594,13 +615,15 @@ __device__ __forceinline__ void ddpg_rows_body(const RowsArgs& a, const Ex& ex, 
       const float sv = dzr[0] * w[0] + dzr[1] * w[1] + dzr[2] * w[2] + dzr[3] * w[3];
       const float v = (hk[i * 256 + x.tid] > 0.f) ? sv : 0.f;
       x.hs[i * RLD + x.tid] = v;
-      g[(int64_t)(x.r0 + i) * 256 + x.tid] = v;
+      rows_gst(x, g + (int64_t)(x.r0 + i) * 256 + x.tid, v);
     }
   }
   __syncthreads();
   ROWS_STAMP(8);
   rows_hidden_bwd(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
   ROWS_STAMP(9);
+  if (STEP) step_signal(a.sync, STEP_DONE_ACTOR, (a.lab_step & 1) ? 0 : 1);
+  return 3 * nrg + rgrp;
 }
 
 template <bool EX>
@@ -610,6 +633,59 @@ __global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
 template <bool EX>
 __global__ __launch_bounds__(256) void ddpg_rows_her_kernel(RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
   ddpg_rows_body<EX, true>(a, ex, &her, seed_stride);
+}
+
+// ---- the whole single-rank update in ONE launch of B workgroups (curious_ddpg_update on the row-local route): the row
+// groups of ddpg_rows_her_kernel (the spare quarter gathers the NEXT batch); a workgroup that is through with its rows
+// then works as tile worker `w` (its role index) on the tiles of dw_adam_her_kernel -- weight / bias gradients with Adam
+// in the epilogue, the loss block -- from two lists:
+//   C  the critic's tiles (hidden matrices, then the compact small list): tile i goes to worker i mod 3B/4 of the spare,
+//      target and main-critic workgroups; they run while the actor-side chain is in its last three layers
+//   A  the actor's tiles and the loss block: tile i goes to worker i mod B of all workgroups; they run when that chain ends
+// A worker prefetches theta / m / v of its tile, then waits (mlp_common.h step_wait) for the row groups that produce
+// what the tile reads.  No launch boundary between the two halves of an update (~1.3 us idle, the ramp of a fresh grid,
+// the cold start of every tile at once), and nothing depends on dispatch order: every workgroup of the launch is
+// resident from the start (B workgroups <= CUs is required) and first does its rows, then waits.
+// Same arithmetic as the two launches, bit for bit.
+struct StepPlan { int32_t hot_c, small_c, hot_a, small_a; };   // tiles: critic hidden / small, actor hidden / small
+__global__ __launch_bounds__(256) void ddpg_step_kernel(RowsArgs a, Ex ex, DwAllArgs args, AdamFuse A, HerArgs her,
+                                                        StepPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+  const int wk = ddpg_rows_body<false, true, true>(a, ex, &her, 0);
+  const int nrg = a.B / ROWS_R;
+  StepSync S;
+  // (a tile has to outlast the consumers of Q' it waits behind: 8 x their patience)
+  S.c = a.sync; S.n = nrg; S.fault = a.fault; S.lab = a.lab_step;
+  S.spins = (a.spins > 0 && a.spins < (1 << 27)) ? 8 * a.spins : (1 << 30);
+  S.st = nullptr;
+  int nst = 0;
+  const int nC = plan.hot_c + plan.small_c, nA = plan.hot_a + plan.small_a + 1;
+  if (wk < 3 * nrg) {
+    for (int i = wk; i < nC; i += 3 * nrg) {
+      __syncthreads();                                       // (LDS and step_wait's flag are reused from tile to tile)
+      if (a.stamps && wk % nrg == 0 && nst < 4) {            // lab: workers 0, nrg, 2 nrg
+        S.st = a.stamps + 128 + 8 * (4 * (wk / nrg) + nst++);
+        if (threadIdx.x == 0) S.st[0] = __builtin_readcyclecounter();
+      }
+      if (i < plan.hot_c) dw_hot_body<true>(args.hot, A, i, rows_lds, 0, 0, &S);
+      else dw_small_item<true>(args.small, A, i - plan.hot_c, rows_lds, 0, 0, &S);
+      if (S.st && threadIdx.x == 0) S.st[4] = __builtin_readcyclecounter();
+      S.st = nullptr;
+    }
+  }
+  for (int i = wk; i < nA; i += 4 * nrg) {
+    __syncthreads();
+    if (a.stamps && wk % nrg == 0 && nst < 4) {
+      S.st = a.stamps + 128 + 8 * (4 * (wk / nrg) + nst++);
+      if (threadIdx.x == 0) S.st[0] = __builtin_readcyclecounter();
+    }
+    if (i < plan.hot_a) dw_hot_body<true>(args.hot, A, plan.hot_c + i, rows_lds, 0, 0, &S);
+    else if (i < nA - 1) dw_small_item<true>(args.small, A, plan.small_c + (i - plan.hot_a), rows_lds, 0, 0, &S);
+    else dw_loss_fin(args.small.fin, rows_lds, 0, &S);
+    if (S.st && threadIdx.x == 0) S.st[4] = __builtin_readcyclecounter();
+    S.st = nullptr;
+  }
+  step_ticket(a.sync, a.n_tickets, a.step_ctr);
 }
 
 // ---- (re)build the transposed copies from the parameters: dst[j][n][k] = src[j][k][n], 256 x 256 each.

@@ -1269,7 +1269,7 @@ class DDPG(object):
         self._fault_pending = False
         n = int(self._fault_pin[0])
         if n:
-            self._fault.zero_()
+            ops.fault_word(self.net_cfg, self.batch_size, self._workspace, 64).zero_()
             raise HandoffFault("%d consumer wave(s) of the row-local update never received Q' from their target group "
                                '(agent %s, rank %d): the optimiser was skipped from that update on' %
                                (n, self.scope, dist.rank()))

@@ -450,9 +450,11 @@ class option:
         set_option(self.name, self.old)
 
 
-def fault_word(cfg, B, workspace):
-    """int32 view (1 element) of the fault word inside a gradient workspace (curious_workspace_fault_offset)."""
+def fault_word(cfg, B, workspace, n=1):
+    """int32 view (1 element) of the fault word inside a gradient workspace (curious_workspace_fault_offset).  n = 64:
+    the whole block it sits in -- word 0 the fault word, words 16..19 the counters of the one-launch update (zero between
+    launches; a launch that was given up on may leave them set: clear the block together with the word)."""
     off = int(lib().curious_workspace_fault_offset(C.byref(cfg), int(B)))
     if off < 0:
         raise _lib.CuriousHipError('curious_workspace_fault_offset: bad arguments')
-    return _dev(workspace, 'workspace')[off:off + 1].view(torch.int32)
+    return _dev(workspace, 'workspace')[off:off + n].view(torch.int32)
