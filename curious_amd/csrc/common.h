@@ -85,7 +85,7 @@ struct CuriousOptions {
   int rows_xcd;        // 1: kinds of ddpg_rows_kernel placed by XCD; 0: plain block-id order                 [CURIOUS_ROWS_XCD]
   int xcd_map;         // 0 / 4 / 8: XCD-aware block placement of fwd_hot / dx_hot (tiled route)              [CURIOUS_XCD_MAP]
   int one_launch;      // 0 (default): a fused update = the row-local launch, then the weight-gradient / optimiser launch;
-                       // 1: ONE launch (mlp_rows.h ddpg_step_kernel) -- same results, measured SLOWER (48 vs 45.5 us per
+                       // 1: ONE launch (mlp_step.h ddpg_step_kernel) -- same results, measured SLOWER (48 vs 45.5 us per
                        // update incl. the launch gaps: DESIGN 4.5); kept as a tested experiment          [CURIOUS_ONE_LAUNCH]
   int fault_inject;    // > 0: the target group of row group (fault_inject - 1) never publishes Q' (tests)
   int qt_spins;        // polls before a consumer of Q' gives up

@@ -39,6 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mlp_layer0.h"
 #include "mlp_heads.h"
 #include "mlp_rows.h"
+#include "mlp_step.h"
 #include "mlp_rows_act.h"
 #include "mlp_rows_res.h"
 
@@ -701,7 +702,7 @@ struct DdpgPass {
   // counter's increment moves to the weight-gradient launch (mlp_rows.h RowsArgs.n_her)
   bool gather_in_rows = false;
   HerArgs her_rows;
-  // one-launch update (mlp_rows.h ddpg_step_kernel): rows_pass() only prepares the row-local launch, weight_grads()
+  // one-launch update (mlp_step.h ddpg_step_kernel): rows_pass() only prepares the row-local launch, weight_grads()
   // enqueues it together with its tiles -- or, should the tile lists not qualify, on its own first (launch_rows)
   bool one_launch = false;
   bool rows_pending = false;
@@ -1161,7 +1162,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     const int nsmall = smAll.nprob * smAll.slots;           // + 1 block for the loss finalisation
     if (rows_pending && tail && copies_kept) {
       // the whole update in one launch of 4 * nrg workgroups: row groups (the spare quarter gathers the next batch), each
-      // followed by its share of the tiles (mlp_rows.h ddpg_step_kernel)
+      // followed by its share of the tiles (mlp_step.h ddpg_step_kernel)
       RowsArgs a = ra;
       const int nrg = B / ROWS_R;
       a.n_her = tail->her ? nrg : 0;

@@ -65,7 +65,7 @@ struct LossFin {         // final, fixed-order reduction of the per-row loss ter
 };
 struct DwArgs { DwProb p[MAX_DW]; int32_t nprob; LossFin fin; };
 
-// ================================================================== one-launch update (mlp_rows.h ddpg_step_kernel)
+// ================================================================== one-launch update (mlp_step.h ddpg_step_kernel)
 // The row-local pass and the weight-gradient / optimiser tiles of an update in ONE launch of B workgroups: a workgroup
 // that has finished its rows (or its share of the gather) turns to the tiles its worker index assigns to it, prefetches
 // their optimiser operands and waits on counters in the workspace (next to the fault word, zero between launches) until

@@ -18,7 +18,7 @@ import torch
 from curious_amd import dist, logger
 from curious_amd.experiment import config
 from curious_amd.rollout import RolloutWorker
-from curious_amd.util import find_save_path, freeze_setup_objects, mpi_average
+from curious_amd.util import find_save_path, freeze_setup_objects, mpi_average, thaw_setup_objects
 
 ENV = 'MultiTaskFetchArm4-v5'
 NUM_CPU = 1
@@ -30,8 +30,18 @@ TASK_REPLAY = 'replay_task_cp_buffer'
 t0 = time.time()
 
 
-def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
-          save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None, **kwargs):
+def train(*args, **kwargs):
+    """train.py:49-166 (see _train); the objects that exist when the loop starts are kept out of the cycle collector's
+    way for its duration (util.freeze_setup_objects)."""
+    freeze_setup_objects()
+    try:
+        return _train(*args, **kwargs)
+    finally:
+        thaw_setup_objects()
+
+
+def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
+           save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None, **kwargs):
     """train.py:49-166.  expert_bank (task_experts only): update ALL experts in one batched launch sequence after
     every rollout (BASELINE configs[4]) instead of only the expert that collected it."""
     rank = dist.rank()
@@ -44,7 +54,6 @@ def train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles
         latest_policy_path = best_policy_path = periodic_policy_path = None
     best_success_rate = -1
     nb_tasks = params['nb_tasks']
-    freeze_setup_objects()
 
     if structure == 'task_experts':
         p = 1 / nb_tasks * np.ones([nb_tasks])

@@ -30,6 +30,13 @@ def freeze_setup_objects():
     gc.freeze()
 
 
+def thaw_setup_objects():
+    """End of the job: hand the frozen objects back to the collector (a process that runs several jobs one after the
+    other -- the test session -- would otherwise never free the cyclic garbage of the earlier ones)."""
+    import gc
+    gc.unfreeze()
+
+
 def store_args(method):
     """Decorator: copy the call's arguments (with defaults) onto `self` (util.py:13-37)."""
     sig = inspect.signature(method)

@@ -74,8 +74,9 @@ int main() {
     CK(hipDeviceSynchronize());
   }
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
+  // (the kernel also has ~1 KB of static LDS: dynamic + static must stay <= 160 KB)
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
-                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float))));
   dim3 grid(4 * (B / ROWS_R), 1, 1);
   auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
   for (int i = 0; i < 5; ++i) launch();
