@@ -37,8 +37,10 @@ def synth_episodes(rng, E, nb, dimo):
     return dict(o=o, u=u, g=g, ag=ag, task_descr=td, change=change, info_is_success=succ)
 
 
-def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', use_graph=False, hidden=256, layers=3):
-    """(product agent, oracle agent) with identical weights and empty buffers."""
+def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', use_graph=False, hidden=256, layers=3,
+               normalize_obs=False):
+    """(product agent, oracle agent) with identical weights and empty buffers (normalize_obs: the product agent only --
+    the oracle agent has no input normalisation; its networks do, tests/test_gpu_kernels.py)."""
     from curious_amd.ddpg import DDPG
     from curious_amd.envs import sparse_reward_fun
     from curious_amd.her import make_sample_multi_task_her_transitions
@@ -60,7 +62,7 @@ def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', u
     agent = DDPG(input_dims=dims, hidden=hidden, layers=layers, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
                  polyak=0.95, batch_size=batch_size, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1.,
                  action_l2=1., clip_obs=200., scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None,
-                 relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                 relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=normalize_obs,
                  sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
                  task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious', rng_mode=rng_mode, seed=seed,
                  use_graph=use_graph)
@@ -226,12 +228,13 @@ def test_device_rng_graph_equals_eager_and_learns():
     assert np.all(td.sum(axis=1) == 1)
 
 
-@pytest.mark.parametrize('shape', ['default', 'small', 'layers4', 'layers2'])
+@pytest.mark.parametrize('shape', ['default', 'small', 'layers4', 'layers2', 'normalize'])
 def test_fused_update_equals_unfused_sequence(shape, route):
     """curious_ddpg_update (Adam in the weight-gradient launch + next gather riding along) against the three separate
     launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit: lean kernels, the generic fallback, and
     4 layers per network (the row-local pass with the generic weight gradients + the stand-alone optimiser)."""
-    kw = dict(default={}, small=dict(batch_size=64, hidden=64), layers4=dict(layers=4), layers2=dict(layers=2))[shape]
+    kw = dict(default={}, small=dict(batch_size=64, hidden=64), layers4=dict(layers=4), layers2=dict(layers=2),
+              normalize=dict(normalize_obs=True))[shape]   # --normalize_obs: statistics of the stored episodes feed the nets
     a_f, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
     a_u, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
     rng = np.random.RandomState(5)
@@ -240,6 +243,8 @@ def test_fused_update_equals_unfused_sequence(shape, route):
     for a in (a_f, a_u):
         np.random.seed(2)
         a.store_episode({k: v.copy() for k, v in ep.items()}, cp, 40)
+    if shape == 'normalize':
+        assert float(a_f.o_stats.mean.abs().sum()) > 0 and a_f.normalize_obs      # non-trivial statistics feed the nets
     for k in range(9):
         lf, qf = a_f.train()
         if a_u._tables_dirty:

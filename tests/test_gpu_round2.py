@@ -148,6 +148,7 @@ def _expected_keys(nb, structure):
     ('task_experts', dict(task_selection='random')),
     ('task_experts', dict(task_selection='random', experts_update='batched')),
     ('flat', dict(task_selection='random')),
+    ('curious', dict(task_selection='active_competence_progress', normalize_obs=True)),   # --normalize_obs True
 ])
 def test_launch_runs_every_structure_and_logs_the_reference_columns(tmp_path, structure, extra):
     """experiment.train.launch() end to end (train.py:217-339 -> train() :49-166): configs[0] = num_cpu 1, structure
@@ -158,13 +159,14 @@ def test_launch_runs_every_structure_and_logs_the_reference_columns(tmp_path, st
                 batch_size=256)
     extra = dict(extra)
     task_selection = extra.pop('task_selection')
+    normalize_obs = extra.pop('normalize_obs', False)
     over.update(extra)
     task_replay = 'replay_task_cp_buffer' if structure == 'curious' else \
         'replay_current_task_buffer' if structure == 'task_experts' else ''
     if structure == 'flat':
         over.update(rng_mode='numpy', use_graph=False)
     best = train.launch(env='MultiTaskFetchArm4-v5', trial_id=0, n_epochs=2, num_cpu=1, seed=5, policy_save_interval=1,
-                        clip_return=1, normalize_obs=False, structure=structure, task_selection=task_selection,
+                        clip_return=1, normalize_obs=normalize_obs, structure=structure, task_selection=task_selection,
                         goal_selection='random', goal_replay='her', task_replay=task_replay, save_policies=True,
                         override_params=over, save_root=str(tmp_path) + '/')
     assert 0.0 <= best <= 1.0
