@@ -19,15 +19,17 @@ python tools/trace_gaps.py $O/stats --tail 0.6 > $O/trace_gaps_single.txt 2>&1
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?" >> $O/bench_default.err
 export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
-CURIOUS_FORCE_DIST=1 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_one_rank_rccl_auto.json 2> $O/bench_one_rank_rccl_auto.err
-CURIOUS_FORCE_DIST=1 CURIOUS_GRAPH_ALLREDUCE=0 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_one_rank_rccl_eager.json 2> $O/bench_one_rank_rccl_eager.err
-CURIOUS_FORCE_DIST=1 timeout 200 python bench.py --structure task_experts --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_task_experts_one_rank_rccl.json 2> $O/bench_task_experts_one_rank_rccl.err
+CURIOUS_FORCE_DIST=1 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $O/bench_one_rank_rccl_auto.err | grep '^{' > $O/bench_one_rank_rccl_auto.json
+CURIOUS_FORCE_DIST=1 CURIOUS_GRAPH_ALLREDUCE=0 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $O/bench_one_rank_rccl_eager.err | grep '^{' > $O/bench_one_rank_rccl_eager.json
+CURIOUS_FORCE_DIST=1 timeout 200 python bench.py --structure task_experts --steps 20 --warmup 5 --no-cpu-baseline 2> $O/bench_task_experts_one_rank_rccl.err | grep '^{' > $O/bench_task_experts_one_rank_rccl.json
 unset RANK WORLD_SIZE LOCAL_RANK MASTER_ADDR MASTER_PORT
 timeout 200 python bench.py --structure task_experts --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_task_experts.json 2> $O/bench_task_experts.err
 timeout 200 python bench.py --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_arm8_1024env.json 2> $O/bench_arm8_1024env.err
 CURIOUS_RESIDENT=0 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_resident_off.json 2> $O/bench_resident_off.err
 head -c 600 $O/bench_kernel_stats.csv; cat $O/pmc_hbm.txt | tail -20; tail -n 2 $O/*.err
-timeout 200 python tools/cycle_timeline.py > $O/cycle_timeline.txt 2>&1
+timeout 200 python tools/cycle_timeline.py 2>&1 | grep -v amdgpu.ids > $O/cycle_timeline.txt
+( timeout 200 python tools/exploit_cycle_probe.py --cycles 200; timeout 200 python tools/exploit_cycle_probe.py --cycles 200 --no-freeze; timeout 200 python tools/exploit_cycle_probe.py --cycles 200 --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 ) 2>&1 | grep -v amdgpu.ids > $O/cycle_probe.txt
+( CURIOUS_ONE_LAUNCH=1 timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one_launch=1:', d['ms_per_step'], 'ms per cycle', {k: v['avg_us'] for k, v in d['kernels'].items() if 'ddpg' in k or 'dw' in k})"; CURIOUS_ONE_LAUNCH=1 timeout 100 python tools/step_stamps.py ) 2>&1 | grep -v amdgpu.ids > $O/step_lab_tail.txt
 timeout 100 tools/rows_lab > $O/rows_lab.txt 2>&1
 cd $O && export PYTHONPATH=$R
 ( time timeout 600 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --n_epochs 150 --n_cycles 25 --n_batches 40 --rollout_batch_size 256 --seed 1 > learn_curious.log 2>&1 ) 2> time_curious.txt
