@@ -626,12 +626,21 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   return 3 * nrg + rgrp;
 }
 
+// waves_per_eu(2, 2): left alone the compiler spends 255 + 32 registers on this kernel -- one workgroup per CU.  Held to
+// 256 it needs no spill, and two workgroups share a CU: nothing changes for a single agent (B / 4 * 4 workgroups <= CUs,
+// one each), but batched experts (3 or 4 times as many workgroups as CUs) gain 17 % per cycle -- while one workgroup sits
+// in an epilogue, a head or a hand-off, the other keeps the CU's fill path busy.
+// (Not a way to make ONE row group faster: tools/rows_lab.hip B = 512 shows two co-resident groups streaming the same
+//  matrices in the time of one, but they share the fetched lines through the L1; a variant of this kernel with 8 waves
+//  per row group, 128 KB of each layer per wave quartet, ran every layer 1.3-1.5 x SLOWER -- the CU's fill path, not the
+//  number of loads in flight, is what bounds a layer.)
 template <bool EX>
-__global__ __launch_bounds__(256) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
   ddpg_rows_body<EX, false>(a, ex, nullptr, 0);
 }
 template <bool EX>
-__global__ __launch_bounds__(256) void ddpg_rows_her_kernel(RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void ddpg_rows_her_kernel(RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
   ddpg_rows_body<EX, true>(a, ex, &her, seed_stride);
 }
 

@@ -21,8 +21,9 @@ __global__ void touch(float* p, size_t n) {   // rewrite the parameters (what th
   if (i < n) p[i] = p[i] * 1.0f;
 }
 
-int main() {
-  const int B = 256, H = 256, O = 40, N = 4, G = 12, U = 4, nl = 3, ld = 152;
+int main(int argc, char** argv) {
+  const int B = (argc > 1) ? atoi(argv[1]) : 256;             // 256: one workgroup per CU; 512: two
+  const int H = 256, O = 40, N = 4, G = 12, U = 4, nl = 3, ld = 152;
   const int Sa = O + N, Sc = Sa + U;
   auto net_size = [&](int S, int D) { return S * H + H + G * H + (nl - 1) * (H * H + H) + H * D + D; };
   const int PQ = net_size(Sc, 1), PP = net_size(Sa, U);
@@ -78,6 +79,7 @@ int main() {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float))));
   dim3 grid(4 * (B / ROWS_R), 1, 1);
+  printf("B = %d\n", B);
   auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
