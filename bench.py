@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
 L2_PEAK_TBS = 34.5              # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs; 135 GB/s per CU)
+L2_PER_CU_GBS = 135.0           # the same figure per CU (64 bytes per clock)
 
 ENV = 'MultiTaskFetchArm4-v5'
 B_R = 256                      # parallel rollouts per GPU (configs[1])
@@ -195,9 +196,9 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     return dict(
         # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
         ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
-                              l2_stream_bytes=rows_l2_bytes),
+                              l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor),
         ddpg_rows_her_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
-                                  l2_stream_bytes=rows_l2_bytes),
+                                  l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor),
         policy_rows_kernel=dict(bound='mfma', per_update=0, launches_update=0, per_env_step=2 * B_R * net(Sa, U),
                                 launches_env_step=1),
         # the weights-resident rollout: layer 0 is computed by all 4 members of a group (x 4), the rest once
@@ -315,6 +316,12 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms):
         tb = w['l2_stream_bytes'] / avg_s / 1e12
         out['l2_stream'] = dict(achieved=round(tb, 3), peak=L2_PEAK_TBS, unit='TB/s', frac=round(tb / L2_PEAK_TBS, 4),
                                 bytes_per_launch=int(w['l2_stream_bytes']))
+        # ... and the CU on the critical path: an actor-side workgroup pulls 12 network passes of weights through ITS fill
+        # path (MI355X_MICROARCH.md: 64 B/clk = 135 GB/s per CU), one layer after the other, for the whole launch
+        gb = w['critical_cu_bytes'] / avg_s / 1e9
+        out['l2_stream']['critical_cu'] = dict(achieved=round(gb, 1), peak=L2_PER_CU_GBS, unit='GB/s',
+                                               frac=round(gb / L2_PER_CU_GBS, 4),
+                                               bytes_per_launch=int(w['critical_cu_bytes']))
     return out, table
 
 
