@@ -87,6 +87,84 @@ def test_her_sample_kernel_bit_exact(ops, name):
     assert not np.isnan(batch[:, :layout.boff_extra + layout.dimextra].cpu().numpy()).any()
 
 
+@pytest.mark.parametrize('case', range(16))
+def test_her_sample_random_shapes_vs_oracle(ops, case):
+    """Seeded sweep over shapes the golden cases do not enumerate: 1-10 tasks with RAGGED goal slots (1-4 goal dims per
+    task, achieved-goal slots at least as wide: her.py:154 takes ag_id[:len(g_id)]), observations of 3-120 floats, horizons
+    2-60, 1-40 stored episodes (every episode sampled many times over), batches that are no multiple of the 4 transitions a
+    workgroup handles, an extra info key, every relabel mode, future_p 0 / 0.8 / 1, with and without the +-clip, relative
+    goals and the output permutation -- the gather, relabel, reward and clip of her.py:99-183 + ddpg.py:326-353 against the
+    oracle on the same draws, bit for bit."""
+    from curious_amd import _lib
+    from curious_amd.layout import RecordLayout, pack_episodes
+    from oracle import her as oher
+    from oracle.ddpg import preprocess_og
+    from oracle.reward import make_reward_fun
+    rs = np.random.RandomState(1000 + case)
+    nb = int(rs.randint(1, 11))
+    g_ids, ag_ids, goff, aoff = [], [], 0, 0
+    for j in range(nb):
+        ng = int(rs.randint(1, 5))
+        na = ng + int(rs.randint(0, 3))
+        g_ids.append(list(range(goff, goff + ng)))
+        ag_ids.append(list(range(aoff, aoff + na)))
+        goff += ng
+        aoff += na
+    G, AG = goff, aoff
+    dimo = int(rs.randint(3, 121))
+    T = int(rs.randint(2, 61))
+    E = int(rs.randint(1, 41))
+    B = int(rs.choice([1, 3, 37, 256, 515, 700]))
+    mode = ['replay_task_cp_buffer', 'replay_task_cp_buffer', 'replay_current_task_transition',
+            'replay_task_random_buffer'][case % 4]
+    future_p = [0.8, 0.8, 1.0, 0.0][(case // 4) % 4]
+    clip = [float('inf'), 5.0][case % 2]
+    relative = (case % 3 == 0) and G == AG                    # g - ag needs equal widths (ddpg.py:118-127)
+    permute = case % 5 != 0
+    scale = 10.0
+    ep = dict(o=(rs.randn(E, T + 1, dimo) * scale).astype(np.float32), u=rs.uniform(-1, 1, [E, T, 4]).astype(np.float32),
+              g=(rs.randn(E, T, G) * scale).astype(np.float32), ag=(rs.randn(E, T + 1, AG) * 0.04).astype(np.float32),
+              task_descr=np.zeros([E, T, nb], np.float32), change=rs.randint(0, 2, [E, T, AG]).astype(np.float32),
+              info_is_success=rs.randint(0, 2, [E, T, 1]).astype(np.float32),
+              info_x=rs.randn(E, T, 2).astype(np.float32))
+    ep['task_descr'][np.arange(E), :, rs.randint(0, nb, E)] = 1.0
+    layout = RecordLayout(shapes_of(ep, T), T)
+    storage = dev(pack_episodes(layout, ep))
+    tasks = _lib.make_tasks(ag_ids, g_ids)
+    draws = oher.draw_her(rs, E, T, B)
+    ttr = None if case % 8 == 1 else int(rs.randint(0, nb))       # None: the transition's own task (her.py:132-134)
+    P = _lib.SampleParams()
+    P.future_p, P.reward_eps, P.clip_obs, P.relative_goals = future_p, 0.05, clip, int(relative)
+    P.relabel_mode = _lib.RELABEL_CURRENT_TASK if mode == 'replay_current_task_transition' else _lib.RELABEL_BUFFER_TASK
+    P.flat_reward = 0
+    perm = rs.permutation(B) if permute else np.arange(B)
+    inv = np.empty(B, np.int32)
+    inv[perm] = np.arange(B)
+    plan = ops.make_plan(dev(draws[0], torch.int32), dev(draws[1], torch.int32), dev(draws[2]), dev(draws[3]),
+                         task_to_replay=dev(np.full(B, -1 if ttr is None else ttr, np.int32)),
+                         out_row=dev(inv) if permute else None)
+    batch = torch.full([B, layout.batch_stride], float('nan'), device='cuda')
+    ops.her_sample(storage, 0, layout, tasks, P, B, batch, plan=plan)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in layout.batch_views(batch).items()}
+    ep64 = {k: v.astype(np.float64) for k, v in ep.items()}
+    ep64['o_2'] = ep64['o'][:, 1:]
+    ep64['ag_2'] = ep64['ag'][:, 1:]
+    tr = oher.apply_multi_task(ep64, draws, future_p=future_p, tasks_ag_id=ag_ids, tasks_g_id=g_ids, task_replay=mode,
+                               reward_fun=make_reward_fun(ag_ids, g_ids), task_to_replay=ttr)
+    tr = {k: v[perm] for k, v in tr.items()}
+    o, g = preprocess_og(tr['o'], tr['ag'], tr['g'], clip, relative)
+    o2, g2 = preprocess_og(tr['o_2'], tr['ag_2'], tr['g'], clip, relative)
+    want = dict(o=o, g=g, o_2=o2, g_2=g2, r=tr['r'], u=tr['u'], task_descr=tr['task_descr'], ag=tr['ag'],
+                ag_2=tr['ag_2'], change=tr['change'], info_is_success=tr['info_is_success'], info_x=tr['info_x'])
+    for k, w in want.items():
+        np.testing.assert_array_equal(got[k].astype(np.float64),
+                                      np.asarray(w, dtype=np.float32).astype(np.float64).reshape(got[k].shape),
+                                      err_msg='case %d key %s (nb %d dimo %d T %d E %d B %d %s)' %
+                                      (case, k, nb, dimo, T, E, B, mode))
+    assert not np.isnan(batch[:, :layout.boff_extra + layout.dimextra].cpu().numpy()).any()
+
+
 def test_her_sample_clip_relative_and_permutation(ops):
     from curious_amd import _lib
     from curious_amd.layout import RecordLayout, pack_episodes
