@@ -400,6 +400,62 @@ def test_ddpg_grads_vs_oracle(ops, cfg, route):
         assert err <= max(4 * err32, 1e-6 * np.abs(want).max())
 
 
+@pytest.mark.parametrize('case', range(12))
+def test_ddpg_grads_random_shapes_vs_oracle(ops, case):
+    """Seeded sweep of curious_ddpg_grads over shapes between the enumerated ones: 1-10 tasks, goals of 1-30 floats (not
+    3 per task), observations of 3-100 floats, batches 4..512 (multiples of 4 and not), hidden 256 (the row-local / lean
+    routes where the shape allows, the generic kernels otherwise) or 32-128, 1-4 layers, max_u / gamma / clip_return /
+    clip_pos_returns / action_l2 varied -- losses, Q_pi and both flat gradients within 1e-5 of the float64 oracle."""
+    from curious_amd.layout import RecordLayout
+    from oracle.networks import DDPGMath
+    rs = np.random.RandomState(500 + case)
+    nb = int(rs.randint(1, 11))
+    G = int(rs.randint(1, 31))
+    dimo = int(rs.randint(3, 101))
+    B = int(rs.choice([4, 16, 48, 130, 256, 260, 512]))
+    hidden = int(rs.choice([256, 256, 256, 128, 64, 32]))
+    layers = int(rs.randint(1, 5)) if hidden != 256 else int(rs.randint(2, 5))
+    max_u = float(rs.choice([0.5, 1.0, 2.0]))
+    gamma = float(rs.choice([0.98, 0.9]))
+    clip_return = float(rs.choice([50.0, 2.0]))
+    clip_pos = bool(rs.randint(0, 2))
+    action_l2 = float(rs.choice([0.0, 1.0, 0.3]))
+    T = 5
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), task_descr=(T, nb), change=(T, G),
+                  info_is_success=(T, 1))
+    layout = RecordLayout(shapes, T)
+    batch = _rand_batch(rs, layout, B, nb)
+    m64 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, gamma, clip_return, clip_pos, action_l2, True, np.float64)
+    m32 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, gamma, clip_return, clip_pos, action_l2, True, np.float32)
+    theta, theta_t = m32.init(rs), m32.init(rs)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, hidden, layers, True, max_u, gamma, clip_return, action_l2,
+                            clip_pos_returns=clip_pos)
+    PQ, Ppi, off_pi, total = ops.param_layout(ncfg)
+    assert (PQ, Ppi) == (m32.P_Q, m32.P_pi)
+    ws = torch.zeros(ops.workspace_floats(ncfg, B), device='cuda')
+    grad = torch.full([total], float('nan'), device='cuda')
+    losses = torch.zeros(2, device='cuda')
+    Qpi = torch.zeros(B, device='cuda')
+    ops.ddpg_grads(ncfg, dev(ops.pad_params(ncfg, theta)), dev(ops.pad_params(ncfg, theta_t)), dev(batch), layout,
+                   B, ws, grad, losses, Qpi)
+    torch.cuda.synchronize()
+    bd = {k: batch[:, o:o + d] for k, (o, d) in layout.batch_cols.items()}
+    ref = m64.losses_and_grads(theta.astype(np.float64), theta_t.astype(np.float64), bd)
+    ref32 = m32.losses_and_grads(theta, theta_t, bd)
+    got_l = losses.cpu().numpy()
+    tag = 'case %d: nb %d G %d dimo %d B %d hidden %d layers %d' % (case, nb, G, dimo, B, hidden, layers)
+    assert abs(got_l[0] - ref['Q_loss']) <= 1e-5 * max(abs(ref['Q_loss']), 1e-3), tag
+    assert abs(got_l[1] - ref['pi_loss']) <= 1e-5 * max(abs(ref['pi_loss']), 1e-3), tag
+    np.testing.assert_allclose(Qpi.cpu().numpy(), ref['Q_pi'][:, 0], rtol=1e-5, atol=2e-6, err_msg=tag)
+    g = ops.unpad_params(ncfg, grad.cpu().numpy())
+    assert not np.isnan(g).any(), tag
+    for name, sl in (('Q_grad', slice(0, PQ)), ('pi_grad', slice(PQ, PQ + Ppi))):
+        want = ref[name]
+        err = np.abs(g[sl] - want).max()
+        err32 = np.abs(ref32[name] - want).max()
+        assert err <= max(1e-5 * np.abs(want).max(), 4 * err32), (tag, name, err, np.abs(want).max())
+
+
 def test_policy_forward_and_noise(ops, route):
     from oracle.networks import DDPGMath
     from oracle.ddpg import action_postprocess, preprocess_og
