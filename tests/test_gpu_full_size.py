@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 CAP = 19998        # (10^6 - 10^6 % rollout_batch_size) // T episodes per buffer: config.py:190-199 at 256 rollouts
 
 
-def _job(seed=0):
-    params, dims, policy, worker = bench.build_job(use_graph=True, seed=seed)
-    assert policy.buffer[1].size == CAP and policy.batch_size == 256 and worker.rollout_batch_size == 256
+def _job(seed=0, env=None, b_r=256):
+    params, dims, policy, worker = bench.build_job(use_graph=True, seed=seed, env=env, b_r=b_r)
+    assert policy.batch_size == 256 and worker.rollout_batch_size == b_r
+    assert policy.buffer[1].size == (CAP if b_r == 256 else (10 ** 6 - 10 ** 6 % b_r) // 50)
     return policy, worker
 
 
@@ -26,11 +27,12 @@ def _fill_signatures(policy):
     buffer) -- all below clip_obs = 200, which the sampler applies -- and values derived from (e, t, column) elsewhere."""
     lay, dev = policy._layout, policy.device
     T, O, AG = lay.T, lay.dims['o'], lay.dims['ag']
+    CAP = policy.buffer[1].size
     e = torch.arange(CAP, device=dev, dtype=torch.float32)[:, None, None]
     t = torch.arange(T + 1, device=dev, dtype=torch.float32)[None, :, None]
-    for i in range(1, policy.nb_tasks + 1):
+    for i in range(1, min(policy.nb_tasks, 5) + 1):
         buf = policy.buffer[i]
-        assert buf.pool_index == i                                   # Arm4: no aliased buffers
+        assert buf.pool_index == i                                   # (buffers 6.. of Arm8 are buffer 5: ddpg.py:106-110)
         rec = buf.records
         rec.zero_()
         v = lay.record_views(rec)
@@ -188,3 +190,67 @@ def test_a_full_size_cycle_is_deterministic_and_keeps_its_invariants():
     a, b = res
     assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and a[5] == b[5] and a[6] == b[6] == 3 * 256
     assert all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
+
+
+def test_her_gather_from_full_aliased_buffers_arm8():
+    """BASELINE configs[2] (MultiTaskFetchArm8-v5, 1 024 rollouts: buffers of 19 988 episodes): the logical buffers 6, 7, 8
+    of the distractor tasks ARE buffer 5 (ddpg.py:106-110), only tasks < 5 are ever routed (ddpg.py:183), yet every logical
+    buffer is sampled with its own task_to_replay (ddpg.py:326-336) -- rows from pool slot 5 therefore come relabelled to
+    tasks 4..7, goals written on THAT task's slots from the episode's own later achieved goal."""
+    policy, _ = _job(env='MultiTaskFetchArm8-v5', b_r=1024)
+    assert policy.buffer[8] is policy.buffer[5] and policy.buffer[6].pool_index == 5
+    _fill_signatures(policy)
+    cap = policy.buffer[1].size
+    assert cap == 19988
+    policy.cp = np.array([0.3, 0.0, 0.2, 0.1, 0.05, 0.15, 0.0, 0.2])
+    lay, T, nb = policy._layout, policy._layout.T, policy.nb_tasks
+    n_draws, B = 60, policy.batch_size
+    rows = []
+    for k in range(n_draws):
+        rows.append(policy._sample_packed().clone())
+        policy._step_ctr += 1
+    prop = policy.proportions
+    assert prop.sum() == B and prop[0] == 0 and (prop[5:] > 0).sum() >= 3
+    v = lay.batch_views(torch.cat(rows))
+    o = v['o']
+    e = (o[:, 0] * 128 + o[:, 1]).long()
+    t = o[:, 2].long()
+    b = o[:, 3].long()                                               # PHYSICAL buffer (pool slot) of the row
+    assert int(e.max()) < cap and int(e.max()) > 0.98 * cap and set(b.unique().tolist()) <= set(range(1, 6))
+    per_draw = torch.stack([(b.view(n_draws, B) == i).sum(1) for i in range(6)], 1).cpu().numpy()
+    want = np.array([0, prop[1], prop[2], prop[3], prop[4], prop[5:].sum()])
+    assert (per_draw == want[None, :]).all()                         # slot 5 serves logical buffers 5..8 together
+    st = policy._pool.storage
+    src, nxt = st[b, e, t], st[b, e, t + 1]
+    for key, rows_ in (('o', src), ('u', src), ('ag', src), ('o_2', nxt), ('ag_2', nxt)):
+        off, dim = lay.off[key.replace('_2', '')], lay.dims[key.replace('_2', '')]
+        assert torch.equal(v[key], rows_[:, off:off + dim]), key
+    g, g_stored = v['g'], src[:, lay.off['g']:lay.off['g'] + lay.dims['g']]
+    her = ~(g == g_stored).all(1)
+    assert 0.77 < float(her.float().mean()) < 0.83
+    task = v['task_descr'].argmax(1)
+    assert bool((v['task_descr'].sum(1) == 1).all())
+    # rows kept as stored carry the stored descriptor (the pool slot's task); relabelled rows of slot i < 5 the task i - 1,
+    # relabelled rows of slot 5 one of the tasks 4..7 -- each as often as its logical buffer's share of the batch says
+    assert bool((task[~her] == b[~her] - 1).all())
+    low = her & (b < 5)
+    assert bool((task[low] == b[low] - 1).all())
+    hi = her & (b == 5)
+    assert set(task[hi].unique().tolist()) == {k for k in range(4, 8) if prop[k + 1] > 0}
+    for k in range(4, 8):
+        n_k = int((task[hi] == k).sum())
+        expect = 0.8 * n_draws * prop[k + 1]
+        assert abs(n_k - expect) <= 4 * np.sqrt(max(expect, 1.0)) + 1, (k, n_k, expect)
+    slots = (3 * task)[:, None] + torch.arange(3, device=g.device)[None, :]
+    on_slots = torch.gather(g, 1, slots)
+    outside = g.clone()
+    outside.scatter_(1, slots, 0.0)
+    assert float(outside[her].abs().sum()) == 0.0
+    fut = st[b, e][:, :, lay.off['ag']:lay.off['ag'] + lay.dims['ag']]
+    fut = torch.gather(fut, 2, slots[:, None, :].expand(-1, T + 1, -1))
+    later = torch.arange(T + 1, device=g.device)[None, :] > t[:, None]
+    assert bool(((fut == on_slots[:, None, :]).all(2) & later).any(1)[her].all())
+    from oracle.reward import make_reward_fun
+    ids = [list(range(3 * j, 3 * j + 3)) for j in range(nb)]
+    r = make_reward_fun(ids, ids)(v['ag_2'].cpu().numpy(), g.cpu().numpy(), v['task_descr'].cpu().numpy(), None)
+    assert np.array_equal(v['r'].cpu().numpy(), r)
