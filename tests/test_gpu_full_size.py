@@ -254,3 +254,34 @@ def test_her_gather_from_full_aliased_buffers_arm8():
     ids = [list(range(3 * j, 3 * j + 3)) for j in range(nb)]
     r = make_reward_fun(ids, ids)(v['ag_2'].cpu().numpy(), g.cpu().numpy(), v['task_descr'].cpu().numpy(), None)
     assert np.array_equal(v['r'].cpu().numpy(), r)
+
+
+def test_full_size_batched_experts_cycles_are_deterministic():
+    """BASELINE configs[4] at full size on one GPU: 4 experts on the shared per-task buffers, every cycle one expert's 256
+    rollouts and 100 batched updates of ALL experts (400 agent-updates in 200 launches).  Two identically seeded jobs agree
+    bit for bit after 4 cycles (each expert has acted once); the experts have moved apart; each one's batches are
+    relabelled to ITS task (ddpg.py:302-318, her.py:135-136)."""
+    res = []
+    for _ in range(2):
+        np.random.seed(5)
+        params, dims, bank, workers = bench.build_experts_job(use_graph=True, seed=3)
+        bench.prefill(bank[0], 2048, seed=1)
+        for k in range(4):
+            bench.experts_cycle(bank, workers, k)
+        for x in bank:
+            x.settle()
+        torch.cuda.synchronize()
+        bank.check_faults()
+        assert all(int(x._step_ctr) == 400 == x.Q_adam.t for x in bank)
+        lay = bank[0]._layout
+        for i, x in enumerate(bank):
+            td = lay.batch_views(x._staged)['task_descr']
+            # relabelled rows (future_p = 0.8) carry expert i's task; rows kept as stored carry what the (synthetic,
+            # randomly labelled) prefill wrote
+            assert float((td.argmax(1) == i).float().mean()) > 0.7 and bool((td.sum(1) == 1).all())
+        res.append([x.theta.clone() for x in bank] + [x.theta_target.clone() for x in bank] +
+                   [workers[i].n_episodes for i in range(4)])
+    a, b = res
+    assert all(torch.equal(x, y) for x, y in zip(a[:8], b[:8])) and a[8:] == b[8:]
+    assert all(torch.isfinite(x).all() for x in a[:8])
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[2], a[3])
