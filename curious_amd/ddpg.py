@@ -931,8 +931,8 @@ class DDPG(object):
         ts = np.arange(t0 + 1, t0 + n + 1)
         tab = np.empty([n, 2], np.float32)
         pos = (ts - 1) % n
-        tab[pos, 0] = [self.Q_adam.alpha(self.Q_lr, int(t)) for t in ts]
-        tab[pos, 1] = [self.pi_adam.alpha(self.pi_lr, int(t)) for t in ts]
+        tab[pos, 0] = self.Q_adam.alpha_table(self.Q_lr, ts)
+        tab[pos, 1] = self.pi_adam.alpha_table(self.pi_lr, ts)
         self._alpha_tab.copy_(torch.from_numpy(tab))
         self._alpha_base = 0
         self._alpha_filled = t0 + n

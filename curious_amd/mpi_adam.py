@@ -33,6 +33,10 @@ class MpiAdam:
     def alpha(self, stepsize, t=None):
         return ops.adam_alpha(stepsize, self.t if t is None else t, self.beta1, self.beta2)
 
+    def alpha_table(self, stepsize, ts):
+        """alpha(stepsize, t) for every t of `ts` (float32 array, the same values)."""
+        return ops.adam_alpha_table(stepsize, ts, self.beta1, self.beta2)
+
     def update(self, localg, stepsize):
         if self.t % 100 == 0:                                        # mpi_adam.py:22-23
             self.check_synced()

@@ -308,6 +308,17 @@ def adam_alpha(stepsize, t, beta1=0.9, beta2=0.999):
     return np.float32(stepsize * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t))
 
 
+def adam_alpha_table(stepsize, ts, beta1=0.9, beta2=0.999):
+    """adam_alpha for a run of step numbers, element for element the same float32 values: the powers come from Python's
+    float ** int (one libm call each, as in the scalar form -- NumPy's vectorised power may round differently), the
+    rest are IEEE-exact element-wise operations in the scalar form's order."""
+    tl = [int(t) for t in np.asarray(ts).tolist()]
+    b1, b2 = float(beta1), float(beta2)
+    p1 = np.array([b1 ** t for t in tl], np.float64)
+    p2 = np.array([b2 ** t for t in tl], np.float64)
+    return (stepsize * np.sqrt(1 - p2) / (1 - p1)).astype(np.float32)
+
+
 def adam_update(theta, m, v, grad, n_Q, n_pi, alpha_Q=None, alpha_pi=None, beta1=0.9, beta2=0.999, epsilon=1e-08,
                 alpha_tab=None, step_ctr=None, tab_base=0, keep=None):
     f = np.float32

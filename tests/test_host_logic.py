@@ -186,3 +186,15 @@ def test_perturbation_switch_sets_bias_on_the_first_two_envs_or_refuses():
         perturb_envs(Worker([Env()]), b)
     with pytest.raises(NotImplementedError):                         # an env without the switch: refused, not ignored
         perturb_envs(Worker([Env(False), Env(False)]), b)
+
+
+def test_adam_step_size_table_equals_the_scalar_formula():
+    """The ring of Adam step sizes the device reads (DDPG._fill_alpha_table) is filled by a vectorised form of
+    mpi_adam.py:30; it has to give the float32 values of the scalar form element for element, for any start step."""
+    from curious_amd import ops
+    for lr, b1, b2 in ((1e-3, 0.9, 0.999), (5e-4, 0.8, 0.99)):
+        for t0 in (1, 4090, 123456, 10 ** 7):
+            ts = np.arange(t0, t0 + 600)
+            want = np.array([ops.adam_alpha(lr, int(t), b1, b2) for t in ts])
+            got = ops.adam_alpha_table(lr, ts, b1, b2)
+            assert got.dtype == np.float32 and np.array_equal(got, want)
