@@ -12,6 +12,7 @@ makes the C10 broadcasts of p / CP unnecessary.
 """
 import pickle
 from collections import deque
+from itertools import islice
 
 import numpy as np
 import torch
@@ -19,6 +20,11 @@ import torch
 from curious_amd import dist
 from curious_amd.queues import CompetenceQueue, task_probabilities
 from curious_amd.util import convert_episode_to_batch_major, store_args
+
+# What a slot of the per-rollout task / goal lists holds when this rank has nothing for it (rollout.py:149-150: []).  The
+# batched worker fills hundreds of slots per cycle and the histories keep them all (rollout.py:370-371): ONE shared empty
+# list instead of a new one per slot per cycle (nothing ever appends to a slot; slots are assigned).
+_NOTHING = []
 
 
 class RolloutWorker:
@@ -312,9 +318,9 @@ class RolloutWorker:
             # return without waiting: the policy routes the episodes on the device, the flags are read in settle()
             env.request_flags()
             task_list = tasks.tolist()
-            tk = [[] for _ in range(self.nb_goals_per_rollout)]
+            tk = [_NOTHING] * self.nb_goals_per_rollout
             tk[self.rank * B:(self.rank + 1) * B] = task_list
-            self._pending = dict(tasks=tk, goals=[[] for _ in range(self.nb_goals_per_rollout)], task_list=task_list)
+            self._pending = dict(tasks=tk, goals=[_NOTHING] * self.nb_goals_per_rollout, task_list=task_list)
             self.n_episodes += B * self.nb_cpu
             views = env.episode_views()
             self.policy.expect_async_store(views, env.flags[env.n:env.n + 1], env._flags_pin[env.n:env.n + 1])
@@ -327,9 +333,9 @@ class RolloutWorker:
             return self._generate_rollouts_batched(retry=True)
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
         task_list = tasks.tolist()
-        self.tasks = [[] for _ in range(self.nb_goals_per_rollout)]
+        self.tasks = [_NOTHING] * self.nb_goals_per_rollout
         self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
-        self.goals = [[] for _ in range(self.nb_goals_per_rollout)]
+        self.goals = [_NOTHING] * self.nb_goals_per_rollout
         goals_now = None
         if self.goal_selection == 'active' and not self.eval and self.exploit:
             goals_now = 0.5 * goals                               # the envs' goals on their task slots (goal space)
@@ -466,7 +472,8 @@ class RolloutWorker:
                 if not self.eval:
                     CPs = self.get_CP()
                     logs += [('CP_task' + str(i), "%.3g" % CPs[i])]
-                    hist = [x for x in list(self.task_history)[-100:]]
+                    # the last 100 entries (rollout.py:475), without copying a history of millions every epoch
+                    hist = list(islice(reversed(self.task_history), 100))
                     per = np.mean(np.array([h == i for h in hist])) if hist else 0.0
                     logs += [('%_task' + str(i), "%.3g" % per)]
                     logs += [('p_task' + str(i), "%.3g" % self.p[i])]
