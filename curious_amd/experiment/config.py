@@ -14,28 +14,12 @@ from curious_amd.util import import_function
 
 DEFAULT_ENV_PARAMS = {'FetchReach-v1': {'n_cycles': 10}}
 
-_COMMON = {
-    'max_u': 1.,                  # config.py:22,56
-    'layers': 3, 'hidden': 256,
-    'Q_lr': 0.001, 'pi_lr': 0.001,
-    'buffer_size': int(1E6),
-    'polyak': 0.95,
-    'action_l2': 1.0,
-    'clip_obs': 200.,
-    'scope': 'ddpg',
-    'relative_goals': False,
-    'n_cycles': 25,
-    'rollout_batch_size': 2,
-    'n_batches': 100,
-    'batch_size': 256,
-    'n_test_rollouts': 5,
-    'test_with_polyak': False,
-    'random_eps': 0.3,
-    'noise_eps': 0.2,
-    'her_replay_k': 4,
-    'norm_eps': 0.01,
-    'norm_clip': 5,
-}
+# what both parameter sets share (config.py:21-45 / 55-83: same keys, same values)
+_COMMON = dict(
+    max_u=1., layers=3, hidden=256, Q_lr=0.001, pi_lr=0.001, buffer_size=int(1E6), polyak=0.95, action_l2=1.0,
+    clip_obs=200., scope='ddpg', relative_goals=False,                                   # DDPG
+    n_cycles=25, rollout_batch_size=2, n_batches=100, batch_size=256, n_test_rollouts=5, test_with_polyak=False,  # loop
+    random_eps=0.3, noise_eps=0.2, her_replay_k=4, norm_eps=0.01, norm_clip=5)           # exploration, HER, normaliser
 
 DEFAULT_PARAMS = dict(_COMMON, network_class='curious_amd.actor_critic:ActorCritic',
                       her_sampling_func='curious_amd.her:make_sample_her_transitions', queue_length=200)
