@@ -36,67 +36,60 @@ def cached_make_env(make_env):
     return CACHED_ENVS[make_env]
 
 
+# what prepare_params moves into ddpg_params (config.py:129-139); a '_name' copy stays in the params for the logs
+_DDPG_KEYS = ('hidden', 'layers', 'network_class', 'polyak', 'batch_size', 'Q_lr', 'pi_lr', 'norm_eps', 'norm_clip',
+              'max_u', 'action_l2', 'clip_obs', 'scope', 'relative_goals')
+_DEVICE_KEYS = ('rng_mode', 'use_graph', 'seed', 'async_store')     # MI355X-side knobs (not in the reference)
+
+
 def prepare_params(kwargs):
-    """config.py:106-144."""
-    ddpg_params = dict()
-    env_name = kwargs['env_name']
+    """config.py:106-144: env-derived entries (tasks, horizon, gamma), the learning-rate shorthand, the DDPG sub-dict."""
     if 'make_env' not in kwargs:
-        kwargs['make_env'] = EnvFactory(env_name)
-    tmp_env = cached_make_env(kwargs['make_env'])
+        kwargs['make_env'] = EnvFactory(kwargs['env_name'])
+    probe = cached_make_env(kwargs['make_env'])
+    core = probe.unwrapped
     if kwargs['structure'] == 'flat':
-        tmp_env.unwrapped.set_flat_env()
-    kwargs['nb_tasks'] = tmp_env.unwrapped.nb_tasks
-    kwargs['tasks_g_id'] = tmp_env.unwrapped.tasks_g_id
-    kwargs['tasks_ag_id'] = tmp_env.unwrapped.tasks_ag_id
-    assert hasattr(tmp_env, '_max_episode_steps')
-    kwargs['T'] = tmp_env._max_episode_steps
-    tmp_env.reset()
-    kwargs['max_u'] = np.array(kwargs['max_u']) if isinstance(kwargs['max_u'], list) else kwargs['max_u']
-    kwargs['gamma'] = 1. - 1. / kwargs['T']
-    if 'lr' in kwargs:
-        kwargs['pi_lr'] = kwargs['lr']
-        kwargs['Q_lr'] = kwargs['lr']
-        del kwargs['lr']
-    for name in ['hidden', 'layers', 'network_class', 'polyak', 'batch_size', 'Q_lr', 'pi_lr', 'norm_eps',
-                 'norm_clip', 'max_u', 'action_l2', 'clip_obs', 'scope', 'relative_goals']:
-        ddpg_params[name] = kwargs[name]
-        kwargs['_' + name] = kwargs[name]
-        del kwargs[name]
-    for name in ['rng_mode', 'use_graph', 'seed', 'async_store']:   # MI355X-side knobs (not in the reference)
-        if name in kwargs:
-            ddpg_params[name] = kwargs[name]
-    kwargs['ddpg_params'] = ddpg_params
+        core.set_flat_env()
+    kwargs.update(nb_tasks=core.nb_tasks, tasks_g_id=core.tasks_g_id, tasks_ag_id=core.tasks_ag_id)
+    assert hasattr(probe, '_max_episode_steps')
+    horizon = probe._max_episode_steps
+    kwargs['T'] = horizon
+    probe.reset()
+    if isinstance(kwargs['max_u'], list):
+        kwargs['max_u'] = np.array(kwargs['max_u'])
+    kwargs['gamma'] = 1. - 1. / horizon
+    if 'lr' in kwargs:                                              # one rate for both networks
+        kwargs['pi_lr'] = kwargs['Q_lr'] = kwargs.pop('lr')
+    ddpg = {}
+    for key in _DDPG_KEYS:
+        ddpg[key] = kwargs['_' + key] = kwargs.pop(key)
+    ddpg.update((key, kwargs[key]) for key in _DEVICE_KEYS if key in kwargs)
+    kwargs['ddpg_params'] = ddpg
     return kwargs
 
 
 def log_params(params, logger=logger):
-    for key in sorted(params.keys()):
-        logger.info('{}: {}'.format(key, params[key]))
+    for name in sorted(params):
+        logger.info('%s: %s' % (name, params[name]))
 
 
 def configure_her(params):
     """config.py:152-174.  The reward closure carries the kernel-side reward description of the env."""
     env = cached_make_env(params['make_env'])
     env.reset()
+    core = env.unwrapped
     if params['structure'] == 'flat':
-        env.unwrapped.set_flat_env()
-    spec = getattr(env.unwrapped, 'reward_spec', None)
+        core.set_flat_env()
+    spec = getattr(core, 'reward_spec', None)
     if spec is not None and not params.get('host_reward', False):
         reward_fun = sparse_reward_fun(spec)                        # evaluated inside the HER kernel
     else:
         # a real environment (gym_flowers): the reference's closure, evaluated on the host per sampled batch
         def reward_fun(ag_2, g, task_descr=None, info=None):        # config.py:158-159
-            return env.unwrapped.compute_reward(achieved_goal=ag_2, goal=g, task_descr=task_descr, info=info)
-    her_params = {
-        'reward_fun': reward_fun,
-        'tasks_ag_id': params['tasks_ag_id'],
-        'tasks_g_id': params['tasks_g_id'],
-        'goal_replay': params['goal_replay'],
-        'her_replay_k': params['her_replay_k'],
-        'task_replay': params['task_replay'],
-    }
-    her_sampling_func = import_function(params['her_sampling_func'])
-    return her_sampling_func(**her_params)
+            return core.compute_reward(achieved_goal=ag_2, goal=g, task_descr=task_descr, info=info)
+    passed_on = ('tasks_ag_id', 'tasks_g_id', 'goal_replay', 'her_replay_k', 'task_replay')
+    factory = import_function(params['her_sampling_func'])
+    return factory(reward_fun=reward_fun, **{key: params[key] for key in passed_on})
 
 
 def simple_goal_subtract(a, b):
@@ -105,80 +98,57 @@ def simple_goal_subtract(a, b):
 
 
 def dims_to_shapes(input_dims):
-    return {key: tuple([val]) if val > 0 else tuple() for key, val in input_dims.items()}
+    return {name: ((dim,) if dim > 0 else ()) for name, dim in input_dims.items()}
 
 
 def configure_buffer(dims, params):
     """config.py:184-216: nb_tasks+1 buffers when 'buffer' in task_replay, else one -- here on one HBM pool."""
     T = params['T']
-    structure = params['structure']
-    buffer_size = params['buffer_size']
-    rollout_batch_size = params['rollout_batch_size']
-    task_replay = params['task_replay']
-    sample_her_transitions = configure_her(params)
-    input_shapes = dims_to_shapes(dims)
-    dimg, dimag = dims['g'], dims['ag']
-    buffer_shapes = {key: (T if key != 'o' else T + 1, *input_shapes[key]) for key, val in input_shapes.items()}
-    buffer_shapes['g'] = (buffer_shapes['g'][0], dimg)
-    buffer_shapes['ag'] = (T + 1, dimag)
-    buffer_size = (buffer_size // rollout_batch_size) * rollout_batch_size
-    if structure in ('curious', 'task_experts'):
-        buffer_shapes['task_descr'] = (buffer_shapes['g'][0], dims['task_descr'])
-        buffer_shapes['change'] = (buffer_shapes['g'][0], dimag)
+    sampler = configure_her(params)
+    # per-episode shapes: T + 1 observations / achieved goals, T of everything else (config.py:200-208)
+    shapes = {name: ((T + 1 if name == 'o' else T),) + tail for name, tail in dims_to_shapes(dims).items()}
+    shapes['g'] = (T, dims['g'])
+    shapes['ag'] = (T + 1, dims['ag'])
+    if params['structure'] in ('curious', 'task_experts'):
+        shapes['task_descr'] = (T, dims['task_descr'])
+        shapes['change'] = (T, dims['ag'])
     else:
-        buffer_shapes.pop('task_descr', None)
-    if 'buffer' in task_replay:
-        return make_pooled_buffers(buffer_shapes, buffer_size, T, sample_her_transitions, params['nb_tasks'] + 1,
-                                   alias_from=5)
-    return ReplayBuffer(buffer_shapes, buffer_size, T, sample_her_transitions)
+        shapes.pop('task_descr', None)
+    per_rollout = params['rollout_batch_size']
+    capacity = params['buffer_size'] // per_rollout * per_rollout   # in transitions (config.py:210)
+    if 'buffer' in params['task_replay']:
+        return make_pooled_buffers(shapes, capacity, T, sampler, params['nb_tasks'] + 1, alias_from=5)
+    return ReplayBuffer(shapes, capacity, T, sampler)
 
 
 def configure_ddpg(dims, params, buffers, reuse=False, use_mpi=True, clip_return=True, t_id=None, **hooks):
     """config.py:219-254.  `hooks`: construction hooks of this implementation (curious_amd.experts.ExpertBank)."""
-    sample_her_transitions = configure_her(params)
+    sampler = configure_her(params)
     gamma = params['gamma']
-    rollout_batch_size = params['rollout_batch_size']
+    cached_make_env(params['make_env']).reset()
     ddpg_params = params['ddpg_params']
-    input_dims = dims.copy()
-    env = cached_make_env(params['make_env'])
-    env.reset()
-    ddpg_params.update({'input_dims': input_dims,
-                        'T': params['T'],
-                        'clip_pos_returns': True,
-                        'clip_return': (1. / (1. - gamma)) if clip_return else np.inf,
-                        'rollout_batch_size': rollout_batch_size,
-                        'subtract_goals': simple_goal_subtract,
-                        'sample_transitions': sample_her_transitions,
-                        'gamma': gamma,
-                        'task_replay': params['task_replay'],
-                        'structure': params['structure'],
-                        'tasks_ag_id': params['tasks_ag_id'],
-                        'tasks_g_id': params['tasks_g_id'],
-                        'eps_task': params['eps_task']})
+    ddpg_params.update(input_dims=dims.copy(), T=params['T'], gamma=gamma, clip_pos_returns=True,
+                       clip_return=(1. / (1. - gamma)) if clip_return else np.inf,
+                       rollout_batch_size=params['rollout_batch_size'], subtract_goals=simple_goal_subtract,
+                       sample_transitions=sampler,
+                       **{key: params[key] for key in ('task_replay', 'structure', 'tasks_ag_id', 'tasks_g_id',
+                                                       'eps_task')})
     kw = dict(ddpg_params)
     if t_id is not None:
         # the reference's experts get different TensorFlow initialisations; here expert t_id draws its weights (and its
         # device RNG streams) from seed + t_id
-        kw.update({'t_id': t_id, 'seed': int(ddpg_params.get('seed', 0)) + int(t_id)})
+        kw.update(t_id=t_id, seed=int(ddpg_params.get('seed', 0)) + int(t_id))
     kw['info'] = {'env_name': params['env_name']}
     kw.update(hooks)
     return DDPG(reuse=reuse, **kw, buffers=buffers, use_mpi=use_mpi)
 
 
 def configure_dims(params):
-    """config.py:257-275."""
+    """config.py:257-275: observation / action / goal widths from the env's spaces, one 'info_<key>' entry per info value."""
     env = cached_make_env(params['make_env'])
-    info = env.unwrapped.info
-    dims = {
-        'o': env.observation_space.spaces['observation'].shape[0],
-        'u': env.action_space.shape[0],
-        'g': env.observation_space.spaces['desired_goal'].shape[0],
-        'ag': env.observation_space.spaces['achieved_goal'].shape[0],
-    }
-    dims['task_descr'] = params['nb_tasks']
-    for key, value in info.items():
-        value = np.array(value)
-        if value.ndim == 0:
-            value = value.reshape(1)
-        dims['info_{}'.format(key)] = value.shape[0]
+    spaces = env.observation_space.spaces
+    dims = dict(o=spaces['observation'].shape[0], u=env.action_space.shape[0], g=spaces['desired_goal'].shape[0],
+                ag=spaces['achieved_goal'].shape[0], task_descr=params['nb_tasks'])
+    for name, value in env.unwrapped.info.items():
+        dims['info_' + name] = int(np.atleast_1d(np.array(value)).shape[0])
     return dims
