@@ -1,4 +1,6 @@
 """Kernel-level parity: every C-ABI entry point against the oracle / golden vectors, on a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -87,7 +89,7 @@ def test_her_sample_kernel_bit_exact(ops, name):
     assert not np.isnan(batch[:, :layout.boff_extra + layout.dimextra].cpu().numpy()).any()
 
 
-@pytest.mark.parametrize('case', range(16))
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_HER', 16))))
 def test_her_sample_random_shapes_vs_oracle(ops, case):
     """Seeded sweep over shapes the golden cases do not enumerate: 1-10 tasks with RAGGED goal slots (1-4 goal dims per
     task, achieved-goal slots at least as wide: her.py:154 takes ag_id[:len(g_id)]), observations of 3-120 floats, horizons
@@ -400,12 +402,13 @@ def test_ddpg_grads_vs_oracle(ops, cfg, route):
         assert err <= max(4 * err32, 1e-6 * np.abs(want).max())
 
 
-@pytest.mark.parametrize('case', range(12))
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_GRADS', 12))))
 def test_ddpg_grads_random_shapes_vs_oracle(ops, case):
     """Seeded sweep of curious_ddpg_grads over shapes between the enumerated ones: 1-10 tasks, goals of 1-30 floats (not
     3 per task), observations of 3-100 floats, batches 4..512 (multiples of 4 and not), hidden 256 (the row-local / lean
     routes where the shape allows, the generic kernels otherwise) or 32-128, 1-4 layers, max_u / gamma / clip_return /
-    clip_pos_returns / action_l2 varied -- losses, Q_pi and both flat gradients within 1e-5 of the float64 oracle."""
+    clip_pos_returns / action_l2 varied -- losses, Q_pi and both flat gradients within 1e-5 of the float64 oracle.
+    CURIOUS_FUZZ_GRADS=N (and CURIOUS_FUZZ_HER=N for the sweep above) extends the seeded range for a one-off hunt."""
     from curious_amd.layout import RecordLayout
     from oracle.networks import DDPGMath
     rs = np.random.RandomState(500 + case)
@@ -449,11 +452,35 @@ def test_ddpg_grads_random_shapes_vs_oracle(ops, case):
     np.testing.assert_allclose(Qpi.cpu().numpy(), ref['Q_pi'][:, 0], rtol=1e-5, atol=2e-6, err_msg=tag)
     g = ops.unpad_params(ncfg, grad.cpu().numpy())
     assert not np.isnan(g).any(), tag
+    # A ReLU that sits on its kink for some batch row (|pre-activation| ~ 1e-7: float32 in another summation order and
+    # float64 disagree about its sign) takes that row's contribution to a hidden unit's gradients in or out -- a
+    # legitimate difference far above 1e-5 (seen in 5 of 400 cases of the extended sweep, CURIOUS_FUZZ_GRADS).  The
+    # float64 oracle tells whether this batch has such a row; then only the losses are held to the tolerance.
+    kink = _relu_margin(m64, theta.astype(np.float64), bd) < 3e-6
     for name, sl in (('Q_grad', slice(0, PQ)), ('pi_grad', slice(PQ, PQ + Ppi))):
         want = ref[name]
-        err = np.abs(g[sl] - want).max()
+        err, scale = np.abs(g[sl] - want).max(), np.abs(want).max()
         err32 = np.abs(ref32[name] - want).max()
-        assert err <= max(1e-5 * np.abs(want).max(), 4 * err32), (tag, name, err, np.abs(want).max())
+        assert err <= (2e-2 * scale if kink else max(1e-5 * scale, 4 * err32)), (tag, name, err, scale, kink)
+
+
+def _relu_margin(m, theta, bd):
+    """Smallest |pre-activation| of a hidden layer over the three passes of the main networks whose ReLU masks gate the
+    gradients: actor(o, g), critic(o, g, u), critic(o, g, pi) (oracle/networks.py DDPGMath, modular networks)."""
+    Qm, pim = m.split(theta)
+    o, g, u, td = (bd[k].astype(np.float64) for k in ('o', 'g', 'u', 'task_descr'))
+    pi, _, _ = m.actor(pim, o, td, g)
+
+    def margin(params, x_state):
+        pre = x_state @ params[0] + params[1] + g @ params[2]
+        rest, out = params[3:], np.inf
+        for i in range(len(rest) // 2):
+            out = min(out, float(np.abs(pre).min()))
+            pre = np.maximum(pre, 0) @ rest[2 * i] + rest[2 * i + 1]
+        return out
+    st = np.concatenate([o, td], axis=1)
+    return min(margin(pim, st), margin(Qm, np.concatenate([st, u / m.max_u], axis=1)),
+               margin(Qm, np.concatenate([st, pi / m.max_u], axis=1)))
 
 
 def test_policy_forward_and_noise(ops, route):
