@@ -483,6 +483,94 @@ def _relu_margin(m, theta, bd):
                margin(Qm, np.concatenate([st, pi / m.max_u], axis=1)))
 
 
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_ACT', 10))))
+def test_policy_forward_random_shapes_vs_oracle(ops, case):
+    """Seeded sweep of curious_policy_forward (DDPG.get_actions' network part, ddpg.py:129-147): 1-600 rows, 1-10 tasks,
+    goals of 1-30 floats, observations of 3-100 floats, hidden 32-256, 1-4 layers, clip on / off, relative goals where the
+    widths allow -- pi and Q(pi) within 1e-5 of the float64 oracle (row-local, lean and generic acting kernels alike)."""
+    from oracle.ddpg import preprocess_og
+    from oracle.networks import DDPGMath
+    rs = np.random.RandomState(900 + case)
+    nb, G, dimo = int(rs.randint(1, 11)), int(rs.randint(1, 31)), int(rs.randint(3, 101))
+    n = int(rs.choice([1, 2, 3, 4, 37, 48, 256, 600]))
+    hidden = int(rs.choice([256, 256, 256, 128, 64, 32]))
+    layers = int(rs.randint(1, 5)) if hidden != 256 else int(rs.randint(2, 5))
+    max_u = float(rs.choice([0.5, 1.0, 2.0]))
+    clip = float(rs.choice([200.0, 2.0]))
+    m64 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, 0.98, 50., True, 1.0, True, np.float64)
+    m32 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, 0.98, 50., True, 1.0, True, np.float32)
+    theta = m32.init(rs)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, hidden, layers, True, max_u, 0.98, 50., 1.0)
+    o = (rs.randn(n, dimo) * 3).astype(np.float32)
+    g = rs.randn(n, G).astype(np.float32)
+    ag = rs.randn(n, G).astype(np.float32)
+    td = np.eye(nb, dtype=np.float32)[rs.randint(nb, size=n)]
+    ws = torch.zeros(ops.workspace_floats(ncfg, n), device='cuda')
+    pi = torch.full([n, 4], float('nan'), device='cuda')
+    Q = torch.full([n, 1], float('nan'), device='cuda')
+    ops.policy_forward(ncfg, dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), n, clip, ws, pi, Q, ag=dev(ag))
+    torch.cuda.synchronize()
+    oc, gc = preprocess_og(o, ag, g, clip)
+    Qp, pip = m64.split(theta.astype(np.float64))
+    want_pi, _, _ = m64.actor(pip, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64))
+    want_Q, _ = m64.critic(Qp, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64), want_pi / max_u)
+    tag = 'case %d: n %d nb %d G %d dimo %d hidden %d layers %d' % (case, n, nb, G, dimo, hidden, layers)
+    np.testing.assert_allclose(pi.cpu().numpy(), want_pi, rtol=1e-5, atol=2e-6 * max_u, err_msg=tag)
+    np.testing.assert_allclose(Q.cpu().numpy(), want_Q, rtol=1e-5, atol=4e-6, err_msg=tag)
+
+
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_NORM', 8))))
+def test_normalizer_pair_and_adam_random_sizes_vs_oracle(ops, case):
+    """Seeded sweep of the two reductions / element-wise kernels whose grids depend on the sizes: curious_norm_update_pair
+    (1-20 000 rows, both widths 1-120, arbitrary column offsets: sums within 1e-6, the recomputed mean / std bit-exact given
+    the sums) and curious_adam_update (parameter counts that are no multiple of anything, both halves: bit-exact)."""
+    from oracle.normalizer import Normalizer
+    from oracle.optim import adam_update
+    rs = np.random.RandomState(1300 + case)
+    da, db = int(rs.randint(1, 121)), int(rs.randint(1, 121))
+    n = int(rs.choice([1, 5, 63, 64, 65, 1000, 12800, 20000]))
+    off_a = int(rs.randint(0, 9))
+    off_b = off_a + da + int(rs.randint(0, 7))
+    stride = off_b + db + int(rs.randint(0, 5))
+    rows = (rs.randn(n, stride) * 2 + 0.3).astype(np.float32)
+    na, nbz = Normalizer(da, eps=0.01), Normalizer(db, eps=0.02)
+    acc = [torch.zeros(2 * d + 1, device='cuda') for d in (da, db)]
+    state = []
+    for d in (da, db):
+        st = torch.zeros(4 * d + 1, device='cuda')
+        st[2 * d] = 1.0
+        st[3 * d + 1:] = 1.0
+        state.append(st)
+    scratch = torch.zeros(ops.norm_pair_scratch_doubles(n, da, db), dtype=torch.float64, device='cuda')
+    ops.norm_update_pair(dev(rows), n, stride, off_a, da, off_b, db, acc[0], acc[1], state[0], state[1], 0.01, 0.02,
+                         scratch)
+    torch.cuda.synchronize()
+    for nz, d, off, st in ((na, da, off_a, state[0]), (nbz, db, off_b, state[1])):
+        nz.update(rows[:, off:off + d].astype(np.float64))
+        nz.recompute_stats()
+        s = st.cpu().numpy()
+        np.testing.assert_allclose(s[:d], nz.sum, rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(s[d:2 * d], nz.sumsq, rtol=2e-6)
+        assert s[2 * d] == nz.count[0]
+        np.testing.assert_allclose(s[2 * d + 1:3 * d + 1], nz.mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(s[3 * d + 1:], nz.std, rtol=1e-5, atol=1e-6)
+    assert float(acc[0].abs().sum()) == 0.0 and float(acc[1].abs().sum()) == 0.0
+    # Adam on odd sizes
+    nQ, npi = int(rs.randint(1, 5000)), int(rs.randint(1, 5000))
+    theta0 = rs.randn(nQ + npi).astype(np.float32)
+    th, m, v = dev(theta0), torch.zeros(nQ + npi, device='cuda'), torch.zeros(nQ + npi, device='cuda')
+    oq = (theta0[:nQ].copy(), np.zeros(nQ, np.float32), np.zeros(nQ, np.float32), 0)
+    op = (theta0[nQ:].copy(), np.zeros(npi, np.float32), np.zeros(npi, np.float32), 0)
+    for k in range(3):
+        gr = rs.randn(nQ + npi).astype(np.float32)
+        ops.adam_update(th, m, v, dev(gr), nQ, npi, ops.adam_alpha(1e-3, k + 1), ops.adam_alpha(3e-4, k + 1))
+        oq = adam_update(*oq, gr[:nQ], 1e-3, nep50=False)
+        op = adam_update(*op, gr[nQ:], 3e-4, nep50=False)
+    np.testing.assert_array_equal(th.cpu().numpy(), np.concatenate([oq[0], op[0]]))
+    np.testing.assert_array_equal(m.cpu().numpy(), np.concatenate([oq[1], op[1]]))
+    np.testing.assert_array_equal(v.cpu().numpy(), np.concatenate([oq[2], op[2]]))
+
+
 def test_policy_forward_and_noise(ops, route):
     from oracle.networks import DDPGMath
     from oracle.ddpg import action_postprocess, preprocess_og
