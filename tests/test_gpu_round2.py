@@ -580,6 +580,48 @@ def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B, l
     assert float(acts.abs().max()) <= 1.0 and float(acts.abs().sum()) > 0
 
 
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_ROLLOUT', 8))))
+def test_rollout_entry_point_random_sizes(case):
+    """Seeded sweep of curious_policy_rollout against one launch per step, bit for bit, over the sizes that decide its
+    route: 4-300 envs (the weights-resident kernel needs n % 4 == 0 and n <= CUs; 260 and 300 envs stream, 30 and 37 take
+    the generic launches), 2-4 layers, Arm4 / Arm8, exploration noise on and off."""
+    from curious_amd import ops
+    from curious_amd.envs import EnvFactory, REWARD_EPS
+    rs0 = np.random.RandomState(2100 + case)
+    env_name, nb, dimo = [('MultiTaskFetchArm4-v5', 4, 40), ('MultiTaskFetchArm8-v5', 8, 52)][int(rs0.randint(0, 2))]
+    B = int(rs0.choice([4, 8, 12, 30, 37, 100, 252, 256, 260, 300]))
+    layers = int(rs0.choice([2, 3, 3, 4]))
+    noise, reps = [(0.2, 0.3), (0.0, 0.0), (0.05, 1.0)][int(rs0.randint(0, 3))]
+    outs = []
+    for mode in ('rollout', 'steps'):
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, layers=layers)
+        env = EnvFactory(env_name).make_batched(B)
+        env.seed(11 + case)
+        rs = np.random.RandomState(3)
+        ws = torch.zeros(ops.workspace_floats(agent.net_cfg, B), dtype=torch.float32, device='cuda')
+        u = torch.zeros([B, 4], dtype=torch.float32, device='cuda')
+        recs = []
+        for ep in range(2):
+            env.reset_all(rs.randint(0, nb, B), rs.uniform(-1, 1, (B, 3)).astype(np.float32))
+            args = (agent.net_cfg, agent.theta, B, agent.clip_obs, ws, noise, reps, 999 + case)
+            tail = (env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS)
+            if mode == 'rollout':
+                ops.policy_rollout(*args, 1 + ep * T, u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T,
+                                   *tail, flags=env.flags)
+            else:
+                for t in range(T):
+                    ops.policy_act_env_step(*args, 1 + ep * T + t, u, env._cfg, env.layout, env.env_id0, env.episode,
+                                            env.tasks, t, *tail, flags=env.flags)
+            torch.cuda.synchronize()
+            assert float(env.flags[B]) == 0.0                        # neither a NaN word nor a member that gave up (2)
+            recs.append((env.staging.clone(), u.clone(), env.flags.clone(), env.o.clone(), env.ag.clone()))
+        outs.append(recs)
+    tag = 'case %d: %s B %d layers %d noise %s' % (case, env_name, B, layers, (noise, reps))
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), tag
+
+
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_async_store_equals_the_host_routed_cycle(use_graph):
     """async_store: the cycle rollout -> store_episode -> train_batches with the episodes routed on the device and the
