@@ -731,3 +731,68 @@ def test_route_store_kernel_matches_the_host_routing(E, cap):
         assert len(alive) == len(set(alive)) == len(set(want_dst))         # one surviving pair per destination
         assert cur.cpu().numpy().tolist() == want_cur.tolist()
         assert torch.equal(storage.reshape(6 * cap, Tn + 1, lay.row_stride), ref)
+
+
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_ROUTE', 10))))
+def test_route_store_kernel_random_shapes(case):
+    """Seeded sweep of curious_route_store_episodes against the sequential rule of ddpg.py:178-197 +
+    replay_buffer.py:90-109: 1-8 tasks (only the first 5 routed, buffers 6.. alias buffer 5), 1-2 048 episodes, capacities
+    from a handful of slots (every episode fights for one) to room for all, buffers empty / half full / full, sparse to dense
+    activity: pair list, sizes and the stored records."""
+    from curious_amd import ops
+    from curious_amd.layout import RecordLayout
+    rng = np.random.RandomState(3100 + case)
+    nb = int(rng.randint(1, 9))
+    nr = min(nb, 5)
+    E = int(rng.choice([1, 2, 7, 255, 256, 257, 700, 2048]))
+    cap = int(rng.choice([3, 17, 200, 3000, 30000]))
+    Tn = 3
+    dimg = 3 * nb
+    shapes = dict(o=(Tn + 1, 6), u=(Tn, 4), g=(Tn, dimg), ag=(Tn + 1, dimg), info_is_success=(Tn, 1),
+                  task_descr=(Tn, nb), change=(Tn, dimg))
+    lay = RecordLayout(shapes, Tn)
+    dev = torch.device('cuda', 0)
+    staging = torch.randn([E, Tn + 1, lay.row_stride], device=dev)
+    active_np = (rng.rand(E, nb) < rng.choice([0.02, 0.4, 1.0])).astype(np.int32)
+    active = torch.from_numpy(active_np).to(dev)
+    alias_np = np.array([min(i, 5) for i in range(nb + 1)], np.int32)
+    nphys = int(alias_np.max()) + 1
+    alias = torch.from_numpy(alias_np).to(dev)
+    fill = rng.choice(['empty', 'half', 'full', 'mixed'])
+    cur0 = dict(empty=np.zeros(nb + 1), half=np.full(nb + 1, cap // 2), full=np.full(nb + 1, cap),
+                mixed=rng.randint(0, cap + 1, nb + 1))[fill].astype(np.int32)
+    for i in range(6, nb + 1):
+        cur0[i] = cur0[5]                                            # logical buffers 6.. ARE buffer 5
+    storage = torch.zeros([nphys, cap, Tn + 1, lay.row_stride], device=dev)
+    cur = torch.from_numpy(cur0.copy()).to(dev)
+    src = torch.zeros(max(1, E * nr), dtype=torch.int32, device=dev)
+    dst = torch.zeros(max(1, E * nr), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    skip = torch.zeros(1, device=dev)
+    seed, call = 1234567 + case, 5 + case
+    ops.route_store_episodes(storage, staging, lay, active.reshape(-1), nb, nr, E, cur, alias, cap, seed, call, skip, src,
+                             dst, cnt)
+    torch.cuda.synchronize()
+    a = active_np.astype(bool)
+    want_src, want_dst, want_cur = [], [], cur0.copy()
+    ref = torch.zeros([nphys * cap, Tn + 1, lay.row_stride], device=dev)
+    for j in range(nr):
+        eps = np.nonzero(a[:, j])[0]
+        free = max(0, cap - int(cur0[1 + j]))
+        slots = np.arange(cur0[1 + j], cur0[1 + j] + min(eps.size, free)).tolist()
+        if eps.size > free:
+            slots += ops.store_slots_host(seed, call, j, cap, eps[free:]).tolist()
+        want_cur[1 + j] = min(cap, int(cur0[1 + j]) + eps.size)
+        for e, sl in zip(eps.tolist(), slots):
+            ref[sl + int(alias_np[1 + j]) * cap] = staging[e]
+        want_src += eps.tolist()
+        want_dst += [sl + int(alias_np[1 + j]) * cap for sl in slots]
+    k = int(cnt)
+    tag = 'case %d: nb %d E %d cap %d %s' % (case, nb, E, cap, fill)
+    assert k == len(want_src), tag
+    got_src, got_dst = src[:k].cpu().tolist(), dst[:k].cpu().tolist()
+    assert got_dst == want_dst and all(g in (w, -1) for g, w in zip(got_src, want_src)), tag
+    alive = [d for g, d in zip(got_src, got_dst) if g >= 0]
+    assert len(alive) == len(set(alive)) == len(set(want_dst)), tag
+    assert cur.cpu().numpy()[1:1 + nr].tolist() == want_cur[1:1 + nr].tolist(), tag
+    assert torch.equal(storage.reshape(nphys * cap, Tn + 1, lay.row_stride), ref), tag
