@@ -1,5 +1,7 @@
 """Agent-level parity on a real MI355X: curious_amd.DDPG / ReplayBuffer / RolloutWorker against the oracle on
 identical seeds (bit-exact sampling, relabelling and rewards; losses within 1e-5 relative)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -228,24 +230,18 @@ def test_device_rng_graph_equals_eager_and_learns():
     assert np.all(td.sum(axis=1) == 1)
 
 
-@pytest.mark.parametrize('shape', ['default', 'small', 'layers4', 'layers2', 'normalize'])
-def test_fused_update_equals_unfused_sequence(shape, route):
-    """curious_ddpg_update (Adam in the weight-gradient launch + next gather riding along) against the three separate
-    launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit: lean kernels, the generic fallback, and
-    4 layers per network (the row-local pass with the generic weight gradients + the stand-alone optimiser)."""
-    kw = dict(default={}, small=dict(batch_size=64, hidden=64), layers4=dict(layers=4), layers2=dict(layers=2),
-              normalize=dict(normalize_obs=True))[shape]   # --normalize_obs: statistics of the stored episodes feed the nets
-    a_f, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
-    a_u, _ = build_pair(4, 40, rng_mode='device', use_graph=False, **kw)
+def _fused_vs_unfused(nb, dimo, kw, n_updates=9):
+    a_f, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, **kw)
+    a_u, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, **kw)
     rng = np.random.RandomState(5)
-    cp = np.array([0.3, 0.0, 0.2, 0.1])
-    ep = synth_episodes(rng, 40, 4, 40)
+    cp = np.array([0.3, 0.0, 0.2, 0.1] * 3)[:nb]
+    ep = synth_episodes(rng, 40, nb, dimo)
     for a in (a_f, a_u):
         np.random.seed(2)
         a.store_episode({k: v.copy() for k, v in ep.items()}, cp, 40)
-    if shape == 'normalize':
+    if kw.get('normalize_obs'):
         assert float(a_f.o_stats.mean.abs().sum()) > 0 and a_f.normalize_obs      # non-trivial statistics feed the nets
-    for k in range(9):
+    for k in range(n_updates):
         lf, qf = a_f.train()
         if a_u._tables_dirty:
             a_u._refresh_device_tables()
@@ -260,6 +256,29 @@ def test_fused_update_equals_unfused_sequence(shape, route):
         assert torch.equal(a_f.theta, a_u.theta) and torch.equal(a_f._m, a_u._m) and torch.equal(a_f._v, a_u._v)
         assert float(lf) == float(lu) and torch.equal(qf, qu)
     assert float(a_f.theta.abs().sum()) != float(a_f.theta_target.abs().sum())   # the parameters did move
+
+
+@pytest.mark.parametrize('shape', ['default', 'small', 'layers4', 'layers2', 'normalize'])
+def test_fused_update_equals_unfused_sequence(shape, route):
+    """curious_ddpg_update (Adam in the weight-gradient launch + next gather riding along) against the three separate
+    launches it replaces -- her_sample, ddpg_grads, adam_update -- bit for bit: lean kernels, the generic fallback, and
+    4 layers per network (the row-local pass with the generic weight gradients + the stand-alone optimiser)."""
+    kw = dict(default={}, small=dict(batch_size=64, hidden=64), layers4=dict(layers=4), layers2=dict(layers=2),
+              normalize=dict(normalize_obs=True))[shape]   # --normalize_obs: statistics of the stored episodes feed the nets
+    _fused_vs_unfused(4, 40, kw)
+
+
+@pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_UPDATE', 8))))
+def test_fused_update_random_shapes(case):
+    """The same identity over seeded random agents: 1-10 tasks, observations of 31-90 floats, batches of 64-512, hidden
+    64 / 128 / 256, 2-4 layers, input normalisation on / off -- whichever kernels the shape selects for the fused form
+    (row-local + lean tail, row-local + generic tail + stand-alone Adam, tiled) against the unfused sequence."""
+    rs = np.random.RandomState(4100 + case)
+    nb = int(rs.randint(1, 11))
+    dimo = int(rs.randint(3 * nb + 4, 3 * nb + 61))                  # the synthetic episodes keep ag = o[:3 nb]
+    kw = dict(batch_size=int(rs.choice([64, 128, 256, 512])), hidden=int(rs.choice([64, 128, 256, 256])),
+              layers=int(rs.randint(2, 5)), normalize_obs=bool(rs.randint(0, 2)))
+    _fused_vs_unfused(nb, dimo, kw, n_updates=5)
 
 
 def test_step_size_ring_refill_under_chained_graphs():
