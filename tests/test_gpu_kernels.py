@@ -616,11 +616,14 @@ def test_policy_forward_and_noise(ops, route):
     assert np.abs(x).max() <= 1.0
 
 
-@pytest.mark.parametrize('name', ['MultiTaskFetchArm4-v5', 'MultiTaskFetchArm8-v5'])
+@pytest.mark.parametrize('name', ['MultiTaskFetchArm4-v5', 'MultiTaskFetchArm8-v5', (1, 7), (3, 21), (5, 43), (6, 33),
+                                  (7, 46), (8, 128)])
 def test_env_bit_exact_vs_oracle(ops, name):
+    """env_reset_kernel / env_step_kernel against oracle/env.py, bit for bit: the two named configurations and synthetic
+    arms of other task counts and observation widths (1-8 tasks; widths that are no multiple of 4; the 128-float maximum)."""
     from curious_amd.layout import RecordLayout
     from oracle.env import ENV_CONFIGS, SyntheticMultiTaskArm
-    nb, dimo, T = ENV_CONFIGS[name]
+    nb, dimo, T = ENV_CONFIGS[name] if isinstance(name, str) else (name[0], name[1], 50)
     T = 9
     G = 3 * nb
     n = 70

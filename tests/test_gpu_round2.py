@@ -119,10 +119,8 @@ def test_batched_experts_random_banks(case):
     moments, target networks and the next staged batch of every expert, bit for bit."""
     from curious_amd.experts import ExpertBank
     rs = np.random.RandomState(5100 + case)
-    nb = int(rs.choice([2, 3, 4, 4, 4, 6, 8, 8]))
-    dimo = int(rs.randint(3 * nb + 4, 3 * nb + 50))
-    if nb % 4 == 0 and rs.rand() < 0.8:
-        dimo -= dimo % 4                                             # mostly shapes the batched launches accept
+    nb = int(rs.choice([2, 3, 4, 4, 5, 6, 7, 8]))
+    dimo = int(rs.randint(3 * nb + 4, min(3 * nb + 50, 96 - 4 * nb)))  # [o | td | u | g] has to fit the 100-float input row
     batch = int(rs.choice([256, 512]))
     use_graph = bool(rs.randint(0, 2))
     n_up = int(rs.choice([3, 8, 13]))
@@ -154,9 +152,7 @@ def test_batched_experts_random_banks(case):
         x.update_target_net()
     torch.cuda.synchronize()
     tag = 'case %d: nb %d dimo %d batch %d graph %s updates %d' % (case, nb, dimo, batch, use_graph, n_up)
-    # the batched launches need what the row-local kernels need: [o | td] and g a multiple of 4 floats wide; other banks
-    # report it and update their experts one by one (same results either way)
-    assert bank.batched == ((dimo + nb) % 4 == 0 and (3 * nb) % 4 == 0), tag
+    assert bank.batched, tag
     for a, b in zip(bx, sx):
         assert a.Q_adam.t == b.Q_adam.t == n_up, tag
         assert torch.equal(a.theta, b.theta) and torch.equal(a._m, b._m) and torch.equal(a._v, b._v), tag
@@ -633,14 +629,20 @@ def test_rollout_entry_point_equals_one_launch_per_step(env_name, nb, dimo, B, l
 
 
 @pytest.mark.parametrize('case', range(int(os.environ.get('CURIOUS_FUZZ_ROLLOUT', 8))))
-def test_rollout_entry_point_random_sizes(case):
+def test_rollout_entry_point_random_sizes(case, monkeypatch):
     """Seeded sweep of curious_policy_rollout against one launch per step, bit for bit, over the sizes that decide its
     route: 4-300 envs (the weights-resident kernel needs n % 4 == 0 and n <= CUs; 260 and 300 envs stream, 30 and 37 take
-    the generic launches), 2-4 layers, Arm4 / Arm8, exploration noise on and off."""
+    the generic launches), 2-4 layers, Arm4 / Arm8 and synthetic arms of 3 / 5 / 6 / 7 tasks whose widths are no multiple of
+    4, exploration noise on and off."""
     from curious_amd import ops
     from curious_amd.envs import EnvFactory, REWARD_EPS
+    from curious_amd import envs as envs_mod
+    # synthetic arms of other widths than the two named configurations (widths that are no multiple of 4 included)
+    extra = {'SynthArm3': (3, 21, 50), 'SynthArm5': (5, 43, 50), 'SynthArm6': (6, 33, 50), 'SynthArm7': (7, 46, 50)}
+    monkeypatch.setattr(envs_mod, 'ENV_CONFIGS', dict(envs_mod.ENV_CONFIGS, **extra))
     rs0 = np.random.RandomState(2100 + case)
-    env_name, nb, dimo = [('MultiTaskFetchArm4-v5', 4, 40), ('MultiTaskFetchArm8-v5', 8, 52)][int(rs0.randint(0, 2))]
+    shapes = [('MultiTaskFetchArm4-v5', 4, 40), ('MultiTaskFetchArm8-v5', 8, 52)] + [(k, v[0], v[1]) for k, v in extra.items()]
+    env_name, nb, dimo = shapes[int(rs0.randint(0, len(shapes)))]
     B = int(rs0.choice([4, 8, 12, 30, 37, 100, 252, 256, 260, 300]))
     layers = int(rs0.choice([2, 3, 3, 4]))
     noise, reps = [(0.2, 0.3), (0.0, 0.0), (0.05, 1.0)][int(rs0.randint(0, 3))]
