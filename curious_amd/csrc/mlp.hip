@@ -436,7 +436,7 @@ static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
 
 static bool act_rows_ok(const curious_net_cfg_t* c, int n, bool relative, const float* theta) {
   return rows_enabled() && c->modular && c->layers >= 2 && c->layers <= ROWS_MAXL && c->hidden == 256 && c->dimu == 4 &&
-         (n % ROWS_R == 0) && !c->normalize_obs && !relative && c->dimo + c->dimtd + 4 + c->dimg <= XLD &&
+         (n % ROWS_R == 0) && !c->normalize_obs && !relative && c->dimo + c->dimtd + 4 + c->dimg <= ROWS_MAXIN &&
          aligned16(theta);
 }
 
@@ -747,7 +747,7 @@ int DdpgPass::setup(curious_stream_t stream) {
 
 bool DdpgPass::rows_route() const {
   return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % 16 == 0) &&
-         !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= XLD && aligned16(thQ) && aligned16(thPi) &&
+         !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= ROWS_MAXIN && aligned16(thQ) && aligned16(thPi) &&
          aligned16(ttQ) && aligned16(ttPi) && aligned16(workspace) && (offQ.Wout % 4 == 0) && (offPi.Wout % 4 == 0);
 }
 

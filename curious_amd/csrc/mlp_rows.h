@@ -36,7 +36,8 @@
 #define ROWS_MAXL 4          // layers per network on this route (layer 0 + up to 3 hidden layers)
 #define ROWS_R 4             // batch rows per workgroup
 #define RLD 264              // LDS row stride of an activation row (8 mod 64: conflict-free b128 broadcast reads)
-#define XLD 100              // LDS row stride of the layer-0 input row [o | td | action | g]: 100 mod 64 = 36 puts the 4 rows a
+#define ROWS_MAXIN 128       // widest layer-0 input [o | td | action | g] the row-local kernels take: two passes of 64 (rows_l0_fwd)
+#define XLD 132              // LDS row stride of that input row: 132 mod 64 = 4 puts the 4 rows a
                              // wave reads together on 4 different banks (96 made rows 0/2 and 1/3 collide: 14 % of the LDS cycles)
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 

@@ -348,8 +348,10 @@ def _rand_batch(rng, layout, B, nb):
     dict(nb=4, dimo=40, B=512, hidden=256, layers=4, max_u=2.0),     # deeper net, two batch chunks, max_u != 1
     dict(nb=4, dimo=40, B=37, hidden=64, layers=2, max_u=1.5),       # ragged rows / other depth
     dict(nb=3, dimo=10, B=5, hidden=24, layers=1, max_u=2.0),        # tiny, nothing multiple of 16
-    dict(nb=12, dimo=64, B=256, hidden=256, layers=3, max_u=1.0),    # 64 + 12 + 4 + 36 = 116 input floats: wider than
-                                                                     # the row-local kernels' input row, tiled by itself
+    dict(nb=12, dimo=64, B=256, hidden=256, layers=3, max_u=1.0),    # 64 + 12 + 4 + 36 = 116 input floats: two passes of
+                                                                     # the row-local layer 0
+    dict(nb=12, dimo=90, B=256, hidden=256, layers=3, max_u=1.0),    # 142 input floats: wider than the row-local kernels'
+                                                                     # input row (128), tiled by itself
 ])
 def test_ddpg_grads_vs_oracle(ops, cfg, route):
     from curious_amd.layout import RecordLayout
