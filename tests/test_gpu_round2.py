@@ -120,7 +120,7 @@ def test_batched_experts_random_banks(case):
     from curious_amd.experts import ExpertBank
     rs = np.random.RandomState(5100 + case)
     nb = int(rs.choice([2, 3, 4, 4, 5, 6, 7, 8]))
-    dimo = int(rs.randint(3 * nb + 4, min(3 * nb + 50, 96 - 4 * nb)))  # [o | td | u | g] has to fit the 100-float input row
+    dimo = int(rs.randint(3 * nb + 4, min(3 * nb + 60, 124 - 4 * nb)))  # [o | td | u | g] has to fit the 128-float input row
     batch = int(rs.choice([256, 512]))
     use_graph = bool(rs.randint(0, 2))
     n_up = int(rs.choice([3, 8, 13]))
