@@ -104,6 +104,8 @@ struct Ws {   // workspace carve-up
   float* zp[2];                // layer-0 pre-activations of target critic / main critic without the action term
   float* part[6];              // dot-epilogue partials [4 tiles][B][<=4]: pi_target, pi, Q, Q_target, Q_pi, dz
   float* qt;                   // hand-off words of the row-local pass (mlp_rows.h): [B] x 64 bit
+  float* xn[2];                // input normalisation on the row-local route: normalised layer-0 input rows [B][XLD] of the
+                               // main critic(u) / main actor passes (mlp_rows.h)
   float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h)
   int32_t* fault;              // fault word (mlp_rows.h): consumers of Q' that gave up; sticky until the host clears it.
                                // wT and fault are the ONLY parts of the workspace that carry state between calls
@@ -132,6 +134,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.zp[1] = take(BH);
   for (int i = 0; i < 6; ++i) w.part[i] = take(16 * (int64_t)B);
   w.qt = take(2 * (int64_t)B);
+  for (int i = 0; i < 2; ++i) w.xn[i] = c->normalize_obs ? take((int64_t)B * XLD) : nullptr;
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l < c->layers; ++l) w.wT[net][l] = (l >= 1) ? take((int64_t)c->hidden * c->hidden) : nullptr;
   w.fault = reinterpret_cast<int32_t*>(take(64));
@@ -704,6 +707,7 @@ struct DdpgPass {
   HerArgs her_rows;
   // one-launch update (mlp_step.h ddpg_step_kernel): rows_pass() only prepares the row-local launch, weight_grads()
   // enqueues it together with its tiles -- or, should the tile lists not qualify, on its own first (launch_rows)
+  bool xn_rows = false;       // the row-local launch of this pass keeps the NORMALISED layer-0 input rows in w.xn
   bool one_launch = false;
   bool rows_pending = false;
   RowsArgs ra;
@@ -747,7 +751,7 @@ int DdpgPass::setup(curious_stream_t stream) {
 
 bool DdpgPass::rows_route() const {
   return rows_enabled() && cfg->modular && nl >= 2 && nl <= ROWS_MAXL && H == 256 && U == 4 && (B % 16 == 0) &&
-         !cfg->normalize_obs && cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= ROWS_MAXIN && aligned16(thQ) && aligned16(thPi) &&
+         cfg->dimo + cfg->dimtd + 4 + cfg->dimg <= ROWS_MAXIN && aligned16(thQ) && aligned16(thPi) &&
          aligned16(ttQ) && aligned16(ttPi) && aligned16(workspace) && (offQ.Wout % 4 == 0) && (offPi.Wout % 4 == 0);
 }
 
@@ -759,7 +763,7 @@ bool DdpgPass::rows_route() const {
 //  write the copies)
 bool DdpgPass::keeps_copies(const UpdateTail* tail) const {
   const bool dx_ok = hot_ok(B, H, H) && aligned16(thQ) && aligned16(thPi) && aligned16(workspace);
-  return tail && dx_ok && (B % 256 == 0) && (nl - 1) <= 4 && 2 * (nl - 1) <= 4 && !cfg->normalize_obs &&
+  return tail && dx_ok && (B % 256 == 0) && (nl - 1) <= 4 && 2 * (nl - 1) <= 4 &&
          (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64);
 }
 
@@ -796,6 +800,11 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.xmap = (curious_options().rows_xcd && xd.nex == 1) ? 1 : 0;
   a.fault = w.fault; a.inject = curious_options().fault_inject; a.spins = curious_options().qt_spins;
   a.lab_no_target = curious_options().lab_no_target;
+  xn_rows = cfg->normalize_obs != 0;
+  if (cfg->normalize_obs) {
+    a.o_mean = cur.o_mean; a.o_std = cur.o_std; a.g_mean = cur.g_mean; a.g_std = cur.g_std; a.nclip = cur.nclip;
+    a.xn_c = w.xn[0]; a.xn_a = w.xn[1];
+  }
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
@@ -1096,7 +1105,7 @@ int DdpgPass::actor_backward() {
 
 int DdpgPass::weight_grads(const UpdateTail* tail) {
   // ---- weight/bias gradients: problem lists for the lean kernels (launched after the actor's backward chain)
-  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && !cfg->normalize_obs;
+  const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && (!cfg->normalize_obs || xn_rows);
   LossFin fin;
   fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
   fin.step_ctr = gather_in_rows ? step_ctr : nullptr;
@@ -1126,7 +1135,19 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     }
     hw.nprob = nh;
     Seg seg[MAX_SEG];
-    int ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
+    int ns;
+    if (xn_rows) {
+      // input normalisation: the row-local launch left the normalised rows [o | td | u / max_u | g] in the workspace
+      const float* xr = w.xn[critic ? 0 : 1];
+      const int Sa = cfg->dimo + cfg->dimtd;
+      ObsIn in;
+      memset(&in, 0, sizeof(in));
+      in.o = xr; in.td = xr + cfg->dimo; in.u = xr + Sa; in.g = xr + Sa + 4;
+      in.ldo = in.ldtd = in.ldu = in.ldg = XLD;
+      ns = l0_segments(cfg, off, nullptr, in, critic, 1.0f, seg);
+    } else {
+      ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
+    }
     int64_t r = 0;
     for (int s = 0; s < ns; ++s) {
       const bool goal_branch = cfg->modular && s == ns - 1;

@@ -68,6 +68,12 @@ struct RowsArgs {
                                   // batch (her_body.h) -- on CUs the three kinds leave idle, hidden behind the chains.
                                   // The step counter is then NOT incremented here (the gather keys its Philox stream on
                                   // it: counter + 1) but by the weight-gradient launch that follows (LossFin.step_ctr).
+  // input normalisation (actor_critic.py:76-83, --normalize_obs): mean / std of the observation and goal normalisers or
+  // NULL; the normalised input rows [o | td | u / max_u | g] of the main critic(u) and main actor passes are kept in
+  // xn_c / xn_a ([B][XLD]) for the layer-0 weight gradients
+  const float *o_mean, *o_std, *g_mean, *g_std;
+  float nclip;
+  float *xn_c, *xn_a;
   int32_t* sync;                  // one-launch update (ddpg_step_kernel, mlp_common.h StepSync): the counters the row groups
   int32_t n_tickets;              // publish on, and how many workgroups take a ticket; NULL / 0 in every other launch
   int32_t lab_step;               // lab only (CuriousOptions.lab_step)
@@ -265,18 +271,28 @@ __device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {    
 
 // layer-0 input rows of the workgroup's 4 batch rows: xin[i] = [o | td | action slot | g]; the action slot receives
 // the batch action / max_u (actor_critic.py:96) when with_u, else it is filled later from the actor's output
+// keep: where the rows are also stored for the layer-0 weight gradients (input normalisation only: without it those
+// read the batch itself), or NULL
 __device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& a, const float* batch, int off_o,
-                                                 int off_g, bool with_u) {
+                                                 int off_g, bool with_u, float* keep = nullptr) {
   const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
   for (int idx = x.tid; idx < 4 * tot; idx += 256) {
     const int i = idx / tot, k = idx - i * tot;
     const float* row = batch + (int64_t)(x.r0 + i) * a.ld;
     float v;
-    if (k < a.dimo) v = row[off_o + k];
-    else if (k < Sa) v = row[a.off_td + (k - a.dimo)];
-    else if (k < S) v = with_u ? fdiv(row[a.off_u + (k - Sa)], a.max_u) : 0.f;
-    else v = row[off_g + (k - S)];
+    if (k < a.dimo) {
+      v = row[off_o + k];
+      if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[k]), a.o_std[k]), -a.nclip, a.nclip);     // normalizer.py:72-77
+    } else if (k < Sa) {
+      v = row[a.off_td + (k - a.dimo)];
+    } else if (k < S) {
+      v = with_u ? fdiv(row[a.off_u + (k - Sa)], a.max_u) : 0.f;
+    } else {
+      v = row[off_g + (k - S)];
+      if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - S]), a.g_std[k - S]), -a.nclip, a.nclip);
+    }
     x.xin[i * XLD + k] = v;
+    if (keep) keep[(int64_t)(x.r0 + i) * XLD + k] = v;
   }
 }
 
@@ -435,7 +451,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     ROWS_STAMP(0);
     rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
     const float b0_mq = mq[a.mQ.b0 + x.tid];
-    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true);
+    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true, a.xn_c ? a.xn_c + eo : nullptr);
     __syncthreads();
     ROWS_STAMP(1);
     // operands of the head / loss / first backward step, fetched ahead of the hidden layers
@@ -509,7 +525,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   ROWS_STAMP(0);
   rows_l0_load(wb[0], mp + a.mPi.W0, Sa, mp + a.mPi.Wg, Sa + G, x.wave, x.lane, 0);
   const float b0_mp = mp[a.mPi.b0 + x.tid];
-  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false);
+  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false, a.xn_a ? a.xn_a + eo : nullptr);
   __syncthreads();
   ROWS_STAMP(1);
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);

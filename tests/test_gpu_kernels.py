@@ -711,7 +711,7 @@ def test_ddpg_grads_flat_network_vs_oracle(ops):
     assert np.abs(g[PQ:] - ref['pi_grad']).max() <= 1e-5 * np.abs(ref['pi_grad']).max()
 
 
-def test_ddpg_grads_with_input_normalisation(ops):
+def test_ddpg_grads_with_input_normalisation(ops, route):
     """normalize_obs=True (actor_critic.py:76-83): nets see clip((x - mean) / std, +-norm_clip)."""
     from curious_amd.layout import RecordLayout
     from oracle.networks import DDPGMath
