@@ -29,6 +29,9 @@ struct ActRowsArgs {
   double reward_eps;
   float* flags;                                   // optional rollout flags (env_step_body)
   int32_t noise_lds;                              // != 0: the launch has the LDS area for pre-drawn noise
+  // input normalisation (plain forward only: the fused entry points carry no statistics): mean / std or NULL
+  const float *o_mean, *o_std, *g_mean, *g_std;
+  float nclip;
 };
 
 // + the pre-drawn exploration noise of a multi-step launch: 4 envs x nsteps x 4 components x (z, coin, uniform) doubles
@@ -62,10 +65,17 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       const int i = idx / tot, k = idx - i * tot;
       const int64_t r = x.r0 + i;
       float v;
-      if (k < a.dimo) v = fclip(a.o[r * a.ldo + k], -c, c);
-      else if (k < Sa) v = a.td[r * a.ldtd + (k - a.dimo)];
-      else if (k < Sc) v = 0.f;
-      else v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+      if (k < a.dimo) {
+        v = fclip(a.o[r * a.ldo + k], -c, c);
+        if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[k]), a.o_std[k]), -a.nclip, a.nclip);     // actor_critic.py:76-83
+      } else if (k < Sa) {
+        v = a.td[r * a.ldtd + (k - a.dimo)];
+      } else if (k < Sc) {
+        v = 0.f;
+      } else {
+        v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+        if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - Sc]), a.g_std[k - Sc]), -a.nclip, a.nclip);
+      }
       x.xin[i * XLD + k] = v;
     }
   }

@@ -502,17 +502,32 @@ def test_policy_forward_random_shapes_vs_oracle(ops, case):
     m64 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, 0.98, 50., True, 1.0, True, np.float64)
     m32 = DDPGMath(dimo, G, 4, nb, hidden, layers, max_u, 0.98, 50., True, 1.0, True, np.float32)
     theta = m32.init(rs)
-    ncfg = ops.make_net_cfg(dimo, G, 4, nb, hidden, layers, True, max_u, 0.98, 50., 1.0)
+    norm = case % 3 == 1                                             # --normalize_obs (actor_critic.py:76-83)
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, hidden, layers, True, max_u, 0.98, 50., 1.0, normalize_obs=norm,
+                            norm_clip=5.0)
     o = (rs.randn(n, dimo) * 3).astype(np.float32)
     g = rs.randn(n, G).astype(np.float32)
     ag = rs.randn(n, G).astype(np.float32)
     td = np.eye(nb, dtype=np.float32)[rs.randint(nb, size=n)]
+    stats = {}
+    if norm:
+        for key, d in (('o', dimo), ('g', G)):
+            mean, std = (rs.randn(d) * 0.3).astype(np.float32), (0.5 + rs.rand(d)).astype(np.float32)
+            st = np.zeros(4 * d + 1, np.float32)
+            st[2 * d] = 1
+            st[2 * d + 1:3 * d + 1] = mean
+            st[3 * d + 1:] = std
+            stats[key] = (mean, std, dev(st))
     ws = torch.zeros(ops.workspace_floats(ncfg, n), device='cuda')
     pi = torch.full([n, 4], float('nan'), device='cuda')
     Q = torch.full([n, 1], float('nan'), device='cuda')
-    ops.policy_forward(ncfg, dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), n, clip, ws, pi, Q, ag=dev(ag))
+    ops.policy_forward(ncfg, dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), n, clip, ws, pi, Q, ag=dev(ag),
+                       o_stats=stats['o'][2] if norm else None, g_stats=stats['g'][2] if norm else None)
     torch.cuda.synchronize()
     oc, gc = preprocess_og(o, ag, g, clip)
+    if norm:
+        oc = np.clip((oc.astype(np.float32) - stats['o'][0]) / stats['o'][1], -5, 5)
+        gc = np.clip((gc.astype(np.float32) - stats['g'][0]) / stats['g'][1], -5, 5)
     Qp, pip = m64.split(theta.astype(np.float64))
     want_pi, _, _ = m64.actor(pip, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64))
     want_Q, _ = m64.critic(Qp, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64), want_pi / max_u)
