@@ -439,6 +439,7 @@ static RowsNet rows_net(const float* th, const NetOff& o, int nl) {
 
 // with_stats: the caller can hand the normalisers' statistics to the kernel (the plain forward; the fused acting entry
 // points carry none)
+// relative: goals relative to the achieved goal, which only the plain forward can compute (it is handed ag)
 static bool act_rows_ok(const curious_net_cfg_t* c, int n, bool relative, const float* theta, bool with_stats = false) {
   return rows_enabled() && c->modular && c->layers >= 2 && c->layers <= ROWS_MAXL && c->hidden == 256 && c->dimu == 4 &&
          (n % ROWS_R == 0) && (!c->normalize_obs || with_stats) && !relative && c->dimo + c->dimtd + 4 + c->dimg <= ROWS_MAXIN &&
@@ -528,7 +529,7 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
   NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
   const int H = cfg->hidden, nl = cfg->layers;
   const float* thPi = theta + pi_offset(cfg);
-  if (act_rows_ok(cfg, n, relative_goals != 0, theta, o_stats && g_stats) && aligned16(thPi)) {
+  if (act_rows_ok(cfg, n, relative_goals != 0 && !ag, theta, o_stats && g_stats) && aligned16(thPi)) {
     ActRowsArgs a;
     memset(&a, 0, sizeof(a));
     if (cfg->normalize_obs) {
@@ -538,6 +539,7 @@ extern "C" int curious_policy_forward(const curious_net_cfg_t* cfg, const float*
       a.o_mean = st_in.o_mean; a.o_std = st_in.o_std; a.g_mean = st_in.g_mean; a.g_std = st_in.g_std;
       a.nclip = st_in.nclip;
     }
+    if (relative_goals) { a.ag = ag; a.ldag = ldag; }
     a.pi = rows_net(thPi, offPi, nl); a.q = rows_net(theta, offQ, nl);
     a.o = o; a.td = td; a.g = g; a.ldo = ldo; a.ldtd = ldtd; a.ldg = ldg; a.clip = clip_obs;
     a.n = n; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg; a.max_u = cfg->max_u;

@@ -32,6 +32,8 @@ struct ActRowsArgs {
   // input normalisation (plain forward only: the fused entry points carry no statistics): mean / std or NULL
   const float *o_mean, *o_std, *g_mean, *g_std;
   float nclip;
+  // relative goals (ddpg.py:119-124, plain forward only): g - ag before the clip, or NULL
+  const float* ag; int32_t ldag;
 };
 
 // + the pre-drawn exploration noise of a multi-step launch: 4 envs x nsteps x 4 components x (z, coin, uniform) doubles
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       } else if (k < Sc) {
         v = 0.f;
       } else {
-        v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+        v = a.g[r * a.ldg + (k - Sc)];
+        if (a.ag) v = __fsub_rn(v, a.ag[r * a.ldag + (k - Sc)]);
+        v = fclip(v, -c, c);
         if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - Sc]), a.g_std[k - Sc]), -a.nclip, a.nclip);
       }
       x.xin[i * XLD + k] = v;

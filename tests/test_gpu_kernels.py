@@ -521,10 +521,12 @@ def test_policy_forward_random_shapes_vs_oracle(ops, case):
     ws = torch.zeros(ops.workspace_floats(ncfg, n), device='cuda')
     pi = torch.full([n, 4], float('nan'), device='cuda')
     Q = torch.full([n, 1], float('nan'), device='cuda')
+    relative = case % 4 == 2                                         # relative_goals (ddpg.py:119-124)
     ops.policy_forward(ncfg, dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), n, clip, ws, pi, Q, ag=dev(ag),
-                       o_stats=stats['o'][2] if norm else None, g_stats=stats['g'][2] if norm else None)
+                       relative_goals=relative, o_stats=stats['o'][2] if norm else None,
+                       g_stats=stats['g'][2] if norm else None)
     torch.cuda.synchronize()
-    oc, gc = preprocess_og(o, ag, g, clip)
+    oc, gc = preprocess_og(o, ag, g, clip, relative)
     if norm:
         oc = np.clip((oc.astype(np.float32) - stats['o'][0]) / stats['o'][1], -5, 5)
         gc = np.clip((gc.astype(np.float32) - stats['g'][0]) / stats['g'][1], -5, 5)
