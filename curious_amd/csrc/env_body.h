@@ -45,13 +45,18 @@ __device__ inline EnvConsts env_consts(const curious_env_cfg_t& E, const curious
 // v: o[e][lane] before the step (lanes >= dimo: ignored).  Returns o[e][lane] after the step.
 // STORE = false: the step is computed (return value, `next_in`) but nothing is written to global memory -- the members of
 // a workgroup group that step the same envs redundantly (mlp_rows_res.h) leave the stores to one of them.
+// what the policy's input normalisation does to an observation entry on its way into the next step's input row
+// (actor_critic.py:76-83); mean == NULL: nothing
+struct InNorm { const float* mean; const float* stdv; float nclip; };
+
 template <bool STORE = true>
 __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_layout_t& L, int32_t env_id0,
                                       const EnvConsts& C, const float* ue /* the env's 4 action values (global or LDS) */,
                                       int32_t t, const float v, float* __restrict__ o, float* __restrict__ ag,
                                       float* __restrict__ staging, int32_t off_change, int32_t off_success,
                                       double reward_eps, const int e, const int lane, float* __restrict__ flags,
-                                      const int n, float* next_in, const float in_clip) {
+                                      const int n, float* next_in, const float in_clip,
+                                      const InNorm nrm = InNorm{nullptr, nullptr, 0.f}) {
   const int AG = 3 * E.ntasks;
   float* oe = o + (int64_t)e * E.dimo;
   float* ep0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
@@ -93,7 +98,11 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
     } else if (i == AG + 3) {
       nv = uc[3];
     }
-    if (next_in) next_in[i] = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
+    if (next_in) {
+      float w = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
+      if (nrm.mean) w = fclip(fdiv(__fsub_rn(w, nrm.mean[i]), nrm.stdv[i]), -nrm.nclip, nrm.nclip);
+      next_in[i] = w;
+    }
   }
   if (STORE && i < E.dimo) {
     oe[i] = nv;

@@ -579,12 +579,14 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
                                 const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                                 const int32_t* episode, const int32_t* tasks, int32_t t, int32_t nsteps, float* o,
                                 float* ag, const float* g, const float* td, float* staging, int32_t off_change,
-                                int32_t off_success, double reward_eps, float* flags, curious_stream_t stream) {
+                                int32_t off_success, double reward_eps, float* flags, curious_stream_t stream,
+                                const float* o_stats = nullptr, const float* g_stats = nullptr) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
                 "curious_policy_act_env_step: NULL argument");
-  CURIOUS_CHECK(!cfg->normalize_obs && cfg->modular, "curious_policy_act_env_step: modular nets without input "
-                                                     "normalisation only (use curious_policy_forward otherwise)");
+  CURIOUS_CHECK(cfg->modular, "curious_policy_act_env_step: modular nets only (use curious_policy_forward otherwise)");
+  CURIOUS_CHECK(!cfg->normalize_obs || (o_stats && g_stats),
+                "curious_policy_act_env_step: input normalisation needs the statistics (curious_policy_*_stats)");
   CURIOUS_CHECK(cfg->dimu == 4 && L->dimu == 4 && cfg->dimo == E->dimo && cfg->dimtd == E->ntasks &&
                     cfg->dimg == 3 * E->ntasks, "curious_policy_act_env_step: network / env dimensions differ");
   CURIOUS_CHECK(t >= 0 && nsteps >= 1 && t + nsteps <= L->T, "curious_policy_act_env_step: t out of range");
@@ -595,9 +597,13 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   NetOff offPi = net_off(cfg, false);
   const int H = cfg->hidden, nl = cfg->layers;
   const float* thPi = theta + pi_offset(cfg);
-  if (act_rows_ok(cfg, n, false, theta) && aligned16(thPi)) {
+  ObsIn st_in;
+  memset(&st_in, 0, sizeof(st_in));
+  fill_obs_stats(cfg, st_in, o_stats, g_stats);
+  if (act_rows_ok(cfg, n, false, theta, true) && aligned16(thPi)) {
     ActRowsArgs a;
     memset(&a, 0, sizeof(a));
+    a.o_mean = st_in.o_mean; a.o_std = st_in.o_std; a.g_mean = st_in.g_mean; a.g_std = st_in.g_std; a.nclip = st_in.nclip;
     a.pi = rows_net(thPi, offPi, nl);
     a.o = o; a.td = td; a.g = g; a.ldo = E->dimo; a.ldtd = E->ntasks; a.ldg = 3 * E->ntasks; a.clip = clip_obs;
     a.n = n; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg; a.max_u = cfg->max_u;
@@ -618,7 +624,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     for (int s = 0; s < nsteps; ++s) {
       const int rc = policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter + s,
                                           counter_base, u_out, ldu, E, L, env_id0, episode, tasks, t + s, 1, o, ag, g, td,
-                                          staging, off_change, off_success, reward_eps, flags, stream);
+                                          staging, off_change, off_success, reward_eps, flags, stream, o_stats, g_stats);
       if (rc) return rc;
     }
     return 0;
@@ -627,6 +633,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   memset(&in, 0, sizeof(in));
   in.o = o; in.ldo = E->dimo; in.td = td; in.ldtd = E->ntasks; in.g = g; in.ldg = 3 * E->ntasks;
   in.clip = clip_obs;
+  fill_obs_stats(cfg, in, o_stats, g_stats);
   Chain a;
   a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
   // output layer as a dot epilogue of the last hidden layer when that layer runs on the lean kernel
@@ -676,6 +683,34 @@ extern "C" int curious_policy_rollout(const curious_net_cfg_t* cfg, const float*
   return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
                               u_out, ldu, E, L, env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, off_change,
                               off_success, reward_eps, flags, stream);
+}
+
+extern "C" int curious_policy_act_env_step_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n,
+                                                 float clip_obs, float* workspace, double noise_scale, double random_eps,
+                                                 uint64_t seed, uint64_t counter, const int64_t* counter_base,
+                                                 float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                                                 const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
+                                                 const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
+                                                 const float* td, float* staging, int32_t off_change,
+                                                 int32_t off_success, double reward_eps, float* flags,
+                                                 const float* o_stats, const float* g_stats, curious_stream_t stream) {
+  return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
+                              u_out, ldu, E, L, env_id0, episode, tasks, t, 1, o, ag, g, td, staging, off_change,
+                              off_success, reward_eps, flags, stream, o_stats, g_stats);
+}
+
+extern "C" int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                            float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                            uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                            const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                            const int32_t* episode, const int32_t* tasks, int32_t t0, int32_t nsteps,
+                                            float* o, float* ag, const float* g, const float* td, float* staging,
+                                            int32_t off_change, int32_t off_success, double reward_eps, float* flags,
+                                            const float* o_stats, const float* g_stats, curious_stream_t stream) {
+  CURIOUS_CHECK(nsteps >= 1, "curious_policy_rollout: nsteps must be positive");
+  return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
+                              u_out, ldu, E, L, env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, off_change,
+                              off_success, reward_eps, flags, stream, o_stats, g_stats);
 }
 
 // What follows the gradients in curious_ddpg_update: Adam (+ the gather of the next batch).

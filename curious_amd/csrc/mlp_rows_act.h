@@ -29,7 +29,7 @@ struct ActRowsArgs {
   double reward_eps;
   float* flags;                                   // optional rollout flags (env_step_body)
   int32_t noise_lds;                              // != 0: the launch has the LDS area for pre-drawn noise
-  // input normalisation (plain forward only: the fused entry points carry no statistics): mean / std or NULL
+  // input normalisation (curious_policy_forward, curious_policy_*_stats): mean / std of the normalisers or NULL
   const float *o_mean, *o_std, *g_mean, *g_std;
   float nclip;
   // relative goals (ddpg.py:119-124, plain forward only): g - ag before the clip, or NULL
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       ov = env_step_core(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
                          a.off_success, a.reward_eps, m, x.lane, a.flags, a.n,
-                         (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip);
+                         (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip,
+                         InNorm{a.o_mean, a.o_std, a.nclip});
     }
     return;
   }

@@ -147,10 +147,17 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       const int i = idx / tot, k = idx - i * tot;
       const int64_t r = x.r0 + i;
       float v;
-      if (k < a.dimo) v = fclip(a.o[r * a.ldo + k], -c, c);
-      else if (k < Sa) v = a.td[r * a.ldtd + (k - a.dimo)];
-      else if (k < Sc) v = 0.f;
-      else v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+      if (k < a.dimo) {
+        v = fclip(a.o[r * a.ldo + k], -c, c);
+        if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[k]), a.o_std[k]), -a.nclip, a.nclip);     // actor_critic.py:76-83
+      } else if (k < Sa) {
+        v = a.td[r * a.ldtd + (k - a.dimo)];
+      } else if (k < Sc) {
+        v = 0.f;
+      } else {
+        v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+        if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - Sc]), a.g_std[k - Sc]), -a.nclip, a.nclip);
+      }
       x.xin[i * XLD + k] = v;
     }
   }
@@ -246,10 +253,12 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     float* nin = (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr;
     if (member == 0)
       ov = env_step_core<true>(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
-                               a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip);
+                               a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip,
+                               InNorm{a.o_mean, a.o_std, a.nclip});
     else
       ov = env_step_core<false>(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
-                                a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip);
+                                a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip,
+                               InNorm{a.o_mean, a.o_std, a.nclip});
     RES_STAMP(6);
     if (rx.stamps && blockIdx.x == 0 && x.tid == 0) rx.stamps[7] += 1;
   }

@@ -281,7 +281,7 @@ class DDPG(object):
 
     def can_act_and_step(self, env, compute_Q):
         """The fused acting step applies to the GPU-resident synthetic env in throughput mode."""
-        return (self.rng_mode == 'device' and not compute_Q and self.modular and not self.normalize_obs
+        return (self.rng_mode == 'device' and not compute_Q and self.modular
                 and not self.relative_goals and self.dimu == 4 and hasattr(env, 'step_all')
                 and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
 
@@ -301,7 +301,9 @@ class DDPG(object):
         ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
                                 self.seed * 2654435761 + 12345 + dist.rank() * 1000003, self._noise_counter,
                                 self._act_u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, t, env.o,
-                                env.ag, env.g, env.td, env.staging, REWARD_EPS, flags=getattr(env, 'flags', None))
+                                env.ag, env.g, env.td, env.staging, REWARD_EPS, flags=getattr(env, 'flags', None),
+                                o_stats=self.o_stats.state if self.normalize_obs else None,
+                                g_stats=self.g_stats.state if self.normalize_obs else None)
         return self._act_u
 
     def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
@@ -337,7 +339,9 @@ class DDPG(object):
             ops.policy_rollout(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps, seed, 1,
                                u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T, env.o, env.ag,
                                env.g, env.td, env.staging, REWARD_EPS, counter_base=self._noise_base,
-                               flags=getattr(env, 'flags', None))
+                               flags=getattr(env, 'flags', None),
+                               o_stats=self.o_stats.state if self.normalize_obs else None,
+                               g_stats=self.g_stats.state if self.normalize_obs else None)
             ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T

@@ -238,10 +238,13 @@ def test_launch_runs_every_structure_and_logs_the_reference_columns(tmp_path, st
 @pytest.mark.parametrize('env_name,nb,dimo,B', [('MultiTaskFetchArm4-v5', 4, 40, 48),
                                                  ('MultiTaskFetchArm8-v5', 8, 52, 48),
                                                  ('MultiTaskFetchArm8-v5', 8, 52, 37)])
-def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B, route):
+@pytest.mark.parametrize('normalize', [False, True])
+def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B, normalize, route):
     """curious_policy_act_env_step == get_actions + env.step_all, bit for bit, eager and as a replayed hipGraph, on both
     env sizes and both routes: `rows` = policy_rows_kernel when B % 4 == 0 (generic kernels for B = 37); `tiled` =
-    fwd_l01<1|2> + fwd_hot<DOT> + act_step<PART> when B % 16 == 0, generic kernels otherwise."""
+    fwd_l01<1|2> + fwd_hot<DOT> + act_step<PART> when B % 16 == 0, generic kernels otherwise.  normalize: networks with
+    input normalisation (--normalize_obs) -- the fused entry points then take the normalisers' statistics
+    (curious_policy_*_stats) and apply them to every observation the env step hands to the next acting step."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker
     from curious_amd import logger
@@ -249,7 +252,13 @@ def test_fused_acting_equals_unfused_lean_and_generic(env_name, nb, dimo, B, rou
     dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
     recs = []
     for mode in ('fused_graph', 'fused_eager', 'unfused'):
-        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=(mode == 'fused_graph'))
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=(mode == 'fused_graph'), normalize_obs=normalize)
+        if normalize:                                                # statistics that really move and scale the inputs
+            rs = np.random.RandomState(31)
+            for nz in (agent.o_stats, agent.g_stats):
+                d = nz.size
+                nz.state[2 * d + 1:3 * d + 1] = torch.from_numpy((rs.randn(d) * 0.2).astype(np.float32)).cuda()
+                nz.state[3 * d + 1:] = torch.from_numpy((0.3 + rs.rand(d)).astype(np.float32)).cuda()
         if mode == 'unfused':
             agent.can_act_and_step = lambda env, compute_Q: False
         w = RolloutWorker(EnvFactory(env_name), agent, dims, logger, T=T, rollout_batch_size=B, noise_eps=0.2,
@@ -646,9 +655,18 @@ def test_rollout_entry_point_random_sizes(case, monkeypatch):
     B = int(rs0.choice([4, 8, 12, 30, 37, 100, 252, 256, 260, 300]))
     layers = int(rs0.choice([2, 3, 3, 4]))
     noise, reps = [(0.2, 0.3), (0.0, 0.0), (0.05, 1.0)][int(rs0.randint(0, 3))]
+    normalize = bool(rs0.randint(0, 2))
     outs = []
     for mode in ('rollout', 'steps'):
-        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, layers=layers)
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=False, layers=layers, normalize_obs=normalize)
+        stats = {}
+        if normalize:
+            rs1 = np.random.RandomState(77 + case)
+            for nz in (agent.o_stats, agent.g_stats):
+                d = nz.size
+                nz.state[2 * d + 1:3 * d + 1] = torch.from_numpy((rs1.randn(d) * 0.2).astype(np.float32)).cuda()
+                nz.state[3 * d + 1:] = torch.from_numpy((0.3 + rs1.rand(d)).astype(np.float32)).cuda()
+            stats = dict(o_stats=agent.o_stats.state, g_stats=agent.g_stats.state)
         env = EnvFactory(env_name).make_batched(B)
         env.seed(11 + case)
         rs = np.random.RandomState(3)
@@ -661,16 +679,16 @@ def test_rollout_entry_point_random_sizes(case, monkeypatch):
             tail = (env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS)
             if mode == 'rollout':
                 ops.policy_rollout(*args, 1 + ep * T, u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T,
-                                   *tail, flags=env.flags)
+                                   *tail, flags=env.flags, **stats)
             else:
                 for t in range(T):
                     ops.policy_act_env_step(*args, 1 + ep * T + t, u, env._cfg, env.layout, env.env_id0, env.episode,
-                                            env.tasks, t, *tail, flags=env.flags)
+                                            env.tasks, t, *tail, flags=env.flags, **stats)
             torch.cuda.synchronize()
             assert float(env.flags[B]) == 0.0                        # neither a NaN word nor a member that gave up (2)
             recs.append((env.staging.clone(), u.clone(), env.flags.clone(), env.o.clone(), env.ag.clone()))
         outs.append(recs)
-    tag = 'case %d: %s B %d layers %d noise %s' % (case, env_name, B, layers, (noise, reps))
+    tag = 'case %d: %s B %d layers %d noise %s normalize %s' % (case, env_name, B, layers, (noise, reps), normalize)
     for a, b in zip(outs[0], outs[1]):
         for x, y in zip(a, b):
             assert torch.equal(x, y), tag
