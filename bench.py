@@ -263,12 +263,16 @@ def profile_pass(policy, worker, n_cycles=1):
     return stats, overhead_ms, t_plain / N_BATCHES
 
 
+def pmc_traffic_file():
+    return next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic.json' % r) for r in (4, 3, 2, 1))
+                 if os.path.exists(p)), '')
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
     the bytes of 16-byte-per-lane streaming reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  None if absent."""
-    path = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic.json' % r) for r in (3, 2, 1))
-                 if os.path.exists(p)), '')
+    path = pmc_traffic_file()
     try:
         with open(path) as f:
             table = json.load(f)
@@ -308,7 +312,12 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms):
     else:
         ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
     out = dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
-               frac=round(ach / peak, 5), traffic=pmc_traffic(dominant), algorithmic_per_launch=round(per_launch, 1),
+               frac=round(ach / peak, 5), traffic=pmc_traffic(dominant),
+               # PMC counters cannot be read from inside the process: the figure comes from the committed rocprofv3 --pmc
+               # passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not from this run
+               traffic_source='%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, committed; not '
+                              'measured in this run)' % os.path.relpath(pmc_traffic_file() or 'none', ROOT),
+               algorithmic_per_launch=round(per_launch, 1),
                avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3))
     if 'l2_stream_bytes' in w:
         # the resource that actually bounds this kernel: weight bytes streamed L2 -> CU (each CU's fill path), against the
@@ -511,6 +520,71 @@ def cpu_baseline_ranks(n_ranks, budget_s=12.0):
                        'in place of MPI), %.1f s' % (rec['cycles'], n_ranks, total))
 
 
+def collective_report(policy, policies):
+    """What a several-rank line needs to be read on its own (SCALE runs): the gradient all-reduce timed alone (a chain
+    of 100 all-reduces of the fused [P] float32 vector, replayed from one hipGraph when the update graphs capture their
+    collective too, eager otherwise), the communicator's settings as this process saw them, and the agreement of the
+    replicas (128-bit parameter checksums of all ranks, mpi_adam.py:42-50)."""
+    import torch
+    import torch.distributed as td
+    from curious_amd import dist
+    world, backend = dist.world_size(), td.get_backend()
+    captured = bool(dist.captured_allreduce_ok())
+    n_chain = 100
+    buf = torch.zeros_like(policy.grad)
+    torch.cuda.synchronize()
+    dist.barrier()
+
+    def chain():
+        for _ in range(n_chain):
+            td.all_reduce(buf)
+    graph = None
+    if captured:
+        chain()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            chain()
+    run = graph.replay if graph is not None else chain
+    run()                                                          # warm
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_us = e0.elapsed_time(e1) * 1e3 / (reps * n_chain)
+    t = torch.tensor([dev_us, wall * 1e6 / (reps * n_chain)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    del graph
+    # replicas: every rank's checksum of every policy, gathered
+    sums = []
+    for pol in policies:
+        pol._check_synced(wait=True)                               # raises RankDivergence on a mismatch with rank 0
+        sums.append(pol._sync_buf[0].clone())
+    mine = torch.stack(sums).reshape(1, -1)
+    allsums = dist.allgather(mine) if world > 1 else mine
+    identical = bool((allsums == allsums[:1]).all())
+    try:
+        ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return dict(allreduce_us=round(float(t[0]), 3), allreduce_host_us=round(float(t[1]), 3),
+                allreduce_bytes=int(buf.numel() * 4), allreduce_chain=n_chain,
+                rccl=dict(backend=backend, world=world, captured=captured, version=ver,
+                          env={k: os.environ.get(k) for k in ('NCCL_PROTO', 'NCCL_ALGO', 'NCCL_MIN_NCHANNELS',
+                                                              'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE',
+                                                              'HSA_ENABLE_IPC_MODE_LEGACY', 'CURIOUS_GRAPH_ALLREDUCE',
+                                                              'CURIOUS_ALLREDUCE')}),
+                replicas_identical=identical, replica_checksums=[[int(x) for x in row] for row in allsums.cpu()])
+
+
 def teardown(policies, bank=None):
     """Captured graphs hold the communicator's streams: drop them before the process group goes, then leave through the
     normal interpreter exit (curious_amd.experiment.train.shutdown)."""
@@ -599,6 +673,10 @@ def main():
         stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles)
         roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms)
 
+    coll = None
+    if dist.is_distributed():
+        coll = collective_report(policy, list(bank) if experts else [policy])
+
     if rank == 0:
         T = params['T']
         n_pol = len(bank) if experts else 1
@@ -634,6 +712,8 @@ def main():
                          'frac': round(args.steps * N_BATCHES * BATCH * n_pol / elapsed * 47213 / 1e9 / HBM_PEAK_GBS, 5)},
             'kernels': table,
         }
+        if coll is not None:
+            out['collectives'] = coll
         if phases:
             out['phases'] = phases
         if cpu is not None:
