@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 6          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 7          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -70,7 +70,7 @@ class AdamState(C.Structure):
 
 class Transposed(C.Structure):
     _fields_ = [('n', C.c_int32), ('dim', C.c_int32), ('src_off', C.c_int64 * 8), ('dst', C.c_void_p * 8),
-                ('fault', C.c_void_p)]
+                ('fault', C.c_void_p), ('fault_flag', C.c_int64)]
 
 
 class NextBatch(C.Structure):

@@ -161,6 +161,7 @@ extern "C" int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, 
   memset(out, 0, sizeof(*out));
   const Ws w = carve(cfg, B, workspace);
   out->fault = w.fault;
+  out->fault_flag = pi_offset(cfg);                          // 1 + (offset of theta_pi - 1): always padding (P_Q % 4 == 1)
   if (cfg->hidden != 256 || cfg->layers < 2 || 2 * (cfg->layers - 1) > 8) return 0;    // nothing is kept for this shape
   const NetOff offQ = net_off(cfg, true), offPi = net_off(cfg, false);
   out->dim = cfg->hidden;
@@ -459,28 +460,39 @@ static int device_cu_count() {
 
 // Multi-step rollouts with the hidden matrices resident in LDS (mlp_rows_res.h): 4 workgroups per 4 envs that spin on
 // each other, so every workgroup of the launch must be resident at once -- one per CU (157 KB of LDS each).
+// The kernel needs more dynamic LDS than the 64 KB default: the device must have it and the attribute call must succeed
+// (checked once per process; a device or partition without 160 KB of LDS per workgroup takes the streaming kernel).
+static bool resident_lds_ok() {
+  static int ok = -1;
+  if (ok < 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    const size_t need = res_lds_floats(3) * sizeof(float);
+    ok = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        (size_t)prop.maxSharedMemoryPerMultiProcessor >= need) {
+      ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_resident_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    }
+    (void)hipGetLastError();
+  }
+  return ok == 1;
+}
 static bool resident_ok(const ActRowsArgs& a, int n, const float* workspace) {
   return curious_options().resident && a.fused && a.nsteps >= 4 && (a.nl == 2 || a.nl == 3) && n >= 4 &&
-         n <= device_cu_count() && workspace != nullptr;
+         n <= device_cu_count() && workspace != nullptr && resident_lds_ok();
 }
 
-static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, hipStream_t st) {
+static int launch_policy_resident(ActRowsArgs& a, int n, float* workspace, int64_t ws_floats, hipStream_t st) {
   ResX rx;
   rx.xbuf = reinterpret_cast<unsigned long long*>(workspace);
   rx.xmap = (n % 32 == 0) ? 1 : 0;
   rx.spins = curious_options().res_spins;
   rx.inject = curious_options().fault_inject;
-  // lab: per-phase cycle stamps of block 0 behind the exchange buffer (the workspace has room: checked by the caller)
-  rx.stamps = curious_options().lab_res_stamps
+  // lab: per-phase cycle stamps of block 0 (8 x 64 bit) behind the exchange buffer, when the workspace has room for them
+  rx.stamps = (curious_options().lab_res_stamps && (int64_t)res_xbuf_floats(n) + 16 <= ws_floats)
                   ? reinterpret_cast<unsigned long long*>(workspace + res_xbuf_floats(n)) : nullptr;
   const size_t lds = res_lds_floats(a.nl) * sizeof(float);
-  static bool lds_set = false;
-  if (!lds_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_resident_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    lds_set = true;
-  }
   { ProfScope ps__(CK_ACT_RES, st);
     hipLaunchKernelGGL(policy_resident_kernel, dim3(n), dim3(256), lds, st, a, rx); }
   CURIOUS_LAUNCH_CHECK("policy_resident_kernel");
@@ -492,13 +504,17 @@ static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
   size_t lds = act_rows_lds_floats(nsteps) * sizeof(float);
   a.noise_lds = (nsteps > 1 && lds <= 150 * 1024) ? 1 : 0;
   if (!a.noise_lds) lds = act_rows_lds_floats(1) * sizeof(float);
-  static bool lds_set = false;
-  if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_rows_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static int lds_big = -1;
+  if (lds_big < 0) {                                         // > 64 KB of dynamic LDS has to be allowed once per kernel
+    lds_big = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_rows_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     (void)hipGetLastError();
-    lds_set = true;
   }
+  if (!lds_big && lds > 64 * 1024) {                         // refused: the per-step noise form fits the default limit
+    a.noise_lds = 0;
+    lds = act_rows_lds_floats(1) * sizeof(float);
+  }
+  CURIOUS_CHECK(lds_big || lds <= 64 * 1024, "policy_rows_kernel: the device refused %zu bytes of dynamic LDS", lds);
   { ProfScope ps__(CK_ACT_ROWS, st);
     hipLaunchKernelGGL(policy_rows_kernel, dim3(n / ROWS_R), dim3(256), lds, st, a); }
   CURIOUS_LAUNCH_CHECK("policy_rows_kernel");
@@ -617,7 +633,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     // the exchange buffer of the resident form is the head of the workspace (the row-local routes use nothing else of it)
     if (resident_ok(a, n, workspace) &&
         (int64_t)res_xbuf_floats(n) <= curious_workspace_floats(cfg, n) && aligned16(workspace))
-      return launch_policy_resident(a, n, workspace, st);
+      return launch_policy_resident(a, n, workspace, curious_workspace_floats(cfg, n), st);
     return launch_policy_rows(a, n, st);
   }
   if (nsteps > 1) {
@@ -1155,6 +1171,9 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   LossFin fin;
   fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
   fin.step_ctr = gather_in_rows ? step_ctr : nullptr;
+  // gradients only (the all-reduce of several ranks follows): the fault word rides along as a padding element
+  fin.fault = tail ? nullptr : w.fault;
+  fin.flag = tail ? nullptr : grad + pi_offset(cfg) - 1;
   auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
     int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
     bool ok = true;

@@ -62,7 +62,12 @@ struct LossFin {         // final, fixed-order reduction of the per-row loss ter
   float action_l2;
   int64_t* step_ctr;     // non-NULL: the update's increment of the step counter happens HERE (deferred from the gradient
                          // launch, whose gather blocks read the counter: mlp_rows.h)
+  const int32_t* fault;  // gradients-only calls (several ranks): the workspace's fault word and the padding element of the
+  float* flag;           // gradient vector that carries it through the all-reduce (curious_transposed_t.fault_flag), or NULL
 };
+__device__ inline void loss_fin_flag(const LossFin& F, const int64_t eo, const int64_t eg) {
+  if (F.flag) F.flag[eg] = (*reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(F.fault) + eo) != 0) ? 1.0f : 0.0f;
+}
 struct DwArgs { DwProb p[MAX_DW]; int32_t nprob; LossFin fin; };
 
 // ================================================================== one-launch update (mlp_step.h ddpg_step_kernel)

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
     if (tid == 0) {
       const float invB = 1.0f / (float)F.B;
       if (F.step_ctr) *F.step_ctr += 1;
+      loss_fin_flag(F, 0, 0);
       F.out[0] = red[0] * invB;
       F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
     }

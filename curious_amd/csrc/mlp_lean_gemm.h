@@ -462,7 +462,7 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
 }
 
 // losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
-__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const StepSync* S) {
+__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const int64_t eg, const StepSync* S) {
   const int tid = threadIdx.x;
   {
     if (S && !step_wait(*S, 5u)) return;
@@ -492,6 +492,7 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
     if (tid == 0) {
       const float invB = 1.0f / (float)F.B;
       if (F.step_ctr) *ex_i64(F.step_ctr, eo) += 1;
+      loss_fin_flag(F, eo, eg);
       F.out[eo + 0] = red[0] * invB;
       F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
     }
@@ -506,7 +507,7 @@ __device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A,
   const int pi = bid / args.slots, t = bid - pi * args.slots;
   if (pi >= args.nprob) {
     // extra last block (only launched when fin.rows != NULL)
-    dw_loss_fin(args.fin, red, eo, S);
+    dw_loss_fin(args.fin, red, eo, eg, S);
     return;
   }
   const DwSmall& P = args.p[pi];

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ddpg_step_kernel(RowsArgs a, Ex ex, DwAll
     }
     if (i < plan.hot_a) dw_hot_body<true>(args.hot, A, plan.hot_c + i, rows_lds, 0, 0, &S);
     else if (i < nA - 1) dw_small_item<true>(args.small, A, plan.small_c + (i - plan.hot_a), rows_lds, 0, 0, &S);
-    else dw_loss_fin(args.small.fin, rows_lds, 0, &S);
+    else dw_loss_fin(args.small.fin, rows_lds, 0, 0, &S);
     if (S.st && threadIdx.x == 0) S.st[4] = __builtin_readcyclecounter();
     S.st = nullptr;
   }

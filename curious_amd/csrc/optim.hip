@@ -28,8 +28,18 @@ struct AdamArgs {
 __device__ __forceinline__ const int64_t* opt_i64(const int64_t* p, int64_t eo) {
   return reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(p) + eo);
 }
-__device__ __forceinline__ bool adam_faulted(const AdamArgs& a, const int64_t eo) {
-  return a.keep.fault && *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(a.keep.fault) + eo) != 0;
+// The optimiser leaves everything alone while the fault word of the gradient workspace is non-zero -- or, on several
+// ranks, while ANY rank's was when the gradients were produced: that rank's flag element came through the all-reduce with
+// the gradients (curious_transposed_t.fault_flag).  The decision is the same on every rank, so the replicas stay identical;
+// one thread per agent then raises the local word as well, which makes the freeze sticky and visible to this rank's host.
+__device__ __forceinline__ bool adam_faulted(const AdamArgs& a, const int64_t eo, const int64_t eg) {
+  if (!a.keep.fault) return false;
+  if (*reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(a.keep.fault) + eo) != 0) return true;
+  return a.keep.fault_flag > 0 && a.grad[eg + a.keep.fault_flag - 1] != 0.0f;
+}
+__device__ __forceinline__ void adam_note_fault(const AdamArgs& a, const int64_t eo, const int64_t eg) {
+  int32_t* word = const_cast<int32_t*>(reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(a.keep.fault) + eo));
+  if (a.keep.fault_flag > 0 && a.grad[eg + a.keep.fault_flag - 1] != 0.0f && *word == 0) atomicAdd(word, 1);
 }
 
 __device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi, const int64_t eo) {
@@ -64,7 +74,10 @@ typedef float f32x4_o __attribute__((ext_vector_type(4)));
 // layout of curious_param_total) -- one thread then takes 4 consecutive elements with 16-byte loads and stores
 __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks, const int64_t eo,
                                           const int64_t eg, const bool vec4) {
-  if (adam_faulted(a, eo)) return;
+  if (adam_faulted(a, eo, eg)) {
+    if (block == 0 && threadIdx.x == 0) adam_note_fault(a, eo, eg);
+    return;
+  }
   float aQ, aPi;
   adam_alphas(a, aQ, aPi, eo);
   const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
@@ -108,7 +121,7 @@ static inline bool adam_vec4(const AdamArgs& a, int64_t expert_stride, int64_t g
 #define ADAM_TILE 32
 __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1],
                                                const int64_t eo, const int64_t eg) {
-  if (adam_faulted(a, eo)) return;
+  if (adam_faulted(a, eo, eg)) return;
   float aQ, aPi;
   adam_alphas(a, aQ, aPi, eo);
   const int dim = a.keep.dim, per = dim / ADAM_TILE;
@@ -170,7 +183,7 @@ static int fill_adam(AdamArgs& a, float* theta, float* m, float* v, const float*
                      float epsilon, const curious_transposed_t* keep) {
   CURIOUS_CHECK(theta && m && v && grad, "curious_adam_update: NULL argument");
   memset(&a.keep, 0, sizeof(a.keep));
-  if (keep) a.keep.fault = keep->fault;
+  if (keep) { a.keep.fault = keep->fault; a.keep.fault_flag = keep->fault_flag; }
   if (keep && keep->n > 0) {
     CURIOUS_CHECK(keep->n <= 8 && keep->dim > 0 && keep->dim % ADAM_TILE == 0,
                   "curious_adam_update: bad description of the transposed copies");

@@ -361,6 +361,21 @@ class DDPG(object):
             self._roll_graphs[key] = g
         g.replay()
 
+    def rewind_rollout(self, env, T):
+        """Undo the bookkeeping of the act_rollout that was just enqueued for `env` so that the SAME rollout can be
+        generated again (same episode numbers -> same initial states, same noise counters -> same exploration noise):
+        used when the weights-resident launch reported itself void (envs.ResidentRolloutVoid) and the rollout is redone
+        on the streaming kernel, which computes the same numbers."""
+        self._noise_counter -= T
+        self._noise_base_val = self._noise_counter
+        self._noise_base.fill_(self._noise_counter)
+        env.episode.sub_(1)                                          # the reset advanced every env's episode counter
+
+    def drop_rollout_graphs(self):
+        """Forget the captured rollout launches (the route of curious_policy_rollout is chosen when it is captured)."""
+        if getattr(self, '_roll_graphs', None):
+            self._roll_graphs = {}
+
     def can_eval_rollout(self, env, noise_eps, random_eps):
         """Noise-free rollouts (evaluator, exploit) of the GPU-resident env can be replayed from one hipGraph: with both
         eps at 0 the result does not depend on the noise counter, so nothing host-side changes between replays."""
@@ -411,8 +426,13 @@ class DDPG(object):
     def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
         """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
         block produced by the batched RolloutWorker (ddpg.py:163-223)."""
-        self.settle()
+        self._store_episode(episode_batch, cp, n_ep, update_stats)
+        # verdict of an earlier fault-word copy that has arrived (no stall).  Raised AFTER the episodes are stored: a
+        # caller that catches HandoffFault and goes on has lost nothing of this call
         self.check_faults(wait=False)
+
+    def _store_episode(self, episode_batch, cp, n_ep, update_stats=True):
+        self.settle()
         self.cp = cp
         self.n_episodes = n_ep
         layout = self._layout
@@ -719,10 +739,11 @@ class DDPG(object):
         self.pi_adam.t += 1
         if use_table:
             ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
-                            alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base)
+                            alpha_tab=self._alpha_tab, step_ctr=self._step_ctr, tab_base=self._alpha_base,
+                            keep=self._fault_guard())
         else:
             ops.adam_update(self.theta, self._m, self._v, self.grad, self.off_pi, self.P_total - self.off_pi,
-                            self.Q_adam.alpha(self.Q_lr), self.pi_adam.alpha(self.pi_lr))
+                            self.Q_adam.alpha(self.Q_lr), self.pi_adam.alpha(self.pi_lr), keep=self._fault_guard())
 
     # ------------------------------------------------------------------ sampling
     def _proportions(self):
@@ -937,7 +958,17 @@ class DDPG(object):
         pos = (ts - 1) % n
         tab[pos, 0] = self.Q_adam.alpha_table(self.Q_lr, ts)
         tab[pos, 1] = self.pi_adam.alpha_table(self.pi_lr, ts)
-        self._alpha_tab.copy_(torch.from_numpy(tab))
+        # pinned + asynchronous: from pageable memory this H2D copy would block the host until the run of updates that
+        # was just enqueued has finished (_keep_alpha_ahead refills BEHIND a run).  Two pinned blocks alternate: the
+        # previous refill's copy was enqueued >= ALPHA_TAB - 2 * MAX_CHAIN updates ago
+        pins = getattr(self, '_alpha_pins', None)
+        if pins is None:
+            pins = self._alpha_pins = [torch.empty([n, 2], dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._alpha_pin_k = 0
+        pin = pins[self._alpha_pin_k]
+        self._alpha_pin_k ^= 1
+        pin.numpy()[:] = tab
+        self._alpha_tab.copy_(pin, non_blocking=True)
         self._alpha_base = 0
         self._alpha_filled = t0 + n
         self._step_ctr.fill_(t0)
@@ -994,6 +1025,32 @@ class DDPG(object):
                 k = min(n, MAX_CHAIN)                                # eager launches: one run, copies kept between updates
             out = self._train_device(k) if self._device_loop() else self.train()
             n -= k
+        return out
+
+    def train_batches_guarded(self, n):
+        """train_batches(n) with the hand-off guard read SYNCHRONOUSLY (the host waits for these n updates): when an
+        update of the run faulted, the parameters, moments and counters are put back to where the run started and the
+        run is replayed once -- same batches (the sampler is keyed by the step counter), same step sizes, so the job
+        ends bit-identical to one that never faulted.  A fault in the replay is raised.  The price is the host no longer
+        running ahead of the GPU across this call (experiment.train: --fault_check sync); the default (asynchronous)
+        form reads the verdict cycles later, keeps the job alive on the last good parameters and loses the frozen
+        updates.  With several ranks every rank sees the fault (collective flag) and every rank replays."""
+        snap = (self.theta.clone(), self._m.clone(), self._v.clone(), self._step_ctr.clone(), self.Q_adam.t,
+                self.pi_adam.t, self._alpha_filled)
+        out = self.train_batches(n)
+        try:
+            self.check_faults(wait=True)
+            return out
+        except HandoffFault as err:
+            import warnings
+            warnings.warn('%s -- replaying the %d updates of this run from the parameters it started with' % (err, n))
+        self.theta.copy_(snap[0]); self._m.copy_(snap[1]); self._v.copy_(snap[2]); self._step_ctr.copy_(snap[3])
+        self.Q_adam.t, self.pi_adam.t = snap[4], snap[5]
+        if self._alpha_filled != snap[6]:
+            self._alpha_filled = 0                                   # the ring was refilled past the run: fill it again
+        self._batch_stale = True                                     # the first batch of the run is drawn again
+        out = self.train_batches(n)
+        self.check_faults(wait=True)                                 # a repeat is raised
         return out
 
     def _train_ranks_pipelined(self, n):
@@ -1216,6 +1273,16 @@ class DDPG(object):
             self._kept = ops.ddpg_transposed(self.net_cfg, self.batch_size, self._workspace)
         return self._kept
 
+    def _fault_guard(self):
+        """The description of _kept_copies() without the copies: an optimiser call given it only honours the fault word of
+        the gradient workspace and the collective fault flag in the gradient vector (the one-at-a-time train() path)."""
+        if getattr(self, '_guard', None) is None:
+            g = _lib.Transposed()
+            k = self._kept_copies()
+            g.fault, g.fault_flag = k.fault, k.fault_flag
+            self._guard = g
+        return self._guard
+
     def _capture(self, fn):
         """Capture `fn`'s kernel launches into a hipGraph (after one eager warm-up on a side stream)."""
         ctr = self._step_ctr.clone()
@@ -1238,13 +1305,21 @@ class DDPG(object):
         ops.polyak_update(self.theta_target, self.theta, 0.0)        # ddpg.py:459-460
 
     def update_target_net(self):
-        self.check_faults(wait=False)                                # verdict of an earlier copy that has arrived (no stall)
-        ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
         # the fault word travels to the host every FAULT_CHECK_EVERY-th cycle (train.py:154: once per cycle we are here):
         # a faulted update freezes the parameters until the word is cleared, so a late report loses nothing
         self._fault_tick = getattr(self, '_fault_tick', 0) + 1
+        ops.polyak_update(self.theta_target, self.theta, self.polyak)   # ddpg.py:461-462
         if self._fault_tick % FAULT_CHECK_EVERY == 1:
             self._enqueue_fault_check()
+        # verdict of an earlier copy, raised when the work of this call is done.  One rank: as soon as the copy has
+        # arrived (no stall).  Several ranks: a fault on ANY rank froze ALL of them (the flag element of the gradient
+        # all-reduce), and all of them read their verdict at the SAME cycle count, FAULT_CHECK_EVERY - 1 cycles after
+        # the copy was enqueued (it arrived long ago) -- every rank raises, clears and resumes in the same cycle, the
+        # replicas stay identical
+        if not dist.is_distributed():
+            self.check_faults(wait=False)
+        elif self._fault_tick % FAULT_CHECK_EVERY == 0:
+            self._fault_verdict(wait=True)
 
     # ------------------------------------------------------------------ guard of the in-kernel Q' hand-off
     def _enqueue_fault_check(self):
@@ -1264,6 +1339,11 @@ class DDPG(object):
         the exception can go on training from the last good parameters."""
         if wait:
             self._enqueue_fault_check()
+        elif dist.is_distributed():
+            return                                                   # read at a fixed cycle count: update_target_net
+        self._fault_verdict(wait)
+
+    def _fault_verdict(self, wait):
         if not getattr(self, '_fault_pending', False):
             return
         if wait:

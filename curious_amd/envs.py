@@ -109,6 +109,12 @@ def sparse_reward_fun(spec):
     return reward_fun
 
 
+class ResidentRolloutVoid(_lib.CuriousHipError):
+    """The weights-resident rollout launch (policy_resident_kernel) reported itself void: a workgroup never got an answer
+    from a peer of its group, i.e. the launch was not fully resident (shared device, CU mask, partition).  Nothing of the
+    rollout may be used; the streaming kernel (option 'resident' = 0) computes the same numbers."""
+
+
 class BatchedSyntheticArm(ArmSpec):
     def __init__(self, name, n, seed=0, env_id0=0, T=None):
         super().__init__(name)
@@ -177,8 +183,9 @@ class BatchedSyntheticArm(ArmSpec):
         if host[self.n] == 2.0:
             # include/curious_hip.h, curious_policy_rollout: a workgroup of the resident-weights rollout never got an
             # answer from a peer of its group (the launch was not fully resident) -- the rollout is void
-            raise _lib.CuriousHipError('curious_policy_rollout: a member of a workgroup group gave up waiting for its '
-                                       "peers; rerun with CURIOUS_RESIDENT=0 (option 'resident')")
+            raise ResidentRolloutVoid('curious_policy_rollout: a member of a workgroup group gave up waiting for its '
+                                      "peers (the launch was not fully resident); option 'resident' = 0 selects the "
+                                      'streaming kernel')
         return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
 
     def fetch_flags(self):

@@ -40,6 +40,32 @@ def train(*args, **kwargs):
         thaw_setup_objects()
 
 
+class FaultTolerance:
+    """What the training loop does with a HandoffFault (curious_amd.ddpg): the optimiser froze the parameters at the
+    last good update, so the job can simply go on -- the check that raised has already cleared the word.  An isolated
+    fault is logged and survived; a second one within `window` cycles of the first means the hand-off does not work on
+    this device / partition at all and is raised.  (fault_check='sync': DDPG.train_batches_guarded replays the faulted
+    run of updates instead, bit-identical to a run without the fault.)"""
+
+    def __init__(self, window=64):
+        self.window, self.cycle, self.last, self.count = window, 0, None, 0
+
+    def tick(self):
+        self.cycle += 1
+
+    def call(self, fn, *args):
+        from curious_amd.ddpg import HandoffFault
+        try:
+            return fn(*args)
+        except HandoffFault as err:
+            self.count += 1
+            if self.last is not None and self.cycle - self.last <= self.window:
+                raise
+            self.last = self.cycle
+            logger.warn('%s -- training goes on from the last good parameters' % err)
+            return None
+
+
 def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
            save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None, **kwargs):
     """train.py:49-166.  expert_bank (task_experts only): update ALL experts in one batched launch sequence after
@@ -54,6 +80,13 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
         latest_policy_path = best_policy_path = periodic_policy_path = None
     best_success_rate = -1
     nb_tasks = params['nb_tasks']
+    ft = FaultTolerance()
+    sync_faults = params.get('fault_check', 'async') == 'sync'
+
+    def updates(pol, n):
+        if sync_faults and hasattr(pol, 'train_batches_guarded'):
+            return pol.train_batches_guarded(n)
+        return ft.call(pol.train_batches, n)
 
     if structure == 'task_experts':
         p = 1 / nb_tasks * np.ones([nb_tasks])
@@ -75,15 +108,16 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
                 i_policy = dist.broadcast_object(i_policy, 0)
             rollout_worker[i_policy].clear_history()
             for _ in range(n_cycles):
+                ft.tick()
                 episode, cp, n_ep = rollout_worker[i_policy].generate_rollouts()
-                policy[i_policy].store_episode(episode, cp, n_ep)
+                ft.call(policy[i_policy].store_episode, episode, cp, n_ep)
                 if expert_bank is not None:
                     if expert_bank.trainable():
-                        expert_bank.train_batches(n_batches)          # every expert, one launch sequence per update
-                        expert_bank.update_target_net()
+                        updates(expert_bank, n_batches)               # every expert, one launch sequence per update
+                        ft.call(expert_bank.update_target_net)
                     continue
-                policy[i_policy].train_batches(n_batches)             # = n_batches x train() (train.py:101-102)
-                policy[i_policy].update_target_net()
+                updates(policy[i_policy], n_batches)                  # = n_batches x train() (train.py:101-102)
+                ft.call(policy[i_policy].update_target_net)
             evaluator.clear_history()
             for _ in range(n_test_rollouts):
                 evaluator.generate_rollouts()
@@ -106,10 +140,11 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
             if perturbation_study and epoch == 250:
                 perturb_envs(rollout_worker, evaluator)              # train.py:142-146
             for cyc in range(n_cycles):                               # train.py:148-155 -- the hot loop
+                ft.tick()
                 episode, cp, n_ep = rollout_worker.generate_rollouts()
-                policy.store_episode(episode, cp, n_ep)
-                policy.train_batches(n_batches)                      # = n_batches x train() (train.py:152-153)
-                policy.update_target_net()
+                ft.call(policy.store_episode, episode, cp, n_ep)
+                updates(policy, n_batches)                           # = n_batches x train() (train.py:152-153)
+                ft.call(policy.update_target_net)
             evaluator.clear_history()
             for _ in range(n_test_rollouts):
                 evaluator.generate_rollouts()
@@ -312,10 +347,14 @@ def main(argv=None):
     parser.add_argument('--n_batches', type=int, default=None)
     parser.add_argument('--experts_update', type=str, default='sequential', choices=['sequential', 'batched'],
                         help="task_experts: 'batched' updates all experts in one launch sequence per update")
+    parser.add_argument('--fault_check', type=str, default='async', choices=['async', 'sync'],
+                        help="guard of the in-kernel Q' hand-off: 'async' reads the verdict cycles later, survives an "
+                             "isolated fault on the last good parameters; 'sync' waits for every run of updates and replays "
+                             'a faulted one bit-identically (DDPG.train_batches_guarded)')
     args = vars(parser.parse_args(argv))
     over = {'rng_mode': args.pop('rng_mode'), 'use_graph': bool(args.pop('use_graph')),
             'async_store': bool(args.pop('async_store')),
-            'experts_update': args.pop('experts_update')}
+            'experts_update': args.pop('experts_update'), 'fault_check': args.pop('fault_check')}
     for k in ('rollout_batch_size', 'n_cycles', 'n_batches'):
         v = args.pop(k)
         if v is not None:

@@ -259,6 +259,39 @@ class ExpertBank:
             return [x.train_batches(n) for x in self.experts]
         return [(x._losses[0], x._Q_pi) for x in self.experts]
 
+    def train_batches_guarded(self, n):
+        """train_batches(n) with the hand-off guard read synchronously and a faulted run replayed once from the state it
+        started with (DDPG.train_batches_guarded for the bank: the slab holds every expert's parameters, moments,
+        counters, step-size rings and fault words)."""
+        from curious_amd.ddpg import HandoffFault
+        snap = self.slab.clone()
+        ts = [(x.Q_adam.t, x.pi_adam.t, x._alpha_filled) for x in self.experts]
+        cur = self._cur
+        out = self.train_batches(n)
+        try:
+            self.check_faults(wait=True)
+            return out
+        except HandoffFault as err:
+            import warnings
+            warnings.warn('%s -- replaying the %d updates of this run from the state it started with' % (err, n))
+        for x in self.experts:                                # the check above stopped at the first expert that raised
+            try:
+                x.check_faults(wait=True)
+            except HandoffFault:
+                pass
+        self.slab.copy_(snap)
+        self._cur = cur
+        for x, (tq, tp, filled) in zip(self.experts, ts):
+            x.Q_adam.t, x.pi_adam.t = tq, tp
+            if x._alpha_filled != filled:
+                x._alpha_filled = 0
+            x._cur = cur
+            x._staged = x._pp[cur]
+            x._batch_stale = True
+        out = self.train_batches(n)
+        self.check_faults(wait=True)
+        return out
+
     def update_target_net(self):
         for x in self.experts:
             x.update_target_net()

@@ -237,12 +237,21 @@ class RolloutWorker:
         p, self._pending = getattr(self, '_pending', None), None
         if p is None:
             return
-        successful, o_has_nan = self.benv.wait_flags()
-        if np.isnan(successful).any() or o_has_nan:
-            # the sync path would have generated the rollout again (rollout.py:268-271); here its updates are already
-            # enqueued: the device dropped the episodes instead of storing them
-            self.logger.warning('NaN caught during rollout generation. Its episodes were not stored.')
-            successful = np.nan_to_num(successful)
+        from curious_amd.envs import ResidentRolloutVoid
+        try:
+            successful, o_has_nan = self.benv.wait_flags()
+            lost = bool(np.isnan(successful).any() or o_has_nan)
+        except ResidentRolloutVoid as err:
+            self._resident_off(err)
+            lost = True
+        if lost:
+            # the sync path generates such a rollout again before anybody sees it (rollout.py:268-271).  Here its updates
+            # are already enqueued and the device dropped its episodes instead of storing them: the replacement is
+            # generated and stored NOW, one cycle late, so the buffers miss nothing
+            self.logger.warning('NaN caught during rollout generation. Trying again...')
+            self.n_episodes -= self.rollout_batch_size * self.nb_cpu  # the lost rollout does not count
+            self._replace_lost_rollout()
+            return
         exploit, self.exploit = self.exploit, False
         any_exploit, self._any_exploit = getattr(self, '_any_exploit', False), False
         self.tasks, self.goals = p['tasks'], p['goals']
@@ -250,7 +259,33 @@ class RolloutWorker:
         self._finish_rollout(successful, successful - 1.0, None, p['task_list'], None)
         self.exploit, self._any_exploit = exploit, any_exploit
 
-    def _generate_rollouts_batched(self, retry=False):
+    MAX_NAN_RETRIES = 3                   # the reference recurses without a bound (rollout.py:268-271)
+
+    def _resident_off(self, err):
+        """A void weights-resident rollout: switch the process to the streaming rollout kernel (same numbers), once."""
+        from curious_amd import ops
+        if ops.get_option('resident'):
+            self.logger.warning('%s -- switching this process to the streaming rollout kernel' % err)
+            ops.set_option('resident', 0)
+        for pol in (self.policy if isinstance(self.policy, (list, tuple)) else [self.policy]):
+            if hasattr(pol, 'drop_rollout_graphs'):
+                pol.drop_rollout_graphs()                         # they captured the resident launch
+
+    def _replace_lost_rollout(self):
+        """async_store: the rollout just settled was lost (NaN / void launch) and dropped on the device.  Generate its
+        replacement, waiting for its flags, and store it through the policy.  With several ranks the replacement feeds no
+        normaliser statistics: their update is a collective the other ranks are not part of at this point."""
+        exploit, self.exploit = self.exploit, False               # (only exploration rollouts take the async form)
+        any_exploit, self._any_exploit = getattr(self, '_any_exploit', False), False
+        try:
+            episode, cp, n_ep = self._generate_rollouts_batched(retry=True, force_sync=True)
+            self.policy.store_episode(episode, cp, n_ep, update_stats=not dist.is_distributed())
+        finally:
+            self.exploit, self._any_exploit = exploit, any_exploit
+
+    def _generate_rollouts_batched(self, retry=False, force_sync=False, n_retry=0, redo=None):
+        """redo = (tasks, goals): generate exactly the rollout that was just enqueued once more (DDPG.rewind_rollout put
+        the episode and noise counters back) instead of drawing a new one."""
         self.settle()
         if hasattr(self.policy, 'settle'):
             self.policy.settle()
@@ -264,13 +299,18 @@ class RolloutWorker:
             self._any_exploit = True if self.eval else dist.host_any(self.exploit)
         B, env = self.rollout_batch_size, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
-        tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
         experts = isinstance(self.policy, (list, tuple))          # task_experts evaluator (rollout.py:212-224)
-        if experts:
+        if redo is not None:
+            tasks, goals = redo
+        else:
+            tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
+        if experts and redo is None:
             # the draws are i.i.d., so any order of the envs is the same distribution: sorted by task, every expert's
             # envs are one contiguous row range of the batched env
             tasks = np.sort(tasks)
-        if self.goal_selection == 'active' and not self.eval:
+        if redo is not None:
+            pass
+        elif self.goal_selection == 'active' and not self.eval:
             # SAGG-RIAC goals live in goal space; reset_task_goal(directly=True) (rollout.py:143) = raw draw x 2 here
             goals = np.stack([2.0 * self.goal_selectors[int(ta)].sample_goal() for ta in tasks]).astype(np.float32)
         else:
@@ -314,7 +354,7 @@ class RolloutWorker:
         # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
         if not self.eval and hasattr(self.policy, 'prefetch_activity'):
             self.policy.prefetch_activity(env.episode_views())     # arrives with the flags: one host sync per cycle
-        if self._async_ok(env, fused and hasattr(self.policy, 'act_rollout')):
+        if not force_sync and self._async_ok(env, fused and hasattr(self.policy, 'act_rollout')):
             # return without waiting: the policy routes the episodes on the device, the flags are read in settle()
             env.request_flags()
             task_list = tasks.tolist()
@@ -327,10 +367,26 @@ class RolloutWorker:
             return views, self.CP, self.n_episodes
         if getattr(self.policy, '_async_batch', None) is not None:
             self.policy._async_batch = None                       # a marked rollout that was never stored: forget it
-        successful, o_has_nan = env.fetch_flags()                 # written by the last env step of the rollout
+        from curious_amd.envs import ResidentRolloutVoid
+        try:
+            successful, o_has_nan = env.fetch_flags()             # written by the last env step of the rollout
+        except ResidentRolloutVoid as err:
+            # the launch was not fully resident: nothing of it may be used.  Switch the process to the streaming kernel
+            # and generate the SAME rollout again -- same tasks and goals, same episode numbers, same noise counters: the
+            # job goes on with exactly the numbers it would have had
+            if n_retry >= self.MAX_NAN_RETRIES:
+                raise
+            self._resident_off(err)
+            self.policy.rewind_rollout(env, self.T)
+            self.count -= B
+            return self._generate_rollouts_batched(retry=True, force_sync=force_sync, n_retry=n_retry + 1,
+                                                   redo=(tasks, goals))
         if np.isnan(successful).any() or o_has_nan:
+            if n_retry >= self.MAX_NAN_RETRIES:
+                raise RuntimeError('%d rollouts in a row produced NaN observations (rollout.py:268-271 would try '
+                                   'again for ever): the policy has diverged' % (n_retry + 1))
             self.logger.warning('NaN caught during rollout generation. Trying again...')
-            return self._generate_rollouts_batched(retry=True)
+            return self._generate_rollouts_batched(retry=True, force_sync=force_sync, n_retry=n_retry + 1)
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
         task_list = tasks.tolist()
         self.tasks = [_NOTHING] * self.nb_goals_per_rollout

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 6      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 7      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -298,6 +298,13 @@ typedef struct curious_transposed {
   int64_t src_off[8];
   float* dst[8];
   const int32_t* fault;                /* the workspace's fault word (curious_workspace_fault_offset); set even when n == 0 */
+  int64_t fault_flag;                  /* 1 + index, in the GRADIENT vector, of the collective fault flag (0 = none): a
+                                        * padding element of the fused layout (the last one in front of theta_pi) that
+                                        * curious_ddpg_grads* sets to 1.0 when the workspace's fault word is non-zero, 0.0
+                                        * otherwise.  It travels through the ranks' gradient all-reduce (SUM) with the
+                                        * gradients, so an optimiser call given this description skips on EVERY rank when
+                                        * ANY rank's hand-off failed (and raises its own fault word: the freeze is sticky
+                                        * everywhere) -- the replicas stay identical (mpi_adam.py:42-50) */
 } curious_transposed_t;
 int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, float* workspace, curious_transposed_t* out);
 

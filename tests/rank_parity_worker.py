@@ -77,6 +77,8 @@ def main():
     np.random.seed(900 + rank)
     cp = np.array([0.3, 0.0, 0.2, 0.1])
 
+    if mode == 'fault':
+        return fault_main(out, rank, rng, cp)
     if mode == 'single':
         agent, _, _ = make_agent(graph)
         agents, bank = [agent], None
@@ -145,6 +147,50 @@ def main():
     np.savez(out + '.rank%d.npz' % rank, **rec)
     from curious_amd.experiment.train import shutdown
     shutdown(agents, bank)
+
+
+def fault_main(out, rank, rng, cp):
+    """A hand-off fault on ONE rank (rank 1 loses a producer of Q' in one update): the flag element of the gradient
+    all-reduce freezes BOTH ranks from that update on, both raise HandoffFault at the same cycle count, both resume."""
+    from curious_amd import ops
+    from curious_amd.ddpg import FAULT_CHECK_EVERY, HandoffFault
+    from test_gpu_agent import synth_episodes
+    agent, _, _ = make_agent(False)
+    agent.store_episode({k: v.copy() for k, v in synth_episodes(rng, 24, NB, DIMO).items()}, cp, 24)
+    rec = {}
+
+    def snap(tag):
+        torch.cuda.synchronize()
+        rec['theta_' + tag] = agent.theta.cpu().numpy().copy()
+        rec['m_' + tag] = agent._m.cpu().numpy().copy()
+        rec['fault_' + tag] = np.int64(int(ops.fault_word(agent.net_cfg, agent.batch_size, agent._workspace)))
+    for _ in range(3):
+        agent.train()
+    snap('good')
+    if rank == 1:
+        with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+            agent.train()
+            torch.cuda.synchronize()
+    else:
+        agent.train()
+    snap('hit')                                                      # the faulted update: skipped on BOTH ranks
+    agent.train_batches(2)
+    snap('frozen')                                                   # sticky on both ranks
+    raised = []
+    for tick in range(1, 2 * FAULT_CHECK_EVERY + 1):
+        try:
+            agent.update_target_net()
+        except HandoffFault:
+            raised.append(tick)
+    rec['raised'] = np.array(raised, np.int64)
+    snap('cleared')
+    agent.train_batches(3)
+    snap('resumed')
+    agent._check_synced(wait=True)
+    agent.check_faults(wait=True)
+    np.savez(out + '.rank%d.npz' % rank, **rec)
+    from curious_amd.experiment.train import shutdown
+    shutdown([agent], None)
 
 
 if __name__ == '__main__':

@@ -392,7 +392,8 @@ def test_ddpg_grads_vs_oracle(ops, cfg, route):
     assert abs(got_l[1] - ref['pi_loss']) <= 1e-5 * abs(ref['pi_loss'])
     np.testing.assert_allclose(Qpi.cpu().numpy(), ref['Q_pi'][:, 0], rtol=1e-5, atol=1e-6)
     g = grad.cpu().numpy()
-    assert np.isnan(g[PQ:off_pi]).all()          # pads are never written
+    assert np.isnan(g[PQ:off_pi - 1]).all()      # pads are never written ...
+    assert g[off_pi - 1] == 0.0                  # ... but the last one in front of theta_pi: the collective fault flag
     g = ops.unpad_params(ncfg, g)
     assert not np.isnan(g).any()
     for name, sl in (('Q_grad', slice(0, PQ)), ('pi_grad', slice(PQ, PQ + Ppi))):

@@ -122,7 +122,8 @@ def test_handoff_fault_with_batched_experts():
 
 def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
     """async_store: a rollout whose observations turn NaN is neither stored nor fed to the normalisers (the reference
-    regenerates it before store_episode ever sees it, rollout.py:268-271); the worker reports it a cycle late; the NaN
+    regenerates it before store_episode ever sees it, rollout.py:268-271); the worker sees it a cycle late, when it
+    settles the flags, and generates + stores the replacement then (round 4; round 3 only reported the loss); the NaN
     word is cleared by the next reset."""
     from curious_amd import logger
     from curious_amd.envs import EnvFactory
@@ -158,11 +159,21 @@ def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
     agent.store_episode(ep, cp, n_ep)
     torch.cuda.synchronize()
     assert float(w.benv.flags[B]) == 1.0
-    w.settle(); agent.settle()
+    agent.settle()
     assert [b.current_size for b in agent.buffer] == sizes            # nothing stored
     for a, b in zip(stats, (agent.o_stats.state, agent.g_stats.state, agent._stats_acc)):
         assert torch.equal(a, b)                                      # nothing accumulated
     assert torch.isfinite(agent.o_stats.state).all()
+    n_before = w.n_episodes
+    w.settle()                                                       # the lost rollout is replaced NOW (rollout.py:268-271)
+    agent.settle()
+    torch.cuda.synchronize()
+    assert float(w.benv.flags[B]) == 0.0                             # the replacement's reset cleared the NaN word
+    replaced = [b.current_size for b in agent.buffer]
+    assert sum(replaced[1:nb + 1]) > sum(sizes[1:nb + 1])
+    assert w.n_episodes == n_before                                  # - the lost rollout + its replacement
+    assert not torch.equal(stats[0], agent.o_stats.state) and torch.isfinite(agent.o_stats.state).all()
+    sizes = replaced
     ep, cp, n_ep = w.generate_rollouts()                             # the next reset clears the NaN word
     agent.store_episode(ep, cp, n_ep)
     w.settle(); agent.settle()
@@ -306,14 +317,23 @@ def test_resident_rollout_reports_a_member_that_never_shows_up():
     torch.cuda.synchronize()
     assert ops.prof_launch_counts()['policy_resident_kernel'] == before + 1     # the resident route is the one taken
     assert float(w.benv.flags[B]) == 0.0
-    with ops.option('fault_inject', 3), ops.option('res_spins', 20000):
-        with pytest.raises(_lib.CuriousHipError, match='gave up waiting'):
-            w.generate_rollouts()
-    torch.cuda.synchronize()
-    assert float(w.benv.flags[B]) == 2.0
-    ep, _, _ = w.generate_rollouts()                                   # (reset clears the word)
-    torch.cuda.synchronize()
-    assert float(w.benv.flags[B]) == 0.0 and bool(torch.isfinite(ep.records).all())
+    from curious_amd.envs import ResidentRolloutVoid
+    try:
+        with ops.option('fault_inject', 3), ops.option('res_spins', 20000):
+            w.benv.reset_all(np.zeros(B, np.int64), np.zeros([B, 3], np.float32))
+            agent.act_rollout(w.benv, T, noise_eps=0.2, random_eps=0.3)
+            with pytest.raises(ResidentRolloutVoid, match='gave up waiting'):      # a CuriousHipError
+                w.benv.fetch_flags()
+            assert float(w.benv.flags[B]) == 2.0
+            # the worker (round 4) does not pass the error on: it switches the process to the streaming kernel and
+            # generates the rollout again (tests/test_gpu_round4.py: with the same numbers)
+            ep, _, _ = w.generate_rollouts()
+            assert ops.get_option('resident') == 0
+        torch.cuda.synchronize()
+        assert float(w.benv.flags[B]) == 0.0 and bool(torch.isfinite(ep.records).all())
+        assert issubclass(ResidentRolloutVoid, _lib.CuriousHipError)
+    finally:
+        ops.set_option('resident', 1)
 
 
 def test_ipc_allreduce_adam_prototype_two_processes_one_gpu(tmp_path):

@@ -158,3 +158,208 @@ def test_bench_runs_end_to_end_on_two_ranks():
     assert c['allreduce_us'] > 0 and c['allreduce_bytes'] >= 4 * 294661
     assert c['replicas_identical'] is True and len(c['replica_checksums']) == 2
     assert c['replica_checksums'][0] == c['replica_checksums'][1]
+
+
+# ------------------------------------------------------------------ faults: the job goes on
+def test_a_handoff_fault_on_one_rank_freezes_and_resumes_every_rank_alike():
+    """the guard of the Q' hand-off used to be rank-local -- the faulted rank skipped its optimiser,
+    the healthy ranks applied the NaN-summed gradient.  Now the fault word rides through the gradient all-reduce as a
+    padding element of the gradient vector (curious_transposed_t.fault_flag): rank 1 loses a producer in one update, BOTH
+    ranks skip that update and every later one, both raise HandoffFault at the same cycle count, both resume, and the
+    replicas are bit-identical throughout (mpi_adam.py:42-50)."""
+    from curious_amd.ddpg import FAULT_CHECK_EVERY
+    prefix = os.path.join(tempfile.mkdtemp(), 'fault')
+    out = _launch2([os.path.join(ROOT, 'tests', 'rank_parity_worker.py'), prefix, 'fault', '0'], _two_rank_env())
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = [np.load('%s.rank%d.npz' % (prefix, r)) for r in range(2)]
+    for tag in ('good', 'hit', 'frozen', 'cleared', 'resumed'):
+        np.testing.assert_array_equal(rec[0]['theta_' + tag], rec[1]['theta_' + tag], err_msg=tag)
+        np.testing.assert_array_equal(rec[0]['m_' + tag], rec[1]['m_' + tag], err_msg=tag)
+    for r in range(2):
+        assert np.isfinite(rec[r]['theta_resumed']).all()
+        for tag in ('hit', 'frozen', 'cleared'):                     # nothing moved from the faulted update on
+            np.testing.assert_array_equal(rec[r]['theta_good'], rec[r]['theta_' + tag], err_msg=tag)
+            np.testing.assert_array_equal(rec[r]['m_good'], rec[r]['m_' + tag], err_msg=tag)
+        assert int(rec[r]['fault_good']) == 0
+        assert int(rec[r]['fault_frozen']) > 0                       # the healthy rank raised its own word as well
+        assert int(rec[r]['fault_cleared']) == 0
+        assert list(rec[r]['raised']) == [FAULT_CHECK_EVERY]         # every rank in the same cycle, once
+        assert not np.array_equal(rec[r]['theta_good'], rec[r]['theta_resumed'])
+    assert int(rec[1]['fault_hit']) == 4 and int(rec[0]['fault_hit']) == 1     # 4 waves gave up / raised by the optimiser
+
+
+def _job(seed=11, B=16, use_graph=True, async_store=False):
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from test_gpu_agent import T, build_pair, synth_episodes
+    nb, dimo = 4, 40
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    agent, _ = build_pair(nb, dimo, cap_eps=200, rng_mode='device', use_graph=use_graph, seed=seed)
+    agent.async_store = async_store
+    w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                      noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='random', queue_length=6,
+                      eval=False)
+    w.seed(seed)
+    w._decide_exploit = lambda: None
+    agent.store_episode(synth_episodes(np.random.RandomState(21), 24, nb, dimo), w.CP, 24)
+    return agent, w
+
+
+def _cycles(agent, w, n, n_batches=4):
+    for _ in range(n):
+        ep, cp, n_ep = w.generate_rollouts()
+        agent.store_episode(ep, cp, n_ep)
+        agent.train_batches(n_batches)
+        agent.update_target_net()
+    w.settle(); agent.settle()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_a_void_resident_rollout_is_redone_on_the_streaming_kernel_with_the_same_numbers(use_graph):
+    """a time-out of the weights-resident rollout used to end the job ("rerun with CURIOUS_RESIDENT=0").
+    Now the worker switches the process to the streaming kernel, warns once and generates the SAME rollout again (same
+    tasks / goals / episode numbers / noise counters): the run ends bit-identical to one that never saw the fault."""
+    from curious_amd import ops
+    assert ops.get_option('resident') == 1
+    np.random.seed(5)
+    ref_agent, ref_w = _job(use_graph=use_graph)
+    _cycles(ref_agent, ref_w, 3)
+    try:
+        np.random.seed(5)
+        agent, w = _job(use_graph=use_graph)
+        _cycles(agent, w, 1)
+        agent.drop_rollout_graphs()                                  # (the injection is a launch argument: capture anew)
+        with ops.option('fault_inject', 1), ops.option('res_spins', 20000):
+            ep, cp, n_ep = w.generate_rollouts()                     # void -> switched -> redone, inside this call
+        assert ops.get_option('resident') == 0                      # the process stays on the streaming kernel
+        agent.store_episode(ep, cp, n_ep)
+        agent.train_batches(4)
+        agent.update_target_net()
+        _cycles(agent, w, 1)
+    finally:
+        ops.set_option('resident', 1)
+    for name in ('theta', '_m', '_v', 'theta_target'):
+        assert torch.equal(getattr(agent, name), getattr(ref_agent, name)), name
+    assert [b.current_size for b in agent.buffer] == [b.current_size for b in ref_agent.buffer]
+    for b, rb in zip(agent.buffer[1:], ref_agent.buffer[1:]):         # (the storage beyond the stored episodes is never
+        assert torch.equal(b.records[:b.current_size], rb.records[:rb.current_size])   # initialised)
+    assert torch.equal(w.benv.staging, ref_w.benv.staging)
+    assert w.n_episodes == ref_w.n_episodes and agent._noise_counter == ref_agent._noise_counter
+
+
+def test_a_void_resident_rollout_on_the_async_path_is_replaced_a_cycle_late():
+    """async_store: the void launch is seen when its flags are settled, a cycle late -- the device dropped its episodes,
+    the worker switches to the streaming kernel and generates + stores a replacement at once; the job goes on."""
+    from curious_amd import ops
+    np.random.seed(5)
+    agent, w = _job(async_store=True)
+    try:
+        _cycles(agent, w, 2)
+        sizes = sum(b.current_size for b in agent.buffer[1:5])
+        n_ep0 = w.n_episodes
+        agent.drop_rollout_graphs()
+        with ops.option('fault_inject', 1), ops.option('res_spins', 20000):
+            ep, cp, n_ep = w.generate_rollouts()
+            assert getattr(w, '_pending', None) is not None           # returned without waiting
+            agent.store_episode(ep, cp, n_ep)
+            torch.cuda.synchronize()
+        assert float(w.benv.flags[w.benv.n]) == 2.0
+        agent.train_batches(4)
+        agent.update_target_net()
+        agent.settle()
+        assert sum(b.current_size for b in agent.buffer[1:5]) == sizes       # dropped on the device
+        _cycles(agent, w, 1)                                         # settles the void rollout: replacement + this cycle's
+        assert ops.get_option('resident') == 0
+        assert sum(b.current_size for b in agent.buffer[1:5]) > sizes
+        assert w.n_episodes == n_ep0 + 2 * 16                        # the lost rollout does not count, its replacement does
+        assert torch.isfinite(agent.theta).all()
+    finally:
+        ops.set_option('resident', 1)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_guarded_updates_replay_a_faulted_run_bit_identically(use_graph):
+    """fault_check='sync' (DDPG.train_batches_guarded): a run of updates in which a consumer of Q' gave up is replayed
+    once from the parameters, moments and step counter it started with -- same batches, same step sizes: the job ends
+    bit-identical to one that never faulted; a fault in the replay is raised."""
+    from curious_amd import ops
+    from curious_amd.ddpg import HandoffFault
+    from test_gpu_round3 import _filled_agent
+    ref, _ = _filled_agent(use_graph=use_graph)
+    ref.train_batches(3)
+    ref.train_batches(12)
+    ref.train_batches(4)
+    agent, _ = _filled_agent(use_graph=use_graph)
+    agent.train_batches(3)
+    plain = agent.train_batches
+    calls = []
+
+    def faulty_first(n):
+        if not calls:
+            saved = (agent._graphs, agent._chains)
+            agent._graphs, agent._chains = [None, None], None          # captured with the injection baked in: dropped below
+            with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+                out = plain(n)
+                torch.cuda.synchronize()
+            agent._graphs, agent._chains = saved
+        else:
+            out = plain(n)
+        calls.append(n)
+        return out
+    agent.train_batches = faulty_first
+    with pytest.warns(UserWarning, match='replaying'):
+        agent.train_batches_guarded(12)
+    assert calls == [12, 12]
+    agent.train_batches = plain
+    agent.train_batches_guarded(4)                                   # a clean run: no replay
+    torch.cuda.synchronize()
+    for name in ('theta', '_m', '_v', '_step_ctr'):
+        assert torch.equal(getattr(agent, name), getattr(ref, name)), name
+    assert agent.Q_adam.t == ref.Q_adam.t == 19
+    # a fault that repeats in the replay is raised
+    with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+        agent._graphs, agent._chains = [None, None], None
+        with pytest.warns(UserWarning), pytest.raises(HandoffFault):
+            agent.train_batches_guarded(2)
+    agent._graphs, agent._chains = [None, None], None
+    agent.check_faults()
+
+
+def test_the_training_loop_survives_an_isolated_handoff_fault():
+    """experiment.train.FaultTolerance (the default, asynchronous form): the verdict arrives cycles later, the loop logs
+    it and goes on from the last good parameters; a second fault within the window is raised."""
+    from curious_amd import ops
+    from curious_amd.ddpg import FAULT_CHECK_EVERY, HandoffFault
+    from curious_amd.experiment.train import FaultTolerance
+    np.random.seed(5)
+    agent, w = _job(use_graph=False)
+    ft = FaultTolerance(window=4 * FAULT_CHECK_EVERY)
+
+    def cycle(inject=False):
+        ft.tick()
+        ep, cp, n_ep = w.generate_rollouts()
+        ft.call(agent.store_episode, ep, cp, n_ep)
+        if inject:
+            with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+                ft.call(agent.train_batches, 3)
+                torch.cuda.synchronize()
+        else:
+            ft.call(agent.train_batches, 3)
+        ft.call(agent.update_target_net)
+    for _ in range(2):
+        cycle()
+    torch.cuda.synchronize()
+    good = agent.theta.clone()
+    cycle(inject=True)
+    for _ in range(3 * FAULT_CHECK_EVERY):
+        cycle()
+    torch.cuda.synchronize()
+    assert ft.count == 1                                             # seen once, survived
+    assert torch.isfinite(agent.theta).all() and not torch.equal(good, agent.theta)
+    agent.check_faults()
+    cycle(inject=True)                                               # again, inside the window: raised
+    with pytest.raises(HandoffFault):
+        for _ in range(3 * FAULT_CHECK_EVERY):
+            cycle()
