@@ -100,6 +100,7 @@ PROTOTYPES = {
     'curious_set_option': (C.c_int, [C.c_char_p, _I64]),
     'curious_get_option': (_I64, [C.c_char_p]),
     'curious_workspace_fault_offset': (_I64, [C.POINTER(NetCfg), _I32]),
+    'curious_workspace_stamps_offset': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
                                      C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
                                      _P]),

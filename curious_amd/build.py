@@ -13,6 +13,9 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('
     [os.path.join(os.path.dirname(HERE), 'include', 'curious_hip.h')]      # every header takes part in the rebuild check
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-x', 'hip']
+# kernarg preloading (gfx940+): the leading scalar arguments of a kernel arrive in SGPRs with the wave instead of being
+# fetched from the (uncached) kernarg segment -- mlp_lean_gemm.h "DwMap"
+SOURCE_FLAGS = {'mlp.hip': ['-mllvm', '-amdgpu-kernarg-preload-count=14']}
 
 
 def source_digest():
@@ -25,6 +28,7 @@ def _digest():
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(SOURCE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -42,7 +46,7 @@ def build(force=False, verbose=True):
         # the source digest is compiled into the library (curious_build_digest): _lib.lib() refuses a binary that was
         # built from other sources than the ones next to it (the stamp file below is only the fast path of this function)
         extra = ['-DCURIOUS_BUILD_DIGEST="%s"' % dig] if s == 'api.cpp' else []
-        cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, s), '-o', obj]
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(s, []) + extra + ['-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -97,6 +97,8 @@ CuriousOptions& curious_options() {
     o.fault_inject = 0;
     o.qt_spins = 1 << 22;
     o.lab_no_target = 0;
+    o.dw_xcd = env_int("CURIOUS_DW_XCD", 1) != 0;
+    o.lab_dw_stamps = 0;
     o.lab_step = env_int("CURIOUS_LAB_STEP", 0);
     o.lab_res_stamps = 0;
     o.resident = env_int("CURIOUS_RESIDENT", 1) != 0;
@@ -115,6 +117,8 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "fault_inject")) return &o.fault_inject;
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
   if (!strcmp(name, "lab_no_target")) return &o.lab_no_target;
+  if (!strcmp(name, "dw_xcd")) return &o.dw_xcd;
+  if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
   if (!strcmp(name, "lab_step")) return &o.lab_step;
   if (!strcmp(name, "lab_res_stamps")) return &o.lab_res_stamps;
   if (!strcmp(name, "resident")) return &o.resident;

@@ -96,6 +96,8 @@ struct CuriousOptions {
                        // 64-bit words behind its exchange buffer in the workspace
   int lab_step;        // LAB ONLY (timing experiments on ddpg_step_kernel; results are wrong with bit 0): bit 0 no release
                        // fence when publishing, bit 1 long sleeps between polls, bit 2 tiles do not wait       [CURIOUS_LAB_STEP]
+  int dw_xcd;          // 1: blocks of the weight-gradient / optimiser launch placed by XCD (mlp_lean_gemm.h DwMap)  [CURIOUS_DW_XCD]
+  int lab_dw_stamps;   // LAB ONLY (tools/dw_stamps.py): dw_adam_her_kernel writes per-block cycle stamps into the workspace
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere
 };

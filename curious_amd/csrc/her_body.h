@@ -4,6 +4,14 @@
 #include "common.h"
 
 #define SPB 4                 // samples per block pass (= waves per block)
+struct DwStamp { unsigned long long t[4]; };   // lab: cycle stamps a block collects in registers (mlp_lean_gemm.h)
+#ifndef DW_STAMP
+#ifdef DW_STAMPS
+#define DW_STAMP(st, k) do { if (st) (st)->t[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DW_STAMP(st, k) do { } while (0)
+#endif
+#endif
 #define STREAM_SAMPLE_A 11u
 #define STREAM_SAMPLE_B 12u
 
@@ -27,13 +35,17 @@ struct HerArgs {
 // organised as exactly two: (1) everything needed to decide WHERE to read -- the task tables (into LDS), the
 // sampling tables / host plan and the step counter, all issued together; (2) the three row segments of the
 // transition.  Relabelling, reward and clipping then run out of LDS / registers.
+// Past the one barrier that publishes the task tables a wave works on its transition alone (round 4): its own LDS slot,
+// no further workgroup barrier -- with two __syncthreads() every wave of a block waited twice for the slowest of four random HBM reads
+// (tools/dw_stamps.py: 6 k cycles between "rows in LDS" and the exit of a gather block).  LDS operations of one wave
+// execute in order, so between a wave's own writes and its reads only the compiler has to be kept from reordering.
 // eo / seed_add: batched experts (mlp_common.h "Ex"): the staged batch, the sampling tables and the step counter of
 // expert e live eo floats behind expert 0's, its Philox key is seed + seed_add; the replay storage is shared.
 // step_add: added to the step counter read from memory (the gather that rides in ddpg_rows_kernel runs BEFORE the
 // update's increment of the counter, mlp_rows.h: + 1 gives the key the gather after it would have used).
 __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int block, float* lds, const int64_t eo = 0,
-                                                const uint64_t seed_add = 0, const int64_t step_add = 0) {
-  __shared__ int32_t s_tab[TAB_INTS];
+                                                const uint64_t seed_add = 0, const int64_t step_add = 0,
+                                                DwStamp* stamps = nullptr) {
   const curious_layout_t& L = a.L;
   const curious_batch_layout_t& BL = a.BL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -45,6 +57,10 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
   float* s_fut = s_next + head;                         // future ag
   float* s_g = s_fut + L.dimag;                         // relabelled goal
   float* s_td = s_g + L.dimg;                           // relabelled task descriptor
+  // task tables: ONE copy per workgroup in LDS, fetched with round trip 1 (reads of the kernel's arguments are not
+  // cached: read where they are needed they would cost a full round trip each).  The one workgroup barrier that
+  // publishes the copy sits in front of round trip 2, where the four waves have all just waited for the same tables.
+  __shared__ int32_t s_tab[TAB_INTS];
   const int32_t* s_len = s_tab;
   const int32_t* s_gid = s_tab + CURIOUS_MAX_TASKS;
   const int32_t* s_agid = s_gid + CURIOUS_MAX_TASKS * CURIOUS_MAX_TASK_DIMS;
@@ -95,10 +111,12 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     out_row = gic;
   }
   // her.py:115-118 in float64 / truncation toward zero
-  const bool her = u_her < a.P.future_p;
+  const bool her = __builtin_amdgcn_readfirstlane((int)(u_her < a.P.future_p)) != 0;   // (wave-uniform)
   const int off = (int)(u_off * (double)(L.T - t));
   const int future_t = t + 1 + off;
   const int64_t ep_base = (int64_t)buf * a.buf_stride + (int64_t)ep * (L.T + 1) * L.row_stride;
+  DW_STAMP(stamps, 1);
+  __syncthreads();                                      // the task tables are in LDS (the only workgroup barrier)
 
   // ---- round trip 2: row t, the (o, ag) head of row t+1 (replay_buffer.py:47-48) and the future achieved goal
   {
@@ -108,7 +126,8 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     for (int i = lane; i < n1; i += 64) s_row[i] = src[i];
     for (int i = lane; i < L.dimag; i += 64) s_fut[i] = fut[i];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  DW_STAMP(stamps, 2);
 
   const int mode = a.P.relabel_mode;
   // current task of the sampled transition = position of the 1 in task_descr (her.py:133,159)
@@ -117,6 +136,8 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     if (s_row[L.off_td + jj] > s_row[L.off_td + cur]) cur = jj;
   int rt = cur;
   if (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK) rt = (ttr >= 0) ? ttr : cur;
+  cur = __builtin_amdgcn_readfirstlane(cur);            // (the same on every lane of the wave: one transition per wave)
+  rt = __builtin_amdgcn_readfirstlane(rt);
   const int ntasks = a.tasks.ntasks;
   for (int i = lane; i < L.dimg; i += 64) {
     float v = s_row[L.off_g + i];
@@ -138,7 +159,7 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
   const bool retask = her && (mode == CURIOUS_RELABEL_BUFFER_TASK || mode == CURIOUS_RELABEL_GIVEN_TASK);
   for (int i = lane; i < L.dimtd; i += 64) s_td[i] = retask ? ((i == rt) ? 1.0f : 0.0f) : s_row[L.off_td + i];
   const int rtask = retask ? rt : cur;                  // first maximum of the (one-hot) descriptor
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
 
   // reward (oracle/reward.py): float64, sequential, no FMA, correctly rounded sqrt; computed redundantly by all lanes
   const float* ag2 = s_next + L.dimo;

@@ -152,6 +152,12 @@ extern "C" int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, 
   return (int64_t)(reinterpret_cast<float*>(carve(cfg, B, dummy).fault) - dummy);
 }
 
+extern "C" int64_t curious_workspace_stamps_offset(const curious_net_cfg_t* cfg, int32_t B) {
+  if (!cfg || B <= 0) return -1;
+  static float dummy[1];
+  return (int64_t)(carve(cfg, B, dummy).part[0] - dummy);
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int curious_ddpg_transposed(const curious_net_cfg_t* cfg, int32_t B, float* workspace,
@@ -1274,18 +1280,45 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       return 0;
     }
     if (rows_pending && launch_rows()) return -1;
+    // XCD-aware placement of the launch's blocks (mlp_lean_gemm.h DwMap; option "dw_xcd"): applies when the hidden
+    // matrices divide the 8 XCDs evenly (2 or 4 of them: 4 or 2 XCDs each)
+    DwMap map;
+    memset(&map, 0, sizeof(map));
+    auto dw_grid = [&](int n_her) -> int {
+      const int np = hwAll.nprob;
+      if (curious_options().dw_xcd && (np == 2 || np == 4) && hwAll.tiles_per == 64) {
+        map.units = 8 / np;
+        map.r_hot = hwAll.tiles_per / map.units;
+        map.r_her = (n_her + 7) / 8;
+        const int r_small = smAll.slots * ((smAll.nprob + 1 + 7) / 8);      // + 1: the loss finalisation
+        return 8 * (map.r_her + map.r_hot + r_small);
+      }
+      return n_her + tAll + nsmall + 1;
+    };
+    if (curious_options().lab_dw_stamps) dwAll.stamps = reinterpret_cast<unsigned long long*>(w.part[0]);
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
+      const int gx = dw_grid(n_her);
+      if (dwAll.stamps && (int64_t)gx * 8 * 2 > 6 * 16 * (int64_t)B) dwAll.stamps = nullptr;   // (room: part[0..5])
       { ProfScope ps__(CK_DW_ADAM_HER, st);
-        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(n_her + tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll,
-                           tail->adam, tail->h, n_her, xd.stride, xd.gstride, seed_stride); }
+        const AdamFuse& af = tail->adam;
+        // (never NULL in the kernel: a block loads both words before it knows whether it will need them)
+        const int32_t* fault0 = af.fault ? af.fault : reinterpret_cast<const int32_t*>(af.theta);
+        const int64_t* ctr0 = af.alpha_tab ? af.step_ctr : reinterpret_cast<const int64_t*>(af.theta);
+        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
+                           smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, map.units, fault0, ctr0,
+                           (int64_t)xd.stride, dwAll, tail->adam, tail->h, (int64_t)xd.gstride, seed_stride); }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
       return 0;
     }
+    dwAll.stamps = nullptr;
     CURIOUS_CHECK(xd.nex == 1 || !tail, "batched experts need the fused update tail");
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
-      hipLaunchKernelGGL(dw_all_kernel, dim3(tAll + nsmall + 1, xd.nex), dim3(256), 0, st, dwAll, xd.stride, xd.gstride); }
+      const int gx = dw_grid(0);
+      hipLaunchKernelGGL(dw_all_kernel, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob, smAll.slots,
+                         smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
+                         (int64_t)xd.gstride); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
     if (rows_pending && launch_rows()) return -1;

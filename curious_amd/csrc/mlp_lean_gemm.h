@@ -37,6 +37,52 @@ __device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int
   }
 }
 
+// The optimiser's two scalar inputs without their latency: a tile used to begin with  load fault word -> wait -> load
+// step counter -> wait -> (64-bit modulo) -> load step sizes -> ... -> first operand load, three dependent round trips
+// through cold caches before its own 80 KB were even requested.  adam_early() only ISSUES the two loads (branch-free: a
+// NULL pointer reads a valid dummy address and is masked later); the verdict on the fault word is taken in the tile's
+// epilogue, and the step sizes are looked up (adam_alphas_late) once the tile's operand loads are in flight -- their
+// round trip hides behind the matrix instructions.
+// (PIN_V: an empty asm that takes the value through a vector register.  The loaded words are uniform, and hipcc would
+//  move them to scalar registers -- v_readfirstlane behind an s_waitcnt -- right where they are loaded; behind the pin
+//  they count as per-lane values, so the wait sits where the pin is and the arithmetic that follows stays in the VALU.)
+#define PIN_V(x) asm volatile("" : "+v"(x))
+#define DW_INLINE __forceinline__
+
+struct AdamEarly { int32_t fw, lo, hi; };
+__device__ inline AdamEarly adam_early(const AdamFuse& A, int64_t eo) {
+  AdamEarly e;
+
+  const int32_t* fp = A.fault ? reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(A.fault) + eo)
+                              : reinterpret_cast<const int32_t*>(A.theta);
+  const int64_t* cp = A.alpha_tab ? ex_i64(A.step_ctr, eo) : reinterpret_cast<const int64_t*>(A.theta);
+  e.fw = *fp;
+  const int64_t c = *cp;
+  e.lo = (int32_t)c; e.hi = (int32_t)(c >> 32);
+  return e;
+}
+__device__ inline bool adam_early_faulted(const AdamFuse& A, AdamEarly& e) {
+  PIN_V(e.fw);
+  return A.fault && e.fw != 0;
+}
+__device__ inline void adam_alphas_late(const AdamFuse& A, AdamEarly& e, float& aQ, float& aPi, int64_t eo) {
+  aQ = A.a_Q; aPi = A.a_pi;
+  if (A.alpha_tab) {
+    PIN_V(e.lo); PIN_V(e.hi);
+    const int64_t ctr = (int64_t)(((uint64_t)(uint32_t)e.hi << 32) | (uint32_t)e.lo);
+    const int64_t v = ctr + A.step_add - 1 - A.tab_base;
+    int64_t idx;
+    if ((A.tab_len & (A.tab_len - 1)) == 0) {
+      idx = v & (int64_t)(A.tab_len - 1);                   // the ring of ALPHA_TAB = 4096 entries: no 64-bit division
+    } else {
+      idx = v % A.tab_len;
+      if (idx < 0) idx += A.tab_len;
+    }
+    aQ = A.alpha_tab[eo + 2 * idx];
+    aPi = A.alpha_tab[eo + 2 * idx + 1];
+  }
+}
+
 __device__ inline float adam_elem(const AdamFuse& A, float na, float g, float& m, float& v, float th) {
   m = __fadd_rn(__fmul_rn(A.b1, m), __fmul_rn(A.omb1, g));                       // mpi_adam.py:31
   v = __fadd_rn(__fmul_rn(A.b2, v), __fmul_rn(A.omb2, __fmul_rn(g, g)));         // mpi_adam.py:32
@@ -230,11 +276,9 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
-__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
-                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr) {
-  // problem and tile from arithmetic on the block id: the descriptor load below does not wait for another load
-  const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
-  const GemmHot& P = args.p[pi];
+__device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const int t, float* red,
+                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
+                                   DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
   const int nx = P.N >> 6;
   const int by = t / nx, bx = t - by * nx;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
@@ -250,9 +294,9 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
   AdamPre4 pre;
   float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
   bool faulted = false;
+  AdamEarly early;
   if (ADAM) {
-    faulted = adam_faulted(A, eo);
-    adam_alphas(A, aQ, aPi, eo);
+    early = given ? *given : adam_early(A, eo);
     pre = adam_prefetch4(A, pidx + eo);
     if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
@@ -260,7 +304,6 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
     // one-launch update: the optimiser operands above are in flight; the activations and gradients below exist once
     // the row groups of this matrix's network have published (and nobody reads the matrix any more)
     if (!step_wait(*S, ((int64_t)(P.C - A.grad) < A.n_Q) ? 3u : 4u)) return;
-    faulted = adam_faulted_now(A);
   }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
@@ -279,6 +322,7 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
       }
     }
     LOADS_FIRST();
+    DW_STAMP(stamps, 1);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -289,6 +333,14 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
       }
   }
   if (S && S->st && tid == 0) S->st[3] = __builtin_readcyclecounter();
+  DW_STAMP(stamps, 2);
+  if (ADAM) {
+    // the matrix instructions are issued: the step counter has long arrived, the look-up of the step sizes hides behind
+    // the reduction of the tile.  (Outside the loop on purpose: a pinned value redefined inside it becomes loop-carried,
+    // and the copy in front of the loop waits for the load -- before the tile's operands are even requested.)
+    adam_alphas_late(A, early, aQ, aPi, eo);
+    faulted = S ? adam_faulted_now(A) : adam_early_faulted(A, early);
+  }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   *reinterpret_cast<f32x4*>(dst) = v;
@@ -320,6 +372,15 @@ __device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, con
 }
 
 
+template <bool ADAM>
+__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
+                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
+                                   DwStamp* stamps = nullptr) {
+  // problem and tile from arithmetic on the block id: the descriptor load does not wait for another load
+  const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
+  dw_hot_tile<ADAM>(args.p[pi], A, t, red, eo, eg, S, stamps);
+}
+
 // Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
 //   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
 struct DwSmall {
@@ -339,8 +400,9 @@ struct DwSmallArgs {
 // layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
 template <bool ADAM, bool YV>
-__device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
-                                     const int64_t eo, const int64_t eg, const StepSync* S) {
+__device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
+                                     const int64_t eo, const int64_t eg, const StepSync* S,
+                                     DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   const int by = t / nx, bx = t - by * nx;
@@ -362,9 +424,9 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   AdamPre4 pre;
   pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
   bool faulted = false;
+  AdamEarly early;
   if (ADAM) {
-    faulted = adam_faulted(A, eo);
-    adam_alphas(A, aQ, aPi, eo);
+    early = given ? *given : adam_early(A, eo);
     if (YV) {
       pre = adam_prefetch4(A, (own ? pidx : 0) + eo);
     } else if (own) {                                       // N == 1: one element per owning thread
@@ -374,7 +436,6 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
   }
   if (S) {
     if (!step_wait(*S, ((int64_t)(P.dW - A.grad) < A.n_Q) ? 3u : 4u)) return;
-    faulted = adam_faulted_now(A);
   }
   // dQ / dz: a 128-byte line holds the values of several row groups, written on different XCDs -> agent-coherent loads
   const bool ycoh = S && P.lddy < 64;
@@ -408,6 +469,7 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
       }
     }
     LOADS_FIRST();
+    DW_STAMP(stamps, 1);
     if (P.div != 1.0f) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -427,6 +489,11 @@ __device__ inline void dw_small_tile(const DwSmall& P, const int M, const AdamFu
           acc[0] = MFMA(av, b[u][s][0], acc[0]);
         }
       }
+  }
+  DW_STAMP(stamps, 2);
+  if (ADAM) {
+    adam_alphas_late(A, early, aQ, aPi, eo);
+    faulted = S ? adam_faulted_now(A) : adam_early_faulted(A, early);
   }
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
@@ -500,20 +567,21 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
 }
 
 template <bool ADAM>
-__device__ inline void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
-                                     const int64_t eo, const int64_t eg, const StepSync* S = nullptr) {
+__device__ DW_INLINE void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
+                                     const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
+                                     DwStamp* stamps = nullptr) {
   // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
   // arithmetic, so the descriptor load does not wait for a search through the table
   const int pi = bid / args.slots, t = bid - pi * args.slots;
   if (pi >= args.nprob) {
-    // extra last block (only launched when fin.rows != NULL)
-    dw_loss_fin(args.fin, red, eo, eg, S);
+    // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
+    if (pi == args.nprob && t == 0) dw_loss_fin(args.fin, red, eo, eg, S);
     return;
   }
   const DwSmall& P = args.p[pi];
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S);
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S, stamps);
+  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S, stamps);
 }
 
 // item `it` of the compact tile list (DwSmallArgs.tile0)
@@ -532,14 +600,115 @@ __device__ inline void dw_small_item(const DwSmallArgs& args, const AdamFuse& A,
 // hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
 // launches only bought a second ~4.5 us dependent stage).
 // (batched experts: blockIdx.y = expert, as in dw_adam_her_kernel below)
-struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; };
-__global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args, int64_t ex_stride, int64_t grad_stride) {
+// XCD-aware block placement (xcd = 1; grid.x = 8 * (r_her + r_hot + r_small)).  Workgroups are dealt round-robin over
+// the 8 XCDs in block-id order, so x = blockIdx.x & 7 IS the XCD and r = blockIdx.x >> 3 a row of 8 blocks, one per XCD:
+//   r <  r_her                : gather block r * 8 + x
+//   r <  r_her + r_hot        : hidden-layer tile; XCD x owns `units`-th part u = x % units of matrix x / units -- its
+//                               r_hot = 64 / units tiles are the row strips [u, u + 1) * 16 / units x all 4 column panels,
+//                               i.e. ONE XCD's L2 fetches that part of X and the matrix's dY once, instead of every XCD
+//                               fetching a quarter panel of every matrix (1.25 MB per XCD at Arm4 -> 0.38 MB)
+//   otherwise                 : small problem p = x + 8 * (j / slots), tile j % slots (j = r - r_her - r_hot): the tiles
+//                               of one small problem share an XCD; the block behind the last problem finalises the losses
+// Speed only -- nothing depends on the placement for correctness.
+// The routing scalars travel as the kernel's LEADING arguments: with -mllvm -amdgpu-kernarg-preload-count they arrive in
+// scalar registers with the wave (kernarg preloading, gfx940+), so a block knows its role without a single memory access.
+// That matters because reads of the kernarg segment are not cached on this machine: EVERY dependent s_load of an argument
+// costs a full ~3 k-cycle (1.4 us) round trip (tools/dw_stamps.py: a block that finds it has nothing to do used to need
+// 3 k cycles to find out; a hidden tile issued its operand loads 6 k cycles after its start, a small tile 10-12 k).
+struct DwMap { int32_t r_her, r_hot, units; };                // units == 0: plain block order
+struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; };
+// lab (a build with -DDW_STAMPS, tools/build_variant.py, + option "lab_dw_stamps"): 8 x 64-bit words per block of expert 0 -- [0] entry, [1] operand loads issued /
+// gather: tables in, [2] MFMA loop over / gather: rows in LDS, [3] exit, [4] kind (0 gather, 1 hidden tile, 2 small),
+// [5] s_memrealtime at entry (100 MHz, device-wide)
+__device__ inline unsigned long long* dw_stamp_base(const DwAllArgs& a) {
+  return (a.stamps && blockIdx.y == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+}
+struct DwRole { int kind, pi, idx; };
+__device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, const int hot_nprob, const int slots,
+                                          const int n_her, const int r_her, const int r_hot, const int units) {
+  DwRole R;
+  R.kind = -1; R.pi = 0; R.idx = 0;
+  const int b = (int)blockIdx.x;
+  if (units == 0) {
+    const int bid = b - n_her;
+    if (bid < 0) { R.kind = 0; R.idx = b; }
+    else if (bid < n_hot) { R.kind = 1; R.pi = bid / tiles_per; R.idx = bid - R.pi * tiles_per; }
+    else { R.kind = 2; R.idx = bid - n_hot; }
+    return R;
+  }
+  const int x = b & 7, r = b >> 3;
+  if (r < r_her) {
+    if (r * 8 + x < n_her) { R.kind = 0; R.idx = r * 8 + x; }
+  } else if (r < r_her + r_hot) {
+    const int pi = x / units, u = x - pi * units;
+    if (pi < hot_nprob) { R.kind = 1; R.pi = pi; R.idx = u * r_hot + (r - r_her); }
+  } else {
+    const int j = r - r_her - r_hot;
+    const int p = x + 8 * (j / slots);
+    R.kind = 2; R.idx = p * slots + j % slots;
+  }
+  return R;
+}
+// One batch of argument loads per block: a by-value copy of everything the role needs, taken through an empty asm that
+// wants every field in a scalar register AT THIS POINT -- the compiler then issues all the s_loads together and waits
+// once, instead of fetching field by field, branch by branch (one uncached round trip each).
+#define PIN_S(x) "+s"(x)
+__device__ __forceinline__ void pin_hot(GemmHot& P) {
+  asm volatile("" : PIN_S(P.A), PIN_S(P.B), PIN_S(P.C), PIN_S(P.aux_out), PIN_S(P.dot_out), PIN_S(P.lda), PIN_S(P.ldb),
+               PIN_S(P.ldc), PIN_S(P.M), PIN_S(P.N), PIN_S(P.K));
+}
+__device__ __forceinline__ void pin_small(DwSmall& P) {
+  asm volatile("" : PIN_S(P.x), PIN_S(P.dY), PIN_S(P.dW), PIN_S(P.db), PIN_S(P.ldx), PIN_S(P.lddy), PIN_S(P.w), PIN_S(P.N),
+               PIN_S(P.div));
+}
+__device__ __forceinline__ void pin_adam(AdamFuse& A) {
+  asm volatile("" : PIN_S(A.theta), PIN_S(A.m), PIN_S(A.v), PIN_S(A.grad), PIN_S(A.n_Q), PIN_S(A.alpha_tab),
+               PIN_S(A.step_ctr), PIN_S(A.tab_base), PIN_S(A.tab_len), PIN_S(A.a_Q), PIN_S(A.a_pi), PIN_S(A.b1),
+               PIN_S(A.omb1), PIN_S(A.b2), PIN_S(A.omb2), PIN_S(A.eps), PIN_S(A.fault), PIN_S(A.step_add));
+}
+
+// (the leading scalars: preloaded into SGPRs, see DwMap)
+#define DW_ROUTE_PARAMS const int tiles_per, const int hot_nprob, const int slots, const int small_nprob, const int n_her, \
+                        const int r_her, const int r_hot, const int units
+// the tile work of a block whose role is known: ONE batch of argument loads, then the tile
+template <bool ADAM>
+__device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& args, const AdamFuse& A_, const int slots,
+                                             const int small_nprob, float* red, const int64_t eo, int64_t grad_stride,
+                                             DwStamp* sp, const AdamEarly* early) {
+  AdamFuse A = A_;
+  if (R.kind == 1) {
+    GemmHot P = args.hot.p[R.pi];
+    pin_hot(P);
+    if (ADAM) pin_adam(A);
+    asm volatile("" : "+s"(grad_stride));
+    dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, nullptr, sp, early);
+    return;
+  }
+  const int pi = R.idx / slots, t = R.idx - pi * slots;
+  if (pi >= small_nprob) {
+    // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
+    if (pi == small_nprob && t == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride, nullptr);
+    return;
+  }
+  DwSmall P = args.small.p[pi];
+  int M = args.small.M;
+  pin_small(P);
+  if (ADAM) pin_adam(A);
+  asm volatile("" : "+s"(grad_stride), "+s"(M));
+  if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
+  const int64_t eg = (int64_t)blockIdx.y * grad_stride;
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, nullptr, sp, early);
+  else dw_small_tile<ADAM, false>(P, M, A, t, red, eo, eg, nullptr, sp, early);
+}
+
+__global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
+                                                     int64_t grad_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   AdamFuse none;
   none.fault = nullptr;
-  const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
-  if ((int)blockIdx.x < args.n_hot) dw_hot_body<false>(args.hot, none, blockIdx.x, red, eo, eg);
-  else dw_small_body<false>(args.small, none, (int)blockIdx.x - args.n_hot, red, eo, eg);
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, 0, r_her, r_hot, units);
+  if (R.kind > 0) dw_tile_role<false>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
 }
 
 // The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
@@ -548,12 +717,40 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DwAllArgs args, int64_t ex_
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
-__global__ __launch_bounds__(256) void dw_adam_her_kernel(DwAllArgs args, AdamFuse A, HerArgs h, int n_her,
-                                                          int64_t ex_stride, int64_t grad_stride, uint64_t seed_stride) {
+__global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
+                                                          int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
+                                                          int64_t grad_stride, uint64_t seed_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  const int bid = (int)blockIdx.x - n_her;
-  const int64_t eo = (int64_t)blockIdx.y * ex_stride, eg = (int64_t)blockIdx.y * grad_stride;
-  if (bid < 0) her_sample_body(h, blockIdx.x, red, eo, (uint64_t)blockIdx.y * seed_stride);
-  else if (bid < args.n_hot) dw_hot_body<true>(args.hot, A, bid, red, eo, eg);
-  else dw_small_body<true>(args.small, A, bid - args.n_hot, red, eo, eg);
+#ifdef DW_STAMPS
+  DwStamp stamp;
+  stamp.t[0] = __builtin_readcyclecounter();                 // (before anything of the arguments is read)
+  stamp.t[1] = stamp.t[2] = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  DwStamp* sp = &stamp;
+#else
+  DwStamp* sp = nullptr;
+#endif
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, n_her, r_her, r_hot, units);
+  if (R.kind == 0) {
+    her_sample_body(h, R.idx, red, eo, (uint64_t)blockIdx.y * seed_stride, 0, sp);
+  } else if (R.kind > 0) {
+    // the optimiser's two scalar inputs (fault word, step counter): their pointers came with the wave, so the loads go
+    // out before the first argument is fetched from memory (fault0 / ctr0 == A.fault / A.step_ctr or a valid dummy)
+    AdamEarly early;
+    {
+      early.fw = *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(fault0) + eo);
+      const int64_t c = *ex_i64(ctr0, eo);
+      early.lo = (int32_t)c; early.hi = (int32_t)(c >> 32);
+    }
+    dw_tile_role<true>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
+  }
+#ifdef DW_STAMPS
+  unsigned long long* st = dw_stamp_base(args);
+  if (st && threadIdx.x == 0) {
+    st[0] = stamp.t[0]; st[1] = stamp.t[1]; st[2] = stamp.t[2]; st[3] = __builtin_readcyclecounter();
+    st[4] = (unsigned long long)(R.kind + 1); st[5] = rt0;
+    st[6] = (unsigned long long)R.pi; st[7] = (unsigned long long)R.idx;
+  }
+#endif
 }

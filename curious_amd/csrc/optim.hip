@@ -42,6 +42,47 @@ __device__ __forceinline__ void adam_note_fault(const AdamArgs& a, const int64_t
   if (a.keep.fault_flag > 0 && a.grad[eg + a.keep.fault_flag - 1] != 0.0f && *word == 0) atomicAdd(word, 1);
 }
 
+// The launch's three scalar inputs -- fault word, collective fault flag, step counter -- without their latency (round 4;
+// mlp_lean_gemm.h adam_early / PIN_V): a block used to begin with  load fault word, wait; load step counter, wait; load
+// step sizes, wait; -- three dependent round trips through cold caches before its first operand was requested, in a
+// kernel of 6 us.  adam_scalars() only ISSUES the loads (branch-free: a NULL pointer reads a valid dummy and is masked
+// later); the verdict and the step sizes are taken (adam_verdict) when the block's first operands are in flight.
+#define OPT_PIN_V(x) asm volatile("" : "+v"(x))
+struct AdamScalars { int32_t fw, lo, hi; float flag; };
+__device__ __forceinline__ AdamScalars adam_scalars(const AdamArgs& a, const int64_t eo, const int64_t eg) {
+  AdamScalars s;
+  const int32_t* fp = a.keep.fault ? reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(a.keep.fault) + eo)
+                                   : reinterpret_cast<const int32_t*>(a.theta);
+  const float* gp = (a.keep.fault && a.keep.fault_flag > 0) ? a.grad + eg + a.keep.fault_flag - 1 : a.theta;
+  const int64_t* cp = a.alpha_tab ? opt_i64(a.step_ctr, eo) : reinterpret_cast<const int64_t*>(a.theta);
+  s.fw = *fp;
+  s.flag = *gp;
+  const int64_t c = *cp;
+  s.lo = (int32_t)c; s.hi = (int32_t)(c >> 32);
+  return s;
+}
+// false: the launch leaves everything alone (adam_faulted); otherwise the step sizes of this update
+__device__ __forceinline__ bool adam_verdict(const AdamArgs& a, AdamScalars& s, float& aQ, float& aPi, const int64_t eo) {
+  OPT_PIN_V(s.fw); OPT_PIN_V(s.flag); OPT_PIN_V(s.lo); OPT_PIN_V(s.hi);
+  aQ = a.a_Q; aPi = a.a_pi;
+  if (a.alpha_tab) {
+    const int64_t ctr = (int64_t)(((uint64_t)(uint32_t)s.hi << 32) | (uint32_t)s.lo);
+    const int64_t v = ctr - 1 - a.tab_base;
+    int64_t idx;
+    if ((a.tab_len & (a.tab_len - 1)) == 0) {
+      idx = v & (int64_t)(a.tab_len - 1);
+    } else {
+      idx = v % a.tab_len;
+      if (idx < 0) idx += a.tab_len;
+    }
+    aQ = a.alpha_tab[eo + 2 * idx];
+    aPi = a.alpha_tab[eo + 2 * idx + 1];
+  }
+  const bool local = a.keep.fault && s.fw != 0;
+  const bool collective = a.keep.fault && a.keep.fault_flag > 0 && s.flag != 0.0f;
+  return !(local || collective);
+}
+
 __device__ __forceinline__ void adam_alphas(const AdamArgs& a, float& aQ, float& aPi, const int64_t eo) {
   aQ = a.a_Q; aPi = a.a_pi;
   if (a.alpha_tab) {
@@ -74,12 +115,9 @@ typedef float f32x4_o __attribute__((ext_vector_type(4)));
 // layout of curious_param_total) -- one thread then takes 4 consecutive elements with 16-byte loads and stores
 __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, const int nblocks, const int64_t eo,
                                           const int64_t eg, const bool vec4) {
-  if (adam_faulted(a, eo, eg)) {
-    if (block == 0 && threadIdx.x == 0) adam_note_fault(a, eo, eg);
-    return;
-  }
-  float aQ, aPi;
-  adam_alphas(a, aQ, aPi, eo);
+  AdamScalars sc = adam_scalars(a, eo, eg);
+  float aQ = 0.f, aPi = 0.f;
+  bool go = true, decided = false;
   const int64_t msize = (int64_t)a.keep.dim * a.keep.dim;
   if (vec4) {
     for (int64_t i = ((int64_t)block * 256 + threadIdx.x) * 4; i < a.n; i += (int64_t)nblocks * 1024) {
@@ -89,6 +127,12 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
       const f32x4_o g = *reinterpret_cast<const f32x4_o*>(a.grad + i + eg);
       f32x4_o m = *reinterpret_cast<const f32x4_o*>(a.m + i + eo), v = *reinterpret_cast<const f32x4_o*>(a.v + i + eo);
       f32x4_o th = *reinterpret_cast<const f32x4_o*>(a.theta + i + eo);
+      if (!decided) {                                       // (the first operands are in flight: now the verdict)
+        __builtin_amdgcn_sched_barrier(0);
+        go = adam_verdict(a, sc, aQ, aPi, eo);
+        decided = true;
+      }
+      if (!go) break;
       const float na = (i < a.n_Q) ? -aQ : -aPi;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -100,6 +144,13 @@ __device__ __forceinline__ void adam_body(const AdamArgs& a, const int block, co
       *reinterpret_cast<f32x4_o*>(a.v + i + eo) = v;
       *reinterpret_cast<f32x4_o*>(a.theta + i + eo) = th;
     }
+    if (!decided) go = adam_verdict(a, sc, aQ, aPi, eo);
+    if (!go && block == 0 && threadIdx.x == 0) adam_note_fault(a, eo, eg);
+    return;
+  }
+  go = adam_verdict(a, sc, aQ, aPi, eo);
+  if (!go) {
+    if (block == 0 && threadIdx.x == 0) adam_note_fault(a, eo, eg);
     return;
   }
   for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.n; i += (int64_t)nblocks * 256) {
@@ -121,9 +172,8 @@ static inline bool adam_vec4(const AdamArgs& a, int64_t expert_stride, int64_t g
 #define ADAM_TILE 32
 __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, float (*tile)[ADAM_TILE + 1],
                                                const int64_t eo, const int64_t eg) {
-  if (adam_faulted(a, eo, eg)) return;
+  AdamScalars sc = adam_scalars(a, eo, eg);
   float aQ, aPi;
-  adam_alphas(a, aQ, aPi, eo);
   const int dim = a.keep.dim, per = dim / ADAM_TILE;
   const int j = tb / (per * per), t = tb - j * per * per;
   const int k0 = (t / per) * ADAM_TILE, n0 = (t % per) * ADAM_TILE;
@@ -138,6 +188,8 @@ __device__ __forceinline__ void adam_tile_body(const AdamArgs& a, const int tb, 
     const int64_t e = base + (int64_t)(k0 + 8 * i + r8) * dim + n0 + c;
     g[i] = a.grad[e + eg]; m[i] = a.m[e + eo]; v[i] = a.v[e + eo]; th[i] = a.theta[e + eo];
   }
+  __builtin_amdgcn_sched_barrier(0);
+  if (!adam_verdict(a, sc, aQ, aPi, eo)) return;            // (uniform over the workgroup: nobody reaches the barrier)
   const float na = (base < a.n_Q) ? -aQ : -aPi;             // a matrix lies inside one network
 #pragma unroll
   for (int i = 0; i < NE; ++i) {

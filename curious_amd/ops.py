@@ -475,3 +475,12 @@ def fault_word(cfg, B, workspace, n=1):
     if off < 0:
         raise _lib.CuriousHipError('curious_workspace_fault_offset: bad arguments')
     return _dev(workspace, 'workspace')[off:off + n].view(torch.int32)
+
+
+def dw_stamps(cfg, B, workspace, n_blocks):
+    """Lab (option 'lab_dw_stamps'): the [n_blocks, 8] int64 cycle stamps the weight-gradient / optimiser launch left in
+    the workspace (curious_workspace_stamps_offset)."""
+    off = int(lib().curious_workspace_stamps_offset(C.byref(cfg), int(B)))
+    if off < 0:
+        raise _lib.CuriousHipError('curious_workspace_stamps_offset: bad arguments')
+    return workspace[off:off + 16 * n_blocks].view(torch.int64).view(n_blocks, 8)

@@ -238,6 +238,9 @@ int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
  * knows the workspace (curious_ddpg_update*, curious_adam_update* given curious_ddpg_transposed()) leaves theta, m, v
  * and the transposed copies untouched: the caller reads the word once per cycle, raises, and clears it. */
 int64_t curious_workspace_fault_offset(const curious_net_cfg_t* cfg, int32_t B);
+/* Lab only (option "lab_dw_stamps", tools/dw_stamps.py): float offset of the area of the workspace -- unused on the
+ * row-local route -- into which the weight-gradient / optimiser launch writes 8 64-bit cycle stamps per block. */
+int64_t curious_workspace_stamps_offset(const curious_net_cfg_t* cfg, int32_t B);
 
 /* Where the device-drawn HER gather of the NEXT update's batch goes (curious_her_sample with `rng`) when it rides along
  * with another call: replay storage + layouts + sampler description + the staging tensor to fill. */
