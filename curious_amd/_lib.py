@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 7          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 8          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -151,10 +151,10 @@ PROTOTYPES = {
                                          _P, _I32, _I32, _D, _P, _P]),
     'curious_policy_act_env_step_stats': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
                                                     C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _P, _P, _P,
-                                                    _P, _P, _I32, _I32, _D, _P, _P, _P, _P]),
+                                                    _P, _P, _I32, _I32, _D, _P, _I32, _P, _P, _P]),
     'curious_policy_rollout_stats': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
                                                C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _I32, _P, _P, _P,
-                                               _P, _P, _I32, _I32, _D, _P, _P, _P, _P]),
+                                               _P, _P, _I32, _I32, _D, _P, _I32, _P, _P, _P]),
     'curious_route_store_episodes': (C.c_int, [_P, _P, C.POINTER(Layout), _P, _I32, _I32, _I32, _P, _P, _I64, _U64, _U64,
                                                _P, _P, _P, _P, _P]),
     'curious_store_slots_host': (C.c_int, [_U64, _U64, _I32, _I64, _I32, _P, _P]),

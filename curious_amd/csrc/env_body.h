@@ -47,7 +47,12 @@ __device__ inline EnvConsts env_consts(const curious_env_cfg_t& E, const curious
 // a workgroup group that step the same envs redundantly (mlp_rows_res.h) leave the stores to one of them.
 // what the policy's input normalisation does to an observation entry on its way into the next step's input row
 // (actor_critic.py:76-83); mean == NULL: nothing
-struct InNorm { const float* mean; const float* stdv; float nclip; };
+// rel_off >= 0: relative goals (ddpg.py:119-124): the goal part of the input row, at column rel_off, is g - ag of the NEW
+// achieved goal (clipped, then normalised with g_mean / g_std when given) -- it changes with every step
+struct InNorm {
+  const float* mean; const float* stdv; float nclip;
+  int rel_off = -1; const float* g_mean = nullptr; const float* g_std = nullptr;
+};
 
 template <bool STORE = true>
 __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_layout_t& L, int32_t env_id0,
@@ -102,6 +107,12 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
       float w = (in_clip > 0.f) ? fclip(nv, -in_clip, in_clip) : nv;
       if (nrm.mean) w = fclip(fdiv(__fsub_rn(w, nrm.mean[i]), nrm.stdv[i]), -nrm.nclip, nrm.nclip);
       next_in[i] = w;
+      if (nrm.rel_off >= 0 && i < AG) {                     // (the achieved goal = the first AG observation entries)
+        float r = __fsub_rn(C.ge_i, nv);                                                  // ddpg.py:121-123
+        if (in_clip > 0.f) r = fclip(r, -in_clip, in_clip);                               // ddpg.py:126
+        if (nrm.g_mean) r = fclip(fdiv(__fsub_rn(r, nrm.g_mean[i]), nrm.g_std[i]), -nrm.nclip, nrm.nclip);
+        next_in[nrm.rel_off + i] = r;
+      }
     }
   }
   if (STORE && i < E.dimo) {

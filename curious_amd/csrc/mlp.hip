@@ -602,7 +602,8 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
                                 const int32_t* episode, const int32_t* tasks, int32_t t, int32_t nsteps, float* o,
                                 float* ag, const float* g, const float* td, float* staging, int32_t off_change,
                                 int32_t off_success, double reward_eps, float* flags, curious_stream_t stream,
-                                const float* o_stats = nullptr, const float* g_stats = nullptr) {
+                                const float* o_stats = nullptr, const float* g_stats = nullptr,
+                                int32_t relative_goals = 0) {
   if (check_cfg(cfg)) return -1;
   CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
                 "curious_policy_act_env_step: NULL argument");
@@ -625,6 +626,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   if (act_rows_ok(cfg, n, false, theta, true) && aligned16(thPi)) {
     ActRowsArgs a;
     memset(&a, 0, sizeof(a));
+    if (relative_goals) { a.ag = ag; a.ldag = 3 * E->ntasks; }   // (dimag == dimg == 3 ntasks in this env)
     a.o_mean = st_in.o_mean; a.o_std = st_in.o_std; a.g_mean = st_in.g_mean; a.g_std = st_in.g_std; a.nclip = st_in.nclip;
     a.pi = rows_net(thPi, offPi, nl);
     a.o = o; a.td = td; a.g = g; a.ldo = E->dimo; a.ldtd = E->ntasks; a.ldg = 3 * E->ntasks; a.clip = clip_obs;
@@ -637,7 +639,8 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     a.episode = episode; a.tasks = tasks; a.eo = o; a.eag = ag; a.staging = staging; a.reward_eps = reward_eps;
     a.flags = flags;
     // the exchange buffer of the resident form is the head of the workspace (the row-local routes use nothing else of it)
-    if (resident_ok(a, n, workspace) &&
+    // (relative goals: the streaming kernel -- the resident form does not carry the goal part through its exchanges)
+    if (!relative_goals && resident_ok(a, n, workspace) &&
         (int64_t)res_xbuf_floats(n) <= curious_workspace_floats(cfg, n) && aligned16(workspace))
       return launch_policy_resident(a, n, workspace, curious_workspace_floats(cfg, n), st);
     return launch_policy_rows(a, n, st);
@@ -646,7 +649,8 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     for (int s = 0; s < nsteps; ++s) {
       const int rc = policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter + s,
                                           counter_base, u_out, ldu, E, L, env_id0, episode, tasks, t + s, 1, o, ag, g, td,
-                                          staging, off_change, off_success, reward_eps, flags, stream, o_stats, g_stats);
+                                          staging, off_change, off_success, reward_eps, flags, stream, o_stats, g_stats,
+                                          relative_goals);
       if (rc) return rc;
     }
     return 0;
@@ -655,6 +659,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   memset(&in, 0, sizeof(in));
   in.o = o; in.ldo = E->dimo; in.td = td; in.ldtd = E->ntasks; in.g = g; in.ldg = 3 * E->ntasks;
   in.clip = clip_obs;
+  if (relative_goals) { in.ag = ag; in.ldag = 3 * E->ntasks; in.relative = 1; }
   fill_obs_stats(cfg, in, o_stats, g_stats);
   Chain a;
   a.theta = thPi; a.off = offPi; a.in = in; a.critic = false; a.act = w.act[2]; a.store_h0 = false;
@@ -715,10 +720,11 @@ extern "C" int curious_policy_act_env_step_stats(const curious_net_cfg_t* cfg, c
                                                  const int32_t* tasks, int32_t t, float* o, float* ag, const float* g,
                                                  const float* td, float* staging, int32_t off_change,
                                                  int32_t off_success, double reward_eps, float* flags,
-                                                 const float* o_stats, const float* g_stats, curious_stream_t stream) {
+                                                 int32_t relative_goals, const float* o_stats, const float* g_stats,
+                                                 curious_stream_t stream) {
   return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
                               u_out, ldu, E, L, env_id0, episode, tasks, t, 1, o, ag, g, td, staging, off_change,
-                              off_success, reward_eps, flags, stream, o_stats, g_stats);
+                              off_success, reward_eps, flags, stream, o_stats, g_stats, relative_goals);
 }
 
 extern "C" int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
@@ -728,11 +734,12 @@ extern "C" int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const 
                                             const int32_t* episode, const int32_t* tasks, int32_t t0, int32_t nsteps,
                                             float* o, float* ag, const float* g, const float* td, float* staging,
                                             int32_t off_change, int32_t off_success, double reward_eps, float* flags,
-                                            const float* o_stats, const float* g_stats, curious_stream_t stream) {
+                                            int32_t relative_goals, const float* o_stats, const float* g_stats,
+                                            curious_stream_t stream) {
   CURIOUS_CHECK(nsteps >= 1, "curious_policy_rollout: nsteps must be positive");
   return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
                               u_out, ldu, E, L, env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, off_change,
-                              off_success, reward_eps, flags, stream, o_stats, g_stats);
+                              off_success, reward_eps, flags, stream, o_stats, g_stats, relative_goals);
 }
 
 // What follows the gradients in curious_ddpg_update: Adam (+ the gather of the next batch).

@@ -32,7 +32,7 @@ struct ActRowsArgs {
   // input normalisation (curious_policy_forward, curious_policy_*_stats): mean / std of the normalisers or NULL
   const float *o_mean, *o_std, *g_mean, *g_std;
   float nclip;
-  // relative goals (ddpg.py:119-124, plain forward only): g - ag before the clip, or NULL
+  // relative goals (ddpg.py:119-124): g - ag before the clip, or NULL.  Fused steps: ag = the env's achieved goals
   const float* ag; int32_t ldag;
 };
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       ov = env_step_core(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
                          a.off_success, a.reward_eps, m, x.lane, a.flags, a.n,
                          (s + 1 < a.nsteps) ? x.xin + x.wave * XLD : nullptr, a.clip,
-                         InNorm{a.o_mean, a.o_std, a.nclip});
+                         InNorm{a.o_mean, a.o_std, a.nclip, a.ag ? Sc : -1, a.g_mean, a.g_std});
     }
     return;
   }

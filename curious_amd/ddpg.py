@@ -282,7 +282,7 @@ class DDPG(object):
     def can_act_and_step(self, env, compute_Q):
         """The fused acting step applies to the GPU-resident synthetic env in throughput mode."""
         return (self.rng_mode == 'device' and not compute_Q and self.modular
-                and not self.relative_goals and self.dimu == 4 and hasattr(env, 'step_all')
+                and self.dimu == 4 and hasattr(env, 'step_all')
                 and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
 
     def act_and_step(self, env, t, noise_eps=0., random_eps=0., use_target_net=False):
@@ -303,7 +303,8 @@ class DDPG(object):
                                 self._act_u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, t, env.o,
                                 env.ag, env.g, env.td, env.staging, REWARD_EPS, flags=getattr(env, 'flags', None),
                                 o_stats=self.o_stats.state if self.normalize_obs else None,
-                                g_stats=self.g_stats.state if self.normalize_obs else None)
+                                g_stats=self.g_stats.state if self.normalize_obs else None,
+                                relative_goals=self.relative_goals)
         return self._act_u
 
     def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
@@ -341,7 +342,8 @@ class DDPG(object):
                                env.g, env.td, env.staging, REWARD_EPS, counter_base=self._noise_base,
                                flags=getattr(env, 'flags', None),
                                o_stats=self.o_stats.state if self.normalize_obs else None,
-                               g_stats=self.g_stats.state if self.normalize_obs else None)
+                               g_stats=self.g_stats.state if self.normalize_obs else None,
+                               relative_goals=self.relative_goals)
             ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T

@@ -34,6 +34,28 @@ def world_size():
     return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
 
 
+class _stdout_to_stderr:
+    """gloo announces every process group on the process's STDOUT from C++ ("[Gloo] Rank 0 is connected to ...").  A job
+    whose stdout is a protocol (bench.py: ONE JSON line) must not carry that: while a group is being created, file
+    descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        import sys
+        try:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:
+            self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 def init_from_env(backend=None):
     """Initialise the process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for 1 rank."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
@@ -46,8 +68,13 @@ def init_from_env(backend=None):
     if torch.cuda.is_available():
         torch.cuda.set_device(local_device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    td.init_process_group(backend=backend)
-    host_group()                                                     # (collective: every rank creates it here)
+    with _stdout_to_stderr():
+        td.init_process_group(backend=backend)
+        host_group()                                                 # (collective: every rank creates it here)
+        if td.get_backend() == 'gloo' or _HOST_GROUP:
+            # gloo connects (and announces itself) lazily, at the first collective of a group: have that happen here
+            t = torch.zeros(1)
+            td.all_reduce(t, group=host_group())
 
 
 _HOST_GROUP = None

@@ -379,24 +379,25 @@ def counter_add(p, delta):
 
 def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
                         env_id0, episode, tasks, t, o, ag, g, td, staging, reward_eps, counter_base=None, flags=None,
-                        o_stats=None, g_stats=None):
-    """o_stats / g_stats: the normalisers' state vectors for networks with input normalisation (the *_stats entry)."""
+                        o_stats=None, g_stats=None, relative_goals=False):
+    """o_stats / g_stats: the normalisers' state vectors for networks with input normalisation; relative_goals: the policy
+    sees g - ag (both through the *_stats entry)."""
     L = layout.c_layout()
     args = (C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs), ptr(workspace), float(noise_scale),
             float(random_eps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(counter_base), ptr(u_out),
             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), int(t), ptr(o),
             ptr(ag), ptr(g), ptr(td), ptr(staging), int(layout.off['change']), int(layout.off['info_is_success']),
             float(reward_eps), ptr(flags))
-    if o_stats is not None or g_stats is not None:
-        check(lib().curious_policy_act_env_step_stats(*args, ptr(o_stats), ptr(g_stats), current_stream()),
-              'curious_policy_act_env_step_stats')
+    if o_stats is not None or g_stats is not None or relative_goals:
+        check(lib().curious_policy_act_env_step_stats(*args, int(bool(relative_goals)), ptr(o_stats), ptr(g_stats),
+                                                      current_stream()), 'curious_policy_act_env_step_stats')
     else:
         check(lib().curious_policy_act_env_step(*args, current_stream()), 'curious_policy_act_env_step')
 
 
 def policy_rollout(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
                    env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, reward_eps, counter_base=None, flags=None,
-                   o_stats=None, g_stats=None):
+                   o_stats=None, g_stats=None, relative_goals=False):
     """nsteps x policy_act_env_step (steps t0 .. t0 + nsteps - 1, noise counters counter, counter + 1, ...); one launch
     on the row-local route."""
     L = layout.c_layout()
@@ -405,9 +406,9 @@ def policy_rollout(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, 
             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), int(t0), int(nsteps),
             ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging), int(layout.off['change']),
             int(layout.off['info_is_success']), float(reward_eps), ptr(flags))
-    if o_stats is not None or g_stats is not None:
-        check(lib().curious_policy_rollout_stats(*args, ptr(o_stats), ptr(g_stats), current_stream()),
-              'curious_policy_rollout_stats')
+    if o_stats is not None or g_stats is not None or relative_goals:
+        check(lib().curious_policy_rollout_stats(*args, int(bool(relative_goals)), ptr(o_stats), ptr(g_stats),
+                                                 current_stream()), 'curious_policy_rollout_stats')
     else:
         check(lib().curious_policy_rollout(*args, current_stream()), 'curious_policy_rollout')
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 7      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 8      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -483,23 +483,24 @@ int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int
  * g_stats = the state vectors of the observation / goal normalisers (layout as in curious_norm_recompute: mean at
  * 2 dim + 1, std at 3 dim + 1), applied to the clipped observation and goal on their way into the policy -- at the start
  * of the launch and, inside it, to every new observation the env step hands to the next acting step.  NULL statistics =
- * the entry points above. */
+ * the entry points above.  relative_goals != 0 (ddpg.py:118-127): the policy sees g - ag, recomputed from the new
+ * achieved goal after every env step (the row-local streaming kernel; the weights-resident form is not taken). */
 int curious_policy_act_env_step_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                                       float* workspace, double noise_scale, double random_eps, uint64_t seed,
                                       uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
                                       const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
                                       const int32_t* episode, const int32_t* tasks, int32_t t, float* o, float* ag,
                                       const float* g, const float* td, float* staging, int32_t off_change,
-                                      int32_t off_success, double reward_eps, float* flags, const float* o_stats,
-                                      const float* g_stats, curious_stream_t stream);
+                                      int32_t off_success, double reward_eps, float* flags, int32_t relative_goals,
+                                      const float* o_stats, const float* g_stats, curious_stream_t stream);
 int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                                  float* workspace, double noise_scale, double random_eps, uint64_t seed, uint64_t counter,
                                  const int64_t* counter_base, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
                                  const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
                                  const int32_t* tasks, int32_t t0, int32_t nsteps, float* o, float* ag, const float* g,
                                  const float* td, float* staging, int32_t off_change, int32_t off_success,
-                                 double reward_eps, float* flags, const float* o_stats, const float* g_stats,
-                                 curious_stream_t stream);
+                                 double reward_eps, float* flags, int32_t relative_goals, const float* o_stats,
+                                 const float* g_stats, curious_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ def synth_episodes(rng, E, nb, dimo):
 
 
 def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', use_graph=False, hidden=256, layers=3,
-               normalize_obs=False):
+               normalize_obs=False, relative_goals=False):
     """(product agent, oracle agent) with identical weights and empty buffers (normalize_obs: the product agent only --
     the oracle agent has no input normalisation; its networks do, tests/test_gpu_kernels.py)."""
     from curious_amd.ddpg import DDPG
@@ -64,7 +64,8 @@ def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', u
     agent = DDPG(input_dims=dims, hidden=hidden, layers=layers, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
                  polyak=0.95, batch_size=batch_size, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1.,
                  action_l2=1., clip_obs=200., scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None,
-                 relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=normalize_obs,
+                 relative_goals=relative_goals, clip_pos_returns=True, clip_return=1. / (1. - gamma),
+                 normalize_obs=normalize_obs,
                  sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
                  task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious', rng_mode=rng_mode, seed=seed,
                  use_graph=use_graph)
@@ -73,7 +74,7 @@ def build_pair(nb, dimo, cap_eps=64, batch_size=256, seed=3, rng_mode='numpy', u
                                                            tasks_g_id=g_ids)
     obufs = [OBuf(shapes, T * cap_eps, T, osampler) for _ in range(nb + 1)]
     oracle = OracleDDPG(dims, T, obufs, osampler, ag_ids, g_ids, hidden=hidden, layers=layers, batch_size=batch_size,
-                        weight_rng=np.random.RandomState(seed))
+                        weight_rng=np.random.RandomState(seed), relative_goals=relative_goals)
     return agent, oracle
 
 

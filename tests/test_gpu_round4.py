@@ -145,8 +145,9 @@ def test_bench_runs_end_to_end_on_two_ranks():
     out = _launch2([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--prefill', '256'],
                    _two_rank_env())
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-1500:]                        # rank 0 prints ONE line
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-1500:]   # stdout = rank 0's ONE line, nothing
+    #                                                                  else (gloo's own announcements go to stderr)
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
     assert rec['config']['parallelism'] == 'dp2'
@@ -363,3 +364,93 @@ def test_the_training_loop_survives_an_isolated_handoff_fault():
     with pytest.raises(HandoffFault):
         for _ in range(3 * FAULT_CHECK_EVERY):
             cycle()
+
+
+# ------------------------------------------------------------------ relative goals in the fused acting kernels
+@pytest.mark.parametrize('normalize_obs', [False, True])
+def test_relative_goals_in_the_fused_rollout(normalize_obs):
+    """ddpg.py:118-127 with relative_goals: the policy sees clip(g - ag), and ag changes with every env step.  Round 3
+    acted through one plain forward + noise + env-step launch per step in this mode; now curious_policy_rollout_stats /
+    curious_policy_act_env_step_stats carry the flag: the goal part of the policy's input row is recomputed from the new
+    achieved goal inside the env step.  (a) the one-launch rollout == one fused launch per step == the unfused sequence,
+    bit for bit, with exploration noise; (b) without noise the recorded actions are the oracle policy's on the recorded
+    observations (1e-4) and the oracle env reproduces the recorded episode exactly."""
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from oracle.env import SyntheticMultiTaskArm
+    from test_gpu_agent import T, build_pair
+    nb, dimo, B = 4, 40, 8
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+
+    def job(noise, seed=9):
+        agent, oracle = build_pair(nb, dimo, rng_mode='device', use_graph=False, relative_goals=True,
+                                   normalize_obs=normalize_obs, seed=seed)
+        if normalize_obs:                                            # non-trivial statistics
+            rng = np.random.RandomState(4)
+            for nz in (agent.o_stats, agent.g_stats):
+                nz.update(torch.as_tensor(rng.randn(300, nz.size).astype(np.float32) * 0.5 + 0.1, device='cuda'))
+                nz.recompute_stats()
+        w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                          noise_eps=0.2 if noise else 0.0, random_eps=0.3 if noise else 0.0, structure='curious',
+                          task_selection='random', queue_length=6, eval=False)
+        w.seed(13)
+        w._decide_exploit = lambda: None
+        return agent, oracle, w
+
+    # ---- (a) three ways of stepping, with noise
+    recs = []
+    for mode in ('rollout', 'per_step', 'unfused'):
+        agent, _, w = job(True)
+        assert agent.relative_goals and agent.can_act_and_step(w.benv, False)
+        np.random.seed(31)
+        if mode == 'rollout':
+            ep, _, _ = w.generate_rollouts()
+        else:
+            env = w.benv
+            tasks = np.random.choice(range(nb), p=w.p, size=B)
+            goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+            env.reset_all(tasks, goals)
+            for t in range(T):
+                if mode == 'per_step':
+                    agent.act_and_step(env, t, noise_eps=0.2, random_eps=0.3)
+                else:
+                    u = agent.get_actions(env.o, env.ag, env.g, task_descr=env.td, noise_eps=0.2, random_eps=0.3)
+                    env.step_all(u, t)
+            ep = env.episode_views()
+        torch.cuda.synchronize()
+        recs.append({k: v.clone() for k, v in ep.items()})
+    for k in recs[0]:
+        assert torch.equal(recs[0][k], recs[1][k]), ('rollout vs per-step', k)
+        assert torch.equal(recs[0][k], recs[2][k]), ('rollout vs unfused', k)
+    assert float(recs[0]['u'].abs().sum()) > 0
+
+    # ---- (b) no noise: against the oracle policy (relative goals) and the oracle env
+    if normalize_obs:
+        return              # (the oracle AGENT has no input normalisation -- its networks do: tests/test_gpu_kernels.py)
+    agent, oracle, w = job(False)
+    np.random.seed(31)
+    ep, _, _ = w.generate_rollouts()
+    rec = {k: v.cpu().numpy() for k, v in ep.items()}
+    envs = [SyntheticMultiTaskArm(nb, dimo, T, seed=13, env_id=i) for i in range(B)]
+    np.random.seed(31)
+    tasks = np.random.choice(range(nb), p=np.ones(nb) / nb, size=B)
+    goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+    obs = []
+    for i, e in enumerate(envs):
+        e.reset()
+        obs.append(e.reset_task_goal(goals[i], int(tasks[i])))
+    o = np.stack([x['observation'] for x in obs])
+    g = np.stack([x['desired_goal'] for x in obs])
+    td = np.stack([x['mask'] for x in obs])
+    np.testing.assert_array_equal(rec['o'][:, 0], o)
+    moved = 0.0
+    for t in range(T):
+        ou = oracle.get_actions(o, o[:, :12], g, task_descr=td, noise_eps=0., random_eps=0.)
+        np.testing.assert_allclose(rec['u'][:, t], ou, rtol=1e-4, atol=2e-5, err_msg='step %d' % t)
+        res = [e.step(rec['u'][i, t]) for i, e in enumerate(envs)]
+        o_new = np.stack([r[0]['observation'] for r in res])
+        np.testing.assert_array_equal(rec['o'][:, t + 1], o_new)
+        moved += np.abs(o_new[:, :12] - o[:, :12]).sum()
+        o = o_new
+    assert moved > 0                                                 # the achieved goals did change: g - ag was re-derived
