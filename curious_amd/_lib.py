@@ -123,10 +123,10 @@ PROTOTYPES = {
     'curious_ddpg_update': (C.c_int, [C.POINTER(NetCfg), _P, _P, _P, C.POINTER(BatchLayout), _I32, _P, _P, _P, _P,
                                       _P, _P, _P, C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
     'curious_ddpg_update_experts': (C.c_int, [C.POINTER(NetCfg), _I32, _I64, _I64, _U64, _P, _P, _P,
-                                              C.POINTER(BatchLayout), _I32, _P, _P, _P, _P, _P, C.POINTER(AdamState),
-                                              C.POINTER(NextBatch), _P]),
+                                              C.POINTER(BatchLayout), _I32, _P, _P, _P, _P, _P, _P, _P,
+                                              C.POINTER(AdamState), C.POINTER(NextBatch), _P]),
     'curious_ddpg_grads_experts': (C.c_int, [C.POINTER(NetCfg), _I32, _I64, _I64, _P, _P, _P, C.POINTER(BatchLayout),
-                                             _I32, _P, _P, _P, _P, _P, _I32, _U64, C.POINTER(NextBatch), _P]),
+                                             _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _U64, C.POINTER(NextBatch), _P]),
     'curious_adam_update_and_sample_experts': (C.c_int, [_I32, _I64, _I64, _U64, _P, _P, _P, _P, _I64, _I64, _P, _P,
                                                          _I64, _I32, _F, _F, _F, _F, _F, _P, _I64, C.POINTER(Layout),
                                                          C.POINTER(Tasks), C.POINTER(SampleParams),

@@ -1502,30 +1502,33 @@ static int check_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_
 extern "C" int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                           int64_t grad_stride, const float* theta_main, const float* theta_target,
                                           const float* batch, const curious_batch_layout_t* BL, int32_t B,
-                                          float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                                          int64_t* step_ctr, int32_t params_unchanged, uint64_t seed_stride,
+                                          const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                                          float* out_losses, float* out_Q_pi, int64_t* step_ctr,
+                                          int32_t params_unchanged, uint64_t seed_stride,
                                           const curious_next_batch_t* next, curious_stream_t stream) {
   if (check_experts(cfg, n_experts, expert_stride, grad_stride)) return -1;
-  CURIOUS_CHECK(!cfg->normalize_obs, "curious_ddpg_grads_experts: input normalisation is not supported");
+  CURIOUS_CHECK(!cfg->normalize_obs || (o_stats && g_stats),
+                "curious_ddpg_grads_experts: input normalisation needs the experts' statistics");
   ExDim xd;
   xd.nex = n_experts; xd.stride = expert_stride; xd.gstride = grad_stride;
-  return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
+  return ddpg_grads_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
                          out_Q_pi, step_ctr, stream, nullptr, xd, seed_stride, params_unchanged != 0, next);
 }
 
 extern "C" int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                            int64_t grad_stride, uint64_t seed_stride, float* theta_main,
                                            const float* theta_target, const float* batch,
-                                           const curious_batch_layout_t* BL, int32_t B, float* workspace, float* grad,
-                                           float* out_losses, float* out_Q_pi, int64_t* step_ctr,
-                                           const curious_adam_state_t* adam, const curious_next_batch_t* next,
-                                           curious_stream_t stream) {
+                                           const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
+                                           const float* g_stats, float* workspace, float* grad, float* out_losses,
+                                           float* out_Q_pi, int64_t* step_ctr, const curious_adam_state_t* adam,
+                                           const curious_next_batch_t* next, curious_stream_t stream) {
   if (check_experts(cfg, n_experts, expert_stride, grad_stride)) return -1;
-  CURIOUS_CHECK(cfg && !cfg->normalize_obs, "curious_ddpg_update_experts: input normalisation is not supported");
+  CURIOUS_CHECK(cfg && (!cfg->normalize_obs || (o_stats && g_stats)),
+                "curious_ddpg_update_experts: input normalisation needs the experts' statistics");
   CURIOUS_CHECK(step_ctr && adam && adam->alpha_tab && next,
                 "curious_ddpg_update_experts: device step counter, step-size table and next batch are required");
   ExDim xd;
   xd.nex = n_experts; xd.stride = expert_stride; xd.gstride = grad_stride;
-  return ddpg_update_impl(cfg, theta_main, theta_target, batch, BL, B, nullptr, nullptr, workspace, grad, out_losses,
+  return ddpg_update_impl(cfg, theta_main, theta_target, batch, BL, B, o_stats, g_stats, workspace, grad, out_losses,
                           out_Q_pi, step_ctr, adam, next, stream, xd, seed_stride);
 }

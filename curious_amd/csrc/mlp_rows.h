@@ -273,8 +273,9 @@ __device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {    
 // the batch action / max_u (actor_critic.py:96) when with_u, else it is filled later from the actor's output
 // keep: where the rows are also stored for the layer-0 weight gradients (input normalisation only: without it those
 // read the batch itself), or NULL
+// so: the expert's slab offset (batched experts: every expert has its own normalisers, expert_stride floats apart)
 __device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& a, const float* batch, int off_o,
-                                                 int off_g, bool with_u, float* keep = nullptr) {
+                                                 int off_g, bool with_u, float* keep = nullptr, const int64_t so = 0) {
   const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
   for (int idx = x.tid; idx < 4 * tot; idx += 256) {
     const int i = idx / tot, k = idx - i * tot;
@@ -282,14 +283,14 @@ __device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& 
     float v;
     if (k < a.dimo) {
       v = row[off_o + k];
-      if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[k]), a.o_std[k]), -a.nclip, a.nclip);     // normalizer.py:72-77
+      if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[so + k]), a.o_std[so + k]), -a.nclip, a.nclip);   // normalizer.py:72-77
     } else if (k < Sa) {
       v = row[a.off_td + (k - a.dimo)];
     } else if (k < S) {
       v = with_u ? fdiv(row[a.off_u + (k - Sa)], a.max_u) : 0.f;
     } else {
       v = row[off_g + (k - S)];
-      if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - S]), a.g_std[k - S]), -a.nclip, a.nclip);
+      if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[so + k - S]), a.g_std[so + k - S]), -a.nclip, a.nclip);
     }
     x.xin[i * XLD + k] = v;
     if (keep) keep[(int64_t)(x.r0 + i) * XLD + k] = v;
@@ -406,7 +407,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     ROWS_STAMP(0);
     rows_l0_load(wb[0], tp + a.tPi.W0, Sa, tp + a.tPi.Wg, Sa + G, x.wave, x.lane, 0);
     const float b0_tp = tp[a.tPi.b0 + x.tid];
-    rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false);
+    rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false, nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
@@ -451,7 +452,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     ROWS_STAMP(0);
     rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
     const float b0_mq = mq[a.mQ.b0 + x.tid];
-    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true, a.xn_c ? a.xn_c + eo : nullptr);
+    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true, a.xn_c ? a.xn_c + eo : nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     // operands of the head / loss / first backward step, fetched ahead of the hidden layers
@@ -525,7 +526,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   ROWS_STAMP(0);
   rows_l0_load(wb[0], mp + a.mPi.W0, Sa, mp + a.mPi.Wg, Sa + G, x.wave, x.lane, 0);
   const float b0_mp = mp[a.mPi.b0 + x.tid];
-  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false, a.xn_a ? a.xn_a + eo : nullptr);
+  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false, a.xn_a ? a.xn_a + eo : nullptr, eo);
   __syncthreads();
   ROWS_STAMP(1);
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);

@@ -131,9 +131,11 @@ class DDPG(object):
         self.P_Q, self.P_pi, self.off_pi, self.P_total = ops.param_layout(cfg)
         dev = self.device
         # running averages; both accumulators in one buffer -> one all-reduce per cycle
-        self._stats_acc = torch.zeros(2 * self.dimo + 1 + 2 * self.dimg + 1, dtype=torch.float32, device=dev)
-        self.o_stats = Normalizer(self.dimo, self.norm_eps, self.norm_clip, _acc=self._stats_acc[:2 * self.dimo + 1])
-        self.g_stats = Normalizer(self.dimg, self.norm_eps, self.norm_clip, _acc=self._stats_acc[2 * self.dimo + 1:])
+        self._stats_acc = self._new([2 * self.dimo + 1 + 2 * self.dimg + 1])
+        self.o_stats = Normalizer(self.dimo, self.norm_eps, self.norm_clip, _acc=self._stats_acc[:2 * self.dimo + 1],
+                                  _state=self._new([4 * self.dimo + 1]))
+        self.g_stats = Normalizer(self.dimg, self.norm_eps, self.norm_clip, _acc=self._stats_acc[2 * self.dimo + 1:],
+                                  _state=self._new([4 * self.dimg + 1]))
         # parameters: Xavier-uniform kernels, zero biases (util.py:81,87-88,99).  TensorFlow draws them from its own
         # generator (not NumPy's), so a private RandomState is used and the NumPy global stream is left untouched.
         wrng = np.random.RandomState(self.seed)
@@ -682,7 +684,7 @@ class DDPG(object):
             assert skip is None
             self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
             self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
-            recompute_many([self.o_stats, self.g_stats])
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc)
             return
         # both normalisers from the one batch in two launches; on a single rank the second one also recomputes the
         # statistics, with several ranks the (packed) accumulators are all-reduced first (normalizer.py:84-94)
@@ -695,7 +697,7 @@ class DDPG(object):
                              self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
                              self._stats_scratch, skip=skip)
         if not single:
-            recompute_many([self.o_stats, self.g_stats])
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc)
 
     def _stats_rng(self, n_episodes, n):
         r = _lib.SampleRng()

@@ -83,12 +83,14 @@ class ExpertBank:
         for e, x in enumerate(self.experts):
             if x.seed != x0.seed + e:
                 raise ValueError('expert seeds must be consecutive (seed_0 + t_id)')
-            if not x._device_loop() or x.normalize_obs:
-                raise ValueError("the batched update needs rng_mode='device', per-task buffers and normalize_obs=False")
+            if not x._device_loop():
+                raise ValueError("the batched update needs rng_mode='device' and per-task buffers")
             for name in ('theta', 'theta_target', '_m', '_v', '_workspace', '_losses', '_Q_pi', '_step_ctr',
                          '_alpha_tab', '_tables'):
                 a, b = getattr(x, name), getattr(x0, name)
                 assert a.data_ptr() - b.data_ptr() == 4 * e * self.stride, name
+            for nz, nz0 in ((x.o_stats, x0.o_stats), (x.g_stats, x0.g_stats)):      # every expert has its own normalisers
+                assert nz.state.data_ptr() - nz0.state.data_ptr() == 4 * e * self.stride
             assert x.grad.data_ptr() - x0.grad.data_ptr() == 4 * e * self.grad_stride
         self.use_graph = bool(x0.use_graph)
         self._graphs = {}
@@ -128,7 +130,9 @@ class ExpertBank:
                                 x0.theta_target, x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad,
                                 x0._losses, x0._Q_pi, x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base,
                                 x0._pp[p ^ 1], x0._pool.storage, x0._pool.buf_stride, S.tasks,
-                                S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, params_unchanged=chained)
+                                S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, params_unchanged=chained,
+                                o_stats=x0.o_stats.state if x0.normalize_obs else None,
+                                g_stats=x0.g_stats.state if x0.normalize_obs else None)
 
     # the two halves of an update on several ranks: the all-reduce of the gradient block sits between them
     def _grads_all(self, p, chained=False):
@@ -140,7 +144,9 @@ class ExpertBank:
                                x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi, x0._step_ctr,
                                params_unchanged=chained, seed_stride=SEED_STRIDE_SAMPLER, next_batch=x0._pp[p ^ 1],
                                storage=x0._pool.storage, buf_stride=x0._pool.buf_stride, tasks=S.tasks,
-                               params=S.params(x0.clip_obs, x0.relative_goals), rng=x0._rng_desc)
+                               params=S.params(x0.clip_obs, x0.relative_goals), rng=x0._rng_desc,
+                               o_stats=x0.o_stats.state if x0.normalize_obs else None,
+                               g_stats=x0.g_stats.state if x0.normalize_obs else None)
 
     def _adam_all(self):
         """Adam of every expert from the summed gradients (one launch, grid.y = expert)."""

@@ -13,13 +13,16 @@ from curious_amd import dist, ops
 
 
 class Normalizer:
-    def __init__(self, size, eps=1e-2, default_clip_range=np.inf, sess=None, _acc=None):
+    def __init__(self, size, eps=1e-2, default_clip_range=np.inf, sess=None, _acc=None, _state=None):
         self.size = size
         self.eps = eps
         self.default_clip_range = default_clip_range
         dev = torch.device('cuda', torch.cuda.current_device())
         self.acc = _acc if _acc is not None else torch.zeros(2 * size + 1, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(4 * size + 1, dtype=torch.float32, device=dev)
+        # (_acc / _state: storage handed in by the owner -- DDPG packs both normalisers' accumulators into one buffer,
+        #  an ExpertBank carves every expert's state out of its slab row)
+        self.state = _state if _state is not None else torch.zeros(4 * size + 1, dtype=torch.float32, device=dev)
+        self.state.zero_()
         self.state[2 * size] = 1.0                                   # count_tf = ones (normalizer.py:37-39)
         self.state[3 * size + 1:] = 1.0                              # std = ones     (normalizer.py:43-45)
         self._scratch = None
@@ -64,13 +67,19 @@ class Normalizer:
         return self.mean + v * self.std
 
 
-def recompute_many(normalizers):
+def recompute_many(normalizers, packed=None):
     """recompute_stats for several normalisers with ONE all-reduce: their `acc` vectors must be slices of one
-    device buffer (DDPG allocates o_stats / g_stats that way)."""
-    base = normalizers[0].acc._base if normalizers[0].acc._base is not None else normalizers[0].acc
+    device buffer (DDPG allocates o_stats / g_stats that way).  packed: that buffer (required when it is
+    itself a view of something larger -- an expert's slab row)."""
+    if packed is None:
+        packed = normalizers[0].acc._base if normalizers[0].acc._base is not None else normalizers[0].acc
+        for nz in normalizers:
+            assert (nz.acc._base if nz.acc._base is not None else nz.acc) is packed
+    lo, hi = packed.data_ptr(), packed.data_ptr() + 4 * packed.numel()
     for nz in normalizers:
-        assert (nz.acc._base if nz.acc._base is not None else nz.acc) is base
-    dist.allreduce_sum_(base)
+        assert lo <= nz.acc.data_ptr() and nz.acc.data_ptr() + 4 * nz.acc.numel() <= hi
+    assert packed.numel() == sum(nz.acc.numel() for nz in normalizers)
+    dist.allreduce_sum_(packed)
     ws = dist.world_size()
     for nz in normalizers:
         ops.norm_recompute(nz.acc, nz.state, nz.size, ws, nz.eps)

@@ -235,14 +235,15 @@ def _adam_state(m, v, alpha_tab, tab_base, alpha_Q, alpha_pi, beta1, beta2, epsi
 
 def ddpg_grads_experts(cfg, n_experts, expert_stride, grad_stride, theta_main, theta_target, batch, layout, B, workspace,
                        grad, out_losses, out_Q_pi, step_ctr, params_unchanged=False, seed_stride=0, next_batch=None,
-                       storage=None, buf_stride=0, tasks=None, params=None, rng=None):
+                       storage=None, buf_stride=0, tasks=None, params=None, rng=None, o_stats=None, g_stats=None):
     """curious_ddpg_grads for n_experts agents in one launch sequence (the first half of a data-parallel batched
     update); tensors as in ddpg_update_experts.  next_batch: every expert's next batch is gathered in the same launch."""
     BL = layout.c_batch_layout()
     N = _next_batch(layout, next_batch, storage, buf_stride, tasks, params, rng)
     check(lib().curious_ddpg_grads_experts(C.byref(cfg), int(n_experts), int(expert_stride), int(grad_stride),
                                            ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
-                                           ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),
+                                           ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
+                                           ptr(workspace), ptr(grad),
                                            ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr), int(bool(params_unchanged)),
                                            int(seed_stride) & 0xFFFFFFFFFFFFFFFF, C.byref(N) if N is not None else None,
                                            current_stream()), 'curious_ddpg_grads_experts')
@@ -267,7 +268,7 @@ def adam_update_and_sample_experts(n_experts, expert_stride, grad_stride, seed_s
 def ddpg_update_experts(cfg, n_experts, expert_stride, grad_stride, seed_stride, theta_main, theta_target, batch, layout,
                         B, workspace, grad, out_losses, out_Q_pi, m, v, step_ctr, alpha_tab, tab_base, next_batch,
                         storage, buf_stride, tasks, params, rng, beta1=0.9, beta2=0.999, epsilon=1e-08,
-                        params_unchanged=False):
+                        params_unchanged=False, o_stats=None, g_stats=None):
     """One update of n_experts agents in one launch sequence (curious_ddpg_update_experts).  Every tensor is expert
     0's view of a slab [n_experts, expert_stride] (the gradients: of a block [n_experts, grad_stride]); `rng` is expert
     0's sampler description."""
@@ -281,7 +282,8 @@ def ddpg_update_experts(cfg, n_experts, expert_stride, grad_stride, seed_stride,
     check(lib().curious_ddpg_update_experts(C.byref(cfg), int(n_experts), int(expert_stride), int(grad_stride),
                                             int(seed_stride) & 0xFFFFFFFFFFFFFFFF,
                                             ptr(_dev(theta_main, 'theta_main')), ptr(theta_target),
-                                            ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(workspace), ptr(grad),
+                                            ptr(_dev(batch, 'batch')), C.byref(BL), int(B), ptr(o_stats), ptr(g_stats),
+                                            ptr(workspace), ptr(grad),
                                             ptr(out_losses), ptr(out_Q_pi), ptr(step_ctr), C.byref(A), C.byref(N),
                                             current_stream()), 'curious_ddpg_update_experts')
 

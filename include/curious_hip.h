@@ -366,14 +366,16 @@ int curious_ddpg_update(const curious_net_cfg_t* cfg, float* theta_main, const f
  * curious_param_total(): a contiguous [n_experts][grad_stride] block, see curious_ddpg_grads_experts).  Shared:
  * next->storage, the layouts, tasks, sampler parameters.  Expert e draws its batches with the
  * Philox key next->rng->seed + e * seed_stride.  Results per expert are bit-identical to curious_ddpg_update on that
- * expert alone.  Requires the fast routes (modular nets, hidden 256, 2-3 layers, dimu 4, B % 256 == 0, no input normalisation) and
- * fails with an error otherwise (the caller then updates the experts one by one). */
+ * expert alone.  Requires the fast routes (modular nets, hidden 256, 2-3 layers, dimu 4, B % 256 == 0) and fails with an
+ * error otherwise (the caller then updates the experts one by one).  o_stats / g_stats (input normalisation,
+ * actor_critic.py:76-83; NULL without): expert 0's normaliser state vectors -- every expert has its own
+ * (train.py:285-291), expert e's live expert_stride floats further like everything else of its state. */
 int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                 int64_t grad_stride, uint64_t seed_stride, float* theta_main,
                                 const float* theta_target, const float* batch, const curious_batch_layout_t* BL,
-                                int32_t B, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
-                                int64_t* step_ctr, const curious_adam_state_t* adam, const curious_next_batch_t* next,
-                                curious_stream_t stream);
+                                int32_t B, const float* o_stats, const float* g_stats, float* workspace, float* grad,
+                                float* out_losses, float* out_Q_pi, int64_t* step_ctr, const curious_adam_state_t* adam,
+                                const curious_next_batch_t* next, curious_stream_t stream);
 
 /* The two halves of curious_ddpg_update_experts for DATA-PARALLEL batched experts (BASELINE configs[4] on several
  * GPUs): the reference runs task_experts under MPI like everything else -- every expert's two MpiAdam instances sum
@@ -390,10 +392,10 @@ int curious_ddpg_update_experts(const curious_net_cfg_t* cfg, int32_t n_experts,
  * and -- with one rank -- to curious_ddpg_update_experts. */
 int curious_ddpg_grads_experts(const curious_net_cfg_t* cfg, int32_t n_experts, int64_t expert_stride,
                                int64_t grad_stride, const float* theta_main, const float* theta_target,
-                               const float* batch, const curious_batch_layout_t* BL, int32_t B, float* workspace,
-                               float* grad, float* out_losses, float* out_Q_pi, int64_t* step_ctr,
-                               int32_t params_unchanged, uint64_t seed_stride, const curious_next_batch_t* next,
-                               curious_stream_t stream);
+                               const float* batch, const curious_batch_layout_t* BL, int32_t B, const float* o_stats,
+                               const float* g_stats, float* workspace, float* grad, float* out_losses, float* out_Q_pi,
+                               int64_t* step_ctr, int32_t params_unchanged, uint64_t seed_stride,
+                               const curious_next_batch_t* next, curious_stream_t stream);
 int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_stride, int64_t grad_stride,
                                            uint64_t seed_stride, float* theta, float* m, float* v, const float* grad,
                                            int64_t n_Q, int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr,

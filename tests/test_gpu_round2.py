@@ -13,7 +13,7 @@ from test_gpu_agent import T, build_pair, synth_episodes, tables
 pytestmark = pytest.mark.gpu
 
 
-def _expert_kit(nb=4, dimo=40, batch_size=256, hidden=256, cap_eps=64):
+def _expert_kit(nb=4, dimo=40, batch_size=256, hidden=256, cap_eps=64, normalize_obs=False):
     from curious_amd.envs import sparse_reward_fun
     from curious_amd.her import make_sample_multi_task_her_transitions
     from curious_amd.replay_buffer import make_pooled_buffers
@@ -34,7 +34,7 @@ def _expert_kit(nb=4, dimo=40, batch_size=256, hidden=256, cap_eps=64):
                     network_class='curious_amd.actor_critic:MultiTaskActorCritic', polyak=0.95, batch_size=batch_size,
                     Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1., clip_obs=200.,
                     scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None, relative_goals=False,
-                    clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                    clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=normalize_obs,
                     sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
                     task_replay=tr, eps_task=0.4, structure='task_experts', t_id=t_id, seed=10 + t_id,
                     rng_mode='device', use_graph=use_graph, **hooks)

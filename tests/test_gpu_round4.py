@@ -454,3 +454,48 @@ def test_relative_goals_in_the_fused_rollout(normalize_obs):
         moved += np.abs(o_new[:, :12] - o[:, :12]).sum()
         o = o_new
     assert moved > 0                                                 # the achieved goals did change: g - ag was re-derived
+
+
+# ------------------------------------------------------------------ batched experts with input normalisation
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_batched_experts_with_input_normalisation_equal_sequential_experts(use_graph):
+    """actor_critic.py:76-83 + train.py:285-291: every task expert is a DDPG of its own -- with --normalize_obs each has
+    its own two normalisers, fed only by the rollouts IT collected.  Round 3's ExpertBank refused normalize_obs; now the
+    experts' normaliser state lives in their slab rows and the batched launches read expert e's statistics at e x stride.
+    Bit-identical to the same experts updated one after the other (whose kernel is checked against the oracle with
+    normalisation in tests/test_gpu_kernels.py)."""
+    from curious_amd.experts import ExpertBank
+    from test_gpu_agent import synth_episodes
+    from test_gpu_round2 import _expert_kit
+    nb = 4
+    groups = []
+    for batched in (True, False):
+        make, bufs, dims, shapes, ids, tr = _expert_kit(normalize_obs=True)
+        if batched:
+            bank = ExpertBank(lambda t, **h: make(t, use_graph=use_graph, **h), nb)
+            xs = list(bank)
+        else:
+            bank, xs = None, [make(t, use_graph=use_graph) for t in range(nb)]
+        rng = np.random.RandomState(2)
+        for e in (0, 2, 3, 0):                                       # stores through different experts: different statistics
+            np.random.seed(1 + e)
+            xs[e].store_episode({k: v.copy() for k, v in synth_episodes(rng, 16, nb, 40).items()}, np.zeros(nb), 16)
+        groups.append((bank, xs))
+    (bank, bx), (_, sx) = groups
+    for a, b in zip(bx, sx):
+        assert torch.equal(a.o_stats.state, b.o_stats.state) and torch.equal(a.g_stats.state, b.g_stats.state)
+    assert not torch.equal(bx[0].o_stats.state, bx[2].o_stats.state)
+    assert float(bx[1].o_stats.state[2 * 40]) == 1.0                   # expert 1 never stored: count 1, mean 0, std 1
+    for n in (1, 1, 22, 3):
+        bank.train_batches(n)
+        for x in sx:
+            x.train_batches(n)
+    torch.cuda.synchronize()
+    assert bank.batched
+    for e, (a, b) in enumerate(zip(bx, sx)):
+        for name in ('theta', '_m', '_v'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (e, name)
+        assert float(a._losses[0]) == float(b._losses[0]) and np.isfinite(float(a._losses[0]))
+    # the statistics matter: an expert with other statistics ends elsewhere
+    assert not torch.equal(bx[0].theta, bx[2].theta)
+    bank.check_faults()
