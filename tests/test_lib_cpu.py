@@ -176,11 +176,11 @@ def test_round3_entry_points_host_code_without_gpu():
     fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(12)]
     P = L.curious_param_total(C.byref(cfg))
     # strides are validated first
-    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1000, P, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
-                                      fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1000, P, fake[0], fake[1], fake[2], C.byref(BL), 256, None, None,
+                                      fake[3], fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
     assert rc != 0 and b'expert_stride' in L.curious_last_error()
-    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P - 64, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
-                                      fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P - 64, fake[0], fake[1], fake[2], C.byref(BL), 256, None, None,
+                                      fake[3], fake[4], fake[5], fake[6], fake[7], 0, 0, None, None)
     assert rc != 0 and b'grad_stride' in L.curious_last_error()
     # a next batch must be keyed by the call's own step counter and must not alias the current batch
     lay = _lib.Layout()
@@ -203,8 +203,8 @@ def test_round3_entry_points_host_code_without_gpu():
     rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 256, None, None, fake[3], fake[4],
                               fake[5], fake[6], fake[10], 0, C.byref(nb), None)
     assert rc != 0 and b'launch failed' in L.curious_last_error()
-    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P, fake[0], fake[1], fake[2], C.byref(BL), 256, fake[3],
-                                      fake[4], fake[5], fake[6], fake[10], 1, 104729, C.byref(nb), None)
+    rc = L.curious_ddpg_grads_experts(C.byref(cfg), 4, 1 << 22, P, fake[0], fake[1], fake[2], C.byref(BL), 256, None, None,
+                                      fake[3], fake[4], fake[5], fake[6], fake[10], 1, 104729, C.byref(nb), None)
     assert rc != 0 and b'launch failed' in L.curious_last_error()
     # the optimiser half for the experts, without a gather (storage NULL)
     rc = L.curious_adam_update_and_sample_experts(4, 1 << 22, P, 104729, fake[0], fake[1], fake[2], fake[3],
