@@ -1430,6 +1430,8 @@ class DDPG(object):
         """Policies can be reloaded from a pickle for acting; training cannot be resumed from it (ddpg.py:511-521).
         The state is the constructor's own arguments (the reference filters __dict__ by substrings, which here would
         also drop e.g. use_graph) plus the weights in save_weights order."""
+        if '_snapshot_state' in self.__dict__:                       # curious_amd.util.PolicySnapshot of this policy
+            return self.__dict__['_snapshot_state']
         import inspect
         names = [n for n in inspect.signature(DDPG.__init__).parameters if n not in ('self', 'kwargs')]
         names += list(getattr(self, '_extra_kwargs', ()))

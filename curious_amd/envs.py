@@ -138,7 +138,11 @@ class BatchedSyntheticArm(ArmSpec):
         self.goals_host = np.zeros([n, 3], np.float32)
         # pinned staging for the per-rollout task / goal upload: the copy is enqueued without blocking the host,
         # so the next rollout can be queued behind the previous cycle's updates
-        self._pin = torch.empty(n * 4, dtype=torch.float32).pin_memory()
+        # (a small ring: evaluation rollouts are enqueued back to back without a host wait in between, so the block of
+        #  reset k must not be refilled before its copy has run; a block is reused only behind its own event)
+        self._pins = [torch.empty(n * 4, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._pin_events = [None] * len(self._pins)
+        self._pin_k = 0
         self._goals_dev = self._tg_dev[n:].view(n, 3)
         self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
         # rollout flags written by the last env step: is_success per env + one "an observation is NaN" word
@@ -160,10 +164,17 @@ class BatchedSyntheticArm(ArmSpec):
         self.tasks_host[:] = tasks
         self.goals_host[:] = goals_raw
         n = self.n
-        # the previous use of the pinned block has completed: every rollout ends with a device->host sync
-        self._pin[:n].view(torch.int32).copy_(torch.from_numpy(self.tasks_host))
-        self._pin[n:].view(n, 3).copy_(torch.from_numpy(self.goals_host))
-        self._tg_dev.copy_(self._pin, non_blocking=True)
+        k = self._pin_k
+        self._pin_k = (k + 1) % len(self._pins)
+        if self._pin_events[k] is not None:
+            self._pin_events[k].synchronize()                        # (its previous copy ran long ago, as a rule)
+        pin = self._pins[k]
+        pin[:n].view(torch.int32).copy_(torch.from_numpy(self.tasks_host))
+        pin[n:].view(n, 3).copy_(torch.from_numpy(self.goals_host))
+        self._tg_dev.copy_(pin, non_blocking=True)
+        if self._pin_events[k] is None:
+            self._pin_events[k] = torch.cuda.Event()
+        self._pin_events[k].record()
         ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
                       self.o, self.ag, self.g, self.td, self.staging,      # also advances self.episode on the device
                       flags=self.flags)                                    # and clears the NaN word of the coming rollout
@@ -172,14 +183,22 @@ class BatchedSyntheticArm(ArmSpec):
         ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,
                      self.g, self.td, self.staging, REWARD_EPS, flags=self.flags)
 
-    def request_flags(self):
-        """Enqueue the D2H copy of the rollout flags (no wait)."""
-        self._flags_pin.copy_(self.flags, non_blocking=True)
+    def request_flags(self, slot=None):
+        """Enqueue the D2H copy of the rollout flags (no wait).  slot: one of several pinned blocks -- rollouts that are
+        enqueued back to back and waited for together (RolloutWorker.generate_eval_rollouts) each keep their own."""
+        if slot is None:
+            pin = self._flags_pin
+        else:
+            pins = self.__dict__.setdefault('_flags_slots', [])
+            while len(pins) <= slot:
+                pins.append(torch.zeros(self.n + 1, dtype=torch.float32).pin_memory())
+            pin = pins[slot]
+        pin.copy_(self.flags, non_blocking=True)
         self._flags_ready.record()
 
-    def wait_flags(self):
+    def wait_flags(self, slot=None):
         self._flags_ready.synchronize()
-        host = self._flags_pin.numpy()
+        host = (self._flags_pin if slot is None else self._flags_slots[slot]).numpy()
         if host[self.n] == 2.0:
             # include/curious_hip.h, curious_policy_rollout: a workgroup of the resident-weights rollout never got an
             # answer from a peer of its group (the launch was not fully resident) -- the rollout is void

@@ -33,11 +33,19 @@ t0 = time.time()
 def train(*args, **kwargs):
     """train.py:49-166 (see _train); the objects that exist when the loop starts are kept out of the cycle collector's
     way for its duration (util.freeze_setup_objects)."""
+    from curious_amd.util import BackgroundWriter
+    evaluator = kwargs.get('evaluator', args[2] if len(args) > 2 else None)
+    writer = BackgroundWriter() if evaluator is not None and not hasattr(evaluator, 'writer') else None
+    if writer is not None:
+        evaluator.writer = writer                                    # policy files are written behind the training loop
     freeze_setup_objects()
     try:
         return _train(*args, **kwargs)
     finally:
         thaw_setup_objects()
+        if writer is not None:
+            del evaluator.writer
+            writer.close()                                           # every file is on disk when train() returns
 
 
 class FaultTolerance:
@@ -93,8 +101,7 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
         epoch, i_policy = -1, -1
         evaluator.clear_history()
         evaluator.clear_competence_queue()
-        for _ in range(n_test_rollouts):
-            evaluator.generate_rollouts()
+        evaluator.generate_eval_rollouts(n_test_rollouts)
         best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate, best_policy_path,
                                  periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
                                  policy[i_policy], rank, structure, i_policy=i_policy, task_experts_cp=p)
@@ -119,8 +126,7 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
                 updates(policy[i_policy], n_batches)                  # = n_batches x train() (train.py:101-102)
                 ft.call(policy[i_policy].update_target_net)
             evaluator.clear_history()
-            for _ in range(n_test_rollouts):
-                evaluator.generate_rollouts()
+            evaluator.generate_eval_rollouts(n_test_rollouts)
             best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate,
                                      best_policy_path, periodic_policy_path, policy_save_interval, save_policies,
                                      latest_policy_path, policy[i_policy], rank, structure, i_policy=i_policy,
@@ -128,8 +134,7 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
     else:
         epoch = -1
         evaluator.clear_history()
-        for _ in range(n_test_rollouts):
-            evaluator.generate_rollouts()
+        evaluator.generate_eval_rollouts(n_test_rollouts)
         best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
                                  periodic_policy_path, policy_save_interval, save_policies, latest_policy_path, policy,
                                  rank, structure)
@@ -146,8 +151,7 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
                 updates(policy, n_batches)                           # = n_batches x train() (train.py:152-153)
                 ft.call(policy.update_target_net)
             evaluator.clear_history()
-            for _ in range(n_test_rollouts):
-                evaluator.generate_rollouts()
+            evaluator.generate_eval_rollouts(n_test_rollouts)
             torch.cuda.synchronize()
             logger.info('Epoch', epoch, 'over in ', time.time() - t_ep, 's.')
             best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
@@ -196,16 +200,22 @@ def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, 
     else:
         logger._state['kv'].clear()
     success_rate = mpi_average(evaluator.current_success_rate())
+    snap = []                                                        # one host copy of the policy for all saves below
+
+    def snapshot():
+        if not snap:
+            snap.append(evaluator.snapshot_policy())
+        return snap[0]
     if rank == 0 and success_rate >= best_success_rate and save_policies and best_policy_path:
         best_success_rate = success_rate
         logger.info('New best success rate: {}. Saving policy to {} ...'.format(best_success_rate, best_policy_path))
-        evaluator.save_policy(best_policy_path)
+        evaluator.save_policy(best_policy_path, snapshot())
     if rank == 0 and policy_save_interval > 0 and epoch % policy_save_interval == 0 and save_policies \
             and periodic_policy_path:
         policy_path = periodic_policy_path.format(epoch)
         logger.info('Saving periodic policy to {} ...'.format(policy_path))
-        evaluator.save_policy(policy_path)
-        evaluator.save_policy(latest_policy_path)
+        evaluator.save_policy(policy_path, snapshot())
+        evaluator.save_policy(latest_policy_path, snapshot())
     # ranks must hold different RNG streams (train.py:207-212, C13)
     local_uniform = np.random.uniform(size=(1,))
     root_uniform = dist.broadcast_object(float(local_uniform[0]), 0)

@@ -129,6 +129,20 @@ class RolloutWorker:
             self.exploit = True
             self.p = 1 / self.nb_tasks * np.ones([self.nb_tasks])
 
+    def generate_eval_rollouts(self, n):
+        """`for _ in range(n): evaluator.generate_rollouts()` (train.py:156-158): same draws, same statistics, same
+        order.  On the batched path of an evaluator the n rollouts are ENQUEUED back to back -- each keeps its flags and its
+        Q sum in a pinned slot of its own -- and waited for once: round 3 waited for every rollout's flags before the next
+        one was even enqueued (10 round trips of host latency per epoch).  Nothing an evaluation rollout draws
+        depends on the previous one's outcome (uniform task probabilities, rollout.py:187-189)."""
+        if not (self.batched and self.eval and n > 1):
+            for _ in range(n):
+                self.generate_rollouts()
+            return
+        finish = [self._generate_rollouts_batched(defer=k) for k in range(n)]
+        for fin in finish:
+            fin()
+
     def generate_rollouts(self):
         """Returns (episode batch, CP, n_episodes) (rollout.py:177-406)."""
         if self.batched:
@@ -283,9 +297,11 @@ class RolloutWorker:
         finally:
             self.exploit, self._any_exploit = exploit, any_exploit
 
-    def _generate_rollouts_batched(self, retry=False, force_sync=False, n_retry=0, redo=None):
+    def _generate_rollouts_batched(self, retry=False, force_sync=False, n_retry=0, redo=None, defer=None):
         """redo = (tasks, goals): generate exactly the rollout that was just enqueued once more (DDPG.rewind_rollout put
-        the episode and noise counters back) instead of drawing a new one."""
+        the episode and noise counters back) instead of drawing a new one.
+        defer = k (evaluators, generate_eval_rollouts): enqueue only; the flags and the Q sum travel to pinned slot k and
+        the returned closure -- called once everything is enqueued -- waits and books the rollout."""
         self.settle()
         if hasattr(self.policy, 'settle'):
             self.policy.settle()
@@ -367,6 +383,39 @@ class RolloutWorker:
             return views, self.CP, self.n_episodes
         if getattr(self.policy, '_async_batch', None) is not None:
             self.policy._async_batch = None                       # a marked rollout that was never stored: forget it
+        if defer is not None:
+            env.request_flags(slot=defer)
+            q_pin = None
+            if self.compute_Q:
+                pins = self.__dict__.setdefault('_q_slots', [])
+                while len(pins) <= defer:
+                    pins.append(torch.zeros(1, dtype=torch.float32).pin_memory())
+                q_pin = pins[defer]
+                q_pin.copy_(q_sum.reshape(1), non_blocking=True)
+                env._flags_ready.record()                         # (behind the Q copy as well)
+            exploit, any_exploit, task_list = self.exploit, self._any_exploit, tasks.tolist()
+
+            def finish():
+                from curious_amd.envs import ResidentRolloutVoid
+                try:
+                    successful, o_has_nan = env.wait_flags(slot=defer)
+                except ResidentRolloutVoid as err:
+                    self._resident_off(err)
+                    successful, o_has_nan = np.zeros(B), True
+                if np.isnan(successful).any() or o_has_nan:
+                    # (the sync path regenerates; a deferred rollout's successors are enqueued already: book this one anew)
+                    self.logger.warning('NaN caught during rollout generation. Trying again...')
+                    self._generate_rollouts_batched(retry=True, force_sync=True)
+                    return
+                saved = self.exploit, self._any_exploit
+                self.exploit, self._any_exploit = exploit, any_exploit
+                self.tasks = [_NOTHING] * self.nb_goals_per_rollout
+                self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
+                self.goals = [_NOTHING] * self.nb_goals_per_rollout
+                self._finish_rollout(successful, successful - 1.0,
+                                     float(q_pin[0]) / self.T if self.compute_Q else None, task_list, None)
+                self.exploit, self._any_exploit = saved
+            return finish
         from curious_amd.envs import ResidentRolloutVoid
         try:
             successful, o_has_nan = env.fetch_flags()             # written by the last env step of the rollout
@@ -491,17 +540,36 @@ class RolloutWorker:
     def current_mean_Q(self):
         return np.mean(self.Q_history)
 
-    def save_policy(self, path):
+    def save_policy(self, path, snapshot=None):
         """rollout.py:425-433.  The reference swallows every exception of save_weights because a task_experts policy
         is a list without that method; here the list case is handled (one weights file per expert) and real errors
         surface."""
-        with open(path, 'wb') as f:
-            pickle.dump(self.policy, f)
-        if isinstance(self.policy, (list, tuple)):
-            for i, p in enumerate(self.policy):
-                p.save_weights(path + str(i))
+        snap = snapshot if snapshot is not None else self.snapshot_policy()
+        writer = getattr(self, 'writer', None)
+        if writer is None:
+            self._write_policy(path, snap)
         else:
-            self.policy.save_weights(path)
+            writer.submit(lambda: self._write_policy(path, snap))     # (experiment.train: curious_amd.util.BackgroundWriter)
+
+    def snapshot_policy(self):
+        """Host copies of everything save_policy writes (one D2H round per network vector), valid for the point in time of
+        the call (logs() saves the same policy up to three times: one snapshot serves all of them)."""
+        from curious_amd.util import PolicySnapshot
+        if isinstance(self.policy, (list, tuple)):
+            return [PolicySnapshot(p) for p in self.policy]
+        return PolicySnapshot(self.policy)
+
+    @staticmethod
+    def _write_policy(path, snap):
+        with open(path, 'wb') as f:
+            pickle.dump(snap, f)
+        if isinstance(snap, (list, tuple)):
+            for i, s in enumerate(snap):
+                with open(path + str(i) + '_weights.pkl', 'wb') as f:
+                    pickle.dump(s.state['weights'], f)             # DDPG.save_weights (ddpg.py:481-497)
+        else:
+            with open(path + '_weights.pkl', 'wb') as f:
+                pickle.dump(snap.state['weights'], f)
 
     def save_goal_task_history(self, path):
         pass                                                          # rollout.py:437-449 (commented out upstream)

@@ -499,3 +499,74 @@ def test_batched_experts_with_input_normalisation_equal_sequential_experts(use_g
     # the statistics matter: an expert with other statistics ends elsewhere
     assert not torch.equal(bx[0].theta, bx[2].theta)
     bank.check_faults()
+
+
+# ------------------------------------------------------------------ the epoch outside the cycles
+def test_evaluation_rollouts_enqueued_together_equal_one_at_a_time():
+    """train.py:156-158: `for _ in range(n_test_rollouts): evaluator.generate_rollouts()`.  generate_eval_rollouts(n)
+    enqueues all n and waits once: same NumPy draws, same success / Q histories, same competence queues, same episode
+    counts as n calls of generate_rollouts()."""
+    import pickle
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from test_gpu_agent import T, build_pair
+    nb, dimo, B = 4, 40, 16
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    outs = []
+    for together in (False, True):
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=True, seed=4)
+        ev = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                           exploit=True, use_target_net=False, compute_Q=True, structure='curious',
+                           task_selection='active_competence_progress', queue_length=6, eval=True)
+        ev.seed(21)
+        np.random.seed(17)
+        for epoch in range(2):
+            ev.clear_history()
+            if together:
+                ev.generate_eval_rollouts(5)
+            else:
+                for _ in range(5):
+                    ev.generate_rollouts()
+        outs.append(dict(succ=list(ev.success_history), Q=list(ev.Q_history), n=ev.n_episodes, C=np.array(ev.get_C()),
+                         tasks=list(ev.task_history), draw=np.random.random(), logs=ev.logs('test'),
+                         staging=ev.benv.staging.clone()))
+    a, b = outs
+    assert a['succ'] == b['succ'] and a['Q'] == b['Q'] and a['n'] == b['n'] == 2 * 5 * B
+    assert len(a['succ']) == 5 and np.isfinite(a['Q']).all()
+    np.testing.assert_array_equal(a['C'], b['C'])
+    assert a['tasks'] == b['tasks'] and a['draw'] == b['draw'] and a['logs'] == b['logs']
+    assert torch.equal(a['staging'], b['staging'])
+
+
+def test_policy_snapshot_pickles_like_the_policy_and_is_written_in_the_background(tmp_path):
+    """train.py:195-205 off the training thread: RolloutWorker.save_policy hands a host snapshot (PolicySnapshot) to a
+    BackgroundWriter; the files are byte for byte what the synchronous form writes, in submission order, and a failing
+    job surfaces at close()."""
+    import pickle
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from curious_amd.util import BackgroundWriter, PolicySnapshot
+    from test_gpu_agent import T, build_pair
+    agent, _ = build_pair(4, 40, rng_mode='device', seed=4)
+    snap = PolicySnapshot(agent)
+    assert pickle.dumps(snap) == pickle.dumps(agent)
+    clone = pickle.loads(pickle.dumps(snap))
+    assert type(clone) is type(agent) and torch.equal(clone.theta, agent.theta)
+    dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+    ev = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=4,
+                       structure='curious', task_selection='random', queue_length=6, eval=True)
+    sync = str(tmp_path / 'sync.pkl')
+    ev.save_policy(sync)
+    ev.writer = BackgroundWriter()
+    back = str(tmp_path / 'back.pkl')
+    ev.save_policy(back)
+    agent.theta.add_(1.0)                                            # the snapshot was taken when save_policy was called
+    ev.writer.close()
+    for suffix in ('', '_weights.pkl'):
+        assert open(sync + suffix, 'rb').read() == open(back + suffix, 'rb').read()
+    ev.writer = BackgroundWriter()
+    ev.save_policy(str(tmp_path / 'no_such_dir' / 'x.pkl'))
+    with pytest.raises(OSError):
+        ev.writer.close()
