@@ -73,6 +73,11 @@ class Transposed(C.Structure):
                 ('fault', C.c_void_p), ('fault_flag', C.c_int64)]
 
 
+class IpcPeers(C.Structure):
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('grad', C.c_void_p * 8), ('theta', C.c_void_p * 8),
+                ('flags', C.c_void_p * 8)]
+
+
 class NextBatch(C.Structure):
     _fields_ = [('storage', C.c_void_p), ('buf_stride', C.c_int64), ('L', C.POINTER(Layout)),
                 ('tasks', C.POINTER(Tasks)), ('P', C.POINTER(SampleParams)), ('rng', C.POINTER(SampleRng)),
@@ -101,6 +106,13 @@ PROTOTYPES = {
     'curious_get_option': (_I64, [C.c_char_p]),
     'curious_workspace_fault_offset': (_I64, [C.POINTER(NetCfg), _I32]),
     'curious_workspace_stamps_offset': (_I64, [C.POINTER(NetCfg), _I32]),
+    'curious_ipc_alloc': (C.c_int, [_I64, C.POINTER(C.c_void_p)]),
+    'curious_ipc_free': (C.c_int, [_P]),
+    'curious_ipc_export': (C.c_int, [_P, C.c_char_p]),
+    'curious_ipc_import': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'curious_ipc_close': (C.c_int, [_P]),
+    'curious_allreduce_adam_ipc': (C.c_int, [C.POINTER(IpcPeers), _P, _P, _I64, _I64, _P, _P, _I64, _I32, _F, _F, _F, _F,
+                                             _F, _P, _P, _I32, C.POINTER(Transposed), _P]),
     'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
                                      C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
                                      _P]),

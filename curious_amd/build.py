@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcurious_hip.so')
-SOURCES = ['api.cpp', 'her_sample.hip', 'store.hip', 'normalizer.hip', 'optim.hip', 'actor.hip', 'env.hip', 'mlp.hip']
+SOURCES = ['api.cpp', 'her_sample.hip', 'store.hip', 'normalizer.hip', 'optim.hip', 'ipc.hip', 'actor.hip', 'env.hip',
+           'mlp.hip']
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
     [os.path.join(os.path.dirname(HERE), 'include', 'curious_hip.h')]      # every header takes part in the rebuild check
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function',

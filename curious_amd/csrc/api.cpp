@@ -71,7 +71,7 @@ static const char* k_names[CK_COUNT] = {
     "adam_her_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel", "env_step_kernel",
     "counter_add_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel",
     "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel",
-    "policy_resident_kernel", "ddpg_rows_her_kernel", "ddpg_step_kernel"};
+    "policy_resident_kernel", "ddpg_rows_her_kernel", "ddpg_step_kernel", "allreduce_adam_ipc_kernel"};
 int64_t g_curious_launches[CK_COUNT] = {0};
 
 // launches per kernel id since the library was loaded (counted whether or not event timing is enabled, also during

@@ -75,7 +75,7 @@ enum {
   CK_NORM_PAIR_FINAL, CK_FWD_LAYER0, CK_FWD_GENERIC, CK_FWD_LAYER, CK_DX, CK_DX_GENERIC, CK_DW, CK_DW_SMALL, CK_HEAD_FWD,
   CK_CRITIC_HEAD, CK_CRITIC_HEAD_GENERIC, CK_ACTOR_DZ, CK_ACTOR_DZ_GENERIC, CK_ADAM, CK_ADAM_HER, CK_POLYAK, CK_CHECKSUM,
   CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_COUNTER_ADD, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS,
-  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_ACT_RES, CK_ROWS_HER, CK_STEP, CK_COUNT
+  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_ACT_RES, CK_ROWS_HER, CK_STEP, CK_IPC, CK_COUNT
 };
 extern int g_curious_prof_on;
 

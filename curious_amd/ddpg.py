@@ -65,6 +65,10 @@ class DDPG(object):
         # construction hooks of this implementation (_alloc: slab allocator of curious_amd.experts.ExpertBank)
         self._extra_kwargs = tuple(k for k in kwargs.keys() if not k.startswith('_'))
         self._alloc = kwargs.get('_alloc')
+        # several ranks: 'rccl' (default) = RCCL all-reduce + stand-alone optimiser launch; 'ipc' = the fused
+        # reduce-scatter + Adam + all-gather kernel over peer-mapped buffers (csrc/ipc.hip; functional, opt-in)
+        self._allreduce = kwargs.get('_allreduce') or os.environ.get('CURIOUS_ALLREDUCE', 'rccl')
+        assert self._allreduce in ('rccl', 'ipc'), self._allreduce
         self._scope_arg = scope
         self.create_actor_critic = import_function(self.network_class)
         self.dimo, self.dimg = self.input_dims['o'], self.input_dims['g']
@@ -121,6 +125,12 @@ class DDPG(object):
         gradient vector in the bank's contiguous gradient block instead)."""
         if self._alloc is not None:
             return self._alloc(shape, dtype, name)
+        if name in ('theta', 'grad') and self._allreduce == 'ipc' and dist.is_distributed():
+            # what the peers read and write lives in a block of its own (curious_amd.ipc.IpcBlock: theta | grad | flags)
+            if getattr(self, '_ipc_block', None) is None:
+                from curious_amd.ipc import IpcBlock
+                self._ipc_block = IpcBlock([int(np.prod(shape))] * 2)
+            return self._ipc_block.tensor(0 if name == 'theta' else 1).view(*shape)
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def _create_network(self, reuse=False):
@@ -140,7 +150,7 @@ class DDPG(object):
         # generator (not NumPy's), so a private RandomState is used and the NumPy global stream is left untouched.
         wrng = np.random.RandomState(self.seed)
         flat = np.concatenate([self._xavier(self._shapes(True), wrng), self._xavier(self._shapes(False), wrng)])
-        self.theta = self._new([self.P_total])
+        self.theta = self._new([self.P_total], name='theta')
         self.theta.copy_(torch.from_numpy(ops.pad_params(cfg, flat)))
         self.theta_target = self._new([self.P_total])
         self.grad = self._new([self.P_total], name='grad')
@@ -1007,6 +1017,8 @@ class DDPG(object):
         ranks the eager all-reduce splits every update; the loop is then software-pipelined so that Adam of update k
         and the gradients of update k+1 share one graph launch."""
         out = None
+        if self._device_loop() and dist.is_distributed() and self._allreduce == 'ipc':
+            return self._train_ranks_ipc(n)
         if self._device_loop() and self.use_graph and dist.is_distributed() and not self._graph_allreduce():
             while n > 0:
                 k = min(n, 1000)
@@ -1088,6 +1100,66 @@ class DDPG(object):
         self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
 
+    # ------------------------------------------------------------------ several ranks, fused IPC all-reduce + Adam (opt-in)
+    def _ipc_setup(self):
+        """Map every rank's gradient vector, parameter vector and flag block into this process (once)."""
+        if getattr(self, '_ipc', None) is not None:
+            return
+        ws = dist.world_size()
+        if ws > 8 or self.P_total % ws:
+            raise _lib.CuriousHipError("_allreduce='ipc' needs a world size <= 8 that divides the parameter count")
+        blk = getattr(self, '_ipc_block', None)
+        if blk is None:
+            raise _lib.CuriousHipError("_allreduce='ipc' has to be chosen when the agent is built (its parameter and "
+                                       'gradient vectors live in a block the peers can map)')
+        words = torch.zeros(2, dtype=torch.int32, device=self.device)     # [blocks done, a wait gave up]
+        torch.cuda.synchronize()
+        blk.connect()
+        peers = _lib.IpcPeers()
+        peers.world, peers.rank = ws, dist.rank()
+        for r in range(ws):
+            peers.theta[r], peers.grad[r], peers.flags[r] = blk.peer_ptr(r, 0), blk.peer_ptr(r, 1), blk.peer_flags(r)
+        self._ipc = dict(peers=peers, words=words)
+
+    def _ipc_update(self, p, chained):
+        """One update: gradients of the batch staged in tensor p (+ the gather of the next batch), then the one kernel
+        that sums the ranks' gradients slice by slice, runs Adam on the owned slice, hands the new slices round and
+        rebuilds the transposed copies (so the next gradient launch is told params_unchanged)."""
+        if self.use_graph:
+            g = self._ipc.setdefault('graphs', {})
+            if (p, chained) not in g:
+                g[(p, chained)] = self._capture(lambda: self._grads_next(p, chained))
+            g[(p, chained)].replay()
+        else:
+            self._grads_next(p, chained)
+        w = self._ipc['words']
+        ops.allreduce_adam_ipc(self._ipc['peers'], self._m, self._v, self.off_pi, self.P_total - self.off_pi,
+                               self._alpha_tab, self._step_ctr, self._alpha_base, w[0:1], w[1:2], self._kept_copies())
+
+    def _train_ranks_ipc(self, n):
+        """n updates on several ranks through curious_allreduce_adam_ipc (DDPG(_allreduce='ipc')).  Same gradients, same
+        step sizes, same order as the RCCL path; sums in rank order."""
+        self._train_device_prologue(n)
+        self._ipc_setup()
+        if self._batch_stale:
+            self._sample_packed()
+            self._batch_stale = False
+        p = self._cur
+        for i in range(n):
+            if (self.Q_adam.t + i) % 100 == 0:
+                self._check_synced()
+                if int(self._ipc['words'][1]):
+                    raise _lib.CuriousHipError('curious_allreduce_adam_ipc: a wait for a peer rank gave up (rank %d)' %
+                                               dist.rank())
+            self._ipc_update(p, chained=i > 0)
+            p ^= 1
+        self._cur = p
+        self._staged = self._pp[self._cur]
+        self.Q_adam.t += n
+        self.pi_adam.t += n
+        self._keep_alpha_ahead()
+        return self._losses[0], self._Q_pi
+
     def _rank_graphs(self):
         """The split update graphs of the several-rank path with an eager collective: A[p] = gradients of the batch in
         staging tensor p (+ the gather of the next batch into the other one), B = the optimiser, BA[p] = B then A[p]."""
@@ -1137,6 +1209,8 @@ class DDPG(object):
         chain of CHAIN updates).  Several ranks: the gradient all-reduce splits every update into graph A (gradients)
         and graph B (Adam + next gather).  An explicit gather is issued whenever the buffers or the sampling tables
         changed since the last one, so every batch is still drawn after the latest store_episode."""
+        if dist.is_distributed() and self._allreduce == 'ipc':
+            return self._train_ranks_ipc(k)                          # (every update of this agent: the moments are sliced)
         self._train_device_prologue(k)
         if dist.is_distributed():
             assert k == 1 or (k in (CHAIN, MAX_CHAIN) and self._graph_allreduce() and 100 % CHAIN == 0 and MAX_CHAIN == 100)

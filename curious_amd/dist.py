@@ -171,6 +171,15 @@ def broadcast_object(obj, root=0):
     return box[0]
 
 
+def allgather_object(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (pickled, host-side group)."""
+    if not is_distributed():
+        return [obj]
+    out = [None] * world_size()
+    td.all_gather_object(out, obj, group=host_group())
+    return out
+
+
 def barrier():
     if is_distributed():
         td.barrier()

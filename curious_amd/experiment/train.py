@@ -320,6 +320,9 @@ def shutdown(policies, expert_bank=None):
         p._chains = None
         p._graphs = [None, None]
         p._roll_graphs = {}
+        if getattr(p, '_ipc', None) is not None:
+            p._ipc = None
+            p._ipc_block.disconnect()                                # (collective: unmap the peers' blocks)
     if expert_bank is not None:
         expert_bank._graphs = {}
     gc.collect()

@@ -487,3 +487,15 @@ def dw_stamps(cfg, B, workspace, n_blocks):
     if off < 0:
         raise _lib.CuriousHipError('curious_workspace_stamps_offset: bad arguments')
     return workspace[off:off + 16 * n_blocks].view(torch.int64).view(n_blocks, 8)
+
+
+def allreduce_adam_ipc(peers, m, v, n_Q, n_pi, alpha_tab, step_ctr, tab_base, done, err, keep, spins=0, beta1=0.9,
+                       beta2=0.999, epsilon=1e-08):
+    """curious_allreduce_adam_ipc: reduce-scatter over the peers' gradient vectors + Adam on the owned slice + all-gather
+    of the new slices + the transposed copies, one kernel (csrc/ipc.hip).  peers: _lib.IpcPeers of mapped pointers."""
+    f = np.float32
+    check(lib().curious_allreduce_adam_ipc(C.byref(peers), ptr(_dev(m, 'm')), ptr(v), int(n_Q), int(n_pi), ptr(alpha_tab),
+                                           ptr(step_ctr), int(tab_base), int(alpha_tab.shape[0]), float(f(beta1)),
+                                           float(f(1 - beta1)), float(f(beta2)), float(f(1 - beta2)), float(f(epsilon)),
+                                           ptr(done), ptr(err), int(spins), C.byref(keep) if keep is not None else None,
+                                           current_stream()), 'curious_allreduce_adam_ipc')

@@ -406,6 +406,46 @@ int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_str
                                            float* batch, const curious_batch_layout_t* BL,
                                            const curious_transposed_t* keep, curious_stream_t stream);
 
+/* The gradient all-reduce of several ranks as ONE kernel per rank over peer-mapped buffers, fused with the optimiser
+ * (reduce-scatter + Adam + all-gather; csrc/ipc.hip): replaces Allreduce(SUM) + Adam of MpiAdam.update
+ * (mpi_adam.py:21-35) -- in this build: the RCCL all-reduce + curious_adam_update of the several-rank update.  Every rank
+ * calls it after its gradient launches with
+ *   peers   every rank's gradient vector, parameter vector and flag block ([2][CURIOUS_IPC_MAX_RANKS] uint32, zeroed
+ *           once) AS MAPPED INTO THIS PROCESS (hipIpcOpenMemHandle / the own rank's local pointers);
+ *   m, v    the local moment vectors (full length; only the rank's slice [rank * n / world, (rank + 1) * n / world) is
+ *           used: each rank runs the optimiser on its slice only and writes the new slice into every rank's parameters);
+ *   step_ctr  the device step counter the gradient launches advanced: its value is the hand-shake token of the update
+ *             and indexes the step-size ring like curious_adam_update;
+ *   done, err  two local uint32 / int32 device words (zeroed once): block bookkeeping / "a wait gave up after `spins`
+ *              polls" (the kernel then ends without hanging; the caller raises);
+ *   keep    curious_ddpg_transposed() of the LOCAL workspace: fault word and flag index of the collective hand-off guard
+ *           (every rank reads every rank's flag element and all skip alike), and the transposed copies, rebuilt from the
+ *           new parameters at the end of the kernel (the next gradient call may say params_unchanged).
+ * Sums are taken in rank order 0 .. world - 1 on every rank: the replicas stay bit-identical (mpi_adam.py:42-50).
+ * n_Q + n_pi must divide by world.  The kernel's 64 workgroups wait for peers: every rank must call it for every update. */
+#define CURIOUS_IPC_MAX_RANKS 8
+typedef struct curious_ipc_peers {
+  int32_t world, rank;
+  const float* grad[CURIOUS_IPC_MAX_RANKS];
+  float* theta[CURIOUS_IPC_MAX_RANKS];
+  uint32_t* flags[CURIOUS_IPC_MAX_RANKS];
+} curious_ipc_peers_t;
+int curious_allreduce_adam_ipc(const curious_ipc_peers_t* peers, float* m, float* v, int64_t n_Q, int64_t n_pi,
+                               const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
+                               float beta1, float one_minus_beta1, float beta2, float one_minus_beta2, float epsilon,
+                               uint32_t* done, int32_t* err, int32_t spins, const curious_transposed_t* keep,
+                               curious_stream_t stream);
+
+/* Set-up / tear-down of the peer mappings (host side, synchronous: once per job, not per update).  The vectors a rank
+ * shares come from curious_ipc_alloc (hipMalloc, zeroed), are exported as 64-byte handles (hipIpcGetMemHandle), exchanged
+ * by the caller (any host-side collective) and imported by the peers (hipIpcOpenMemHandle).  Every imported pointer is
+ * closed before its owner frees the block. */
+int curious_ipc_alloc(int64_t bytes, void** out);
+int curious_ipc_free(void* ptr);
+int curious_ipc_export(const void* ptr, unsigned char* handle64);
+int curious_ipc_import(const unsigned char* handle64, void** out);
+int curious_ipc_close(void* ptr);
+
 /* target <- polyak*target + one_minus_polyak*main (ddpg.py:461-462); the two factors are the float32
  * roundings of the Python doubles `polyak` and `1. - polyak`.  polyak = 0, one_minus = 1 copies (ddpg.py:459-460). */
 int curious_polyak_update(float* target, const float* main_, int64_t n, float polyak, float one_minus_polyak,

@@ -570,3 +570,67 @@ def test_policy_snapshot_pickles_like_the_policy_and_is_written_in_the_backgroun
     ev.save_policy(str(tmp_path / 'no_such_dir' / 'x.pkl'))
     with pytest.raises(OSError):
         ev.writer.close()
+
+
+# ------------------------------------------------------------------ fused IPC all-reduce + Adam (opt-in)
+def test_ipc_allreduce_adam_on_one_rank_equals_the_standalone_optimiser():
+    """curious_allreduce_adam_ipc with world = 1 (the rank's own buffers as its only peer): the sum over ranks is the
+    gradient itself, so parameters, moments and the rebuilt transposed copies must equal curious_adam_update with `keep`
+    bit for bit -- mpi_adam.py:29-35 once more, and the index arithmetic of slices, step-size ring and copies."""
+    from curious_amd import _lib, ops
+    from test_gpu_round3 import _filled_agent
+    agent, _ = _filled_agent()
+    agent.train_batches(3)
+    torch.cuda.synchronize()
+    # a gradient for the current parameters, step counter advanced as the several-rank gradient call does
+    agent._train_device_prologue(1)
+    agent._sample_packed()
+    agent._grads_next(agent._cur)
+    torch.cuda.synchronize()
+    keep = agent._kept_copies()
+    state = [x.clone() for x in (agent.theta, agent._m, agent._v, agent._workspace)]
+    ops.adam_update(agent.theta, agent._m, agent._v, agent.grad, agent.off_pi, agent.P_total - agent.off_pi,
+                    alpha_tab=agent._alpha_tab, step_ctr=agent._step_ctr, tab_base=agent._alpha_base, keep=keep)
+    torch.cuda.synchronize()
+    want = [x.clone() for x in (agent.theta, agent._m, agent._v, agent._workspace)]
+    for x, s in zip((agent.theta, agent._m, agent._v, agent._workspace), state):
+        x.copy_(s)
+    flags = torch.zeros(16, dtype=torch.int32, device='cuda')
+    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    peers = _lib.IpcPeers()
+    peers.world, peers.rank = 1, 0
+    peers.grad[0], peers.theta[0], peers.flags[0] = agent.grad.data_ptr(), agent.theta.data_ptr(), flags.data_ptr()
+    ops.allreduce_adam_ipc(peers, agent._m, agent._v, agent.off_pi, agent.P_total - agent.off_pi, agent._alpha_tab,
+                           agent._step_ctr, agent._alpha_base, words[0:1], words[1:2], keep)
+    torch.cuda.synchronize()
+    assert int(words[1]) == 0 and int(words[0]) == 64
+    tok = int(agent._step_ctr)
+    assert flags[0].item() == tok and flags[8].item() == tok           # ready / landed words carry the update's token
+    for name, got, w in zip(('theta', 'm', 'v', 'workspace'), (agent.theta, agent._m, agent._v, agent._workspace), want):
+        assert torch.equal(got, w), name
+    assert not torch.equal(agent.theta, state[0])
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ipc_allreduce_adam_ranks_on_one_gpu(world):
+    """DDPG(_allreduce='ipc') (env CURIOUS_ALLREDUCE=ipc): `world` processes share this GPU, map each other's gradient /
+    parameter vectors through CUDA-IPC handles and run 35 updates + 2 whole cycles of the bench job -- gradients SUMMED in
+    rank order, Adam on the owned slice, new slices handed round, transposed copies rebuilt in the same kernel.  Every
+    rank ends with the same parameters (check_synced on the way); at 2 ranks, where a sum of two is the same in any order,
+    they are bit for bit those of the default path (gloo all-reduce + stand-alone optimiser)."""
+    digests = {}
+    for mode in (('ipc', 'rccl') if world == 2 else ('ipc',)):
+        prefix = os.path.join(tempfile.mkdtemp(), 'digest')
+        env = _two_rank_env(CURIOUS_RANK_CHECK_CYCLES='2', CURIOUS_RANK_CHECK_OUT=prefix, CURIOUS_ALLREDUCE=mode,
+                            HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+               os.path.join(ROOT, 'tools', 'rank_path_check.py')]
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (mode, out.stdout[-1500:], out.stderr[-3000:])
+        found = [open('%s.rank%d' % (prefix, r)).read().split() for r in range(world)]
+        assert len({f[1] for f in found}) == 1 and len(found[0][1]) == 64, (mode, found)
+        assert all(f[2] == '235' for f in found)
+        digests[mode] = found[0][1]
+    if world == 2:
+        assert digests['ipc'] == digests['rccl'], digests

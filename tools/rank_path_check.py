@@ -14,13 +14,17 @@ def main():
     from curious_amd import dist
     dist.init_from_env()
     torch.cuda.set_device(dist.local_device_index())
+    import numpy as np
+    np.random.seed(1234 + 1000000 * dist.rank())                # train.py:242 (the rollouts' task / goal draws)
     if os.environ.get('CURIOUS_RANK_CHECK_STRUCTURE') == 'task_experts':
         return experts_main()
-    params, dims, policy, worker = bench.build_job(use_graph=True)
+    params, dims, policy, worker = bench.build_job(use_graph=os.environ.get('CURIOUS_RANK_CHECK_NOGRAPH', '0') != '1')
     bench.prefill(policy, 256, seed=dist.rank())
     for _ in range(5):
         policy.train()
     policy.train_batches(30)
+    for _ in range(int(os.environ.get('CURIOUS_RANK_CHECK_EXTRA', '0'))):      # (debugging aid: runs of 100 updates, no rollout)
+        policy.train_batches(100)
     # optional: whole cycles (rollout + store + updates) so that ranks diverge in data and must agree through collectives
     for _ in range(int(os.environ.get('CURIOUS_RANK_CHECK_CYCLES', '0'))):
         bench.cycle(policy, worker)
