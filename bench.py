@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--cpu-ranks', type=int, default=-1,
                     help='ranks of the multi-process CPU baseline (default min(19, host cores); 0 = skip)')
     ap.add_argument('--cpu-rank-worker', type=int, nargs=4, default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--ipc-probe', type=int, default=0, help=argparse.SUPPRESS)     # child mode of ipc_probe()
+    ap.add_argument('--no-ipc-probe', action='store_true',
+                    help='several ranks: skip the side measurement of the fused IPC all-reduce + Adam path')
     return ap.parse_args()
 
 
@@ -585,6 +588,68 @@ def collective_report(policy, policies):
                 replicas_identical=identical, replica_checksums=[[int(x) for x in row] for row in allsums.cpu()])
 
 
+def ipc_probe_child(args):
+    """Child mode (bench.py --ipc-probe K, one child per rank, its own process group on MASTER_PORT): K timed cycles of the
+    same workload with DDPG(_allreduce='ipc') -- the fused reduce-scatter + Adam + all-gather kernel over peer-mapped
+    buffers (csrc/ipc.hip) in place of the RCCL all-reduce + optimiser launch.  Rank 0 prints one JSON line."""
+    import numpy as np
+    import torch
+    from curious_amd import dist
+    os.environ['CURIOUS_ALLREDUCE'] = 'ipc'
+    dist.init_from_env()
+    rank, world = dist.rank(), dist.world_size()
+    torch.cuda.set_device(dist.local_device_index())
+    np.random.seed(1234 + 1000000 * rank)
+    params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=args.rollout_batch_size)
+    prefill(policy, args.prefill, seed=rank)
+    for _ in range(2):
+        cycle(policy, worker)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.ipc_probe):
+        cycle(policy, worker)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    err = int(policy._ipc['words'][1]) if getattr(policy, '_ipc', None) else -1
+    policy._check_synced(wait=True)
+    if rank == 0:
+        print(json.dumps(dict(ms_per_step=round(1e3 * elapsed / args.ipc_probe, 4), steps=args.ipc_probe, world=world,
+                              wait_gave_up=err, replicas_identical=True)), flush=True)
+    teardown([policy])
+
+
+def ipc_probe(args, steps=10, timeout=100.0):
+    """Several ranks: how the same cycle runs with the fused IPC all-reduce + Adam kernel instead of RCCL + the optimiser
+    launch -- the only place this path can meet real xGMI links is the driver's multi-GPU run.  Measured in CHILD
+    processes (one per rank, on the rank's GPU, while the parents idle), so that whatever goes wrong there -- a mapping
+    that fails, a wait that never ends -- cannot take the bench line with it: a failure is reported as {"error": ...}."""
+    port = int(os.environ.get('MASTER_PORT', '29500')) + 23
+    cmd = [sys.executable, os.path.abspath(__file__), '--ipc-probe', str(steps), '--gpus', str(args.gpus),
+           '--env', args.env, '--rollout-batch-size', str(args.rollout_batch_size), '--prefill', str(args.prefill)]
+    if args.no_graph:
+        cmd.append('--no-graph')
+    env = dict(os.environ, MASTER_PORT=str(port), CURIOUS_ALLREDUCE='ipc')
+    for k in list(env):                                            # the children rendezvous among themselves (rank 0's child
+        if k.startswith('TORCHELASTIC_'):                          # hosts the store), not through the launcher's agent store
+            del env[k]
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        try:
+            out, errtxt = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return dict(error='timed out after %.0f s' % timeout)
+        if p.returncode != 0:
+            return dict(error='child exited with %d: %s' % (p.returncode, errtxt.decode(errors='replace')[-300:]))
+        lines = [ln for ln in out.decode().splitlines() if ln.startswith('{')]
+        return json.loads(lines[-1]) if lines else dict(ok=True)
+    except Exception as err:                                       # a side measurement must never sink the bench line
+        return dict(error='%s: %s' % (type(err).__name__, err))
+
+
 def teardown(policies, bank=None):
     """Captured graphs hold the communicator's streams: drop them before the process group goes, then leave through the
     normal interpreter exit (curious_amd.experiment.train.shutdown)."""
@@ -596,6 +661,9 @@ def main():
     args = parse()
     if args.cpu_rank_worker is not None:
         cpu_rank_worker(*args.cpu_rank_worker)
+        return
+    if args.ipc_probe:
+        ipc_probe_child(args)
         return
     maybe_relaunch(args)
     # the CPU legs run first, before this process touches the GPU (rank 0 of a one-GPU run only)
@@ -676,6 +744,12 @@ def main():
     coll = None
     if dist.is_distributed():
         coll = collective_report(policy, list(bank) if experts else [policy])
+        if world > 1 and not experts and not args.no_ipc_probe and os.environ.get('CURIOUS_ALLREDUCE', 'rccl') != 'ipc':
+            torch.cuda.synchronize()
+            dist.barrier()
+            probe = ipc_probe(args)                                 # every rank runs its child; rank 0's child reports
+            dist.barrier()
+            coll['ipc_probe'] = probe
 
     if rank == 0:
         T = params['T']

@@ -159,6 +159,9 @@ def test_bench_runs_end_to_end_on_two_ranks():
     assert c['allreduce_us'] > 0 and c['allreduce_bytes'] >= 4 * 294661
     assert c['replicas_identical'] is True and len(c['replica_checksums']) == 2
     assert c['replica_checksums'][0] == c['replica_checksums'][1]
+    # the side measurement of the fused IPC all-reduce + Adam path, run in child processes: ran, nobody gave up
+    assert 'error' not in c['ipc_probe'], c['ipc_probe']
+    assert c['ipc_probe']['world'] == 2 and c['ipc_probe']['ms_per_step'] > 0 and c['ipc_probe']['wait_gave_up'] == 0
 
 
 # ------------------------------------------------------------------ faults: the job goes on
