@@ -652,19 +652,20 @@ __device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, 
 // One batch of argument loads per block: a by-value copy of everything the role needs, taken through an empty asm that
 // wants every field in a scalar register AT THIS POINT -- the compiler then issues all the s_loads together and waits
 // once, instead of fetching field by field, branch by branch (one uncached round trip each).
-#define PIN_S(x) "+s"(x)
-__device__ __forceinline__ void pin_hot(GemmHot& P) {
-  asm volatile("" : PIN_S(P.A), PIN_S(P.B), PIN_S(P.C), PIN_S(P.aux_out), PIN_S(P.dot_out), PIN_S(P.lda), PIN_S(P.ldb),
-               PIN_S(P.ldc), PIN_S(P.M), PIN_S(P.N), PIN_S(P.K));
+// (Input-only operands: the values must be in scalar registers at this point, but they are not redefined -- a pointer that
+//  came OUT of an asm would have lost its provenance, and the compiler would address it with FLAT instructions, which cost
+//  an s_waitcnt vmcnt(0) lgkmcnt(0) whenever their results are needed and cannot be counted past.)
+__device__ __forceinline__ void pin_hot(const GemmHot& P) {
+  asm volatile("" :: "s"(P.A), "s"(P.B), "s"(P.C), "s"(P.aux_out), "s"(P.dot_out), "s"(P.lda), "s"(P.ldb), "s"(P.ldc),
+               "s"(P.M), "s"(P.N), "s"(P.K));
 }
-__device__ __forceinline__ void pin_small(DwSmall& P) {
-  asm volatile("" : PIN_S(P.x), PIN_S(P.dY), PIN_S(P.dW), PIN_S(P.db), PIN_S(P.ldx), PIN_S(P.lddy), PIN_S(P.w), PIN_S(P.N),
-               PIN_S(P.div));
+__device__ __forceinline__ void pin_small(const DwSmall& P) {
+  asm volatile("" :: "s"(P.x), "s"(P.dY), "s"(P.dW), "s"(P.db), "s"(P.ldx), "s"(P.lddy), "s"(P.w), "s"(P.N), "s"(P.div));
 }
-__device__ __forceinline__ void pin_adam(AdamFuse& A) {
-  asm volatile("" : PIN_S(A.theta), PIN_S(A.m), PIN_S(A.v), PIN_S(A.grad), PIN_S(A.n_Q), PIN_S(A.alpha_tab),
-               PIN_S(A.step_ctr), PIN_S(A.tab_base), PIN_S(A.tab_len), PIN_S(A.a_Q), PIN_S(A.a_pi), PIN_S(A.b1),
-               PIN_S(A.omb1), PIN_S(A.b2), PIN_S(A.omb2), PIN_S(A.eps), PIN_S(A.fault), PIN_S(A.step_add));
+__device__ __forceinline__ void pin_adam(const AdamFuse& A) {
+  asm volatile("" :: "s"(A.theta), "s"(A.m), "s"(A.v), "s"(A.grad), "s"(A.n_Q), "s"(A.alpha_tab), "s"(A.step_ctr),
+               "s"(A.tab_base), "s"(A.tab_len), "s"(A.a_Q), "s"(A.a_pi), "s"(A.b1), "s"(A.omb1), "s"(A.b2), "s"(A.omb2),
+               "s"(A.eps), "s"(A.fault), "s"(A.step_add));
 }
 
 // (the leading scalars: preloaded into SGPRs, see DwMap)
@@ -680,7 +681,8 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
     GemmHot P = args.hot.p[R.pi];
     pin_hot(P);
     if (ADAM) pin_adam(A);
-    asm volatile("" : "+s"(grad_stride));
+    asm volatile("" :: "s"(grad_stride));
+    DW_STAMP(sp, 3);
     dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, nullptr, sp, early);
     return;
   }
@@ -694,7 +696,8 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   int M = args.small.M;
   pin_small(P);
   if (ADAM) pin_adam(A);
-  asm volatile("" : "+s"(grad_stride), "+s"(M));
+  asm volatile("" :: "s"(grad_stride), "s"(M));
+  DW_STAMP(sp, 3);
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
   const int64_t eg = (int64_t)blockIdx.y * grad_stride;
   if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, nullptr, sp, early);
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const
 #ifdef DW_STAMPS
   DwStamp stamp;
   stamp.t[0] = __builtin_readcyclecounter();                 // (before anything of the arguments is read)
-  stamp.t[1] = stamp.t[2] = 0;
+  stamp.t[1] = stamp.t[2] = stamp.t[3] = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   DwStamp* sp = &stamp;
 #else
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const
   if (st && threadIdx.x == 0) {
     st[0] = stamp.t[0]; st[1] = stamp.t[1]; st[2] = stamp.t[2]; st[3] = __builtin_readcyclecounter();
     st[4] = (unsigned long long)(R.kind + 1); st[5] = rt0;
-    st[6] = (unsigned long long)R.pi; st[7] = (unsigned long long)R.idx;
+    st[6] = stamp.t[3]; st[7] = (unsigned long long)R.idx;
   }
 #endif
 }

@@ -54,14 +54,15 @@ def main():
                     (rows[:, 1] - rows[:, 0])[rows[:, 1] > 0].mean() if (rows[:, 1] > 0).any() else 0,
                     (rows[:, 2] - rows[:, 1])[rows[:, 2] > 0].mean() if (rows[:, 2] > 0).any() else 0,
                     (rows[:, 3] - rows[:, 2])[rows[:, 2] > 0].mean() if (rows[:, 2] > 0).any() else 0,
-                    (rows[:, 5] - t0).mean() * 10.0, (rows[:, 5] - t0).max() * 10.0, sel.sum()])
+                    (rows[:, 5] - t0).mean() * 10.0, (rows[:, 5] - t0).max() * 10.0, sel.sum(),
+                    (rows[:, 6] - rows[:, 0])[rows[:, 6] > 0].mean() if (rows[:, 6] > 0).any() else 0])
         # the slowest blocks of the last launch
         order = np.argsort(-(a[:, 3] - a[:, 0]) * live)[:12]
         print('slowest blocks of one launch: block id, kind, pi, idx | total = prologue + loads/mfma + epilogue | start ns')
         for b in order:
             r = a[b]
             print('  %4d %-16s %2d %4d | %6d = %6d + %6d + %6d | %5d' %
-                  (b, names[int(r[4])], r[6], r[7], r[3] - r[0], max(r[1] - r[0], 0), max(r[2] - r[1], 0),
+                  (b, names[int(r[4])], 0, r[7], r[3] - r[0], max(r[1] - r[0], 0), max(r[2] - r[1], 0),
                    r[3] - max(r[2], r[0]), (r[5] - t0) * 10))
         if os.environ.get('DW_STAMPS_ALL'):
             print('all small-tile blocks of one launch by (problem, tile): total = prologue + loads/mfma + epilogue')
@@ -74,8 +75,8 @@ def main():
               ('kind', 'blocks', 'mean cyc', 'max cyc', 'prologue', 'loads+mfma', 'epilogue'))
         for kind, rows in acc.items():
             m = np.median(np.array(rows), axis=0)
-            print('%-18s %6d | %9.0f %9.0f | %9.0f %9.0f %9.0f | %7.0f %7.0f' %
-                  (names[kind], m[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6]))
+            print('%-18s %6d | %9.0f %9.0f | %9.0f %9.0f %9.0f | %7.0f %7.0f | arguments in after %5.0f' %
+                  (names[kind], m[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[8]))
     # duration of the launch by events, eager
     ops.prof_collect()
     ops.prof_enable(True)
