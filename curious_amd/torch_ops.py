@@ -13,11 +13,22 @@ The entry points whose arguments are tensors and scalars are registered with `to
     torch.ops.curious_hip.policy_forward(cfg_i, cfg_f, theta, o, g, td, clip_obs, compute_Q) -> (pi, Q)
     torch.ops.curious_hip.ddpg_grads(cfg_i, cfg_f, theta, theta_target, batch, batch_layout, grad) -> (losses, Q_pi)
 
-Entry points that take the reference's table-shaped arguments (record / batch layouts, task tables, sample plans:
-`curious_her_sample`, `curious_store_episodes`, `curious_ddpg_update*`, the env kernels) stay on the struct-carrying
-ctypes binding (curious_amd/ops.py): the dispatcher schema language has no struct type, and flattening ~60 layout
-fields into integer lists per call would only move the unchecked part from pointers to list positions.  Both faces
-call the same symbols; there is no second implementation.
+The three HOT entry points take the reference's table-shaped arguments (record / batch layouts, task tables, sampler
+descriptions) -- the dispatcher's schema language has no struct type.  They get an opaque DESCRIPTOR instead (round 4):
+`desc_create(...)` files the structs once and returns an int64 handle, the ops then take the handle + tensors:
+
+    d = torch_ops.desc_create(layout=..., tasks=..., params=..., rng=..., buf_stride=..., n=...)
+    torch.ops.curious_hip.her_sample(d, storage, batch)                                   # her.py:99-183, ddpg.py:326-353
+    d = torch_ops.desc_create(cfg=..., layout=..., B=..., tab_base=..., tasks=..., params=..., rng=..., buf_stride=...)
+    torch.ops.curious_hip.ddpg_update(d, theta, theta_target, batch, workspace, grad, losses, Q_pi, m, v, step_ctr,
+                                      alpha_tab, next_batch, storage, params_unchanged)   # ddpg.py:235-248 + mpi_adam
+    d = torch_ops.desc_create(cfg=..., ecfg=..., layout=..., n=..., clip_obs=..., noise_scale=..., random_eps=..., seed=...,
+                              counter=..., env_id0=..., t0=..., nsteps=..., reward_eps=..., relative_goals=...)
+    torch.ops.curious_hip.policy_rollout(d, theta, workspace, u_out, counter_base, episode, tasks, o, ag, g, td, staging,
+                                         flags)                                            # rollout.py:226-303 x T
+
+The remaining struct-carrying entry points (`curious_store_episodes`, the env reset / step kernels, the batched experts)
+stay on the ctypes binding (curious_amd/ops.py).  Both faces call the same symbols; there is no second implementation.
 """
 import ctypes as C
 
@@ -116,3 +127,61 @@ def ddpg_grads(cfg_i: list[int], cfg_f: list[float], theta: torch.Tensor, theta_
 @ddpg_grads.register_fake
 def _(cfg_i, cfg_f, theta, theta_target, batch, batch_layout, grad):
     return batch.new_empty(2), batch.new_empty([batch.shape[0], 1])
+
+
+# ------------------------------------------------------------------ descriptor-carrying ops (the three hot entry points)
+_DESCS = {}
+
+
+def desc_create(**fields):
+    """File the struct-shaped arguments of a hot entry point (layouts, task tables, sampler / env descriptions, scalars)
+    and return an int64 handle for the ops below.  The descriptor keeps what it is given alive (e.g. the device tables a
+    SampleRng points into, through `keep=`)."""
+    h = (max(_DESCS) + 1) if _DESCS else 1
+    _DESCS[h] = dict(fields)
+    return h
+
+
+def desc_free(handle):
+    _DESCS.pop(int(handle), None)
+
+
+def _desc(handle):
+    try:
+        return _DESCS[int(handle)]
+    except KeyError:
+        raise _lib.CuriousHipError('unknown descriptor handle %r (torch_ops.desc_create)' % (handle,))
+
+
+@torch.library.custom_op(_NS + '::her_sample', mutates_args=('batch',), device_types='cuda')
+def her_sample(desc: int, storage: torch.Tensor, batch: torch.Tensor) -> None:
+    d = _desc(desc)                                                                  # her.py:99-183, ddpg.py:326-353
+    ops.her_sample(storage, d['buf_stride'], d['layout'], d['tasks'], d['params'], d['n'], batch, plan=d.get('plan'),
+                   rng=d.get('rng'))
+
+
+@torch.library.custom_op(_NS + '::ddpg_update',
+                         mutates_args=('theta', 'workspace', 'grad', 'losses', 'Q_pi', 'm', 'v', 'step_ctr', 'next_batch'),
+                         device_types='cuda')
+def ddpg_update(desc: int, theta: torch.Tensor, theta_target: torch.Tensor, batch: torch.Tensor, workspace: torch.Tensor,
+                grad: torch.Tensor, losses: torch.Tensor, Q_pi: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
+                step_ctr: torch.Tensor, alpha_tab: torch.Tensor, next_batch: torch.Tensor, storage: torch.Tensor,
+                params_unchanged: bool) -> None:
+    d = _desc(desc)                                                                  # ddpg.py:235-248, mpi_adam.py:29-35
+    ops.ddpg_update(d['cfg'], theta, theta_target, batch, d['layout'], d['B'], workspace, grad, losses, Q_pi, m, v,
+                    step_ctr=step_ctr, alpha_tab=alpha_tab, tab_base=d.get('tab_base', 0), o_stats=d.get('o_stats'),
+                    g_stats=d.get('g_stats'), next_batch=next_batch, storage=storage, buf_stride=d['buf_stride'],
+                    tasks=d['tasks'], params=d['params'], rng=d['rng'], params_unchanged=params_unchanged)
+
+
+@torch.library.custom_op(_NS + '::policy_rollout',
+                         mutates_args=('workspace', 'u_out', 'episode', 'o', 'ag', 'staging', 'flags'), device_types='cuda')
+def policy_rollout(desc: int, theta: torch.Tensor, workspace: torch.Tensor, u_out: torch.Tensor,
+                   counter_base: torch.Tensor, episode: torch.Tensor, tasks: torch.Tensor, o: torch.Tensor,
+                   ag: torch.Tensor, g: torch.Tensor, td: torch.Tensor, staging: torch.Tensor, flags: torch.Tensor) -> None:
+    d = _desc(desc)                                                                  # rollout.py:226-303 for every env
+    ops.policy_rollout(d['cfg'], theta, d['n'], d['clip_obs'], workspace, d['noise_scale'], d['random_eps'], d['seed'],
+                       d['counter'], u_out, d['ecfg'], d['layout'], d['env_id0'], episode, tasks, d['t0'], d['nsteps'],
+                       o, ag, g, td, staging, d['reward_eps'], counter_base=counter_base, flags=flags,
+                       o_stats=d.get('o_stats'), g_stats=d.get('g_stats'),
+                       relative_goals=bool(d.get('relative_goals', False)))

@@ -637,3 +637,73 @@ def test_ipc_allreduce_adam_ranks_on_one_gpu(world):
         digests[mode] = found[0][1]
     if world == 2:
         assert digests['ipc'] == digests['rccl'], digests
+
+
+# ------------------------------------------------------------------ custom-op face of the three hot entry points
+def test_torch_custom_op_face_of_the_hot_entry_points():
+    """north_star: "exposed to Python via PyTorch-ROCm custom ops".  torch.ops.curious_hip.{her_sample, ddpg_update,
+    policy_rollout} take an opaque descriptor (torch_ops.desc_create: the struct-shaped arguments, filed once) + tensors
+    and call the same symbols as curious_amd.ops: two identically seeded jobs, one driven through each face, end bit for
+    bit alike."""
+    import curious_amd.torch_ops as T
+    from curious_amd import ops
+    from curious_amd.envs import REWARD_EPS
+    from test_gpu_agent import T as horizon
+
+    def run(face):
+        np.random.seed(5)
+        agent, w = _job(use_graph=False, seed=11)
+        S = agent.sample_transitions
+        env = w.benv
+        # -- her_sample: one device-drawn minibatch
+        agent._train_device_prologue(1)
+        P = S.params(agent.clip_obs, agent.relative_goals)
+        batch = agent._pp[0]
+        if face == 'ops':
+            ops.her_sample(agent._pool.storage, agent._pool.buf_stride, agent._layout, S.tasks, P, agent.batch_size, batch,
+                           rng=agent._rng_desc)
+        else:
+            d = T.desc_create(layout=agent._layout, tasks=S.tasks, params=P, rng=agent._rng_desc,
+                              buf_stride=agent._pool.buf_stride, n=agent.batch_size, keep=agent._tables)
+            torch.ops.curious_hip.her_sample(d, agent._pool.storage, batch)
+        # -- ddpg_update: three fused updates (gradients + Adam + the gather of the next batch)
+        if face != 'ops':
+            du = T.desc_create(cfg=agent.net_cfg, layout=agent._layout, B=agent.batch_size, tab_base=agent._alpha_base,
+                               tasks=S.tasks, params=P, rng=agent._rng_desc, buf_stride=agent._pool.buf_stride)
+        for k in range(3):
+            p = k & 1
+            if face == 'ops':
+                agent._update_fused(p, chained=k > 0)
+            else:
+                torch.ops.curious_hip.ddpg_update(du, agent.theta, agent.theta_target, agent._pp[p], agent._workspace,
+                                                  agent.grad, agent._losses, agent._Q_pi, agent._m, agent._v,
+                                                  agent._step_ctr, agent._alpha_tab, agent._pp[p ^ 1], agent._pool.storage,
+                                                  k > 0)
+        # -- policy_rollout: a whole T-step rollout of the batched env in one launch
+        env.reset_all(np.arange(env.n) % 4, np.linspace(-1, 1, 3 * env.n, dtype=np.float32).reshape(env.n, 3))
+        ws = torch.zeros(ops.workspace_floats(agent.net_cfg, env.n), device='cuda')
+        u = torch.empty([env.n, 4], device='cuda')
+        base = torch.zeros(1, dtype=torch.int64, device='cuda')
+        seed = 987654321
+        if face == 'ops':
+            ops.policy_rollout(agent.net_cfg, agent.theta, env.n, agent.clip_obs, ws, 0.2, 0.3, seed, 1, u, env._cfg,
+                               env.layout, env.env_id0, env.episode, env.tasks, 0, horizon, env.o, env.ag, env.g, env.td,
+                               env.staging, REWARD_EPS, counter_base=base, flags=env.flags)
+        else:
+            dr = T.desc_create(cfg=agent.net_cfg, ecfg=env._cfg, layout=env.layout, n=env.n, clip_obs=agent.clip_obs,
+                               noise_scale=0.2, random_eps=0.3, seed=seed, counter=1, env_id0=env.env_id0, t0=0,
+                               nsteps=horizon, reward_eps=REWARD_EPS)
+            torch.ops.curious_hip.policy_rollout(dr, agent.theta, ws, u, base, env.episode, env.tasks, env.o, env.ag, env.g,
+                                                 env.td, env.staging, env.flags)
+            for h in (d, du, dr):
+                T.desc_free(h)
+        torch.cuda.synchronize()
+        return dict(batch=batch.clone(), theta=agent.theta.clone(), m=agent._m.clone(), losses=agent._losses.clone(),
+                    staging=env.staging.clone(), flags=env.flags.clone(), u=u.clone(), ctr=agent._step_ctr.clone())
+
+    a, b = run('ops'), run('torch')
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a['u'].abs().sum()) > 0 and int(a['ctr']) == 3
+    with pytest.raises(Exception):
+        torch.ops.curious_hip.her_sample(12345, a['batch'], a['batch'])             # unknown descriptor
