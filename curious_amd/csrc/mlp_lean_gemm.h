@@ -48,6 +48,27 @@ __device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int
 //  they count as per-lane values, so the wait sits where the pin is and the arithmetic that follows stays in the VALU.)
 #define PIN_V(x) asm volatile("" : "+v"(x))
 #define DW_INLINE __forceinline__
+// Operand address = wave-uniform base pointer + 32-bit per-lane byte offset: the form hipcc emits as
+//   global_load vdst, voff, s[base:base+1]
+// i.e. the row part of every address is SALU work (an s_add / s_addc pair beside the vector pipeline) and the lane part is ONE
+// register for the whole tile.  With 64-bit per-lane pointers a tile spent 160 VALU instructions (5 per load, 2 waves per
+// SIMD: ~1.5 k cycles) on addresses before its first operand load went out (tools/dw_stamps.py).
+__device__ __forceinline__ float ld_su(const float* ubase, uint32_t lane_bytes) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + lane_bytes);
+}
+__device__ __forceinline__ f32x4 ld4_su(const float* ubase, uint32_t lane_bytes) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ubase) + lane_bytes);
+}
+// t / nx, t % nx for a uniform t: a shift when nx is a power of two (the hidden layers: nx = 4) instead of the
+// v_rcp-based division sequence
+__device__ __forceinline__ void tile_divmod(const int t, const int nx, int& by, int& bx) {
+  if ((nx & (nx - 1)) == 0) {
+    const int sh = __builtin_ctz(nx);
+    by = t >> sh; bx = t & (nx - 1);
+  } else {
+    by = t / nx; bx = t - by * nx;
+  }
+}
 
 struct AdamEarly { int32_t fw, lo, hi; };
 __device__ inline AdamEarly adam_early(const AdamFuse& A, int64_t eo) {
@@ -280,11 +301,15 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
                                    const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
                                    DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
   const int nx = P.N >> 6;
-  const int by = t / nx, bx = t - by * nx;
+  int by, bx;
+  tile_divmod(t, nx, by, bx);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int k0 = by * 16, n0 = bx * 64;
-  const float* xc = P.A + eo + k0 + j;
-  const float* yc = P.B + eo + n0 + 4 * j;
+  const float* xu = P.A + eo + k0;                           // (uniform parts; lane parts below, ld_su)
+  const float* yu = P.B + eo + n0;
+  const uint32_t xo = (uint32_t)(4 * q * P.lda + j) * 4u;
+  const uint32_t yo = (uint32_t)(4 * q * P.ldb + 4 * j) * 4u;
   // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0);
   // pidx / bidx = parameter indices (the same for every expert), addressed at index + eo
   const int64_t toff = (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
@@ -312,13 +337,13 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
     f32x4 b[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         // (one-launch update: plain loads are enough for these [B, 256] matrices -- no workgroup on this XCD has
         //  touched the rows of OTHER row groups since the launch began, so no stale line can sit in its L2 or L1)
-        a[u][s] = xc[(int64_t)(mq + s) * P.lda];
-        b[u][s] = ldv(yc + (int64_t)(mq + s) * P.ldb);
+        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
+        b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
       }
     }
     LOADS_FIRST();
@@ -405,14 +430,18 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
                                      DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
-  const int by = t / nx, bx = t - by * nx;
+  int by, bx;
+  tile_divmod(t, nx, by, bx);
   const int j = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int k0 = by * 16, n0 = bx * 64;
   const int krow = k0 + j, col = n0 + 4 * j;
   const bool k_ok = krow < P.w;
-  const float* xc = P.x + eo + min(krow, P.w - 1);
   const int colc = YV ? min(col, P.N - 4) : 0;
-  const float* yc = P.dY + eo + colc;
+  const float* xu = P.x + eo;                                 // (uniform parts; lane parts below, ld_su)
+  const float* yu = P.dY + eo;
+  const uint32_t xo = (uint32_t)(4 * q * P.ldx + min(krow, P.w - 1)) * 4u;
+  const uint32_t yo = (uint32_t)(4 * q * P.lddy + colc) * 4u;
   // optimiser operands of what this thread finishes, fetched with the first batch of loads
   const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
   const bool own = grow < P.w && gcol < P.N;
@@ -447,10 +476,11 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
     f32x4 b[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int mq = mb + (wave + 4 * u) * 16 + 4 * q;
+      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
+      const int mq = mu + 4 * q;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[u][s] = xc[(int64_t)(mq + s) * P.ldx];
+        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
         if (ycoh) {
           if (YV) {
             b[u][s] = coh_ld4(ry, ((mq + s) * P.lddy + colc) * 4);
@@ -460,10 +490,10 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
           }
         } else {
           if (YV) {
-            b[u][s] = ldv(yc + (int64_t)(mq + s) * P.lddy);
+            b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
           } else {
             b[u][s] = zero4();
-            b[u][s][0] = yc[(int64_t)(mq + s) * P.lddy];
+            b[u][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
           }
         }
       }
