@@ -94,9 +94,14 @@ struct RowsArgs {
 #else
 #define ROWS_DBG(x) do { } while (0)
 #endif
+#ifdef ROWS_DEBUG2          // (tools/rows_lab.hip -DROWS_DEBUG2: a stamp behind every chunk of the forward hidden layers)
+#define ROWS_DBG2(x) ROWS_DBG(x)
+#else
+#define ROWS_DBG2(x) do { } while (0)
+#endif
 struct RCtx {
   mutable unsigned long long* dbg;
-  float* hs; float* part; float* xin; float* sm; float* keep;
+  float* hs; mutable float* part; mutable float* part2; float* xin; float* sm; float* keep;
   int tid, wave, lane, r0;
   bool pub;   // one-launch update: what the tiles of the same launch read is stored THROUGH the L2 (agent-coherent stores)
 };
@@ -150,29 +155,56 @@ __device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* h
 // ---- epilogues: partial tiles -> LDS -> finished rows (next layer's input in hs, optional copies)
 // forward: acc[e][r] = partial of out[row r][column 4 lane + e] over this wave's k quarter
 // bv = bias[tid], loaded by the caller at the start of the layer (not here: its latency would be exposed)
-__device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[4], const float bv, float* keep,
-                                               float* gout) {
+// lean = false: two workgroup barriers (partials published | finished rows published).
+// lean (the update chains, round 4): ONE.  Thread tid finishes column tid = 64 wave + lane, and the next layer's
+// wave reads exactly the columns [64 wave, 64 wave + 64) of hs as its A operand: the finished rows never cross a wave on
+// their way into the next hidden layer, and LDS operations of one wave execute in order.  What would race without the
+// second barrier is the NEXT layer's partials against a slow wave still summing this layer's: the partials alternate
+// between two buffers (x.part / x.part2), and a buffer comes round again only behind the barrier of the layer in between.
+// A layer whose rows ARE read across waves next (an output layer, the action-slot product) keeps both.
+// While no wave is held at the issue of a load the CU's fill path idles (tools/rowchain2_lab.hip: every cycle of epilogue
+// is a cycle added to the layer), so the epilogue is kept short: all 16 partials are requested before the first sum, the
+// copies and stores sit behind one uniform branch each instead of one per row.
+__device__ __forceinline__ void rows_finish_sums(const RCtx& x, const f32x4 (&acc)[4], float (&s)[4], const bool lean) {
+  float* part = x.part;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    *reinterpret_cast<f32x4*>(x.part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
+    *reinterpret_cast<f32x4*>(part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
   }
   __syncthreads();
+  float p[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[r][j] = part[(j * 4 + r) * 256 + x.tid];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = (p[r][0] + p[r][1]) + (p[r][2] + p[r][3]);
+  if (lean) { x.part = x.part2; x.part2 = part; }
+}
+__device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[4], const float bv, float* keep,
+                                               float* gout, const bool lean = false) {
+  float s[4];
+  rows_finish_sums(x, acc, s, lean);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float s = (x.part[(0 * 4 + r) * 256 + x.tid] + x.part[(1 * 4 + r) * 256 + x.tid]) +
-              (x.part[(2 * 4 + r) * 256 + x.tid] + x.part[(3 * 4 + r) * 256 + x.tid]);
-    s = fmaxf(s + bv, 0.f);
-    x.hs[r * RLD + x.tid] = s;
-    if (keep) keep[r * 256 + x.tid] = s;
-    if (gout) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s);
+    s[r] = fmaxf(s[r] + bv, 0.f);
+    x.hs[r * RLD + x.tid] = s[r];
   }
-  __syncthreads();
+  if (keep) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r * 256 + x.tid] = s[r];
+  }
+  if (gout) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
+  }
+  if (!lean) __syncthreads();
 }
 // ---- one 256 x 256 hidden layer, forward: hs <- relu(hs . W + bias)
 // (the first chunk of W is already in flight into wb[0]: rows_prefetch of the predecessor)
 __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* bias,
-                                             float* keep, float* gout, const RNext& next) {
+                                             float* keep, float* gout, const RNext& next, const bool lean = false) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const float bv = bias[x.tid];
 #pragma unroll
@@ -181,14 +213,15 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
     else rows_prefetch(wb[0], next, x.wave, x.lane);
     __builtin_amdgcn_sched_barrier(0);
     rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
+    ROWS_DBG2(x);
   }
-  rows_fw_finish(x, acc, bv, keep, gout);
+  rows_fw_finish(x, acc, bv, keep, gout, lean);
   ROWS_DBG(x);                                               // (one stamp per layer: finer ones slow the measured group down)
 }
 // ---- one 256 x 256 hidden layer, backward on the TRANSPOSED matrix: hs <- (hs . WT) * relu'(mask), WT[n][k] = W[k][n].
 // The forward product with another epilogue (no bias; the kept activation of the layer below gates the gradient).
 __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const float* mask,
-                                              float* gout, const RNext& next) {
+                                              float* gout, const RNext& next, const bool lean = false) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -197,21 +230,21 @@ __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16],
     __builtin_amdgcn_sched_barrier(0);
     rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
   }
+  float mk[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mk[r] = mask[r * 256 + x.tid];    // (this thread's own copies: requested ahead of the barrier)
+  float s[4];
+  rows_finish_sums(x, acc, s, lean);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    *reinterpret_cast<f32x4*>(x.part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
+    s[r] = (mk[r] > 0.f) ? s[r] : 0.f;
+    x.hs[r * RLD + x.tid] = s[r];
   }
-  __syncthreads();
+  if (gout) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float s = (x.part[(0 * 4 + r) * 256 + x.tid] + x.part[(1 * 4 + r) * 256 + x.tid]) +
-              (x.part[(2 * 4 + r) * 256 + x.tid] + x.part[(3 * 4 + r) * 256 + x.tid]);
-    s = (mask[r * 256 + x.tid] > 0.f) ? s : 0.f;
-    x.hs[r * RLD + x.tid] = s;
-    if (gout) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s);
+    for (int r = 0; r < 4; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
   }
-  __syncthreads();
+  if (!lean) __syncthreads();
 }
 
 // ---- layer 0: hs <- relu(x . W0 + g . Wg + b0).  The input row in LDS is xin[i] = [o | td | action slot | g]: the first
@@ -235,7 +268,7 @@ __device__ __forceinline__ void rows_l0_mac(const RCtx& x, const f32x4 (&b)[16],
 // parameters were just rewritten by the optimiser, a load issued here would be a second cold round trip)
 __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W0, int S, const float* Wg,
                                             int G, int gofs, const float bv, float* keep, float* gout,
-                                            const RNext& next) {
+                                            const RNext& next, const bool lean = false) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const int nk = S + G;
   const bool two = nk > 64;
@@ -245,7 +278,7 @@ __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], c
   rows_prefetch(wb[0], next, x.wave, x.lane);
   __builtin_amdgcn_sched_barrier(0);
   if (two) rows_l0_mac(x, wb[1], S, nk, gofs, 16, acc);
-  rows_fw_finish(x, acc, bv, keep, gout);
+  rows_fw_finish(x, acc, bv, keep, gout, lean);
 }
 
 // ---- output layers: wave i finishes batch row r0 + i; the result is uniform over the wave.  The output-layer weights
@@ -300,13 +333,16 @@ __device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& 
 // hidden layers 1 .. nl-1 of a network, forward; which: 0 nothing stored, 1 -> a.actc[l], 2 -> a.acta[l]
 // (the kernarg arrays are indexed in place: handing their address around would copy the struct to scratch memory)
 // `after` = what follows the network's last hidden layer
+// (the network's last hidden layer keeps both barriers: an output layer reads its rows across the waves)
 __device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
                                                 const float* th, float* keep0, int which, int64_t eo,
                                                 const RNext& after) {
+  if (a.nl == 1) __syncthreads();                            // (layer 0 ran with one barrier: rows_fw_finish)
   for (int l = 1; l < a.nl; ++l) {
     float* g = (which == 1) ? a.actc[l] + eo : (which == 2) ? a.acta[l] + eo : nullptr;
-    const RNext nx = (l + 1 < a.nl) ? rnext(RN_FWD, th + N.W[l + 1]) : after;
-    rows_big_fwd(x, wb, th + N.W[l], th + N.b[l], keep0 ? keep0 + l * 1024 : nullptr, g, nx);
+    float* kp = keep0 ? keep0 + l * 1024 : nullptr;
+    const bool more = l + 1 < a.nl;
+    rows_big_fwd(x, wb, th + N.W[l], th + N.b[l], kp, g, more ? rnext(RN_FWD, th + N.W[l + 1]) : after, more);
   }
 }
 // hidden layers nl-1 .. 1 of a network, backward on the transposed copies; which: 0 critic, nothing stored,
@@ -317,7 +353,7 @@ __device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16
     float* g = (which == 1) ? a.dactc[l - 1] + eo : (which == 2) ? a.dacta[l - 1] + eo : nullptr;
     const float* wt = ((which == 2) ? a.wTpi[l] : a.wTq[l]) + eo;
     const RNext nx = (l > 1) ? rnext(RN_FWD, ((which == 2) ? a.wTpi[l - 1] : a.wTq[l - 1]) + eo) : after;
-    rows_big_bwdT(x, wb, wt, keep0 + (l - 1) * 1024, g, nx);
+    rows_big_bwdT(x, wb, wt, keep0 + (l - 1) * 1024, g, nx, l > 1);
   }
 }
 // what the layer in front of a network's backward pass loads ahead: the first chunk of its top hidden matrix
@@ -328,7 +364,7 @@ __device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, i
 // ================================================================== the kernel
 // grid (4 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
-  return 4 * RLD + 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;
+  return 4 * RLD + 2 * 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;   // (two buffers of partials: rows_fw_finish)
 }
 
 // HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
@@ -345,7 +381,8 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   x.pub = STEP;
   x.hs = rows_lds;
   x.part = x.hs + 4 * RLD;
-  x.xin = x.part + 4 * 4 * 256;
+  x.part2 = x.part + 4 * 4 * 256;
+  x.xin = x.part2 + 4 * 4 * 256;
   x.sm = x.xin + 4 * XLD;
   x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
@@ -414,7 +451,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     const float bpi_t = tp[a.tPi.bout + (x.lane & 3)];
     const float b0_tq = tq[a.tQ.b0 + x.tid];
     rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, nullptr, nullptr,
-                rnext(RN_FWD, tp + a.tPi.W[1]));
+                rnext(RN_FWD, tp + a.tPi.W[1]), true);
     ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.tPi, tp, nullptr, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
     ROWS_STAMP(3);
@@ -434,7 +471,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     __syncthreads();
     ROWS_STAMP(4);
     rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, nullptr, nullptr,
-                rnext(RN_FWD, tq + a.tQ.W[1]));
+                rnext(RN_FWD, tq + a.tQ.W[1]), true);
     rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
     const float Qt = rows_head1(x, wq_t) + bq_t;                                           // ddpg.py:427-431
@@ -462,7 +499,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     const float rew = batch[(int64_t)m * a.ld + a.off_r];
     // activations kept for the backward pass and the weight gradients
     rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, x.keep, a.actc[0] + eo,
-                rnext(RN_FWD, mq + a.mQ.W[1]));
+                rnext(RN_FWD, mq + a.mQ.W[1]), true);
     ROWS_STAMP(2);
     rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rows_bwd_first(a, false, eo));
     ROWS_STAMP(3);
@@ -533,7 +570,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const f32x4 bpi = ldv(mp + a.mPi.bout);
   const float b0_mq = mq[a.mQ.b0 + x.tid];
   rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, keepA, a.acta[0] + eo,
-              rnext(RN_FWD, mp + a.mPi.W[1]));
+              rnext(RN_FWD, mp + a.mPi.W[1]), true);
   ROWS_STAMP(2);
   rows_hidden_fwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
   ROWS_STAMP(3);
@@ -565,7 +602,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const float wq_col = mq[a.mQ.Wout + x.tid];
   // ---- main critic on (o, g, pi) -> Q_pi
   rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, keepD, nullptr,
-              rnext(RN_FWD, mq + a.mQ.W[1]));
+              rnext(RN_FWD, mq + a.mQ.W[1]), true);
   rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
   ROWS_STAMP(5);
   {

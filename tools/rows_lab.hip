@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
       unsigned long long d[256];
       CK(hipMemcpy(d, dst + 96, sizeof(d), hipMemcpyDeviceToHost));
       printf("  actor side, end of each forward hidden layer, deltas: ");
-      for (int k = 1; k < 8 && d[k]; ++k) printf(" %llu", d[k] - d[k - 1]);
+      for (int k = 1; k < 40 && d[k]; ++k) printf(" %llu", d[k] - d[k - 1]);
       printf("\n");
     }
   }
