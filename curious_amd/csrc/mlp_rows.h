@@ -120,10 +120,13 @@ __device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int
 // ---- what a layer routine loads ahead for its successor (weights do not depend on activations): the successor's
 // first chunk lands in wb[0] while this layer's last chunk is multiplied / its epilogue runs
 enum { RN_NONE = 0, RN_FWD = 1, RN_L0 = 3 };
-struct RNext { int kind; const float* W; int S; const float* Wg; int nk; };     // RN_L0: W = W0
-__device__ __forceinline__ RNext rnext(int kind, const float* W, int S = 0, const float* Wg = nullptr, int nk = 0) {
+// (off: added to W where the prefetch is issued, not where the descriptor is built -- an offset that was itself just
+//  fetched from the arguments is then waited for behind the layer's own loads, rows_hidden_fwd)
+struct RNext { int kind; const float* W; int S; const float* Wg; int nk; int64_t off; };     // RN_L0: W = W0
+__device__ __forceinline__ RNext rnext(int kind, const float* W, int S = 0, const float* Wg = nullptr, int nk = 0,
+                                       int64_t off = 0) {
   RNext n;
-  n.kind = kind; n.W = W; n.S = S; n.Wg = Wg; n.nk = nk;
+  n.kind = kind; n.W = W; n.S = S; n.Wg = Wg; n.nk = nk; n.off = off;
   return n;
 }
 // layer-0 rows of the virtual k = 4 (t0 + t) + wave, t = 0..15 (rows past the end are clamped to row 0 and ignored)
@@ -138,7 +141,7 @@ __device__ __forceinline__ void rows_l0_load(f32x4 (&b)[16], const float* W0, in
   }
 }
 __device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, int wave, int lane) {
-  if (n.kind == RN_FWD) rows_fw_load(b, n.W, wave, lane, 0);
+  if (n.kind == RN_FWD) rows_fw_load(b, n.W + n.off, wave, lane, 0);
   else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
 }
 __device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c,
@@ -203,14 +206,22 @@ __device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)
 }
 // ---- one 256 x 256 hidden layer, forward: hs <- relu(hs . W + bias)
 // (the first chunk of W is already in flight into wb[0]: rows_prefetch of the predecessor)
+// late_off: added to next.off of a lean layer where the prefetch is issued (a value that may still be on its way from the
+// arguments when the layer starts)
 __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* bias,
-                                             float* keep, float* gout, const RNext& next, const bool lean = false) {
+                                             float* keep, float* gout, const RNext& next, const bool lean = false,
+                                             const int64_t late_off = 0) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const float bv = bias[x.tid];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    if (c < 3) rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
-    else rows_prefetch(wb[0], next, x.wave, x.lane);
+    if (c < 3) {
+      rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
+    } else {
+      RNext n = next;
+      if (lean) n.off += late_off;                            // (lean <=> another hidden layer of the network follows)
+      rows_prefetch(wb[0], n, x.wave, x.lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
     ROWS_DBG2(x);
@@ -334,26 +345,35 @@ __device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& 
 // (the kernarg arrays are indexed in place: handing their address around would copy the struct to scratch memory)
 // `after` = what follows the network's last hidden layer
 // (the network's last hidden layer keeps both barriers: an output layer reads its rows across the waves)
+// The offsets of layer l + 1 are fetched while layer l runs and carried in registers: read at the top of a layer, as
+// `th + N.W[l]`, they put two dependent scalar-load waits (~300 cycles) between the barrier and the layer's first operand
+// load -- with the fill path idle.
 __device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
                                                 const float* th, float* keep0, int which, int64_t eo,
                                                 const RNext& after) {
   if (a.nl == 1) __syncthreads();                            // (layer 0 ran with one barrier: rows_fw_finish)
+  int Wc = N.W[1], bc = N.b[1];
   for (int l = 1; l < a.nl; ++l) {
+    const bool more = l + 1 < a.nl;
+    const int ln = more ? l + 1 : l;
+    const int Wn = N.W[ln], bn = N.b[ln];                    // (consumed by the prefetch behind this layer's third chunk)
     float* g = (which == 1) ? a.actc[l] + eo : (which == 2) ? a.acta[l] + eo : nullptr;
     float* kp = keep0 ? keep0 + l * 1024 : nullptr;
-    const bool more = l + 1 < a.nl;
-    rows_big_fwd(x, wb, th + N.W[l], th + N.b[l], kp, g, more ? rnext(RN_FWD, th + N.W[l + 1]) : after, more);
+    rows_big_fwd(x, wb, th + Wc, th + bc, kp, g, more ? rnext(RN_FWD, th) : after, more, Wn);
+    Wc = Wn; bc = bn;
   }
 }
 // hidden layers nl-1 .. 1 of a network, backward on the transposed copies; which: 0 critic, nothing stored,
 // 1 critic -> a.dactc[l-1], 2 actor -> a.dacta[l-1]
 __device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a,
                                                 const float* keep0, int which, int64_t eo, const RNext& after) {
+  const float* wt = (which == 2) ? a.wTpi[a.nl - 1] : a.wTq[a.nl - 1];
   for (int l = a.nl - 1; l >= 1; --l) {
+    const int ln = (l > 1) ? l - 1 : l;
+    const float* wn = (which == 2) ? a.wTpi[ln] : a.wTq[ln];            // (fetched while layer l runs: rows_hidden_fwd)
     float* g = (which == 1) ? a.dactc[l - 1] + eo : (which == 2) ? a.dacta[l - 1] + eo : nullptr;
-    const float* wt = ((which == 2) ? a.wTpi[l] : a.wTq[l]) + eo;
-    const RNext nx = (l > 1) ? rnext(RN_FWD, ((which == 2) ? a.wTpi[l - 1] : a.wTq[l - 1]) + eo) : after;
-    rows_big_bwdT(x, wb, wt, keep0 + (l - 1) * 1024, g, nx, l > 1);
+    rows_big_bwdT(x, wb, wt + eo, keep0 + (l - 1) * 1024, g, (l > 1) ? rnext(RN_FWD, wn, 0, nullptr, 0, eo) : after, l > 1);
+    wt = wn;
   }
 }
 // what the layer in front of a network's backward pass loads ahead: the first chunk of its top hidden matrix
