@@ -117,6 +117,14 @@ __device__ __forceinline__ void rows_fw_load(f32x4 (&b)[16], const float* W, int
 #pragma unroll
   for (int i = 0; i < 16; ++i) b[i] = ldv(p + (int64_t)i * 256);
 }
+// (rows 4 kq .. 4 kq + 3 of the chunk: the hidden layers issue a chunk's loads 4 at a time, in front of each group of 16
+//  matrix instructions -- a wave that issues 16 loads in a row is held until the texture path has taken them all, and its
+//  matrix instructions wait behind them: tools/rowchain2_lab.hip, 2.34 -> 2.23 us per layer)
+__device__ __forceinline__ void rows_fw_load4(f32x4 (&b)[16], const float* W, int wave, int lane, int c, int kq) {
+  const float* p = W + (int64_t)(64 * wave + 16 * c + 4 * kq) * 256 + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[4 * kq + i] = ldv(p + (int64_t)i * 256);
+}
 // ---- what a layer routine loads ahead for its successor (weights do not depend on activations): the successor's
 // first chunk lands in wb[0] while this layer's last chunk is multiplied / its epilogue runs
 enum { RN_NONE = 0, RN_FWD = 1, RN_L0 = 3 };
@@ -140,9 +148,51 @@ __device__ __forceinline__ void rows_l0_load(f32x4 (&b)[16], const float* W0, in
     b[t] = ldv(p + 4 * lane);
   }
 }
+__device__ __forceinline__ void rows_l0_load4(f32x4 (&b)[16], const float* W0, int S, const float* Wg, int nk, int wave,
+                                              int lane, int t0, int kq) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = 4 * kq + i;
+    const int kv = 4 * (t0 + t) + wave;
+    const int kc = (kv < nk) ? kv : 0;
+    const float* p = (kc < S) ? W0 + (int64_t)kc * 256 : Wg + (int64_t)(kc - S) * 256;
+    b[t] = ldv(p + 4 * lane);
+  }
+}
+__device__ __forceinline__ void rows_prefetch4(f32x4 (&b)[16], const RNext& n, int wave, int lane, int kq) {
+  if (n.kind == RN_FWD) rows_fw_load4(b, n.W + n.off, wave, lane, 0, kq);
+  else if (n.kind == RN_L0) rows_l0_load4(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0, kq);
+}
 __device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, int wave, int lane) {
   if (n.kind == RN_FWD) rows_fw_load(b, n.W + n.off, wave, lane, 0);
   else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
+}
+__device__ __forceinline__ void rows_fw_mac4(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c, int kq,
+                                             f32x4 (&acc)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * RLD + 64 * wave + 16 * c + 4 * kq);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = MFMA4(a[s], b[4 * kq + s][e], acc[e]);
+}
+// the chunk loop of a hidden layer (forward, or backward on the transposed copy): chunk c + 1 (the successor's first chunk
+// behind the last one) is requested in four pieces between the four groups of matrix instructions of chunk c
+__device__ __forceinline__ void rows_big_chunks(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const RNext& next,
+                                                const bool lean, const int64_t late_off, f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    RNext n = next;
+    if (c == 3 && lean) n.off += late_off;                    // (lean <=> another hidden layer of the network follows)
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      if (c < 3) rows_fw_load4(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1, kq);
+      else rows_prefetch4(wb[0], n, x.wave, x.lane, kq);
+      __builtin_amdgcn_sched_barrier(0);
+      rows_fw_mac4(wb[c & 1], x.hs, x.wave, x.lane, c, kq, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ROWS_DBG2(x);
+  }
 }
 __device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c,
                                             f32x4 (&acc)[4]) {
@@ -213,19 +263,7 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
                                              const int64_t late_off = 0) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const float bv = bias[x.tid];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c < 3) {
-      rows_fw_load(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1);
-    } else {
-      RNext n = next;
-      if (lean) n.off += late_off;                            // (lean <=> another hidden layer of the network follows)
-      rows_prefetch(wb[0], n, x.wave, x.lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
-    ROWS_DBG2(x);
-  }
+  rows_big_chunks(x, wb, W, next, lean, late_off, acc);
   rows_fw_finish(x, acc, bv, keep, gout, lean);
   ROWS_DBG(x);                                               // (one stamp per layer: finer ones slow the measured group down)
 }
@@ -234,13 +272,7 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
 __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const float* mask,
                                               float* gout, const RNext& next, const bool lean = false) {
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c < 3) rows_fw_load(wb[(c + 1) & 1], WT, x.wave, x.lane, c + 1);
-    else rows_prefetch(wb[0], next, x.wave, x.lane);
-    __builtin_amdgcn_sched_barrier(0);
-    rows_fw_mac(wb[c & 1], x.hs, x.wave, x.lane, c, acc);
-  }
+  rows_big_chunks(x, wb, WT, next, false, 0, acc);
   float mk[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) mk[r] = mask[r * 256 + x.tid];    // (this thread's own copies: requested ahead of the barrier)

@@ -9,6 +9,7 @@
 //          c = 2 / 3), so TWO chunks are queued when the epilogue begins.
 // EPI: extra s_sleep rounds in the epilogue (64 cycles each): the product's epilogue is longer than the lab's (copies kept
 // for the backward pass, stores for the weight gradients, argument fetches at the next layer's start).
+//   MODE 4: MODE 0 with the 16 loads of the next chunk issued 4 at a time, in front of each group of 16 matrix instructions.
 //   MODE 2: the matrix instructions alone (no weight loads);  MODE 3: the weight stream alone (MODE 0's loads, 4 VALU
 //          operations per 4 loaded registers instead of 16 matrix instructions).
 //   hipcc --offload-arch=gfx950 -O3 tools/rowchain2_lab.hip -o /tmp/rowchain2_lab && /tmp/rowchain2_lab
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
     const bool more = l + 1 < L;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      const float* nx4 = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
       if (MODE == 0 || MODE == 3) {
         const float* nx = (c < 3) ? wl + (size_t)(16 * (c + 1)) * H : wl + (size_t)H * H;
         if (c < 3 || more) {
@@ -72,6 +74,13 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
       const bool refill = MODE == 1 && (c < 2 || more);
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
+        if (MODE == 4) {
+          if (c < 3 || more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[(c + 1) & 1][4 * kq + i] = ldv(nx4 + (size_t)(4 * kq + i) * H);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const f32x4 a = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * HLD + 64 * wave + 16 * c + 4 * kq);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
             if (MODE == 3) { if (e == 0) acc[s] += b[c & 1][4 * kq + s] * a[s]; }   // loads only: 16 VALU ops per chunk row group
             else acc[e] = MFMA4(a[s], b[c & 1][4 * kq + s][e], acc[e]);
           }
+        if (MODE == 4) __builtin_amdgcn_sched_barrier(0);
         if (MODE == 1) {
           __builtin_amdgcn_sched_barrier(0);
           if (refill) {
@@ -186,6 +196,7 @@ int main() {
   w8_main(X, W, b, Y, B);
   report<0, 0>("one chunk across the boundary", X, W, b, Y, B);
   report<1, 0>("two chunks across the boundary", X, W, b, Y, B);
+  report<4, 0>("one chunk, loads 4 by 4", X, W, b, Y, B);
   report<2, 0>("matrix instructions only", X, W, b, Y, B);
   report<3, 0>("weight stream only (loads first)", X, W, b, Y, B);
   report<0, 8>("one chunk across the boundary", X, W, b, Y, B);
