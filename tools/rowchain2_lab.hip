@@ -10,6 +10,8 @@
 // EPI: extra s_sleep rounds in the epilogue (64 cycles each): the product's epilogue is longer than the lab's (copies kept
 // for the backward pass, stores for the weight gradients, argument fetches at the next layer's start).
 //   MODE 4: MODE 0 with the 16 loads of the next chunk issued 4 at a time, in front of each group of 16 matrix instructions.
+//   MODE 9: MODE 4, and the successor's chunk 1 is requested INSIDE the epilogue (8 loads in front of the barrier, 8 behind
+//          the LDS reads of the partial sums), where the waves wait anyway.
 //   MODE 2: the matrix instructions alone (no weight loads);  MODE 3: the weight stream alone (MODE 0's loads, 4 VALU
 //          operations per 4 loaded registers instead of 16 matrix instructions).
 //   hipcc --offload-arch=gfx950 -O3 tools/rowchain2_lab.hip -o /tmp/rowchain2_lab && /tmp/rowchain2_lab
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
   const float* wl = Wc + (size_t)(64 * wave) * H + 4 * lane;         // this wave's k quarter of layer l
 #pragma unroll
   for (int i = 0; i < 16; ++i) b[0][i] = ldv(wl + (size_t)i * H);
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 9) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) b[1][i] = ldv(wl + (size_t)(16 + i) * H);
   }
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
       const bool refill = MODE == 1 && (c < 2 || more);
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        if (MODE == 4) {
+        if (MODE == 4 || (MODE == 9 && c > 0)) {
           if (c < 3 || more) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) b[(c + 1) & 1][4 * kq + i] = ldv(nx4 + (size_t)(4 * kq + i) * H);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
             if (MODE == 3) { if (e == 0) acc[s] += b[c & 1][4 * kq + s] * a[s]; }   // loads only: 16 VALU ops per chunk row group
             else acc[e] = MFMA4(a[s], b[c & 1][4 * kq + s][e], acc[e]);
           }
-        if (MODE == 4) __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 4 || MODE == 9) __builtin_amdgcn_sched_barrier(0);
         if (MODE == 1) {
           __builtin_amdgcn_sched_barrier(0);
           if (refill) {
@@ -106,13 +108,29 @@ __global__ __launch_bounds__(256) void rowchain(const float* __restrict__ X, con
       f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
       *reinterpret_cast<f32x4*>(part + ((wave * 4 + r) * H + 4 * lane)) = v;
     }
+    if (MODE == 9 && more) {                                         // (wl = the next layer now) its chunk 1, first half
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[1][i] = ldv(wl + (size_t)(16 + i) * H);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPI; ++e) __builtin_amdgcn_s_sleep(1);
+    float pp[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pp[r][j] = part[(j * 4 + r) * H + tid];
+    if (MODE == 9 && more) {                                         // second half, behind the LDS reads
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 8; i < 16; ++i) b[1][i] = ldv(wl + (size_t)(16 + i) * H);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float s = (part[(0 * 4 + r) * H + tid] + part[(1 * 4 + r) * H + tid]) +
-                (part[(2 * 4 + r) * H + tid] + part[(3 * 4 + r) * H + tid]);
+      float s = (pp[r][0] + pp[r][1]) + (pp[r][2] + pp[r][3]);
       s = fmaxf(s + bv, 0.f);
       hs[r * HLD + tid] = s;
       if (l == L - 1) Yc[(size_t)(r0 + r) * H + tid] = s;
@@ -197,6 +215,8 @@ int main() {
   report<0, 0>("one chunk across the boundary", X, W, b, Y, B);
   report<1, 0>("two chunks across the boundary", X, W, b, Y, B);
   report<4, 0>("one chunk, loads 4 by 4", X, W, b, Y, B);
+  report<9, 0>("4 by 4 + chunk 1 in the epilogue", X, W, b, Y, B);
+  report<9, 8>("4 by 4 + chunk 1 in the epilogue", X, W, b, Y, B);
   report<2, 0>("matrix instructions only", X, W, b, Y, B);
   report<3, 0>("weight stream only (loads first)", X, W, b, Y, B);
   report<0, 8>("one chunk across the boundary", X, W, b, Y, B);
