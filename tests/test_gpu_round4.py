@@ -707,3 +707,17 @@ def test_torch_custom_op_face_of_the_hot_entry_points():
     assert float(a['u'].abs().sum()) > 0 and int(a['ctr']) == 3
     with pytest.raises(Exception):
         torch.ops.curious_hip.her_sample(12345, a['batch'], a['batch'])             # unknown descriptor
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the row-local launch's in-kernel synchronisation (one workgroup barrier per layer, partial tiles alternating between two
+# LDS buffers, the Q' hand-off between workgroups): the same gradient call many times, every output bit for bit the first's
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['single', 'experts'])
+def test_repeated_gradient_calls_are_bit_identical(mode):
+    import subprocess
+    n = '3000' if mode == 'single' else '1000'
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'rows_determinism.py'), n] + (['experts'] if mode == 'experts' else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-400:] + p.stderr[-400:]
+    assert 'all identical to the first' in p.stdout
