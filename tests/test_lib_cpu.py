@@ -217,3 +217,54 @@ def test_round3_entry_points_host_code_without_gpu():
                                                   fake[10], 0, 4096, 0.9, 0.1, 0.999, 0.001, 1e-8, None, 0, C.byref(lay),
                                                   C.byref(tasks), C.byref(sp), C.byref(rng), 256, None, C.byref(BL), None, None)
     assert rc != 0 and b'bad strides' in L.curious_last_error()
+
+
+def test_round4_entry_points_host_code_without_gpu():
+    """The fused IPC all-reduce + Adam call, the set-up calls of its peer mappings and the stamp offset of the lab build:
+    argument validation up to the failing launch / allocation (sanitizer coverage of their host side, tools/sanitize_cpu.sh)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('would launch kernels on fake pointers')
+    from curious_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.NetCfg()
+    cfg.dimo, cfg.dimg, cfg.dimtd, cfg.layers, cfg.dimu, cfg.hidden, cfg.modular = 40, 12, 4, 3, 4, 256, 1
+    cfg.max_u, cfg.gamma, cfg.clip_return, cfg.action_l2, cfg.clip_pos_returns = 1.0, 0.98, 50.0, 1.0, 1
+    ws = L.curious_workspace_floats(C.byref(cfg), 256)
+    so = L.curious_workspace_stamps_offset(C.byref(cfg), 256)
+    assert 0 < so < ws
+    fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(10)]
+    P = _lib.IpcPeers()
+    f32 = C.c_float
+
+    def call(peers, n_Q, n_pi, keep=None, tab_len=4096):
+        return L.curious_allreduce_adam_ipc(C.byref(peers) if peers is not None else None, fake[0], fake[1], n_Q, n_pi,
+                                            fake[2], fake[3], 0, tab_len, f32(0.9), f32(0.1), f32(0.999), f32(0.001),
+                                            f32(1e-8), fake[4], fake[5], 0, keep, None)
+    assert call(None, 64, 64) != 0 and b'NULL argument' in L.curious_last_error()
+    P.world, P.rank = 9, 0
+    assert call(P, 64, 64) != 0 and b'world must be' in L.curious_last_error()
+    P.world, P.rank = 2, 2
+    assert call(P, 64, 64) != 0 and b'world must be' in L.curious_last_error()
+    P.world, P.rank = 4, 1
+    assert call(P, 64, 65) != 0 and b'divide by the world size' in L.curious_last_error()
+    assert call(P, 64, 64) != 0 and b'rank 0 is not mapped' in L.curious_last_error()
+    for r in range(4):
+        P.grad[r], P.theta[r], P.flags[r] = fake[6].value + 4096 * r, fake[7].value + 4096 * r, fake[8].value + 64 * r
+    P.theta[3] = None
+    assert call(P, 64, 64) != 0 and b'rank 3 is not mapped' in L.curious_last_error()
+    P.theta[3] = fake[7].value + 4096 * 3
+    T = _lib.Transposed()
+    T.n, T.dim = 2, 100                                        # not a multiple of the optimiser's tile
+    assert call(P, 64, 64, C.byref(T)) != 0 and b'transposed copies' in L.curious_last_error()
+    assert call(P, 64, 64, tab_len=0) != 0 and b'NULL argument' in L.curious_last_error()
+    assert call(P, 64, 64) != 0 and b'launch failed' in L.curious_last_error()     # everything in order: up to the launch
+    # the mappings: bad arguments are refused, without a device the allocation itself fails cleanly
+    out = C.c_void_p()
+    assert L.curious_ipc_alloc(0, C.byref(out)) != 0 and b'bad argument' in L.curious_last_error()
+    assert L.curious_ipc_alloc(4096, None) != 0
+    assert L.curious_ipc_alloc(4096, C.byref(out)) != 0 and b'hipMalloc' in L.curious_last_error()
+    h = C.create_string_buffer(64)
+    assert L.curious_ipc_export(None, h) != 0 and L.curious_ipc_import(None, C.byref(out)) != 0
+    assert L.curious_ipc_close(None) == 0 and L.curious_ipc_free(None) == 0
