@@ -98,6 +98,7 @@ CuriousOptions& curious_options() {
     o.qt_spins = 1 << 22;
     o.lab_no_target = 0;
     o.dw_xcd = env_int("CURIOUS_DW_XCD", 1) != 0;
+    o.rows_pre = env_int("CURIOUS_ROWS_PRE", 1) != 0;
     o.lab_dw_stamps = 0;
     o.lab_step = env_int("CURIOUS_LAB_STEP", 0);
     o.lab_res_stamps = 0;
@@ -118,6 +119,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
   if (!strcmp(name, "lab_no_target")) return &o.lab_no_target;
   if (!strcmp(name, "dw_xcd")) return &o.dw_xcd;
+  if (!strcmp(name, "rows_pre")) return &o.rows_pre;
   if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
   if (!strcmp(name, "lab_step")) return &o.lab_step;
   if (!strcmp(name, "lab_res_stamps")) return &o.lab_res_stamps;

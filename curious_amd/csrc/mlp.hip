@@ -919,14 +919,32 @@ int DdpgPass::launch_rows() {
   const size_t lds = ra_lds;
   rows_pending = false;
   dim3 grid((a.xmap || gather_in_rows ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
+  // the leading arguments (mlp_rows.h RowsPre: in scalar registers when the wave starts)
+  const int Sa = a.dimo + a.dimtd, Sc = Sa + 4;
+  const auto fits16 = [](int v) { return v >= 0 && v < 65536; };
+  const bool pre_ok = xd.nex == 1 && a.xmap && !a.o_mean && !a.g_mean && curious_options().rows_pre &&
+                      fits16(B) && fits16(a.ld) && fits16(a.off_o) && fits16(a.off_td) && fits16(a.off_u) &&
+                      fits16(a.off_g) && fits16(a.off_o2) && fits16(a.off_g2) && a.dimo < 256 && a.dimtd < 256 &&
+                      a.dimg < 256 && offPi.Wg == offPi.W0 + (int64_t)(Sa + 1) * H && offQ.Wg == offQ.W0 + (int64_t)(Sc + 1) * H;
+  const float* pw0a = a.mPi.th + a.mPi.W0;
+  const float* pw0t = a.tPi.th + a.tPi.W0;
+  const float* pw0c = a.mQ.th + a.mQ.W0;
+  const uint32_t k0 = (uint32_t)a.ld | ((uint32_t)a.off_o << 16), k1 = (uint32_t)a.off_td | ((uint32_t)a.off_g << 16);
+  const uint32_t k2 = (uint32_t)a.off_o2 | ((uint32_t)a.off_g2 << 16);
+  const uint32_t k3 = (uint32_t)a.off_u | ((uint32_t)a.dimo << 16) | ((uint32_t)a.dimtd << 24);
+  const uint32_t k4 = pre_ok ? ((uint32_t)B | ((uint32_t)a.dimg << 16) | (1u << 25)) : 0u, k5 = 0u;
   if (gather_in_rows) {
     ProfScope ps__(CK_ROWS_HER, st);
-    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_her_kernel<true>), grid, dim3(256), lds, st, a, ex, her_rows, seed_stride);
-    else hipLaunchKernelGGL((ddpg_rows_her_kernel<false>), grid, dim3(256), lds, st, a, ex, her_rows, seed_stride);
+    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_her_kernel<true>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
+                                       k0, k1, k2, k3, k4, k5, a, ex, her_rows, seed_stride);
+    else hipLaunchKernelGGL((ddpg_rows_her_kernel<false>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
+                            k0, k1, k2, k3, k4, k5, a, ex, her_rows, seed_stride);
   } else {
     ProfScope ps__(CK_ROWS, st);
-    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, a, ex);
-    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, a, ex);
+    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
+                                       k0, k1, k2, k3, k4, k5, a, ex);
+    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
+                            k0, k1, k2, k3, k4, k5, a, ex);
   }
   CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");
   return 0;

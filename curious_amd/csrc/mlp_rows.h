@@ -354,28 +354,73 @@ __device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {    
 // keep: where the rows are also stored for the layer-0 weight gradients (input normalisation only: without it those
 // read the batch itself), or NULL
 // so: the expert's slab offset (batched experts: every expert has its own normalisers, expert_stride floats apart)
-__device__ __forceinline__ void rows_load_inputs(const RCtx& x, const RowsArgs& a, const float* batch, int off_o,
-                                                 int off_g, bool with_u, float* keep = nullptr, const int64_t so = 0) {
-  const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
-  for (int idx = x.tid; idx < 4 * tot; idx += 256) {
-    const int i = idx / tot, k = idx - i * tot;
-    const float* row = batch + (int64_t)(x.r0 + i) * a.ld;
-    float v;
-    if (k < a.dimo) {
-      v = row[off_o + k];
-      if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[so + k]), a.o_std[so + k]), -a.nclip, a.nclip);   // normalizer.py:72-77
-    } else if (k < Sa) {
-      v = row[a.off_td + (k - a.dimo)];
-    } else if (k < S) {
-      v = with_u ? fdiv(row[a.off_u + (k - Sa)], a.max_u) : 0.f;
-    } else {
-      v = row[off_g + (k - S)];
-      if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[so + k - S]), a.g_std[so + k - S]), -a.nclip, a.nclip);
+// In two halves: the raw loads (rows_inputs_issue: needs nothing but the batch pointer, the row stride, the column offsets
+// and the widths -- RowsPre below hands those over in scalar registers, so the loads go out before the first argument has
+// arrived from memory) and what is done to the values (rows_inputs_commit: action / max_u, normalisation, the LDS rows).
+struct RowsIn { int dimo, dimtd, dimg, ld, off_td, off_u; };
+#define ROWS_IN_IT ((4 * ROWS_MAXIN + 255) / 256)             // elements per thread
+__device__ __forceinline__ void rows_inputs_issue(const int tid, const int r0, const RowsIn& in, const float* batch,
+                                                  int off_o, int off_g, bool with_u, float (&v)[ROWS_IN_IT]) {
+  const int Sa = in.dimo + in.dimtd, S = Sa + 4, tot = S + in.dimg;
+#pragma unroll
+  for (int it = 0; it < ROWS_IN_IT; ++it) {
+    const int idx = tid + 256 * it;
+    v[it] = 0.f;
+    if (idx < 4 * tot) {
+      const int i = idx / tot, k = idx - i * tot;
+      const float* row = batch + (int64_t)(r0 + i) * in.ld;
+      if (k < in.dimo) v[it] = row[off_o + k];
+      else if (k < Sa) v[it] = row[in.off_td + (k - in.dimo)];
+      else if (k < S) { if (with_u) v[it] = row[in.off_u + (k - Sa)]; }
+      else v[it] = row[off_g + (k - S)];
     }
-    x.xin[i * XLD + k] = v;
-    if (keep) keep[(int64_t)(x.r0 + i) * XLD + k] = v;
   }
 }
+__device__ __forceinline__ void rows_inputs_commit(const RCtx& x, const RowsArgs& a, bool with_u,
+                                                   const float (&raw)[ROWS_IN_IT], float* keep = nullptr,
+                                                   const int64_t so = 0) {
+  const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
+#pragma unroll
+  for (int it = 0; it < ROWS_IN_IT; ++it) {
+    const int idx = x.tid + 256 * it;
+    if (idx < 4 * tot) {
+      const int i = idx / tot, k = idx - i * tot;
+      float v = raw[it];
+      if (k < a.dimo) {
+        if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[so + k]), a.o_std[so + k]), -a.nclip, a.nclip);   // normalizer.py:72-77
+      } else if (k < Sa) {
+      } else if (k < S) {
+        v = with_u ? fdiv(v, a.max_u) : 0.f;
+      } else {
+        if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[so + k - S]), a.g_std[so + k - S]), -a.nclip, a.nclip);
+      }
+      x.xin[i * XLD + k] = v;
+      if (keep) keep[(int64_t)(x.r0 + i) * XLD + k] = v;
+    }
+  }
+}
+__device__ __forceinline__ RowsIn rows_in_of(const RowsArgs& a) {
+  RowsIn in;
+  in.dimo = a.dimo; in.dimtd = a.dimtd; in.dimg = a.dimg; in.ld = a.ld; in.off_td = a.off_td; in.off_u = a.off_u;
+  return in;
+}
+
+// ---- the kernel's LEADING arguments (round 4): with -mllvm -amdgpu-kernarg-preload-count they arrive in scalar registers
+// with the wave.  A row group needs 1.4 k cycles to get its first argument from memory (tools/rows_lab.hip) and only then
+// could request its input rows and its first layer-0 weights -- another cold round trip.  With these 14 dwords it knows its
+// role, its rows and its first matrix at once: the two round trips overlap.  Host-checked (flag in k[4]): single agent on
+// the XCD-aware grid, no input normalisation, 16-bit offsets, Wg right behind W0's bias row (the parameter layout of
+// util.py:79-92 as this library stores it); otherwise the flag is clear and the arguments are fetched as before.
+struct RowsPre {
+  const float* w0[3];          // layer-0 matrices W0 of: main actor | target actor | main critic
+  const float* batch;
+  uint32_t k[6];               // ld | off_o << 16,  off_td | off_g << 16,  off_o2 | off_g2 << 16,
+                               // off_u | dimo << 16 | dimtd << 24,  B | dimg << 16 | ok << 25,  (spare)
+};
+#define ROWS_PRE_PARAMS const float* pw0a, const float* pw0t, const float* pw0c, const float* pbatch, const uint32_t pk0, \
+                        const uint32_t pk1, const uint32_t pk2, const uint32_t pk3, const uint32_t pk4, const uint32_t pk5
+#define ROWS_PRE_MAKE(pre) RowsPre pre; pre.w0[0] = pw0a; pre.w0[1] = pw0t; pre.w0[2] = pw0c; pre.batch = pbatch; \
+                           pre.k[0] = pk0; pre.k[1] = pk1; pre.k[2] = pk2; pre.k[3] = pk3; pre.k[4] = pk4; pre.k[5] = pk5
 
 // hidden layers 1 .. nl-1 of a network, forward; which: 0 nothing stored, 1 -> a.actc[l], 2 -> a.acta[l]
 // (the kernarg arrays are indexed in place: handing their address around would copy the struct to scratch memory)
@@ -417,6 +462,43 @@ __device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, i
   return rnext(RN_FWD, (actor ? a.wTpi[a.nl - 1] : a.wTq[a.nl - 1]) + eo);
 }
 
+// What a row group requests first: the first 16 rows of its first layer-0 matrix and its input rows.  The description comes
+// from the leading arguments (pre_path: nothing is read from the argument segment) or from the arguments proper; one load
+// sequence either way.  kind: 0 actor side (main actor), 1 target (target actor), 2 main critic.
+template <bool EX>
+__device__ __forceinline__ void rows_first_loads(const RCtx& x, const RowsArgs& a, const Ex& ex, const RowsPre* pre,
+                                                 const bool pre_path, const int kind, const int rgrp, const int expert,
+                                                 f32x4 (&wb0)[16], float (&xraw)[ROWS_IN_IT]) {
+  const float *fW0, *fbatch;
+  int fS, fWg_off, foff_o, foff_g;
+  RowsIn fin;
+  if (pre_path) {
+    fin.ld = (int)(pre->k[0] & 0xffffu); fin.off_td = (int)(pre->k[1] & 0xffffu); fin.off_u = (int)(pre->k[3] & 0xffffu);
+    fin.dimo = (int)((pre->k[3] >> 16) & 0xffu); fin.dimtd = (int)(pre->k[3] >> 24); fin.dimg = (int)((pre->k[4] >> 16) & 0xffu);
+    fS = fin.dimo + fin.dimtd + ((kind == 2) ? 4 : 0);
+    fW0 = (kind == 0) ? pre->w0[0] : (kind == 1) ? pre->w0[1] : pre->w0[2];
+    fWg_off = (fS + 1) * 256;
+    fbatch = pre->batch;
+    foff_o = (kind == 1) ? (int)(pre->k[2] & 0xffffu) : (int)(pre->k[0] >> 16);
+    foff_g = (kind == 1) ? (int)(pre->k[2] >> 16) : (int)(pre->k[1] >> 16);
+  } else {
+    int64_t eo;
+    (void)ex_decode<EX>(ex, expert, eo);
+    fin = rows_in_of(a);
+    fS = fin.dimo + fin.dimtd + ((kind == 2) ? 4 : 0);
+    const RowsNet& N = (kind == 0) ? a.mPi : (kind == 1) ? a.tPi : a.mQ;
+    fW0 = N.th + eo + N.W0;
+    fWg_off = N.Wg - N.W0;
+    fbatch = a.batch + eo;
+    foff_o = (kind == 1) ? a.off_o2 : a.off_o;
+    foff_g = (kind == 1) ? a.off_g2 : a.off_g;
+    asm volatile("" : "+s"(fS), "+s"(foff_o), "+s"(foff_g));   // (no select between the two descriptions: see the caller)
+  }
+  rows_l0_load(wb0, fW0, fS, fW0 + fWg_off, fS + fin.dimg, x.wave, x.lane, 0);
+  rows_inputs_issue(x.tid, rgrp * ROWS_R, fin, fbatch, foff_o, foff_g, kind == 2, xraw);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ================================================================== the kernel
 // grid (4 * B / 4, 1, n_experts); B % 16 == 0.
 static inline size_t rows_lds_floats(int nl) {
@@ -430,7 +512,7 @@ static inline size_t rows_lds_floats(int nl) {
 // STEP: the one-launch update -- results are published for the tiles of the same launch (mlp_common.h StepSync).
 template <bool EX, bool HER, bool STEP = false>
 __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
-                                              const uint64_t seed_stride) {
+                                              const uint64_t seed_stride, const RowsPre* pre = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
   x.dbg = nullptr;
@@ -444,63 +526,81 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   // Kind of workgroup and row group from the block id.  Workgroups are dealt round-robin over the 8 XCDs in block-id
   // order (block b lands on XCD b % 8; speed only, nothing depends on it for correctness).  A layer's time is set by
-  // how many workgroups stream weights out of one XCD's L2 at the same time (24 per XCD: 7.1 k cycles, 16: 5.9 k), and
+  // how many workgroups stream weights out of one XCD's L2 at the same time, and
   // the actor-side chain is the longest: it gets XCDs 0-3 for itself, 16 workgroups per XCD at B = 256, while the target
   // and main-critic groups share XCDs 4-7, 32 per XCD -- they have the slack.  grid.x = 4 * nrg: slot = b / 8;
   //   XCD 0-3: slots [0, nrg/4) actor side, the rest exit;   XCD 4-7: slots [0, nrg/4) target, [nrg/4, nrg/2) main critic
   // (lower block ids are dispatched first: the longest chain and the producers start before the consumers).
-  const int nrg = a.B / ROWS_R, per = nrg >> 2;
-  int kind, rgrp, expert = 0;
-  if (a.xmap) {                                              // single agent, grid.x = 4 * nrg
+  // Without the XCD map: grid (3 * nrg, 1, experts), kinds in dispatch order ACROSS the experts: the actor-side groups of
+  // all experts, then all target groups, then all main-critic groups (batched experts fill the chip several times over; a
+  // main-critic group that is dispatched while its target group still runs would hold a CU just to wait); kind 3 (grid.x =
+  // 4 * nrg only with n_her > 0): the gather blocks.
+  // The role and what a row group requests FIRST -- its input rows and the first 16 rows of its first layer-0 matrix --
+  // come from the leading arguments when the host filled them (RowsPre: nothing is read from the argument segment up to
+  // the `sched_barrier` below), else from the arguments proper; ONE site issues the loads either way.
+  f32x4 wb[2][16];
+  float xraw[ROWS_IN_IT];
+  int nrg, kind, rgrp, expert = 0, spare = -1;
+  int64_t eo = 0;
+  const bool pre_path = !EX && pre != nullptr && ((pre->k[4] >> 25) & 1u);
+  // (the arguments proper are read inside `else` branches that end in an empty asm: a plain select between a leading
+  //  argument and a fetched one would wait for the fetch on both paths)
+  bool xmap = true;
+  nrg = (int)(pre_path ? (pre->k[4] & 0xffffu) : 0u) / ROWS_R;
+  if (!pre_path) {
+    int bv = a.B, xm = a.xmap;
+    asm volatile("" : "+s"(bv), "+s"(xm));
+    nrg = bv / ROWS_R;
+    xmap = xm != 0;
+  }
+  if (xmap) {                                                // single agent, grid.x = 4 * nrg
+    const int per = nrg >> 2;
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    if (xcd < 4 && slot >= per) {                            // the spare quarter of the grid: the gather, or nothing
-      const int idx = xcd * per + (slot - per);
-      if (HER && idx < a.n_her) her_sample_body(*her, idx, rows_lds, 0, 0, 1);
-      return idx;
-    }
     kind = (xcd < 4) ? 0 : (slot < per) ? 1 : 2;
     rgrp = (xcd & 3) * per + (slot < per ? slot : slot - per);
+    if (xcd < 4 && slot >= per) { kind = 3; spare = xcd * per + (slot - per); }   // the spare quarter: the gather, or nothing
   } else {
-    // grid (3 * nrg, 1, experts), kinds in dispatch order ACROSS the experts: the actor-side groups of all experts,
-    // then all target groups, then all main-critic groups.  Batched experts fill the chip several times over; a
-    // main-critic group that is dispatched while its target group still runs would hold a CU just to wait.
     const int groups = nrg * (int)gridDim.z;
     const int lin = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
     kind = lin / groups;
     const int rem = lin - kind * groups;
     expert = rem / nrg;
     rgrp = rem - expert * nrg;
-    if (kind == 3) {                                         // (grid.x = 4 * nrg only with n_her > 0) the gather blocks
-      int64_t ge;
-      (void)ex_decode<EX>(ex, expert, ge);
-      if (HER && rgrp < a.n_her) her_sample_body(*her, rgrp, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
-      return rgrp;
+  }
+  if (kind == 3) {
+    if (xmap) {
+      if (HER && spare < a.n_her) her_sample_body(*her, spare, rows_lds, 0, 0, 1);
+      return spare;
     }
+    int64_t ge;
+    (void)ex_decode<EX>(ex, expert, ge);
+    if (HER && rgrp < a.n_her) her_sample_body(*her, rgrp, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
+    return rgrp;
   }
   x.r0 = rgrp * ROWS_R;
-#ifdef ROWS_DEBUG
-  if (a.stamps && rgrp == 0 && kind == 0) x.dbg = a.stamps + 96;
-#endif
-  int64_t eo;
-  (void)ex_decode<EX>(ex, expert, eo);                      // one problem per expert
-  const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
-  const float* batch = a.batch + eo;
-  const int m = x.r0 + x.wave;                              // the batch row whose output layers this wave finishes
-  const float invB = 1.0f / (float)a.B;
-  float* sm_s = x.sm;                                       // [4] per-row scalar handed from wave i to the column threads
-  float* sm_v = x.sm + 16;                                  // [4][4] per-row 4-vectors (pi, dz)
-  unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + m;
-  f32x4 wb[2][16];
+  // what every kind derives from the arguments proper -- expanded INSIDE each kind's branch, behind the branch's first
+  // loads (rows_first_loads): in front of the branches these lines would wait for the argument fetch before any load went out
+#define ROWS_COMMON()                                                                                            \
+  (void)ex_decode<EX>(ex, expert, eo);                      /* one problem per expert */                        \
+  const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;                                           \
+  const float* batch = a.batch + eo; (void)batch;                                                                \
+  const int m = x.r0 + x.wave;                              /* the batch row whose output layers this wave finishes */ \
+  const float invB = 1.0f / (float)a.B; (void)invB;                                                              \
+  float* sm_s = x.sm; (void)sm_s;                           /* [4] per-row scalar handed from wave i to the column threads */ \
+  float* sm_v = x.sm + 16; (void)sm_v;                      /* [4][4] per-row 4-vectors (pi, dz) */             \
+  unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + m; (void)qt; \
+  (void)Sc; (void)G; (void)nl
 
   if (kind == 1) {
-    if (a.lab_no_target) return nrg + rgrp;
     // ================================================= target group: pi' = target actor(o_2, g_2), Q' = target critic
+    rows_first_loads<EX>(x, a, ex, pre, pre_path, 1, rgrp, expert, wb[0], xraw);
+    ROWS_COMMON();
+    if (a.lab_no_target) return nrg + rgrp;
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
     ROWS_STAMP(0);
-    rows_l0_load(wb[0], tp + a.tPi.W0, Sa, tp + a.tPi.Wg, Sa + G, x.wave, x.lane, 0);
     const float b0_tp = tp[a.tPi.b0 + x.tid];
-    rows_load_inputs(x, a, batch, a.off_o2, a.off_g2, false, nullptr, eo);
+    rows_inputs_commit(x, a, false, xraw, nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
@@ -540,12 +640,13 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
 
   if (kind == 2) {
     // ================================================= main-critic group: critic(o, g, u), loss, backward
+    rows_first_loads<EX>(x, a, ex, pre, pre_path, 2, rgrp, expert, wb[0], xraw);
+    ROWS_COMMON();
     if (!HER && rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
     const float* mq = a.mQ.th + eo;
     ROWS_STAMP(0);
-    rows_l0_load(wb[0], mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G, x.wave, x.lane, 0);
     const float b0_mq = mq[a.mQ.b0 + x.tid];
-    rows_load_inputs(x, a, batch, a.off_o, a.off_g, true, a.xn_c ? a.xn_c + eo : nullptr, eo);
+    rows_inputs_commit(x, a, true, xraw, a.xn_c ? a.xn_c + eo : nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     // operands of the head / loss / first backward step, fetched ahead of the hidden layers
@@ -612,14 +713,18 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   }
 
   // =================================================== actor side
+  rows_first_loads<EX>(x, a, ex, pre, pre_path, 0, rgrp, expert, wb[0], xraw);
+  ROWS_COMMON();
+#ifdef ROWS_DEBUG
+  if (a.stamps && rgrp == 0) x.dbg = a.stamps + 96;
+#endif
   const float* mp = a.mPi.th + eo;
   const float* mq = a.mQ.th + eo;
   float* keepA = x.keep;                                    // actor activations
   float* keepD = x.keep + nl * 1024;                        // critic(pi) activations
   ROWS_STAMP(0);
-  rows_l0_load(wb[0], mp + a.mPi.W0, Sa, mp + a.mPi.Wg, Sa + G, x.wave, x.lane, 0);
   const float b0_mp = mp[a.mPi.b0 + x.tid];
-  rows_load_inputs(x, a, batch, a.off_o, a.off_g, false, a.xn_a ? a.xn_a + eo : nullptr, eo);
+  rows_inputs_commit(x, a, false, xraw, a.xn_a ? a.xn_a + eo : nullptr, eo);
   __syncthreads();
   ROWS_STAMP(1);
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);
@@ -755,25 +860,34 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
 // for the first argument it needs follows right behind the scheduling fence and covers these loads (SMEM waits are
 // all-or-nothing) -- and the dummy target register stays reserved to the kernel's end.
 __device__ __forceinline__ uint32_t rows_kernarg_touch() {
-  static_assert(sizeof(RowsArgs) > 64 * 10 && sizeof(RowsArgs) <= 64 * 11, "rows_kernarg_touch: line list");
+  static_assert(14 * 4 + sizeof(RowsArgs) > 64 * 11 && 14 * 4 + sizeof(RowsArgs) <= 64 * 12, "rows_kernarg_touch: line list");
   const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   uint32_t d;
   asm volatile(RKA_T(0) RKA_T(64) RKA_T(128) RKA_T(192) RKA_T(256) RKA_T(320) RKA_T(384) RKA_T(448) RKA_T(512) RKA_T(576)
-               RKA_T(640) : "=&s"(d) : "s"(ka) : "memory");
+               RKA_T(640) RKA_T(704) : "=&s"(d) : "s"(ka) : "memory");
   __builtin_amdgcn_sched_barrier(0);
   return d;
 }
 template <bool EX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ddpg_rows_kernel(RowsArgs a, Ex ex) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void ddpg_rows_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex) {
+#ifdef ROWS_DEBUG
+  const unsigned long long t_entry = __builtin_readcyclecounter();   // (before the first argument is read)
+#endif
+  ROWS_PRE_MAKE(pre);
   const uint32_t touched = rows_kernarg_touch();
-  ddpg_rows_body<EX, false>(a, ex, nullptr, 0);
+  ddpg_rows_body<EX, false>(a, ex, nullptr, 0, &pre);
   asm volatile("" :: "s"(touched));
+#ifdef ROWS_DEBUG
+  if (a.stamps && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.stamps[31] = t_entry;   // (actor-side group 0)
+#endif
 }
 template <bool EX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void ddpg_rows_her_kernel(RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
+void ddpg_rows_her_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
+  ROWS_PRE_MAKE(pre);
   const uint32_t touched = rows_kernarg_touch();
-  ddpg_rows_body<EX, true>(a, ex, &her, seed_stride);
+  ddpg_rows_body<EX, true>(a, ex, &her, seed_stride, &pre);
   asm volatile("" :: "s"(touched));
 }
 

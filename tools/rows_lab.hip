@@ -80,7 +80,20 @@ int main(int argc, char** argv) {
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float))));
   dim3 grid(4 * (B / ROWS_R), 1, 1);
   printf("B = %d\n", B);
-  auto launch = [&]() { hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, a, ex); };
+  // the kernel's leading arguments (mlp_rows.h RowsPre), as DdpgPass::launch_rows fills them; argv[2] = 0: flag clear
+  const bool use_pre = !(argc > 2 && atoi(argv[2]) == 0);
+  const float* pw0a = a.mPi.th + a.mPi.W0;
+  const float* pw0t = a.tPi.th + a.tPi.W0;
+  const float* pw0c = a.mQ.th + a.mQ.W0;
+  const uint32_t k0 = (uint32_t)a.ld | ((uint32_t)a.off_o << 16), k1 = (uint32_t)a.off_td | ((uint32_t)a.off_g << 16);
+  const uint32_t k2 = (uint32_t)a.off_o2 | ((uint32_t)a.off_g2 << 16);
+  const uint32_t k3 = (uint32_t)a.off_u | ((uint32_t)a.dimo << 16) | ((uint32_t)a.dimtd << 24);
+  const uint32_t k4 = use_pre ? ((uint32_t)B | ((uint32_t)a.dimg << 16) | (1u << 25)) : 0u, k5 = 0u;
+  printf("leading arguments %s\n", use_pre ? "in use" : "off");
+  auto launch = [&]() {
+    hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, 0, pw0a, pw0t, pw0c, a.batch, k0, k1, k2, k3, k4, k5,
+                       a, ex);
+  };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -107,6 +120,8 @@ int main(int argc, char** argv) {
                                  "", "", ""}};
     const int nst[3] = {10, 7, 7};
     const char* kinds[3] = {"actor side ", "target     ", "main critic"};
+    printf("  actor-side group 0: %llu cycles from the kernel's first instruction to its role and arguments known\n",
+           st[0] - st[31]);
     for (int ty = 0; ty < 3; ++ty) {
       printf("  %s (shader cycles, from the actor group's start: %lld): ", kinds[ty], (long long)(st[ty * 32] - st[0]));
       for (int k = 1; k < nst[ty]; ++k) printf("%s %llu | ", names[ty][k], st[ty * 32 + k] - st[ty * 32 + k - 1]);
