@@ -122,6 +122,10 @@ int curious_prof_launch_counts(int64_t* counts_host);
 /* Run-time options, read at every call (so one process can run both routes).  Names:
  *   "rows"         1 (default; env CURIOUS_ROWS): the row-local routes; 0: the tiled multi-launch routes
  *   "rows_xcd"     1 (default; env CURIOUS_ROWS_XCD): workgroup kinds of the row-local update placed by XCD
+ *   "rows_pre"     1 (default; env CURIOUS_ROWS_PRE): the row-local update's role, input rows and first layer-0 matrix are
+ *                  handed to the kernel as leading arguments (in scalar registers when a wave starts) where the shapes
+ *                  allow; 0: fetched from the argument segment (same results; A/B)
+ *   "dw_xcd"       1 (default; env CURIOUS_DW_XCD): blocks of the weight-gradient / optimiser launch placed by XCD
  *   "one_launch"   0 (default; env CURIOUS_ONE_LAUNCH): curious_ddpg_update on the row-local route = the row-local launch,
  *                  then the weight-gradient / optimiser launch; 1: both in ONE launch whose workgroups first do their
  *                  rows, then their share of the tiles (same results bit for bit; measured slower on MI355X -- DESIGN.md
