@@ -171,6 +171,7 @@ static void report(const char* name, const float* X, const float* W, const float
 }
 
 void raw_main(const float* W, float* Y);
+void ta_main(const float* W, float* Y);
 void ld_main(const float* X, const float* W, const float* b, float* Y, int B);
 void lr_main(const float* X, const float* W, const float* b, float* Y, int B);
 void l7_main(const float* X, const float* W, const float* b, float* Y, int B);
@@ -208,6 +209,7 @@ int main() {
     }
   }
   raw_main(W, Y);
+  ta_main(W, Y);
   ld_main(X, W, b, Y, B);
   lr_main(X, W, b, Y, B);
   l7_main(X, W, b, Y, B);
@@ -849,4 +851,64 @@ void w8_main(const float* X, const float* W, const float* b, float* Y, int B) {
   }
   report_8w<0>(X, W, b, Y, B);
   report_8w<8>(X, W, b, Y, B);
+}
+
+// ---- what one vector-memory instruction costs the CU's texture path, by shape (4 waves per workgroup, 64 workgroups, data
+// L2-resident): PAT 0 = one 1 KB row per wave instruction (global_load_dwordx4, the weight stream); PAT 1 = the dW tiles' X
+// operand: dword per lane, 16 lanes x 4 bytes contiguous in each of 4 rows 1 KB apart (4 x 64 B per instruction);
+// PAT 2 = the dW tiles' dY operand: dwordx4 per lane, 16 lanes x 16 bytes in each of 4 rows (4 x 256 B per instruction).
+template <int PAT>
+__global__ __launch_bounds__(256) void ta_cost(const float* __restrict__ W, float* __restrict__ Y, int iters) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const float* base = W + (size_t)blockIdx.x * 4096 + (size_t)wave * 64 * H;
+  f32x4 keep = zero4();
+  for (int it = 0; it < iters; ++it) {
+    const float* p = base + (size_t)((it & 3) * 16) * H;
+    if (PAT == 0) {
+      f32x4 b[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) b[i] = ldv(p + (size_t)i * H + 4 * lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" :: "v"(b[i]));
+    } else if (PAT == 1) {
+      float b[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) b[i] = p[(size_t)((i >> 2) * 16 + 4 * q + (i & 3)) * H + j];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" :: "v"(b[i]));
+    } else {
+      f32x4 b[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) b[i] = ldv(p + (size_t)((i >> 2) * 16 + 4 * q + (i & 3)) * H + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" :: "v"(b[i]));
+    }
+  }
+  if (keep[0] == 123.456f) Y[tid] = keep[1];
+#endif
+}
+template <int PAT>
+static void report_ta(const char* name, const float* W, float* Y) {
+  float t[2];
+  const int its[2] = {64, 576};
+  for (int k = 0; k < 2; ++k) {
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((ta_cost<PAT>), dim3(64), dim3(256), 0, 0, W, Y, its[k]);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((ta_cost<PAT>), dim3(64), dim3(256), 0, 0, W, Y, its[k]);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    t[k] = ms * 1000.f / 200;
+  }
+  const double per = (t[1] - t[0]) * 1000.0 / (512.0 * 16 * 4);       // ns per wave instruction and CU (4 waves issue)
+  printf("%-44s %.1f ns per wave instruction per CU = %.0f cycles at 2.4 GHz\n", name, per, per * 2.4);
+}
+void ta_main(const float* W, float* Y) {
+  report_ta<0>("dwordx4, one 1 KB row", W, Y);
+  report_ta<1>("dword, 4 rows x 64 B (dW tiles' X)", W, Y);
+  report_ta<2>("dwordx4, 4 rows x 256 B (dW tiles' dY)", W, Y);
 }
