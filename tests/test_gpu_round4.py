@@ -721,3 +721,36 @@ def test_repeated_gradient_calls_are_bit_identical(mode):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-400:] + p.stderr[-400:]
     assert 'all identical to the first' in p.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# speed-only options of the update's two launches change no number
+@pytest.mark.gpu
+@pytest.mark.parametrize('option', ['rows_pre', 'rows_xcd', 'dw_xcd'])
+def test_placement_and_argument_options_change_no_result(option):
+    """rows_pre (the row-local launch's role / first loads from leading kernel arguments, mlp_rows.h RowsPre), rows_xcd and
+    dw_xcd (XCD-aware block placement of the two launches): 13 updates, eager and as chained graphs, with the option off
+    end bit for bit where they end with it on -- parameters, moments, gradients, losses, the next staged batch."""
+    from curious_amd import ops
+    from test_gpu_round3 import _filled_agent
+    assert ops.get_option(option) == 1
+    agents = []
+    for on in (1, 0):
+        with ops.option(option, on):
+            a, _ = _filled_agent(use_graph=False)
+            g, _ = _filled_agent(use_graph=True)
+            for _ in range(7):
+                a.train()
+            g.train_batches(7)
+            a.train_batches(6)
+            g.train_batches(6)
+            torch.cuda.synchronize()
+            a.check_faults()
+            g.check_faults()
+            agents.append((a, g))
+    for x, y in zip(agents[0], agents[1]):
+        assert torch.equal(x.theta, y.theta) and torch.equal(x._m, y._m) and torch.equal(x._v, y._v)
+        assert torch.equal(x._staged, y._staged) and torch.equal(x.grad, y.grad)
+        assert torch.equal(x._losses, y._losses) and torch.equal(x._Q_pi, y._Q_pi)
+        assert int(x._step_ctr) == int(y._step_ctr) == 13
+    assert torch.equal(agents[0][0].theta, agents[0][1].theta)      # eager == graph
