@@ -44,8 +44,13 @@ def parse():
     ap.add_argument('--env', default=ENV, help='diagnostic: another synthetic env (the headline is %s)' % ENV)
     ap.add_argument('--phases', action='store_true', help='diagnostic: time rollout / store / updates separately '
                                                             '(adds device syncs; not the headline number)')
-    ap.add_argument('--rollout-batch-size', type=int, default=B_R,
-                    help='diagnostic: parallel rollouts per GPU (configs[2]: --env MultiTaskFetchArm8-v5 with 1024)')
+    ap.add_argument('--rollout-batch-size', type=int, default=None,
+                    help='diagnostic: parallel rollouts per GPU (configs[2]: --env MultiTaskFetchArm8-v5 with 1024); per '
+                         'virtual rank with --virtual-ranks (default then: 2, the reference\'s)')
+    ap.add_argument('--virtual-ranks', type=int, default=1,
+                    help="diagnostic: V of the reference's MPI ranks per GPU (readme.md:16: the published runs use 19): V "
+                         'private buffer sets / seeds / rollout groups, every update = V minibatches of 256 in one launch '
+                         'sequence, gradients summed over them (mpi_adam.py:26-28) -- the regime cpu_baseline.ranks times')
     ap.add_argument('--structure', default='curious', choices=['curious', 'task_experts'],
                     help="diagnostic: 'task_experts' = BASELINE configs[4], every expert updated in one batched launch "
                          "sequence per update (curious_ddpg_update_experts)")
@@ -55,7 +60,10 @@ def parse():
     ap.add_argument('--ipc-probe', type=int, default=0, help=argparse.SUPPRESS)     # child mode of ipc_probe()
     ap.add_argument('--no-ipc-probe', action='store_true',
                     help='several ranks: skip the side measurement of the fused IPC all-reduce + Adam path')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.rollout_batch_size is None:
+        args.rollout_batch_size = 2 if args.virtual_ranks > 1 else B_R
+    return args
 
 
 def maybe_relaunch(args):
@@ -65,7 +73,7 @@ def maybe_relaunch(args):
         sys.exit(subprocess.call(cmd))
 
 
-def build_job(use_graph, seed=0, env=None, b_r=B_R):
+def build_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1):
     from curious_amd import dist, logger
     from curious_amd.experiment import config
     from curious_amd.rollout import RolloutWorker
@@ -74,7 +82,7 @@ def build_job(use_graph, seed=0, env=None, b_r=B_R):
                   task_replay='replay_task_cp_buffer', goal_replay='her', structure='curious', normalize_obs=False,
                   num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=b_r,
                   n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph,
-                  async_store=os.environ.get('CURIOUS_ASYNC_STORE', '1') != '0')
+                  async_store=os.environ.get('CURIOUS_ASYNC_STORE', '1') != '0', virtual_ranks=virtual_ranks)
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = False
     params['ddpg_params']['seed'] = seed
@@ -86,7 +94,9 @@ def build_job(use_graph, seed=0, env=None, b_r=B_R):
                            random_eps=params['random_eps'], structure='curious',
                            task_selection='active_competence_progress', goal_selection='random',
                            queue_length=params['queue_length'], eval=False)
-    worker.seed(seed + 1000000 * dist.rank())
+    worker.seed(seed + 1000000 * dist.rank() * virtual_ranks)
+    if virtual_ranks > 1:
+        worker.seed_ranks([seed + 1000000 * (dist.rank() * virtual_ranks + v) for v in range(virtual_ranks)])
     return params, dims, policy, worker
 
 
@@ -136,8 +146,7 @@ def prefill(policy, n_eps, seed):
     gen = torch.Generator(device='cuda')
     gen.manual_seed(seed)
     seen = set()
-    for i in range(1, policy.nb_tasks + 1):
-        buf = policy.buffer[i]
+    for buf in [bl[i] for bl in policy._rank_buffers for i in range(1, policy.nb_tasks + 1)]:   # (every virtual rank's)
         if id(buf) in seen:
             continue
         seen.add(id(buf))
@@ -178,7 +187,7 @@ def cycle(policy, worker):
 def kernel_flops_bytes(policy, lay, B_R=B_R):
     """ALGORITHMIC work of one launch of each kernel class in one update / one rollout step."""
     c = policy
-    B, H, nl, U = c.batch_size, c.hidden, c.layers, c.dimu
+    B, H, nl, U = c._Bt, c.hidden, c.layers, c.dimu               # (virtual ranks: V minibatches of 256 per launch)
     O, G, N = c.dimo, c.dimg, c.dimtd
     Ka, Kc = O + N + G, O + N + U + G
     hid = nl - 1
@@ -668,11 +677,17 @@ def main():
     maybe_relaunch(args)
     # the CPU legs run first, before this process touches the GPU (rank 0 of a one-GPU run only)
     cpu = None
+    V = args.virtual_ranks
     if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
         n_ranks = min(19, os.cpu_count() or 1) if args.cpu_ranks < 0 else args.cpu_ranks
-        if n_ranks >= 2:
-            cpu['ranks'] = cpu_baseline_ranks(n_ranks)
+        if V > 1:
+            # the SAME job on the host cores: R single-threaded oracle processes, 2 rollouts and batch 256 per rank,
+            # gradients summed over ranks -- as many ranks as the box has cores for (stated in `cores`)
+            cpu = cpu_baseline_ranks(max(2, n_ranks), budget_s=20.0)
+        else:
+            cpu = cpu_baseline()
+            if n_ranks >= 2:
+                cpu['ranks'] = cpu_baseline_ranks(n_ranks)
     import numpy as np
     import torch
     from curious_amd import dist, ops
@@ -694,7 +709,7 @@ def main():
             counter[0] += 1
         policy, worker = bank[0], workers[0]
     else:
-        params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=b_r)
+        params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=b_r, virtual_ranks=V)
         prefill(policy, args.prefill, seed=rank)
 
         def step():
@@ -753,37 +768,47 @@ def main():
 
     if rank == 0:
         T = params['T']
-        n_pol = len(bank) if experts else 1
-        headline = (args.env == ENV and b_r == B_R and not experts)
+        n_pol = len(bank) if experts else V                        # minibatches of BATCH rows per update
+        headline = (args.env == ENV and b_r == B_R and not experts and V == 1)
         workload = ('%s, %d parallel rollouts x T=%d per GPU, HER future k=4, batch %d, %d updates per cycle, %d per-task '
-                    'buffers' % (args.env, b_r, T, BATCH, N_BATCHES, policy.nb_tasks + 1))
+                    'buffers' % (args.env, b_r * V, T, BATCH, N_BATCHES, policy.nb_tasks + 1))
         if headline:
             workload += ' (configs[1])'
+        elif V > 1:
+            workload = ('%s in the reference\'s published regime (readme.md:16, --num_cpu %d) as %d VIRTUAL RANKS per GPU: '
+                        'per rank %d rollouts x T=%d, private per-task buffers and seeds, a minibatch of %d per update; '
+                        'every update consumes the %d minibatches in one launch sequence, gradients summed over them '
+                        '(mpi_adam.py:26-28), normaliser sums averaged (normalizer.py:84-94); %d updates per cycle '
+                        '(diagnostic, not the headline configuration)' %
+                        (args.env, V * world, V, b_r, T, BATCH, V, N_BATCHES))
         elif experts:
             workload += ('; structure=task_experts: %d experts, every update applies to all of them in one batched launch '
                          'sequence (configs[4], diagnostic)' % n_pol)
         else:
             workload += ' (diagnostic, not the headline configuration)'
+        bpt = 47213.0 if (experts or V == 1) else 1034.0 + (47213.0 - 1034.0) / V
         out = {
             'metric': 'HER-sampled gradient transitions/sec (+ env_steps_per_sec), %s cycle' % args.env,
             'value': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed, 1),
             'unit': 'transitions/s',
-            'env_steps_per_sec': round(args.steps * b_r * T * world / elapsed, 1),
-            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES * n_pol / elapsed, 1),
+            'env_steps_per_sec': round(args.steps * b_r * V * T * world / elapsed, 1),
+            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES * (n_pol if experts else 1) / elapsed, 1),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'step': 'one cycle: rollout + store_episode + 100 x train() + update_target_net',
-                       'rollout_batch_size': b_r, 'batch_size': BATCH, 'n_batches': N_BATCHES,
+                       'rollout_batch_size': b_r, 'batch_size': BATCH, 'n_batches': N_BATCHES, 'virtual_ranks': V,
                        'hipgraph': not args.no_graph, 'rng': 'device (Philox)',
                        'parallelism': 'dp%d' % world},
             'roofline': roof,
-            # SURVEY 8d whole-update figure: 47 213 algorithmic bytes per gradient transition (HER rows + 40 B/param)
+            # SURVEY 8d whole-update figure: 47 213 algorithmic bytes per gradient transition (1 034 B of HER rows + the
+            # 40 B/param of an update spread over its 256 transitions -- over V x 256 with virtual ranks)
             'step_hbm': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS * world,
-                         'achieved': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed * 47213 / 1e9, 2),
-                         'frac': round(args.steps * N_BATCHES * BATCH * n_pol / elapsed * 47213 / 1e9 / HBM_PEAK_GBS, 5)},
+                         'bytes_per_transition': round(bpt, 1),
+                         'achieved': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed * bpt / 1e9, 2),
+                         'frac': round(args.steps * N_BATCHES * BATCH * n_pol / elapsed * bpt / 1e9 / HBM_PEAK_GBS, 5)},
             'kernels': table,
         }
         if coll is not None:

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 8          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 9          # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -51,14 +51,16 @@ class SamplePlan(C.Structure):
 class SampleRng(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('step_ctr', C.c_void_p), ('step_host', C.c_int64),
                 ('prop_prefix', C.c_void_p), ('cur_size', C.c_void_p), ('buf_alias', C.c_void_p),
-                ('buf_task', C.c_void_p), ('nbuf', C.c_int32)]
+                ('buf_task', C.c_void_p), ('nbuf', C.c_int32), ('rank_rows', C.c_int32),
+                ('rank_tab_stride', C.c_int64), ('rank_seed_stride', C.c_uint64)]
 
 
 class NetCfg(C.Structure):
     _fields_ = [('dimo', C.c_int32), ('dimg', C.c_int32), ('dimu', C.c_int32), ('dimtd', C.c_int32),
                 ('hidden', C.c_int32), ('layers', C.c_int32), ('modular', C.c_int32),
                 ('max_u', C.c_float), ('gamma', C.c_float), ('clip_return', C.c_float), ('action_l2', C.c_float),
-                ('clip_pos_returns', C.c_int32), ('normalize_obs', C.c_int32), ('norm_clip', C.c_float)]
+                ('clip_pos_returns', C.c_int32), ('normalize_obs', C.c_int32), ('norm_clip', C.c_float),
+                ('loss_rows', C.c_int32)]
 
 
 class AdamState(C.Structure):
@@ -74,7 +76,7 @@ class Transposed(C.Structure):
 
 
 class IpcPeers(C.Structure):
-    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('grad', C.c_void_p * 8), ('theta', C.c_void_p * 8),
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('grad', C.c_void_p * 8), ('stage', C.c_void_p * 8),
                 ('flags', C.c_void_p * 8)]
 
 
@@ -82,6 +84,10 @@ class NextBatch(C.Structure):
     _fields_ = [('storage', C.c_void_p), ('buf_stride', C.c_int64), ('L', C.POINTER(Layout)),
                 ('tasks', C.POINTER(Tasks)), ('P', C.POINTER(SampleParams)), ('rng', C.POINTER(SampleRng)),
                 ('batch', C.c_void_p)]
+
+
+class RankGroups(C.Structure):
+    _fields_ = [('group', C.c_int32), ('reserved', C.c_int32), ('seed_stride', C.c_uint64), ('exploit', C.c_void_p)]
 
 
 class EnvCfg(C.Structure):
@@ -111,8 +117,8 @@ PROTOTYPES = {
     'curious_ipc_export': (C.c_int, [_P, C.c_char_p]),
     'curious_ipc_import': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     'curious_ipc_close': (C.c_int, [_P]),
-    'curious_allreduce_adam_ipc': (C.c_int, [C.POINTER(IpcPeers), _P, _P, _I64, _I64, _P, _P, _I64, _I32, _F, _F, _F, _F,
-                                             _F, _P, _P, _I32, C.POINTER(Transposed), _P]),
+    'curious_allreduce_adam_ipc': (C.c_int, [C.POINTER(IpcPeers), _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _F, _F, _F,
+                                             _F, _F, _P, _P, _P, _I32, C.POINTER(Transposed), _P]),
     'curious_her_sample': (C.c_int, [_P, _I64, C.POINTER(Layout), C.POINTER(Tasks), C.POINTER(SampleParams),
                                      C.POINTER(SamplePlan), C.POINTER(SampleRng), _I32, _P, C.POINTER(BatchLayout),
                                      _P]),
@@ -167,8 +173,13 @@ PROTOTYPES = {
     'curious_policy_rollout_stats': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
                                                C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _I32, _P, _P, _P,
                                                _P, _P, _I32, _I32, _D, _P, _I32, _P, _P, _P]),
+    'curious_policy_rollout_ranks': (C.c_int, [C.POINTER(NetCfg), _P, _I32, _F, _P, _D, _D, _U64, _U64, _P, _P, _I32,
+                                               C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _I32, _I32, _P, _P, _P,
+                                               _P, _P, _I32, _I32, _D, _P, _I32, _P, _P, C.POINTER(RankGroups), _P]),
     'curious_route_store_episodes': (C.c_int, [_P, _P, C.POINTER(Layout), _P, _I32, _I32, _I32, _P, _P, _I64, _U64, _U64,
                                                _P, _P, _P, _P, _P]),
+    'curious_route_store_episodes_ranks': (C.c_int, [_P, _P, C.POINTER(Layout), _P, _I32, _I32, _I32, _I32, _P, _P, _I64,
+                                                     _I64, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
     'curious_store_slots_host': (C.c_int, [_U64, _U64, _I32, _I64, _I32, _P, _P]),
     'curious_counter_add': (C.c_int, [_P, _I64, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,

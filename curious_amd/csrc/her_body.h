@@ -85,24 +85,34 @@ __device__ __forceinline__ void her_sample_body(const HerArgs& a, const int bloc
     out_row = a.plan.out_row ? a.plan.out_row[gic] : gic;
   } else {
     const curious_sample_rng_t& R = a.rng;
+    // virtual ranks (curious_sample_rng_t.rank_rows): this wave's sample is sample gl of rank vr -- that rank's tables,
+    // that rank's Philox key, the index it has within the rank's own batch; it lands in row gic of the joint batch
+    int gl = gic;
+    int64_t to = eo;
+    uint64_t seed = R.seed + seed_add;
+    if (R.rank_rows > 0) {
+      const int vr = gic / R.rank_rows;
+      gl = gic - vr * R.rank_rows;
+      to += (int64_t)vr * R.rank_tab_stride;
+      seed += (uint64_t)vr * R.rank_seed_stride;
+    }
     // lane b looks at logical buffer b: all table entries are fetched in one batch
     const int b = min(lane, R.nbuf - 1);
-    const int pe = R.prop_prefix[eo + b + 1];
-    const int al = R.buf_alias ? R.buf_alias[eo + b] : b;
-    const int tk = R.buf_task ? R.buf_task[eo + b] : -1;
-    const int cs = R.cur_size[eo + b];
+    const int pe = R.prop_prefix[to + b + 1];
+    const int al = R.buf_alias ? R.buf_alias[to + b] : b;
+    const int tk = R.buf_task ? R.buf_task[to + b] : -1;
+    const int cs = R.cur_size[to + b];
     const int64_t step = (R.step_ctr
         ? *reinterpret_cast<const int64_t*>(reinterpret_cast<const float*>(R.step_ctr) + eo) : R.step_host) + step_add;
-    const uint64_t seed = R.seed + seed_add;
-    const unsigned long long beyond = __ballot(lane < R.nbuf && gic >= pe);
+    const unsigned long long beyond = __ballot(lane < R.nbuf && gl >= pe);
     int lb = __popcll(beyond);
     if (lb >= R.nbuf) lb = R.nbuf - 1;
     buf = __shfl(al, lb);
     ttr = __shfl(tk, lb);
     const uint32_t E = (uint32_t)__shfl(cs, lb);
-    Philox4 r1 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_A,
+    Philox4 r1 = philox4x32((uint32_t)gl, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_A,
                             (uint32_t)seed, (uint32_t)(seed >> 32));
-    Philox4 r2 = philox4x32((uint32_t)gic, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_B,
+    Philox4 r2 = philox4x32((uint32_t)gl, (uint32_t)step, (uint32_t)(step >> 32), STREAM_SAMPLE_B,
                             (uint32_t)seed, (uint32_t)(seed >> 32));
     ep = (int)(((uint64_t)r1.x * E) >> 32);
     t = (int)(((uint64_t)r1.y * (uint32_t)L.T) >> 32);
@@ -243,6 +253,8 @@ static inline int her_fill_args(HerArgs& a, const float* storage, int64_t buf_st
   CURIOUS_CHECK(L->off_o == 0 && L->off_ag == L->dimo, "curious_her_sample: record rows must start with [o | ag]");
   CURIOUS_CHECK(tasks->ntasks <= CURIOUS_MAX_TASKS, "curious_her_sample: too many tasks");
   CURIOUS_CHECK(!rng || rng->nbuf <= 64, "curious_her_sample: at most 64 logical buffers");
+  CURIOUS_CHECK(!rng || rng->rank_rows == 0 || (rng->rank_rows > 0 && n % rng->rank_rows == 0 && rng->rank_tab_stride >= 0),
+                "curious_her_sample: n must be a whole number of ranks of rank_rows samples");
   CURIOUS_CHECK(!P->relative_goals || L->dimg == L->dimag, "relative_goals needs dimg == dimag (config.py:177-179)");
   memset(&a, 0, sizeof(a));
   a.storage = storage;

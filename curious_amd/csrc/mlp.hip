@@ -603,8 +603,11 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
                                 float* ag, const float* g, const float* td, float* staging, int32_t off_change,
                                 int32_t off_success, double reward_eps, float* flags, curious_stream_t stream,
                                 const float* o_stats = nullptr, const float* g_stats = nullptr,
-                                int32_t relative_goals = 0) {
+                                int32_t relative_goals = 0, const curious_rank_groups_t* rgp = nullptr) {
   if (check_cfg(cfg)) return -1;
+  RankGroups rg;
+  memset(&rg, 0, sizeof(rg));
+  if (rgp && rgp->group > 0) { rg.group = rgp->group; rg.seed_stride = rgp->seed_stride; rg.exploit = rgp->exploit; }
   CURIOUS_CHECK(theta && workspace && u_out && E && L && episode && tasks && o && ag && g && td && staging,
                 "curious_policy_act_env_step: NULL argument");
   CURIOUS_CHECK(cfg->modular, "curious_policy_act_env_step: modular nets only (use curious_policy_forward otherwise)");
@@ -638,6 +641,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     a.off_success = off_success;
     a.episode = episode; a.tasks = tasks; a.eo = o; a.eag = ag; a.staging = staging; a.reward_eps = reward_eps;
     a.flags = flags;
+    a.rg = rg;
     // the exchange buffer of the resident form is the head of the workspace (the row-local routes use nothing else of it)
     // (relative goals: the streaming kernel -- the resident form does not carry the goal part through its exchanges)
     if (!relative_goals && resident_ok(a, n, workspace) &&
@@ -650,7 +654,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
       const int rc = policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter + s,
                                           counter_base, u_out, ldu, E, L, env_id0, episode, tasks, t + s, 1, o, ag, g, td,
                                           staging, off_change, off_success, reward_eps, flags, stream, o_stats, g_stats,
-                                          relative_goals);
+                                          relative_goals, rgp);
       if (rc) return rc;
     }
     return 0;
@@ -679,6 +683,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
   k.episode = episode; k.tasks = tasks; k.o = o; k.ag = ag; k.g = g; k.td = td; k.staging = staging;
   k.reward_eps = reward_eps;
   k.flags = flags;
+  k.rg = rg;
   { ProfScope ps__(CK_ACT_STEP, st);
     if (part) hipLaunchKernelGGL(act_step_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, k);
     else hipLaunchKernelGGL(act_step_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, k); }
@@ -742,6 +747,22 @@ extern "C" int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const 
                               off_success, reward_eps, flags, stream, o_stats, g_stats, relative_goals);
 }
 
+extern "C" int curious_policy_rollout_ranks(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                            float* workspace, double noise_scale, double random_eps, uint64_t seed,
+                                            uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
+                                            const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                            const int32_t* episode, const int32_t* tasks, int32_t t0, int32_t nsteps,
+                                            float* o, float* ag, const float* g, const float* td, float* staging,
+                                            int32_t off_change, int32_t off_success, double reward_eps, float* flags,
+                                            int32_t relative_goals, const float* o_stats, const float* g_stats,
+                                            const curious_rank_groups_t* groups, curious_stream_t stream) {
+  CURIOUS_CHECK(nsteps >= 1, "curious_policy_rollout: nsteps must be positive");
+  CURIOUS_CHECK(!groups || groups->group >= 0, "curious_policy_rollout_ranks: negative group size");
+  return policy_act_env_steps(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, counter_base,
+                              u_out, ldu, E, L, env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, off_change,
+                              off_success, reward_eps, flags, stream, o_stats, g_stats, relative_goals, groups);
+}
+
 // What follows the gradients in curious_ddpg_update: Adam (+ the gather of the next batch).
 struct UpdateTail {
   AdamFuse adam;
@@ -764,6 +785,7 @@ struct DdpgPass {
   ExDim xd; uint64_t seed_stride = 0;     // batched experts: every pointer above is expert 0's
   // derived
   hipStream_t st; int H, nl, U, ld;
+  int Bl;                        // rows per (virtual) rank: cfg->loss_rows, or B
   Ws w; NetOff offQ, offPi;
   const float *thQ, *thPi, *ttQ, *ttPi; float *gQ, *gPi;
   ObsIn cur, nxt;
@@ -799,6 +821,8 @@ int DdpgPass::setup(curious_stream_t stream) {
   CURIOUS_CHECK(theta_main && theta_target && batch && BL && workspace && grad && out_losses && out_Q_pi,
                 "curious_ddpg_grads: NULL argument");
   CURIOUS_CHECK(B > 0, "curious_ddpg_grads: empty batch");
+  Bl = cfg->loss_rows > 0 ? cfg->loss_rows : B;
+  CURIOUS_CHECK(B % Bl == 0, "curious_ddpg_grads: the batch (%d rows) is not a whole number of ranks of loss_rows = %d rows", B, Bl);
   CURIOUS_CHECK(!cfg->normalize_obs || (o_stats && g_stats), "curious_ddpg_grads: normalize_obs needs stats");
   st = as_stream(stream);
   H = cfg->hidden; nl = cfg->layers; U = cfg->dimu;
@@ -870,7 +894,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   }
   a.dQ = w.dQ; a.dz = w.dz; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
   a.qt = reinterpret_cast<unsigned long long*>(w.qt);
-  a.B = B; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
+  a.B = B; a.Bl = Bl; a.nl = nl; a.dimo = cfg->dimo; a.dimtd = cfg->dimtd; a.dimg = cfg->dimg;
   // option "rows_xcd" = 0: the plain block-id order (A/B); batched experts fill the chip several times over: plain order
   a.xmap = (curious_options().rows_xcd && xd.nex == 1) ? 1 : 0;
   a.fault = w.fault; a.inject = curious_options().fault_inject; a.spins = curious_options().qt_spins;
@@ -882,7 +906,7 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   }
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
-  a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+  a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(Bl * U));
   const size_t lds = rows_lds_floats(nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
@@ -1047,7 +1071,7 @@ int DdpgPass::critic_backward() {
     a.WoutQ = thQ + offQ.Wout; a.boutQ = thQ + offQ.bout;
     a.e2 = w.act[3][l]; a.WoutQt = ttQ + offQ.Wout; a.boutQt = ttQ + offQ.bout;
     a.r = batch + BL->off_r; a.ldr = ld; a.pi = w.pi; a.ldpi = U;
-    a.B = B; a.H = H; a.U = U;
+    a.B = B; a.Bl = Bl; a.H = H; a.U = U;
     a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
     a.max_u = cfg->max_u;
     a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi; a.step_ctr = step_ctr;
@@ -1068,7 +1092,7 @@ int DdpgPass::critic_backward() {
     a.WoutQ = thQ + offQ.Wout; a.boutQ = thQ + offQ.bout;
     a.WoutQt = ttQ + offQ.Wout; a.boutQt = ttQ + offQ.bout;
     a.r = batch + BL->off_r; a.ldr = ld; a.pi = w.pi; a.ldpi = U;
-    a.B = B; a.H = H; a.U = U;
+    a.B = B; a.Bl = Bl; a.H = H; a.U = U;
     a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
     a.max_u = cfg->max_u;
     a.dc2 = w.dact[0][nl - 1]; a.dd2 = w.dact[1][nl - 1]; a.dQ = w.dQ; a.rows = w.rows; a.out_Qpi = out_Q_pi;
@@ -1131,7 +1155,7 @@ int DdpgPass::critic_backward() {
 int DdpgPass::actor_backward() {
   // ---- into the action slot of critic(pi), through tanh + l2 term -> dz; backward through the actor output layer
   //      (fused with the actor's first hidden backward level when the lean kernels apply)
-  const float l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(B * U));
+  const float l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(Bl * U));
   const bool fuse_actor = fuse_crit && U == 4 && aligned16(w.pi) && aligned16(w.dz) && aligned16(thQ + offQ.W0 + urow * H) &&
                           aligned16(thPi + offPi.Wout);
   CURIOUS_CHECK(!use_part || fuse_actor, "curious_ddpg_grads: inconsistent lean-path conditions");
@@ -1200,7 +1224,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   // ---- weight/bias gradients: problem lists for the lean kernels (launched after the actor's backward chain)
   const bool dw_hot = dx_hot && (B % 256 == 0) && (nl - 1) <= 4 && (!cfg->normalize_obs || xn_rows);
   LossFin fin;
-  fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.U = U; fin.action_l2 = cfg->action_l2;
+  fin.rows = w.rows; fin.out = out_losses; fin.B = B; fin.Bl = Bl; fin.U = U; fin.action_l2 = cfg->action_l2;
   fin.step_ctr = gather_in_rows ? step_ctr : nullptr;
   // gradients only (the all-reduce of several ranks follows): the fault word rides along as a padding element
   fin.fault = tail ? nullptr : w.fault;

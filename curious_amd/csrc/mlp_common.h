@@ -57,8 +57,10 @@ struct FwdArgs { FwdProb p[3]; int32_t nprob; };
 struct DxArgs { DxProb p[2]; int32_t nprob; };
 struct LossFin {         // final, fixed-order reduction of the per-row loss terms (rides on the dW launch)
   const float* rows;     // [3][B]: (target-Q)^2, Q_pi, sum_j (pi_j/max_u)^2
-  float* out;            // [2]: Q_loss, pi_loss
+  float* out;            // [B / Bl][2]: Q_loss, pi_loss of every rank
   int32_t B, U;
+  int32_t Bl;            // rows per (virtual) rank (curious_net_cfg_t.loss_rows; == B for one rank): every block of Bl rows
+                         // has its own means
   float action_l2;
   int64_t* step_ctr;     // non-NULL: the update's increment of the step counter happens HERE (deferred from the gradient
                          // launch, whose gather blocks read the counter: mlp_rows.h)
@@ -312,4 +314,25 @@ __device__ __forceinline__ float pick16(const float (&vals)[16], int lane) {
 #pragma unroll
   for (int i = 1; i < 16; ++i) m = (lane == i) ? vals[i] : m;
   return m;
+}
+
+// Ranks beyond the first: one wave per rank, each lane sums its rows in ascending order, then the wave-wide sum.
+// (The first rank keeps the workgroup-wide tree of the one-rank form -- see the callers --, so a batch of ONE rank is
+// finalised exactly as before; the per-rank losses are outputs only, no gradient depends on their order of summation.)
+__device__ inline void loss_fin_ranks(const LossFin& F, const float* rows, float* out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int R = F.B / F.Bl;
+  for (int r = 1 + wave; r < R; r += 4) {
+    float lq = 0.f, lp = 0.f, ll = 0.f;
+    for (int i = lane; i < F.Bl; i += 64) {
+      const int m = r * F.Bl + i;
+      lq += rows[m]; lp += rows[F.B + m]; ll += rows[2 * F.B + m];
+    }
+    lq = wave_sum(lq); lp = wave_sum(lp); ll = wave_sum(ll);
+    if (lane == 0) {
+      const float invB = 1.0f / (float)F.Bl;
+      out[2 * r] = lq * invB;
+      out[2 * r + 1] = -lp * invB + F.action_l2 * ll / (float)(F.Bl * F.U);
+    }
+  }
 }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
     if (blockIdx.x != 0 || blockIdx.y != 0) return;
     const LossFin& F = args.fin;
     float lq = 0.f, lp = 0.f, ll = 0.f;
-    for (int m = tid; m < F.B; m += 256) {
+    for (int m = tid; m < F.Bl; m += 256) {                  // (the first rank's rows; the others: loss_fin_ranks)
       lq += F.rows[m];
       lp += F.rows[F.B + m];
       ll += F.rows[2 * F.B + m];
@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs args) {
       __syncthreads();
     }
     if (tid == 0) {
-      const float invB = 1.0f / (float)F.B;
+      const float invB = 1.0f / (float)F.Bl;
       if (F.step_ctr) *F.step_ctr += 1;
       loss_fin_flag(F, 0, 0);
       F.out[0] = red[0] * invB;
-      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+      F.out[1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.Bl * F.U);
     }
+    if (F.Bl < F.B) loss_fin_ranks(F, F.rows, F.out);
     return;
   }
   const DwProb& P = args.p[blockIdx.z];

@@ -207,6 +207,7 @@ struct CriticHeadArgs {
   const float* r; int32_t ldr;
   const float* pi; int32_t ldpi;
   int32_t B, H, U;
+  int32_t Bl;                     // rows per (virtual) rank (curious_net_cfg_t.loss_rows): divisor of the loss means
   float gamma, clip_lo, clip_hi, max_u;
   float *dc2, *dd2;               // gradients wrt c2 / d2                                                      [B,H]
   float* dQ;                      // [B] d Q_loss / d Q   (feeds dWout/dbout of main/Q)
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void critic_head_kernel(CriticHeadArgs a) {
   row_dot_fast<1>(d2, a.WoutQ, a.H, lane, qp_);
   row_dot_fast<1>(e2, a.WoutQt, a.H, lane, qt_);
   const float Q = q_[0] + a.boutQ[0], Qpi = qp_[0] + a.boutQ[0], Qt = qt_[0] + a.boutQt[0];
-  const float invB = 1.0f / (float)a.B;
+  const float invB = 1.0f / (float)a.Bl;
   const float target = fclip(a.r[(int64_t)m * a.ldr] + a.gamma * Qt, a.clip_lo, a.clip_hi);   // ddpg.py:437-438
   const float diff = target - Q;
   const float dQ = -2.0f * invB * diff;                      // d mean((target-Q)^2) / dQ
@@ -284,6 +285,7 @@ struct DxCritArgs {
   const float* r; int32_t ldr;
   const float* pi; int32_t ldpi;
   int32_t B, H, U;
+  int32_t Bl;                     // rows per (virtual) rank: divisor of the loss means
   float gamma, clip_lo, clip_hi, max_u;
   float* dQ; float* rows; float* out_Qpi; int64_t* step_ctr;
 };
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void dx_crit_kernel(DxCritArgs a, Ex ex) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0 && tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
   const float* hrow = a.hl[ch] + eo + (int64_t)(m0 + j) * H;
   const float* wr = a.W + eo + (int64_t)(k0 + 4 * j) * H;
-  const float invB = 1.0f / (float)a.B;
+  const float invB = 1.0f / (float)a.Bl;
   const bool need_dots = (ch == 0) || (blockIdx.x == 0);
   // ---- all loads
   f32x4 pr_h[4], pr_e[4];                                   // prologue rows m0 + 4*wave + r, this lane's 4 columns
@@ -705,6 +707,7 @@ struct ActStepArgs {
   float* o; float* ag; const float* g; const float* td; float* staging;
   double reward_eps;
   float* flags;                              // optional rollout flags (env_step_body)
+  RankGroups rg;                             // virtual ranks (noise_body.h); group == 0: one rank
 };
 
 template <bool PART>
@@ -737,8 +740,9 @@ __global__ __launch_bounds__(256) void act_step_kernel(ActStepArgs a) {
       if (d == lane) v = o_[d];
     v = a.max_u_f * tanhf(v + a.bout[lane]);                  // actor_critic.py:89
     const uint64_t ctr = a.counter + (a.counter_base ? (uint64_t)*a.counter_base : 0ull);
-    v = noise_apply(v, e * a.U + lane, e, a.noise_scale, a.random_eps, a.max_u, nullptr, nullptr, nullptr, a.seed,
-                    ctr);                                     // ddpg.py:149-152
+    const RowNoise rn = row_noise(a.rg, e, a.seed, a.noise_scale, a.random_eps);
+    v = noise_apply(v, rn.row * a.U + lane, rn.row, rn.noise_scale, rn.random_eps, a.max_u, nullptr, nullptr, nullptr,
+                    rn.seed, ctr);                            // ddpg.py:149-152
     s_u[wave][lane] = v;
     a.u_out[(int64_t)e * a.ldu + lane] = v;
   }

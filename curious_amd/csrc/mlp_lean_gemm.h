@@ -565,7 +565,7 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
     if (S && !step_wait(*S, 5u)) return;
     float lq = 0.f, lp = 0.f, ll = 0.f;
     const __amdgpu_buffer_rsrc_t rr = coh_rsrc(F.rows + eo);
-    for (int m = tid; m < F.B; m += 256) {
+    for (int m = tid; m < F.Bl; m += 256) {                  // (the first rank's rows; the others: loss_fin_ranks)
       if (S) {
         lq += coh_ld1(rr, m * 4);
         lp += coh_ld1(rr, (F.B + m) * 4);
@@ -587,12 +587,13 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
       __syncthreads();
     }
     if (tid == 0) {
-      const float invB = 1.0f / (float)F.B;
+      const float invB = 1.0f / (float)F.Bl;
       if (F.step_ctr) *ex_i64(F.step_ctr, eo) += 1;
       loss_fin_flag(F, eo, eg);
       F.out[eo + 0] = red[0] * invB;
-      F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.B * F.U);
+      F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.Bl * F.U);
     }
+    if (F.Bl < F.B) loss_fin_ranks(F, F.rows + eo, F.out + eo);
   }
 }
 

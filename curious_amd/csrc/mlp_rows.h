@@ -57,6 +57,7 @@ struct RowsArgs {
   const float* wTq[ROWS_MAXL]; const float* wTpi[ROWS_MAXL];   // transposed hidden matrices of main critic / actor
   int64_t* step_ctr;
   int32_t B, nl, dimo, dimtd, dimg, xmap;
+  int32_t Bl;                     // rows per (virtual) rank: the loss means divide by it (curious_net_cfg_t.loss_rows; B for one rank)
   float gamma, clip_lo, clip_hi, max_u, l2c;
   unsigned long long* stamps;     // diagnostics (tools/rows_lab.hip): [3][32] s_memtime stamps of row group 0, else NULL
   int32_t* fault;                 // fault word of the workspace: incremented by every consumer wave that gave up on Q';
@@ -585,7 +586,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;                                           \
   const float* batch = a.batch + eo; (void)batch;                                                                \
   const int m = x.r0 + x.wave;                              /* the batch row whose output layers this wave finishes */ \
-  const float invB = 1.0f / (float)a.B; (void)invB;                                                              \
+  const float invB = 1.0f / (float)a.Bl; (void)invB;                                                             \
   float* sm_s = x.sm; (void)sm_s;                           /* [4] per-row scalar handed from wave i to the column threads */ \
   float* sm_v = x.sm + 16; (void)sm_v;                      /* [4][4] per-row 4-vectors (pi, dz) */             \
   unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + m; (void)qt; \

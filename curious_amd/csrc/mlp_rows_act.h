@@ -34,6 +34,7 @@ struct ActRowsArgs {
   float nclip;
   // relative goals (ddpg.py:119-124): g - ag before the clip, or NULL.  Fused steps: ag = the env's achieved goals
   const float* ag; int32_t ldag;
+  RankGroups rg;                                  // virtual ranks (noise_body.h); group == 0: one rank
 };
 
 // + the pre-drawn exploration noise of a multi-step launch: 4 envs x nsteps x 4 components x (z, coin, uniform) doubles
@@ -98,10 +99,12 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
     // pairs, same numbers.)  Too many steps for the LDS area: drawn per step as before.
     double* nz = reinterpret_cast<double*>(x.sm + 64) + (size_t)x.wave * 3 * 4 * a.nsteps;
     const bool predrawn = a.nsteps > 1 && a.noise_lds;
+    // (the env of a wave is wave-uniform: the group's key and noise switches live in scalar registers)
+    const RowNoise rn = row_noise(a.rg, __builtin_amdgcn_readfirstlane(m), a.seed, a.noise_scale, a.random_eps);
     if (predrawn) {
       for (int q = x.lane; q < 4 * a.nsteps; q += 64) {
-        const NoiseDraw d = noise_draw(m * 4 + (q & 3), m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed,
-                                       ctr0 + (uint64_t)(q >> 2));
+        const NoiseDraw d = noise_draw(rn.row * 4 + (q & 3), rn.row, rn.random_eps, a.max_u_d, nullptr, nullptr, nullptr,
+                                       rn.seed, ctr0 + (uint64_t)(q >> 2));
         nz[3 * q] = d.z; nz[3 * q + 1] = d.b; nz[3 * q + 2] = d.ru;
       }
     }
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
       NoiseDraw nd;
       nd.z = nd.b = nd.ru = 0.0;
       if (!predrawn && x.lane < 4)
-        nd = noise_draw(m * 4 + x.lane, m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed, ctr0 + (uint64_t)s);
+        nd = noise_draw(rn.row * 4 + x.lane, rn.row, rn.random_eps, a.max_u_d, nullptr, nullptr, nullptr, rn.seed,
+                        ctr0 + (uint64_t)s);
       __syncthreads();                                       // input rows of all 4 envs are in LDS
       rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr,
                   rnext(RN_FWD, pp + a.pi.W[1]));
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
           const int q = 4 * s + x.lane;
           nd.z = nz[3 * q]; nd.b = nz[3 * q + 1]; nd.ru = nz[3 * q + 2];
         }
-        v = noise_mix(v, nd, a.noise_scale, a.max_u_d);
+        v = noise_mix(v, nd, rn.noise_scale, a.max_u_d);
         s_u[x.lane] = v;
         a.u_out[(int64_t)m * a.ldu + x.lane] = v;
       }

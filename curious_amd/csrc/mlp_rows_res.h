@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
   const EnvConsts ec = env_consts(a.E, a.L, a.episode, a.tasks, a.eo, a.g, a.td, a.staging, m, x.lane);
   float ov = (x.lane < a.E.dimo) ? a.eo[(int64_t)m * a.E.dimo + x.lane] : 0.f;
   double* nz = nzb + (size_t)x.wave * 3 * 4 * RES_NOISE_CH;
+  const RowNoise rn = row_noise(a.rg, __builtin_amdgcn_readfirstlane(m), a.seed, a.noise_scale, a.random_eps);
   unsigned long long* xg = rx.xbuf + (size_t)group * 2 * 4 * 256;
   uint32_t q = (uint32_t)(2ull * ctr0) + 1u;                 // tag of the next exchange
   bool lost = false;
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       // exploration noise of the next RES_NOISE_CH steps of this wave's env, drawn by all 64 lanes (mlp_rows_act.h)
       const int left = min(RES_NOISE_CH, a.nsteps - s);
       for (int i = x.lane; i < 4 * left; i += 64) {
-        const NoiseDraw d = noise_draw(m * 4 + (i & 3), m, a.random_eps, a.max_u_d, nullptr, nullptr, nullptr, a.seed,
-                                       ctr0 + (uint64_t)(s + (i >> 2)));
+        const NoiseDraw d = noise_draw(rn.row * 4 + (i & 3), rn.row, rn.random_eps, a.max_u_d, nullptr, nullptr, nullptr,
+                                       rn.seed, ctr0 + (uint64_t)(s + (i >> 2)));
         nz[3 * i] = d.z; nz[3 * i + 1] = d.b; nz[3 * i + 2] = d.ru;
       }
     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       NoiseDraw nd;
       const int i = 4 * (s % RES_NOISE_CH) + x.lane;
       nd.z = nz[3 * i]; nd.b = nz[3 * i + 1]; nd.ru = nz[3 * i + 2];
-      v = noise_mix(v, nd, a.noise_scale, a.max_u_d);                                          // ddpg.py:149-152
+      v = noise_mix(v, nd, rn.noise_scale, a.max_u_d);                                         // ddpg.py:149-152
       s_u[x.lane] = v;
       if (member == 0) a.u_out[(int64_t)m * a.ldu + x.lane] = v;
     }

@@ -33,6 +33,24 @@ __device__ inline NoiseDraw noise_draw(int idx, int row, double random_eps, doub
   return n;
 }
 
+// Virtual ranks inside one batched rollout (curious_rank_groups_t): the launch's envs are consecutive groups of `group`
+// envs, one group per rank.  Env `row` of the launch is env row % group of group row / group: it draws with that group's
+// Philox key at its own row index -- the numbers a process of its own with that key would draw --, and a group whose
+// exploit flag is set acts without exploration noise (rollout.py:183-189: every rank decides for itself).
+struct RankGroups { int32_t group; int32_t pad_; uint64_t seed_stride; const int32_t* exploit; };
+struct RowNoise { uint64_t seed; int row; double noise_scale, random_eps; };
+__device__ inline RowNoise row_noise(const RankGroups& g, int row, uint64_t seed, double noise_scale, double random_eps) {
+  RowNoise r;
+  r.seed = seed; r.row = row; r.noise_scale = noise_scale; r.random_eps = random_eps;
+  if (g.group > 0) {
+    const int gi = row / g.group;
+    r.row = row - gi * g.group;
+    r.seed = seed + (uint64_t)gi * g.seed_stride;
+    if (g.exploit && g.exploit[gi] != 0) { r.noise_scale = 0.0; r.random_eps = 0.0; }
+  }
+  return r;
+}
+
 __device__ inline float noise_mix(float pi, const NoiseDraw& n, double noise_scale, double max_u) {
   float v = (float)__dadd_rn((double)pi, __dmul_rn(noise_scale, n.z));             // ddpg.py:149-150
   v = fclip(v, (float)-max_u, (float)max_u);                                      // ddpg.py:151

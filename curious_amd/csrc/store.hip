@@ -12,9 +12,11 @@ __global__ __launch_bounds__(256) void store_episodes_kernel(float* __restrict__
                                                             const float* __restrict__ staging,
                                                             const int32_t* __restrict__ pair_src,
                                                             const int64_t* __restrict__ pair_dst, int64_t rec_floats,
-                                                            int32_t vec_ok, const int32_t* __restrict__ n_pairs_dev) {
+                                                            int32_t vec_ok, const int32_t* __restrict__ n_pairs_dev,
+                                                            int32_t seg) {
+  // (seg: pairs per segment of a list made rank by rank -- segment s holds n_pairs_dev[s] pairs; one segment otherwise)
   const int pair = blockIdx.y;
-  if (n_pairs_dev && pair >= *n_pairs_dev) return;
+  if (n_pairs_dev && (pair % seg) >= n_pairs_dev[pair / seg]) return;
   if (pair_src[pair] < 0) return;                            // a later episode of the batch drew the same slot
   const float* src = staging + (int64_t)pair_src[pair] * rec_floats;
   float* dst = storage + pair_dst[pair] * rec_floats;
@@ -43,7 +45,7 @@ extern "C" int curious_store_episodes(float* storage, const float* staging, cons
   if (bx > 16) bx = 16;
   if (bx < 1) bx = 1;
   { ProfScope ps__(CK_STORE, as_stream(stream)); hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_pairs), dim3(256), 0, as_stream(stream), storage, staging,
-                     pair_src, pair_dst, rec, vec_ok, (const int32_t*)nullptr); }
+                     pair_src, pair_dst, rec, vec_ok, (const int32_t*)nullptr, 1 << 30); }
   CURIOUS_LAUNCH_CHECK("store_episodes_kernel");
   return 0;
 }
@@ -64,6 +66,9 @@ __host__ __device__ inline int64_t store_random_slot(uint64_t seed, uint64_t cal
 // (replay_buffer.py:101-102); when two episodes of the batch end up on one slot the later one wins (sequential
 // semantics) and the earlier pair is marked dead (src = -1).  Writes the (src, dst) pair list, its length, and the new
 // sizes into the sampler's table.
+// Virtual ranks (grid.x = rank): block v routes ITS n_episodes episodes -- staging records v * n_episodes .. -- into ITS
+// buffers (size / alias tables tab_stride int32 further per rank, Philox key seed + v * seed_stride, pair-list segment and
+// count of its own), exactly as a launch of its own would.
 #define ROUTE_MAX_EPISODES 2048
 #define ROUTE_HASH 4096u                                     // >= 2 x ROUTE_MAX_EPISODES, a power of two
 __device__ inline unsigned route_hash(int slot) { return ((unsigned)slot * 2654435761u >> 16) & (ROUTE_HASH - 1u); }
@@ -75,7 +80,17 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
                                                             const float* __restrict__ skip,
                                                             int32_t* __restrict__ pair_src,
                                                             int64_t* __restrict__ pair_dst,
-                                                            int32_t* __restrict__ n_pairs) {
+                                                            int32_t* __restrict__ n_pairs, int64_t tab_stride,
+                                                            uint64_t seed_stride) {
+  const int vr = blockIdx.x;
+  const int ep0 = vr * n_episodes;                           // this rank's first record in the staging block
+  active += (int64_t)ep0 * ntasks;
+  cur_size += (int64_t)vr * tab_stride;
+  buf_alias += (int64_t)vr * tab_stride;
+  seed += (uint64_t)vr * seed_stride;
+  pair_src += (int64_t)ep0 * n_route;
+  pair_dst += (int64_t)ep0 * n_route;
+  n_pairs += vr;
   __shared__ int wave_cnt[4];
   __shared__ int slot_of[ROUTE_MAX_EPISODES];                // this task's slot per episode, -1: not routed
   __shared__ int rank_of[ROUTE_MAX_EPISODES];                // its position in this task's part of the pair list
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
         if (on) {
           const int rank = routed + off + before;
           slot = (cur0 + rank < capacity) ? cur0 + rank : (int)store_random_slot(seed, call, b, j, capacity);
-          pair_src[out0 + rank] = b;
+          pair_src[out0 + rank] = ep0 + b;
           pair_dst[out0 + rank] = pool + slot;
           rank_of[b] = rank;
         }
@@ -162,12 +177,39 @@ extern "C" int curious_store_slots_host(uint64_t seed, uint64_t call, int32_t ta
   return 0;
 }
 
+static int route_store_ranks(float* storage, const float* staging, const curious_layout_t* L, const int32_t* active,
+                             int32_t ntasks, int32_t n_route, int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
+                             const int32_t* buf_alias, int64_t tab_stride, int64_t capacity, uint64_t seed,
+                             uint64_t seed_stride, uint64_t call, const float* skip, int32_t* pair_src,
+                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream);
+
 extern "C" int curious_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
                                             const int32_t* active, int32_t ntasks, int32_t n_route,
                                             int32_t n_episodes, int32_t* cur_size, const int32_t* buf_alias,
                                             int64_t capacity, uint64_t seed, uint64_t call, const float* skip,
                                             int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
                                             curious_stream_t stream) {
+  return route_store_ranks(storage, staging, L, active, ntasks, n_route, n_episodes, 1, cur_size, buf_alias, 0, capacity,
+                           seed, 0, call, skip, pair_src, pair_dst, n_pairs, stream);
+}
+
+extern "C" int curious_route_store_episodes_ranks(float* storage, const float* staging, const curious_layout_t* L,
+                                                  const int32_t* active, int32_t ntasks, int32_t n_route,
+                                                  int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
+                                                  const int32_t* buf_alias, int64_t tab_stride, int64_t capacity,
+                                                  uint64_t seed, uint64_t seed_stride, uint64_t call, const float* skip,
+                                                  int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
+                                                  curious_stream_t stream) {
+  CURIOUS_CHECK(n_ranks >= 1 && n_ranks <= 4096 && tab_stride >= 0, "curious_route_store_episodes_ranks: bad rank arguments");
+  return route_store_ranks(storage, staging, L, active, ntasks, n_route, n_episodes, n_ranks, cur_size, buf_alias,
+                           tab_stride, capacity, seed, seed_stride, call, skip, pair_src, pair_dst, n_pairs, stream);
+}
+
+static int route_store_ranks(float* storage, const float* staging, const curious_layout_t* L, const int32_t* active,
+                             int32_t ntasks, int32_t n_route, int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
+                             const int32_t* buf_alias, int64_t tab_stride, int64_t capacity, uint64_t seed,
+                             uint64_t seed_stride, uint64_t call, const float* skip, int32_t* pair_src,
+                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream) {
   CURIOUS_CHECK(storage && staging && L && active && cur_size && buf_alias && pair_src && pair_dst && n_pairs,
                 "curious_route_store_episodes: NULL argument");
   CURIOUS_CHECK(ntasks >= 1 && n_route >= 0 && n_route <= ntasks && capacity > 0 && capacity < (1ll << 31),
@@ -177,8 +219,9 @@ extern "C" int curious_route_store_episodes(float* storage, const float* staging
   if (n_episodes <= 0 || n_route == 0) return 0;
   hipStream_t st = as_stream(stream);
   { ProfScope ps__(CK_ROUTE, st);
-    hipLaunchKernelGGL(route_episodes_kernel, dim3(1), dim3(256), 0, st, active, ntasks, n_route, n_episodes, cur_size,
-                       buf_alias, capacity, seed, call, skip, pair_src, pair_dst, n_pairs); }
+    hipLaunchKernelGGL(route_episodes_kernel, dim3(n_ranks), dim3(256), 0, st, active, ntasks, n_route, n_episodes,
+                       cur_size, buf_alias, capacity, seed, call, skip, pair_src, pair_dst, n_pairs, tab_stride,
+                       seed_stride); }
   CURIOUS_LAUNCH_CHECK("route_episodes_kernel");
   int64_t rec = (int64_t)(L->T + 1) * L->row_stride;
   int vec_ok = (rec % 4 == 0) && (((uintptr_t)storage | (uintptr_t)staging) % 16 == 0);
@@ -187,8 +230,9 @@ extern "C" int curious_route_store_episodes(float* storage, const float* staging
   if (bx > 16) bx = 16;
   if (bx < 1) bx = 1;
   { ProfScope ps__(CK_STORE, st);
-    hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_episodes * n_route), dim3(256), 0, st, storage, staging,
-                       (const int32_t*)pair_src, (const int64_t*)pair_dst, rec, vec_ok, (const int32_t*)n_pairs); }
+    hipLaunchKernelGGL(store_episodes_kernel, dim3(bx, n_ranks * n_episodes * n_route), dim3(256), 0, st, storage, staging,
+                       (const int32_t*)pair_src, (const int64_t*)pair_dst, rec, vec_ok, (const int32_t*)n_pairs,
+                       n_episodes * n_route); }
   CURIOUS_LAUNCH_CHECK("store_episodes_kernel");
   return 0;
 }

@@ -38,6 +38,7 @@ MAX_CHAIN_GRAPHS = 4    # distinct chain lengths kept captured; further lengths 
 # hipStreamCaptureModeThreadLocal: HIP calls of OTHER threads (the RCCL watchdog polling events) must not invalidate a
 # capture that only this thread's launches take part in
 CAPTURE_MODE = 'thread_local'
+RANK_SEED_STRIDE = 1000003   # what separates the device RNG keys of consecutive (global) ranks
 
 
 class HandoffFault(_lib.CuriousHipError):
@@ -57,10 +58,22 @@ class DDPG(object):
                  rollout_batch_size, subtract_goals, relative_goals, clip_pos_returns, clip_return,
                  normalize_obs, sample_transitions, gamma, buffers=None, reuse=False, tasks_ag_id=None,
                  tasks_g_id=None, task_replay='', t_id=None, eps_task=None, structure='curious',
-                 rng_mode='numpy', seed=0, use_graph=False, async_store=False, **kwargs):
-        """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph / async_store."""
+                 rng_mode='numpy', seed=0, use_graph=False, async_store=False, virtual_ranks=1, **kwargs):
+        """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph / async_store / virtual_ranks.
+
+        virtual_ranks = V > 1: this process stands for V of the reference's MPI ranks (readme.md:16: the published runs use
+        19; train.py:272-281).  Every virtual rank keeps what a rank keeps for itself -- its replay buffers
+        (config.py:210-214), its RNG streams (train.py:242-243), its rollouts -- and ONE update consumes V minibatches of
+        `batch_size` transitions, one per virtual rank, in one launch sequence: the losses are means per virtual rank and
+        the gradient is their SUM, exactly what MpiAdam.update's Allreduce(SUM) makes of V processes (mpi_adam.py:26-28);
+        the normaliser sums are averaged over the V x world ranks (normalizer.py:84-94).  Global rank of virtual rank v
+        = dist.rank() * V + v: its streams are the ones that real rank would have."""
         if self.clip_return is None:
             self.clip_return = np.inf
+        self.V = self.virtual_ranks = int(virtual_ranks or 1)
+        if self.V > 1 and not (rng_mode == 'device' and structure == 'curious'):
+            raise ValueError("virtual_ranks > 1 needs rng_mode='device' and structure='curious'")
+        self._Bt = self.V * int(batch_size)                          # rows of one update's joint batch
         # e.g. info, use_mpi: stored by store_args, pickled with the policy; names with a leading underscore are
         # construction hooks of this implementation (_alloc: slab allocator of curious_amd.experts.ExpertBank)
         self._extra_kwargs = tuple(k for k in kwargs.keys() if not k.startswith('_'))
@@ -99,10 +112,16 @@ class DDPG(object):
         if structure in ('curious', 'task_experts'):
             self.nb_tasks = len(tasks_g_id)
         if buffers is not None:
-            self.buffer = buffers
-            if type(self.buffer) is list and len(self.buffer) > 5:
-                for i in range(6, len(self.buffer)):                 # distractor buffers are equal (ddpg.py:106-110)
-                    self.buffer[i] = self.buffer[5]
+            self.buffer = buffers                                    # (virtual ranks: rank 0's list; .ranks has them all)
+            ranks = getattr(buffers, 'ranks', None)
+            if self.V > 1 and (ranks is None or len(ranks) != self.V):
+                raise ValueError('virtual_ranks = %d needs the buffers of every rank on one pool '
+                                 '(replay_buffer.make_pooled_buffers(..., n_ranks=%d))' % (self.V, self.V))
+            self._rank_buffers = list(ranks) if ranks is not None else [self.buffer]
+            for bl in self._rank_buffers:
+                if isinstance(bl, list) and len(bl) > 5:
+                    for i in range(6, len(bl)):                      # distractor buffers are equal (ddpg.py:106-110)
+                        bl[i] = bl[5]
             self._adopt_buffers()
         self.first = True
         self.cp = np.zeros(self.nb_tasks) if hasattr(self, 'nb_tasks') else None
@@ -125,18 +144,20 @@ class DDPG(object):
         gradient vector in the bank's contiguous gradient block instead)."""
         if self._alloc is not None:
             return self._alloc(shape, dtype, name)
-        if name in ('theta', 'grad') and self._allreduce == 'ipc' and dist.is_distributed():
-            # what the peers read and write lives in a block of its own (curious_amd.ipc.IpcBlock: theta | grad | flags)
+        if name == 'grad' and self._allreduce == 'ipc' and dist.is_distributed():
+            # what the peers read and write lives in a fine-grained block of its own (curious_amd.ipc.IpcBlock: grad |
+            # staging vector of the new parameters | flags); theta stays ordinary local memory (csrc/ipc.hip)
             if getattr(self, '_ipc_block', None) is None:
                 from curious_amd.ipc import IpcBlock
                 self._ipc_block = IpcBlock([int(np.prod(shape))] * 2)
-            return self._ipc_block.tensor(0 if name == 'theta' else 1).view(*shape)
+            return self._ipc_block.tensor(0).view(*shape)
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def _create_network(self, reuse=False):
         cfg = ops.make_net_cfg(self.dimo, self.dimg, self.dimu, self.dimtd, self.hidden, self.layers, self.modular,
                                self.max_u, self.gamma, self.clip_return, self.action_l2, self.clip_pos_returns,
-                               self.normalize_obs, self.norm_clip)
+                               self.normalize_obs, self.norm_clip,
+                               loss_rows=self.batch_size if self.V > 1 else 0)
         self.net_cfg = cfg
         self.P_Q, self.P_pi, self.off_pi, self.P_total = ops.param_layout(cfg)
         dev = self.device
@@ -160,10 +181,10 @@ class DDPG(object):
         self.pi_adam = MpiAdam(self.theta[self.off_pi:], scale_grad_by_procs=False)
         self.Q_adam.m, self.Q_adam.v = self._m[:self.off_pi], self._v[:self.off_pi]
         self.pi_adam.m, self.pi_adam.v = self._m[self.off_pi:], self._v[self.off_pi:]
-        self._workspace = self._new([ops.workspace_floats(cfg, self.batch_size)])
+        self._workspace = self._new([ops.workspace_floats(cfg, self._Bt)])
         self._act_ws = {}
-        self._losses = self._new([2])
-        self._Q_pi = self._new([self.batch_size, 1])
+        self._losses = self._new([2 * self.V])                       # [Q_loss, pi_loss] of every virtual rank
+        self._Q_pi = self._new([self._Bt, 1])
         self._step_ctr = self._new([1], torch.int64)
         self._alpha_tab = self._new([ALPHA_TAB, 2])
         self._alpha_base = 0
@@ -194,9 +215,14 @@ class DDPG(object):
                 parts.append(np.zeros(s, np.float32))
         return np.concatenate(parts)
 
+    def _grank0(self):
+        """Global rank of this process's first (virtual) rank: rank r of a job with V virtual ranks per process stands for
+        the reference's ranks r V .. r V + V - 1 (train.py:242-243: every rank has its own seed)."""
+        return dist.rank() * self.V
+
     def _adopt_buffers(self):
         """All per-task buffers must share one pool so that a mixed minibatch is a single gather launch."""
-        bufs = self.buffer if isinstance(self.buffer, list) else [self.buffer]
+        bufs = [b for bl in self._rank_buffers for b in (bl if isinstance(bl, list) else [bl])]
         real = [b for b in bufs if b is not None]
         pool = real[0].pool
         for b in real:
@@ -261,7 +287,7 @@ class DDPG(object):
         else:
             self._noise_counter += 1
             ops.action_noise(u, n, self.dimu, noise_scale, random_eps, self.max_u,
-                             seed=self.seed * 2654435761 + 12345 + dist.rank() * 1000003, counter=self._noise_counter)
+                             seed=self.seed * 2654435761 + 12345 + self._grank0() * RANK_SEED_STRIDE, counter=self._noise_counter)
         if host_io:
             hout = io['hout'][io['k']]
             hout[:, :self.dimu].copy_(u, non_blocking=True)
@@ -311,7 +337,7 @@ class DDPG(object):
         self._noise_counter += 1
         from curious_amd.envs import REWARD_EPS
         ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
-                                self.seed * 2654435761 + 12345 + dist.rank() * 1000003, self._noise_counter,
+                                self.seed * 2654435761 + 12345 + self._grank0() * RANK_SEED_STRIDE, self._noise_counter,
                                 self._act_u, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, t, env.o,
                                 env.ag, env.g, env.td, env.staging, REWARD_EPS, flags=getattr(env, 'flags', None),
                                 o_stats=self.o_stats.state if self.normalize_obs else None,
@@ -319,11 +345,14 @@ class DDPG(object):
                                 relative_goals=self.relative_goals)
         return self._act_u
 
-    def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False):
+    def act_rollout(self, env, T, noise_eps=0., random_eps=0., use_target_net=False, exploit=None):
         """The T-step acting loop of a batched rollout (rollout.py:226-303 for every env): T x act_and_step, as ONE
         launch (curious_policy_rollout) where the row-local route applies.  With use_graph the launches are captured once
         per (env, noise setting) and replayed; the Philox noise counter is (t + 1) + a device-resident base that advances
-        by T per rollout, so replays draw fresh noise and the eager loop draws the same numbers."""
+        by T per rollout, so replays draw fresh noise and the eager loop draws the same numbers.
+        exploit (virtual ranks): one flag per virtual rank -- the envs of a rank that exploits act without exploration
+        noise in this rollout (rollout.py:183-189); the envs are V consecutive groups, each drawing its noise from the
+        stream of its own global rank."""
         from curious_amd.envs import REWARD_EPS
         n = env.n
         theta = self.theta_target if use_target_net else self.theta
@@ -344,8 +373,23 @@ class DDPG(object):
         if self._noise_base_val != self._noise_counter:
             self._noise_base.fill_(self._noise_counter)
             self._noise_base_val = self._noise_counter
-        seed = self.seed * 2654435761 + 12345 + dist.rank() * 1000003     # same stream as get_actions / act_and_step
+        seed = self.seed * 2654435761 + 12345 + self._grank0() * RANK_SEED_STRIDE     # same stream as get_actions / act_and_step
         u_out = self._act_u
+        groups = None
+        if self.V > 1:
+            group = getattr(env, 'n_used', n) // self.V            # envs per virtual rank (padding envs: groups >= V)
+            ng = (n + group - 1) // group
+            if getattr(self, '_exploit_dev', None) is None or self._exploit_dev.numel() != ng:
+                self._exploit_dev = torch.zeros(ng, dtype=torch.int32, device=self.device)
+                self._exploit_pins = [torch.zeros(ng, dtype=torch.int32).pin_memory() for _ in range(4)]
+                self._exploit_k = 0
+            pin = self._exploit_pins[self._exploit_k]               # (a small ring: the copy is asynchronous)
+            self._exploit_k = (self._exploit_k + 1) % len(self._exploit_pins)
+            pin.zero_()
+            if exploit is not None:
+                pin[:self.V] = torch.from_numpy(np.asarray(exploit, dtype=np.int32))
+            self._exploit_dev.copy_(pin, non_blocking=True)
+            groups = ops.rank_groups(group, RANK_SEED_STRIDE, self._exploit_dev)
 
         def steps():
             # T x policy_act_env_step (noise counters 1 .. T on top of the base): one launch on the row-local route
@@ -355,7 +399,7 @@ class DDPG(object):
                                flags=getattr(env, 'flags', None),
                                o_stats=self.o_stats.state if self.normalize_obs else None,
                                g_stats=self.g_stats.state if self.normalize_obs else None,
-                               relative_goals=self.relative_goals)
+                               relative_goals=self.relative_goals, groups=groups)
             ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T
@@ -414,7 +458,7 @@ class DDPG(object):
             u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
             Q = torch.empty([n, 1], dtype=torch.float32, device=self.device) if compute_Q else None
             q_acc = torch.zeros((), dtype=torch.float32, device=self.device)
-            seed = self.seed * 2654435761 + 12345 + dist.rank() * 1000003
+            seed = self.seed * 2654435761 + 12345 + self._grank0() * RANK_SEED_STRIDE
 
             def steps():
                 q_acc.zero_()
@@ -426,7 +470,7 @@ class DDPG(object):
                     ops.action_noise(u, n, self.dimu, 0.0, 0.0, self.max_u, seed=seed, counter=0)   # the clip only
                     env.step_all(u, t)
                     if compute_Q:
-                        q_acc.add_(Q.mean())
+                        q_acc.add_(Q[:getattr(env, 'n_used', n)].mean())      # (idle padding envs do not count)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
@@ -493,27 +537,36 @@ class DDPG(object):
                            for j in range(self.nb_tasks) if counts[j])
                 distinct = len({id(self.buffer[j + 1]) for j in range(self.nb_tasks) if counts[j]}) == \
                     int((counts > 0).sum())
+                if self.V > 1 and not distinct:
+                    raise NotImplementedError('virtual ranks: the routed tasks need a buffer each')
                 if self.rng_mode == 'device' and distinct:
                     # device RNG mode: the rule of replay_buffer.py:90-109 per episode -- consecutive slots while the
                     # buffer has room, then a random slot -- with the random slots drawn from the Philox stream the
-                    # device-routed form uses (curious_route_store_episodes), so both forms store the same thing
+                    # device-routed form uses (curious_route_store_episodes), so both forms store the same thing.
+                    # Virtual ranks: rank v's episodes (rows v * per ..) into rank v's buffers, with rank v's key and
+                    # ITS episode numbers -- what a process of its own would do
                     call = self._next_store_call()
-                    for j in range(self.nb_tasks):
-                        if counts[j]:
-                            buf = self.buffer[j + 1]
-                            eps = np.nonzero(routed[:, j])[0]
+                    per = batch_size // self.V
+                    for v in range(self.V):
+                        bufs = self._rank_buffers[v]
+                        rows = routed[v * per:(v + 1) * per]
+                        for j in range(self.nb_tasks):
+                            eps = np.nonzero(rows[:, j])[0]
+                            if not eps.size:
+                                continue
+                            buf = bufs[j + 1]
                             free = max(0, buf.size - buf.current_size)
                             slots = np.arange(buf.current_size, buf.current_size + min(eps.size, free), dtype=np.int64)
                             buf.current_size = min(buf.size, buf.current_size + eps.size)
                             buf.n_transitions_stored += eps.size * self.T
                             if eps.size > free:
-                                slots = np.concatenate([slots, ops.store_slots_host(self._store_seed(), call, j, buf.size,
-                                                                                    eps[free:])])
+                                slots = np.concatenate([slots, ops.store_slots_host(self._store_seed(v), call, j,
+                                                                                    buf.size, eps[free:])])
                                 # of two episodes on one slot the later one wins (sequential semantics)
                                 _, first_rev = np.unique(slots[::-1], return_index=True)
                                 keep = np.sort(eps.size - 1 - first_rev)
                                 eps, slots = eps[keep], slots[keep]
-                            fast_src.append(eps.astype(np.int32))
+                            fast_src.append((eps + v * per).astype(np.int32))
                             fast_dst.append(slots.astype(np.int64) + buf.pool_index * buf.pool.capacity)
                 elif fits and distinct:
                     # no buffer overflows within this batch -> slots are consecutive and no random number is drawn
@@ -583,12 +636,14 @@ class DDPG(object):
             return False
         self.settle()
         nr = min(self.nb_tasks, 5)
-        bufs = [self.buffer[j + 1] for j in range(nr)]
-        return len({id(b) for b in bufs}) == nr and batch_size <= 2048 and all(b.current_size > 0 for b in bufs) \
-            and self.dimo + self.dimg <= 256
+        for bl in self._rank_buffers:                                # (batch_size: the episodes of ONE rank's rollout)
+            bufs = [bl[j + 1] for j in range(nr)]
+            if not (len({id(b) for b in bufs}) == nr and all(b.current_size > 0 for b in bufs)):
+                return False
+        return batch_size <= 2048 and self.dimo + self.dimg <= 256
 
-    def _store_seed(self):
-        return (self.seed * 6700417 + 29 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+    def _store_seed(self, v=0):
+        return (self.seed * 6700417 + 29 + (self._grank0() + v) * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
 
     def _next_store_call(self):
         self._store_calls = getattr(self, '_store_calls', 0) + 1
@@ -614,13 +669,14 @@ class DDPG(object):
         nb1 = self.nb_tasks + 1
         n0 = nb1 + 1
         if getattr(self, '_route_count', None) is None:
-            self._route_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._route_count = torch.zeros(self.V, dtype=torch.int32, device=self.device)
             self._nan_pin = torch.zeros(1, dtype=torch.float32).pin_memory()
         src_d, dst_d = self._route_bufs[4][:na], self._route_bufs[5][:na]
         ops.route_store_episodes(self._pool.storage, staging, layout, self._route_bufs[0][:na], self.nb_tasks,
-                                 min(self.nb_tasks, 5), batch_size, self._tables[n0 + 2 * nb1:],
-                                 self._tables[n0:n0 + nb1], self._pool.capacity, self._store_seed(),
-                                 self._next_store_call(), skip, src_d, dst_d, self._route_count)
+                                 min(self.nb_tasks, 5), batch_size // self.V, self._tables[n0 + 2 * nb1:],
+                                 self._tables[n0:], self._pool.capacity, self._store_seed(),
+                                 self._next_store_call(), skip, src_d, dst_d, self._route_count, n_ranks=self.V,
+                                 tab_stride=4 * nb1 + 1, seed_stride=RANK_SEED_STRIDE)
         if skip_host is None:
             self._nan_pin.copy_(skip, non_blocking=True)
             skip_host = self._nan_pin
@@ -643,12 +699,14 @@ class DDPG(object):
             routed = active_host.numpy().reshape(batch_size, self.nb_tasks).astype(bool)
             if self.nb_tasks >= 5:
                 routed[:, 5:] = False                                # only tasks j < 5 are routed (ddpg.py:183)
-            counts = routed.sum(axis=0)
-            for j in range(self.nb_tasks):
-                if counts[j]:
-                    buf = self.buffer[j + 1]
-                    buf.current_size = min(buf.size, buf.current_size + int(counts[j]))
-                    buf.n_transitions_stored += int(counts[j]) * self.T
+            per = batch_size // self.V
+            for v, bufs in enumerate(self._rank_buffers):
+                counts = routed[v * per:(v + 1) * per].sum(axis=0)
+                for j in range(self.nb_tasks):
+                    if counts[j]:
+                        buf = bufs[j + 1]
+                        buf.current_size = min(buf.size, buf.current_size + int(counts[j]))
+                        buf.n_transitions_stored += int(counts[j]) * self.T
         self._tables_sizes = self._sizes_key()
 
     def prefetch_activity(self, episode_batch):
@@ -687,7 +745,10 @@ class DDPG(object):
             self._stats_batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
         batch = self._stats_batch
         P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
-        ops.her_sample(staging, 0, layout, self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
+        # (virtual ranks: every rank draws its batch_size / V * T transitions from ITS episodes -- "buffer" v of the staging
+        #  block = the records of rank v)
+        ops.her_sample(staging, (batch_size // self.V) * layout.rec_floats if self.V > 1 else 0, layout,
+                       self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
         cols = layout.batch_cols
         if self.dimo + self.dimg > 256:
             # wider than the paired kernel's one workgroup: the two normalisers one after the other (ddpg.py:216-223)
@@ -701,32 +762,40 @@ class DDPG(object):
         need = ops.norm_pair_scratch_doubles(n, self.dimo, self.dimg)
         if getattr(self, '_stats_scratch', None) is None or self._stats_scratch.numel() < need:
             self._stats_scratch = torch.empty(need, dtype=torch.float64, device=self.device)
-        single = not dist.is_distributed()
+        # one rank: the finishing launch also recomputes the statistics.  Several (real or virtual) ranks: the accumulators
+        # hold the SUM over this process's virtual ranks; all-reduced over the processes, then divided by the number of
+        # ranks (normalizer.py:84-94: the MEAN over ranks of every rank's local sums)
+        single = not dist.is_distributed() and self.V == 1
         ops.norm_update_pair(batch, n, batch.stride(0), cols['o'][0], self.dimo, cols['g'][0], self.dimg,
                              self.o_stats.acc, self.g_stats.acc, self.o_stats.state if single else None,
                              self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
                              self._stats_scratch, skip=skip)
         if not single:
-            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc)
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc, ranks_per_process=self.V)
 
     def _stats_rng(self, n_episodes, n):
+        """Sampler description of the normaliser batch: n transitions from the n_episodes fresh episodes; with virtual
+        ranks n / V from each rank's n_episodes / V (one table row [prefix 0, prefix 1, size, alias, task] per rank)."""
         r = _lib.SampleRng()
+        V = self.V
         if getattr(self, '_stats_tables_key', None) != (n_episodes, n):
-            self._stats_tables = (torch.tensor([0, n], dtype=torch.int32, device=self.device),
-                                  torch.tensor([n_episodes], dtype=torch.int32, device=self.device),
-                                  torch.tensor([0], dtype=torch.int32, device=self.device),
-                                  torch.tensor([-1], dtype=torch.int32, device=self.device))
+            rows = [[0, n // V, n_episodes // V, v, -1] for v in range(V)]
+            self._stats_tables = torch.tensor(rows, dtype=torch.int32, device=self.device).reshape(-1)
             self._stats_tables_key = (n_episodes, n)
-        r.seed = (self.seed * 7919 + 17 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+        r.seed = (self.seed * 7919 + 17 + self._grank0() * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
         r.step_ctr = None
         self._stats_calls = getattr(self, '_stats_calls', 0) + 1
         r.step_host = self._stats_calls
-        r.prop_prefix, r.cur_size, r.buf_alias, r.buf_task = [x.data_ptr() for x in self._stats_tables]
+        t = self._stats_tables
+        r.prop_prefix, r.cur_size, r.buf_alias, r.buf_task = (t[0:].data_ptr(), t[2:].data_ptr(), t[3:].data_ptr(),
+                                                              t[4:].data_ptr())
         r.nbuf = 1
+        if V > 1:
+            r.rank_rows, r.rank_tab_stride, r.rank_seed_stride = n // V, 5, RANK_SEED_STRIDE
         return r
 
     def get_current_buffer_size(self):
-        self.settle()
+        self.settle()                                                # (virtual ranks: rank 0's, like everything a rank logs)
         return sum([self.buffer[i].get_current_size() for i in range(self.nb_tasks)])
 
     # ------------------------------------------------------------------ optimiser plumbing
@@ -737,7 +806,7 @@ class DDPG(object):
         """chained: the launch in front of this one on the stream was an optimiser call that keeps the transposed weight
         copies of the workspace current (_adam_only) inside the same captured graph -- see _update_fused."""
         b = self._staged
-        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, b, self._layout_for_batch, self.batch_size,
+        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, b, self._layout_for_batch, self._Bt,
                        self._workspace, self.grad, self._losses, self._Q_pi,
                        o_stats=self.o_stats.state if self.normalize_obs else None,
                        g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr,
@@ -760,10 +829,12 @@ class DDPG(object):
                             self.Q_adam.alpha(self.Q_lr), self.pi_adam.alpha(self.pi_lr), keep=self._fault_guard())
 
     # ------------------------------------------------------------------ sampling
-    def _proportions(self):
-        """ddpg.py:255-286 (curious, multi-buffer) and ddpg.py:303-318 (task_experts)."""
+    def _proportions(self, bufs=None):
+        """ddpg.py:255-286 (curious, multi-buffer) and ddpg.py:303-318 (task_experts).  bufs: the buffers of one virtual
+        rank (default: self.buffer) -- every rank splits ITS minibatch by the sizes of ITS buffers."""
         nb1 = self.nb_tasks + 1
-        sizes = np.array([self.buffer[i].current_size * self.T for i in range(nb1)])
+        bufs = self.buffer if bufs is None else bufs
+        sizes = np.array([bufs[i].current_size * self.T for i in range(nb1)])
         prop = np.zeros([nb1])
         if self.structure == 'curious':
             if sizes[1:].sum() < self.T:
@@ -808,7 +879,8 @@ class DDPG(object):
         return self.t_id                                             # ddpg.py:335
 
     def _sizes_key(self):
-        return (self._pool.version,) + tuple(self.buffer[i].current_size for i in range(self.nb_tasks + 1))
+        return (self._pool.version,) + tuple(bl[i].current_size for bl in self._rank_buffers
+                                             for i in range(self.nb_tasks + 1))
 
     def _tables_stale(self):
         """The device sampling tables follow the buffers: task experts share their buffers, so an episode stored through
@@ -818,27 +890,32 @@ class DDPG(object):
     def _prealloc_device_loop(self):
         """Allocate what the device-resident update loop otherwise allocates lazily (ExpertBank: identical slab layouts)."""
         if self._pp is None:
-            shape = [self.batch_size, self._layout.batch_stride]
+            shape = [self._Bt, self._layout.batch_stride]
             self._pp = [self._new(shape) for _ in range(2)]
             self._cur = 0
         if getattr(self, '_tables', None) is None:
-            n = 4 * (self.nb_tasks + 1) + 1
+            n = (4 * (self.nb_tasks + 1) + 1) * self.V
             self._tables = self._new([n], torch.int32)
             self._tables_host = torch.zeros(n, dtype=torch.int32).pin_memory()
 
     def _refresh_device_tables(self):
         self.settle()
         nb1 = self.nb_tasks + 1
-        self.proportions = self._proportions()
-        assert self.proportions.sum() == self.batch_size             # ddpg.py:323
-        prefix = np.concatenate([[0], np.cumsum(self.proportions)]).astype(np.int32)
-        alias = np.array([self.buffer[i].pool_index for i in range(nb1)], np.int32)
-        cur = np.array([self.buffer[i].current_size for i in range(nb1)], np.int32)    # per LOGICAL buffer
-        for i in range(nb1):
-            assert self.proportions[i] == 0 or self.buffer[i].current_size > 0   # replay_buffer.py:43
         task = np.array([-1 if self._task_of_buffer(i) is None else self._task_of_buffer(i) for i in range(nb1)],
                         np.int32)
-        host = np.concatenate([prefix, alias, task, cur])
+        rows = []
+        for v, bufs in enumerate(self._rank_buffers):                # one table row per virtual rank
+            prop = self._proportions(bufs)
+            assert prop.sum() == self.batch_size                     # ddpg.py:323
+            prefix = np.concatenate([[0], np.cumsum(prop)]).astype(np.int32)
+            alias = np.array([bufs[i].pool_index for i in range(nb1)], np.int32)
+            cur = np.array([bufs[i].current_size for i in range(nb1)], np.int32)       # per LOGICAL buffer
+            for i in range(nb1):
+                assert prop[i] == 0 or bufs[i].current_size > 0      # replay_buffer.py:43
+            rows += [prefix, alias, task, cur]
+            if v == 0:
+                self.proportions = prop
+        host = np.concatenate(rows)
         if getattr(self, '_tables', None) is None or self._tables.numel() != host.size:
             self._tables = self._new([host.size], torch.int32)
             self._tables_host = torch.zeros(host.size, dtype=torch.int32).pin_memory()
@@ -847,7 +924,7 @@ class DDPG(object):
         self._tables.copy_(self._tables_host, non_blocking=True)
         n0 = nb1 + 1
         r = _lib.SampleRng()
-        r.seed = (self.seed * 104729 + 7 + dist.rank() * 1000003) & 0xFFFFFFFFFFFFFFFF
+        r.seed = (self.seed * 104729 + 7 + self._grank0() * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
         r.step_ctr = self._step_ctr.data_ptr()
         r.step_host = 0
         r.prop_prefix = self._tables[:n0].data_ptr()
@@ -855,6 +932,8 @@ class DDPG(object):
         r.buf_task = self._tables[n0 + nb1:n0 + 2 * nb1].data_ptr()
         r.cur_size = self._tables[n0 + 2 * nb1:].data_ptr()
         r.nbuf = nb1
+        if self.V > 1:
+            r.rank_rows, r.rank_tab_stride, r.rank_seed_stride = self.batch_size, 4 * nb1 + 1, RANK_SEED_STRIDE
         self._rng_desc = r
         self._tables_dirty = False
         self._tables_sizes = self._sizes_key()
@@ -879,7 +958,7 @@ class DDPG(object):
         if host_r and self.relative_goals:
             raise NotImplementedError('a host-evaluated reward with relative_goals is not supported')
         P = S.params(np.inf if host_r else self.clip_obs, self.relative_goals)
-        B = self.batch_size
+        B = self._Bt                                                 # (virtual ranks: V minibatches of batch_size rows)
         if self._multi_buffer():
             layout = self._layout
             if self._staged is None or self._staged.shape != (B, layout.batch_stride):
@@ -952,11 +1031,11 @@ class DDPG(object):
             return
         assert len(self.stage_shapes) == len(batch)
         layout = self._layout
-        host = np.zeros([self.batch_size, layout.batch_stride], np.float32)
+        host = np.zeros([self._Bt, layout.batch_stride], np.float32)
         for key, arr in zip(self.stage_shapes.keys(), batch):
             off, dim = layout.batch_cols[key]
             a = arr.detach().cpu().numpy() if isinstance(arr, torch.Tensor) else np.asarray(arr)
-            host[:, off:off + dim] = a.reshape(self.batch_size, dim)
+            host[:, off:off + dim] = a.reshape(self._Bt, dim)
         self._staged = torch.from_numpy(host).to(self.device)
         self._layout_for_batch = layout
 
@@ -1112,14 +1191,15 @@ class DDPG(object):
         if blk is None:
             raise _lib.CuriousHipError("_allreduce='ipc' has to be chosen when the agent is built (its parameter and "
                                        'gradient vectors live in a block the peers can map)')
-        words = torch.zeros(2, dtype=torch.int32, device=self.device)     # [blocks done, a wait gave up]
+        words = torch.zeros(3, dtype=torch.int32, device=self.device)     # [blocks done, a wait gave up, epoch]
         torch.cuda.synchronize()
         blk.connect()
         peers = _lib.IpcPeers()
         peers.world, peers.rank = ws, dist.rank()
         for r in range(ws):
-            peers.theta[r], peers.grad[r], peers.flags[r] = blk.peer_ptr(r, 0), blk.peer_ptr(r, 1), blk.peer_flags(r)
-        self._ipc = dict(peers=peers, words=words)
+            peers.grad[r], peers.stage[r], peers.flags[r] = blk.peer_ptr(r, 0), blk.peer_ptr(r, 1), blk.peer_flags(r)
+        self._ipc = dict(peers=peers, words=words, err_pin=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                         err_ev=torch.cuda.Event(), err_pending=False)
 
     def _ipc_update(self, p, chained):
         """One update: gradients of the batch staged in tensor p (+ the gather of the next batch), then the one kernel
@@ -1133,8 +1213,9 @@ class DDPG(object):
         else:
             self._grads_next(p, chained)
         w = self._ipc['words']
-        ops.allreduce_adam_ipc(self._ipc['peers'], self._m, self._v, self.off_pi, self.P_total - self.off_pi,
-                               self._alpha_tab, self._step_ctr, self._alpha_base, w[0:1], w[1:2], self._kept_copies())
+        ops.allreduce_adam_ipc(self._ipc['peers'], self.theta, self._m, self._v, self.off_pi, self.P_total - self.off_pi,
+                               self._alpha_tab, self._step_ctr, self._alpha_base, w[2:3], w[0:1], w[1:2],
+                               self._kept_copies())
 
     def _train_ranks_ipc(self, n):
         """n updates on several ranks through curious_allreduce_adam_ipc (DDPG(_allreduce='ipc')).  Same gradients, same
@@ -1144,21 +1225,39 @@ class DDPG(object):
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False
+        self._ipc_verdict()                                          # of the previous run (its copy arrived long ago)
         p = self._cur
         for i in range(n):
             if (self.Q_adam.t + i) % 100 == 0:
                 self._check_synced()
-                if int(self._ipc['words'][1]):
-                    raise _lib.CuriousHipError('curious_allreduce_adam_ipc: a wait for a peer rank gave up (rank %d)' %
-                                               dist.rank())
             self._ipc_update(p, chained=i > 0)
             p ^= 1
+        # "a wait for a peer gave up" is read at the end of EVERY run: the rank skipped that epoch's arithmetic, the
+        # replicas may have parted.  The copy is asynchronous; the verdict is taken when the next run begins (or by
+        # check_faults(wait=True))
+        ipc = self._ipc
+        ipc['err_pin'].copy_(ipc['words'][1:2], non_blocking=True)
+        ipc['err_ev'].record()
+        ipc['err_pending'] = True
         self._cur = p
         self._staged = self._pp[self._cur]
         self.Q_adam.t += n
         self.pi_adam.t += n
         self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
+
+    def _ipc_verdict(self, wait=True):
+        ipc = getattr(self, '_ipc', None)
+        if ipc is None or not ipc['err_pending']:
+            return
+        if wait:
+            ipc['err_ev'].synchronize()
+        elif not ipc['err_ev'].query():
+            return
+        ipc['err_pending'] = False
+        if int(ipc['err_pin'][0]):
+            raise _lib.CuriousHipError('curious_allreduce_adam_ipc: a wait for a peer rank gave up (rank %d): that epoch '
+                                       "was skipped on this rank, the replicas may differ" % dist.rank())
 
     def _rank_graphs(self):
         """The split update graphs of the several-rank path with an eager collective: A[p] = gradients of the batch in
@@ -1265,7 +1364,7 @@ class DDPG(object):
 
     def _grads_next(self, p, chained=False):
         S = self.sample_transitions
-        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self.batch_size,
+        ops.ddpg_grads(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self._Bt,
                        self._workspace, self.grad, self._losses, self._Q_pi,
                        o_stats=self.o_stats.state if self.normalize_obs else None,
                        g_stats=self.g_stats.state if self.normalize_obs else None, step_ctr=self._step_ctr,
@@ -1285,7 +1384,7 @@ class DDPG(object):
         if self.Q_adam.t + k > self._alpha_filled or self._alpha_filled == 0:
             self._fill_alpha_table()
         if self._pp is None:
-            shape = [self.batch_size, self._layout.batch_stride]
+            shape = [self._Bt, self._layout.batch_stride]
             self._pp = [self._new(shape) for _ in range(2)]
             self._cur = 0
             self._batch_stale = True
@@ -1335,7 +1434,7 @@ class DDPG(object):
         which the library may trust the transposed copies it keeps in the workspace; everything else (a single update, the
         head of a chain) has them rebuilt from theta first."""
         S = self.sample_transitions
-        ops.ddpg_update(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self.batch_size,
+        ops.ddpg_update(self.net_cfg, self.theta, self.theta_target, self._pp[p], self._layout, self._Bt,
                         self._workspace, self.grad, self._losses, self._Q_pi, self._m, self._v,
                         step_ctr=self._step_ctr, alpha_tab=self._alpha_tab, tab_base=self._alpha_base,
                         o_stats=self.o_stats.state if self.normalize_obs else None,
@@ -1348,7 +1447,7 @@ class DDPG(object):
         """curious_transposed_t of this agent's workspace: handed to the stand-alone optimiser launch of the multi-rank
         path so that the gradient launch that follows it inside the same graph need not rebuild the copies."""
         if getattr(self, '_kept', None) is None:
-            self._kept = ops.ddpg_transposed(self.net_cfg, self.batch_size, self._workspace)
+            self._kept = ops.ddpg_transposed(self.net_cfg, self._Bt, self._workspace)
         return self._kept
 
     def _fault_guard(self):
@@ -1403,7 +1502,7 @@ class DDPG(object):
     def _enqueue_fault_check(self):
         """Asynchronous D2H copy of the workspace's fault word, stream-ordered behind everything enqueued so far."""
         if getattr(self, '_fault', None) is None:
-            self._fault = ops.fault_word(self.net_cfg, self.batch_size, self._workspace)
+            self._fault = ops.fault_word(self.net_cfg, self._Bt, self._workspace)
             self._fault_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._fault_ev = torch.cuda.Event()
         self._fault_pin.copy_(self._fault, non_blocking=True)
@@ -1417,6 +1516,7 @@ class DDPG(object):
         the exception can go on training from the last good parameters."""
         if wait:
             self._enqueue_fault_check()
+            self._ipc_verdict(wait=True)                             # (fused IPC all-reduce: a wait for a peer gave up)
         elif dist.is_distributed():
             return                                                   # read at a fixed cycle count: update_target_net
         self._fault_verdict(wait)
@@ -1431,15 +1531,16 @@ class DDPG(object):
         self._fault_pending = False
         n = int(self._fault_pin[0])
         if n:
-            ops.fault_word(self.net_cfg, self.batch_size, self._workspace, 64).zero_()
+            ops.fault_word(self.net_cfg, self._Bt, self._workspace, 64).zero_()
             raise HandoffFault("%d consumer wave(s) of the row-local update never received Q' from their target group "
                                '(agent %s, rank %d): the optimiser was skipped from that update on' %
                                (n, self.scope, dist.rank()))
 
     def clear_buffer(self):
         self.settle()
-        for i in range(self.nb_tasks):
-            self.buffer[i].clear_buffer()
+        for bl in self._rank_buffers:
+            for i in range(self.nb_tasks):
+                bl[i].clear_buffer()
         self._tables_dirty = True
 
     # ------------------------------------------------------------------ logging / persistence

@@ -116,10 +116,15 @@ class ResidentRolloutVoid(_lib.CuriousHipError):
 
 
 class BatchedSyntheticArm(ArmSpec):
-    def __init__(self, name, n, seed=0, env_id0=0, T=None):
+    def __init__(self, name, n, seed=0, env_id0=0, T=None, pad_to=1):
+        """pad_to: the batch is filled up to a multiple of it with idle envs (they step like any other env, nobody
+        reads their episodes): the one-launch rollout kernels take whole groups of 4 envs, and 19 virtual ranks x 2
+        rollouts (the reference's regime, readme.md:16) are 38.  n_used = the envs that count, n = the envs launched."""
         super().__init__(name)
         if T is not None:
             self.T = self._max_episode_steps = int(T)
+        self.n_used = int(n)
+        n = (int(n) + pad_to - 1) // pad_to * pad_to
         self.n, self.env_id0 = int(n), int(env_id0)
         self._seed = int(seed)
         dev = torch.device('cuda', torch.cuda.current_device())
@@ -161,8 +166,8 @@ class BatchedSyntheticArm(ArmSpec):
 
     def reset_all(self, tasks, goals_raw):
         """tasks[n] int, goals_raw[n,3] in [-1,1] (rollout.py:120-143 for every env at once)."""
-        self.tasks_host[:] = tasks
-        self.goals_host[:] = goals_raw
+        self.tasks_host[:self.n_used] = tasks                        # (idle padding envs: task 0, goal 0)
+        self.goals_host[:self.n_used] = goals_raw
         n = self.n
         k = self._pin_k
         self._pin_k = (k + 1) % len(self._pins)
@@ -205,7 +210,7 @@ class BatchedSyntheticArm(ArmSpec):
             raise ResidentRolloutVoid('curious_policy_rollout: a member of a workgroup group gave up waiting for its '
                                       "peers (the launch was not fully resident); option 'resident' = 0 selects the "
                                       'streaming kernel')
-        return host[:self.n].astype(np.float64), bool(host[self.n] != 0)
+        return host[:self.n_used].astype(np.float64), bool(host[self.n] != 0)
 
     def fetch_flags(self):
         """(is_success of the final step per env [n], any observation NaN) -- the one D2H sync of a rollout."""
@@ -215,12 +220,12 @@ class BatchedSyntheticArm(ArmSpec):
     def episode_views(self):
         # the staging block is allocated once: so are the views cut from it
         if getattr(self, '_views', None) is None:
-            self._views = EpisodeViews(self.staging, self.layout, with_next=False)
+            self._views = EpisodeViews(self.staging[:self.n_used], self.layout, with_next=False)
         return self._views
 
     def last_success(self):
         """is_success of the final step, [n] float32 on the GPU."""
-        return self.staging[:, self.T - 1, self.layout.off['info_is_success']]
+        return self.staging[:self.n_used, self.T - 1, self.layout.off['info_is_success']]
 
 
 class SyntheticArmEnv(ArmSpec):
@@ -293,5 +298,5 @@ class EnvFactory:
         self._count += 1
         return e
 
-    def make_batched(self, n, env_id0=0):
-        return BatchedSyntheticArm(self.name, n, env_id0=env_id0)
+    def make_batched(self, n, env_id0=0, pad_to=1):
+        return BatchedSyntheticArm(self.name, n, env_id0=env_id0, pad_to=pad_to)

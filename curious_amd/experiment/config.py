@@ -39,7 +39,7 @@ def cached_make_env(make_env):
 # what prepare_params moves into ddpg_params (config.py:129-139); a '_name' copy stays in the params for the logs
 _DDPG_KEYS = ('hidden', 'layers', 'network_class', 'polyak', 'batch_size', 'Q_lr', 'pi_lr', 'norm_eps', 'norm_clip',
               'max_u', 'action_l2', 'clip_obs', 'scope', 'relative_goals')
-_DEVICE_KEYS = ('rng_mode', 'use_graph', 'seed', 'async_store')     # MI355X-side knobs (not in the reference)
+_DEVICE_KEYS = ('rng_mode', 'use_graph', 'seed', 'async_store', 'virtual_ranks')   # MI355X-side knobs (not in the reference)
 
 
 def prepare_params(kwargs):
@@ -117,7 +117,8 @@ def configure_buffer(dims, params):
     per_rollout = params['rollout_batch_size']
     capacity = params['buffer_size'] // per_rollout * per_rollout   # in transitions (config.py:210)
     if 'buffer' in params['task_replay']:
-        return make_pooled_buffers(shapes, capacity, T, sampler, params['nb_tasks'] + 1, alias_from=5)
+        return make_pooled_buffers(shapes, capacity, T, sampler, params['nb_tasks'] + 1, alias_from=5,
+                                   n_ranks=int(params.get('virtual_ranks', 1)))
     return ReplayBuffer(shapes, capacity, T, sampler)
 
 

@@ -239,7 +239,17 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         save_dir = None
     if perturb and structure == 'task_experts':
         raise NotImplementedError('--perturb applies to the curious / flat loop only (train.py:142-146)')
-    rank_seed = seed + 1000000 * rank                                 # train.py:242-243
+    # Virtual ranks: --num_cpu R with R > WORLD_SIZE runs V = ceil(R / WORLD_SIZE) of the reference's ranks per process
+    # (readme.md:16: the published runs use 19 ranks, and "fewer cpus for a longer time is NOT equivalent";
+    # train.py:272-281).  Process r stands for the global ranks r V .. r V + V - 1.
+    world = dist.world_size()
+    V = 1
+    if num_cpu > world:
+        over = dict(override_params or {})
+        ok = (structure == 'curious' and over.get('rng_mode', 'device') == 'device' and 'buffer' in task_replay)
+        if ok:
+            V = -(-num_cpu // world)
+    rank_seed = seed + 1000000 * rank * V                             # train.py:242-243 (of this process's first rank)
     np.random.seed(rank_seed)
     import random
     random.seed(rank_seed)
@@ -253,6 +263,7 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
                   clip_return=clip_return, trial_id=trial_id, seed=seed)
     if override_params:
         params.update(override_params)
+    params['virtual_ranks'] = V
     if rank == 0:
         with open(os.path.join(logger.get_dir(), 'params.json'), 'w') as f:
             json.dump({k: v for k, v in params.items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
@@ -261,9 +272,12 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     params['ddpg_params'].setdefault('seed', seed)                    # identical initial weights on every rank
     if rank == 0:
         config.log_params(params, logger=logger)
-    if num_cpu != dist.world_size():
-        logger.warn('--num_cpu %d differs from WORLD_SIZE %d; ranks are created by torch.distributed.run' %
-                    (num_cpu, dist.world_size()))
+    if V > 1:
+        logger.info('--num_cpu %d on %d process(es): %d virtual ranks per GPU (%d ranks in all)' %
+                    (num_cpu, world, V, V * world))
+    elif num_cpu != world:
+        logger.warn('--num_cpu %d differs from WORLD_SIZE %d; ranks are created by torch.distributed.run (virtual ranks '
+                    "need structure='curious', device RNG and per-task buffers)" % (num_cpu, world))
 
     dims = config.configure_dims(params)
     buffers = config.configure_buffer(dims=dims, params=params)
@@ -300,6 +314,9 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         rollout_worker.seed(rank_seed)
     evaluator = RolloutWorker(params['make_env'], policy, dims, logger, **eval_params)
     evaluator.seed(rank_seed + 100)
+    if V > 1:                                                         # every virtual rank's own host streams
+        rollout_worker.seed_ranks([seed + 1000000 * (rank * V + v) for v in range(V)])
+        evaluator.seed_ranks([seed + 1000000 * (rank * V + v) + 100 for v in range(V)])
 
     best = train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
                  n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],

@@ -61,9 +61,17 @@ def store_episodes(storage, staging, layout, pair_src, pair_dst):
 
 
 def route_store_episodes(storage, staging, layout, active, ntasks, n_route, n_episodes, cur_size, buf_alias, capacity,
-                         seed, call, skip, pair_src, pair_dst, n_pairs):
-    """Device-side routing + copy of a batch of episodes (curious_route_store_episodes)."""
+                         seed, call, skip, pair_src, pair_dst, n_pairs, n_ranks=1, tab_stride=0, seed_stride=0):
+    """Device-side routing + copy of a batch of episodes (curious_route_store_episodes).  n_ranks > 1: n_episodes per
+    virtual rank, every rank into its own buffers (curious_route_store_episodes_ranks)."""
     L = layout.c_layout()
+    if n_ranks > 1:
+        check(lib().curious_route_store_episodes_ranks(
+            ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L), ptr(active), int(ntasks),
+            int(n_route), int(n_episodes), int(n_ranks), ptr(cur_size), ptr(buf_alias), int(tab_stride), int(capacity),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(seed_stride) & 0xFFFFFFFFFFFFFFFF, int(call), ptr(skip), ptr(pair_src),
+            ptr(pair_dst), ptr(n_pairs), current_stream()), 'curious_route_store_episodes_ranks')
+        return
     check(lib().curious_route_store_episodes(ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L),
                                              ptr(active), int(ntasks), int(n_route), int(n_episodes), ptr(cur_size),
                                              ptr(buf_alias), int(capacity), int(seed) & 0xFFFFFFFFFFFFFFFF, int(call),
@@ -116,7 +124,7 @@ def norm_recompute(acc, state, dim, world_size, eps):
 
 
 def make_net_cfg(dimo, dimg, dimu, dimtd, hidden, layers, modular, max_u, gamma, clip_return, action_l2,
-                 clip_pos_returns=True, normalize_obs=False, norm_clip=5.0):
+                 clip_pos_returns=True, normalize_obs=False, norm_clip=5.0, loss_rows=0):
     c = _lib.NetCfg()
     c.dimo, c.dimg, c.dimu, c.dimtd, c.hidden, c.layers = dimo, dimg, dimu, dimtd, hidden, layers
     c.modular = int(bool(modular))
@@ -124,6 +132,7 @@ def make_net_cfg(dimo, dimg, dimu, dimtd, hidden, layers, modular, max_u, gamma,
     c.clip_return = float(min(clip_return, 3.0e38))
     c.clip_pos_returns, c.normalize_obs, c.norm_clip = int(bool(clip_pos_returns)), int(bool(normalize_obs)), \
         float(min(norm_clip, 3.0e38))
+    c.loss_rows = int(loss_rows)             # > 0: the batch holds the minibatches of B / loss_rows virtual ranks
     return c
 
 
@@ -397,18 +406,31 @@ def policy_act_env_step(cfg, theta, n, clip_obs, workspace, noise_scale, random_
         check(lib().curious_policy_act_env_step(*args, current_stream()), 'curious_policy_act_env_step')
 
 
+def rank_groups(group, seed_stride, exploit=None):
+    """curious_rank_groups_t: the envs of a batched rollout as consecutive groups of `group` envs, one per virtual rank;
+    exploit: device int32 [number of groups], non-zero = that group acts without exploration noise."""
+    g = _lib.RankGroups()
+    g.group, g.seed_stride = int(group), int(seed_stride) & 0xFFFFFFFFFFFFFFFF
+    g.exploit = exploit.data_ptr() if exploit is not None else None
+    g._keep = exploit
+    return g
+
+
 def policy_rollout(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, seed, counter, u_out, ecfg, layout,
                    env_id0, episode, tasks, t0, nsteps, o, ag, g, td, staging, reward_eps, counter_base=None, flags=None,
-                   o_stats=None, g_stats=None, relative_goals=False):
+                   o_stats=None, g_stats=None, relative_goals=False, groups=None):
     """nsteps x policy_act_env_step (steps t0 .. t0 + nsteps - 1, noise counters counter, counter + 1, ...); one launch
-    on the row-local route."""
+    on the row-local route.  groups: rank_groups(...) -- the envs of several virtual ranks in one launch."""
     L = layout.c_layout()
     args = (C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs), ptr(workspace), float(noise_scale),
             float(random_eps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(counter_base), ptr(u_out),
             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), int(t0), int(nsteps),
             ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging), int(layout.off['change']),
             int(layout.off['info_is_success']), float(reward_eps), ptr(flags))
-    if o_stats is not None or g_stats is not None or relative_goals:
+    if groups is not None:
+        check(lib().curious_policy_rollout_ranks(*args, int(bool(relative_goals)), ptr(o_stats), ptr(g_stats),
+                                                 C.byref(groups), current_stream()), 'curious_policy_rollout_ranks')
+    elif o_stats is not None or g_stats is not None or relative_goals:
         check(lib().curious_policy_rollout_stats(*args, int(bool(relative_goals)), ptr(o_stats), ptr(g_stats),
                                                  current_stream()), 'curious_policy_rollout_stats')
     else:
@@ -489,13 +511,15 @@ def dw_stamps(cfg, B, workspace, n_blocks):
     return workspace[off:off + 16 * n_blocks].view(torch.int64).view(n_blocks, 8)
 
 
-def allreduce_adam_ipc(peers, m, v, n_Q, n_pi, alpha_tab, step_ctr, tab_base, done, err, keep, spins=0, beta1=0.9,
-                       beta2=0.999, epsilon=1e-08):
+def allreduce_adam_ipc(peers, theta, m, v, n_Q, n_pi, alpha_tab, step_ctr, tab_base, epoch, done, err, keep, spins=0,
+                       beta1=0.9, beta2=0.999, epsilon=1e-08):
     """curious_allreduce_adam_ipc: reduce-scatter over the peers' gradient vectors + Adam on the owned slice + all-gather
-    of the new slices + the transposed copies, one kernel (csrc/ipc.hip).  peers: _lib.IpcPeers of mapped pointers."""
+    of the new slices through the peers' staging vectors + the copy into the local `theta` + the transposed copies, one
+    kernel (csrc/ipc.hip).  peers: _lib.IpcPeers of mapped pointers; epoch / done / err: local device words."""
     f = np.float32
-    check(lib().curious_allreduce_adam_ipc(C.byref(peers), ptr(_dev(m, 'm')), ptr(v), int(n_Q), int(n_pi), ptr(alpha_tab),
-                                           ptr(step_ctr), int(tab_base), int(alpha_tab.shape[0]), float(f(beta1)),
-                                           float(f(1 - beta1)), float(f(beta2)), float(f(1 - beta2)), float(f(epsilon)),
-                                           ptr(done), ptr(err), int(spins), C.byref(keep) if keep is not None else None,
-                                           current_stream()), 'curious_allreduce_adam_ipc')
+    check(lib().curious_allreduce_adam_ipc(C.byref(peers), ptr(_dev(theta, 'theta')), ptr(_dev(m, 'm')), ptr(v), int(n_Q),
+                                           int(n_pi), ptr(alpha_tab), ptr(step_ctr), int(tab_base),
+                                           int(alpha_tab.shape[0]), float(f(beta1)), float(f(1 - beta1)), float(f(beta2)),
+                                           float(f(1 - beta2)), float(f(epsilon)), ptr(epoch), ptr(done), ptr(err),
+                                           int(spins), C.byref(keep) if keep is not None else None, current_stream()),
+          'curious_allreduce_adam_ipc')

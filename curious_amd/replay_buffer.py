@@ -154,11 +154,25 @@ class ReplayBuffer:
         return idx[0] if inc == 1 else idx
 
 
-def make_pooled_buffers(buffer_shapes, size_in_transitions, T, sample_transitions, n_logical, alias_from=None):
+class RankBuffers(list):
+    """The buffer list of virtual rank 0 (what `policy.buffer` is in the reference) + `.ranks`: the lists of ALL the
+    virtual ranks of this process (config.py:210-214 runs once per MPI process: every rank owns a full set)."""
+    ranks = None
+
+
+def make_pooled_buffers(buffer_shapes, size_in_transitions, T, sample_transitions, n_logical, alias_from=None,
+                        n_ranks=1):
     """The reference builds nb_tasks+1 independent buffers (config.py:210-212) and later aliases buffers 6.. to
-    buffer 5 (ddpg.py:106-110).  This builds them on ONE pool; aliased logical buffers share a physical slot."""
+    buffer 5 (ddpg.py:106-110).  This builds them on ONE pool; aliased logical buffers share a physical slot.
+    n_ranks > 1 (DDPG virtual_ranks): one such set per virtual rank, all on the one pool -- a RankBuffers list."""
     layout = RecordLayout(buffer_shapes, T)
     n_phys = n_logical if alias_from is None else min(n_logical, alias_from + 1)
-    pool = ReplayPool(layout, size_in_transitions // T, n_phys)
-    return [ReplayBuffer(buffer_shapes, size_in_transitions, T, sample_transitions, pool=pool, pool_index=i)
-            for i in range(n_phys)] + [None] * (n_logical - n_phys)
+    pool = ReplayPool(layout, size_in_transitions // T, n_phys * n_ranks)
+    ranks = [[ReplayBuffer(buffer_shapes, size_in_transitions, T, sample_transitions, pool=pool,
+                           pool_index=v * n_phys + i) for i in range(n_phys)] + [None] * (n_logical - n_phys)
+             for v in range(n_ranks)]
+    if n_ranks == 1:
+        return ranks[0]
+    out = RankBuffers(ranks[0])
+    out.ranks = [out] + ranks[1:]
+    return out

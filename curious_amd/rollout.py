@@ -40,9 +40,17 @@ class RolloutWorker:
         # the GPU-resident batched env is multi-task; the flat structure (rollout.py:93-95) runs the generic host loop
         self.batched = hasattr(make_env, 'make_batched') and structure != 'flat'
         self.rank = dist.rank()
-        self.nb_cpu = dist.world_size()
+        # virtual ranks (DDPG virtual_ranks = V): this worker runs the rollouts of V of the reference's ranks -- V x
+        # rollout_batch_size envs in one batched env, env ids, exploit decisions and task / goal draws per rank
+        self.V = int(getattr(policy, 'virtual_ranks', 1) or 1) if not isinstance(policy, (list, tuple)) else 1
+        self.nb_cpu = dist.world_size() * self.V
+        self._nloc = rollout_batch_size * self.V                     # envs of this process
+        if self.V > 1 and not (hasattr(make_env, 'make_batched') and structure == 'curious'):
+            raise ValueError("virtual ranks need the GPU-resident batched env and structure='curious'")
+        self._vrng = None                                            # per-virtual-rank host streams (seed_ranks)
         if self.batched:
-            self.benv = make_env.make_batched(rollout_batch_size, env_id0=self.rank * rollout_batch_size)
+            self.benv = (make_env.make_batched(self._nloc, env_id0=self.rank * self._nloc, pad_to=4) if self.V > 1
+                         else make_env.make_batched(self._nloc, env_id0=self.rank * self._nloc))
             self.envs = [self.benv]          # attribute kept; the batch is ONE object
             spec = self.benv
         else:
@@ -119,8 +127,29 @@ class RolloutWorker:
         for i in range(self.rollout_batch_size):
             self.reset_rollout(i)
 
+    def _decide_exploit_ranks(self):
+        """rollout.py:183-189 for every virtual rank, each from its own stream (train.py:242-243): _exploit_v[v].  The
+        worker-wide `exploit` = any of them (the cycle then has the competence exchange)."""
+        if self.eval:
+            self._exploit_v = np.ones(self.V, bool)
+        else:
+            self._exploit_v = np.array([self._rng(v).random_sample() < 0.1 for v in range(self.V)])
+        self.exploit = bool(self._exploit_v.any())
+
+    def _rng(self, v):
+        if self._vrng is None:
+            self.seed_ranks([12345 + 1000000 * (self.rank * self.V + k) for k in range(self.V)])
+        return self._vrng[v]
+
+    def seed_ranks(self, seeds):
+        """Host streams of the virtual ranks: seeds[v] = what train.py:242-243 gives global rank rank * V + v."""
+        assert len(seeds) == self.V
+        self._vrng = [np.random.RandomState(int(s) % (2 ** 32)) for s in seeds]
+
     def _decide_exploit(self):
         """rollout.py:183-189."""
+        if self.V > 1:
+            return self._decide_exploit_ranks()
         if self.structure in ('curious', 'task_experts') and not self.eval:
             self.exploit = True if np.random.random() < 0.1 else False
             if self.exploit and self.structure == 'curious':
@@ -313,18 +342,27 @@ class RolloutWorker:
             # whether this cycle has that exchange at all.  (A rollout regenerated after a NaN keeps the decision: the
             # ranks' host-side exchanges have to stay paired.)
             self._any_exploit = True if self.eval else dist.host_any(self.exploit)
-        B, env = self.rollout_batch_size, self.benv
+        B, env = self._nloc, self.benv
         # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
         experts = isinstance(self.policy, (list, tuple))          # task_experts evaluator (rollout.py:212-224)
         if redo is not None:
             tasks, goals = redo
+        elif self.V > 1:
+            # every virtual rank draws for its own envs from its own stream; a rank that exploits draws its tasks from
+            # the uniform distribution (rollout.py:184-186)
+            per = self.rollout_batch_size
+            uni = 1 / self.nb_tasks * np.ones([self.nb_tasks])
+            tasks = np.concatenate([self._rng(v).choice(range(self.nb_tasks), size=per,
+                                                        p=uni if (self._exploit_v[v] or self.eval) else self.p)
+                                    for v in range(self.V)])
+            goals = np.concatenate([self._rng(v).uniform(-1, 1, (per, 3)) for v in range(self.V)]).astype(np.float32)
         else:
             tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
         if experts and redo is None:
             # the draws are i.i.d., so any order of the envs is the same distribution: sorted by task, every expert's
             # envs are one contiguous row range of the batched env
             tasks = np.sort(tasks)
-        if redo is not None:
+        if redo is not None or self.V > 1:
             pass
         elif self.goal_selection == 'active' and not self.eval:
             # SAGG-RIAC goals live in goal space; reset_task_goal(directly=True) (rollout.py:143) = raw draw x 2 here
@@ -338,10 +376,17 @@ class RolloutWorker:
             q_sum = self._expert_steps(env, tasks, q_sum)
         fused = not experts and hasattr(self.policy, 'can_act_and_step') and \
             self.policy.can_act_and_step(env, self.compute_Q)
-        if fused and hasattr(self.policy, 'act_rollout'):
+        if fused and hasattr(self.policy, 'act_rollout') and self.V > 1:
+            # the noise is switched off rank by rank inside the launch (a rank that exploits: rollout.py:183-189)
+            self.policy.act_rollout(env, self.T, noise_eps=0. if self.eval else self.noise_eps,
+                                    random_eps=0. if self.eval else self.random_eps,
+                                    use_target_net=self.use_target_net, exploit=self._exploit_v)
+        elif fused and hasattr(self.policy, 'act_rollout'):
             self.policy.act_rollout(env, self.T, noise_eps=self.noise_eps if not self.exploit else 0.,
                                     random_eps=self.random_eps if not self.exploit else 0.,
                                     use_target_net=self.use_target_net)
+        elif self.V > 1 and not self.eval:
+            raise NotImplementedError('virtual ranks: training rollouts need the fused rollout (DDPG.act_rollout)')
         noise_eps = self.noise_eps if not self.exploit else 0.
         random_eps = self.random_eps if not self.exploit else 0.
         graphed = not fused and not experts and hasattr(self.policy, 'can_eval_rollout') and \
@@ -377,7 +422,7 @@ class RolloutWorker:
             tk = [_NOTHING] * self.nb_goals_per_rollout
             tk[self.rank * B:(self.rank + 1) * B] = task_list
             self._pending = dict(tasks=tk, goals=[_NOTHING] * self.nb_goals_per_rollout, task_list=task_list)
-            self.n_episodes += B * self.nb_cpu
+            self.n_episodes += self.rollout_batch_size * self.nb_cpu
             views = env.episode_views()
             self.policy.expect_async_store(views, env.flags[env.n:env.n + 1], env._flags_pin[env.n:env.n + 1])
             return views, self.CP, self.n_episodes
@@ -475,12 +520,12 @@ class RolloutWorker:
     # ================================================================== statistics, competence, task probabilities
     def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now, goals_now=None):
         """rollout.py:305-404.  goals_now: [B, len(task slots)] goals of the exploit rollouts for SAGG-RIAC."""
-        B = self.rollout_batch_size
+        B = self._nloc                                               # (virtual ranks: the envs of all of them)
         self.success_history.append(np.mean(successful))
         self.reward_history.append(r_competence)
         if self.compute_Q:
             self.Q_history.append(mean_Q)
-        self.n_episodes += B * self.nb_cpu
+        self.n_episodes += self.rollout_batch_size * self.nb_cpu
         if self.structure not in ('curious', 'task_experts'):
             return
         if not getattr(self, '_any_exploit', self.exploit or dist.is_distributed()) and self.goal_selection != 'active':
@@ -496,6 +541,8 @@ class RolloutWorker:
         rec[:, 0] = tasks_now
         rec[:, 1] = successful
         rec[:, 2] = 1.0 if self.exploit else 0.0
+        if self.V > 1:                                               # only the rollouts of ranks that exploited count
+            rec[:, 2] = np.repeat(self._exploit_v.astype(np.float64), self.rollout_batch_size)
         allrec = dist.allgather_numpy(rec)
         valid = allrec[:, 2] != 0
         task_ids = allrec[:, 0].astype(np.int64)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 8      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 9      /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -97,6 +97,15 @@ typedef struct curious_sample_rng {
   const int32_t* buf_alias;       /* [nbuf] physical buffer of each logical buffer (ddpg.py:106-110) */
   const int32_t* buf_task;        /* [nbuf] task_to_replay of each logical buffer, <0 = None */
   int32_t nbuf;
+  /* Virtual ranks (several MPI ranks' batches drawn by ONE call; config.py:210-214 builds the buffers per process and
+   * train.py:242-243 seeds every rank with seed + 1000000 * rank: both stay private to a rank here).  rank_rows > 0: sample
+   * i belongs to rank r = i / rank_rows and is that rank's sample i' = i - r * rank_rows -- it is drawn exactly as
+   * curious_her_sample would draw sample i' of a call with n = rank_rows, the four tables rank_tab_stride int32 elements
+   * further (r times) and the Philox key seed + r * rank_seed_stride -- and lands in batch row i.  Each rank's tables name
+   * ITS buffers through buf_alias (all ranks' buffers are slots of the one `storage`).  0: one rank. */
+  int32_t rank_rows;
+  int64_t rank_tab_stride;
+  uint64_t rank_seed_stride;
 } curious_sample_rng_t;
 
 const char* curious_last_error(void);
@@ -174,6 +183,19 @@ int curious_route_store_episodes(float* storage, const float* staging, const cur
                                  const int32_t* buf_alias, int64_t capacity, uint64_t seed, uint64_t call,
                                  const float* skip, int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
                                  curious_stream_t stream);
+/* The same for the episodes of n_ranks VIRTUAL RANKS in one call (the reference: one process per rank, each storing its
+ * own rollouts into its own buffers, config.py:210-214): `staging` holds n_ranks * n_episodes records, rank v's are records
+ * v * n_episodes .. (v + 1) * n_episodes - 1 (`active` likewise); its size / alias tables are cur_size / buf_alias +
+ * v * tab_stride (int32 elements), its slot draws use the key seed + v * seed_stride and ITS episode numbers
+ * 0 .. n_episodes - 1; pair_src / pair_dst: n_ranks * n_episodes * n_route entries (rank v's segment at v * n_episodes *
+ * n_route, src = record index in `staging`), n_pairs: n_ranks entries.  Rank by rank the result is what
+ * curious_route_store_episodes gives for that rank alone.  n_episodes <= 2048 per rank. */
+int curious_route_store_episodes_ranks(float* storage, const float* staging, const curious_layout_t* L,
+                                       const int32_t* active, int32_t ntasks, int32_t n_route, int32_t n_episodes,
+                                       int32_t n_ranks, int32_t* cur_size, const int32_t* buf_alias, int64_t tab_stride,
+                                       int64_t capacity, uint64_t seed, uint64_t seed_stride, uint64_t call,
+                                       const float* skip, int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
+                                       curious_stream_t stream);
 /* Host-side twin of the random slots above (no GPU involved): out[i] = slot of episode episodes[i] routed to `task`. */
 int curious_store_slots_host(uint64_t seed, uint64_t call, int32_t task, int64_t size, int32_t n,
                              const int32_t* episodes, int64_t* out);
@@ -225,6 +247,12 @@ typedef struct curious_net_cfg {
   int32_t clip_pos_returns;
   int32_t normalize_obs;       /* actor_critic.py:76-83 (default off, train.py:351) */
   float norm_clip;             /* normalizer.py:72-77 default_clip_range */
+  int32_t loss_rows;           /* 0 (or B): the losses of curious_ddpg_grads / _update are means over the whole batch
+                                * (ddpg.py:439-441).  L > 0 with B % L == 0: the batch holds the minibatches of B / L
+                                * (virtual) RANKS, L consecutive rows each; every rank's losses are means over ITS rows and
+                                * the gradient is the SUM over the ranks of each rank's gradient -- what MpiAdam.update's
+                                * Allreduce(SUM) makes of B / L processes with a batch of L rows each (mpi_adam.py:26-28,
+                                * ddpg.py:452-453).  out_losses then holds B / L pairs [Q_loss, pi_loss], rank by rank */
 } curious_net_cfg_t;
 
 int64_t curious_param_count_Q(const curious_net_cfg_t* cfg);
@@ -414,14 +442,20 @@ int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_str
  * (reduce-scatter + Adam + all-gather; csrc/ipc.hip): replaces Allreduce(SUM) + Adam of MpiAdam.update
  * (mpi_adam.py:21-35) -- in this build: the RCCL all-reduce + curious_adam_update of the several-rank update.  Every rank
  * calls it after its gradient launches with
- *   peers   every rank's gradient vector, parameter vector and flag block ([2][CURIOUS_IPC_MAX_RANKS] uint32, zeroed
- *           once) AS MAPPED INTO THIS PROCESS (hipIpcOpenMemHandle / the own rank's local pointers);
+ *   peers   every rank's gradient vector, STAGING vector (n_Q + n_pi floats: where the peers deliver the new parameter
+ *           slices) and flag block ([2][CURIOUS_IPC_MAX_RANKS] uint32, zeroed once) AS MAPPED INTO THIS PROCESS
+ *           (hipIpcOpenMemHandle / the own rank's local pointers).  All three live in FINE-GRAINED device memory
+ *           (curious_ipc_alloc): peers read, write and poll them while kernels of the owner run;
+ *   theta   the LOCAL parameter vector, ordinary device memory no peer ever touches: the kernel copies the completed
+ *           staging vector into it;
  *   m, v    the local moment vectors (full length; only the rank's slice [rank * n / world, (rank + 1) * n / world) is
- *           used: each rank runs the optimiser on its slice only and writes the new slice into every rank's parameters);
- *   step_ctr  the device step counter the gradient launches advanced: its value is the hand-shake token of the update
- *             and indexes the step-size ring like curious_adam_update;
+ *           used: each rank runs the optimiser on its slice only and writes the new slice into every rank's staging vector);
+ *   step_ctr  the device step counter the gradient launches advanced: indexes the step-size ring like curious_adam_update;
+ *   epoch   a local uint32 device word (zeroed once), advanced by one per call: the hand-shake token.  NOT the step
+ *           counter, which a caller may rewind to replay a run of updates -- tokens never repeat;
  *   done, err  two local uint32 / int32 device words (zeroed once): block bookkeeping / "a wait gave up after `spins`
- *              polls" (the kernel then ends without hanging; the caller raises);
+ *              polls": the rank then skips the arithmetic and the copy of that epoch like a faulted update, keeps
+ *              signalling so that no peer hangs, and the caller raises;
  *   keep    curious_ddpg_transposed() of the LOCAL workspace: fault word and flag index of the collective hand-off guard
  *           (every rank reads every rank's flag element and all skip alike), and the transposed copies, rebuilt from the
  *           new parameters at the end of the kernel (the next gradient call may say params_unchanged).
@@ -431,17 +465,18 @@ int curious_adam_update_and_sample_experts(int32_t n_experts, int64_t expert_str
 typedef struct curious_ipc_peers {
   int32_t world, rank;
   const float* grad[CURIOUS_IPC_MAX_RANKS];
-  float* theta[CURIOUS_IPC_MAX_RANKS];
+  float* stage[CURIOUS_IPC_MAX_RANKS];
   uint32_t* flags[CURIOUS_IPC_MAX_RANKS];
 } curious_ipc_peers_t;
-int curious_allreduce_adam_ipc(const curious_ipc_peers_t* peers, float* m, float* v, int64_t n_Q, int64_t n_pi,
-                               const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base, int32_t tab_len,
-                               float beta1, float one_minus_beta1, float beta2, float one_minus_beta2, float epsilon,
-                               uint32_t* done, int32_t* err, int32_t spins, const curious_transposed_t* keep,
-                               curious_stream_t stream);
+int curious_allreduce_adam_ipc(const curious_ipc_peers_t* peers, float* theta, float* m, float* v, int64_t n_Q,
+                               int64_t n_pi, const float* alpha_tab, const int64_t* step_ctr, int64_t tab_base,
+                               int32_t tab_len, float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
+                               float epsilon, uint32_t* epoch, uint32_t* done, int32_t* err, int32_t spins,
+                               const curious_transposed_t* keep, curious_stream_t stream);
 
 /* Set-up / tear-down of the peer mappings (host side, synchronous: once per job, not per update).  The vectors a rank
- * shares come from curious_ipc_alloc (hipMalloc, zeroed), are exported as 64-byte handles (hipIpcGetMemHandle), exchanged
+ * shares come from curious_ipc_alloc (hipExtMallocWithFlags(hipDeviceMallocFinegrained), zeroed; CURIOUS_IPC_COARSE=1 in
+ * the environment: plain hipMalloc, for A/B), are exported as 64-byte handles (hipIpcGetMemHandle), exchanged
  * by the caller (any host-side collective) and imported by the peers (hipIpcOpenMemHandle).  Every imported pointer is
  * closed before its owner frees the block. */
 int curious_ipc_alloc(int64_t bytes, void** out);
@@ -547,6 +582,28 @@ int curious_policy_rollout_stats(const curious_net_cfg_t* cfg, const float* thet
                                  const float* td, float* staging, int32_t off_change, int32_t off_success,
                                  double reward_eps, float* flags, int32_t relative_goals, const float* o_stats,
                                  const float* g_stats, curious_stream_t stream);
+
+/* curious_policy_rollout_stats for the envs of several VIRTUAL RANKS in one launch.  The reference runs one process per
+ * rank, each with its own envs, its own exploration-noise stream (train.py:242-243) and its own decision whether a rollout
+ * exploits (rollout.py:183-189: noise_eps = random_eps = 0 for that rank's envs).  Here the n envs are consecutive groups of
+ * `group` envs, one group per rank: env i belongs to group i / group; its noise is drawn with the Philox key
+ * seed + (i / group) * seed_stride at row index i % group -- exactly what a launch of its own with that key and n = group
+ * would draw --, and exploit[i / group] != 0 (device int32 array of ceil(n / group) entries, may be NULL) switches the
+ * noise of the whole group off.  groups == NULL or group == 0: curious_policy_rollout_stats. */
+typedef struct curious_rank_groups {
+  int32_t group;
+  int32_t reserved;
+  uint64_t seed_stride;
+  const int32_t* exploit;
+} curious_rank_groups_t;
+int curious_policy_rollout_ranks(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
+                                 float* workspace, double noise_scale, double random_eps, uint64_t seed, uint64_t counter,
+                                 const int64_t* counter_base, float* u_out, int32_t ldu, const curious_env_cfg_t* E,
+                                 const curious_layout_t* L, int32_t env_id0, const int32_t* episode,
+                                 const int32_t* tasks, int32_t t0, int32_t nsteps, float* o, float* ag, const float* g,
+                                 const float* td, float* staging, int32_t off_change, int32_t off_success,
+                                 double reward_eps, float* flags, int32_t relative_goals, const float* o_stats,
+                                 const float* g_stats, const curious_rank_groups_t* groups, curious_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,380 @@
+"""Round 5: virtual ranks -- the reference's published regime (readme.md:16: 19 MPI ranks, gradients SUMMED over ranks
+mpi_adam.py:26-28, normaliser sums AVERAGED normalizer.py:84-94, buffers / seeds / rollouts private to a rank
+config.py:210-214, train.py:242-243) as V virtual ranks of ONE process in one launch sequence -- against the oracle's
+R-rank model, against two real ranks of the product, and piece by piece against the one-rank entry points."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE_KEYS = ['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r']
+NB, DIMO, SEED, B, CAP = 4, 40, 3, 256, 64
+
+
+def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2):
+    from curious_amd.ddpg import DDPG
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    from test_gpu_agent import T, tables
+    G = 3 * NB
+    ag_ids, g_ids = tables(NB)
+    dims = dict(o=DIMO, u=4, g=G, ag=G, task_descr=NB, info_is_success=1)
+    shapes = dict(o=(T + 1, DIMO), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, NB),
+                  change=(T, G))
+    sampler = make_sample_multi_task_her_transitions('her', 4, 'replay_task_cp_buffer',
+                                                     sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    buffers = make_pooled_buffers(shapes, T * cap, T, sampler, NB + 1, alias_from=5, n_ranks=V or 1)
+    gamma = 1. - 1. / T
+    return DDPG(input_dims=dims, hidden=256, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
+                polyak=0.95, batch_size=B, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1.,
+                clip_obs=200., scope='ddpg', T=T, rollout_batch_size=rollout_batch_size, subtract_goals=None,
+                relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                sample_transitions=sampler, gamma=gamma, buffers=buffers, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
+                task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious', rng_mode='device', seed=seed,
+                use_graph=use_graph, **({} if V is None else dict(virtual_ranks=V)))
+
+
+def rank_episodes(V, n_per, first_seed=50):
+    """Rank-private episodes (train.py:242-243), rank v's at rows v * n_per ..; the streams of tests/rank_parity_worker.py"""
+    from test_gpu_agent import synth_episodes
+    rngs = [np.random.RandomState(first_seed + v) for v in range(V)]
+
+    def draw():
+        eps = [synth_episodes(rngs[v], n_per, NB, DIMO) for v in range(V)]
+        return {k: np.concatenate([e[k] for e in eps]) for k in eps[0]}
+    return draw
+
+
+def run_virtual(V, graph, n_per=24, first_seed=50):
+    """The sequence of tests/rank_parity_worker.py (store, 6 updates, store, 2 updates, target update) on ONE process with V
+    virtual ranks; everything the device drew and every state in between is recorded per virtual rank."""
+    from curious_amd import ops
+    agent = make_agent(V, use_graph=bool(graph))
+    draw = rank_episodes(V, n_per, first_seed)
+    cp = np.array([0.3, 0.0, 0.2, 0.1])
+    rec = {}
+    cols = agent._layout.batch_cols
+
+    def store(tag):
+        agent.store_episode(draw(), cp, n_per * V)
+        torch.cuda.synchronize()
+        sb = agent._stats_batch
+        rec['stats_o_' + tag] = sb[:, cols['o'][0]:cols['o'][0] + agent.dimo].cpu().numpy().copy()
+        rec['stats_g_' + tag] = sb[:, cols['g'][0]:cols['g'][0] + agent.dimg].cpu().numpy().copy()
+        rec['o_state_' + tag] = agent.o_stats.state.cpu().numpy().copy()
+        rec['g_state_' + tag] = agent.g_stats.state.cpu().numpy().copy()
+
+    def update(k):
+        for name, vec in (('theta', agent.theta), ('m', agent._m), ('v', agent._v)):
+            rec['%s_pre_%d' % (name, k)] = ops.unpad_params(agent.net_cfg, vec.cpu().numpy())
+        p = agent._cur
+        agent.train()
+        torch.cuda.synchronize()
+        views = agent._layout.batch_views(agent._pp[p])
+        for key in STAGE_KEYS:
+            rec['batch_%d_%s' % (k, key)] = views[key].cpu().numpy().copy()
+        rec['loss_%d' % k] = agent._losses.cpu().numpy().reshape(V, 2).copy()
+        rec['qpi_%d' % k] = agent._Q_pi.cpu().numpy().copy()
+
+    store('a')
+    k = 0
+    for _ in range(6):
+        update(k)
+        k += 1
+    store('b')
+    for _ in range(2):
+        update(k)
+        k += 1
+    agent.update_target_net()
+    torch.cuda.synchronize()
+    for name, vec in (('theta', agent.theta), ('m', agent._m), ('v', agent._v), ('target', agent.theta_target)):
+        rec[name] = ops.unpad_params(agent.net_cfg, vec.cpu().numpy())
+    rec['n_updates'] = k
+    agent.check_faults(wait=True)
+    return agent, rec
+
+
+def _recompute_ranks(nzs):
+    """normalizer.py:84-94 for R ranks in one process: every rank's three Allreduce(SUM) calls return the sum of all ranks'
+    local accumulators, then / comm size."""
+    tot = [sum(nz.local_sum for nz in nzs), sum(nz.local_sumsq for nz in nzs), sum(nz.local_count for nz in nzs)]
+    for nz in nzs:
+        q = [t.copy() for t in tot]
+        nz._allreduce = lambda x, q=q: q.pop(0)
+        nz._comm_size = len(nzs)
+        nz.recompute_stats()
+
+
+@pytest.mark.parametrize('V,graph', [(2, 0), (2, 1), (3, 1), (19, 0), (19, 1)])
+def test_virtual_ranks_match_the_oracle_rank_model(V, graph, route):
+    """V virtual ranks of one process against V oracle ranks: per-rank losses 1e-5 relative, one oracle Adam step from the
+    SUMMED oracle gradients lands on the product's next parameters / moments, normaliser state = 1 + mean of the ranks'
+    counts etc.  Both network routes (the fixture): the loss means are per rank on the row-local and on the tiled kernels."""
+    if V == 19 and route == 'tiled' and graph:
+        pytest.skip('covered by the eager form')
+    from oracle.normalizer import Normalizer as ONorm
+    from oracle.optim import adam_update, polyak_update
+    from test_gpu_round4 import _oracle_agent
+    n_per = 24 if V < 19 else 4
+    # (tiled route, 19 ranks: with the episodes of seeds 50.. one pre-activation of rank 13's first batch lies within
+    #  float32 rounding of zero and the tiled kernels' order of summation puts it on the other side of the ReLU than the
+    #  float64 oracle -- 2e-3 in that unit's weight gradients, with or without virtual ranks: another data seed)
+    agent, rec = run_virtual(V, graph, n_per=n_per, first_seed=250 if (V == 19 and route == 'tiled') else 50)
+    n_upd = rec['n_updates']
+    # ---- the ranks really saw different data, and every rank's rows come from ITS episodes
+    assert not np.array_equal(rec['batch_0_o'][:B], rec['batch_0_o'][B:2 * B])
+    # ---- normalisers: both stores, V oracle normalisers with the mean over ranks
+    o_nz = [ONorm(DIMO, 0.01, 5) for _ in range(V)]
+    g_nz = [ONorm(12, 0.01, 5) for _ in range(V)]
+    rows = n_per * 50
+    for tag in ('a', 'b'):
+        for r in range(V):
+            o_nz[r].update(np.clip(rec['stats_o_' + tag][r * rows:(r + 1) * rows].astype(np.float64), -200, 200))
+            g_nz[r].update(np.clip(rec['stats_g_' + tag][r * rows:(r + 1) * rows].astype(np.float64), -200, 200))
+        _recompute_ranks(o_nz)
+        _recompute_ranks(g_nz)
+        for nz, key in ((o_nz[0], 'o_state_' + tag), (g_nz[0], 'g_state_' + tag)):
+            d = nz.size
+            st = rec[key]
+            np.testing.assert_allclose(st[:d], nz.sum, rtol=1e-5, atol=1e-4, err_msg=key)
+            np.testing.assert_allclose(st[d:2 * d], nz.sumsq, rtol=1e-5, atol=1e-4, err_msg=key)
+            assert float(st[2 * d]) == float(nz.count[0]), key      # 1 + mean over ranks of the rows fed
+            np.testing.assert_allclose(st[2 * d + 1:3 * d + 1], nz.mean, rtol=1e-5, atol=1e-6, err_msg=key)
+            np.testing.assert_allclose(st[3 * d + 1:], nz.std, rtol=1e-5, atol=1e-6, err_msg=key)
+    assert float(o_nz[0].count[0]) == 1.0 + 2 * rows                # two stores of n_per episodes x T on EACH rank
+    # ---- updates, step by step from the product's own state
+    a = _oracle_agent(SEED)
+    np.testing.assert_array_equal(rec['theta_pre_0'], a.theta)
+    target0 = a.theta.copy()
+    PQ = a.math.P_Q
+    for k in range(n_upd):
+        th, m, v = (rec['%s_pre_%d' % (name, k)] for name in ('theta', 'm', 'v'))
+        outs = []
+        for r in range(V):
+            batch = {key: rec['batch_%d_%s' % (k, key)][r * B:(r + 1) * B] for key in STAGE_KEYS}
+            outs.append(a.math.losses_and_grads(th, target0, batch))
+            want, got = float(outs[r]['Q_loss']), float(rec['loss_%d' % k][r, 0])
+            assert abs(got - want) <= 1e-5 * abs(want), (k, r, got, want)
+            want, got = float(outs[r]['pi_loss']), float(rec['loss_%d' % k][r, 1])
+            assert abs(got - want) <= 1e-5 * abs(want) + 1e-7, (k, r, got, want)
+            np.testing.assert_allclose(rec['qpi_%d' % k][r * B:(r + 1) * B], outs[r]['Q_pi'], rtol=1e-4, atol=2e-5)
+        nxt = [np.empty_like(th), np.empty_like(m), np.empty_like(v)]
+        for sl, key, lr in ((slice(0, PQ), 'Q_grad', a.Q_lr), (slice(PQ, None), 'pi_grad', a.pi_lr)):
+            g = sum(o[key] for o in outs)                            # mpi_adam.py:26: SUM over ranks
+            nxt[0][sl], nxt[1][sl], nxt[2][sl], _ = adam_update(th[sl], m[sl], v[sl], k, g, lr)
+        suffix = ('_pre_%d' % (k + 1)) if k + 1 < n_upd else ''
+        got = [rec[name + suffix] for name in ('theta', 'm', 'v')]
+        np.testing.assert_allclose(got[1], nxt[1], rtol=0, atol=2e-5 * np.abs(nxt[1]).max())
+        np.testing.assert_allclose(got[2], nxt[2], rtol=0, atol=4e-5 * np.abs(nxt[2]).max())
+        assert np.abs(got[0] - nxt[0]).max() <= 2e-5, k              # one Adam step of size 1e-3
+        assert (np.abs(got[0] - nxt[0]) > 2e-6).mean() < 1e-3, k
+        if k == 0:
+            # SUM, not mean, and not one rank alone: the first moments are V times one rank's
+            one = adam_update(th[:PQ], m[:PQ], v[:PQ], 0, outs[0]['Q_grad'], a.Q_lr)[1]
+            assert np.abs(got[1][:PQ] - one).max() > 0.2 * np.abs(one).max()
+    np.testing.assert_allclose(rec['target'], polyak_update(target0, rec['theta'], 0.95), rtol=0, atol=1e-6)
+
+
+def test_two_virtual_ranks_draw_what_two_real_ranks_draw():
+    """Virtual rank v of a process = global rank rank * V + v: two virtual ranks of ONE process draw, bit for bit, the
+    batches and the normaliser rows two REAL ranks of the product draw (two processes, gloo; tests/rank_parity_worker.py),
+    and end on the same parameters up to the order in which the two ranks' gradients are summed."""
+    from test_gpu_round4 import _launch2, _two_rank_env
+    prefix = os.path.join(tempfile.mkdtemp(), 'w2')
+    out = _launch2([os.path.join(ROOT, 'tests', 'rank_parity_worker.py'), prefix, 'single', '0'], _two_rank_env())
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    real = [np.load('%s.rank%d.npz' % (prefix, r)) for r in range(2)]
+    _, rec = run_virtual(2, 0)
+    rows = 24 * 50
+    for tag in ('a', 'b'):
+        for r in range(2):
+            np.testing.assert_array_equal(rec['stats_o_' + tag][r * rows:(r + 1) * rows], real[r]['stats_o_' + tag])
+            np.testing.assert_array_equal(rec['stats_g_' + tag][r * rows:(r + 1) * rows], real[r]['stats_g_' + tag])
+        np.testing.assert_allclose(rec['o_state_' + tag], real[0]['o_state_' + tag], rtol=1e-6, atol=1e-6)
+    for key in STAGE_KEYS:                                           # the first batch: same parameters, same streams
+        for r in range(2):
+            np.testing.assert_array_equal(rec['batch_0_' + key][r * B:(r + 1) * B], real[r]['batch_0_0_' + key])
+    for k in range(8):                                               # every later one too: the sampler does not see theta
+        for r in range(2):
+            np.testing.assert_array_equal(rec['batch_%d_o' % k][r * B:(r + 1) * B], real[r]['batch_%d_0_o' % k])
+            np.testing.assert_array_equal(rec['batch_%d_r' % k][r * B:(r + 1) * B], real[r]['batch_%d_0_r' % k])
+    assert np.abs(rec['theta'] - real[0]['theta_0']).max() < 2e-4
+    assert (np.abs(rec['theta'] - real[0]['theta_0']) > 2e-5).mean() < 1e-2
+
+
+def test_one_virtual_rank_is_the_agent_as_it_was():
+    """virtual_ranks = 1 changes nothing: same launches, same bits."""
+    from test_gpu_agent import synth_episodes
+    outs = []
+    for V in (None, 1):
+        agent = make_agent(V, use_graph=True)
+        rng = np.random.RandomState(5)
+        agent.store_episode(synth_episodes(rng, 24, NB, DIMO), np.array([0.3, 0.0, 0.2, 0.1]), 24)
+        agent.train_batches(12)
+        torch.cuda.synchronize()
+        outs.append((agent.theta.cpu().numpy().copy(), agent._losses.cpu().numpy().copy()))
+        assert agent.net_cfg.loss_rows == 0 and agent._rng_desc.rank_rows == 0
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------ piece by piece against the one-rank entry points
+def test_joint_gather_equals_one_gather_per_rank():
+    """curious_sample_rng_t.rank_rows: the joint batch of V ranks is, rank by rank, the batch curious_her_sample draws for
+    that rank alone (its tables, its key, its buffers)."""
+    V = 3
+    agent = make_agent(V)
+    draw = rank_episodes(V, 24)
+    agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 72)
+    agent._train_device_prologue(1)
+    agent._step_ctr.fill_(7)
+    agent._sample_packed()
+    torch.cuda.synchronize()
+    joint = agent._staged.cpu().numpy().copy()
+    from curious_amd import _lib, ops
+    from curious_amd.ddpg import RANK_SEED_STRIDE
+    S = agent.sample_transitions
+    nb1 = NB + 1
+    stride = 4 * nb1 + 1
+    n0 = nb1 + 1
+    for v in range(V):
+        t = agent._tables[v * stride:]
+        r = _lib.SampleRng()
+        r.seed = (agent._rng_desc.seed + v * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+        r.step_ctr = agent._step_ctr.data_ptr()
+        r.prop_prefix, r.buf_alias = t[:n0].data_ptr(), t[n0:n0 + nb1].data_ptr()
+        r.buf_task, r.cur_size = t[n0 + nb1:n0 + 2 * nb1].data_ptr(), t[n0 + 2 * nb1:].data_ptr()
+        r.nbuf = nb1
+        one = torch.zeros([B, agent._layout.batch_stride], device=agent.device)
+        ops.her_sample(agent._pool.storage, agent._pool.buf_stride, agent._layout, S.tasks,
+                       S.params(agent.clip_obs, False), B, one, rng=r)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(joint[v * B:(v + 1) * B], one.cpu().numpy())
+    # and the ranks' rows come from the ranks' own buffers: rank v's pool slots are v * 5 .. v * 5 + 4
+    assert agent._pool.n_buffers == V * 5
+    sizes = [[b.current_size for b in bl[:nb1]] for bl in agent._rank_buffers]
+    assert all(s[0] == 0 and sum(s[1:]) > 0 for s in sizes) and len({tuple(s) for s in sizes}) > 1
+
+
+def test_routed_store_of_several_ranks_equals_one_store_per_rank():
+    """curious_route_store_episodes_ranks: rank by rank what curious_route_store_episodes does for that rank alone -- also
+    once the buffers are full (random slots from the rank's own Philox key, the later episode winning a slot)."""
+    from curious_amd import ops
+    from curious_amd.replay_buffer import as_records
+    V, per, cap, nb1 = 3, 24, 16, NB + 1                             # 16-episode buffers: the second store overflows
+    agent = make_agent(1)
+    L, dev = agent._layout, agent.device
+    tasks = agent.sample_transitions.tasks
+    draw = rank_episodes(V, per)
+    rec = [cap, 51, L.row_stride]
+    joint = torch.zeros([V * nb1] + rec, device=dev)
+    single = [torch.zeros([nb1] + rec, device=dev) for _ in range(V)]
+    stride = 2 * nb1                                                 # per rank: [cur_size nb1 | alias nb1]
+    tab = torch.zeros(V * stride, dtype=torch.int32, device=dev)
+    for v in range(V):
+        tab[v * stride + nb1:(v + 1) * stride] = torch.arange(v * nb1, (v + 1) * nb1, dtype=torch.int32)
+    tab1 = [torch.cat([torch.zeros(nb1, dtype=torch.int32), torch.arange(nb1, dtype=torch.int32)]).to(dev)
+            for _ in range(V)]
+    skip = torch.zeros(1, device=dev)
+    seed, sstride = 4242, 1000003
+    overflowed = False
+    for call in range(1, 4):
+        staging = as_records(draw(), L)
+        act = torch.empty(V * per * NB, dtype=torch.int32, device=dev)
+        ops.episode_activity(staging, L, tasks, V * per, act)
+        src = torch.empty(V * per * NB, dtype=torch.int32, device=dev)
+        dst = torch.empty(V * per * NB, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(V, dtype=torch.int32, device=dev)
+        ops.route_store_episodes(joint, staging, L, act, NB, NB, per, tab, tab[nb1:], cap, seed, call, skip, src, dst,
+                                 cnt, n_ranks=V, tab_stride=stride, seed_stride=sstride)
+        for v in range(V):
+            st1 = staging[v * per:(v + 1) * per].contiguous()
+            a1 = act[v * per * NB:(v + 1) * per * NB].contiguous()
+            s1 = torch.empty(per * NB, dtype=torch.int32, device=dev)
+            d1 = torch.empty(per * NB, dtype=torch.int64, device=dev)
+            c1 = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.route_store_episodes(single[v], st1, L, a1, NB, NB, per, tab1[v], tab1[v][nb1:], cap, seed + v * sstride,
+                                     call, skip, s1, d1, c1)
+            torch.cuda.synchronize()
+            assert int(cnt[v]) == int(c1[0]) > 0
+            np.testing.assert_array_equal(tab[v * stride:v * stride + nb1].cpu().numpy(), tab1[v][:nb1].cpu().numpy())
+            np.testing.assert_array_equal(joint[v * nb1:(v + 1) * nb1].cpu().numpy(), single[v].cpu().numpy(),
+                                          err_msg='call %d rank %d' % (call, v))
+            n1 = int(c1[0])
+            got_src = src[v * per * NB:v * per * NB + n1].cpu().numpy()
+            want_src = s1[:n1].cpu().numpy()
+            np.testing.assert_array_equal(np.where(got_src >= 0, got_src - v * per, -1), want_src)
+            overflowed = overflowed or bool((want_src < 0).any())
+    assert int(tab[1]) == cap and overflowed                         # full buffers, and a contested random slot
+
+
+@pytest.mark.parametrize('resident', [0, 1])
+def test_rollout_of_several_ranks_equals_one_rollout_per_rank(resident):
+    """curious_policy_rollout_ranks: the envs of group k act exactly as a launch of their own with the key seed + k *
+    seed_stride would make them (same noise, same episodes), and a group whose exploit flag is set acts as a launch with
+    noise_eps = random_eps = 0 (rollout.py:183-189) -- streaming kernel and weights-resident kernel."""
+    from curious_amd import ops
+    from curious_amd.ddpg import RANK_SEED_STRIDE
+    from curious_amd.envs import BatchedSyntheticArm, REWARD_EPS
+    agent = make_agent(1)
+    G, V, T = 8, 3, 50
+    n = G * V
+    cfg, theta = agent.net_cfg, agent.theta
+    rng = np.random.RandomState(4)
+    tasks = rng.randint(NB, size=n)
+    goals = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    seed, ctr = 777, 5
+
+    def rollout(env, n_env, sd, noise, reps, groups=None):
+        ws = torch.zeros(ops.workspace_floats(cfg, n_env), device=agent.device)
+        u = torch.empty([n_env, 4], device=agent.device)
+        ops.policy_rollout(cfg, theta, n_env, 200.0, ws, noise, reps, sd, ctr, u, env._cfg, env.layout, env.env_id0,
+                           env.episode, env.tasks, 0, T, env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS,
+                           flags=env.flags, groups=groups)
+        torch.cuda.synchronize()
+        return env.staging.cpu().numpy().copy()
+
+    with ops.option('resident', resident):
+        env = BatchedSyntheticArm('MultiTaskFetchArm4-v5', n, seed=11)
+        env.reset_all(tasks, goals)
+        ex = torch.tensor([0, 1, 0], dtype=torch.int32, device=agent.device)
+        joint = rollout(env, n, seed, 0.2, 0.3, ops.rank_groups(G, RANK_SEED_STRIDE, ex))
+        for k in range(V):
+            e1 = BatchedSyntheticArm('MultiTaskFetchArm4-v5', G, seed=11, env_id0=k * G)
+            e1.reset_all(tasks[k * G:(k + 1) * G], goals[k * G:(k + 1) * G])
+            noise, reps = (0.0, 0.0) if k == 1 else (0.2, 0.3)
+            one = rollout(e1, G, seed + k * RANK_SEED_STRIDE, noise, reps)
+            np.testing.assert_array_equal(joint[k * G:(k + 1) * G], one, err_msg='group %d' % k)
+    assert not np.array_equal(joint[:G, :, env.layout.off['u']:env.layout.off['u'] + 4],
+                              joint[2 * G:, :, env.layout.off['u']:env.layout.off['u'] + 4])
+
+
+# ------------------------------------------------------------------ the training job
+def test_training_job_with_virtual_ranks(tmp_path):
+    """experiment.train --num_cpu 3 on one process = 3 virtual ranks of 30 rollouts each (90 envs, padded to 92 for the
+    one-launch rollout kernels): every rank's buffers fill, the episode count is the reference's (rollout_batch_size x
+    ranks per cycle, rollout.py:343), progress.csv carries the reference's columns, and the agent learns the synthetic
+    arm from gradients summed over the three ranks' minibatches."""
+    import csv
+    from curious_amd.experiment import config, train as tr
+    config.CACHED_ENVS.clear()
+    np.random.seed(0)
+    tr.launch(env='MultiTaskFetchArm4-v5', trial_id=0, n_epochs=100, num_cpu=3, seed=5, policy_save_interval=0,
+              clip_return=1, normalize_obs=False, structure='curious', task_selection='active_competence_progress',
+              goal_selection='random', goal_replay='her', task_replay='replay_task_cp_buffer', save_policies=False,
+              override_params=dict(rng_mode='device', use_graph=True, async_store=True, n_cycles=25, n_batches=40,
+                                   rollout_batch_size=30),
+              save_root=str(tmp_path) + '/')
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'MultiTaskFetchArm4-v5', '0', 'progress.csv'))))
+    assert len(rows) == 101
+    assert int(float(rows[-1]['train/episode'])) == 100 * 25 * 30 * 3    # epochs x cycles x rollouts per rank x ranks
+    got = [float(r['test/success_rate']) for r in rows]
+    # (the 256-env job of test_training_learns_... sits on the one-task plateau of 0.25 for 35 epochs as well)
+    assert max(got) >= 0.75 and got[-1] >= 0.7 and max(got[:30]) < 0.35, got[-5:]
