@@ -1340,7 +1340,9 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
         map.r_hot = hwAll.tiles_per / map.units;
         map.r_her = (n_her + 7) / 8;
         const int r_small = smAll.slots * ((smAll.nprob + 1 + 7) / 8);      // + 1: the loss finalisation
-        return 8 * (map.r_her + map.r_hot + r_small);
+        const int gx_ = 8 * (map.r_her + map.r_hot + r_small);
+        if (B > 256) map.r_her = -map.r_her;                  // several virtual ranks: the gather blocks come last (DwMap)
+        return gx_;
       }
       return n_her + tAll + nsmall + 1;
     };

@@ -667,14 +667,31 @@ __device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, 
     else { R.kind = 2; R.idx = bid - n_hot; }
     return R;
   }
-  const int x = b & 7, r = b >> 3;
-  if (r < r_her) {
+  const int x = b & 7;
+  int r = b >> 3;
+  if (r_her < 0) {
+    // r_her < 0: the -r_her rows of gather blocks come LAST instead of first (batches of several virtual ranks: the
+    // hidden tiles, each a long reduction over V x 256 rows, are then dispatched together at the start of the launch
+    // and walk the rows in step -- the tiles of an XCD share X strips and dY panels through its L2 only while they do)
+    const int rows = (int)gridDim.x >> 3, gr = -r_her;
+    if (r >= rows - gr) {
+      const int i = (r - (rows - gr)) * 8 + x;
+      if (i < n_her) { R.kind = 0; R.idx = i; }
+      return R;
+    }
+    r += gr;                                                 // (the rest of the map as if the gather rows came first)
+  }
+  const int r_her_ = r_her < 0 ? -r_her : r_her;
+  if (r < r_her_) {
     if (r * 8 + x < n_her) { R.kind = 0; R.idx = r * 8 + x; }
-  } else if (r < r_her + r_hot) {
+    return R;
+  }
+  r -= r_her_;
+  if (r < r_hot) {
     const int pi = x / units, u = x - pi * units;
-    if (pi < hot_nprob) { R.kind = 1; R.pi = pi; R.idx = u * r_hot + (r - r_her); }
+    if (pi < hot_nprob) { R.kind = 1; R.pi = pi; R.idx = u * r_hot + r; }
   } else {
-    const int j = r - r_her - r_hot;
+    const int j = r - r_hot;
     const int p = x + 8 * (j / slots);
     R.kind = 2; R.idx = p * slots + j % slots;
   }

@@ -599,16 +599,18 @@ def test_ipc_allreduce_adam_on_one_rank_equals_the_standalone_optimiser():
     for x, s in zip((agent.theta, agent._m, agent._v, agent._workspace), state):
         x.copy_(s)
     flags = torch.zeros(16, dtype=torch.int32, device='cuda')
-    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    words = torch.zeros(3, dtype=torch.int32, device='cuda')         # blocks done | a wait gave up | epoch
+    words[2] = 41                                                    # (tokens are epochs, not Adam steps)
+    stage = torch.zeros_like(agent.theta)                            # where the new slices land before they become theta
     peers = _lib.IpcPeers()
     peers.world, peers.rank = 1, 0
-    peers.grad[0], peers.theta[0], peers.flags[0] = agent.grad.data_ptr(), agent.theta.data_ptr(), flags.data_ptr()
-    ops.allreduce_adam_ipc(peers, agent._m, agent._v, agent.off_pi, agent.P_total - agent.off_pi, agent._alpha_tab,
-                           agent._step_ctr, agent._alpha_base, words[0:1], words[1:2], keep)
+    peers.grad[0], peers.stage[0], peers.flags[0] = agent.grad.data_ptr(), stage.data_ptr(), flags.data_ptr()
+    ops.allreduce_adam_ipc(peers, agent.theta, agent._m, agent._v, agent.off_pi, agent.P_total - agent.off_pi,
+                           agent._alpha_tab, agent._step_ctr, agent._alpha_base, words[2:3], words[0:1], words[1:2], keep)
     torch.cuda.synchronize()
-    assert int(words[1]) == 0 and int(words[0]) == 64
-    tok = int(agent._step_ctr)
-    assert flags[0].item() == tok and flags[8].item() == tok           # ready / landed words carry the update's token
+    assert int(words[1]) == 0 and int(words[0]) == 64 and int(words[2]) == 42
+    assert flags[0].item() == 42 and flags[8].item() == 42             # ready / landed words carry the epoch's token
+    assert torch.equal(stage, agent.theta)
     for name, got, w in zip(('theta', 'm', 'v', 'workspace'), (agent.theta, agent._m, agent._v, agent._workspace), want):
         assert torch.equal(got, w), name
     assert not torch.equal(agent.theta, state[0])

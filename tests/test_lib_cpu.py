@@ -239,9 +239,9 @@ def test_round4_entry_points_host_code_without_gpu():
     f32 = C.c_float
 
     def call(peers, n_Q, n_pi, keep=None, tab_len=4096):
-        return L.curious_allreduce_adam_ipc(C.byref(peers) if peers is not None else None, fake[0], fake[1], n_Q, n_pi,
-                                            fake[2], fake[3], 0, tab_len, f32(0.9), f32(0.1), f32(0.999), f32(0.001),
-                                            f32(1e-8), fake[4], fake[5], 0, keep, None)
+        return L.curious_allreduce_adam_ipc(C.byref(peers) if peers is not None else None, fake[9], fake[0], fake[1], n_Q,
+                                            n_pi, fake[2], fake[3], 0, tab_len, f32(0.9), f32(0.1), f32(0.999),
+                                            f32(0.001), f32(1e-8), fake[4], fake[4], fake[5], 0, keep, None)
     assert call(None, 64, 64) != 0 and b'NULL argument' in L.curious_last_error()
     P.world, P.rank = 9, 0
     assert call(P, 64, 64) != 0 and b'world must be' in L.curious_last_error()
@@ -251,10 +251,10 @@ def test_round4_entry_points_host_code_without_gpu():
     assert call(P, 64, 65) != 0 and b'divide by the world size' in L.curious_last_error()
     assert call(P, 64, 64) != 0 and b'rank 0 is not mapped' in L.curious_last_error()
     for r in range(4):
-        P.grad[r], P.theta[r], P.flags[r] = fake[6].value + 4096 * r, fake[7].value + 4096 * r, fake[8].value + 64 * r
-    P.theta[3] = None
+        P.grad[r], P.stage[r], P.flags[r] = fake[6].value + 4096 * r, fake[7].value + 4096 * r, fake[8].value + 64 * r
+    P.stage[3] = None
     assert call(P, 64, 64) != 0 and b'rank 3 is not mapped' in L.curious_last_error()
-    P.theta[3] = fake[7].value + 4096 * 3
+    P.stage[3] = fake[7].value + 4096 * 3
     T = _lib.Transposed()
     T.n, T.dim = 2, 100                                        # not a multiple of the optimiser's tile
     assert call(P, 64, 64, C.byref(T)) != 0 and b'transposed copies' in L.curious_last_error()
@@ -264,7 +264,7 @@ def test_round4_entry_points_host_code_without_gpu():
     out = C.c_void_p()
     assert L.curious_ipc_alloc(0, C.byref(out)) != 0 and b'bad argument' in L.curious_last_error()
     assert L.curious_ipc_alloc(4096, None) != 0
-    assert L.curious_ipc_alloc(4096, C.byref(out)) != 0 and b'hipMalloc' in L.curious_last_error()
+    assert L.curious_ipc_alloc(4096, C.byref(out)) != 0 and b'hipExtMallocWithFlags' in L.curious_last_error()
     h = C.create_string_buffer(64)
     assert L.curious_ipc_export(None, h) != 0 and L.curious_ipc_import(None, C.byref(out)) != 0
     assert L.curious_ipc_close(None) == 0 and L.curious_ipc_free(None) == 0
