@@ -180,10 +180,14 @@ PROTOTYPES = {
                                                _P, _P, _P, _P, _P]),
     'curious_route_store_episodes_ranks': (C.c_int, [_P, _P, C.POINTER(Layout), _P, _I32, _I32, _I32, _I32, _P, _P, _I64,
                                                      _I64, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
+    'curious_activity_route_store_episodes': (C.c_int, [_P, _P, C.POINTER(Layout), C.POINTER(Tasks), _I32, _P, _I32, _I32,
+                                                        _I32, _P, _P, _I64, _I64, _U64, _U64, _U64, _P, _P, _P, _P, _P]),
     'curious_store_slots_host': (C.c_int, [_U64, _U64, _I32, _I64, _I32, _P, _P]),
     'curious_counter_add': (C.c_int, [_P, _I64, _P]),
     'curious_env_reset': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,
                                     _P, _P, _P]),
+    'curious_env_reset_count': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _P, _P, _P, _P,
+                                          _P, _P, _P, _I64, _P]),
     'curious_env_step': (C.c_int, [C.POINTER(EnvCfg), C.POINTER(Layout), _I32, _P, _P, _P, _I32, _I32, _I32, _P,
                                    _P, _P, _P, _P, _I32, _I32, _D, _P, _P]),
 }

@@ -10,10 +10,12 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
                                  int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
                                  const float* __restrict__ goals_raw, int32_t n, float* __restrict__ o,
                                  float* __restrict__ ag, float* __restrict__ g, float* __restrict__ td,
-                                 float* __restrict__ staging, float* __restrict__ flags) {
+                                 float* __restrict__ staging, float* __restrict__ flags, int64_t* __restrict__ counter,
+                                 int64_t delta) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (flags && e == 0) flags[n] = 0.0f;                     // the NaN word of the coming rollout (env_body.h)
+  if (counter && e == 0) *counter += delta;                 // (curious_env_reset_count)
   const int AG = 3 * E.ntasks;
   float* oe = o + (int64_t)e * E.dimo;
   float* row0 = staging + (int64_t)e * (L.T + 1) * L.row_stride;
@@ -47,6 +49,14 @@ extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layou
                                  int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
                                  float* o, float* ag, float* g, float* td, float* staging, float* flags,
                                  curious_stream_t stream) {
+  return curious_env_reset_count(E, L, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging, flags, nullptr, 0,
+                                 stream);
+}
+
+extern "C" int curious_env_reset_count(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                                       int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                                       float* o, float* ag, float* g, float* td, float* staging, float* flags,
+                                       int64_t* counter, int64_t delta, curious_stream_t stream) {
   CURIOUS_CHECK(E && L && episode && tasks && goals_raw && o && ag && g && td && staging,
                 "curious_env_reset: NULL argument");
   CURIOUS_CHECK(E->dimo <= 128, "curious_env_reset: the synthetic env handles observations of at most 128 floats");
@@ -55,7 +65,7 @@ extern "C" int curious_env_reset(const curious_env_cfg_t* E, const curious_layou
                 "curious_env_reset: layout does not match the synthetic env");
   if (n <= 0) return 0;
   { ProfScope ps__(CK_ENV_RESET, as_stream(stream)); hipLaunchKernelGGL(env_reset_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), *E, *L, env_id0, episode,
-                     tasks, goals_raw, n, o, ag, g, td, staging, flags); }
+                     tasks, goals_raw, n, o, ag, g, td, staging, flags, counter, delta); }
   CURIOUS_LAUNCH_CHECK("env_reset_kernel");
   return 0;
 }

@@ -107,9 +107,17 @@ struct RCtx {
   bool pub;   // one-launch update: what the tiles of the same launch read is stored THROUGH the L2 (agent-coherent stores)
 };
 // a result other workgroups read: the weight-gradient launch that follows, or (pub) the tiles of this very launch
+// (lab, -DROWS_NT_STORES: written through instead of left dirty in the L2 for the release at the end of the kernel --
+//  tools/floor2_lab.hip prices that release at 0.15 us per MB; profiles/r05_floor2_lab.txt)
 __device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
   if (x.pub) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+  else {
+#ifdef ROWS_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+  }
 }
 
 // ---- weight fragments of one 16-deep k-chunk

@@ -72,7 +72,7 @@ __host__ __device__ inline int64_t store_random_slot(uint64_t seed, uint64_t cal
 #define ROUTE_MAX_EPISODES 2048
 #define ROUTE_HASH 4096u                                     // >= 2 x ROUTE_MAX_EPISODES, a power of two
 __device__ inline unsigned route_hash(int slot) { return ((unsigned)slot * 2654435761u >> 16) & (ROUTE_HASH - 1u); }
-__global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __restrict__ active, int32_t ntasks,
+__global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* active, int32_t ntasks,
                                                             int32_t n_route, int32_t n_episodes,
                                                             int32_t* __restrict__ cur_size,
                                                             const int32_t* __restrict__ buf_alias, int64_t capacity,
@@ -81,9 +81,24 @@ __global__ __launch_bounds__(256) void route_episodes_kernel(const int32_t* __re
                                                             int32_t* __restrict__ pair_src,
                                                             int64_t* __restrict__ pair_dst,
                                                             int32_t* __restrict__ n_pairs, int64_t tab_stride,
-                                                            uint64_t seed_stride) {
+                                                            uint64_t seed_stride, const float* __restrict__ staging,
+                                                            curious_layout_t L, curious_tasks_t TK, int32_t off_change,
+                                                            int32_t* active_out) {
   const int vr = blockIdx.x;
   const int ep0 = vr * n_episodes;                           // this rank's first record in the staging block
+  if (active_out) {
+    // the task-activity test of ddpg.py:179-184 (episode_activity_kernel) done here: one launch less per cycle.  The flags
+    // are written out as well -- the host mirrors the buffer sizes from them a cycle later (DDPG.settle)
+    int32_t* mine = active_out + (int64_t)ep0 * ntasks;
+    for (int i = threadIdx.x; i < n_episodes * ntasks; i += 256) {
+      const int b = i / ntasks, j = i - b * ntasks;
+      const float* row = staging + ((int64_t)(ep0 + b) * (L.T + 1) + (L.T - 1)) * L.row_stride + off_change;
+      int any = 0;
+      for (int k = 0; k < TK.len[j]; ++k) any |= (row[TK.ag_id[j][k]] != 0.0f);
+      mine[i] = any;
+    }
+    __syncthreads();
+  }
   active += (int64_t)ep0 * ntasks;
   cur_size += (int64_t)vr * tab_stride;
   buf_alias += (int64_t)vr * tab_stride;
@@ -181,7 +196,8 @@ static int route_store_ranks(float* storage, const float* staging, const curious
                              int32_t ntasks, int32_t n_route, int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
                              const int32_t* buf_alias, int64_t tab_stride, int64_t capacity, uint64_t seed,
                              uint64_t seed_stride, uint64_t call, const float* skip, int32_t* pair_src,
-                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream);
+                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream,
+                             const curious_tasks_t* tasks = nullptr, int32_t off_change = 0);
 
 extern "C" int curious_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
                                             const int32_t* active, int32_t ntasks, int32_t n_route,
@@ -205,11 +221,26 @@ extern "C" int curious_route_store_episodes_ranks(float* storage, const float* s
                            tab_stride, capacity, seed, seed_stride, call, skip, pair_src, pair_dst, n_pairs, stream);
 }
 
+extern "C" int curious_activity_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
+                                                     const curious_tasks_t* tasks, int32_t off_change, int32_t* active,
+                                                     int32_t n_route, int32_t n_episodes, int32_t n_ranks,
+                                                     int32_t* cur_size, const int32_t* buf_alias, int64_t tab_stride,
+                                                     int64_t capacity, uint64_t seed, uint64_t seed_stride, uint64_t call,
+                                                     const float* skip, int32_t* pair_src, int64_t* pair_dst,
+                                                     int32_t* n_pairs, curious_stream_t stream) {
+  CURIOUS_CHECK(tasks && active, "curious_activity_route_store_episodes: NULL argument");
+  CURIOUS_CHECK(n_ranks >= 1 && n_ranks <= 4096 && tab_stride >= 0, "curious_activity_route_store_episodes: bad rank arguments");
+  return route_store_ranks(storage, staging, L, active, tasks->ntasks, n_route, n_episodes, n_ranks, cur_size, buf_alias,
+                           tab_stride, capacity, seed, seed_stride, call, skip, pair_src, pair_dst, n_pairs, stream, tasks,
+                           off_change);
+}
+
 static int route_store_ranks(float* storage, const float* staging, const curious_layout_t* L, const int32_t* active,
                              int32_t ntasks, int32_t n_route, int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
                              const int32_t* buf_alias, int64_t tab_stride, int64_t capacity, uint64_t seed,
                              uint64_t seed_stride, uint64_t call, const float* skip, int32_t* pair_src,
-                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream) {
+                             int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream, const curious_tasks_t* tasks,
+                             int32_t off_change) {
   CURIOUS_CHECK(storage && staging && L && active && cur_size && buf_alias && pair_src && pair_dst && n_pairs,
                 "curious_route_store_episodes: NULL argument");
   CURIOUS_CHECK(ntasks >= 1 && n_route >= 0 && n_route <= ntasks && capacity > 0 && capacity < (1ll << 31),
@@ -219,9 +250,12 @@ static int route_store_ranks(float* storage, const float* staging, const curious
   if (n_episodes <= 0 || n_route == 0) return 0;
   hipStream_t st = as_stream(stream);
   { ProfScope ps__(CK_ROUTE, st);
+    curious_tasks_t tk;
+    memset(&tk, 0, sizeof(tk));
+    if (tasks) tk = *tasks;
     hipLaunchKernelGGL(route_episodes_kernel, dim3(n_ranks), dim3(256), 0, st, active, ntasks, n_route, n_episodes,
                        cur_size, buf_alias, capacity, seed, call, skip, pair_src, pair_dst, n_pairs, tab_stride,
-                       seed_stride); }
+                       seed_stride, staging, *L, tk, off_change, tasks ? const_cast<int32_t*>(active) : (int32_t*)nullptr); }
   CURIOUS_LAUNCH_CHECK("route_episodes_kernel");
   int64_t rec = (int64_t)(L->T + 1) * L->row_stride;
   int vec_ok = (rec % 4 == 0) && (((uintptr_t)storage | (uintptr_t)staging) % 16 == 0);

@@ -318,10 +318,44 @@ class DDPG(object):
         return io
 
     def can_act_and_step(self, env, compute_Q):
-        """The fused acting step applies to the GPU-resident synthetic env in throughput mode."""
-        return (self.rng_mode == 'device' and not compute_Q and self.modular
+        """The fused acting step applies to the GPU-resident synthetic env in throughput mode.  compute_Q (the
+        evaluator, train.py:308-319): the fused kernels record no Q -- the rollout's Q values are computed afterwards
+        from its recorded rows (rollout_q_sum), which needs the whole rollout as one launch (act_rollout)."""
+        return (self.rng_mode == 'device' and self.modular
                 and self.dimu == 4 and hasattr(env, 'step_all')
                 and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
+
+    Q_ROWS = 4096                 # rows per launch of rollout_q_sum (bounds its workspace: ~110 MB)
+
+    def rollout_q_sum(self, env, T, use_target_net=False):
+        """sum over the T steps of the batch-mean Q of the rollout that was just enqueued for `env` (a GPU scalar) -- what
+        RolloutWorker accumulates step by step from get_actions(compute_Q=True) (rollout.py:187-189,226-232; ddpg.py:140-146:
+        Q_pi_tf = Q(o_t, g, pi(o_t, g))), computed AFTER the fused rollout from its recorded rows: record row t of an episode
+        holds the observation, goal and task descriptor the policy saw at step t, so one actor + critic forward over the
+        [n x (T + 1)] rows of the staging block (a few launches of Q_ROWS rows) yields the same Q values bit for bit;
+        their mean is taken over [n_used, T] in one reduction instead of T batch means -- a different order of summation:
+        equal within float32 rounding (~1e-6 relative), not bit for bit."""
+        n, lay = env.n, env.layout
+        rows = env.staging.view(n * (T + 1), lay.row_stride)
+        theta = self.theta_target if use_target_net else self.theta
+        if getattr(self, '_q_rows', None) is None or self._q_rows[0].numel() != rows.shape[0]:
+            chunk = min(self.Q_ROWS, rows.shape[0])
+            self._q_rows = (torch.empty(rows.shape[0], dtype=torch.float32, device=self.device),
+                            torch.empty([chunk, self.dimu], dtype=torch.float32, device=self.device),
+                            torch.zeros(ops.workspace_floats(self.net_cfg, chunk), dtype=torch.float32, device=self.device))
+        q, u, ws = self._q_rows
+        o_, g_, ag_, td_ = lay.off['o'], lay.off['g'], lay.off['ag'], lay.off['task_descr']
+        for r0 in range(0, rows.shape[0], u.shape[0]):
+            blk = rows[r0:r0 + u.shape[0]]
+            m = blk.shape[0]
+            ops.policy_forward(self.net_cfg, theta, blk[:, o_:o_ + self.dimo], blk[:, g_:g_ + self.dimg],
+                               blk[:, td_:td_ + self.dimtd] if self.dimtd > 0 else None, m, self.clip_obs, ws, u[:m],
+                               q[r0:r0 + m].view(m, 1), ag=blk[:, ag_:ag_ + self.dimag],
+                               relative_goals=self.relative_goals,
+                               o_stats=self.o_stats.state if self.normalize_obs else None,
+                               g_stats=self.g_stats.state if self.normalize_obs else None)
+        n_used = getattr(env, 'n_used', n)                           # (idle padding envs and the rows t = T do not count)
+        return q.view(n, T + 1)[:n_used, :T].mean() * T
 
     def act_and_step(self, env, t, noise_eps=0., random_eps=0., use_target_net=False):
         """policy.get_actions(...) + env.step(...) for every env of a BatchedSyntheticArm in one launch
@@ -391,23 +425,32 @@ class DDPG(object):
             self._exploit_dev.copy_(pin, non_blocking=True)
             groups = ops.rank_groups(group, RANK_SEED_STRIDE, self._exploit_dev)
 
+        reset_here = bool(getattr(env, '_reset_pending', False))     # the worker only uploaded the draws (reset_all)
+        env._reset_pending = False
+
         def steps():
-            # T x policy_act_env_step (noise counters 1 .. T on top of the base): one launch on the row-local route
-            ops.policy_rollout(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps, seed, 1,
+            # T x policy_act_env_step (noise counters 1 .. T on top of the base): one launch on the row-local route.
+            # The env reset that heads the rollout also advances the noise base (one launch less per cycle): the rollout
+            # then starts from base + 1 - T
+            if reset_here:
+                env.launch_reset(counter=self._noise_base, delta=T)
+            ops.policy_rollout(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps, seed,
+                               (1 - T) if reset_here else 1,
                                u_out, env._cfg, env.layout, env.env_id0, env.episode, env.tasks, 0, T, env.o, env.ag,
                                env.g, env.td, env.staging, REWARD_EPS, counter_base=self._noise_base,
                                flags=getattr(env, 'flags', None),
                                o_stats=self.o_stats.state if self.normalize_obs else None,
                                g_stats=self.g_stats.state if self.normalize_obs else None,
                                relative_goals=self.relative_goals, groups=groups)
-            ops.counter_add(self._noise_base, T)
+            if not reset_here:
+                ops.counter_add(self._noise_base, T)
 
         self._noise_counter += T
         self._noise_base_val = self._noise_counter                   # steps() ends with the device-side += T
         if not self.use_graph:
             steps()
             return
-        key = (id(env), T, float(noise_eps), float(random_eps), bool(use_target_net))
+        key = (id(env), T, float(noise_eps), float(random_eps), bool(use_target_net), reset_here)
         g = self._roll_graphs.get(key)
         if g is None:
             # capture only records (the side-stream warm-up torch recommends is skipped on purpose: it would step the
@@ -676,7 +719,11 @@ class DDPG(object):
                                  min(self.nb_tasks, 5), batch_size // self.V, self._tables[n0 + 2 * nb1:],
                                  self._tables[n0:], self._pool.capacity, self._store_seed(),
                                  self._next_store_call(), skip, src_d, dst_d, self._route_count, n_ranks=self.V,
-                                 tab_stride=4 * nb1 + 1, seed_stride=RANK_SEED_STRIDE)
+                                 tab_stride=4 * nb1 + 1, seed_stride=RANK_SEED_STRIDE,
+                                 tasks=self.sample_transitions.tasks if getattr(self, '_activity_in_route', False) else None)
+        if getattr(self, '_activity_in_route', False):               # the flags the routing launch evaluated: to the host
+            self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
+            self._activity_in_route = False
         if skip_host is None:
             self._nan_pin.copy_(skip, non_blocking=True)
             skip_host = self._nan_pin
@@ -709,10 +756,11 @@ class DDPG(object):
                         buf.n_transitions_stored += int(counts[j]) * self.T
         self._tables_sizes = self._sizes_key()
 
-    def prefetch_activity(self, episode_batch):
+    def prefetch_activity(self, episode_batch, in_route=False):
         """Called by the batched RolloutWorker right after it enqueued a rollout: the task-activity test of the coming
         store_episode (ddpg.py:179-184) and its D2H copy are enqueued now, so that they arrive with the rollout flags
-        the worker waits for anyway -- one host sync per cycle instead of two."""
+        the worker waits for anyway -- one host sync per cycle instead of two.  in_route: the store will be routed on the
+        device (expect_async_store follows): its routing launch evaluates the flags itself, only the buffers are set up."""
         if not (self.structure in ('curious', 'task_experts') and self._multi_buffer()):
             return
         layout = self._layout
@@ -726,8 +774,10 @@ class DDPG(object):
                                 torch.empty(na, dtype=torch.int64).pin_memory(),
                                 torch.empty(na, dtype=torch.int32, device=self.device),
                                 torch.empty(na, dtype=torch.int64, device=self.device))
-        ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, self._route_bufs[0][:na])
-        self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
+        self._activity_in_route = bool(in_route)
+        if not in_route:
+            ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, self._route_bufs[0][:na])
+            self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
         self._activity_prefetched = (staging.data_ptr(), batch_size)
 
     def _update_stats(self, staging, batch_size, skip=None):

@@ -164,8 +164,9 @@ class BatchedSyntheticArm(ArmSpec):
         self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
         self.episode.zero_()
 
-    def reset_all(self, tasks, goals_raw):
-        """tasks[n] int, goals_raw[n,3] in [-1,1] (rollout.py:120-143 for every env at once)."""
+    def reset_all(self, tasks, goals_raw, launch=True):
+        """tasks[n] int, goals_raw[n,3] in [-1,1] (rollout.py:120-143 for every env at once).  launch=False: only the
+        upload of the draws; the reset launch itself heads the captured rollout (launch_reset, DDPG.act_rollout)."""
         self.tasks_host[:self.n_used] = tasks                        # (idle padding envs: task 0, goal 0)
         self.goals_host[:self.n_used] = goals_raw
         n = self.n
@@ -180,9 +181,13 @@ class BatchedSyntheticArm(ArmSpec):
         if self._pin_events[k] is None:
             self._pin_events[k] = torch.cuda.Event()
         self._pin_events[k].record()
+        if launch:
+            self.launch_reset()
+
+    def launch_reset(self, counter=None, delta=0):
         ops.env_reset(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, self._goals_dev, self.n,
                       self.o, self.ag, self.g, self.td, self.staging,      # also advances self.episode on the device
-                      flags=self.flags)                                    # and clears the NaN word of the coming rollout
+                      flags=self.flags, counter=counter, delta=delta)      # and clears the NaN word of the coming rollout
 
     def step_all(self, u, t):
         ops.env_step(self._cfg, self.layout, self.env_id0, self.episode, self.tasks, u, t, self.n, self.o, self.ag,

@@ -61,10 +61,20 @@ def store_episodes(storage, staging, layout, pair_src, pair_dst):
 
 
 def route_store_episodes(storage, staging, layout, active, ntasks, n_route, n_episodes, cur_size, buf_alias, capacity,
-                         seed, call, skip, pair_src, pair_dst, n_pairs, n_ranks=1, tab_stride=0, seed_stride=0):
+                         seed, call, skip, pair_src, pair_dst, n_pairs, n_ranks=1, tab_stride=0, seed_stride=0,
+                         tasks=None):
     """Device-side routing + copy of a batch of episodes (curious_route_store_episodes).  n_ranks > 1: n_episodes per
-    virtual rank, every rank into its own buffers (curious_route_store_episodes_ranks)."""
+    virtual rank, every rank into its own buffers (curious_route_store_episodes_ranks).  tasks: the routing launch
+    evaluates the activity flags itself and writes them to `active` (curious_activity_route_store_episodes)."""
     L = layout.c_layout()
+    if tasks is not None:
+        check(lib().curious_activity_route_store_episodes(
+            ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L), C.byref(tasks),
+            int(layout.off['change']), ptr(active), int(n_route), int(n_episodes), int(n_ranks), ptr(cur_size),
+            ptr(buf_alias), int(tab_stride), int(capacity), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            int(seed_stride) & 0xFFFFFFFFFFFFFFFF, int(call), ptr(skip), ptr(pair_src), ptr(pair_dst), ptr(n_pairs),
+            current_stream()), 'curious_activity_route_store_episodes')
+        return
     if n_ranks > 1:
         check(lib().curious_route_store_episodes_ranks(
             ptr(_dev(storage, 'storage')), ptr(_dev(staging, 'staging')), C.byref(L), ptr(active), int(ntasks),
@@ -377,11 +387,13 @@ def make_env_cfg(ntasks, dimo, T, seed):
     return e
 
 
-def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging, flags=None):
+def env_reset(ecfg, layout, env_id0, episode, tasks, goals_raw, n, o, ag, g, td, staging, flags=None, counter=None,
+              delta=0):
+    """counter / delta: *counter += delta in the same launch (curious_env_reset_count)."""
     L = layout.c_layout()
-    check(lib().curious_env_reset(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks),
-                                  ptr(goals_raw), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging), ptr(flags),
-                                  current_stream()), 'curious_env_reset')
+    check(lib().curious_env_reset_count(C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks),
+                                        ptr(goals_raw), int(n), ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging),
+                                        ptr(flags), ptr(counter), int(delta), current_stream()), 'curious_env_reset')
 
 
 def counter_add(p, delta):
@@ -423,7 +435,8 @@ def policy_rollout(cfg, theta, n, clip_obs, workspace, noise_scale, random_eps, 
     on the row-local route.  groups: rank_groups(...) -- the envs of several virtual ranks in one launch."""
     L = layout.c_layout()
     args = (C.byref(cfg), ptr(_dev(theta, 'theta')), int(n), float(clip_obs), ptr(workspace), float(noise_scale),
-            float(random_eps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(counter_base), ptr(u_out),
+            float(random_eps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter) & 0xFFFFFFFFFFFFFFFF, ptr(counter_base),
+            ptr(u_out),
             int(u_out.stride(0)), C.byref(ecfg), C.byref(L), int(env_id0), ptr(episode), ptr(tasks), int(t0), int(nsteps),
             ptr(o), ptr(ag), ptr(g), ptr(td), ptr(staging), int(layout.off['change']),
             int(layout.off['info_is_success']), float(reward_eps), ptr(flags))

@@ -369,13 +369,16 @@ class RolloutWorker:
             goals = np.stack([2.0 * self.goal_selectors[int(ta)].sample_goal() for ta in tasks]).astype(np.float32)
         else:
             goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
-        env.reset_all(tasks, goals)
+        fused = not experts and hasattr(self.policy, 'can_act_and_step') and \
+            self.policy.can_act_and_step(env, self.compute_Q)
+        # (a rollout that is ONE launch: its reset launch heads the captured rollout, where it also advances the noise base)
+        one_launch = fused and hasattr(self.policy, 'act_rollout')
+        env.reset_all(tasks, goals, launch=not one_launch)
+        env._reset_pending = one_launch
         self.count += B
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
         if experts:
             q_sum = self._expert_steps(env, tasks, q_sum)
-        fused = not experts and hasattr(self.policy, 'can_act_and_step') and \
-            self.policy.can_act_and_step(env, self.compute_Q)
         if fused and hasattr(self.policy, 'act_rollout') and self.V > 1:
             # the noise is switched off rank by rank inside the launch (a rank that exploits: rollout.py:183-189)
             self.policy.act_rollout(env, self.T, noise_eps=0. if self.eval else self.noise_eps,
@@ -387,6 +390,9 @@ class RolloutWorker:
                                     use_target_net=self.use_target_net)
         elif self.V > 1 and not self.eval:
             raise NotImplementedError('virtual ranks: training rollouts need the fused rollout (DDPG.act_rollout)')
+        if fused and hasattr(self.policy, 'act_rollout') and self.compute_Q:
+            # the fused rollout records no Q: one actor + critic forward over its recorded rows (DDPG.rollout_q_sum)
+            q_sum = self.policy.rollout_q_sum(env, self.T, use_target_net=self.use_target_net)
         noise_eps = self.noise_eps if not self.exploit else 0.
         random_eps = self.random_eps if not self.exploit else 0.
         graphed = not fused and not experts and hasattr(self.policy, 'can_eval_rollout') and \
@@ -413,9 +419,12 @@ class RolloutWorker:
                 u = out
             env.step_all(u, t)
         # success flags and the NaN check of rollout.py:268-271 in ONE D2H sync per rollout
+        async_ok = not force_sync and self._async_ok(env, fused and hasattr(self.policy, 'act_rollout'))
         if not self.eval and hasattr(self.policy, 'prefetch_activity'):
-            self.policy.prefetch_activity(env.episode_views())     # arrives with the flags: one host sync per cycle
-        if not force_sync and self._async_ok(env, fused and hasattr(self.policy, 'act_rollout')):
+            # arrives with the flags: one host sync per cycle.  (A device-routed store evaluates the flags in its routing
+            # launch: nothing to enqueue here)
+            self.policy.prefetch_activity(env.episode_views(), in_route=async_ok)
+        if async_ok:
             # return without waiting: the policy routes the episodes on the device, the flags are read in settle()
             env.request_flags()
             task_list = tasks.tolist()

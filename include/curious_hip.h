@@ -196,6 +196,15 @@ int curious_route_store_episodes_ranks(float* storage, const float* staging, con
                                        int64_t capacity, uint64_t seed, uint64_t seed_stride, uint64_t call,
                                        const float* skip, int32_t* pair_src, int64_t* pair_dst, int32_t* n_pairs,
                                        curious_stream_t stream);
+/* curious_episode_activity + curious_route_store_episodes_ranks in two launches instead of three: the routing launch
+ * first evaluates the activity flags itself (ddpg.py:179-184; `change` in the extra block at off_change) and writes them
+ * to `active` ([n_ranks * n_episodes * tasks->ntasks], an OUTPUT here: the host mirrors the buffer sizes from it later). */
+int curious_activity_route_store_episodes(float* storage, const float* staging, const curious_layout_t* L,
+                                          const curious_tasks_t* tasks, int32_t off_change, int32_t* active,
+                                          int32_t n_route, int32_t n_episodes, int32_t n_ranks, int32_t* cur_size,
+                                          const int32_t* buf_alias, int64_t tab_stride, int64_t capacity, uint64_t seed,
+                                          uint64_t seed_stride, uint64_t call, const float* skip, int32_t* pair_src,
+                                          int64_t* pair_dst, int32_t* n_pairs, curious_stream_t stream);
 /* Host-side twin of the random slots above (no GPU involved): out[i] = slot of episode episodes[i] routed to `task`. */
 int curious_store_slots_host(uint64_t seed, uint64_t call, int32_t task, int64_t size, int32_t n,
                              const int32_t* episodes, int64_t* out);
@@ -509,6 +518,14 @@ int curious_env_reset(const curious_env_cfg_t* E, const curious_layout_t* L, int
                       int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
                       float* o, float* ag, float* g, float* td, float* staging, float* flags /* may be NULL */,
                       curious_stream_t stream);
+
+/* curious_env_reset + curious_counter_add(counter, delta) in the one launch (counter may be NULL): the reset that heads
+ * a captured rollout also advances the device-resident base of the policy's noise counter -- the rollout that follows
+ * passes `counter = 1 - delta` so that it draws from base_before + 1 ... as if the add came behind it. */
+int curious_env_reset_count(const curious_env_cfg_t* E, const curious_layout_t* L, int32_t env_id0,
+                            int32_t* episode, const int32_t* tasks, const float* goals_raw, int32_t n,
+                            float* o, float* ag, float* g, float* td, float* staging, float* flags /* may be NULL */,
+                            int64_t* counter, int64_t delta, curious_stream_t stream);
 
 /* One step of n envs with actions u[n][dimu]: updates o/ag in place, writes u, g, td, change, is_success
  * into staging row t and o, ag into row t+1 (the episode record of rollout.py:273-303).

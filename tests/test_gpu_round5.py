@@ -378,3 +378,138 @@ def test_training_job_with_virtual_ranks(tmp_path):
     got = [float(r['test/success_rate']) for r in rows]
     # (the 256-env job of test_training_learns_... sits on the one-task plateau of 0.25 for 35 epochs as well)
     assert max(got) >= 0.75 and got[-1] >= 0.7 and max(got[:30]) < 0.35, got[-5:]
+
+
+# ------------------------------------------------------------------ the evaluator on the fused rollout
+@pytest.mark.parametrize('B,normalize_obs,relative', [(16, False, False), (16, True, False), (6, False, False),
+                                                       (16, False, True)])
+def test_evaluator_on_the_fused_rollout_equals_the_launch_per_step_evaluator(B, normalize_obs, relative):
+    """train.py:156-161,308-319 / rollout.py:187-189,226-232: an evaluation rollout as ONE launch (curious_policy_rollout,
+    noise off) + one actor / critic forward over its recorded rows for mean_Q (DDPG.rollout_q_sum) against the evaluator of
+    round 4 (policy_forward with Q + clip + env step per step, 150 launches): the episodes, the success flags and every Q
+    value are the same bits; mean_Q is summed in another order (one mean over [B, T] instead of T batch means): 1e-6."""
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from test_gpu_agent import T, build_pair
+    nb, dimo = 4, 40
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    outs = []
+    for fused in (True, False):
+        agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=True, seed=4, normalize_obs=normalize_obs,
+                              relative_goals=relative)
+        if normalize_obs:                                            # statistics that matter
+            agent.o_stats.state[2 * dimo + 1:3 * dimo + 1] = 0.05
+            agent.o_stats.state[3 * dimo + 1:] = 0.7
+        if not fused:
+            agent.can_act_and_step = lambda env, compute_Q: False    # the evaluator of round 4: DDPG.eval_rollout
+        ev = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                           exploit=True, use_target_net=False, compute_Q=True, structure='curious',
+                           task_selection='active_competence_progress', queue_length=6, eval=True)
+        ev.seed(21)
+        np.random.seed(17)
+        ev.generate_eval_rollouts(4)
+        ev.generate_rollouts()
+        qrows = None
+        if fused:
+            qrows = agent._q_rows[0].view(ev.benv.n, T + 1)[:, :T].cpu().numpy().copy()
+        outs.append(dict(succ=list(ev.success_history), Q=list(ev.Q_history), C=np.array(ev.get_C()),
+                         staging=ev.benv.staging.clone(), qrows=qrows, agent=agent, env=ev.benv))
+    a, b = outs
+    assert torch.equal(a['staging'], b['staging'])
+    assert a['succ'] == b['succ'] and len(a['Q']) == 5
+    np.testing.assert_array_equal(a['C'], b['C'])
+    np.testing.assert_allclose(a['Q'], b['Q'], rtol=1e-6, atol=0)
+    assert np.isfinite(a['Q']).all() and abs(a['Q'][0]) > 1e-3
+    # every single Q value: the launch-per-step path of the last rollout, once more, step by step
+    agent, env = b['agent'], b['env']
+    from curious_amd import ops
+    st = a['staging']
+    lay = env.layout
+    u = torch.empty([env.n, 4], device=agent.device)
+    q = torch.empty([env.n, 1], device=agent.device)
+    ws = torch.zeros(ops.workspace_floats(agent.net_cfg, env.n), device=agent.device)
+    for t in (0, 7, T - 1):
+        row = st[:, t]
+        ops.policy_forward(agent.net_cfg, agent.theta, row[:, lay.off['o']:lay.off['o'] + dimo].contiguous(),
+                           row[:, lay.off['g']:lay.off['g'] + 12].contiguous(),
+                           row[:, lay.off['task_descr']:lay.off['task_descr'] + nb].contiguous(), env.n, agent.clip_obs, ws,
+                           u, q, ag=row[:, lay.off['ag']:lay.off['ag'] + 12].contiguous(), relative_goals=relative,
+                           o_stats=agent.o_stats.state if normalize_obs else None,
+                           g_stats=agent.g_stats.state if normalize_obs else None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(a['qrows'][:, t], q.cpu().numpy().reshape(-1))
+
+
+def test_reset_that_heads_a_captured_rollout_also_advances_the_noise_base():
+    """curious_env_reset_count: the training rollout as [reset + counter add, rollout] (2 launches) draws the numbers of
+    [reset, rollout, counter add] (3 launches) -- episodes, noise counters, graphs and eager launches."""
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from test_gpu_agent import T, build_pair
+    nb, dimo, B = 4, 40, 32
+    dims = dict(o=dimo, u=4, g=12, ag=12, task_descr=nb, info_is_success=1)
+    outs = []
+    for graph in (True, False):
+        for fold in (True, False):
+            agent, _ = build_pair(nb, dimo, rng_mode='device', use_graph=graph, seed=4)
+            w = RolloutWorker(EnvFactory('MultiTaskFetchArm4-v5'), agent, dims, logger, T=T, rollout_batch_size=B,
+                              noise_eps=0.2, random_eps=0.3, structure='curious', task_selection='random', queue_length=6)
+            w.seed(3)
+            if not fold:                                             # the three launches of round 4
+                reset_all, act_rollout = w.benv.reset_all, agent.act_rollout
+                w.benv.reset_all = lambda tasks, goals, launch=True: reset_all(tasks, goals, launch=True)
+
+                def act(env, *a, _act=act_rollout, **k):
+                    env._reset_pending = False
+                    return _act(env, *a, **k)
+                agent.act_rollout = act
+            np.random.seed(9)
+            recs = []
+            for _ in range(3):
+                w.generate_rollouts()
+                torch.cuda.synchronize()
+                recs.append(w.benv.staging.clone())
+            outs.append((recs, int(agent._noise_base), agent._noise_counter))
+    for recs, base, ctr in outs[1:]:
+        assert base == outs[0][1] == 3 * T and ctr == outs[0][2]
+        for x, y in zip(recs, outs[0][0]):
+            assert torch.equal(x, y)
+    assert not torch.equal(outs[0][0][0], outs[0][0][1])
+
+
+def test_activity_flags_evaluated_by_the_routing_launch():
+    """curious_activity_route_store_episodes == curious_episode_activity + curious_route_store_episodes_ranks: flags,
+    pair lists, tables and storage."""
+    from curious_amd import ops
+    from curious_amd.replay_buffer import as_records
+    V, per, cap, nb1 = 2, 24, 64, NB + 1
+    agent = make_agent(1)
+    L, dev = agent._layout, agent.device
+    tasks = agent.sample_transitions.tasks
+    staging = as_records(rank_episodes(V, per)(), L)
+    res = []
+    for fused in (False, True):
+        store = torch.zeros([V * nb1, cap, 51, L.row_stride], device=dev)
+        tab = torch.zeros(V * 2 * nb1, dtype=torch.int32, device=dev)
+        for v in range(V):
+            tab[v * 2 * nb1 + nb1:(v + 1) * 2 * nb1] = torch.arange(v * nb1, (v + 1) * nb1, dtype=torch.int32)
+        act = torch.full((V * per * NB,), -7, dtype=torch.int32, device=dev)
+        src = torch.zeros(V * per * NB, dtype=torch.int32, device=dev)
+        dst = torch.zeros(V * per * NB, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(V, dtype=torch.int32, device=dev)
+        if not fused:
+            ops.episode_activity(staging, L, tasks, V * per, act)
+        ops.route_store_episodes(store, staging, L, act, NB, NB, per, tab, tab[nb1:], cap, 99, 1,
+                                 torch.zeros(1, device=dev), src, dst, cnt, n_ranks=V, tab_stride=2 * nb1,
+                                 seed_stride=1000003, tasks=tasks if fused else None)
+        torch.cuda.synchronize()
+        res.append([x.cpu().numpy() for x in (act, tab, cnt, store)] + [src, dst])
+    for x, y in zip(res[0][:4], res[1][:4]):
+        np.testing.assert_array_equal(x, y)
+    assert set(np.unique(res[0][0])) <= {0, 1} and res[0][2].min() > 0
+    for v in range(V):
+        n = int(res[0][2][v])
+        for k in (4, 5):
+            assert torch.equal(res[0][k][v * per * NB:v * per * NB + n], res[1][k][v * per * NB:v * per * NB + n])
