@@ -236,7 +236,7 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     )
 
 
-def profile_pass(policy, worker, n_cycles=1):
+def profile_pass(policy, worker, n_cycles=1, bank=None, step=None):
     """Per-kernel launch durations from HIP events recorded on the launch stream.
 
     Events cannot sit inside a replayed hipGraph, so the same cycle is replayed with eager launches, every kernel
@@ -246,11 +246,14 @@ def profile_pass(policy, worker, n_cycles=1):
     up to the real duration of the sequence (the quantity rocprofv3 --kernel-trace reports)."""
     from curious_amd import ops
     import torch
-    saved = policy.use_graph
-    policy.use_graph = False
+    # (batched experts: the bank's launches; its experts' rollouts are eager as well)
+    graphed = [policy] if bank is None else [bank] + list(bank)
+    saved = [g.use_graph for g in graphed]
+    for g in graphed:
+        g.use_graph = False
 
     def updates():
-        policy.train_batches(N_BATCHES)
+        (policy if bank is None else bank).train_batches(N_BATCHES)
     updates()                                                     # warm the eager path
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -268,10 +271,14 @@ def profile_pass(policy, worker, n_cycles=1):
     overhead_ms = max(0.0, (sum(v[1] for v in st.values()) - t_plain) / max(1, n_launch))
     ops.prof_enable(True)
     for _ in range(n_cycles):
-        cycle(policy, worker)
+        if step is not None:
+            step()
+        else:
+            cycle(policy, worker)
     ops.prof_enable(False)
     stats = ops.prof_collect()
-    policy.use_graph = saved
+    for g, s in zip(graphed, saved):
+        g.use_graph = s
     return stats, overhead_ms, t_plain / N_BATCHES
 
 
@@ -301,8 +308,15 @@ def pmc_traffic(kernel):
         return None
 
 
-def roofline(policy, worker, stats, n_cycles, overhead_ms):
+def roofline(policy, worker, stats, n_cycles, overhead_ms, n_experts=1):
+    """n_experts: batched task experts -- the update kernels carry the expert on grid.z / grid.y, one launch does the work of
+    all of them (the acting kernels run one expert's rollout per cycle)."""
     work = kernel_flops_bytes(policy, policy._layout, worker.rollout_batch_size)
+    if n_experts > 1:
+        for w_ in work.values():
+            for key in ('per_update', 'l2_stream_bytes', 'hbm_bytes_per_update'):
+                if key in w_:
+                    w_[key] *= n_experts
     cal = {k: (v[0], max(v[1] - v[0] * overhead_ms, 0.0)) for k, v in stats.items() if v[0] > 0}
     if not cal:
         return None, {}
@@ -750,9 +764,11 @@ def main():
                       updates_ms=round(tu / 5 * 1e3, 3))
 
     # per-kernel HIP-event timing of the same cycle (eager launches; events cannot sit inside a replayed hipGraph)
-    roof, table = None, {}
-    if not experts:
-        prof_cycles = 1
+    prof_cycles = 1
+    if experts:
+        stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles, bank=bank, step=step)
+        roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms, n_experts=len(bank))
+    else:
         stats, overhead_ms, eager_update_ms = profile_pass(policy, worker, prof_cycles)
         roof, table = roofline(policy, worker, stats, prof_cycles, overhead_ms)
 

@@ -71,7 +71,7 @@ static const char* k_names[CK_COUNT] = {
     "adam_her_kernel", "polyak_kernel", "checksum_kernel", "action_noise_kernel", "env_reset_kernel", "env_step_kernel",
     "counter_add_kernel", "fwd_pi_kernel", "dw_adam_her_kernel", "act_step_kernel", "fwd_l01_kernel",
     "ddpg_rows_kernel", "policy_rows_kernel", "rows_transpose_kernel", "route_episodes_kernel",
-    "policy_resident_kernel", "ddpg_rows_her_kernel", "ddpg_step_kernel", "allreduce_adam_ipc_kernel"};
+    "policy_resident_kernel", "ddpg_rows_her_kernel", "allreduce_adam_ipc_kernel"};
 int64_t g_curious_launches[CK_COUNT] = {0};
 
 // launches per kernel id since the library was loaded (counted whether or not event timing is enabled, also during
@@ -91,7 +91,6 @@ CuriousOptions& curious_options() {
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     o.rows = env_int("CURIOUS_ROWS", 1) != 0;
     o.rows_xcd = env_int("CURIOUS_ROWS_XCD", 1) != 0;
-    o.one_launch = env_int("CURIOUS_ONE_LAUNCH", 0) != 0;
     o.xcd_map = env_int("CURIOUS_XCD_MAP", 0);
     if (o.xcd_map != 4 && o.xcd_map != 8) o.xcd_map = 0;
     o.fault_inject = 0;
@@ -100,7 +99,6 @@ CuriousOptions& curious_options() {
     o.dw_xcd = env_int("CURIOUS_DW_XCD", 1) != 0;
     o.rows_pre = env_int("CURIOUS_ROWS_PRE", 1) != 0;
     o.lab_dw_stamps = 0;
-    o.lab_step = env_int("CURIOUS_LAB_STEP", 0);
     o.lab_res_stamps = 0;
     o.resident = env_int("CURIOUS_RESIDENT", 1) != 0;
     o.res_spins = 1 << 20;
@@ -113,7 +111,6 @@ static int* option_slot(const char* name) {
   if (!name) return nullptr;
   if (!strcmp(name, "rows")) return &o.rows;
   if (!strcmp(name, "rows_xcd")) return &o.rows_xcd;
-  if (!strcmp(name, "one_launch")) return &o.one_launch;
   if (!strcmp(name, "xcd_map")) return &o.xcd_map;
   if (!strcmp(name, "fault_inject")) return &o.fault_inject;
   if (!strcmp(name, "qt_spins")) return &o.qt_spins;
@@ -121,7 +118,6 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "dw_xcd")) return &o.dw_xcd;
   if (!strcmp(name, "rows_pre")) return &o.rows_pre;
   if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
-  if (!strcmp(name, "lab_step")) return &o.lab_step;
   if (!strcmp(name, "lab_res_stamps")) return &o.lab_res_stamps;
   if (!strcmp(name, "resident")) return &o.resident;
   if (!strcmp(name, "res_spins")) return &o.res_spins;

@@ -75,7 +75,7 @@ enum {
   CK_NORM_PAIR_FINAL, CK_FWD_LAYER0, CK_FWD_GENERIC, CK_FWD_LAYER, CK_DX, CK_DX_GENERIC, CK_DW, CK_DW_SMALL, CK_HEAD_FWD,
   CK_CRITIC_HEAD, CK_CRITIC_HEAD_GENERIC, CK_ACTOR_DZ, CK_ACTOR_DZ_GENERIC, CK_ADAM, CK_ADAM_HER, CK_POLYAK, CK_CHECKSUM,
   CK_NOISE, CK_ENV_RESET, CK_ENV_STEP, CK_COUNTER_ADD, CK_FWD_PI, CK_DW_ADAM_HER, CK_ACT_STEP, CK_FWD_L01, CK_ROWS,
-  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_ACT_RES, CK_ROWS_HER, CK_STEP, CK_IPC, CK_COUNT
+  CK_ACT_ROWS, CK_ROWS_T, CK_ROUTE, CK_ACT_RES, CK_ROWS_HER, CK_IPC, CK_COUNT
 };
 extern int g_curious_prof_on;
 
@@ -84,9 +84,6 @@ struct CuriousOptions {
   int rows;            // 1: row-local routes (mlp_rows.h, mlp_rows_act.h); 0: tiled multi-launch routes      [CURIOUS_ROWS]
   int rows_xcd;        // 1: kinds of ddpg_rows_kernel placed by XCD; 0: plain block-id order                 [CURIOUS_ROWS_XCD]
   int xcd_map;         // 0 / 4 / 8: XCD-aware block placement of fwd_hot / dx_hot (tiled route)              [CURIOUS_XCD_MAP]
-  int one_launch;      // 0 (default): a fused update = the row-local launch, then the weight-gradient / optimiser launch;
-                       // 1: ONE launch (mlp_step.h ddpg_step_kernel) -- same results, measured SLOWER (48 vs 45.5 us per
-                       // update incl. the launch gaps: DESIGN 4.5); kept as a tested experiment          [CURIOUS_ONE_LAUNCH]
   int fault_inject;    // > 0: the target group of row group (fault_inject - 1) never publishes Q' (tests)
   int qt_spins;        // polls before a consumer of Q' gives up
   int resident;        // 1: multi-step rollouts keep the actor's hidden matrices in LDS (mlp_rows_res.h) when the grid fits
@@ -94,8 +91,6 @@ struct CuriousOptions {
   int res_spins;       // polls before a member of a resident-rollout group gives up on a peer
   int lab_res_stamps;  // LAB ONLY (tools/res_stamps.py): policy_resident_kernel adds per-phase cycle stamps of block 0 to 8
                        // 64-bit words behind its exchange buffer in the workspace
-  int lab_step;        // LAB ONLY (timing experiments on ddpg_step_kernel; results are wrong with bit 0): bit 0 no release
-                       // fence when publishing, bit 1 long sleeps between polls, bit 2 tiles do not wait       [CURIOUS_LAB_STEP]
   int dw_xcd;          // 1: blocks of the weight-gradient / optimiser launch placed by XCD (mlp_lean_gemm.h DwMap)  [CURIOUS_DW_XCD]
   int rows_pre;        // 1: the row-local launch's role / input rows / first layer-0 matrix travel as leading kernel arguments
                        //    (mlp_rows.h RowsPre; 0 = fetched from the argument segment as before: A/B)  [CURIOUS_ROWS_PRE]

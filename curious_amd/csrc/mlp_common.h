@@ -72,97 +72,6 @@ __device__ inline void loss_fin_flag(const LossFin& F, const int64_t eo, const i
 }
 struct DwArgs { DwProb p[MAX_DW]; int32_t nprob; LossFin fin; };
 
-// ================================================================== one-launch update (mlp_step.h ddpg_step_kernel)
-// The row-local pass and the weight-gradient / optimiser tiles of an update in ONE launch of B workgroups: a workgroup
-// that has finished its rows (or its share of the gather) turns to the tiles its worker index assigns to it, prefetches
-// their optimiser operands and waits on counters in the workspace (next to the fault word, zero between launches) until
-// the row groups that produce what the tile reads have published:
-//   STEP_DONE_CRITIC  main-critic groups that have stored everything the critic's weight gradients read
-//   STEP_PAST_CRITIC  actor-side groups that will not read the critic's parameters (or their transposed copies) again
-//   STEP_DONE_ACTOR   actor-side groups that have finished
-//   STEP_TICKETS      workgroups that have finished; the last one zeroes the counters and advances the step counter,
-//                     which nothing increments while the launch runs
-// The L2s of the 8 XCDs are not coherent with each other, and agent-scope fences are the wrong tool inside this launch:
-// an acquire invalidates the whole L2 of the XCD under the feet of the row groups still streaming weights out of it
-// (measured: 104 us per update instead of 43), a release writes back every dirty line including the optimiser's output
-// (~10 us).  Instead: the row groups store what the tiles read THROUGH the L2 (agent-coherent stores, rows_gst), wait for
-// the acknowledgements, barrier, one relaxed agent-scope add.  A waiting workgroup polls with one thread, barrier; it then
-// reads the [B, 256] matrices with plain loads -- nothing on its XCD has touched the rows of other row groups since the
-// launch began, so neither its L2 nor its L1 can hold a stale line of them -- and the small arrays whose 128-byte lines
-// are shared by row groups on different XCDs (dQ, dz, the per-row loss terms) with agent-coherent loads (coh_ld*).
-#define STEP_DONE_CRITIC 0
-#define STEP_PAST_CRITIC 1
-#define STEP_DONE_ACTOR 2
-#define STEP_TICKETS 3
-#define STEP_SYNC_OFFSET 16      // int32 words behind the fault word (a cache line of its own)
-struct StepSync {
-  int32_t* c;            // the four counters
-  int32_t n;             // row groups per kind (= B / 4)
-  int32_t spins;         // polls before a waiting workgroup gives up (fault word, nothing written)
-  int32_t* fault;
-  int32_t lab;           // lab only (CuriousOptions.lab_step)
-  unsigned long long* st; // lab only: 8 cycle stamps of this workgroup (0 start, 1 wait begins, 2 wait over, 4 end) or NULL
-};
-
-// release: 0 nothing to publish (only "I will not read X again"); 1 everything this workgroup publishes was stored
-// through the L2 (rows_gst): wait until the stores are acknowledged; 2 a full agent-scope release fence (writes ALL of
-// the XCD's dirty lines back, the optimiser's included: ~10 us per update when the row groups publish this way)
-__device__ inline void step_signal(int32_t* c, int which, int release) {
-  if (release == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (release == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(c + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// mask: bit k = counter k has to have reached S.n.  False: gave up (the fault word was incremented).
-__device__ inline bool step_wait(const StepSync& S, unsigned mask) {
-  __shared__ int step_ok;
-  if (S.lab & 4) return true;
-  if (threadIdx.x == 0) {
-    if (S.st) S.st[1] = __builtin_readcyclecounter();
-    int spins = 0;
-    bool got;
-    for (;;) {
-      got = true;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if ((mask >> k) & 1u)
-          got = got && __hip_atomic_load(S.c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S.n;
-      if (got || ++spins > S.spins) break;
-      if (S.lab & 2) __builtin_amdgcn_s_sleep(64);
-      else __builtin_amdgcn_s_sleep(4);
-    }
-    if (!got && S.fault) atomicAdd(S.fault, 1);
-    if (S.st) S.st[2] = __builtin_readcyclecounter();
-    step_ok = got ? 1 : 0;
-  }
-  __syncthreads();
-  return step_ok != 0;
-}
-
-// agent-coherent loads of what OTHER workgroups of the same launch have published (uniform base, per-lane byte offset)
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#define COH_SC1 16
-__device__ inline __amdgpu_buffer_rsrc_t coh_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ inline float coh_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, COH_SC1));
-}
-__device__ inline f32x4 coh_ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, COH_SC1));
-}
-
-__device__ inline void step_ticket(int32_t* c, int n_tickets, int64_t* step_ctr) {
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const int t = __hip_atomic_fetch_add(c + STEP_TICKETS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t != n_tickets - 1) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) __hip_atomic_store(c + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (step_ctr) *step_ctr += 1;
-}
-
 __device__ inline float seg_xform(const Seg& s, float v, int row, int col) {
   if (s.sub) v = __fsub_rn(v, s.sub[(int64_t)row * s.ldsub + col]);
   if (s.clip > 0.0f) v = fclip(v, -s.clip, s.clip);

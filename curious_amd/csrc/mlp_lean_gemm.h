@@ -13,14 +13,9 @@ struct AdamFuse {
   const float* alpha_tab; const int64_t* step_ctr; int64_t tab_base; int32_t tab_len;
   float a_Q, a_pi, b1, omb1, b2, omb2, eps;
   const int32_t* fault;           // fault word of the gradient workspace (mlp_rows.h) or NULL: non-zero = skip the optimiser
-  int32_t step_add;               // 1: the step counter has not been advanced for this update yet (ddpg_step_kernel)
 };
 __device__ inline bool adam_faulted(const AdamFuse& A, int64_t eo) {
   return A.fault && *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(A.fault) + eo) != 0;
-}
-// the same word when it may have been written by another workgroup of this very launch (ddpg_step_kernel)
-__device__ inline bool adam_faulted_now(const AdamFuse& A) {
-  return A.fault && __hip_atomic_load(const_cast<int32_t*>(A.fault), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // eo: slab offset of the expert this block works for (0 for a single agent); i / pidx / bidx below are indices into
@@ -30,7 +25,7 @@ __device__ inline bool adam_faulted_now(const AdamFuse& A) {
 __device__ inline void adam_alphas(const AdamFuse& A, float& aQ, float& aPi, int64_t eo) {
   aQ = A.a_Q; aPi = A.a_pi;
   if (A.alpha_tab) {
-    int64_t idx = ((*ex_i64(A.step_ctr, eo)) + A.step_add - 1 - A.tab_base) % A.tab_len;
+    int64_t idx = ((*ex_i64(A.step_ctr, eo)) - 1 - A.tab_base) % A.tab_len;
     if (idx < 0) idx += A.tab_len;
     aQ = A.alpha_tab[eo + 2 * idx];
     aPi = A.alpha_tab[eo + 2 * idx + 1];
@@ -91,7 +86,7 @@ __device__ inline void adam_alphas_late(const AdamFuse& A, AdamEarly& e, float& 
   if (A.alpha_tab) {
     PIN_V(e.lo); PIN_V(e.hi);
     const int64_t ctr = (int64_t)(((uint64_t)(uint32_t)e.hi << 32) | (uint32_t)e.lo);
-    const int64_t v = ctr + A.step_add - 1 - A.tab_base;
+    const int64_t v = ctr - 1 - A.tab_base;
     int64_t idx;
     if ((A.tab_len & (A.tab_len - 1)) == 0) {
       idx = v & (int64_t)(A.tab_len - 1);                   // the ring of ALPHA_TAB = 4096 entries: no 64-bit division
@@ -298,8 +293,8 @@ __global__ __launch_bounds__(256) void dx_hot_kernel(HotArgs args, Ex ex) {
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
 template <bool ADAM>
 __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const int t, float* red,
-                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
-                                   DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
+                                   const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
+                                   const AdamEarly* given = nullptr) {
   const int nx = P.N >> 6;
   int by, bx;
   tile_divmod(t, nx, by, bx);
@@ -325,11 +320,6 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
     pre = adam_prefetch4(A, pidx + eo);
     if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
-  if (S) {
-    // one-launch update: the optimiser operands above are in flight; the activations and gradients below exist once
-    // the row groups of this matrix's network have published (and nobody reads the matrix any more)
-    if (!step_wait(*S, ((int64_t)(P.C - A.grad) < A.n_Q) ? 3u : 4u)) return;
-  }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < P.M; mb += 256) {
@@ -340,8 +330,6 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
       const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        // (one-launch update: plain loads are enough for these [B, 256] matrices -- no workgroup on this XCD has
-        //  touched the rows of OTHER row groups since the launch began, so no stale line can sit in its L2 or L1)
         a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
         b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
       }
@@ -357,14 +345,13 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
         for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
       }
   }
-  if (S && S->st && tid == 0) S->st[3] = __builtin_readcyclecounter();
   DW_STAMP(stamps, 2);
   if (ADAM) {
     // the matrix instructions are issued: the step counter has long arrived, the look-up of the step sizes hides behind
     // the reduction of the tile.  (Outside the loop on purpose: a pinned value redefined inside it becomes loop-carried,
     // and the copy in front of the loop waits for the load -- before the tile's operands are even requested.)
     adam_alphas_late(A, early, aQ, aPi, eo);
-    faulted = S ? adam_faulted_now(A) : adam_early_faulted(A, early);
+    faulted = adam_early_faulted(A, early);
   }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
@@ -397,15 +384,6 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
 }
 
 
-template <bool ADAM>
-__device__ inline void dw_hot_body(const DwHotArgs& args, const AdamFuse& A, const int bid, float* red,
-                                   const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
-                                   DwStamp* stamps = nullptr) {
-  // problem and tile from arithmetic on the block id: the descriptor load does not wait for another load
-  const int pi = bid / args.tiles_per, t = bid - pi * args.tiles_per;
-  dw_hot_tile<ADAM>(args.p[pi], A, t, red, eo, eg, S, stamps);
-}
-
 // Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
 //   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
 struct DwSmall {
@@ -416,9 +394,6 @@ struct DwSmall {
 #define MAX_DW_SMALL 12
 struct DwSmallArgs {
   DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin;   // `slots` block ids per problem
-  // the same tiles as a compact list (ddpg_step_kernel): problem i owns tiles [tile0[i], tile0[i + 1]); the critic's
-  // problems come first, n_crit of them
-  int32_t tile0[MAX_DW_SMALL + 1]; int32_t n_crit;
 };
 
 // One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
@@ -426,8 +401,8 @@ struct DwSmallArgs {
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
 template <bool ADAM, bool YV>
 __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
-                                     const int64_t eo, const int64_t eg, const StepSync* S,
-                                     DwStamp* stamps = nullptr, const AdamEarly* given = nullptr) {
+                                     const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
+                                     const AdamEarly* given = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   int by, bx;
@@ -463,12 +438,6 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
     }
     if (own_b) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
   }
-  if (S) {
-    if (!step_wait(*S, ((int64_t)(P.dW - A.grad) < A.n_Q) ? 3u : 4u)) return;
-  }
-  // dQ / dz: a 128-byte line holds the values of several row groups, written on different XCDs -> agent-coherent loads
-  const bool ycoh = S && P.lddy < 64;
-  const __amdgpu_buffer_rsrc_t ry = coh_rsrc(P.dY + eo);
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
   for (int mb = 0; mb < M; mb += 256) {
@@ -477,24 +446,14 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
-      const int mq = mu + 4 * q;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
-        if (ycoh) {
-          if (YV) {
-            b[u][s] = coh_ld4(ry, ((mq + s) * P.lddy + colc) * 4);
-          } else {
-            b[u][s] = zero4();
-            b[u][s][0] = coh_ld1(ry, (mq + s) * P.lddy * 4);
-          }
+        if (YV) {
+          b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
         } else {
-          if (YV) {
-            b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
-          } else {
-            b[u][s] = zero4();
-            b[u][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
-          }
+          b[u][s] = zero4();
+          b[u][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
         }
       }
     }
@@ -523,7 +482,7 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
   DW_STAMP(stamps, 2);
   if (ADAM) {
     adam_alphas_late(A, early, aQ, aPi, eo);
-    faulted = S ? adam_faulted_now(A) : adam_early_faulted(A, early);
+    faulted = adam_early_faulted(A, early);
   }
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
@@ -559,22 +518,14 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
 }
 
 // losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
-__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const int64_t eg, const StepSync* S) {
+__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const int64_t eg) {
   const int tid = threadIdx.x;
   {
-    if (S && !step_wait(*S, 5u)) return;
     float lq = 0.f, lp = 0.f, ll = 0.f;
-    const __amdgpu_buffer_rsrc_t rr = coh_rsrc(F.rows + eo);
     for (int m = tid; m < F.Bl; m += 256) {                  // (the first rank's rows; the others: loss_fin_ranks)
-      if (S) {
-        lq += coh_ld1(rr, m * 4);
-        lp += coh_ld1(rr, (F.B + m) * 4);
-        ll += coh_ld1(rr, (2 * F.B + m) * 4);
-      } else {
-        lq += F.rows[eo + m];
-        lp += F.rows[eo + F.B + m];
-        ll += F.rows[eo + 2 * F.B + m];
-      }
+      lq += F.rows[eo + m];
+      lp += F.rows[eo + F.B + m];
+      ll += F.rows[eo + 2 * F.B + m];
     }
     red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
     __syncthreads();
@@ -595,36 +546,6 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
     }
     if (F.Bl < F.B) loss_fin_ranks(F, F.rows + eo, F.out + eo);
   }
-}
-
-template <bool ADAM>
-__device__ DW_INLINE void dw_small_body(const DwSmallArgs& args, const AdamFuse& A, const int bid, float* red,
-                                     const int64_t eo, const int64_t eg, const StepSync* S = nullptr,
-                                     DwStamp* stamps = nullptr) {
-  // every problem owns `slots` consecutive block ids (surplus blocks exit at once): problem and tile follow from
-  // arithmetic, so the descriptor load does not wait for a search through the table
-  const int pi = bid / args.slots, t = bid - pi * args.slots;
-  if (pi >= args.nprob) {
-    // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
-    if (pi == args.nprob && t == 0) dw_loss_fin(args.fin, red, eo, eg, S);
-    return;
-  }
-  const DwSmall& P = args.p[pi];
-  if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S, stamps);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S, stamps);
-}
-
-// item `it` of the compact tile list (DwSmallArgs.tile0)
-template <bool ADAM>
-__device__ inline void dw_small_item(const DwSmallArgs& args, const AdamFuse& A, const int it, float* red,
-                                     const int64_t eo, const int64_t eg, const StepSync* S) {
-  int pi = 0;
-  while (pi + 1 < args.nprob && it >= args.tile0[pi + 1]) ++pi;
-  const DwSmall& P = args.p[pi];
-  const int t = it - args.tile0[pi];
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, args.M, A, t, red, eo, eg, S);
-  else dw_small_tile<ADAM, false>(P, args.M, A, t, red, eo, eg, S);
 }
 
 // Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
@@ -713,7 +634,7 @@ __device__ __forceinline__ void pin_small(const DwSmall& P) {
 __device__ __forceinline__ void pin_adam(const AdamFuse& A) {
   asm volatile("" :: "s"(A.theta), "s"(A.m), "s"(A.v), "s"(A.grad), "s"(A.n_Q), "s"(A.alpha_tab), "s"(A.step_ctr),
                "s"(A.tab_base), "s"(A.tab_len), "s"(A.a_Q), "s"(A.a_pi), "s"(A.b1), "s"(A.omb1), "s"(A.b2), "s"(A.omb2),
-               "s"(A.eps), "s"(A.fault), "s"(A.step_add));
+               "s"(A.eps), "s"(A.fault));
 }
 
 // (the leading scalars: preloaded into SGPRs, see DwMap)
@@ -731,13 +652,13 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
     if (ADAM) pin_adam(A);
     asm volatile("" :: "s"(grad_stride));
     DW_STAMP(sp, 3);
-    dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, nullptr, sp, early);
+    dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, sp, early);
     return;
   }
   const int pi = R.idx / slots, t = R.idx - pi * slots;
   if (pi >= small_nprob) {
     // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
-    if (pi == small_nprob && t == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride, nullptr);
+    if (pi == small_nprob && t == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
     return;
   }
   DwSmall P = args.small.p[pi];
@@ -748,8 +669,8 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   DW_STAMP(sp, 3);
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
   const int64_t eg = (int64_t)blockIdx.y * grad_stride;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, nullptr, sp, early);
-  else dw_small_tile<ADAM, false>(P, M, A, t, red, eo, eg, nullptr, sp, early);
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, sp, early);
+  else dw_small_tile<ADAM, false>(P, M, A, t, red, eo, eg, sp, early);
 }
 
 __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,

@@ -75,9 +75,6 @@ struct RowsArgs {
   const float *o_mean, *o_std, *g_mean, *g_std;
   float nclip;
   float *xn_c, *xn_a;
-  int32_t* sync;                  // one-launch update (ddpg_step_kernel, mlp_common.h StepSync): the counters the row groups
-  int32_t n_tickets;              // publish on, and how many workgroups take a ticket; NULL / 0 in every other launch
-  int32_t lab_step;               // lab only (CuriousOptions.lab_step)
 };
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
@@ -104,20 +101,16 @@ struct RCtx {
   mutable unsigned long long* dbg;
   float* hs; mutable float* part; mutable float* part2; float* xin; float* sm; float* keep;
   int tid, wave, lane, r0;
-  bool pub;   // one-launch update: what the tiles of the same launch read is stored THROUGH the L2 (agent-coherent stores)
 };
-// a result other workgroups read: the weight-gradient launch that follows, or (pub) the tiles of this very launch
+// a result other workgroups read: the weight-gradient launch that follows
 // (lab, -DROWS_NT_STORES: written through instead of left dirty in the L2 for the release at the end of the kernel --
 //  tools/floor2_lab.hip prices that release at 0.15 us per MB; profiles/r05_floor2_lab.txt)
 __device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
-  if (x.pub) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else {
 #ifdef ROWS_NT_STORES
-    __builtin_nontemporal_store(v, p);
+  __builtin_nontemporal_store(v, p);
 #else
-    *p = v;
+  *p = v;
 #endif
-  }
 }
 
 // ---- weight fragments of one 16-deep k-chunk
@@ -516,16 +509,14 @@ static inline size_t rows_lds_floats(int nl) {
 
 // HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
 // form keeps its 632-byte kernarg -- HerArgs adds 1.4 KB)
-// Returns the workgroup's role as a worker index (ddpg_step_kernel hands out its tiles by it): spare blocks [0, nrg),
-// target groups nrg + row group, main-critic groups 2 nrg + row group, actor-side groups 3 nrg + row group.
-// STEP: the one-launch update -- results are published for the tiles of the same launch (mlp_common.h StepSync).
-template <bool EX, bool HER, bool STEP = false>
+// Returns the workgroup's role as an index: spare blocks [0, nrg), target groups nrg + row group, main-critic groups
+// 2 nrg + row group, actor-side groups 3 nrg + row group.
+template <bool EX, bool HER>
 __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
                                               const uint64_t seed_stride, const RowsPre* pre = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
   x.dbg = nullptr;
-  x.pub = STEP;
   x.hs = rows_lds;
   x.part = x.hs + 4 * RLD;
   x.part2 = x.part + 4 * 4 * 256;
@@ -717,7 +708,6 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     ROWS_STAMP(5);
     rows_hidden_bwd(x, wb, a, x.keep, 1, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(6);
-    if (STEP) step_signal(a.sync, STEP_DONE_CRITIC, (a.lab_step & 1) ? 0 : 1);
     return 2 * nrg + rgrp;
   }
 
@@ -802,7 +792,6 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   rows_hidden_bwd(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
   ROWS_STAMP(7);
   // (every operand that comes from the critic's parameters is in registers or consumed by now: wu, wq_col above)
-  if (STEP) step_signal(a.sync, STEP_PAST_CRITIC, 0);
   {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
     // pi = max_u tanh(z) and the l2 term (ddpg.py:440-441)
@@ -818,12 +807,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     }
     if (x.lane == 0) {
       const f32x4 o = {dz[0], dz[1], dz[2], dz[3]};
-      if (STEP) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) rows_gst(x, a.dz + eo + (int64_t)m * 4 + d, dz[d]);
-      } else {
-        *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
-      }
+      *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
       *reinterpret_cast<f32x4*>(sm_v + 4 * x.wave) = o;
     }
   }
@@ -847,7 +831,6 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   ROWS_STAMP(8);
   rows_hidden_bwd(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
   ROWS_STAMP(9);
-  if (STEP) step_signal(a.sync, STEP_DONE_ACTOR, (a.lab_step & 1) ? 0 : 1);
   return 3 * nrg + rgrp;
 }
 

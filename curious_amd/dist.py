@@ -12,6 +12,9 @@ import torch
 import torch.distributed as td
 
 
+RANK_SEED_STRIDE = 1000003   # what separates the device RNG keys of consecutive (global) ranks
+
+
 class RankDivergence(RuntimeError):
     """MpiAdam.check_synced (mpi_adam.py:42-50): the ranks no longer hold bit-identical parameters."""
 

@@ -299,9 +299,21 @@ class ExpertBank:
         return out
 
     def update_target_net(self):
-        for x in self.experts:
-            x.update_target_net()
+        """Every expert's target update and fault bookkeeping, whatever one of them reports: a HandoffFault of expert e is
+        raised AFTER the loop, so that the experts behind it get their Polyak step, their tick and their fault-check copy in
+        the same cycle (experiment.train.FaultTolerance goes on with the job; the experts' ticks must stay in phase)."""
+        self._each(lambda x: x.update_target_net())
 
     def check_faults(self, wait=True):
+        self._each(lambda x: x.check_faults(wait))
+
+    def _each(self, fn):
+        from curious_amd.ddpg import HandoffFault
+        first = None
         for x in self.experts:
-            x.check_faults(wait)
+            try:
+                fn(x)
+            except HandoffFault as err:
+                first = first or err
+        if first is not None:
+            raise first

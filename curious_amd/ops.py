@@ -507,8 +507,7 @@ class option:
 
 def fault_word(cfg, B, workspace, n=1):
     """int32 view (1 element) of the fault word inside a gradient workspace (curious_workspace_fault_offset).  n = 64:
-    the whole block it sits in -- word 0 the fault word, words 16..19 the counters of the one-launch update (zero between
-    launches; a launch that was given up on may leave them set: clear the block together with the word)."""
+    the whole (zeroed) block it sits in."""
     off = int(lib().curious_workspace_fault_offset(C.byref(cfg), int(B)))
     if off < 0:
         raise _lib.CuriousHipError('curious_workspace_fault_offset: bad arguments')

@@ -383,11 +383,11 @@ class RolloutWorker:
             # the noise is switched off rank by rank inside the launch (a rank that exploits: rollout.py:183-189)
             self.policy.act_rollout(env, self.T, noise_eps=0. if self.eval else self.noise_eps,
                                     random_eps=0. if self.eval else self.random_eps,
-                                    use_target_net=self.use_target_net, exploit=self._exploit_v)
+                                    use_target_net=self.use_target_net, exploit=self._exploit_v, evaluation=self.eval)
         elif fused and hasattr(self.policy, 'act_rollout'):
             self.policy.act_rollout(env, self.T, noise_eps=self.noise_eps if not self.exploit else 0.,
                                     random_eps=self.random_eps if not self.exploit else 0.,
-                                    use_target_net=self.use_target_net)
+                                    use_target_net=self.use_target_net, evaluation=self.eval)
         elif self.V > 1 and not self.eval:
             raise NotImplementedError('virtual ranks: training rollouts need the fused rollout (DDPG.act_rollout)')
         if fused and hasattr(self.policy, 'act_rollout') and self.compute_Q:
@@ -480,7 +480,7 @@ class RolloutWorker:
             if n_retry >= self.MAX_NAN_RETRIES:
                 raise
             self._resident_off(err)
-            self.policy.rewind_rollout(env, self.T)
+            self.policy.rewind_rollout(env, self.T, evaluation=self.eval)
             self.count -= B
             return self._generate_rollouts_batched(retry=True, force_sync=force_sync, n_retry=n_retry + 1,
                                                    redo=(tasks, goals))

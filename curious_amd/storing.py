@@ -1,0 +1,348 @@
+"""Storing half of the agent (DDPG.store_episode baselines/her/ddpg.py:163-223, ReplayBuffer.store_episode
+replay_buffer.py:57-109): the task-activity test, the routing of episodes into the per-task buffers -- on the host, or on
+the device without waiting for the rollout's flags (async_store) --, the normaliser update from the fresh episodes
+(ddpg.py:207-223, normalizer.py:64-118).  Virtual ranks: every rank's episodes into that rank's buffers.  Mixed into
+curious_amd.ddpg.DDPG."""
+import numpy as np
+import torch
+
+from curious_amd import _lib, dist, ops
+from curious_amd.dist import RANK_SEED_STRIDE
+from curious_amd.her import upload_plan
+from curious_amd.normalizer import recompute_many
+from curious_amd.replay_buffer import as_records
+
+
+class StoringMixin:
+    def store_episode(self, episode_batch, cp, n_ep, update_stats=True):
+        """episode_batch: {key: [batch, T or T+1, dim]} NumPy arrays, or the EpisodeViews of a device staging
+        block produced by the batched RolloutWorker (ddpg.py:163-223)."""
+        self._store_episode(episode_batch, cp, n_ep, update_stats)
+        # verdict of an earlier fault-word copy that has arrived (no stall).  Raised AFTER the episodes are stored: a
+        # caller that catches HandoffFault and goes on has lost nothing of this call
+        self.check_faults(wait=False)
+
+    def _store_episode(self, episode_batch, cp, n_ep, update_stats=True):
+        self.settle()
+        self.cp = cp
+        self.n_episodes = n_ep
+        layout = self._layout
+        staging = as_records(episode_batch, layout)
+        batch_size = staging.shape[0]
+        marked, self._async_batch = self._async_batch, None
+        if marked is not None and marked[:2] == (staging.data_ptr(), batch_size) and update_stats:
+            return self._store_episode_async(staging, batch_size, marked[2], marked[3])
+        if self.structure in ('curious', 'task_experts'):
+            if 'buffer' in self.task_replay or self.task_replay == 'hand_designed':
+                na = batch_size * self.nb_tasks
+                if getattr(self, '_route_bufs', None) is None or self._route_bufs[0].numel() < na:
+                    # device + pinned host mirrors for the activity flags and the (src, dst) routing pairs
+                    self._route_bufs = (torch.empty(na, dtype=torch.int32, device=self.device),
+                                        torch.empty(na, dtype=torch.int32).pin_memory(),
+                                        torch.empty(na, dtype=torch.int32).pin_memory(),
+                                        torch.empty(na, dtype=torch.int64).pin_memory(),
+                                        torch.empty(na, dtype=torch.int32, device=self.device),
+                                        torch.empty(na, dtype=torch.int64, device=self.device))
+                active_dev, active_host = self._route_bufs[0][:na], self._route_bufs[1][:na]
+                pre = getattr(self, '_activity_prefetched', None)
+                self._activity_prefetched = None
+                have = pre == (staging.data_ptr(), batch_size)       # RolloutWorker already fetched it with its flags
+                if not have:
+                    ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, active_dev)
+                    active_host.copy_(active_dev, non_blocking=True)
+                    arrived = torch.cuda.Event()
+                    arrived.record()
+                if update_stats and self.rng_mode == 'device':
+                    # the normaliser update needs no host decision and (in this mode) no NumPy draw: enqueue it now, so
+                    # that the GPU works while the host routes the episodes
+                    self._update_stats(staging, batch_size)
+                    update_stats = False
+                if not have:
+                    arrived.synchronize()                            # one D2H sync per cycle
+                active = active_host.numpy().reshape(batch_size, self.nb_tasks)
+                per_buffer = {}
+                fast_src, fast_dst = [], []
+                routed = active.astype(bool)
+                if self.nb_tasks >= 5:
+                    routed[:, 5:] = False                            # only tasks j < 5 are routed (ddpg.py:183)
+                counts = routed.sum(axis=0)
+                fits = all(self.buffer[j + 1].current_size + int(counts[j]) <= self.buffer[j + 1].size
+                           for j in range(self.nb_tasks) if counts[j])
+                distinct = len({id(self.buffer[j + 1]) for j in range(self.nb_tasks) if counts[j]}) == \
+                    int((counts > 0).sum())
+                if self.V > 1 and not distinct:
+                    raise NotImplementedError('virtual ranks: the routed tasks need a buffer each')
+                if self.rng_mode == 'device' and distinct:
+                    # device RNG mode: the rule of replay_buffer.py:90-109 per episode -- consecutive slots while the
+                    # buffer has room, then a random slot -- with the random slots drawn from the Philox stream the
+                    # device-routed form uses (curious_route_store_episodes), so both forms store the same thing.
+                    # Virtual ranks: rank v's episodes (rows v * per ..) into rank v's buffers, with rank v's key and
+                    # ITS episode numbers -- what a process of its own would do
+                    call = self._next_store_call()
+                    per = batch_size // self.V
+                    for v in range(self.V):
+                        bufs = self._rank_buffers[v]
+                        rows = routed[v * per:(v + 1) * per]
+                        for j in range(self.nb_tasks):
+                            eps = np.nonzero(rows[:, j])[0]
+                            if not eps.size:
+                                continue
+                            buf = bufs[j + 1]
+                            free = max(0, buf.size - buf.current_size)
+                            slots = np.arange(buf.current_size, buf.current_size + min(eps.size, free), dtype=np.int64)
+                            buf.current_size = min(buf.size, buf.current_size + eps.size)
+                            buf.n_transitions_stored += eps.size * self.T
+                            if eps.size > free:
+                                slots = np.concatenate([slots, ops.store_slots_host(self._store_seed(v), call, j,
+                                                                                    buf.size, eps[free:])])
+                                # of two episodes on one slot the later one wins (sequential semantics)
+                                _, first_rev = np.unique(slots[::-1], return_index=True)
+                                keep = np.sort(eps.size - 1 - first_rev)
+                                eps, slots = eps[keep], slots[keep]
+                            fast_src.append((eps + v * per).astype(np.int32))
+                            fast_dst.append(slots.astype(np.int64) + buf.pool_index * buf.pool.capacity)
+                elif fits and distinct:
+                    # no buffer overflows within this batch -> slots are consecutive and no random number is drawn
+                    # (replay_buffer.py:94-95): same result as the per-episode loop below, without the loop
+                    for j in range(self.nb_tasks):
+                        if counts[j]:
+                            buf = self.buffer[j + 1]
+                            eps = np.nonzero(routed[:, j])[0]
+                            slots = np.arange(buf.current_size, buf.current_size + eps.size)
+                            buf.current_size += eps.size
+                            buf.n_transitions_stored += eps.size * self.T
+                            fast_src.append(eps.astype(np.int32))
+                            fast_dst.append(slots.astype(np.int64) + buf.pool_index * buf.pool.capacity)
+                else:
+                    for b in range(batch_size):                      # ddpg.py:178-195, order of the RNG draws kept
+                        for j in range(self.nb_tasks):
+                            if routed[b, j]:
+                                buf = self.buffer[j + 1]
+                                slot = buf._get_storage_idx(1)
+                                buf.n_transitions_stored += self.T
+                                per_buffer.setdefault(id(buf), (buf, [], []))
+                                per_buffer[id(buf)][1].append(b)
+                                per_buffer[id(buf)][2].append(slot)
+                # sequential semantics of the reference: when two episodes of this batch draw the same (random)
+                # slot the later one wins -> keep only the last writer of every destination
+                last = {}
+                for buf, eps, slots in per_buffer.values():
+                    for b, s in zip(eps, slots):
+                        last[int(s) + buf.pool_index * buf.pool.capacity] = b
+                dst, src = list(last.keys()), list(last.values())
+                if fast_src:
+                    src, dst = np.concatenate(fast_src), np.concatenate(fast_dst)
+                if len(src):
+                    k = len(src)
+                    assert k <= na
+                    src_h, dst_h, src_d, dst_d = (b[:k] for b in self._route_bufs[2:])
+                    src_h.numpy()[:] = np.asarray(src, np.int32)
+                    dst_h.numpy()[:] = np.asarray(dst, np.int64)
+                    src_d.copy_(src_h, non_blocking=True)
+                    dst_d.copy_(dst_h, non_blocking=True)
+                    ops.store_episodes(self._pool.storage, staging, layout, src_d, dst_d)
+                    self._pool.version += 1
+            else:
+                for b in range(batch_size):
+                    slot = self.buffer._get_storage_idx(1)
+                    self.buffer.n_transitions_stored += self.T
+                    self.buffer.store_records(staging, [b], [slot])
+        else:                                                        # flat (ddpg.py:199-204)
+            for b in range(batch_size):
+                slot = self.buffer._get_storage_idx(1)
+                self.buffer.n_transitions_stored += self.T
+                self.buffer.store_records(staging, [b], [slot])
+        self._tables_dirty = True
+
+        if update_stats:                                             # ddpg.py:207-223
+            self._update_stats(staging, batch_size)
+
+    def can_store_async(self, batch_size):
+        """The device can route the episodes of the coming rollout itself (curious_route_store_episodes) and nothing the
+        host would compute from the rollout's flags is needed before the updates: every routed buffer is non-empty (the
+        replay proportions, ddpg.py:255-286, then depend on the competence progress only).  Single agent on its own
+        buffers, device RNG (the random slots of full buffers are Philox draws in that mode).  With several ranks the
+        normaliser all-reduce of the store is stream-ordered like everything else: nothing here needs the host either."""
+        if not (self.async_store and self.structure == 'curious' and self._multi_buffer() and self.rng_mode == 'device'
+                and isinstance(self.buffer, list)):
+            return False
+        self.settle()
+        nr = min(self.nb_tasks, 5)
+        for bl in self._rank_buffers:                                # (batch_size: the episodes of ONE rank's rollout)
+            bufs = [bl[j + 1] for j in range(nr)]
+            if not (len({id(b) for b in bufs}) == nr and all(b.current_size > 0 for b in bufs)):
+                return False
+        return batch_size <= 2048 and self.dimo + self.dimg <= 256
+
+    def _store_seed(self, v=0):
+        return (self.seed * 6700417 + 29 + (self._grank0() + v) * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+
+    def _next_store_call(self):
+        self._store_calls = getattr(self, '_store_calls', 0) + 1
+        return self._store_calls
+
+    def expect_async_store(self, episode_batch, skip, skip_host=None):
+        """Called by the batched RolloutWorker when it returns WITHOUT having waited for the rollout's flags: the next
+        store_episode of exactly this batch takes the device-routed form.  skip: the rollout's NaN word (device);
+        skip_host: where its value arrives on the host (pinned, the D2H copy already enqueued: the worker's flag copy)."""
+        staging = as_records(episode_batch, self._layout)
+        self._async_batch = (staging.data_ptr(), staging.shape[0], skip, skip_host)
+
+    def _store_episode_async(self, staging, batch_size, skip, skip_host=None):
+        """store_episode (ddpg.py:163-223) with the routing decided on the device: same slots, same table, same stats
+        as the host-routed form; the host's mirror of the buffer sizes follows in settle()."""
+        layout = self._layout
+        na = batch_size * self.nb_tasks
+        assert getattr(self, '_activity_prefetched', None) == (staging.data_ptr(), batch_size)
+        self._activity_prefetched = None
+        self._update_stats(staging, batch_size, skip=skip)           # a NaN rollout feeds no statistics either
+        if self._tables_stale() or getattr(self, '_tables', None) is None:
+            self._refresh_device_tables()                            # from the host's (settled) sizes
+        nb1 = self.nb_tasks + 1
+        n0 = nb1 + 1
+        if getattr(self, '_route_count', None) is None:
+            self._route_count = torch.zeros(self.V, dtype=torch.int32, device=self.device)
+            self._nan_pin = torch.zeros(1, dtype=torch.float32).pin_memory()
+        src_d, dst_d = self._route_bufs[4][:na], self._route_bufs[5][:na]
+        ops.route_store_episodes(self._pool.storage, staging, layout, self._route_bufs[0][:na], self.nb_tasks,
+                                 min(self.nb_tasks, 5), batch_size // self.V, self._tables[n0 + 2 * nb1:],
+                                 self._tables[n0:], self._pool.capacity, self._store_seed(),
+                                 self._next_store_call(), skip, src_d, dst_d, self._route_count, n_ranks=self.V,
+                                 tab_stride=4 * nb1 + 1, seed_stride=RANK_SEED_STRIDE,
+                                 tasks=self.sample_transitions.tasks if getattr(self, '_activity_in_route', False) else None)
+        if getattr(self, '_activity_in_route', False):               # the flags the routing launch evaluated: to the host
+            self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
+            self._activity_in_route = False
+        if skip_host is None:
+            self._nan_pin.copy_(skip, non_blocking=True)
+            skip_host = self._nan_pin
+        arrived = torch.cuda.Event()
+        arrived.record()                                             # behind the D2H copies of the activity and rollout flags
+        self._pool.version += 1
+        self._tables_dirty = False
+        self._tables_sizes = self._sizes_key()                       # the device table is ahead of the host's sizes
+        self._batch_stale = True                                     # until settle(); the next batch is drawn from it
+        self._store_pending = (self._route_bufs[1][:na], batch_size, arrived, skip_host)
+
+    def settle(self):
+        """Bring the host's mirror of the buffer sizes up to date with a device-routed store (async_store)."""
+        p, self._store_pending = self._store_pending, None
+        if p is None:
+            return
+        active_host, batch_size, arrived, skip_host = p
+        arrived.synchronize()
+        if float(skip_host[0]) == 0.0:                               # (a NaN rollout was dropped on the device as well)
+            routed = active_host.numpy().reshape(batch_size, self.nb_tasks).astype(bool)
+            if self.nb_tasks >= 5:
+                routed[:, 5:] = False                                # only tasks j < 5 are routed (ddpg.py:183)
+            per = batch_size // self.V
+            for v, bufs in enumerate(self._rank_buffers):
+                counts = routed[v * per:(v + 1) * per].sum(axis=0)
+                for j in range(self.nb_tasks):
+                    if counts[j]:
+                        buf = bufs[j + 1]
+                        buf.current_size = min(buf.size, buf.current_size + int(counts[j]))
+                        buf.n_transitions_stored += int(counts[j]) * self.T
+        self._tables_sizes = self._sizes_key()
+
+    def prefetch_activity(self, episode_batch, in_route=False):
+        """Called by the batched RolloutWorker right after it enqueued a rollout: the task-activity test of the coming
+        store_episode (ddpg.py:179-184) and its D2H copy are enqueued now, so that they arrive with the rollout flags
+        the worker waits for anyway -- one host sync per cycle instead of two.  in_route: the store will be routed on the
+        device (expect_async_store follows): its routing launch evaluates the flags itself, only the buffers are set up."""
+        if not (self.structure in ('curious', 'task_experts') and self._multi_buffer()):
+            return
+        layout = self._layout
+        staging = as_records(episode_batch, layout)
+        batch_size = staging.shape[0]
+        na = batch_size * self.nb_tasks
+        if getattr(self, '_route_bufs', None) is None or self._route_bufs[0].numel() < na:
+            self._route_bufs = (torch.empty(na, dtype=torch.int32, device=self.device),
+                                torch.empty(na, dtype=torch.int32).pin_memory(),
+                                torch.empty(na, dtype=torch.int32).pin_memory(),
+                                torch.empty(na, dtype=torch.int64).pin_memory(),
+                                torch.empty(na, dtype=torch.int32, device=self.device),
+                                torch.empty(na, dtype=torch.int64, device=self.device))
+        # (the routing launch is ONE workgroup per rank: beyond 2 048 flags -- 1 024 envs of Arm8 -- its 256 threads take
+        #  longer over the flags, 32 dependent reads each, than a launch of their own with a thread per flag: 55 against 25 us)
+        in_route = bool(in_route) and na // self.V <= 2048
+        self._activity_in_route = in_route
+        if not in_route:
+            ops.episode_activity(staging, layout, self.sample_transitions.tasks, batch_size, self._route_bufs[0][:na])
+            self._route_bufs[1][:na].copy_(self._route_bufs[0][:na], non_blocking=True)
+        self._activity_prefetched = (staging.data_ptr(), batch_size)
+
+    def _update_stats(self, staging, batch_size, skip=None):
+        """HER-sample batch_size * T transitions from the fresh episodes and feed both normalisers (ddpg.py:207-223).
+        skip: the NaN word of the rollout (device) on the device-routed path -- non-zero = nothing is accumulated."""
+        layout = self._layout
+        n = batch_size * self.T
+        if self.rng_mode == 'numpy':
+            ep, t, u_her, u_off, given = self.sample_transitions.draw(batch_size, self.T, n)
+            plan = upload_plan(n, ep, t, u_her, u_off, ttr=given)
+            rng = None
+        else:
+            plan, rng = None, self._stats_rng(batch_size, n)
+        if getattr(self, '_stats_batch', None) is None or self._stats_batch.shape[0] != n:
+            self._stats_batch = torch.empty([n, layout.batch_stride], dtype=torch.float32, device=self.device)
+        batch = self._stats_batch
+        P = self.sample_transitions.params(self.clip_obs, self.relative_goals)
+        # (virtual ranks: every rank draws its batch_size / V * T transitions from ITS episodes -- "buffer" v of the staging
+        #  block = the records of rank v)
+        ops.her_sample(staging, (batch_size // self.V) * layout.rec_floats if self.V > 1 else 0, layout,
+                       self.sample_transitions.tasks, P, n, batch, plan=plan, rng=rng)
+        cols = layout.batch_cols
+        if self.dimo + self.dimg > 256:
+            # wider than the paired kernel's one workgroup: the two normalisers one after the other (ddpg.py:216-223)
+            assert skip is None
+            self.o_stats.update(batch[:, cols['o'][0]:cols['o'][0] + self.dimo])
+            self.g_stats.update(batch[:, cols['g'][0]:cols['g'][0] + self.dimg])
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc)
+            return
+        # both normalisers from the one batch in two launches; on a single rank the second one also recomputes the
+        # statistics, with several ranks the (packed) accumulators are all-reduced first (normalizer.py:84-94)
+        need = ops.norm_pair_scratch_doubles(n, self.dimo, self.dimg)
+        if getattr(self, '_stats_scratch', None) is None or self._stats_scratch.numel() < need:
+            self._stats_scratch = torch.empty(need, dtype=torch.float64, device=self.device)
+        # one rank: the finishing launch also recomputes the statistics.  Several (real or virtual) ranks: the accumulators
+        # hold the SUM over this process's virtual ranks; all-reduced over the processes, then divided by the number of
+        # ranks (normalizer.py:84-94: the MEAN over ranks of every rank's local sums)
+        single = not dist.is_distributed() and self.V == 1
+        ops.norm_update_pair(batch, n, batch.stride(0), cols['o'][0], self.dimo, cols['g'][0], self.dimg,
+                             self.o_stats.acc, self.g_stats.acc, self.o_stats.state if single else None,
+                             self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
+                             self._stats_scratch, skip=skip)
+        if not single:
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc, ranks_per_process=self.V)
+
+    def _stats_rng(self, n_episodes, n):
+        """Sampler description of the normaliser batch: n transitions from the n_episodes fresh episodes; with virtual
+        ranks n / V from each rank's n_episodes / V (one table row [prefix 0, prefix 1, size, alias, task] per rank)."""
+        r = _lib.SampleRng()
+        V = self.V
+        if getattr(self, '_stats_tables_key', None) != (n_episodes, n):
+            rows = [[0, n // V, n_episodes // V, v, -1] for v in range(V)]
+            self._stats_tables = torch.tensor(rows, dtype=torch.int32, device=self.device).reshape(-1)
+            self._stats_tables_key = (n_episodes, n)
+        r.seed = (self.seed * 7919 + 17 + self._grank0() * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+        r.step_ctr = None
+        self._stats_calls = getattr(self, '_stats_calls', 0) + 1
+        r.step_host = self._stats_calls
+        t = self._stats_tables
+        r.prop_prefix, r.cur_size, r.buf_alias, r.buf_task = (t[0:].data_ptr(), t[2:].data_ptr(), t[3:].data_ptr(),
+                                                              t[4:].data_ptr())
+        r.nbuf = 1
+        if V > 1:
+            r.rank_rows, r.rank_tab_stride, r.rank_seed_stride = n // V, 5, RANK_SEED_STRIDE
+        return r
+
+    def get_current_buffer_size(self):
+        self.settle()                                                # (virtual ranks: rank 0's, like everything a rank logs)
+        return sum([self.buffer[i].get_current_size() for i in range(self.nb_tasks)])
+
+    def clear_buffer(self):
+        self.settle()
+        for bl in self._rank_buffers:
+            for i in range(self.nb_tasks):
+                bl[i].clear_buffer()
+        self._tables_dirty = True

@@ -135,10 +135,6 @@ int curious_prof_launch_counts(int64_t* counts_host);
  *                  handed to the kernel as leading arguments (in scalar registers when a wave starts) where the shapes
  *                  allow; 0: fetched from the argument segment (same results; A/B)
  *   "dw_xcd"       1 (default; env CURIOUS_DW_XCD): blocks of the weight-gradient / optimiser launch placed by XCD
- *   "one_launch"   0 (default; env CURIOUS_ONE_LAUNCH): curious_ddpg_update on the row-local route = the row-local launch,
- *                  then the weight-gradient / optimiser launch; 1: both in ONE launch whose workgroups first do their
- *                  rows, then their share of the tiles (same results bit for bit; measured slower on MI355X -- DESIGN.md
- *                  4.5 -- and kept as a tested alternative)
  *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
  *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes; a member of group k - 1 of
  *                  the resident-weights rollout never shows up (fault-path tests)
@@ -271,8 +267,7 @@ int64_t curious_param_total(const curious_net_cfg_t* cfg);
 /* workspace floats for curious_ddpg_grads / curious_policy_forward at batch size B */
 int64_t curious_workspace_floats(const curious_net_cfg_t* cfg, int32_t B);
 /* Float offset, inside that workspace, of its FAULT WORD (one int32, the first of a block of 64 words that is zeroed
- * together with the workspace; words 16..19 of the block are the counters the workgroups of a "one_launch" update
- * synchronise on -- zero between launches, to be cleared together with the fault word after a fault).  The
+ * together with the workspace).  The
  * row-local update hands Q' of the target networks from one workgroup to another inside one launch; a consumer that
  * never receives its value (HIP does not promise the dispatch order the hand-off relies on) gives up after "qt_spins"
  * polls, turns the loss into NaN and increments this word.  While it is non-zero every optimiser of this library that

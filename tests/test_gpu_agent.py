@@ -658,8 +658,8 @@ def test_active_goal_selection_feeds_sagg_riac():
 
 
 def test_evaluator_rollout_graph_equals_eager():
-    """Evaluator rollouts (exploit, compute_Q): the hipGraph replay of the noise-free acting loop writes the same
-    episode records and reports the same mean Q as the eager per-step loop."""
+    """Evaluator rollouts (exploit, compute_Q): the hipGraph replay of the noise-free rollout writes the same episode
+    records and reports the same mean Q as the eager launches."""
     from curious_amd.envs import EnvFactory
     from curious_amd.rollout import RolloutWorker
     from curious_amd import logger
@@ -675,7 +675,9 @@ def test_evaluator_rollout_graph_equals_eager():
         for _ in range(3):
             ep, _, _ = w.generate_rollouts()
         torch.cuda.synchronize()
-        assert (('eval', id(w.benv), T, False, True) in getattr(agent, '_roll_graphs', {})) == use_graph
+        # (round 5: the evaluator's rollout is the fused one-launch rollout, its Q values come from the recorded rows --
+        #  DDPG.rollout_q_sum; the launch-per-step evaluator is compared with it in tests/test_gpu_round5.py)
+        assert any(k[0] == id(w.benv) for k in getattr(agent, '_roll_graphs', {})) == use_graph
         recs.append(ep.records.clone())
         qs.append(list(w.Q_history))
     assert torch.equal(recs[0], recs[1])

@@ -147,14 +147,14 @@ def test_nan_rollout_on_the_device_routed_path_feeds_nothing():
     torch.cuda.synchronize()
     sizes = [b.current_size for b in agent.buffer]
     stats = (agent.o_stats.state.clone(), agent.g_stats.state.clone(), agent._stats_acc.clone())
-    reset_all = w.benv.reset_all
+    launch_reset = w.benv.launch_reset                               # (the reset launch heads the rollout: DDPG.act_rollout)
 
-    def poisoned_reset(tasks, goals):                                # one env starts from a NaN observation
-        reset_all(tasks, goals)
+    def poisoned_reset(counter=None, delta=0):                       # one env starts from a NaN observation
+        launch_reset(counter=counter, delta=delta)
         w.benv.o[3, 20] = float("nan")                               # an entry the env carries along unchanged
-    w.benv.reset_all = poisoned_reset
+    w.benv.launch_reset = poisoned_reset
     ep, cp, n_ep = w.generate_rollouts()
-    w.benv.reset_all = reset_all
+    w.benv.launch_reset = launch_reset
     assert getattr(w, '_pending', None) is not None
     agent.store_episode(ep, cp, n_ep)
     torch.cuda.synchronize()
@@ -380,81 +380,3 @@ def test_training_learns_the_synthetic_arm_and_reproduces_the_committed_curve(tm
     ref = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r03_learning_curve_arm4.csv'))))
     want = [float(r['test/success_rate']) for r in ref[:71]]
     assert got == want, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:5]
-
-
-@pytest.mark.parametrize('layers', [3, 2])
-def test_one_launch_update_equals_the_two_launch_update(layers):
-    """ddpg_step_kernel (the row groups, each followed by its share of the weight-gradient / optimiser tiles, in ONE
-    launch: option "one_launch" = 1; not the default -- it measured slower, DESIGN 4.5 -- but a supported route) against
-    ddpg_rows_kernel followed by dw_adam_her_kernel: parameters, moments, losses,
-    the batches drawn for the following updates and the step counter, bit for bit -- eager launches and chained graphs;
-    the counters the workgroups synchronise on are back at zero after every launch."""
-    from curious_amd import ops
-    agents = []
-    for one in (1, 0):
-        with ops.option('one_launch', one):
-            before = ops.prof_launch_counts()
-            a, _ = _filled_agent(use_graph=False, layers=layers)
-            g, _ = _filled_agent(use_graph=True, layers=layers)
-            losses = []
-            for _ in range(7):
-                l, q = a.train()
-                losses.append((float(l), q.clone()))
-            g.train_batches(7)                                       # 1 single-update graph + a chain of 6
-            a.train_batches(6)
-            g.train_batches(6)
-            torch.cuda.synchronize()
-            after = ops.prof_launch_counts()
-            ran = {k for k in after if after[k] > before.get(k, 0)}
-            assert ('ddpg_step_kernel' in ran) == bool(one)
-            assert ('dw_adam_her_kernel' in ran) == (not one) and ('ddpg_rows_kernel' in ran) == (not one)
-            agents.append((a, g, losses))
-    for x, y in zip(agents[0][:2], agents[1][:2]):
-        assert torch.equal(x.theta, y.theta) and torch.equal(x._m, y._m) and torch.equal(x._v, y._v)
-        assert torch.equal(x._staged, y._staged) and torch.equal(x.grad, y.grad)
-        assert int(x._step_ctr) == int(y._step_ctr) == 13 == x.Q_adam.t
-        assert torch.equal(x._losses, y._losses) and torch.equal(x._Q_pi, y._Q_pi)
-    assert torch.equal(agents[0][0].theta, agents[0][1].theta)      # eager == graph
-    for (l1, q1), (l0, q0) in zip(agents[0][2], agents[1][2]):
-        assert l1 == l0 and torch.equal(q1, q0)
-    for a in agents[0][:2]:
-        fault = ops.fault_word(a.net_cfg, a.batch_size, a._workspace)
-        off = fault.data_ptr() - a._workspace.data_ptr()
-        words = a._workspace.view(torch.int32)[off // 4: off // 4 + 64]
-        assert int(words.abs().sum()) == 0                           # fault word and the four counters
-        a.check_faults()
-
-
-def test_one_launch_update_reports_a_missing_handoff():
-    """The guard of the Q' hand-off inside ddpg_step_kernel: the consumers give up, the tiles behind them still run (they
-    wait 8 x longer than the consumers), see the fault word and leave theta / m / v alone; the counters are back at zero,
-    check_faults raises and clears, the next update is clean and equals the two-launch route's."""
-    from curious_amd import ops
-    from curious_amd.ddpg import HandoffFault
-    with ops.option('one_launch', 1):
-        agent, _ = _filled_agent(use_graph=False)
-        ref, _ = _filled_agent(use_graph=False)
-        agent.train_batches(3)
-        torch.cuda.synchronize()
-        before = [x.clone() for x in (agent.theta, agent._m, agent._v)]
-        with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
-            loss, _ = agent.train()
-            torch.cuda.synchronize()
-        block = ops.fault_word(agent.net_cfg, agent.batch_size, agent._workspace, 64)
-        assert int(block[0]) == 4 and int(block[16:20].abs().sum()) == 0 and not np.isfinite(float(loss))
-        assert all(torch.equal(a, b) for a, b in zip(before, (agent.theta, agent._m, agent._v)))
-        with pytest.raises(HandoffFault):
-            agent.check_faults()
-        assert int(block.abs().sum()) == 0
-        agent.train()
-        torch.cuda.synchronize()
-        assert not torch.equal(before[0], agent.theta) and torch.isfinite(agent.theta).all()
-    # the same sequence on the two-launch route: 3 updates, 1 skipped (it still draws the next batch), 1 clean
-    ref.train_batches(3)
-    with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
-        ref.train()
-    with pytest.raises(HandoffFault):
-        ref.check_faults()
-    ref.train()
-    torch.cuda.synchronize()
-    assert torch.equal(ref.theta, agent.theta) and torch.equal(ref._staged, agent._staged)

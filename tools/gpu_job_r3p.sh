@@ -29,7 +29,6 @@ CURIOUS_RESIDENT=0 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-ba
 head -c 600 $O/bench_kernel_stats.csv; cat $O/pmc_hbm.txt | tail -20; tail -n 2 $O/*.err
 timeout 200 python tools/cycle_timeline.py 2>&1 | grep -v amdgpu.ids > $O/cycle_timeline.txt
 ( timeout 200 python tools/exploit_cycle_probe.py --cycles 200; timeout 200 python tools/exploit_cycle_probe.py --cycles 200 --no-freeze; timeout 200 python tools/exploit_cycle_probe.py --cycles 200 --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 ) 2>&1 | grep -v amdgpu.ids > $O/cycle_probe.txt
-( CURIOUS_ONE_LAUNCH=1 timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one_launch=1:', d['ms_per_step'], 'ms per cycle', {k: v['avg_us'] for k, v in d['kernels'].items() if 'ddpg' in k or 'dw' in k})"; CURIOUS_ONE_LAUNCH=1 timeout 100 python tools/step_stamps.py ) 2>&1 | grep -v amdgpu.ids > $O/step_lab_tail.txt
 ( timeout 100 tools/rows_lab 256; timeout 100 tools/rows_lab 512 | grep '^B\|per launch'; timeout 100 tools/rows_lab 64 | grep '^B\|per launch\|actor side  (sh' ) > $O/rows_lab.txt 2>&1
 cd $O && export PYTHONPATH=$R
 ( time timeout 600 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --n_epochs 150 --n_cycles 25 --n_batches 40 --rollout_batch_size 256 --seed 1 > learn_curious.log 2>&1 ) 2> time_curious.txt
