@@ -35,9 +35,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // device code, one section per header (all part of this translation unit)
 #include "mlp_common.h"
 #include "mlp_generic.h"
+#include "mlp_adam_fuse.h"
 #include "mlp_lean_gemm.h"
+#include "mlp_dw.h"
 #include "mlp_layer0.h"
 #include "mlp_heads.h"
+#include "mlp_act_step.h"
 #include "mlp_rows.h"
 #include "mlp_rows_act.h"
 #include "mlp_rows_res.h"

@@ -1,0 +1,441 @@
+// Weight-gradient tiles with Adam in the epilogue, the small-problem tiles, the loss finalisation and the update's tail
+// launch dw_adam_her_kernel / dw_all_kernel (included by mlp.hip after mlp_lean_gemm.h: GemmHot, hot_store).
+#pragma once
+
+// C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
+struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
+template <bool ADAM>
+__device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const int t, float* red,
+                                   const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
+                                   const AdamEarly* given = nullptr) {
+  const int nx = P.N >> 6;
+  int by, bx;
+  tile_divmod(t, nx, by, bx);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int k0 = by * 16, n0 = bx * 64;
+  const float* xu = P.A + eo + k0;                           // (uniform parts; lane parts below, ld_su)
+  const float* yu = P.B + eo + n0;
+  const uint32_t xo = (uint32_t)(4 * q * P.lda + j) * 4u;
+  const uint32_t yo = (uint32_t)(4 * q * P.ldb + 4 * j) * 4u;
+  // optimiser operands of the tile element this thread finishes (and of the bias column it finishes when by == 0);
+  // pidx / bidx = parameter indices (the same for every expert), addressed at index + eo
+  const int64_t toff = (int64_t)(k0 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
+  float* const dst = P.C + eg + toff;
+  const int64_t pidx = ADAM ? (int64_t)(P.C - A.grad) + toff : 0;
+  const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
+  AdamPre4 pre;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  bool faulted = false;
+  AdamEarly early;
+  if (ADAM) {
+    early = given ? *given : adam_early(A, eo);
+    pre = adam_prefetch4(A, pidx + eo);
+    if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+  }
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < P.M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
+        b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
+      }
+    }
+    LOADS_FIRST();
+    DW_STAMP(stamps, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bsum += b[u][s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
+      }
+  }
+  DW_STAMP(stamps, 2);
+  if (ADAM) {
+    // the matrix instructions are issued: the step counter has long arrived, the look-up of the step sizes hides behind
+    // the reduction of the tile.  (Outside the loop on purpose: a pinned value redefined inside it becomes loop-carried,
+    // and the copy in front of the loop waits for the load -- before the tile's operands are even requested.)
+    adam_alphas_late(A, early, aQ, aPi, eo);
+    faulted = adam_early_faulted(A, early);
+  }
+  f32x4 v; int orow, c4;
+  hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  *reinterpret_cast<f32x4*>(dst) = v;
+  if (ADAM && !faulted) {
+    adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
+    // transposed copy of the updated tile for the row-local backward layers (mlp_rows.h): WT[n][k] = W[k][n]
+    if (P.dot_out) {
+      float* t = P.dot_out + eo + (int64_t)(n0 + 4 * (tid & 15)) * P.K + k0 + (tid >> 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[(int64_t)e * P.K] = pre.th[e];
+    }
+  }
+  if (by == 0) {
+    // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+      P.aux_out[eg + n0 + tid] = gb;
+      if (ADAM && !faulted) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+      }
+    }
+  }
+}
+
+
+// Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
+//   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
+struct DwSmall {
+  const float* x; const float* dY; float* dW; float* db;
+  int32_t ldx, lddy, w, N;
+  float div;
+};
+#define MAX_DW_SMALL 12
+struct DwSmallArgs {
+  DwSmall p[MAX_DW_SMALL]; int32_t nprob, M, slots; LossFin fin;   // `slots` block ids per problem
+};
+
+// One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
+// layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
+// load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
+template <bool ADAM, bool YV>
+__device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
+                                     const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
+                                     const AdamEarly* given = nullptr) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nx = (P.N + 63) >> 6;
+  int by, bx;
+  tile_divmod(t, nx, by, bx);
+  const int j = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int k0 = by * 16, n0 = bx * 64;
+  const int krow = k0 + j, col = n0 + 4 * j;
+  const bool k_ok = krow < P.w;
+  const int colc = YV ? min(col, P.N - 4) : 0;
+  const float* xu = P.x + eo;                                 // (uniform parts; lane parts below, ld_su)
+  const float* yu = P.dY + eo;
+  const uint32_t xo = (uint32_t)(4 * q * P.ldx + min(krow, P.w - 1)) * 4u;
+  const uint32_t yo = (uint32_t)(4 * q * P.lddy + colc) * 4u;
+  // optimiser operands of what this thread finishes, fetched with the first batch of loads
+  const int grow = k0 + (tid >> 4), gcol = n0 + 4 * (tid & 15);
+  const bool own = grow < P.w && gcol < P.N;
+  float* const dst = P.dW + eg + (int64_t)(own ? grow : 0) * P.N + (own ? gcol : 0);
+  const int64_t pidx = ADAM ? (int64_t)(dst - eg - A.grad) : 0;      // parameter index, addressed at index + eo
+  const bool own_b = P.db && by == 0 && tid < 64 && n0 + tid < P.N;
+  const int64_t bidx = (ADAM && own_b) ? (int64_t)(P.db + n0 + tid - A.grad) : 0;
+  float aQ = 0.f, aPi = 0.f, bm = 0.f, bv = 0.f, bth = 0.f;
+  AdamPre4 pre;
+  pre.m = zero4(); pre.v = zero4(); pre.th = zero4();
+  bool faulted = false;
+  AdamEarly early;
+  if (ADAM) {
+    early = given ? *given : adam_early(A, eo);
+    if (YV) {
+      pre = adam_prefetch4(A, (own ? pidx : 0) + eo);
+    } else if (own) {                                       // N == 1: one element per owning thread
+      pre.m[0] = A.m[pidx + eo]; pre.v[0] = A.v[pidx + eo]; pre.th[0] = A.theta[pidx + eo];
+    }
+    if (own_b) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+  }
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 bsum = zero4();
+  for (int mb = 0; mb < M; mb += 256) {
+    float a[4][4];
+    f32x4 b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
+        if (YV) {
+          b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+        } else {
+          b[u][s] = zero4();
+          b[u][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+        }
+      }
+    }
+    LOADS_FIRST();
+    DW_STAMP(stamps, 1);
+    if (P.div != 1.0f) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[u][s] = fdiv(a[u][s], P.div);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = k_ok ? a[u][s] : 0.f;
+        bsum += b[u][s];
+        if (YV) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
+        } else {
+          acc[0] = MFMA(av, b[u][s][0], acc[0]);
+        }
+      }
+  }
+  DW_STAMP(stamps, 2);
+  if (ADAM) {
+    adam_alphas_late(A, early, aQ, aPi, eo);
+    faulted = adam_early_faulted(A, early);
+  }
+  int orow, c4;
+  f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  if (own) {
+    const float na = (pidx < A.n_Q) ? -aQ : -aPi;
+    if (YV) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+      if (ADAM && !faulted) adam_apply4(A, na, pidx + eo, v, pre);
+    } else {
+      dst[0] = v[0];                                        // N == 1 (gcol == 0)
+      if (ADAM && !faulted) {
+        float m = pre.m[0], vv = pre.v[0];
+        const float th = adam_elem(A, na, v[0], m, vv, pre.th[0]);
+        A.m[pidx + eo] = m; A.v[pidx + eo] = vv; A.theta[pidx + eo] = th;
+      }
+    }
+  }
+  if (P.db && by == 0) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (own_b) {
+      float gb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+      P.db[eg + n0 + tid] = gb;
+      if (ADAM && !faulted) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+      }
+    }
+  }
+}
+
+// losses (ddpg.py:439-441) from the per-row terms, summed in a fixed order
+__device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t eo, const int64_t eg) {
+  const int tid = threadIdx.x;
+  {
+    float lq = 0.f, lp = 0.f, ll = 0.f;
+    for (int m = tid; m < F.Bl; m += 256) {                  // (the first rank's rows; the others: loss_fin_ranks)
+      lq += F.rows[eo + m];
+      lp += F.rows[eo + F.B + m];
+      ll += F.rows[eo + 2 * F.B + m];
+    }
+    red[tid] = lq; red[256 + tid] = lp; red[512 + tid] = ll;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+      if (tid < h) {
+        red[tid] += red[tid + h];
+        red[256 + tid] += red[256 + tid + h];
+        red[512 + tid] += red[512 + tid + h];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float invB = 1.0f / (float)F.Bl;
+      if (F.step_ctr) *ex_i64(F.step_ctr, eo) += 1;
+      loss_fin_flag(F, eo, eg);
+      F.out[eo + 0] = red[0] * invB;
+      F.out[eo + 1] = -red[256] * invB + F.action_l2 * red[512] / (float)(F.Bl * F.U);
+    }
+    if (F.Bl < F.B) loss_fin_ranks(F, F.rows + eo, F.out + eo);
+  }
+}
+
+// Every weight/bias gradient of both networks + the loss finalisation in ONE launch: blocks [0, n_hot) run the
+// hidden-layer tiles, the rest the small-problem tile list (the two lists are independent, so splitting them over two
+// launches only bought a second ~4.5 us dependent stage).
+// (batched experts: blockIdx.y = expert, as in dw_adam_her_kernel below)
+// XCD-aware block placement (xcd = 1; grid.x = 8 * (r_her + r_hot + r_small)).  Workgroups are dealt round-robin over
+// the 8 XCDs in block-id order, so x = blockIdx.x & 7 IS the XCD and r = blockIdx.x >> 3 a row of 8 blocks, one per XCD:
+//   r <  r_her                : gather block r * 8 + x
+//   r <  r_her + r_hot        : hidden-layer tile; XCD x owns `units`-th part u = x % units of matrix x / units -- its
+//                               r_hot = 64 / units tiles are the row strips [u, u + 1) * 16 / units x all 4 column panels,
+//                               i.e. ONE XCD's L2 fetches that part of X and the matrix's dY once, instead of every XCD
+//                               fetching a quarter panel of every matrix (1.25 MB per XCD at Arm4 -> 0.38 MB)
+//   otherwise                 : small problem p = x + 8 * (j / slots), tile j % slots (j = r - r_her - r_hot): the tiles
+//                               of one small problem share an XCD; the block behind the last problem finalises the losses
+// Speed only -- nothing depends on the placement for correctness.
+// The routing scalars travel as the kernel's LEADING arguments: with -mllvm -amdgpu-kernarg-preload-count they arrive in
+// scalar registers with the wave (kernarg preloading, gfx940+), so a block knows its role without a single memory access.
+// That matters because reads of the kernarg segment are not cached on this machine: EVERY dependent s_load of an argument
+// costs a full ~3 k-cycle (1.4 us) round trip (tools/dw_stamps.py: a block that finds it has nothing to do used to need
+// 3 k cycles to find out; a hidden tile issued its operand loads 6 k cycles after its start, a small tile 10-12 k).
+struct DwMap { int32_t r_her, r_hot, units; };                // units == 0: plain block order
+struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; };
+// lab (a build with -DDW_STAMPS, tools/build_variant.py, + option "lab_dw_stamps"): 8 x 64-bit words per block of expert 0 -- [0] entry, [1] operand loads issued /
+// gather: tables in, [2] MFMA loop over / gather: rows in LDS, [3] exit, [4] kind (0 gather, 1 hidden tile, 2 small),
+// [5] s_memrealtime at entry (100 MHz, device-wide)
+__device__ inline unsigned long long* dw_stamp_base(const DwAllArgs& a) {
+  return (a.stamps && blockIdx.y == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+}
+struct DwRole { int kind, pi, idx; };
+__device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, const int hot_nprob, const int slots,
+                                          const int n_her, const int r_her, const int r_hot, const int units) {
+  DwRole R;
+  R.kind = -1; R.pi = 0; R.idx = 0;
+  const int b = (int)blockIdx.x;
+  if (units == 0) {
+    const int bid = b - n_her;
+    if (bid < 0) { R.kind = 0; R.idx = b; }
+    else if (bid < n_hot) { R.kind = 1; R.pi = bid / tiles_per; R.idx = bid - R.pi * tiles_per; }
+    else { R.kind = 2; R.idx = bid - n_hot; }
+    return R;
+  }
+  const int x = b & 7;
+  int r = b >> 3;
+  if (r_her < 0) {
+    // r_her < 0: the -r_her rows of gather blocks come LAST instead of first (batches of several virtual ranks: the
+    // hidden tiles, each a long reduction over V x 256 rows, are then dispatched together at the start of the launch
+    // and walk the rows in step -- the tiles of an XCD share X strips and dY panels through its L2 only while they do)
+    const int rows = (int)gridDim.x >> 3, gr = -r_her;
+    if (r >= rows - gr) {
+      const int i = (r - (rows - gr)) * 8 + x;
+      if (i < n_her) { R.kind = 0; R.idx = i; }
+      return R;
+    }
+    r += gr;                                                 // (the rest of the map as if the gather rows came first)
+  }
+  const int r_her_ = r_her < 0 ? -r_her : r_her;
+  if (r < r_her_) {
+    if (r * 8 + x < n_her) { R.kind = 0; R.idx = r * 8 + x; }
+    return R;
+  }
+  r -= r_her_;
+  if (r < r_hot) {
+    const int pi = x / units, u = x - pi * units;
+    if (pi < hot_nprob) { R.kind = 1; R.pi = pi; R.idx = u * r_hot + r; }
+  } else {
+    const int j = r - r_hot;
+    const int p = x + 8 * (j / slots);
+    R.kind = 2; R.idx = p * slots + j % slots;
+  }
+  return R;
+}
+// One batch of argument loads per block: a by-value copy of everything the role needs, taken through an empty asm that
+// wants every field in a scalar register AT THIS POINT -- the compiler then issues all the s_loads together and waits
+// once, instead of fetching field by field, branch by branch (one uncached round trip each).
+// (Input-only operands: the values must be in scalar registers at this point, but they are not redefined -- a pointer that
+//  came OUT of an asm would have lost its provenance, and the compiler would address it with FLAT instructions, which cost
+//  an s_waitcnt vmcnt(0) lgkmcnt(0) whenever their results are needed and cannot be counted past.)
+__device__ __forceinline__ void pin_hot(const GemmHot& P) {
+  asm volatile("" :: "s"(P.A), "s"(P.B), "s"(P.C), "s"(P.aux_out), "s"(P.dot_out), "s"(P.lda), "s"(P.ldb), "s"(P.ldc),
+               "s"(P.M), "s"(P.N), "s"(P.K));
+}
+__device__ __forceinline__ void pin_small(const DwSmall& P) {
+  asm volatile("" :: "s"(P.x), "s"(P.dY), "s"(P.dW), "s"(P.db), "s"(P.ldx), "s"(P.lddy), "s"(P.w), "s"(P.N), "s"(P.div));
+}
+__device__ __forceinline__ void pin_adam(const AdamFuse& A) {
+  asm volatile("" :: "s"(A.theta), "s"(A.m), "s"(A.v), "s"(A.grad), "s"(A.n_Q), "s"(A.alpha_tab), "s"(A.step_ctr),
+               "s"(A.tab_base), "s"(A.tab_len), "s"(A.a_Q), "s"(A.a_pi), "s"(A.b1), "s"(A.omb1), "s"(A.b2), "s"(A.omb2),
+               "s"(A.eps), "s"(A.fault));
+}
+
+// (the leading scalars: preloaded into SGPRs, see DwMap)
+#define DW_ROUTE_PARAMS const int tiles_per, const int hot_nprob, const int slots, const int small_nprob, const int n_her, \
+                        const int r_her, const int r_hot, const int units
+// the tile work of a block whose role is known: ONE batch of argument loads, then the tile
+template <bool ADAM>
+__device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& args, const AdamFuse& A_, const int slots,
+                                             const int small_nprob, float* red, const int64_t eo, int64_t grad_stride,
+                                             DwStamp* sp, const AdamEarly* early) {
+  AdamFuse A = A_;
+  if (R.kind == 1) {
+    GemmHot P = args.hot.p[R.pi];
+    pin_hot(P);
+    if (ADAM) pin_adam(A);
+    asm volatile("" :: "s"(grad_stride));
+    DW_STAMP(sp, 3);
+    dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, sp, early);
+    return;
+  }
+  const int pi = R.idx / slots, t = R.idx - pi * slots;
+  if (pi >= small_nprob) {
+    // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
+    if (pi == small_nprob && t == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
+    return;
+  }
+  DwSmall P = args.small.p[pi];
+  int M = args.small.M;
+  pin_small(P);
+  if (ADAM) pin_adam(A);
+  asm volatile("" :: "s"(grad_stride), "s"(M));
+  DW_STAMP(sp, 3);
+  if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
+  const int64_t eg = (int64_t)blockIdx.y * grad_stride;
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, sp, early);
+  else dw_small_tile<ADAM, false>(P, M, A, t, red, eo, eg, sp, early);
+}
+
+__global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
+                                                     int64_t grad_stride) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  AdamFuse none;
+  none.fault = nullptr;
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, 0, r_her, r_hot, units);
+  if (R.kind > 0) dw_tile_role<false>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
+}
+
+// The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
+// applied in the tile epilogue, the loss finalisation, and -- in the first n_her blocks -- the HER gather of the NEXT
+// update's batch (it depends on nothing this update computes; it must target a different staging buffer than the one
+// the layer-0 gradient tiles of this launch still read).
+// Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
+// sampler seed is h.rng.seed + expert * seed_stride.
+__global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
+                                                          int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
+                                                          int64_t grad_stride, uint64_t seed_stride) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+#ifdef DW_STAMPS
+  DwStamp stamp;
+  stamp.t[0] = __builtin_readcyclecounter();                 // (before anything of the arguments is read)
+  stamp.t[1] = stamp.t[2] = stamp.t[3] = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  DwStamp* sp = &stamp;
+#else
+  DwStamp* sp = nullptr;
+#endif
+  const int64_t eo = (int64_t)blockIdx.y * ex_stride;
+  const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, n_her, r_her, r_hot, units);
+  if (R.kind == 0) {
+    her_sample_body(h, R.idx, red, eo, (uint64_t)blockIdx.y * seed_stride, 0, sp);
+  } else if (R.kind > 0) {
+    // the optimiser's two scalar inputs (fault word, step counter): their pointers came with the wave, so the loads go
+    // out before the first argument is fetched from memory (fault0 / ctr0 == A.fault / A.step_ctr or a valid dummy)
+    AdamEarly early;
+    {
+      early.fw = *reinterpret_cast<const int32_t*>(reinterpret_cast<const float*>(fault0) + eo);
+      const int64_t c = *ex_i64(ctr0, eo);
+      early.lo = (int32_t)c; early.hi = (int32_t)(c >> 32);
+    }
+    dw_tile_role<true>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
+  }
+#ifdef DW_STAMPS
+  unsigned long long* st = dw_stamp_base(args);
+  if (st && threadIdx.x == 0) {
+    st[0] = stamp.t[0]; st[1] = stamp.t[1]; st[2] = stamp.t[2]; st[3] = __builtin_readcyclecounter();
+    st[4] = (unsigned long long)(R.kind + 1); st[5] = rt0;
+    st[6] = stamp.t[3]; st[7] = (unsigned long long)R.idx;
+  }
+#endif
+}
