@@ -513,3 +513,28 @@ def test_activity_flags_evaluated_by_the_routing_launch():
         n = int(res[0][2][v])
         for k in (4, 5):
             assert torch.equal(res[0][k][v * per * NB:v * per * NB + n], res[1][k][v * per * NB:v * per * NB + n])
+
+
+# ------------------------------------------------------------------ several ranks: a replayed run on the fused IPC path
+def test_guarded_replay_on_the_ipc_path_two_ranks():
+    """DDPG.train_batches_guarded rewinds the Adam step counter and replays the run -- on the fused IPC
+    all-reduce + Adam path, whose hand-shake tokens USED to be that counter (a replayed wait would have fallen through on the
+    flags of the first attempt).  Tokens are an epoch word of their own now: two ranks, rank 1 loses a producer of Q' on the
+    first attempt of a guarded run, both ranks see the collective flag, both replay; the parameters end bit for bit where
+    the run without the fault ends -- and where the gloo all-reduce + stand-alone optimiser path ends."""
+    import subprocess
+    import sys
+    from test_gpu_round4 import _free_port, _two_rank_env
+    digests = {}
+    for mode, guarded in (('ipc', 'inject'), ('ipc', 'clean'), ('rccl', 'inject')):
+        prefix = os.path.join(tempfile.mkdtemp(), 'digest')
+        env = _two_rank_env(CURIOUS_RANK_CHECK_OUT=prefix, CURIOUS_ALLREDUCE=mode, HSA_ENABLE_IPC_MODE_LEGACY='0',
+                            CURIOUS_RANK_CHECK_GUARDED=guarded, CURIOUS_RANK_CHECK_NOGRAPH='1')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tools', 'rank_path_check.py')]
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (mode, guarded, out.stdout[-1500:], out.stderr[-3000:])
+        found = [open('%s.rank%d' % (prefix, r)).read().split() for r in range(2)]
+        assert found[0][1] == found[1][1] and found[0][2] == found[1][2] == '45', (mode, guarded, found)
+        digests[(mode, guarded)] = found[0][1]
+    assert len(set(digests.values())) == 1, digests

@@ -25,6 +25,30 @@ def main():
     policy.train_batches(30)
     for _ in range(int(os.environ.get('CURIOUS_RANK_CHECK_EXTRA', '0'))):      # (debugging aid: runs of 100 updates, no rollout)
         policy.train_batches(100)
+    # optional: a guarded run of 6 updates (DDPG.train_batches_guarded, --fault_check sync) in which rank 1 loses a producer
+    # of Q' on the FIRST attempt ('inject') or not at all ('clean'): every rank sees the collective flag, every rank replays
+    # the run from the state it started with -- the digest must be the clean run's
+    guarded = os.environ.get('CURIOUS_RANK_CHECK_GUARDED')
+    if guarded:
+        from curious_amd import ops
+        calls, plain = [0], policy.train_batches
+
+        def train_batches(n):
+            calls[0] += 1
+            if guarded == 'inject' and calls[0] == 1 and dist.rank() == 1:
+                with ops.option('fault_inject', 3), ops.option('qt_spins', 20000):
+                    out = plain(n)
+                    torch.cuda.synchronize()
+                    return out
+            return plain(n)
+        policy.train_batches = train_batches
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            policy.train_batches_guarded(6)
+        policy.train_batches = plain
+        assert calls[0] == (2 if guarded == 'inject' else 1), calls
+        policy.train_batches(4)
     # optional: whole cycles (rollout + store + updates) so that ranks diverge in data and must agree through collectives
     for _ in range(int(os.environ.get('CURIOUS_RANK_CHECK_CYCLES', '0'))):
         bench.cycle(policy, worker)
