@@ -282,16 +282,18 @@ def profile_pass(policy, worker, n_cycles=1, bank=None, step=None):
     return stats, overhead_ms, t_plain / N_BATCHES
 
 
-def pmc_traffic_file():
-    return next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic.json' % r) for r in (4, 3, 2, 1))
-                 if os.path.exists(p)), '')
+def pmc_traffic_file(virtual_ranks=1):
+    """The committed PMC passes of this command: per round; a --virtual-ranks V line has passes of its own or none."""
+    suffix = '' if virtual_ranks == 1 else '_virtual_ranks_%d' % virtual_ranks
+    return next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic%s.json' % (r, suffix))
+                             for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), '')
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, virtual_ranks=1):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
     the bytes of 16-byte-per-lane streaming reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  None if absent."""
-    path = pmc_traffic_file()
+    path = pmc_traffic_file(virtual_ranks)
     try:
         with open(path) as f:
             table = json.load(f)
@@ -338,11 +340,11 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms, n_experts=1):
     else:
         ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, 'GB/s'
     out = dict(kernel=dominant, bound=w['bound'], achieved=round(ach, 4), peak=peak, unit=unit,
-               frac=round(ach / peak, 5), traffic=pmc_traffic(dominant),
+               frac=round(ach / peak, 5), traffic=pmc_traffic(dominant, getattr(policy, 'V', 1)),
                # PMC counters cannot be read from inside the process: the figure comes from the committed rocprofv3 --pmc
                # passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not from this run
                traffic_source='%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, committed; not '
-                              'measured in this run)' % os.path.relpath(pmc_traffic_file() or 'none', ROOT),
+                              'measured in this run)' % os.path.relpath(pmc_traffic_file(getattr(policy, 'V', 1)) or 'none', ROOT),
                algorithmic_per_launch=round(per_launch, 1),
                avg_launch_us=round(avg_s * 1e6, 3), event_bracket_overhead_us=round(overhead_ms * 1e3, 3))
     if 'l2_stream_bytes' in w:

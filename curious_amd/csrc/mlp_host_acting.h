@@ -213,8 +213,7 @@ static int policy_act_env_steps(const curious_net_cfg_t* cfg, const float* theta
     a.flags = flags;
     a.rg = rg;
     // the exchange buffer of the resident form is the head of the workspace (the row-local routes use nothing else of it)
-    // (relative goals: the streaming kernel -- the resident form does not carry the goal part through its exchanges)
-    if (!relative_goals && resident_ok(a, n, workspace) &&
+    if (resident_ok(a, n, workspace) &&
         (int64_t)res_xbuf_floats(n) <= curious_workspace_floats(cfg, n) && aligned16(workspace))
       return launch_policy_resident(a, n, workspace, curious_workspace_floats(cfg, n), st);
     return launch_policy_rows(a, n, st);

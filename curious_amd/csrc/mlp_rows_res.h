@@ -155,7 +155,11 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
       } else if (k < Sc) {
         v = 0.f;
       } else {
-        v = fclip(a.g[r * a.ldg + (k - Sc)], -c, c);
+        // (relative goals, ddpg.py:119-124: g - ag -- every member holds the whole input row of its 4 envs and runs the
+        //  env step itself, so the goal part is re-derived from the new achieved goal on every member, env_step_core)
+        v = a.g[r * a.ldg + (k - Sc)];
+        if (a.ag) v = __fsub_rn(v, a.ag[r * a.ldag + (k - Sc)]);
+        v = fclip(v, -c, c);
         if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - Sc]), a.g_std[k - Sc]), -a.nclip, a.nclip);
       }
       x.xin[i * XLD + k] = v;
@@ -255,11 +259,11 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     if (member == 0)
       ov = env_step_core<true>(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
                                a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip,
-                               InNorm{a.o_mean, a.o_std, a.nclip});
+                               InNorm{a.o_mean, a.o_std, a.nclip, a.ag ? Sc : -1, a.g_mean, a.g_std});
     else
       ov = env_step_core<false>(a.E, a.L, a.env_id0, ec, s_u, a.t + s, ov, a.eo, a.eag, a.staging, a.off_change,
                                 a.off_success, a.reward_eps, m, x.lane, a.flags, a.n, nin, a.clip,
-                               InNorm{a.o_mean, a.o_std, a.nclip});
+                                InNorm{a.o_mean, a.o_std, a.nclip, a.ag ? Sc : -1, a.g_mean, a.g_std});
     RES_STAMP(6);
     if (rx.stamps && blockIdx.x == 0 && x.tid == 0) rx.stamps[7] += 1;
   }

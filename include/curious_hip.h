@@ -577,7 +577,8 @@ int curious_policy_rollout(const curious_net_cfg_t* cfg, const float* theta, int
  * 2 dim + 1, std at 3 dim + 1), applied to the clipped observation and goal on their way into the policy -- at the start
  * of the launch and, inside it, to every new observation the env step hands to the next acting step.  NULL statistics =
  * the entry points above.  relative_goals != 0 (ddpg.py:118-127): the policy sees g - ag, recomputed from the new
- * achieved goal after every env step (the row-local streaming kernel; the weights-resident form is not taken). */
+ * achieved goal after every env step (streaming and weights-resident kernel alike: every member of a resident group holds
+ * the whole input row and runs the env step itself). */
 int curious_policy_act_env_step_stats(const curious_net_cfg_t* cfg, const float* theta, int32_t n, float clip_obs,
                                       float* workspace, double noise_scale, double random_eps, uint64_t seed,
                                       uint64_t counter, const int64_t* counter_base, float* u_out, int32_t ldu,
