@@ -94,6 +94,8 @@ struct CuriousOptions {
   int dw_xcd;          // 1: blocks of the weight-gradient / optimiser launch placed by XCD (mlp_lean_gemm.h DwMap)  [CURIOUS_DW_XCD]
   int rows_pre;        // 1: the row-local launch's role / input rows / first layer-0 matrix travel as leading kernel arguments
                        //    (mlp_rows.h RowsPre; 0 = fetched from the argument segment as before: A/B)  [CURIOUS_ROWS_PRE]
+  int rows8;           // 1: the row-local update gives 8 batch rows to a workgroup for batches of >= 768 rows (virtual ranks);
+                       //    0: always 4 (A/B)                                                       [CURIOUS_ROWS8]
   int lab_dw_stamps;   // LAB ONLY (tools/dw_stamps.py): dw_adam_her_kernel writes per-block cycle stamps into the workspace
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere

@@ -44,6 +44,7 @@ struct DdpgPass {
   bool xn_rows = false;       // the row-local launch of this pass keeps the NORMALISED layer-0 input rows in w.xn
   RowsArgs ra;
   size_t ra_lds = 0;
+  int ra_R = ROWS_R;                                         // batch rows per workgroup of the row-local launch (4 | 8)
   int launch_rows();
   int forward();
   int critic_backward();
@@ -142,23 +143,28 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.gamma = cfg->gamma; a.clip_lo = -cfg->clip_return; a.clip_hi = cfg->clip_pos_returns ? 0.0f : INFINITY;
   a.max_u = cfg->max_u;
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(Bl * U));
-  const size_t lds = rows_lds_floats(nl) * sizeof(float);
+  // 8 rows per workgroup once every CU holds several row groups (mlp_rows.h ROWS_R2): the rows of a batch are independent,
+  // so the split changes no row's arithmetic
+  ra_R = (curious_options().rows8 && B >= ROWS_R2_MIN && B % (4 * ROWS_R2) == 0) ? ROWS_R2 : ROWS_R;
+  const size_t lds = rows_lds_floats(ra_R) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
-    // (the kernel also has ~1 KB of static LDS -- the task tables of its gather blocks: dynamic + static must stay <= 160 KB)
-    const int max_dyn = (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<true>),
+    // (the kernel also has ~1 KB of static LDS -- the task tables of its gather blocks: dynamic + static must stay <= 80 KB
+    //  for two workgroups to share a CU)
+    const int max_dyn = (int)(rows_lds_floats(ROWS_R2) * sizeof(float));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<true, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<true, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<false, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipGetLastError();                                 // a refusal here must not be mistaken for a failed launch
     lds_set = true;
   }
-  a.n_her = gather_in_rows ? B / ROWS_R : 0;                 // (SPB == ROWS_R: as many gather blocks as row groups)
+  a.n_her = gather_in_rows ? B / ROWS_R : 0;                 // gather blocks of ROWS_R (= SPB) transitions each; a spare
+                                                             // workgroup of the 8-row grid runs two of them
   ra = a;
   ra_lds = lds;
   if (launch_rows()) return -1;
@@ -173,7 +179,7 @@ int DdpgPass::launch_rows() {
   const Ex ex = make_ex(xd, 1);
   const RowsArgs& a = ra;
   const size_t lds = ra_lds;
-  dim3 grid((a.xmap || gather_in_rows ? 4 : 3) * (B / ROWS_R), 1, xd.nex);
+  dim3 grid((a.xmap || gather_in_rows ? 4 : 3) * (B / ra_R), 1, xd.nex);
   // the leading arguments (mlp_rows.h RowsPre: in scalar registers when the wave starts)
   const int Sa = a.dimo + a.dimtd, Sc = Sa + 4;
   const auto fits16 = [](int v) { return v >= 0 && v < 65536; };
@@ -188,19 +194,25 @@ int DdpgPass::launch_rows() {
   const uint32_t k2 = (uint32_t)a.off_o2 | ((uint32_t)a.off_g2 << 16);
   const uint32_t k3 = (uint32_t)a.off_u | ((uint32_t)a.dimo << 16) | ((uint32_t)a.dimtd << 24);
   const uint32_t k4 = pre_ok ? ((uint32_t)B | ((uint32_t)a.dimg << 16) | (1u << 25)) : 0u, k5 = 0u;
+#define ROWS_LAUNCH(kernel, EXF, RR, ...)                                                                      \
+  hipLaunchKernelGGL((kernel<EXF, RR>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch, k0, k1, k2, k3, k4, k5, a, ex, \
+                     ##__VA_ARGS__)
+#define ROWS_LAUNCH_R(kernel, EXF, ...)                                                                         \
+  do {                                                                                                          \
+    if (ra_R == ROWS_R2) ROWS_LAUNCH(kernel, EXF, ROWS_R2, ##__VA_ARGS__);                                      \
+    else ROWS_LAUNCH(kernel, EXF, ROWS_R, ##__VA_ARGS__);                                                       \
+  } while (0)
   if (gather_in_rows) {
     ProfScope ps__(CK_ROWS_HER, st);
-    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_her_kernel<true>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
-                                       k0, k1, k2, k3, k4, k5, a, ex, her_rows, seed_stride);
-    else hipLaunchKernelGGL((ddpg_rows_her_kernel<false>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
-                            k0, k1, k2, k3, k4, k5, a, ex, her_rows, seed_stride);
+    if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_her_kernel, true, her_rows, seed_stride);
+    else ROWS_LAUNCH_R(ddpg_rows_her_kernel, false, her_rows, seed_stride);
   } else {
     ProfScope ps__(CK_ROWS, st);
-    if (xd.nex > 1) hipLaunchKernelGGL((ddpg_rows_kernel<true>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
-                                       k0, k1, k2, k3, k4, k5, a, ex);
-    else hipLaunchKernelGGL((ddpg_rows_kernel<false>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch,
-                            k0, k1, k2, k3, k4, k5, a, ex);
+    if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_kernel, true);
+    else ROWS_LAUNCH_R(ddpg_rows_kernel, false);
   }
+#undef ROWS_LAUNCH_R
+#undef ROWS_LAUNCH
   CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");
   return 0;
 }

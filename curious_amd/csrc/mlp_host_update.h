@@ -211,7 +211,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
                   "curious_ddpg_grads: the next batch must be keyed by this call's step counter");
     if (her_fill_args(p.her_rows, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
                       next->batch, BL)) return -1;
-    p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(cfg->layers) * sizeof(float) &&
+    p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R) * sizeof(float) &&
                        (B % (ROWS_R * 4) == 0) && SPB == ROWS_R;
   }
   if (!rc && p.rows_route()) {

@@ -34,7 +34,12 @@
 #pragma once
 
 #define ROWS_MAXL 4          // layers per network on this route (layer 0 + up to 3 hidden layers)
-#define ROWS_R 4             // batch rows per workgroup
+#define ROWS_R 4             // batch rows per workgroup ...
+#define ROWS_R2 8            // ... or 8: batches of >= ROWS_R2_MIN rows (3 virtual ranks or more, section 4.7 of DESIGN.md: more row groups of 4 than the chip has workgroup slots).  Every CU then
+                             // holds several row groups and the launch is bound by the L2 -> CU weight stream in aggregate, not by
+                             // one chain's latency: with 8 rows a 16-byte load of W feeds 8 matrix instructions, the stream per
+                             // row halves.  (At B = 256 -- one chain per CU -- the 8-row form is the slower one: round 2.)
+#define ROWS_R2_MIN 768
 #define RLD 264              // LDS row stride of an activation row (8 mod 64: conflict-free b128 broadcast reads)
 #define ROWS_MAXIN 128       // widest layer-0 input [o | td | action | g] the row-local kernels take: two passes of 64 (rows_l0_fwd)
 #define XLD 132              // LDS row stride of that input row: 132 mod 64 = 4 puts the 4 rows a
@@ -99,7 +104,8 @@ struct RowsArgs {
 #endif
 struct RCtx {
   mutable unsigned long long* dbg;
-  float* hs; mutable float* part; mutable float* part2; float* xin; float* sm; float* keep;
+  float* hs; mutable float* part; mutable float* part2; float* xin; float* sm;
+  mutable uint64_t kb;            // relu' masks of the kept layers, R bits to a layer (rows_keep)
   int tid, wave, lane, r0;
 };
 // a result other workgroups read: the weight-gradient launch that follows
@@ -116,27 +122,27 @@ __device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
 #include "mlp_rows_layers.h"
 
 // ================================================================== the kernel
-// grid (4 * B / 4, 1, n_experts); B % 16 == 0.
-static inline size_t rows_lds_floats(int nl) {
-  return 4 * RLD + 2 * 4 * 4 * 256 + 4 * XLD + 64 + (size_t)2 * nl * 4 * 256;   // (two buffers of partials: rows_fw_finish)
+// grid (4 * B / R, 1, n_experts); B % (4 R) == 0.
+static inline size_t rows_lds_floats(int R = ROWS_R) {
+  return (size_t)R * RLD + 2 * 4 * R * 256 + R * XLD + 64;   // (two buffers of partials: rows_fw_finish) 39 KB | 77 KB
 }
 
 // HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
 // form keeps its 632-byte kernarg -- HerArgs adds 1.4 KB)
 // Returns the workgroup's role as an index: spare blocks [0, nrg), target groups nrg + row group, main-critic groups
 // 2 nrg + row group, actor-side groups 3 nrg + row group.
-template <bool EX, bool HER>
+template <bool EX, bool HER, int R>
 __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, const HerArgs* her,
                                               const uint64_t seed_stride, const RowsPre* pre = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float rows_lds[];
   RCtx x;
   x.dbg = nullptr;
   x.hs = rows_lds;
-  x.part = x.hs + 4 * RLD;
-  x.part2 = x.part + 4 * 4 * 256;
-  x.xin = x.part2 + 4 * 4 * 256;
-  x.sm = x.xin + 4 * XLD;
-  x.keep = x.sm + 64;                                       // [2 * nl][4 rows][256]: activations kept for relu'
+  x.part = x.hs + R * RLD;
+  x.part2 = x.part + 4 * R * 256;
+  x.xin = x.part2 + 4 * R * 256;
+  x.sm = x.xin + R * XLD;
+  x.kb = 0;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   // Kind of workgroup and row group from the block id.  Workgroups are dealt round-robin over the 8 XCDs in block-id
   // order (block b lands on XCD b % 8; speed only, nothing depends on it for correctness).  A layer's time is set by
@@ -153,18 +159,18 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   // come from the leading arguments when the host filled them (RowsPre: nothing is read from the argument segment up to
   // the `sched_barrier` below), else from the arguments proper; ONE site issues the loads either way.
   f32x4 wb[2][16];
-  float xraw[ROWS_IN_IT];
+  float xraw[ROWS_IN_IT(R)];
   int nrg, kind, rgrp, expert = 0, spare = -1;
   int64_t eo = 0;
   const bool pre_path = !EX && pre != nullptr && ((pre->k[4] >> 25) & 1u);
   // (the arguments proper are read inside `else` branches that end in an empty asm: a plain select between a leading
   //  argument and a fetched one would wait for the fetch on both paths)
   bool xmap = true;
-  nrg = (int)(pre_path ? (pre->k[4] & 0xffffu) : 0u) / ROWS_R;
+  nrg = (int)(pre_path ? (pre->k[4] & 0xffffu) : 0u) / R;
   if (!pre_path) {
     int bv = a.B, xm = a.xmap;
     asm volatile("" : "+s"(bv), "+s"(xm));
-    nrg = bv / ROWS_R;
+    nrg = bv / R;
     xmap = xm != 0;
   }
   if (xmap) {                                                // single agent, grid.x = 4 * nrg
@@ -183,106 +189,129 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   }
   if (kind == 3) {
     if (xmap) {
-      if (HER && spare < a.n_her) her_sample_body(*her, spare, rows_lds, 0, 0, 1);
+      if (HER) {                                             // (a gather block draws ROWS_R transitions: R / 4 of them here)
+#pragma unroll 1
+        for (int u = 0; u < R / 4; ++u) {
+          if ((R / 4) * spare + u < a.n_her) her_sample_body(*her, (R / 4) * spare + u, rows_lds, 0, 0, 1);
+          if (R > 4) __syncthreads();
+        }
+      }
       return spare;
     }
     int64_t ge;
     (void)ex_decode<EX>(ex, expert, ge);
-    if (HER && rgrp < a.n_her) her_sample_body(*her, rgrp, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
+    if (HER) {
+#pragma unroll 1
+      for (int u = 0; u < R / 4; ++u) {
+        if ((R / 4) * rgrp + u < a.n_her) her_sample_body(*her, (R / 4) * rgrp + u, rows_lds, ge, (uint64_t)expert * seed_stride, 1);
+        if (R > 4) __syncthreads();
+      }
+    }
     return rgrp;
   }
-  x.r0 = rgrp * ROWS_R;
+  x.r0 = rgrp * R;
   // what every kind derives from the arguments proper -- expanded INSIDE each kind's branch, behind the branch's first
   // loads (rows_first_loads): in front of the branches these lines would wait for the argument fetch before any load went out
 #define ROWS_COMMON()                                                                                            \
   (void)ex_decode<EX>(ex, expert, eo);                      /* one problem per expert */                        \
   const int nl = a.nl, Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;                                           \
   const float* batch = a.batch + eo; (void)batch;                                                                \
-  const int m = x.r0 + x.wave;                              /* the batch row whose output layers this wave finishes */ \
+  /* wave i finishes the output layers of the workgroup's rows i, i + 4, ...: `row` in the loops over hh below */ \
   const float invB = 1.0f / (float)a.Bl; (void)invB;                                                             \
-  float* sm_s = x.sm; (void)sm_s;                           /* [4] per-row scalar handed from wave i to the column threads */ \
-  float* sm_v = x.sm + 16; (void)sm_v;                      /* [4][4] per-row 4-vectors (pi, dz) */             \
-  unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + m; (void)qt; \
+  float* sm_s = x.sm; (void)sm_s;                           /* [R] per-row scalar handed from wave i to the column threads */ \
+  float* sm_v = x.sm + 16; (void)sm_v;                      /* [R][4] per-row 4-vectors (pi, dz) */             \
+  unsigned long long* qt = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(a.qt) + eo) + x.r0; (void)qt; \
   (void)Sc; (void)G; (void)nl
 
   if (kind == 1) {
     // ================================================= target group: pi' = target actor(o_2, g_2), Q' = target critic
-    rows_first_loads<EX>(x, a, ex, pre, pre_path, 1, rgrp, expert, wb[0], xraw);
+    rows_first_loads<EX, R>(x, a, ex, pre, pre_path, 1, rgrp, expert, wb[0], xraw);
     ROWS_COMMON();
     if (a.lab_no_target) return nrg + rgrp;
     const float* tp = a.tPi.th + eo;
     const float* tq = a.tQ.th + eo;
     ROWS_STAMP(0);
     const float b0_tp = tp[a.tPi.b0 + x.tid];
-    rows_inputs_commit(x, a, false, xraw, nullptr, eo);
+    rows_inputs_commit<R>(x, a, false, xraw, nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
     const float bpi_t = tp[a.tPi.bout + (x.lane & 3)];
     const float b0_tq = tq[a.tQ.b0 + x.tid];
-    rows_l0_fwd(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, nullptr, nullptr,
-                rnext(RN_FWD, tp + a.tPi.W[1]), true);
+    rows_l0_fwd<R>(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, -1, nullptr,
+                   rnext(RN_FWD, tp + a.tPi.W[1]), true);
     ROWS_STAMP(2);
-    rows_hidden_fwd(x, wb, a, a.tPi, tp, nullptr, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
+    rows_hidden_fwd<R>(x, wb, a, a.tPi, tp, -1, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
     ROWS_STAMP(3);
     const f32x4 wq_t = ldv(tq + a.tQ.Wout + 4 * x.lane);
     const float bq_t = tq[a.tQ.bout];
-    {
+#pragma unroll
+    for (int hh = 0; hh < R / 4; ++hh) {
+      const int row = 4 * hh + x.wave;
       float z[4];
-      rows_head4(x, wpi_t, z);
+      rows_head4(x, wpi_t, z, row);
       if (x.lane < 4) {
         float v = 0.f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) v = (x.lane == d) ? z[d] : v;
         v = a.max_u * tanhf(v + bpi_t);                                                    // actor_critic.py:89
-        x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                              // actor_critic.py:93
+        x.xin[row * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                 // actor_critic.py:93
       }
     }
     __syncthreads();
     ROWS_STAMP(4);
-    rows_l0_fwd(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, nullptr, nullptr,
-                rnext(RN_FWD, tq + a.tQ.W[1]), true);
-    rows_hidden_fwd(x, wb, a, a.tQ, tq, nullptr, 0, eo, rnext(RN_NONE, nullptr));
+    rows_l0_fwd<R>(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, -1, nullptr,
+                   rnext(RN_FWD, tq + a.tQ.W[1]), true);
+    rows_hidden_fwd<R>(x, wb, a, a.tQ, tq, -1, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
-    const float Qt = rows_head1(x, wq_t) + bq_t;                                           // ddpg.py:427-431
-    if (x.lane == 0 && !(a.inject > 0 && rgrp == a.inject - 1))
-      __hip_atomic_store(qt, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int hh = 0; hh < R / 4; ++hh) {
+      const int row = 4 * hh + x.wave;
+      const float Qt = rows_head1(x, wq_t, row) + bq_t;                                    // ddpg.py:427-431
+      // (fault injection, tests: the target group of row group inject - 1 of the 4-row grid never publishes)
+      if (x.lane == 0 && !(a.inject > 0 && (x.r0 + row) / ROWS_R == a.inject - 1))
+        __hip_atomic_store(qt + row, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
     ROWS_STAMP(6);
     return nrg + rgrp;
   }
 
   if (kind == 2) {
     // ================================================= main-critic group: critic(o, g, u), loss, backward
-    rows_first_loads<EX>(x, a, ex, pre, pre_path, 2, rgrp, expert, wb[0], xraw);
+    rows_first_loads<EX, R>(x, a, ex, pre, pre_path, 2, rgrp, expert, wb[0], xraw);
     ROWS_COMMON();
     if (!HER && rgrp == 0 && x.tid == 0 && a.step_ctr) *ex_i64(a.step_ctr, eo) += 1;
     const float* mq = a.mQ.th + eo;
     ROWS_STAMP(0);
     const float b0_mq = mq[a.mQ.b0 + x.tid];
-    rows_inputs_commit(x, a, true, xraw, a.xn_c ? a.xn_c + eo : nullptr, eo);
+    rows_inputs_commit<R>(x, a, true, xraw, a.xn_c ? a.xn_c + eo : nullptr, eo);
     __syncthreads();
     ROWS_STAMP(1);
     // operands of the head / loss / first backward step, fetched ahead of the hidden layers
     const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
     const float bq_m = mq[a.mQ.bout];
     const float wq_col = mq[a.mQ.Wout + x.tid];
-    const float rew = batch[(int64_t)m * a.ld + a.off_r];
-    // activations kept for the backward pass and the weight gradients
-    rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, x.keep, a.actc[0] + eo,
-                rnext(RN_FWD, mq + a.mQ.W[1]), true);
+    float rew[R / 4];
+#pragma unroll
+    for (int hh = 0; hh < R / 4; ++hh) rew[hh] = batch[(int64_t)(x.r0 + 4 * hh + x.wave) * a.ld + a.off_r];
+    // relu' masks kept for the backward pass (slots 0 .. nl - 1), layer outputs stored for the weight gradients
+    rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, 0, a.actc[0] + eo,
+                   rnext(RN_FWD, mq + a.mQ.W[1]), true);
     ROWS_STAMP(2);
-    rows_hidden_fwd(x, wb, a, a.mQ, mq, x.keep, 1, eo, rows_bwd_first(a, false, eo));
+    rows_hidden_fwd<R>(x, wb, a, a.mQ, mq, 0, 1, eo, rows_bwd_first(a, false, eo));
     ROWS_STAMP(3);
-    {
-      const float Q = rows_head1(x, wq_m) + bq_m;
+#pragma unroll
+    for (int hh = 0; hh < R / 4; ++hh) {
+      const int row = 4 * hh + x.wave, m = x.r0 + row;
+      const float Q = rows_head1(x, wq_m, row) + bq_m;
       // Q' of this wave's row from the target group (every lane polls the same word: one request per poll)
       unsigned long long word = 0;
       int spins = 0;
       const int max_spins = a.spins > 0 ? a.spins : (1 << 22);
       for (;;) {
         if (a.lab_no_target) { word = ROWS_QT_TAG << 32; break; }
-        word = __hip_atomic_load(qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        word = __hip_atomic_load(qt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((word >> 32) == ROWS_QT_TAG || ++spins > max_spins) break;
         __builtin_amdgcn_s_sleep(1);
       }
@@ -290,18 +319,18 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
       const bool got = (word >> 32) == ROWS_QT_TAG;
       const float Qt = got ? __uint_as_float((unsigned)(word & 0xffffffffull)) : NAN;
       if (x.lane == 0) {
-        __hip_atomic_store(qt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // consumed
+        __hip_atomic_store(qt + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed
         if (!got && a.fault) atomicAdd(reinterpret_cast<int32_t*>(reinterpret_cast<float*>(a.fault) + eo), 1);
       }
       // (fminf / fmaxf drop a NaN operand, so the clip alone would turn a missing Q' into the target clip_lo: the NaN is
       //  re-injected behind it -- a faulted update reports a NaN loss as well as the fault word)
-      const float target = got ? fclip(rew + a.gamma * Qt, a.clip_lo, a.clip_hi) : NAN;    // ddpg.py:437-438
+      const float target = got ? fclip(rew[hh] + a.gamma * Qt, a.clip_lo, a.clip_hi) : NAN;   // ddpg.py:437-438
       const float diff = target - Q;
       const float dq = -2.0f * invB * diff;                  // d mean((target - Q)^2) / dQ, target is a constant
       if (x.lane == 0) {
         rows_gst(x, a.rows + eo + m, diff * diff);           // ddpg.py:439
         rows_gst(x, a.dQ + eo + m, dq);
-        sm_s[x.wave] = dq;
+        sm_s[row] = dq;
       }
     }
     __syncthreads();
@@ -309,61 +338,63 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     {
       const int L = nl - 1;
       const float w = wq_col;
-      const float* hk = x.keep + L * 1024;
+      const uint32_t hk = rows_kept<R>(x, L);
       float* g = a.dactc[L] + eo;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = (hk[i * 256 + x.tid] > 0.f) ? sm_s[i] * w : 0.f;
+      for (int i = 0; i < R; ++i) {
+        const float v = ((hk >> i) & 1u) ? sm_s[i] * w : 0.f;
         x.hs[i * RLD + x.tid] = v;
         rows_gst(x, g + (int64_t)(x.r0 + i) * 256 + x.tid, v);
       }
     }
     __syncthreads();
     ROWS_STAMP(5);
-    rows_hidden_bwd(x, wb, a, x.keep, 1, eo, rnext(RN_NONE, nullptr));
+    rows_hidden_bwd<R>(x, wb, a, 0, 1, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(6);
     return 2 * nrg + rgrp;
   }
 
   // =================================================== actor side
-  rows_first_loads<EX>(x, a, ex, pre, pre_path, 0, rgrp, expert, wb[0], xraw);
+  rows_first_loads<EX, R>(x, a, ex, pre, pre_path, 0, rgrp, expert, wb[0], xraw);
   ROWS_COMMON();
 #ifdef ROWS_DEBUG
   if (a.stamps && rgrp == 0) x.dbg = a.stamps + 96;
 #endif
   const float* mp = a.mPi.th + eo;
   const float* mq = a.mQ.th + eo;
-  float* keepA = x.keep;                                    // actor activations
-  float* keepD = x.keep + nl * 1024;                        // critic(pi) activations
+  const int keepA = 0;                                      // relu' masks: slots of the actor's layers
+  const int keepD = nl;                                     // ... of critic(pi)'s
   ROWS_STAMP(0);
   const float b0_mp = mp[a.mPi.b0 + x.tid];
-  rows_inputs_commit(x, a, false, xraw, a.xn_a ? a.xn_a + eo : nullptr, eo);
+  rows_inputs_commit<R>(x, a, false, xraw, a.xn_a ? a.xn_a + eo : nullptr, eo);
   __syncthreads();
   ROWS_STAMP(1);
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);
   const f32x4 bpi = ldv(mp + a.mPi.bout);
   const float b0_mq = mq[a.mQ.b0 + x.tid];
-  rows_l0_fwd(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, keepA, a.acta[0] + eo,
-              rnext(RN_FWD, mp + a.mPi.W[1]), true);
+  rows_l0_fwd<R>(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, keepA, a.acta[0] + eo,
+                 rnext(RN_FWD, mp + a.mPi.W[1]), true);
   ROWS_STAMP(2);
-  rows_hidden_fwd(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
+  rows_hidden_fwd<R>(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
   ROWS_STAMP(3);
-  float pi[4];
-  {
+  float pi[R / 4][4];
+#pragma unroll
+  for (int hh = 0; hh < R / 4; ++hh) {
+    const int row = 4 * hh + x.wave, m = x.r0 + row;
     float z[4];
-    rows_head4(x, wpi, z);
+    rows_head4(x, wpi, z, row);
     float l2 = 0.f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      pi[d] = a.max_u * tanhf(z[d] + bpi[d]);                                              // actor_critic.py:89
-      const float t = pi[d] / a.max_u;
+      pi[hh][d] = a.max_u * tanhf(z[d] + bpi[d]);                                          // actor_critic.py:89
+      const float t = pi[hh][d] / a.max_u;
       l2 += t * t;                                                                         // ddpg.py:441
     }
     if (x.lane < 4) {
       float v = 0.f;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) v = (x.lane == d) ? pi[d] : v;
-      x.xin[x.wave * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                // actor_critic.py:93
+      for (int d = 0; d < 4; ++d) v = (x.lane == d) ? pi[hh][d] : v;
+      x.xin[row * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                   // actor_critic.py:93
     }
     if (x.lane == 0) rows_gst(x, a.rows + eo + 2 * a.B + m, l2);
   }
@@ -375,12 +406,14 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const float bq_m = mq[a.mQ.bout];
   const float wq_col = mq[a.mQ.Wout + x.tid];
   // ---- main critic on (o, g, pi) -> Q_pi
-  rows_l0_fwd(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, keepD, nullptr,
-              rnext(RN_FWD, mq + a.mQ.W[1]), true);
-  rows_hidden_fwd(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
+  rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, keepD, nullptr,
+                 rnext(RN_FWD, mq + a.mQ.W[1]), true);
+  rows_hidden_fwd<R>(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
   ROWS_STAMP(5);
-  {
-    const float Qpi = rows_head1(x, wq_m) + bq_m;
+#pragma unroll
+  for (int hh = 0; hh < R / 4; ++hh) {
+    const int row = 4 * hh + x.wave, m = x.r0 + row;
+    const float Qpi = rows_head1(x, wq_m, row) + bq_m;
     if (x.lane == 0) {
       rows_gst(x, a.rows + eo + a.B + m, Qpi);               // ddpg.py:440
       a.out_Qpi[eo + m] = Qpi;
@@ -390,9 +423,9 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   // ---- backward of -mean(Q_pi) through the critic into the action slot
   {
     const float w = wq_col * (-invB);
-    const float* hk = keepD + (nl - 1) * 1024;
+    const uint32_t hk = rows_kept<R>(x, keepD + nl - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x.hs[i * RLD + x.tid] = (hk[i * 256 + x.tid] > 0.f) ? w : 0.f;
+    for (int i = 0; i < R; ++i) x.hs[i * RLD + x.tid] = ((hk >> i) & 1u) ? w : 0.f;
   }
   __syncthreads();
   ROWS_STAMP(6);
@@ -403,26 +436,28 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     for (int d = 0; d < 4; ++d) wu[d] = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
   }
   const f32x4 wpi_row = ldv(mp + a.mPi.Wout + 4 * x.tid);
-  rows_hidden_bwd(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
+  rows_hidden_bwd<R>(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
   ROWS_STAMP(7);
   // (every operand that comes from the critic's parameters is in registers or consumed by now: wu, wq_col above)
-  {
+#pragma unroll
+  for (int hh = 0; hh < R / 4; ++hh) {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
     // pi = max_u tanh(z) and the l2 term (ddpg.py:440-441)
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+    const int row = 4 * hh + x.wave, m = x.r0 + row;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(x.hs + row * RLD + 4 * x.lane);
     float dz[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const f32x4 w = wu[d];
       const float v = wave_sum(g4[0] * w[0] + g4[1] * w[1] + g4[2] * w[2] + g4[3] * w[3]);
-      const float th = pi[d] / a.max_u;
-      const float dpi = v / a.max_u + a.l2c * pi[d];
+      const float th = pi[hh][d] / a.max_u;
+      const float dpi = v / a.max_u + a.l2c * pi[hh][d];
       dz[d] = dpi * a.max_u * (1.0f - th * th);
     }
     if (x.lane == 0) {
       const f32x4 o = {dz[0], dz[1], dz[2], dz[3]};
       *reinterpret_cast<f32x4*>(a.dz + eo + (int64_t)m * 4) = o;
-      *reinterpret_cast<f32x4*>(sm_v + 4 * x.wave) = o;
+      *reinterpret_cast<f32x4*>(sm_v + 4 * row) = o;
     }
   }
   __syncthreads();
@@ -430,20 +465,20 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   {
     const int L = nl - 1;
     const f32x4 w = wpi_row;
-    const float* hk = keepA + L * 1024;
+    const uint32_t hk = rows_kept<R>(x, keepA + L);
     float* g = a.dacta[L] + eo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R; ++i) {
       const f32x4 dzr = *reinterpret_cast<const f32x4*>(sm_v + 4 * i);
       const float sv = dzr[0] * w[0] + dzr[1] * w[1] + dzr[2] * w[2] + dzr[3] * w[3];
-      const float v = (hk[i * 256 + x.tid] > 0.f) ? sv : 0.f;
+      const float v = ((hk >> i) & 1u) ? sv : 0.f;
       x.hs[i * RLD + x.tid] = v;
       rows_gst(x, g + (int64_t)(x.r0 + i) * 256 + x.tid, v);
     }
   }
   __syncthreads();
   ROWS_STAMP(8);
-  rows_hidden_bwd(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
+  rows_hidden_bwd<R>(x, wb, a, keepA, 2, eo, rnext(RN_NONE, nullptr));
   ROWS_STAMP(9);
   return 3 * nrg + rgrp;
 }
@@ -474,7 +509,7 @@ __device__ __forceinline__ uint32_t rows_kernarg_touch() {
   __builtin_amdgcn_sched_barrier(0);
   return d;
 }
-template <bool EX>
+template <bool EX, int R = ROWS_R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void ddpg_rows_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex) {
 #ifdef ROWS_DEBUG
@@ -482,18 +517,18 @@ void ddpg_rows_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex) {
 #endif
   ROWS_PRE_MAKE(pre);
   const uint32_t touched = rows_kernarg_touch();
-  ddpg_rows_body<EX, false>(a, ex, nullptr, 0, &pre);
+  ddpg_rows_body<EX, false, R>(a, ex, nullptr, 0, &pre);
   asm volatile("" :: "s"(touched));
 #ifdef ROWS_DEBUG
   if (a.stamps && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.stamps[31] = t_entry;   // (actor-side group 0)
 #endif
 }
-template <bool EX>
+template <bool EX, int R = ROWS_R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void ddpg_rows_her_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
   ROWS_PRE_MAKE(pre);
   const uint32_t touched = rows_kernarg_touch();
-  ddpg_rows_body<EX, true>(a, ex, &her, seed_stride, &pre);
+  ddpg_rows_body<EX, true, R>(a, ex, &her, seed_stride, &pre);
   asm volatile("" :: "s"(touched));
 }
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   x.part = x.hs + 4 * RLD;
   x.xin = x.part + 4 * 4 * 256;
   x.sm = x.xin + 4 * XLD;
-  x.keep = nullptr; x.dbg = nullptr;
+  x.kb = 0; x.dbg = nullptr;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   x.r0 = blockIdx.x * ROWS_R;
   const int Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
         nd = noise_draw(rn.row * 4 + x.lane, rn.row, rn.random_eps, a.max_u_d, nullptr, nullptr, nullptr, rn.seed,
                         ctr0 + (uint64_t)s);
       __syncthreads();                                       // input rows of all 4 envs are in LDS
-      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr,
+      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr,
                   rnext(RN_FWD, pp + a.pi.W[1]));
       const RNext again = (s + 1 < a.nsteps) ? rnext(RN_L0, pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G)
                                              : rnext(RN_NONE, nullptr);
       for (int l = 1; l < a.nl; ++l)
-        rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], nullptr, nullptr,
+        rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], -1, nullptr,
                      (l + 1 < a.nl) ? rnext(RN_FWD, pp + a.pi.W[l + 1]) : again);
       float z[4];
       rows_head4(x, wpi, z);
@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
     return;
   }
   __syncthreads();
-  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr,
+  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr,
               rnext(RN_FWD, pp + a.pi.W[1]));
   const float* qp = a.q.th;
   const RNext after = a.out_Q ? rnext(RN_L0, qp + a.q.W0, Sc, qp + a.q.Wg, Sc + G) : rnext(RN_NONE, nullptr);
   for (int l = 1; l < a.nl; ++l)
-    rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], nullptr, nullptr,
+    rows_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], -1, nullptr,
                  (l + 1 < a.nl) ? rnext(RN_FWD, pp + a.pi.W[l + 1]) : after);
   float z[4];
   rows_head4(x, wpi, z);
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   const f32x4 wq = ldv(qp + a.q.Wout + 4 * x.lane);
   const float bq = qp[a.q.bout];
   __syncthreads();
-  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp[a.q.b0 + x.tid], nullptr, nullptr,
+  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp[a.q.b0 + x.tid], -1, nullptr,
               rnext(RN_FWD, qp + a.q.W[1]));
   for (int l = 1; l < a.nl; ++l)
-    rows_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], nullptr, nullptr,
+    rows_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], -1, nullptr,
                  (l + 1 < a.nl) ? rnext(RN_FWD, qp + a.q.W[l + 1]) : rnext(RN_NONE, nullptr));
   const float Q = rows_head1(x, wq) + bq;
   if (x.lane == 0) a.out_Q[m] = Q;

@@ -62,18 +62,27 @@ __device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, in
   if (n.kind == RN_FWD) rows_fw_load(b, n.W + n.off, wave, lane, 0);
   else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
 }
+// R batch rows per workgroup (4, or 8 for batches of several ranks / experts -- mlp_rows.h): one 16-byte load of W feeds
+// R instructions; acc[h] are rows 4 h .. 4 h + 3
+template <int R>
 __device__ __forceinline__ void rows_fw_mac4(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c, int kq,
-                                             f32x4 (&acc)[4]) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * RLD + 64 * wave + 16 * c + 4 * kq);
+                                             f32x4 (&acc)[R / 4][4]) {
+  f32x4 a[R / 4];
+#pragma unroll
+  for (int h = 0; h < R / 4; ++h)
+    a[h] = *reinterpret_cast<const f32x4*>(hs + (4 * h + (lane & 3)) * RLD + 64 * wave + 16 * c + 4 * kq);
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = MFMA4(a[s], b[4 * kq + s][e], acc[e]);
+    for (int h = 0; h < R / 4; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = MFMA4(a[h][s], b[4 * kq + s][e], acc[h][e]);
 }
 // the chunk loop of a hidden layer (forward, or backward on the transposed copy): chunk c + 1 (the successor's first chunk
 // behind the last one) is requested in four pieces between the four groups of matrix instructions of chunk c
+template <int R>
 __device__ __forceinline__ void rows_big_chunks(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const RNext& next,
-                                                const bool lean, const int64_t late_off, f32x4 (&acc)[4]) {
+                                                const bool lean, const int64_t late_off, f32x4 (&acc)[R / 4][4]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     RNext n = next;
@@ -83,21 +92,10 @@ __device__ __forceinline__ void rows_big_chunks(const RCtx& x, f32x4 (&wb)[2][16
       if (c < 3) rows_fw_load4(wb[(c + 1) & 1], W, x.wave, x.lane, c + 1, kq);
       else rows_prefetch4(wb[0], n, x.wave, x.lane, kq);
       __builtin_amdgcn_sched_barrier(0);
-      rows_fw_mac4(wb[c & 1], x.hs, x.wave, x.lane, c, kq, acc);
+      rows_fw_mac4<R>(wb[c & 1], x.hs, x.wave, x.lane, c, kq, acc);
       __builtin_amdgcn_sched_barrier(0);
     }
     ROWS_DBG2(x);
-  }
-}
-__device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* hs, int wave, int lane, int c,
-                                            f32x4 (&acc)[4]) {
-#pragma unroll
-  for (int kq = 0; kq < 4; ++kq) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(hs + (lane & 3) * RLD + 64 * wave + 16 * c + 4 * kq);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = MFMA4(a[s], b[4 * kq + s][e], acc[e]);
   }
 }
 // ---- epilogues: partial tiles -> LDS -> finished rows (next layer's input in hs, optional copies)
@@ -113,39 +111,54 @@ __device__ __forceinline__ void rows_fw_mac(const f32x4 (&b)[16], const float* h
 // While no wave is held at the issue of a load the CU's fill path idles (tools/rowchain2_lab.hip: every cycle of epilogue
 // is a cycle added to the layer), so the epilogue is kept short: all 16 partials are requested before the first sum, the
 // copies and stores sit behind one uniform branch each instead of one per row.
-__device__ __forceinline__ void rows_finish_sums(const RCtx& x, const f32x4 (&acc)[4], float (&s)[4], const bool lean) {
+template <int R>
+__device__ __forceinline__ void rows_finish_sums(const RCtx& x, const f32x4 (&acc)[R / 4][4], float (&s)[R], const bool lean) {
   float* part = x.part;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    *reinterpret_cast<f32x4*>(part + (x.wave * 4 + r) * 256 + 4 * x.lane) = v;
-  }
+  for (int h = 0; h < R / 4; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = {acc[h][0][r], acc[h][1][r], acc[h][2][r], acc[h][3][r]};
+      *reinterpret_cast<f32x4*>(part + (x.wave * R + 4 * h + r) * 256 + 4 * x.lane) = v;
+    }
   __syncthreads();
-  float p[4][4];
+  float p[R][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[r][j] = part[(j * 4 + r) * 256 + x.tid];
+    for (int j = 0; j < 4; ++j) p[r][j] = part[(j * R + r) * 256 + x.tid];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) s[r] = (p[r][0] + p[r][1]) + (p[r][2] + p[r][3]);
+  for (int r = 0; r < R; ++r) s[r] = (p[r][0] + p[r][1]) + (p[r][2] + p[r][3]);
   if (lean) { x.part = x.part2; x.part2 = part; }
 }
-__device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[4], const float bv, float* keep,
-                                               float* gout, const bool lean = false) {
-  float s[4];
-  rows_finish_sums(x, acc, s, lean);
+// ---- relu' masks of the kept layers.  Thread tid finishes column tid of every row and is the only one that ever asks
+// whether (row r, column tid) of a kept layer was positive: the masks are bits of a per-thread word, R to a layer
+// (slot = layer, + nl for the second network of the actor side; up to 8 slots of up to 8 rows) -- no LDS.  (Until round 5
+// the kept activations themselves lay in LDS, 2 nl x R KB: with 8 rows two workgroups would no longer have shared a CU.)
+template <int R>
+__device__ __forceinline__ void rows_keep(const RCtx& x, const int slot, const float (&s)[R]) {
+  uint32_t bits = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < R; ++r) bits |= (s[r] > 0.f) ? (1u << r) : 0u;
+  x.kb |= (uint64_t)bits << (slot * R);
+}
+template <int R>
+__device__ __forceinline__ uint32_t rows_kept(const RCtx& x, const int slot) { return (uint32_t)(x.kb >> (slot * R)); }
+// keep: slot of the layer's relu' mask (rows_keep) or -1
+template <int R>
+__device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[R / 4][4], const float bv, const int keep,
+                                               float* gout, const bool lean = false) {
+  float s[R];
+  rows_finish_sums<R>(x, acc, s, lean);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
     s[r] = fmaxf(s[r] + bv, 0.f);
     x.hs[r * RLD + x.tid] = s[r];
   }
-  if (keep) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) keep[r * 256 + x.tid] = s[r];
-  }
+  if (keep >= 0) rows_keep<R>(x, keep, s);
   if (gout) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
+    for (int r = 0; r < R; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
   }
   if (!lean) __syncthreads();
 }
@@ -153,34 +166,44 @@ __device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)
 // (the first chunk of W is already in flight into wb[0]: rows_prefetch of the predecessor)
 // late_off: added to next.off of a lean layer where the prefetch is issued (a value that may still be on its way from the
 // arguments when the layer starts)
+template <int R>
+__device__ __forceinline__ void rows_acc_zero(f32x4 (&acc)[R / 4][4]) {
+#pragma unroll
+  for (int h = 0; h < R / 4; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = zero4();
+}
+template <int R = 4>
 __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* bias,
-                                             float* keep, float* gout, const RNext& next, const bool lean = false,
+                                             const int keep, float* gout, const RNext& next, const bool lean = false,
                                              const int64_t late_off = 0) {
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 acc[R / 4][4];
+  rows_acc_zero<R>(acc);
   const float bv = bias[x.tid];
-  rows_big_chunks(x, wb, W, next, lean, late_off, acc);
-  rows_fw_finish(x, acc, bv, keep, gout, lean);
+  rows_big_chunks<R>(x, wb, W, next, lean, late_off, acc);
+  rows_fw_finish<R>(x, acc, bv, keep, gout, lean);
   ROWS_DBG(x);                                               // (one stamp per layer: finer ones slow the measured group down)
 }
 // ---- one 256 x 256 hidden layer, backward on the TRANSPOSED matrix: hs <- (hs . WT) * relu'(mask), WT[n][k] = W[k][n].
 // The forward product with another epilogue (no bias; the kept activation of the layer below gates the gradient).
-__device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const float* mask,
+// (mask: the slot of the kept layer below)
+template <int R>
+__device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const int mask,
                                               float* gout, const RNext& next, const bool lean = false) {
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  rows_big_chunks(x, wb, WT, next, false, 0, acc);
-  float mk[4];
+  f32x4 acc[R / 4][4];
+  rows_acc_zero<R>(acc);
+  rows_big_chunks<R>(x, wb, WT, next, false, 0, acc);
+  const uint32_t mk = rows_kept<R>(x, mask);
+  float s[R];
+  rows_finish_sums<R>(x, acc, s, lean);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) mk[r] = mask[r * 256 + x.tid];    // (this thread's own copies: requested ahead of the barrier)
-  float s[4];
-  rows_finish_sums(x, acc, s, lean);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    s[r] = (mk[r] > 0.f) ? s[r] : 0.f;
+  for (int r = 0; r < R; ++r) {
+    s[r] = ((mk >> r) & 1u) ? s[r] : 0.f;
     x.hs[r * RLD + x.tid] = s[r];
   }
   if (gout) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
+    for (int r = 0; r < R; ++r) rows_gst(x, gout + (int64_t)(x.r0 + r) * 256 + x.tid, s[r]);
   }
   if (!lean) __syncthreads();
 }
@@ -188,35 +211,42 @@ __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16],
 // ---- layer 0: hs <- relu(x . W0 + g . Wg + b0).  The input row in LDS is xin[i] = [o | td | action slot | g]: the first
 // S entries meet the S rows of W0 (S excludes the action slot for an actor), the G entries from `gofs` on meet Wg
 // (util.py:79-92).  Wave w takes the virtual k = 4 t + w of the concatenation.
+template <int R>
 __device__ __forceinline__ void rows_l0_mac(const RCtx& x, const f32x4 (&b)[16], int S, int nk, int gofs, int t0,
-                                            f32x4 (&acc)[4]) {
+                                            f32x4 (&acc)[R / 4][4]) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int kv = 4 * (t0 + t) + x.wave;
     const bool ok = kv < nk;
     const int kc = ok ? kv : 0;
-    const float v = x.xin[(x.lane & 3) * XLD + ((kc < S) ? kc : gofs + (kc - S))];
-    const float av = ok ? v : 0.f;
+    const int col = (kc < S) ? kc : gofs + (kc - S);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = MFMA4(av, b[t][e], acc[e]);
+    for (int h = 0; h < R / 4; ++h) {
+      const float v = x.xin[(4 * h + (x.lane & 3)) * XLD + col];
+      const float av = ok ? v : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = MFMA4(av, b[t][e], acc[h][e]);
+    }
   }
 }
 // (rows t < 16 are already in flight into wb[0]; a second pass covers inputs wider than 64)
 // bv = bias[tid], loaded by the caller ahead of the layer (for a group's first layer: together with its inputs -- the
 // parameters were just rewritten by the optimiser, a load issued here would be a second cold round trip)
+template <int R = 4>
 __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W0, int S, const float* Wg,
-                                            int G, int gofs, const float bv, float* keep, float* gout,
+                                            int G, int gofs, const float bv, const int keep, float* gout,
                                             const RNext& next, const bool lean = false) {
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  f32x4 acc[R / 4][4];
+  rows_acc_zero<R>(acc);
   const int nk = S + G;
   const bool two = nk > 64;
   if (two) rows_l0_load(wb[1], W0, S, Wg, nk, x.wave, x.lane, 16);
   __builtin_amdgcn_sched_barrier(0);
-  rows_l0_mac(x, wb[0], S, nk, gofs, 0, acc);
+  rows_l0_mac<R>(x, wb[0], S, nk, gofs, 0, acc);
   rows_prefetch(wb[0], next, x.wave, x.lane);
   __builtin_amdgcn_sched_barrier(0);
-  if (two) rows_l0_mac(x, wb[1], S, nk, gofs, 16, acc);
-  rows_fw_finish(x, acc, bv, keep, gout, lean);
+  if (two) rows_l0_mac<R>(x, wb[1], S, nk, gofs, 16, acc);
+  rows_fw_finish<R>(x, acc, bv, keep, gout, lean);
 }
 
 // ---- output layers: wave i finishes batch row r0 + i; the result is uniform over the wave.  The output-layer weights
@@ -229,18 +259,21 @@ __device__ __forceinline__ HeadW4 rows_head4_w(const float* Wout, int lane) {   
   for (int e = 0; e < 4; ++e) h.w[e] = ldv(Wout + (int64_t)(4 * lane + e) * 4);
   return h;
 }
-__device__ __forceinline__ void rows_head4(const RCtx& x, const HeadW4& h, float (&out)[4]) {
-  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+// (row: which of the workgroup's rows -- wave i finishes rows i, i + 4, ...)
+__device__ __forceinline__ void rows_head4(const RCtx& x, const HeadW4& h, float (&out)[4], const int row) {
+  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + row * RLD + 4 * x.lane);
 #pragma unroll
   for (int d = 0; d < 4; ++d)
     out[d] = wave_sum(h4[0] * h.w[0][d] + h4[1] * h.w[1][d] + h4[2] * h.w[2][d] + h4[3] * h.w[3][d]);
 }
-__device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {        // w = Wout[4 lane .. +3] of a [256][1]
-  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + x.wave * RLD + 4 * x.lane);
+__device__ __forceinline__ void rows_head4(const RCtx& x, const HeadW4& h, float (&out)[4]) { rows_head4(x, h, out, x.wave); }
+__device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w, const int row) {   // w = Wout[4 lane .. +3] of a [256][1]
+  const f32x4 h4 = *reinterpret_cast<const f32x4*>(x.hs + row * RLD + 4 * x.lane);
   return wave_sum(h4[0] * w[0] + h4[1] * w[1] + h4[2] * w[2] + h4[3] * w[3]);
 }
+__device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) { return rows_head1(x, w, x.wave); }
 
-// layer-0 input rows of the workgroup's 4 batch rows: xin[i] = [o | td | action slot | g]; the action slot receives
+// layer-0 input rows of the workgroup's R batch rows: xin[i] = [o | td | action slot | g]; the action slot receives
 // the batch action / max_u (actor_critic.py:96) when with_u, else it is filled later from the actor's output
 // keep: where the rows are also stored for the layer-0 weight gradients (input normalisation only: without it those
 // read the batch itself), or NULL
@@ -249,15 +282,16 @@ __device__ __forceinline__ float rows_head1(const RCtx& x, const f32x4& w) {    
 // and the widths -- RowsPre below hands those over in scalar registers, so the loads go out before the first argument has
 // arrived from memory) and what is done to the values (rows_inputs_commit: action / max_u, normalisation, the LDS rows).
 struct RowsIn { int dimo, dimtd, dimg, ld, off_td, off_u; };
-#define ROWS_IN_IT ((4 * ROWS_MAXIN + 255) / 256)             // elements per thread
+#define ROWS_IN_IT(R) (((R) * ROWS_MAXIN + 255) / 256)        // elements per thread
+template <int R>
 __device__ __forceinline__ void rows_inputs_issue(const int tid, const int r0, const RowsIn& in, const float* batch,
-                                                  int off_o, int off_g, bool with_u, float (&v)[ROWS_IN_IT]) {
+                                                  int off_o, int off_g, bool with_u, float (&v)[ROWS_IN_IT(R)]) {
   const int Sa = in.dimo + in.dimtd, S = Sa + 4, tot = S + in.dimg;
 #pragma unroll
-  for (int it = 0; it < ROWS_IN_IT; ++it) {
+  for (int it = 0; it < ROWS_IN_IT(R); ++it) {
     const int idx = tid + 256 * it;
     v[it] = 0.f;
-    if (idx < 4 * tot) {
+    if (idx < R * tot) {
       const int i = idx / tot, k = idx - i * tot;
       const float* row = batch + (int64_t)(r0 + i) * in.ld;
       if (k < in.dimo) v[it] = row[off_o + k];
@@ -267,14 +301,15 @@ __device__ __forceinline__ void rows_inputs_issue(const int tid, const int r0, c
     }
   }
 }
+template <int R>
 __device__ __forceinline__ void rows_inputs_commit(const RCtx& x, const RowsArgs& a, bool with_u,
-                                                   const float (&raw)[ROWS_IN_IT], float* keep = nullptr,
+                                                   const float (&raw)[ROWS_IN_IT(R)], float* keep = nullptr,
                                                    const int64_t so = 0) {
   const int Sa = a.dimo + a.dimtd, S = Sa + 4, tot = S + a.dimg;
 #pragma unroll
-  for (int it = 0; it < ROWS_IN_IT; ++it) {
+  for (int it = 0; it < ROWS_IN_IT(R); ++it) {
     const int idx = x.tid + 256 * it;
-    if (idx < 4 * tot) {
+    if (idx < R * tot) {
       const int i = idx / tot, k = idx - i * tot;
       float v = raw[it];
       if (k < a.dimo) {
@@ -320,8 +355,10 @@ struct RowsPre {
 // The offsets of layer l + 1 are fetched while layer l runs and carried in registers: read at the top of a layer, as
 // `th + N.W[l]`, they put two dependent scalar-load waits (~300 cycles) between the barrier and the layer's first operand
 // load -- with the fill path idle.
+// keep0: slot of the network's layer 0 (rows_keep) or -1
+template <int R>
 __device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a, const RowsNet& N,
-                                                const float* th, float* keep0, int which, int64_t eo,
+                                                const float* th, const int keep0, int which, int64_t eo,
                                                 const RNext& after) {
   if (a.nl == 1) __syncthreads();                            // (layer 0 ran with one barrier: rows_fw_finish)
   int Wc = N.W[1], bc = N.b[1];
@@ -330,21 +367,22 @@ __device__ __forceinline__ void rows_hidden_fwd(const RCtx& x, f32x4 (&wb)[2][16
     const int ln = more ? l + 1 : l;
     const int Wn = N.W[ln], bn = N.b[ln];                    // (consumed by the prefetch behind this layer's third chunk)
     float* g = (which == 1) ? a.actc[l] + eo : (which == 2) ? a.acta[l] + eo : nullptr;
-    float* kp = keep0 ? keep0 + l * 1024 : nullptr;
-    rows_big_fwd(x, wb, th + Wc, th + bc, kp, g, more ? rnext(RN_FWD, th) : after, more, Wn);
+    const int kp = keep0 >= 0 ? keep0 + l : -1;
+    rows_big_fwd<R>(x, wb, th + Wc, th + bc, kp, g, more ? rnext(RN_FWD, th) : after, more, Wn);
     Wc = Wn; bc = bn;
   }
 }
 // hidden layers nl-1 .. 1 of a network, backward on the transposed copies; which: 0 critic, nothing stored,
 // 1 critic -> a.dactc[l-1], 2 actor -> a.dacta[l-1]
+template <int R>
 __device__ __forceinline__ void rows_hidden_bwd(const RCtx& x, f32x4 (&wb)[2][16], const RowsArgs& a,
-                                                const float* keep0, int which, int64_t eo, const RNext& after) {
+                                                const int keep0, int which, int64_t eo, const RNext& after) {
   const float* wt = (which == 2) ? a.wTpi[a.nl - 1] : a.wTq[a.nl - 1];
   for (int l = a.nl - 1; l >= 1; --l) {
     const int ln = (l > 1) ? l - 1 : l;
     const float* wn = (which == 2) ? a.wTpi[ln] : a.wTq[ln];            // (fetched while layer l runs: rows_hidden_fwd)
     float* g = (which == 1) ? a.dactc[l - 1] + eo : (which == 2) ? a.dacta[l - 1] + eo : nullptr;
-    rows_big_bwdT(x, wb, wt + eo, keep0 + (l - 1) * 1024, g, (l > 1) ? rnext(RN_FWD, wn, 0, nullptr, 0, eo) : after, l > 1);
+    rows_big_bwdT<R>(x, wb, wt + eo, keep0 + (l - 1), g, (l > 1) ? rnext(RN_FWD, wn, 0, nullptr, 0, eo) : after, l > 1);
     wt = wn;
   }
 }
@@ -356,10 +394,10 @@ __device__ __forceinline__ RNext rows_bwd_first(const RowsArgs& a, bool actor, i
 // What a row group requests first: the first 16 rows of its first layer-0 matrix and its input rows.  The description comes
 // from the leading arguments (pre_path: nothing is read from the argument segment) or from the arguments proper; one load
 // sequence either way.  kind: 0 actor side (main actor), 1 target (target actor), 2 main critic.
-template <bool EX>
+template <bool EX, int R>
 __device__ __forceinline__ void rows_first_loads(const RCtx& x, const RowsArgs& a, const Ex& ex, const RowsPre* pre,
                                                  const bool pre_path, const int kind, const int rgrp, const int expert,
-                                                 f32x4 (&wb0)[16], float (&xraw)[ROWS_IN_IT]) {
+                                                 f32x4 (&wb0)[16], float (&xraw)[ROWS_IN_IT(R)]) {
   const float *fW0, *fbatch;
   int fS, fWg_off, foff_o, foff_g;
   RowsIn fin;
@@ -386,7 +424,7 @@ __device__ __forceinline__ void rows_first_loads(const RCtx& x, const RowsArgs& 
     asm volatile("" : "+s"(fS), "+s"(foff_o), "+s"(foff_g));   // (no select between the two descriptions: see the caller)
   }
   rows_l0_load(wb0, fW0, fS, fW0 + fWg_off, fS + fin.dimg, x.wave, x.lane, 0);
-  rows_inputs_issue(x.tid, rgrp * ROWS_R, fin, fbatch, foff_o, foff_g, kind == 2, xraw);
+  rows_inputs_issue<R>(x.tid, rgrp * R, fin, fbatch, foff_o, foff_g, kind == 2, xraw);
   __builtin_amdgcn_sched_barrier(0);
 }
 

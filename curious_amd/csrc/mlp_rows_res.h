@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
   x.sm = x.xin + 4 * XLD;
   float* h2s = x.sm + 64;                                    // [4][64]: this member's slice of the last hidden layer
   double* nzb = reinterpret_cast<double*>(h2s + 4 * 64);
-  x.keep = nullptr; x.dbg = nullptr;
+  x.kb = 0; x.dbg = nullptr;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   int group, member;
   if (rx.xmap) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     }
     __syncthreads();                                         // input rows (and, first step, the slices) are in LDS
     if (rx.stamps && blockIdx.x == 0 && x.tid == 0) last_stamp = __builtin_readcyclecounter();
-    rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, nullptr, rnext(RN_NONE, nullptr));
+    rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr, rnext(RN_NONE, nullptr));
     RES_STAMP(0);
     float v1 = res_slice(x, w1s, bias1);
     RES_STAMP(1);

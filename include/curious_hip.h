@@ -134,6 +134,9 @@ int curious_prof_launch_counts(int64_t* counts_host);
  *   "rows_pre"     1 (default; env CURIOUS_ROWS_PRE): the row-local update's role, input rows and first layer-0 matrix are
  *                  handed to the kernel as leading arguments (in scalar registers when a wave starts) where the shapes
  *                  allow; 0: fetched from the argument segment (same results; A/B)
+ *   "rows8"        1 (default; env CURIOUS_ROWS8): the row-local update gives 8 batch rows to a workgroup instead of 4 when the
+ *                  batch has >= 768 rows (three virtual ranks or more: half the weight stream per row); 0: always 4 (A/B; results
+ *                  agree to summation order -- the rows are independent, every row's arithmetic is the same)
  *   "dw_xcd"       1 (default; env CURIOUS_DW_XCD): blocks of the weight-gradient / optimiser launch placed by XCD
  *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
  *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes; a member of group k - 1 of

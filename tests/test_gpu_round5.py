@@ -225,6 +225,30 @@ def test_one_virtual_rank_is_the_agent_as_it_was():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize('V', [2, 3, 19])
+@pytest.mark.parametrize('graph', [False, True])
+def test_eight_rows_per_workgroup_change_no_bit(V, graph):
+    """Option rows8 (csrc/mlp_rows.h ROWS_R2): for batches of >= 512 rows the row-local launch gives 8 batch rows to a
+    workgroup instead of 4 -- one load of a weight fragment feeds twice the matrix instructions.  The rows of a batch are
+    independent and every row's arithmetic keeps its order, so losses, parameters and moments are the same bits."""
+    from curious_amd import ops
+    outs = []
+    for rows8 in (0, 1):
+        with ops.option('rows8', rows8):
+            agent = make_agent(V, use_graph=graph)
+            draw = rank_episodes(V, 12)
+            agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+            agent.train_batches(12)
+            agent.update_target_net()
+            agent.train_batches(5)
+            torch.cuda.synchronize()
+            outs.append([t.cpu().numpy().copy() for t in (agent.theta, agent._m, agent._v, agent._losses, agent.theta_target)])
+            agent.check_faults(wait=True)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(outs[0][3]).all()
+
+
 # ------------------------------------------------------------------ piece by piece against the one-rank entry points
 def test_joint_gather_equals_one_gather_per_rank():
     """curious_sample_rng_t.rank_rows: the joint batch of V ranks is, rank by rank, the batch curious_her_sample draws for
