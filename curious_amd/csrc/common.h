@@ -96,6 +96,8 @@ struct CuriousOptions {
                        //    (mlp_rows.h RowsPre; 0 = fetched from the argument segment as before: A/B)  [CURIOUS_ROWS_PRE]
   int rows8;           // 1: the row-local update gives 8 batch rows to a workgroup for batches of >= 768 rows (virtual ranks);
                        //    0: always 4 (A/B)                                                       [CURIOUS_ROWS8]
+  int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h
+                       //    DwSplit; batches of >= 1 024 rows); 10 S_hot + S_small: fixed (A/B)       [CURIOUS_DW_SPLIT]
   int lab_dw_stamps;   // LAB ONLY (tools/dw_stamps.py): dw_adam_her_kernel writes per-block cycle stamps into the workspace
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere

@@ -111,6 +111,8 @@ struct Ws {   // workspace carve-up
   float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h)
   int32_t* fault;              // fault word (mlp_rows.h): consumers of Q' that gave up; sticky until the host clears it.
                                // wT and fault are the ONLY parts of the workspace that carry state between calls
+  float* split;                // batches of >= DW_SPLIT_MIN_B rows: partial tiles of the split weight-gradient reduction
+  int32_t* split_cnt;          // (mlp_dw.h DwSplit) and their ticket counters -- zero between launches
   int64_t total;
 };
 
@@ -140,6 +142,9 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l < c->layers; ++l) w.wT[net][l] = (l >= 1) ? take((int64_t)c->hidden * c->hidden) : nullptr;
   w.fault = reinterpret_cast<int32_t*>(take(64));
+  const bool split = B >= DW_SPLIT_MIN_B;
+  w.split = split ? take((int64_t)DW_SPLIT_TILES * DW_SPLIT_MAX * DW_PART) : nullptr;
+  w.split_cnt = split ? reinterpret_cast<int32_t*>(take(DW_SPLIT_TILES)) : nullptr;
   w.total = off;
   return w;
 }

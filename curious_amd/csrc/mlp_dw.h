@@ -4,10 +4,73 @@
 
 // C[K',N] = A[M,K']^T . B[M,N];  aux_out[N] = colsum(B)    (reduction over P.M)     1-D grid over a tile list
 struct DwHotArgs { GemmHot p[4]; int32_t tiles_per; int32_t nprob; };   // every problem has tiles_per tiles
-template <bool ADAM>
+// ---- split reduction (batches of many chunks of 256 rows: virtual ranks).  The tile list of a launch does not grow with
+// the batch -- 256 hidden tiles + ~80 small ones at Arm4, for 256 CUs -- while every tile's reduction does: at 19 ranks a
+// tile is 30-40 us of work, the CUs that were dealt two of them decide the launch's duration and the others idle for half
+// of it (tools/dw_stamps.py; tools/dw_lab.hip: the hidden tiles alone 28 us, the launch 71).  With S > 1 (grid.z) a tile
+// is worked on by S workgroups, each taking a segment of the chunks: S times as many, shorter work items, which the
+// dispatcher spreads evenly.  A workgroup leaves its partial tile (16 x 64 + the 64 column sums) in the workspace, stored
+// THROUGH the L2 (agent scope: the L2s of the 8 XCDs are not coherent with each other), waits for the acknowledgements and
+// takes a ticket; whoever draws the last ticket of a tile adds the S partial tiles IN SEGMENT ORDER (the same sums whoever
+// it is), resets the ticket counter for the next launch and goes on with the tile's epilogue -- store, optimiser, copies --
+// as the only workgroup always did.  Nobody waits for anybody.
+struct DwSplit { float* pbuf; int32_t* cnt; };               // workspace: [tiles][S][DW_PART] floats, [tiles] tickets (zero between launches)
+struct DwSeg { int seg, S; };                                // this workgroup's segment of its tile's S (dw_role)
+#define DW_PART 1088                                         // floats of a partial tile: 16 x 64 + 64 column sums
+#define DW_SPLIT_MIN_B 1024                                  // batches from this size on have the workspace for it
+#define DW_SPLIT_MAX 8                                       // segments per tile at most
+#define DW_SPLIT_TILES (4 * 64 + 12 * 16)                    // tiles of a launch at most: 4 hidden matrices + MAX_DW_SMALL x 16 slots
+#define DW_SC1 16                                            // aux bit of a raw buffer access: agent scope
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+// true: this workgroup finishes the tile (v / gb then hold the whole sums); red: LDS scratch (one word)
+__device__ __forceinline__ bool dw_split_combine(const DwSplit& sp, const int gt, const int S, const int seg, const int tid,
+                                                 f32x4& v, float& gb, float* red) {
+  if (S == 1) return true;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(sp.pbuf + (int64_t)gt * S * DW_PART, 0, 0x7fffffff,
+                                                                     0x00020000);
+  if (tid < 256) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dw_u32x4, v), r, (seg * DW_PART + 4 * tid) * 4, 0, DW_SC1);
+  if (tid < 64) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, gb), r, (seg * DW_PART + 1024 + tid) * 4, 0, DW_SC1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(red);
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(sp.cnt + gt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == S - 1;
+    if (last) __hip_atomic_store(sp.cnt + gt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  __syncthreads();
+  if (!last) return false;
+  f32x4 sv = zero4();
+  float sb = 0.f;
+  for (int k = 0; k < S; ++k) {                               // (segment order: whoever is last adds the same way)
+    if (tid < 256) sv += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (k * DW_PART + 4 * tid) * 4, 0, DW_SC1));
+    if (tid < 64) sb += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (k * DW_PART + 1024 + tid) * 4, 0, DW_SC1));
+  }
+  v = sv; gb = sb;
+  return true;
+}
+// the rows [m_lo, m_hi) segment `seg` of S takes of M = 256 C
+__device__ __forceinline__ void dw_split_range(const int M, const int S, const int seg, int& m_lo, int& m_hi) {
+  const int C = M >> 8;
+  m_lo = ((seg * C) / S) << 8;
+  m_hi = (((seg + 1) * C) / S) << 8;
+}
+
+// PIPE: the reduction has several chunks and is software-pipelined (below) -- a kernel of its own: the one-chunk kernel of
+// a single rank's batch keeps its registers and its three workgroups on a CU.
+// (Measured and not kept, round 5: 8 or 16 waves per workgroup splitting the chunks of ONE tile -- two waves of a SIMD then
+//  run in lockstep, loads against loads and matrix instructions against matrix instructions: 73.5 -> 71.4 us at 19 ranks.)
+template <bool ADAM, bool PIPE>
 __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const int t, float* red,
                                    const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
-                                   const AdamEarly* given = nullptr) {
+                                   const AdamEarly* given = nullptr, const DwSplit* sp = nullptr, const int gt = 0,
+                                   const DwSeg sg = DwSeg{0, 1}) {
+  const int S = PIPE ? sg.S : 1, seg = PIPE ? sg.seg : 0;     // (split reduction: dw_split_combine)
+  int m_lo = 0, m_hi = P.M;
+  if (S > 1) dw_split_range(P.M, S, seg, m_lo, m_hi);
   const int nx = P.N >> 6;
   int by, bx;
   tile_divmod(t, nx, by, bx);
@@ -30,33 +93,86 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
   AdamEarly early;
   if (ADAM) {
     early = given ? *given : adam_early(A, eo);
-    pre = adam_prefetch4(A, pidx + eo);
-    if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+    if (S == 1) {                                             // (split: the workgroup that finishes the tile fetches them then)
+      pre = adam_prefetch4(A, pidx + eo);
+      if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+    }
   }
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
-  for (int mb = 0; mb < P.M; mb += 256) {
-    float a[4][4];
-    f32x4 b[4][4];
+  // half h of a 256-row chunk: this wave's 16-row pieces u = 2 h, 2 h + 1
+  auto load_half = [&](const int mb, const int h, float (&a)[2][4], f32x4 (&b)[2][4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
+    for (int u2 = 0; u2 < 2; ++u2) {
+      const int mu = mb + (wv + 4 * (2 * h + u2)) * 16;       // (+ 4 q: in the lane offsets)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
-        b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
+        a[u2][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
+        b[u2][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
       }
     }
+  };
+  auto load_pair = [&](const int mb, const int h, const int u2, const int s, float (&a)[2][4], f32x4 (&b)[2][4]) {
+    const int mu = mb + (wv + 4 * (2 * h + u2)) * 16;
+    a[u2][s] = ld_su(xu + (int64_t)(mu + s) * P.lda, xo);
+    b[u2][s] = ld4_su(yu + (int64_t)(mu + s) * P.ldb, yo);
+  };
+  auto mac_pair = [&](const int u2, const int s, const float (&a)[2][4], const f32x4 (&b)[2][4]) {
+    bsum += b[u2][s];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u2][s], b[u2][s][e], acc[e]);
+  };
+  auto mac_half = [&](const float (&a)[2][4], const f32x4 (&b)[2][4]) {
+#pragma unroll
+    for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mac_pair(u2, s, a, b);
+  };
+  float a0[2][4], a1[2][4];
+  f32x4 b0[2][4], b1[2][4];
+  const int step = 256;
+  int mb = m_lo;
+  if (!PIPE) {
+    // one chunk (a batch of one rank): everything requested, then everything multiplied
+    load_half(mb, 0, a0, b0);
+    load_half(mb, 1, a1, b1);
     LOADS_FIRST();
     DW_STAMP(stamps, 1);
+    mac_half(a0, b0);
+    mac_half(a1, b1);
+  } else {
+    // several chunks (virtual ranks): while one half is multiplied the other is on its way -- the same registers and the
+    // same order of the products as above, but the texture path and the matrix cores work at the same time.  The loads of
+    // the other half go out ONE PAIR AT A TIME, each behind the matrix instructions of one pair of this half: the CU's
+    // waves share one texture path, a wave that issues 16 loads in a row is held at every one of them until the path has
+    // taken it, and its matrix instructions wait behind them -- texture time and matrix time add up instead of overlapping
+    // (tools/dw_lab.hip: 3.5 k cycles per chunk = 1.5 k + 2.0 k, whatever the number of workgroups on the CU; two
+    // workgroups on a CU 48 -> 33 us for the hidden tiles of 19 ranks).
+    if (mb < m_hi) load_half(mb, 0, a0, b0);
+    DW_STAMP(stamps, 1);
+    for (; mb < m_hi; mb += step) {
+      // (behind the last chunk the same rows once more, unused: a branch around those loads makes the number of loads in
+      //  flight depend on the path, and the waits in front of the products become vmcnt(0))
+      const int mbn = (mb + step < m_hi) ? mb + step : mb;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+      for (int u2 = 0; u2 < 2; ++u2)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bsum += b[u][s];
+        for (int s = 0; s < 4; ++s) {
+          load_pair(mb, 1, u2, s, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          mac_pair(u2, s, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = MFMA(a[u][s], b[u][s][e], acc[e]);
-      }
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          load_pair(mbn, 0, u2, s, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          mac_pair(u2, s, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
   }
   DW_STAMP(stamps, 2);
   if (ADAM) {
@@ -68,6 +184,24 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
   }
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
+  float gb = 0.f;
+  if (by == 0) {
+    // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+    }
+  }
+  if (PIPE && S > 1) {
+    if (!dw_split_combine(*sp, gt, S, seg, tid, v, gb, red)) return;
+    if (ADAM) {
+      pre = adam_prefetch4(A, pidx + eo);
+      if (by == 0 && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+    }
+  }
   *reinterpret_cast<f32x4*>(dst) = v;
   if (ADAM && !faulted) {
     adam_apply4(A, (pidx < A.n_Q) ? -aQ : -aPi, pidx + eo, v, pre);
@@ -78,20 +212,11 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
       for (int e = 0; e < 4; ++e) t[(int64_t)e * P.K] = pre.th[e];
     }
   }
-  if (by == 0) {
-    // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
-    __syncthreads();
-    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
-    __syncthreads();
-    if (tid < 64) {
-      float gb = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.aux_out[eg + n0 + tid] = gb;
-      if (ADAM && !faulted) {
-        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
-      }
+  if (by == 0 && tid < 64) {
+    P.aux_out[eg + n0 + tid] = gb;
+    if (ADAM && !faulted) {
+      const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+      A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
     }
   }
 }
@@ -112,10 +237,14 @@ struct DwSmallArgs {
 // One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
 // layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
-template <bool ADAM, bool YV>
+template <bool ADAM, bool YV, bool PIPE>
 __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
                                      const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
-                                     const AdamEarly* given = nullptr) {
+                                     const AdamEarly* given = nullptr, const DwSplit* sp = nullptr, const int gt = 0,
+                                     const DwSeg sg = DwSeg{0, 1}) {
+  const int S = PIPE ? sg.S : 1, seg = PIPE ? sg.seg : 0;     // (split reduction: dw_split_combine)
+  int m_lo = 0, m_hi = M;
+  if (S > 1) dw_split_range(M, S, seg, m_lo, m_hi);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nx = (P.N + 63) >> 6;
   int by, bx;
@@ -144,53 +273,97 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
   AdamEarly early;
   if (ADAM) {
     early = given ? *given : adam_early(A, eo);
+  }
+  auto fetch_params = [&]() {
     if (YV) {
       pre = adam_prefetch4(A, (own ? pidx : 0) + eo);
     } else if (own) {                                       // N == 1: one element per owning thread
       pre.m[0] = A.m[pidx + eo]; pre.v[0] = A.v[pidx + eo]; pre.th[0] = A.theta[pidx + eo];
     }
     if (own_b) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
-  }
+  };
+  if (ADAM && S == 1) fetch_params();                         // (split: the workgroup that finishes the tile fetches them then)
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   f32x4 bsum = zero4();
-  for (int mb = 0; mb < M; mb += 256) {
-    float a[4][4];
-    f32x4 b[4][4];
+  auto load_half = [&](const int mb, const int h, float (&a)[2][4], f32x4 (&b)[2][4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int mu = mb + (wv + 4 * u) * 16;                  // (+ 4 q: in the lane offsets)
+    for (int u2 = 0; u2 < 2; ++u2) {
+      const int mu = mb + (wv + 4 * (2 * h + u2)) * 16;       // (+ 4 q: in the lane offsets)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[u][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
+        a[u2][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
         if (YV) {
-          b[u][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+          b[u2][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
         } else {
-          b[u][s] = zero4();
-          b[u][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+          b[u2][s] = zero4();
+          b[u2][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
         }
       }
     }
+  };
+  const bool scaled = P.div != 1.0f;
+  auto load_pair = [&](const int mb, const int h, const int u2, const int s, float (&a)[2][4], f32x4 (&b)[2][4]) {
+    const int mu = mb + (wv + 4 * (2 * h + u2)) * 16;
+    a[u2][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
+    if (YV) {
+      b[u2][s] = ld4_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+    } else {
+      b[u2][s] = zero4();
+      b[u2][s][0] = ld_su(yu + (int64_t)(mu + s) * P.lddy, yo);
+    }
+  };
+  auto mac_pair = [&](const int u2, const int s, const float (&a)[2][4], const f32x4 (&b)[2][4]) {
+    const float as = scaled ? fdiv(a[u2][s], P.div) : a[u2][s];
+    const float av = k_ok ? as : 0.f;
+    bsum += b[u2][s];
+    if (YV) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u2][s][e], acc[e]);
+    } else {
+      acc[0] = MFMA(av, b[u2][s][0], acc[0]);
+    }
+  };
+  auto mac_half = [&](const float (&a)[2][4], const f32x4 (&b)[2][4]) {
+#pragma unroll
+    for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mac_pair(u2, s, a, b);
+  };
+  float a0[2][4], a1[2][4];
+  f32x4 b0[2][4], b1[2][4];
+  const int step = 256;
+  int mb = m_lo;
+  if (!PIPE) {
+    load_half(mb, 0, a0, b0);
+    load_half(mb, 1, a1, b1);
     LOADS_FIRST();
     DW_STAMP(stamps, 1);
-    if (P.div != 1.0f) {
+    mac_half(a0, b0);
+    mac_half(a1, b1);
+  } else {                                                    // (several chunks: dw_hot_tile)
+    if (mb < m_hi) load_half(mb, 0, a0, b0);
+    DW_STAMP(stamps, 1);
+    for (; mb < m_hi; mb += step) {
+      const int mbn = (mb + step < m_hi) ? mb + step : mb;    // (unconditional loads: dw_hot_tile)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u2 = 0; u2 < 2; ++u2)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[u][s] = fdiv(a[u][s], P.div);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av = k_ok ? a[u][s] : 0.f;
-        bsum += b[u][s];
-        if (YV) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = MFMA(av, b[u][s][e], acc[e]);
-        } else {
-          acc[0] = MFMA(av, b[u][s][0], acc[0]);
+        for (int s = 0; s < 4; ++s) {
+          load_pair(mb, 1, u2, s, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          mac_pair(u2, s, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          load_pair(mbn, 0, u2, s, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          mac_pair(u2, s, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
   }
   DW_STAMP(stamps, 2);
   if (ADAM) {
@@ -199,6 +372,20 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
   }
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
+  float gb = 0.f;
+  if (P.db && by == 0) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
+    }
+  }
+  if (PIPE && S > 1) {
+    if (!dw_split_combine(*sp, gt, S, seg, tid, v, gb, red)) return;
+    if (ADAM) fetch_params();
+  }
   if (own) {
     const float na = (pidx < A.n_Q) ? -aQ : -aPi;
     if (YV) {
@@ -213,19 +400,11 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
       }
     }
   }
-  if (P.db && by == 0) {
-    __syncthreads();
-    *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
-    __syncthreads();
-    if (own_b) {
-      float gb = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
-      P.db[eg + n0 + tid] = gb;
-      if (ADAM && !faulted) {
-        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
-      }
+  if (own_b) {
+    P.db[eg + n0 + tid] = gb;
+    if (ADAM && !faulted) {
+      const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+      A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
     }
   }
 }
@@ -281,24 +460,34 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
 // costs a full ~3 k-cycle (1.4 us) round trip (tools/dw_stamps.py: a block that finds it has nothing to do used to need
 // 3 k cycles to find out; a hidden tile issued its operand loads 6 k cycles after its start, a small tile 10-12 k).
 struct DwMap { int32_t r_her, r_hot, units; };                // units == 0: plain block order
-struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; };
+struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; DwSplit split; };
 // lab (a build with -DDW_STAMPS, tools/build_variant.py, + option "lab_dw_stamps"): 8 x 64-bit words per block of expert 0 -- [0] entry, [1] operand loads issued /
 // gather: tables in, [2] MFMA loop over / gather: rows in LDS, [3] exit, [4] kind (0 gather, 1 hidden tile, 2 small),
 // [5] s_memrealtime at entry (100 MHz, device-wide)
 __device__ inline unsigned long long* dw_stamp_base(const DwAllArgs& a) {
   return (a.stamps && blockIdx.y == 0) ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 }
-struct DwRole { int kind, pi, idx; };
+// (split reduction, DwSplit: `units_s` = units | S_hot << 8 | S_small << 16; the S segments of a tile are S consecutive rows of
+//  8 blocks / S consecutive block ids -- dispatched together)
+struct DwRole { int kind, pi, idx, seg, S; };
 __device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, const int hot_nprob, const int slots,
-                                          const int n_her, const int r_her, const int r_hot, const int units) {
+                                          const int n_her, const int r_her, const int r_hot, const int units_s) {
   DwRole R;
-  R.kind = -1; R.pi = 0; R.idx = 0;
+  R.kind = -1; R.pi = 0; R.idx = 0; R.seg = 0; R.S = 1;
+  const int units = units_s & 0xff;
+  const int S_hot = ((units_s >> 8) & 0xff) ? ((units_s >> 8) & 0xff) : 1, S_small = ((units_s >> 16) & 0xff) ? ((units_s >> 16) & 0xff) : 1;
   const int b = (int)blockIdx.x;
   if (units == 0) {
-    const int bid = b - n_her;
-    if (bid < 0) { R.kind = 0; R.idx = b; }
-    else if (bid < n_hot) { R.kind = 1; R.pi = bid / tiles_per; R.idx = bid - R.pi * tiles_per; }
-    else { R.kind = 2; R.idx = bid - n_hot; }
+    int bid = b - n_her;
+    if (bid < 0) { R.kind = 0; R.idx = b; return R; }
+    if (bid < n_hot * S_hot) {
+      R.S = S_hot; R.seg = bid % S_hot; bid /= S_hot;
+      R.kind = 1; R.pi = bid / tiles_per; R.idx = bid - R.pi * tiles_per;
+    } else {
+      bid -= n_hot * S_hot;
+      R.S = S_small; R.seg = bid % S_small;
+      R.kind = 2; R.idx = bid / S_small;
+    }
     return R;
   }
   const int x = b & 7;
@@ -321,11 +510,13 @@ __device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, 
     return R;
   }
   r -= r_her_;
-  if (r < r_hot) {
+  if (r < r_hot * S_hot) {
+    R.S = S_hot; R.seg = r % S_hot; r /= S_hot;
     const int pi = x / units, u = x - pi * units;
     if (pi < hot_nprob) { R.kind = 1; R.pi = pi; R.idx = u * r_hot + r; }
   } else {
-    const int j = r - r_hot;
+    int j = r - r_hot * S_hot;
+    R.S = S_small; R.seg = j % S_small; j /= S_small;
     const int p = x + 8 * (j / slots);
     R.kind = 2; R.idx = p * slots + j % slots;
   }
@@ -352,9 +543,9 @@ __device__ __forceinline__ void pin_adam(const AdamFuse& A) {
 
 // (the leading scalars: preloaded into SGPRs, see DwMap)
 #define DW_ROUTE_PARAMS const int tiles_per, const int hot_nprob, const int slots, const int small_nprob, const int n_her, \
-                        const int r_her, const int r_hot, const int units
+                        const int r_her, const int r_hot, const int units   /* units | S_hot << 8 | S_small << 16: dw_role */
 // the tile work of a block whose role is known: ONE batch of argument loads, then the tile
-template <bool ADAM>
+template <bool ADAM, bool PIPE>
 __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& args, const AdamFuse& A_, const int slots,
                                              const int small_nprob, float* red, const int64_t eo, int64_t grad_stride,
                                              DwStamp* sp, const AdamEarly* early) {
@@ -365,13 +556,14 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
     if (ADAM) pin_adam(A);
     asm volatile("" :: "s"(grad_stride));
     DW_STAMP(sp, 3);
-    dw_hot_tile<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, sp, early);
+    dw_hot_tile<ADAM, PIPE>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, sp, early, &args.split,
+                                R.pi * args.hot.tiles_per + R.idx, DwSeg{R.seg, R.S});
     return;
   }
   const int pi = R.idx / slots, t = R.idx - pi * slots;
   if (pi >= small_nprob) {
     // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
-    if (pi == small_nprob && t == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
+    if (pi == small_nprob && t == 0 && R.seg == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
     return;
   }
   DwSmall P = args.small.p[pi];
@@ -382,10 +574,12 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   DW_STAMP(sp, 3);
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
   const int64_t eg = (int64_t)blockIdx.y * grad_stride;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true>(P, M, A, t, red, eo, eg, sp, early);
-  else dw_small_tile<ADAM, false>(P, M, A, t, red, eo, eg, sp, early);
+  const int gt = args.n_hot + R.idx;
+  if ((P.N & 3) == 0) dw_small_tile<ADAM, true, PIPE>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
+  else dw_small_tile<ADAM, false, PIPE>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
                                                      int64_t grad_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
@@ -393,7 +587,7 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex
   none.fault = nullptr;
   const int64_t eo = (int64_t)blockIdx.y * ex_stride;
   const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, 0, r_her, r_hot, units);
-  if (R.kind > 0) dw_tile_role<false>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
+  if (R.kind > 0) dw_tile_role<false, PIPE>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
 }
 
 // The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
@@ -402,6 +596,7 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
+template <bool PIPE>
 __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
                                                           int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
                                                           int64_t grad_stride, uint64_t seed_stride) {
@@ -428,7 +623,7 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const
       const int64_t c = *ex_i64(ctr0, eo);
       early.lo = (int32_t)c; early.hi = (int32_t)(c >> 32);
     }
-    dw_tile_role<true>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
+    dw_tile_role<true, PIPE>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
   }
 #ifdef DW_STAMPS
   unsigned long long* st = dw_stamp_base(args);

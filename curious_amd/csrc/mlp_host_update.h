@@ -89,32 +89,51 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     // matrices divide the 8 XCDs evenly (2 or 4 of them: 4 or 2 XCDs each)
     DwMap map;
     memset(&map, 0, sizeof(map));
-    auto dw_grid = [&](int n_her) -> int {
+    auto dw_grid = [&](int n_her, int S_hot = 1, int S_small = 1) -> int {
       const int np = hwAll.nprob;
       if (curious_options().dw_xcd && (np == 2 || np == 4) && hwAll.tiles_per == 64) {
         map.units = 8 / np;
         map.r_hot = hwAll.tiles_per / map.units;
         map.r_her = (n_her + 7) / 8;
         const int r_small = smAll.slots * ((smAll.nprob + 1 + 7) / 8);      // + 1: the loss finalisation
-        const int gx_ = 8 * (map.r_her + map.r_hot + r_small);
+        const int gx_ = 8 * (map.r_her + map.r_hot * S_hot + r_small * S_small);
         if (B > 256) map.r_her = -map.r_her;                  // several virtual ranks: the gather blocks come last (DwMap)
         return gx_;
       }
-      return n_her + tAll + nsmall + 1;
+      return n_her + tAll * S_hot + (nsmall + 1) * S_small;
     };
     if (curious_options().lab_dw_stamps) dwAll.stamps = reinterpret_cast<unsigned long long*>(w.part[0]);
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
-      const int gx = dw_grid(n_her);
+      // By default only the SMALL tiles are split (mlp_dw.h DwSplit; layer-0 segments and output layers: as many chunks as
+      // a hidden tile, and they are what the launch ends with); option "dw_split" = 10 S_hot + S_small overrides (A/B)
+      int S_hot = 1, S_small = 1;
+      if (w.split && xd.nex == 1 && B % 256 == 0 && tAll + nsmall <= DW_SPLIT_TILES) {
+        const int C = B / 256, opt = curious_options().dw_split;
+        S_small = std::min(4, C / 2);
+        if (opt > 0) { S_hot = opt / 10; S_small = opt % 10; }
+        S_hot = std::max(1, std::min(S_hot, std::min(DW_SPLIT_MAX, C)));
+        S_small = std::max(1, std::min(S_small, std::min(DW_SPLIT_MAX, C)));
+      }
+      const int gx = dw_grid(n_her, S_hot, S_small);
+      const int units_s = map.units | (S_hot << 8) | (S_small << 16);
       if (dwAll.stamps && (int64_t)gx * 8 * 2 > 6 * 16 * (int64_t)B) dwAll.stamps = nullptr;   // (room: part[0..5])
       { ProfScope ps__(CK_DW_ADAM_HER, st);
         const AdamFuse& af = tail->adam;
         // (never NULL in the kernel: a block loads both words before it knows whether it will need them)
         const int32_t* fault0 = af.fault ? af.fault : reinterpret_cast<const int32_t*>(af.theta);
         const int64_t* ctr0 = af.alpha_tab ? af.step_ctr : reinterpret_cast<const int64_t*>(af.theta);
-        hipLaunchKernelGGL(dw_adam_her_kernel, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
-                           smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, map.units, fault0, ctr0,
-                           (int64_t)xd.stride, dwAll, tail->adam, tail->h, (int64_t)xd.gstride, seed_stride); }
+        // batches of several chunks of 256 rows (virtual ranks): the pipelined form of the tiles (mlp_dw.h PIPE)
+        // the split reduction (mlp_dw.h DwSplit): S workgroups per tile, 2 chunks of 256 rows or more each
+        dwAll.split.pbuf = w.split; dwAll.split.cnt = w.split_cnt;
+#define DW_LAUNCH(PIPE)                                                                                        \
+  hipLaunchKernelGGL((dw_adam_her_kernel<PIPE>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,          \
+                     hwAll.nprob, smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, units_s, fault0, ctr0, \
+                     (int64_t)xd.stride, dwAll, tail->adam, tail->h, (int64_t)xd.gstride, seed_stride)
+        if (B <= 256) DW_LAUNCH(false);
+        else DW_LAUNCH(true);
+#undef DW_LAUNCH
+      }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel");
       return 0;
     }
@@ -123,9 +142,14 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
       const int gx = dw_grid(0);
-      hipLaunchKernelGGL(dw_all_kernel, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob, smAll.slots,
-                         smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
-                         (int64_t)xd.gstride); }
+      if (B <= 256)
+        hipLaunchKernelGGL(dw_all_kernel<false>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
+                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
+                           (int64_t)xd.gstride);
+      else
+        hipLaunchKernelGGL(dw_all_kernel<true>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
+                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
+                           (int64_t)xd.gstride); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");

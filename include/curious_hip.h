@@ -135,8 +135,12 @@ int curious_prof_launch_counts(int64_t* counts_host);
  *                  handed to the kernel as leading arguments (in scalar registers when a wave starts) where the shapes
  *                  allow; 0: fetched from the argument segment (same results; A/B)
  *   "rows8"        1 (default; env CURIOUS_ROWS8): the row-local update gives 8 batch rows to a workgroup instead of 4 when the
- *                  batch has >= 768 rows (three virtual ranks or more: half the weight stream per row); 0: always 4 (A/B; results
- *                  agree to summation order -- the rows are independent, every row's arithmetic is the same)
+ *                  batch has >= 768 rows (three virtual ranks or more: half the weight stream per row); 0: always 4 (A/B; the
+ *                  same bits -- the rows are independent and every row's arithmetic keeps its order)
+ *   "dw_split"     0 (default; env CURIOUS_DW_SPLIT): batches of >= 1 024 rows split the reduction over the batch rows of the
+ *                  SMALL weight-gradient tiles (layer-0 segments, output layers) over min(4, chunks of 256 rows / 2)
+ *                  workgroups, the last of which to arrive adds the partial tiles in segment order and runs the optimiser;
+ *                  10 h + s: h workgroups per hidden-layer tile, s per small tile (11 = no split; A/B)
  *   "dw_xcd"       1 (default; env CURIOUS_DW_XCD): blocks of the weight-gradient / optimiser launch placed by XCD
  *   "xcd_map"      0 (default; env CURIOUS_XCD_MAP) / 4 / 8: XCD-aware block placement of the tiled hidden-layer kernels
  *   "fault_inject" 0 (default) / k > 0: the producer of Q' of row group k - 1 never publishes; a member of group k - 1 of

@@ -171,9 +171,14 @@ def test_virtual_ranks_match_the_oracle_rank_model(V, graph, route):
             nxt[0][sl], nxt[1][sl], nxt[2][sl], _ = adam_update(th[sl], m[sl], v[sl], k, g, lr)
         suffix = ('_pre_%d' % (k + 1)) if k + 1 < n_upd else ''
         got = [rec[name + suffix] for name in ('theta', 'm', 'v')]
-        np.testing.assert_allclose(got[1], nxt[1], rtol=0, atol=2e-5 * np.abs(nxt[1]).max())
-        np.testing.assert_allclose(got[2], nxt[2], rtol=0, atol=4e-5 * np.abs(nxt[2]).max())
-        assert np.abs(got[0] - nxt[0]).max() <= 2e-5, k              # one Adam step of size 1e-3
+        # (m, v within 2e-5 / 4e-5 of their max-norm -- but for the odd unit whose pre-activation lies within float32 rounding
+        #  of zero on some row and falls on the other side of the ReLU than in the float64 oracle: that row's term of the
+        #  unit's column, ~1e-4 of the max-norm; with 19 x 256 rows x ~4 000 units per update it happens every few updates.
+        #  At most 0.1 % of the elements, none beyond 5e-4: a lost chunk of rows or a wrong tile would be 100 x that)
+        for gv, nv, tol in ((got[1], nxt[1], 2e-5), (got[2], nxt[2], 4e-5)):
+            dev = np.abs(gv - nv) / np.abs(nv).max()
+            assert dev.max() <= 5e-4 and (dev > tol).mean() <= 1e-3, (k, dev.max(), (dev > tol).mean())
+        assert np.abs(got[0] - nxt[0]).max() <= 1e-4, k              # one Adam step of size 1e-3
         assert (np.abs(got[0] - nxt[0]) > 2e-6).mean() < 1e-3, k
         if k == 0:
             # SUM, not mean, and not one rank alone: the first moments are V times one rank's
@@ -247,6 +252,44 @@ def test_eight_rows_per_workgroup_change_no_bit(V, graph):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(outs[0][3]).all()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_split_reduction_of_the_weight_gradient_tiles(graph):
+    """Option dw_split = 10 S_hot + S_small (csrc/mlp_dw.h DwSplit; batches of >= 1 024 rows): S workgroups per
+    weight-gradient tile (hidden-layer tiles / small tiles) take a segment of the batch rows each, the last one to arrive adds
+    the S partial tiles in segment order and runs the optimiser.
+    Whoever is last, the sums are the same: a run is reproduced bit for bit; against the unsplit launch the gradient
+    agrees to the rounding of another summation order, the losses (computed before) bit for bit."""
+    from curious_amd import ops
+    V = 5                                                             # 1 280 rows: 5 chunks of 256
+    outs = {}
+    for S, rep in ((11, 0), (12, 0), (12, 1), (33, 0), (25, 0), (81, 0), (0, 0)):
+        with ops.option('dw_split', S):
+            agent = make_agent(V, use_graph=graph)
+            draw = rank_episodes(V, 12)
+            agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+            agent.train_batches(1)
+            torch.cuda.synchronize()
+            first = [t.cpu().numpy().copy() for t in (agent.grad, agent._losses, agent._m)]
+            agent.train_batches(11)
+            agent.update_target_net()
+            agent.train_batches(4)
+            torch.cuda.synchronize()
+            agent.check_faults(wait=True)
+            outs[(S, rep)] = first + [t.cpu().numpy().copy() for t in (agent.theta, agent._m, agent._v, agent._losses)]
+    ref = outs[(11, 0)]
+    gmax = np.abs(ref[0]).max()
+    for key, o in outs.items():
+        np.testing.assert_array_equal(o[1], ref[1])                  # losses of the first update
+        assert np.abs(o[0] - ref[0]).max() <= 2e-6 * gmax, key       # its gradient
+        np.testing.assert_allclose(o[2], ref[2], rtol=0, atol=2e-7 * gmax)
+        assert np.isfinite(o[3]).all() and np.abs(o[3] - ref[3]).max() < 5e-3, key
+    for a, b in zip(outs[(12, 0)], outs[(12, 1)]):                    # the same run twice
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(outs[(0, 0)], outs[(12, 0)]):                     # 0 = by batch size: 5 chunks -> small tiles in 2 segments
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(outs[(33, 0)][0] - ref[0]).max() > 0                # (the split did happen)
 
 
 # ------------------------------------------------------------------ piece by piece against the one-rank entry points
