@@ -185,7 +185,7 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
   f32x4 v; int orow, c4;
   hot_store(red, acc, wave, q, j, tid, v, orow, c4);
   float gb = 0.f;
-  if (by == 0) {
+  auto bias_reduce = [&]() {
     // column sums of B: 16 partials (4 waves x 4 lane groups) per column through LDS
     __syncthreads();
     *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
@@ -194,8 +194,10 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
     }
-  }
-  if (PIPE && S > 1) {
+  };
+  const bool split = PIPE && S > 1;
+  if (split) {
+    if (by == 0) bias_reduce();
     if (!dw_split_combine(*sp, gt, S, seg, tid, v, gb, red)) return;
     if (ADAM) {
       pre = adam_prefetch4(A, pidx + eo);
@@ -212,11 +214,14 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
       for (int e = 0; e < 4; ++e) t[(int64_t)e * P.K] = pre.th[e];
     }
   }
-  if (by == 0 && tid < 64) {
-    P.aux_out[eg + n0 + tid] = gb;
-    if (ADAM && !faulted) {
-      const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-      A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+  if (by == 0) {
+    if (!split) bias_reduce();                                // (behind the tile's own stores: they are what the launch waits for)
+    if (tid < 64) {
+      P.aux_out[eg + n0 + tid] = gb;
+      if (ADAM && !faulted) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+      }
     }
   }
 }
@@ -237,7 +242,9 @@ struct DwSmallArgs {
 // One 16 x 64 tile of a small problem.  YV: N % 4 == 0 (16-byte dY fragments); otherwise N == 1 (the critic's output
 // layer): one dY column, one accumulator, a quarter of the MFMAs.  Uniform conditions are hoisted out of the unrolled
 // load / MFMA loops (a branch per fragment made this body slower than a full 256-deep hidden-layer tile).
-template <bool ADAM, bool YV, bool PIPE>
+// SC: the X elements are divided by P.div (the action segment with max_u != 1; a form of its own: with the division behind
+// a select in the common form every tile would pay for it -- 16 divisions per wave and chunk, 0.3 us per launch)
+template <bool ADAM, bool YV, bool PIPE, bool SC>
 __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const AdamFuse& A, const int t, float* red,
                                      const int64_t eo, const int64_t eg, DwStamp* stamps = nullptr,
                                      const AdamEarly* given = nullptr, const DwSplit* sp = nullptr, const int gt = 0,
@@ -301,7 +308,6 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
       }
     }
   };
-  const bool scaled = P.div != 1.0f;
   auto load_pair = [&](const int mb, const int h, const int u2, const int s, float (&a)[2][4], f32x4 (&b)[2][4]) {
     const int mu = mb + (wv + 4 * (2 * h + u2)) * 16;
     a[u2][s] = ld_su(xu + (int64_t)(mu + s) * P.ldx, xo);
@@ -313,7 +319,7 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
     }
   };
   auto mac_pair = [&](const int u2, const int s, const float (&a)[2][4], const f32x4 (&b)[2][4]) {
-    const float as = scaled ? fdiv(a[u2][s], P.div) : a[u2][s];
+    const float as = SC ? fdiv(a[u2][s], P.div) : a[u2][s];
     const float av = k_ok ? as : 0.f;
     bsum += b[u2][s];
     if (YV) {
@@ -373,7 +379,7 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
   int orow, c4;
   f32x4 v = reduce_tile(red, acc, wave, q, j, tid, orow, c4);
   float gb = 0.f;
-  if (P.db && by == 0) {
+  auto bias_reduce = [&]() {
     __syncthreads();
     *reinterpret_cast<f32x4*>(red + (wave * 4 + q) * 64 + 4 * j) = bsum;
     __syncthreads();
@@ -381,8 +387,10 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
 #pragma unroll
       for (int r = 0; r < 16; ++r) gb += red[r * 64 + tid];
     }
-  }
-  if (PIPE && S > 1) {
+  };
+  const bool split = PIPE && S > 1;
+  if (split) {
+    if (P.db && by == 0) bias_reduce();
     if (!dw_split_combine(*sp, gt, S, seg, tid, v, gb, red)) return;
     if (ADAM) fetch_params();
   }
@@ -400,11 +408,14 @@ __device__ DW_INLINE void dw_small_tile(const DwSmall& P, const int M, const Ada
       }
     }
   }
-  if (own_b) {
-    P.db[eg + n0 + tid] = gb;
-    if (ADAM && !faulted) {
-      const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
-      A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+  if (P.db && by == 0) {
+    if (!split) bias_reduce();
+    if (own_b) {
+      P.db[eg + n0 + tid] = gb;
+      if (ADAM && !faulted) {
+        const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+        A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+      }
     }
   }
 }
@@ -575,8 +586,9 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
   const int64_t eg = (int64_t)blockIdx.y * grad_stride;
   const int gt = args.n_hot + R.idx;
-  if ((P.N & 3) == 0) dw_small_tile<ADAM, true, PIPE>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
-  else dw_small_tile<ADAM, false, PIPE>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
+  if ((P.N & 3) != 0) dw_small_tile<ADAM, false, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
+  else if (P.div != 1.0f) dw_small_tile<ADAM, true, PIPE, true>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
+  else dw_small_tile<ADAM, true, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
 }
 
 template <bool PIPE>

@@ -146,12 +146,12 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   // 8 rows per workgroup once every CU holds several row groups (mlp_rows.h ROWS_R2): the rows of a batch are independent,
   // so the split changes no row's arithmetic
   ra_R = (curious_options().rows8 && B >= ROWS_R2_MIN && B % (4 * ROWS_R2) == 0) ? ROWS_R2 : ROWS_R;
-  const size_t lds = rows_lds_floats(ra_R) * sizeof(float);
+  const size_t lds = rows_lds_floats(ra_R, nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
     // (the kernel also has ~1 KB of static LDS -- the task tables of its gather blocks: dynamic + static must stay <= 80 KB
     //  for two workgroups to share a CU)
-    const int max_dyn = (int)(rows_lds_floats(ROWS_R2) * sizeof(float));
+    const int max_dyn = (int)(rows_lds_floats(ROWS_R2, ROWS_MAXL) * sizeof(float));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<true, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false, ROWS_R2>),

@@ -24,7 +24,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     const int chain = critic ? 1 : 2;
     float** dact = w.dact[critic ? 0 : 2];
     auto add_small = [&](const Seg& x, const float* dY, int lddy, int N, float* dW, float* db) {
-      if (ns_ >= MAX_DW_SMALL || x.sub || x.mean || x.clip > 0.0f || !(N % 4 == 0 || N == 1) ||
+      if (ns_ >= MAX_DW_SMALL || x.sub || x.mean || x.clip > 0.0f || !(N % 4 == 0 || N == 1) || (N == 1 && x.div != 1.0f) ||
           !(N == 1 || (aligned16(dY) && lddy % 4 == 0 && aligned16(dW)))) { ok = false; return; }
       DwSmall& p = sm.p[ns_++];
       p.x = x.x; p.ldx = x.ld; p.w = x.w; p.div = x.div; p.dY = dY; p.lddy = lddy; p.N = N; p.dW = dW; p.db = db;
@@ -235,7 +235,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
                   "curious_ddpg_grads: the next batch must be keyed by this call's step counter");
     if (her_fill_args(p.her_rows, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
                       next->batch, BL)) return -1;
-    p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R) * sizeof(float) &&
+    p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R, cfg->layers) * sizeof(float) &&
                        (B % (ROWS_R * 4) == 0) && SPB == ROWS_R;
   }
   if (!rc && p.rows_route()) {

@@ -105,7 +105,8 @@ struct RowsArgs {
 struct RCtx {
   mutable unsigned long long* dbg;
   float* hs; mutable float* part; mutable float* part2; float* xin; float* sm;
-  mutable uint64_t kb;            // relu' masks of the kept layers, R bits to a layer (rows_keep)
+  float* keep;                    // relu' masks of the kept layers: 4 rows per workgroup -- the kept activations in LDS;
+  mutable uint64_t kb;            // 8 rows -- 8 bits to a layer (rows_keep)
   int tid, wave, lane, r0;
 };
 // a result other workgroups read: the weight-gradient launch that follows
@@ -123,8 +124,9 @@ __device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
 
 // ================================================================== the kernel
 // grid (4 * B / R, 1, n_experts); B % (4 R) == 0.
-static inline size_t rows_lds_floats(int R = ROWS_R) {
-  return (size_t)R * RLD + 2 * 4 * R * 256 + R * XLD + 64;   // (two buffers of partials: rows_fw_finish) 39 KB | 77 KB
+static inline size_t rows_lds_floats(int R, int nl) {
+  return (size_t)R * RLD + 2 * 4 * R * 256 + R * XLD + 64 +  // (two buffers of partials: rows_fw_finish)
+         (R == ROWS_R ? (size_t)2 * nl * 4 * 256 : 0);       // 4 rows: the kept activations (rows_keep); 64 KB | 77 KB
 }
 
 // HER: the launch carries the gather of the next batch (ddpg_rows_her_kernel: a kernel of its own, so that the plain
@@ -142,6 +144,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   x.part2 = x.part + 4 * R * 256;
   x.xin = x.part2 + 4 * R * 256;
   x.sm = x.xin + R * XLD;
+  x.keep = x.sm + 64;                                       // (4 rows) [2 * nl][4 rows][256]: activations kept for relu'
   x.kb = 0;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   // Kind of workgroup and row group from the block id.  Workgroups are dealt round-robin over the 8 XCDs in block-id

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   x.part = x.hs + 4 * RLD;
   x.xin = x.part + 4 * 4 * 256;
   x.sm = x.xin + 4 * XLD;
-  x.kb = 0; x.dbg = nullptr;
+  x.keep = nullptr; x.kb = 0; x.dbg = nullptr;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   x.r0 = blockIdx.x * ROWS_R;
   const int Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;

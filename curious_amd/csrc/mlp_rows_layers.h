@@ -131,19 +131,38 @@ __device__ __forceinline__ void rows_finish_sums(const RCtx& x, const f32x4 (&ac
   for (int r = 0; r < R; ++r) s[r] = (p[r][0] + p[r][1]) + (p[r][2] + p[r][3]);
   if (lean) { x.part = x.part2; x.part2 = part; }
 }
-// ---- relu' masks of the kept layers.  Thread tid finishes column tid of every row and is the only one that ever asks
-// whether (row r, column tid) of a kept layer was positive: the masks are bits of a per-thread word, R to a layer
-// (slot = layer, + nl for the second network of the actor side; up to 8 slots of up to 8 rows) -- no LDS.  (Until round 5
-// the kept activations themselves lay in LDS, 2 nl x R KB: with 8 rows two workgroups would no longer have shared a CU.)
+// ---- relu' masks of the kept layers (slot = layer, + nl for the second network of the actor side).  Thread tid finishes
+// column tid of every row and is the only one that ever asks whether (row r, column tid) of a kept layer was positive.
+// 4 rows: the kept activations lie in LDS (x.keep: [slot][4][256]; the form the single-rank kernel was tuned with).  8 rows:
+// the masks are bits of a per-thread word, 8 to a layer -- 2 nl x 8 KB of kept activations would leave no room for a second
+// workgroup on the CU.
 template <int R>
 __device__ __forceinline__ void rows_keep(const RCtx& x, const int slot, const float (&s)[R]) {
+  if (R == 4) {
+    float* keep = x.keep + slot * 1024;
+#pragma unroll
+    for (int r = 0; r < R; ++r) keep[r * 256 + x.tid] = s[r];
+    return;
+  }
   uint32_t bits = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) bits |= (s[r] > 0.f) ? (1u << r) : 0u;
   x.kb |= (uint64_t)bits << (slot * R);
 }
 template <int R>
-__device__ __forceinline__ uint32_t rows_kept(const RCtx& x, const int slot) { return (uint32_t)(x.kb >> (slot * R)); }
+__device__ __forceinline__ uint32_t rows_kept(const RCtx& x, const int slot) {
+  if (R == 4) {
+    const float* keep = x.keep + slot * 1024;
+    float k[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) k[r] = keep[r * 256 + x.tid];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bits |= (k[r] > 0.f) ? (1u << r) : 0u;
+    return bits;
+  }
+  return (uint32_t)(x.kb >> (slot * R));
+}
 // keep: slot of the layer's relu' mask (rows_keep) or -1
 template <int R>
 __device__ __forceinline__ void rows_fw_finish(const RCtx& x, const f32x4 (&acc)[R / 4][4], const float bv, const int keep,

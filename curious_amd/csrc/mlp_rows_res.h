@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
   x.sm = x.xin + 4 * XLD;
   float* h2s = x.sm + 64;                                    // [4][64]: this member's slice of the last hidden layer
   double* nzb = reinterpret_cast<double*>(h2s + 4 * 64);
-  x.kb = 0; x.dbg = nullptr;
+  x.keep = nullptr; x.kb = 0; x.dbg = nullptr;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   int group, member;
   if (rx.xmap) {
