@@ -625,7 +625,9 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const
   const int64_t eo = (int64_t)blockIdx.y * ex_stride;
   const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, n_her, r_her, r_hot, units);
   if (R.kind == 0) {
+#ifndef DW_NO_GATHER        // (lab, tools/build_variant.py: what the gather blocks cost the launch -- wrong batches, right timing)
     her_sample_body(h, R.idx, red, eo, (uint64_t)blockIdx.y * seed_stride, 0, sp);
+#endif
   } else if (R.kind > 0) {
     // the optimiser's two scalar inputs (fault word, step counter): their pointers came with the wave, so the loads go
     // out before the first argument is fetched from memory (fault0 / ctr0 == A.fault / A.step_ctr or a valid dummy)

@@ -12,4 +12,6 @@ cp $S/bench_v19_under_rocprof.json $P/r05_bench_virtual_ranks_19_under_rocprof.j
 cp $S/learn_curious_progress.csv $P/r05_learning_curve_arm4.csv
 cp $S/soak_progress.csv $P/r05_soak_arm4_300_epochs.csv
 cp $S/floor2_lab.txt $P/r05_floor2_lab.txt
+cp $S/learn_num_cpu19_16_progress.csv $P/r05_learning_curve_arm4_num_cpu19_16_rollouts.csv
+[ -s $S/learn_num_cpu19_ref_progress.csv ] && cp $S/learn_num_cpu19_ref_progress.csv $P/r05_learning_curve_arm4_num_cpu19_reference_regime_800_epochs.csv
 cat $S/head.txt

@@ -49,11 +49,19 @@ cp save/MultiTaskFetchArm4-v5/0/progress.csv learn_curious_progress.csv
 ( time timeout 600 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --n_epochs 300 --n_cycles 25 --n_batches 100 --rollout_batch_size 256 --seed 3 --trial_id 2 > soak.log 2>&1 ) 2> time_soak.txt
 cp save/MultiTaskFetchArm4-v5/2/progress.csv soak_progress.csv
 rm -rf save
-tail -n 3 time_curious.txt time_soak.txt
+# the reference's rank count on one GPU (virtual ranks): 19 x 16 rollouts, and the reference's own per-rank numbers (19 x 2, 100 updates)
+( time timeout 300 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --num_cpu 19 --rollout_batch_size 16 --n_batches 40 --n_epochs 150 --n_cycles 25 --seed 1 > learn_num_cpu19_16.log 2>&1 ) 2> time_num_cpu19_16.txt
+cp save/MultiTaskFetchArm4-v5/0/progress.csv learn_num_cpu19_16_progress.csv
+if [ -n "$LONG" ]; then
+( time timeout 900 python -m curious_amd.experiment.train --env MultiTaskFetchArm4-v5 --num_cpu 19 --rollout_batch_size 2 --n_batches 100 --n_epochs 800 --n_cycles 25 --seed 1 --trial_id 3 > learn_num_cpu19_ref.log 2>&1 ) 2> time_num_cpu19_ref.txt
+cp save/MultiTaskFetchArm4-v5/3/progress.csv learn_num_cpu19_ref_progress.csv
+fi
+rm -rf save
+tail -n 3 time_curious.txt time_soak.txt time_num_cpu19_16.txt
 python - <<'PY'
 import csv, re
 import numpy as np
-for f in ('learn_curious_progress.csv', 'soak_progress.csv'):
+for f in ('learn_curious_progress.csv', 'soak_progress.csv', 'learn_num_cpu19_16_progress.csv'):
     rows=list(csv.DictReader(open(f)))
     print(f, len(rows), [ (r['epoch'], r['test/success_rate']) for r in rows[::max(1,len(rows)//10)] ], rows[-1]['test/success_rate'])
 t=np.array([float(m.group(1)) for m in re.finditer(r"over in\s+([0-9.]+)\s+s", open("soak.log").read())])
