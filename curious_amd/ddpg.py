@@ -56,7 +56,8 @@ class DDPG(ActingMixin, StoringMixin, SamplingMixin, UpdateSchedulesMixin, RankS
                  rollout_batch_size, subtract_goals, relative_goals, clip_pos_returns, clip_return,
                  normalize_obs, sample_transitions, gamma, buffers=None, reuse=False, tasks_ag_id=None,
                  tasks_g_id=None, task_replay='', t_id=None, eps_task=None, structure='curious',
-                 rng_mode='numpy', seed=0, use_graph=False, async_store=False, virtual_ranks=1, **kwargs):
+                 rng_mode='numpy', seed=0, use_graph=False, async_store=False, virtual_ranks=1, rank_base=None,
+                 total_ranks=None, **kwargs):
         """Same arguments as the reference (ddpg.py:20-59) plus rng_mode / seed / use_graph / async_store / virtual_ranks.
 
         virtual_ranks = V > 1: this process stands for V of the reference's MPI ranks (readme.md:16: the published runs use
@@ -69,6 +70,10 @@ class DDPG(ActingMixin, StoringMixin, SamplingMixin, UpdateSchedulesMixin, RankS
         if self.clip_return is None:
             self.clip_return = np.inf
         self.V = self.virtual_ranks = int(virtual_ranks or 1)
+        # global rank of this process's first virtual rank / ranks of the whole job: V per process unless the job was laid
+        # out unevenly (dist.virtual_layout: --num_cpu 19 on 8 processes)
+        self.rank_base = int(rank_base) if rank_base is not None else dist.rank() * self.V
+        self.total_ranks = int(total_ranks) if total_ranks is not None else dist.world_size() * self.V
         if self.V > 1 and not (rng_mode == 'device' and structure == 'curious'):
             raise ValueError("virtual_ranks > 1 needs rng_mode='device' and structure='curious'")
         self._Bt = self.V * int(batch_size)                          # rows of one update's joint batch
@@ -214,8 +219,9 @@ class DDPG(ActingMixin, StoringMixin, SamplingMixin, UpdateSchedulesMixin, RankS
 
     def _grank0(self):
         """Global rank of this process's first (virtual) rank: rank r of a job with V virtual ranks per process stands for
-        the reference's ranks r V .. r V + V - 1 (train.py:242-243: every rank has its own seed)."""
-        return dist.rank() * self.V
+        the reference's ranks r V .. r V + V - 1 (train.py:242-243: every rank has its own seed); an uneven layout
+        (dist.virtual_layout) hands the base in."""
+        return self.rank_base
 
     def _adopt_buffers(self):
         """All per-task buffers must share one pool so that a mixed minibatch is a single gather launch."""

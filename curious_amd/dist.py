@@ -144,14 +144,37 @@ def allreduce_sum_numpy(x):
     return t.cpu().numpy()
 
 
-def allgather_numpy(x):
-    """[n, ...] host array per rank -> [world*n, ...] (C9): on the host-side group."""
+def allgather_numpy(x, uneven=False):
+    """[n, ...] host array per rank -> [sum of the ranks' n, ...] in rank order (C9): on the host-side group.  uneven: the
+    ranks' n may differ (processes that stand for different numbers of virtual ranks, virtual_layout): the lengths go
+    round first, the blocks travel padded to the longest."""
     if not is_distributed():
         return np.asarray(x)
-    t = torch.as_tensor(np.ascontiguousarray(x)).to(_comm_device())
+    x = np.ascontiguousarray(x)
+    if uneven:
+        lens = allgather_numpy(np.array([x.shape[0]], np.int64)).astype(np.int64)
+        m = int(lens.max())
+        if x.shape[0] < m:
+            x = np.concatenate([x, np.zeros((m - x.shape[0],) + x.shape[1:], x.dtype)])
+    t = torch.as_tensor(x).to(_comm_device())
     out = [torch.empty_like(t) for _ in range(world_size())]
     td.all_gather(out, t.contiguous(), group=host_group())
+    if uneven:
+        return torch.cat([o[:int(n)] for o, n in zip(out, lens)], dim=0).cpu().numpy()
     return torch.cat(out, dim=0).cpu().numpy()
+
+
+def virtual_layout(num_cpu, world=None, r=None):
+    """--num_cpu R on W processes: process r stands for V_r of the reference's ranks -- R // W of them, one more on the first
+    R % W processes -- starting at global rank base_r; exactly R ranks in all (readme.md:16 publishes R = 19: on 8 GPUs
+    3 + 3 + 3 + 2 + 2 + 2 + 2 + 2).  Returns (V_r, base_r, R); R <= W: (1, r, W)."""
+    world = world_size() if world is None else int(world)
+    r = rank() if r is None else int(r)
+    num_cpu = int(num_cpu)
+    if num_cpu <= world:
+        return 1, r, world
+    q, rem = divmod(num_cpu, world)
+    return q + (1 if r < rem else 0), r * q + min(r, rem), num_cpu
 
 
 def host_any(flag):

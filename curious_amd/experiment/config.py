@@ -39,7 +39,8 @@ def cached_make_env(make_env):
 # what prepare_params moves into ddpg_params (config.py:129-139); a '_name' copy stays in the params for the logs
 _DDPG_KEYS = ('hidden', 'layers', 'network_class', 'polyak', 'batch_size', 'Q_lr', 'pi_lr', 'norm_eps', 'norm_clip',
               'max_u', 'action_l2', 'clip_obs', 'scope', 'relative_goals')
-_DEVICE_KEYS = ('rng_mode', 'use_graph', 'seed', 'async_store', 'virtual_ranks')   # MI355X-side knobs (not in the reference)
+_DEVICE_KEYS = ('rng_mode', 'use_graph', 'seed', 'async_store', 'virtual_ranks', 'rank_base',
+                'total_ranks')                                     # MI355X-side knobs (not in the reference)
 
 
 def prepare_params(kwargs):

@@ -239,17 +239,19 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         save_dir = None
     if perturb and structure == 'task_experts':
         raise NotImplementedError('--perturb applies to the curious / flat loop only (train.py:142-146)')
-    # Virtual ranks: --num_cpu R with R > WORLD_SIZE runs V = ceil(R / WORLD_SIZE) of the reference's ranks per process
-    # (readme.md:16: the published runs use 19 ranks, and "fewer cpus for a longer time is NOT equivalent";
-    # train.py:272-281).  Process r stands for the global ranks r V .. r V + V - 1.
+    # Virtual ranks: --num_cpu R with R > WORLD_SIZE runs the reference's R ranks on the WORLD_SIZE processes -- R // W per
+    # process, one more on the first R % W (readme.md:16: the published runs use 19 ranks, and "fewer cpus for a longer
+    # time is NOT equivalent"; train.py:272-281): exactly R ranks whatever the GPU count (dist.virtual_layout).  Process r
+    # stands for the global ranks base .. base + V - 1.
     world = dist.world_size()
-    V = 1
+    V, base, total = 1, rank, world
     if num_cpu > world:
         over = dict(override_params or {})
         ok = (structure == 'curious' and over.get('rng_mode', 'device') == 'device' and 'buffer' in task_replay)
         if ok:
-            V = -(-num_cpu // world)
-    rank_seed = seed + 1000000 * rank * V                             # train.py:242-243 (of this process's first rank)
+            V, base, total = dist.virtual_layout(num_cpu)
+    # (a process that stands for ONE rank of an uneven layout runs the single-rank agent: nothing of its own needs V)
+    rank_seed = seed + 1000000 * base                                 # train.py:242-243 (of this process's first rank)
     np.random.seed(rank_seed)
     import random
     random.seed(rank_seed)
@@ -264,6 +266,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     if override_params:
         params.update(override_params)
     params['virtual_ranks'] = V
+    if total != world * V or base != rank * V:
+        params['rank_base'], params['total_ranks'] = base, total
     if rank == 0:
         with open(os.path.join(logger.get_dir(), 'params.json'), 'w') as f:
             json.dump({k: v for k, v in params.items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
@@ -273,8 +277,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     if rank == 0:
         config.log_params(params, logger=logger)
     if V > 1:
-        logger.info('--num_cpu %d on %d process(es): %d virtual ranks per GPU (%d ranks in all)' %
-                    (num_cpu, world, V, V * world))
+        logger.info('--num_cpu %d on %d process(es): %d virtual ranks on this GPU, global ranks %d..%d of %d' %
+                    (num_cpu, world, V, base, base + V - 1, total))
     elif num_cpu != world:
         logger.warn('--num_cpu %d differs from WORLD_SIZE %d; ranks are created by torch.distributed.run (virtual ranks '
                     "need structure='curious', device RNG and per-task buffers)" % (num_cpu, world))
@@ -315,8 +319,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     evaluator = RolloutWorker(params['make_env'], policy, dims, logger, **eval_params)
     evaluator.seed(rank_seed + 100)
     if V > 1:                                                         # every virtual rank's own host streams
-        rollout_worker.seed_ranks([seed + 1000000 * (rank * V + v) for v in range(V)])
-        evaluator.seed_ranks([seed + 1000000 * (rank * V + v) + 100 for v in range(V)])
+        rollout_worker.seed_ranks([seed + 1000000 * (base + v) for v in range(V)])
+        evaluator.seed_ranks([seed + 1000000 * (base + v) + 100 for v in range(V)])
 
     best = train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
                  n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],

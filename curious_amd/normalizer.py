@@ -67,11 +67,12 @@ class Normalizer:
         return self.mean + v * self.std
 
 
-def recompute_many(normalizers, packed=None, ranks_per_process=1):
+def recompute_many(normalizers, packed=None, ranks_per_process=1, total_ranks=None):
     """recompute_stats for several normalisers with ONE all-reduce: their `acc` vectors must be slices of one
     device buffer (DDPG allocates o_stats / g_stats that way).  packed: that buffer (required when it is
     itself a view of something larger -- an expert's slab row).  ranks_per_process: virtual ranks (DDPG.virtual_ranks) --
-    the accumulators of a process already hold the sum over its virtual ranks, the mean is over world x that many."""
+    the accumulators of a process already hold the sum over its virtual ranks, the mean is over world x that many --
+    or over total_ranks when the job's ranks are laid out unevenly over the processes (dist.virtual_layout)."""
     if packed is None:
         packed = normalizers[0].acc._base if normalizers[0].acc._base is not None else normalizers[0].acc
         for nz in normalizers:
@@ -81,7 +82,7 @@ def recompute_many(normalizers, packed=None, ranks_per_process=1):
         assert lo <= nz.acc.data_ptr() and nz.acc.data_ptr() + 4 * nz.acc.numel() <= hi
     assert packed.numel() == sum(nz.acc.numel() for nz in normalizers)
     dist.allreduce_sum_(packed)
-    ws = dist.world_size() * int(ranks_per_process)
+    ws = int(total_ranks) if total_ranks else dist.world_size() * int(ranks_per_process)
     for nz in normalizers:
         ops.norm_recompute(nz.acc, nz.state, nz.size, ws, nz.eps)
 

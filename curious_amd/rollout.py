@@ -43,14 +43,19 @@ class RolloutWorker:
         # virtual ranks (DDPG virtual_ranks = V): this worker runs the rollouts of V of the reference's ranks -- V x
         # rollout_batch_size envs in one batched env, env ids, exploit decisions and task / goal draws per rank
         self.V = int(getattr(policy, 'virtual_ranks', 1) or 1) if not isinstance(policy, (list, tuple)) else 1
-        self.nb_cpu = dist.world_size() * self.V
+        # global rank of this process's first virtual rank, ranks of the job (uneven layouts: dist.virtual_layout)
+        single = isinstance(policy, (list, tuple))
+        self.rank_base = self.rank * self.V if single else int(getattr(policy, 'rank_base', self.rank * self.V))
+        self.nb_cpu = dist.world_size() * self.V if single else int(getattr(policy, 'total_ranks', dist.world_size() * self.V))
+        self._uneven = self.nb_cpu != dist.world_size() * self.V     # (the ranks' record blocks then differ in length)
+        self._slot0 = self.rank_base * rollout_batch_size            # this process's first rollout among the job's
         self._nloc = rollout_batch_size * self.V                     # envs of this process
         if self.V > 1 and not (hasattr(make_env, 'make_batched') and structure == 'curious'):
             raise ValueError("virtual ranks need the GPU-resident batched env and structure='curious'")
         self._vrng = None                                            # per-virtual-rank host streams (seed_ranks)
         if self.batched:
-            self.benv = (make_env.make_batched(self._nloc, env_id0=self.rank * self._nloc, pad_to=4) if self.V > 1
-                         else make_env.make_batched(self._nloc, env_id0=self.rank * self._nloc))
+            self.benv = (make_env.make_batched(self._nloc, env_id0=self.rank_base * rollout_batch_size, pad_to=4) if self.V > 1
+                         else make_env.make_batched(self._nloc, env_id0=self.rank_base * rollout_batch_size))
             self.envs = [self.benv]          # attribute kept; the batch is ONE object
             spec = self.benv
         else:
@@ -106,8 +111,8 @@ class RolloutWorker:
                 goal = self.goal_selectors[task].sample_goal()
             else:
                 goal = np.random.uniform(-1, 1, len(self.tasks_g_id[task]))                   # rollout.py:129
-            self.tasks[self.rank * self.rollout_batch_size + i] = task
-            self.goals[self.rank * self.rollout_batch_size + i] = \
+            self.tasks[self._slot0 + i] = task
+            self.goals[self._slot0 + i] = \
                 self.envs[i].unwrapped._compute_goal(goal, task, eval=self.eval)[0][self.tasks_g_id[task]]
             self.count += 1
             obs = self.envs[i].unwrapped.reset_task_goal(goal=goal, task=task, directly=active_goal, eval=self.eval)
@@ -138,7 +143,7 @@ class RolloutWorker:
 
     def _rng(self, v):
         if self._vrng is None:
-            self.seed_ranks([12345 + 1000000 * (self.rank * self.V + k) for k in range(self.V)])
+            self.seed_ranks([12345 + 1000000 * (self.rank_base + k) for k in range(self.V)])
         return self._vrng[v]
 
     def seed_ranks(self, seeds):
@@ -429,7 +434,7 @@ class RolloutWorker:
             env.request_flags()
             task_list = tasks.tolist()
             tk = [_NOTHING] * self.nb_goals_per_rollout
-            tk[self.rank * B:(self.rank + 1) * B] = task_list
+            tk[self._slot0:self._slot0 + B] = task_list
             self._pending = dict(tasks=tk, goals=[_NOTHING] * self.nb_goals_per_rollout, task_list=task_list)
             self.n_episodes += self.rollout_batch_size * self.nb_cpu
             views = env.episode_views()
@@ -464,7 +469,7 @@ class RolloutWorker:
                 saved = self.exploit, self._any_exploit
                 self.exploit, self._any_exploit = exploit, any_exploit
                 self.tasks = [_NOTHING] * self.nb_goals_per_rollout
-                self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
+                self.tasks[self._slot0:self._slot0 + B] = task_list
                 self.goals = [_NOTHING] * self.nb_goals_per_rollout
                 self._finish_rollout(successful, successful - 1.0,
                                      float(q_pin[0]) / self.T if self.compute_Q else None, task_list, None)
@@ -493,7 +498,7 @@ class RolloutWorker:
         mean_Q = float(q_sum) / self.T if self.compute_Q else None
         task_list = tasks.tolist()
         self.tasks = [_NOTHING] * self.nb_goals_per_rollout
-        self.tasks[self.rank * B:(self.rank + 1) * B] = task_list
+        self.tasks[self._slot0:self._slot0 + B] = task_list
         self.goals = [_NOTHING] * self.nb_goals_per_rollout
         goals_now = None
         if self.goal_selection == 'active' and not self.eval and self.exploit:
@@ -552,7 +557,7 @@ class RolloutWorker:
         rec[:, 2] = 1.0 if self.exploit else 0.0
         if self.V > 1:                                               # only the rollouts of ranks that exploited count
             rec[:, 2] = np.repeat(self._exploit_v.astype(np.float64), self.rollout_batch_size)
-        allrec = dist.allgather_numpy(rec)
+        allrec = dist.allgather_numpy(rec, uneven=self._uneven)
         valid = allrec[:, 2] != 0
         task_ids = allrec[:, 0].astype(np.int64)
         task_succ_list = [allrec[valid & (task_ids == task), 1].tolist() for task in range(self.nb_tasks)]
@@ -561,7 +566,7 @@ class RolloutWorker:
         if self.goal_selection == 'active' and not self.eval:             # rollout.py:357-365
             gdim = len(self.tasks_g_id[0])
             grec = np.zeros([B, gdim], np.float64) if goals_now is None else np.asarray(goals_now, np.float64)
-            allgoals = dist.allgather_numpy(grec)                          # same order as allrec: every rank agrees
+            allgoals = dist.allgather_numpy(grec, uneven=self._uneven)     # same order as allrec: every rank agrees
             for task in range(self.nb_tasks):
                 sel = valid & (task_ids == task)
                 new_split, _ = self.goal_selectors[task].update([g.astype(np.float32) for g in allgoals[sel]],

@@ -313,7 +313,8 @@ class StoringMixin:
                              self.g_stats.state if single else None, self.o_stats.eps, self.g_stats.eps,
                              self._stats_scratch, skip=skip)
         if not single:
-            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc, ranks_per_process=self.V)
+            recompute_many([self.o_stats, self.g_stats], packed=self._stats_acc, ranks_per_process=self.V,
+                           total_ranks=self.total_ranks)
 
     def _stats_rng(self, n_episodes, n):
         """Sampler description of the normaliser batch: n transitions from the n_episodes fresh episodes; with virtual

@@ -79,6 +79,16 @@ def main():
 
     if mode == 'fault':
         return fault_main(out, rank, rng, cp)
+    if mode == 'uneven':
+        # 3 of the reference's ranks on these 2 processes (dist.virtual_layout): the sequence of test_gpu_round5.run_virtual
+        import test_gpu_round5 as R5
+        V, base, total = dist.virtual_layout(3)
+        assert (V, base, total) == ((2, 0, 3) if rank == 0 else (1, 2, 3))
+        agent5, rec5 = R5.run_virtual(V, graph, rank_base=base, total_ranks=total)
+        agent5._check_synced(wait=True)                              # mpi_adam.py:42-50
+        np.savez('%s.rank%d.npz' % (out, rank), **{k: v for k, v in rec5.items() if isinstance(v, np.ndarray)})
+        from curious_amd.experiment.train import shutdown
+        return shutdown([agent5])
     if mode == 'single':
         agent, _, _ = make_agent(graph)
         agents, bank = [agent], None

@@ -16,7 +16,7 @@ STAGE_KEYS = ['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r']
 NB, DIMO, SEED, B, CAP = 4, 40, 3, 256, 64
 
 
-def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2):
+def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2, **layout):
     from curious_amd.ddpg import DDPG
     from curious_amd.envs import sparse_reward_fun
     from curious_amd.her import make_sample_multi_task_her_transitions
@@ -38,11 +38,12 @@ def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2):
                 relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
                 sample_transitions=sampler, gamma=gamma, buffers=buffers, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
                 task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious', rng_mode='device', seed=seed,
-                use_graph=use_graph, **({} if V is None else dict(virtual_ranks=V)))
+                use_graph=use_graph, **({} if V is None else dict(virtual_ranks=V)), **layout)
 
 
 def rank_episodes(V, n_per, first_seed=50):
-    """Rank-private episodes (train.py:242-243), rank v's at rows v * n_per ..; the streams of tests/rank_parity_worker.py"""
+    """Rank-private episodes (train.py:242-243), rank v's at rows v * n_per ..; the streams of tests/rank_parity_worker.py
+    (first_seed + v: a process whose first virtual rank is global rank g passes first_seed + g)"""
     from test_gpu_agent import synth_episodes
     rngs = [np.random.RandomState(first_seed + v) for v in range(V)]
 
@@ -52,12 +53,15 @@ def rank_episodes(V, n_per, first_seed=50):
     return draw
 
 
-def run_virtual(V, graph, n_per=24, first_seed=50):
+def run_virtual(V, graph, n_per=24, first_seed=50, rank_base=None, total_ranks=None):
     """The sequence of tests/rank_parity_worker.py (store, 6 updates, store, 2 updates, target update) on ONE process with V
-    virtual ranks; everything the device drew and every state in between is recorded per virtual rank."""
+    virtual ranks; everything the device drew and every state in between is recorded per virtual rank.  rank_base /
+    total_ranks: this process is one of several of an uneven layout (dist.virtual_layout): its first virtual rank is global
+    rank rank_base of total_ranks."""
     from curious_amd import ops
-    agent = make_agent(V, use_graph=bool(graph))
-    draw = rank_episodes(V, n_per, first_seed)
+    layout = {} if rank_base is None else dict(rank_base=rank_base, total_ranks=total_ranks)
+    agent = make_agent(V, use_graph=bool(graph), **layout)
+    draw = rank_episodes(V, n_per, first_seed + (rank_base or 0))
     cp = np.array([0.3, 0.0, 0.2, 0.1])
     rec = {}
     cols = agent._layout.batch_cols
@@ -212,6 +216,42 @@ def test_two_virtual_ranks_draw_what_two_real_ranks_draw():
             np.testing.assert_array_equal(rec['batch_%d_r' % k][r * B:(r + 1) * B], real[r]['batch_%d_0_r' % k])
     assert np.abs(rec['theta'] - real[0]['theta_0']).max() < 2e-4
     assert (np.abs(rec['theta'] - real[0]['theta_0']) > 2e-5).mean() < 1e-2
+
+
+def test_uneven_layout_of_virtual_ranks_over_two_processes():
+    """--num_cpu R on W processes with R % W != 0 (the reference's 19 ranks on 8 GPUs: 3 3 3 2 2 2 2 2,
+    dist.virtual_layout): process 0 stands for global ranks 0 and 1, process 1 for rank 2 -- two processes of the product on
+    this GPU, gloo carrying the gradient all-reduce and the normaliser all-reduce (tests/rank_parity_worker.py, mode
+    'uneven') -- against ONE process with 3 virtual ranks: every rank draws the same batches and normaliser rows bit for
+    bit, the normaliser state is 1 + mean over the THREE ranks' counts on both processes, and both end on the parameters of
+    the one-process run up to the order in which the three ranks' gradients are summed."""
+    from curious_amd import dist
+    from test_gpu_round4 import _launch2, _two_rank_env
+    assert [dist.virtual_layout(19, 8, r) for r in (0, 2, 3, 7)] == [(3, 0, 19), (3, 6, 19), (2, 9, 19), (2, 17, 19)]
+    assert dist.virtual_layout(3, 2, 1) == (1, 2, 3) and dist.virtual_layout(2, 8, 5) == (1, 5, 8)
+    prefix = os.path.join(tempfile.mkdtemp(), 'u2')
+    out = _launch2([os.path.join(ROOT, 'tests', 'rank_parity_worker.py'), prefix, 'uneven', '0'], _two_rank_env())
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    parts = [np.load('%s.rank%d.npz' % (prefix, r)) for r in range(2)]
+    _, rec = run_virtual(3, 0)
+    rows = 24 * 50
+    blocks = [(0, 0, 2), (1, 2, 1)]                                  # (process, first global rank, ranks)
+    for tag in ('a', 'b'):
+        for p, g0, nv in blocks:
+            np.testing.assert_array_equal(rec['stats_o_' + tag][g0 * rows:(g0 + nv) * rows], parts[p]['stats_o_' + tag])
+            np.testing.assert_allclose(rec['o_state_' + tag], parts[p]['o_state_' + tag], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(rec['g_state_' + tag], parts[p]['g_state_' + tag], rtol=1e-5, atol=1e-5)
+        d = DIMO
+        assert float(rec['o_state_' + tag][2 * d]) == float(parts[1]['o_state_' + tag][2 * d])   # the count: / 3 ranks
+    for k in range(8):
+        for p, g0, nv in blocks:
+            for key in ('o', 'r', 'g'):
+                np.testing.assert_array_equal(rec['batch_%d_%s' % (k, key)][g0 * B:(g0 + nv) * B],
+                                              parts[p]['batch_%d_%s' % (k, key)])
+            np.testing.assert_allclose(rec['loss_%d' % k][g0:g0 + nv], parts[p]['loss_%d' % k], rtol=2e-4)
+    np.testing.assert_array_equal(parts[0]['theta'], parts[1]['theta'])      # the replicas agree
+    assert np.abs(rec['theta'] - parts[0]['theta']).max() < 2e-4
+    assert (np.abs(rec['theta'] - parts[0]['theta']) > 2e-5).mean() < 1e-2
 
 
 def test_one_virtual_rank_is_the_agent_as_it_was():
