@@ -184,7 +184,7 @@ def cycle(policy, worker):
     policy.update_target_net()
 
 
-def kernel_flops_bytes(policy, lay, B_R=B_R):
+def kernel_flops_bytes(policy, lay, B_R=B_R, n_experts=1):
     """ALGORITHMIC work of one launch of each kernel class in one update / one rollout step."""
     c = policy
     B, H, nl, U = c._Bt, c.hidden, c.layers, c.dimu               # (virtual ranks: V minibatches of 256 per launch)
@@ -204,13 +204,16 @@ def kernel_flops_bytes(policy, lay, B_R=B_R):
     w_actor = l0pi + hidw + H * U + l0q + hidw + H + hidw + U * H + H * U + hidw
     w_target = l0pi + hidw + H * U + l0q + hidw + H
     w_critic = l0q + hidw + 2 * H + hidw
-    rows_l2_bytes = 4 * (w_actor + w_target + w_critic) * (B // 4)
+    # (4 batch rows per workgroup; 8 from 768 rows on -- csrc/mlp_rows.h ROWS_R2: half the stream per row)
+    rows_per_wg = 8 if (B * n_experts >= 768 and B % 32 == 0 and os.environ.get('CURIOUS_ROWS8', '1') != '0') else 4
+    rows_l2_bytes = 4 * (w_actor + w_target + w_critic) * (B // rows_per_wg)
     return dict(
         # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
         ddpg_rows_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
-                              l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor),
+                              l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor, rows_per_workgroup=rows_per_wg),
         ddpg_rows_her_kernel=dict(bound='mfma', per_update=2 * B * (rows_fwd + rows_bwd), launches_update=1,
-                                  l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor),
+                                  l2_stream_bytes=rows_l2_bytes, critical_cu_bytes=4 * w_actor,
+                                  rows_per_workgroup=rows_per_wg),
         policy_rows_kernel=dict(bound='mfma', per_update=0, launches_update=0, per_env_step=2 * B_R * net(Sa, U),
                                 launches_env_step=1),
         # the weights-resident rollout: layer 0 is computed by all 4 members of a group (x 4), the rest once
@@ -313,7 +316,7 @@ def pmc_traffic(kernel, virtual_ranks=1):
 def roofline(policy, worker, stats, n_cycles, overhead_ms, n_experts=1):
     """n_experts: batched task experts -- the update kernels carry the expert on grid.z / grid.y, one launch does the work of
     all of them (the acting kernels run one expert's rollout per cycle)."""
-    work = kernel_flops_bytes(policy, policy._layout, worker.rollout_batch_size)
+    work = kernel_flops_bytes(policy, policy._layout, worker.rollout_batch_size, n_experts)
     if n_experts > 1:
         for w_ in work.values():
             for key in ('per_update', 'l2_stream_bytes', 'hbm_bytes_per_update'):
@@ -352,13 +355,15 @@ def roofline(policy, worker, stats, n_cycles, overhead_ms, n_experts=1):
         # aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s over 256 CUs; the launch occupies 192 of them)
         tb = w['l2_stream_bytes'] / avg_s / 1e12
         out['l2_stream'] = dict(achieved=round(tb, 3), peak=L2_PEAK_TBS, unit='TB/s', frac=round(tb / L2_PEAK_TBS, 4),
-                                bytes_per_launch=int(w['l2_stream_bytes']))
+                                bytes_per_launch=int(w['l2_stream_bytes']), rows_per_workgroup=w.get('rows_per_workgroup', 4))
         # ... and the CU on the critical path: an actor-side workgroup pulls 12 network passes of weights through ITS fill
         # path (MI355X_MICROARCH.md: 64 B/clk = 135 GB/s per CU), one layer after the other, for the whole launch
-        gb = w['critical_cu_bytes'] / avg_s / 1e9
-        out['l2_stream']['critical_cu'] = dict(achieved=round(gb, 1), peak=L2_PER_CU_GBS, unit='GB/s',
-                                               frac=round(gb / L2_PER_CU_GBS, 4),
-                                               bytes_per_launch=int(w['critical_cu_bytes']))
+        # (one chain per CU: a single rank's batch; with several ranks a CU runs many chains one after / beside the other)
+        if getattr(policy, 'V', 1) == 1:
+            gb = w['critical_cu_bytes'] / avg_s / 1e9
+            out['l2_stream']['critical_cu'] = dict(achieved=round(gb, 1), peak=L2_PER_CU_GBS, unit='GB/s',
+                                                   frac=round(gb / L2_PER_CU_GBS, 4),
+                                                   bytes_per_launch=int(w['critical_cu_bytes']))
     return out, table
 
 

@@ -145,7 +145,9 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.l2c = cfg->action_l2 * 2.0f / (cfg->max_u * cfg->max_u * (float)(Bl * U));
   // 8 rows per workgroup once every CU holds several row groups (mlp_rows.h ROWS_R2): the rows of a batch are independent,
   // so the split changes no row's arithmetic
-  ra_R = (curious_options().rows8 && B >= ROWS_R2_MIN && B % (4 * ROWS_R2) == 0) ? ROWS_R2 : ROWS_R;
+  // (batched experts: the rows of all experts count -- what matters is whether the row groups of 4 outnumber the chip's
+  //  workgroup slots; 4 experts x 256 rows: 51.1 -> 49.5 us per launch, 8.12 -> 7.82 ms per cycle)
+  ra_R = (curious_options().rows8 && (int64_t)B * xd.nex >= ROWS_R2_MIN && B % (4 * ROWS_R2) == 0) ? ROWS_R2 : ROWS_R;
   const size_t lds = rows_lds_floats(ra_R, nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
