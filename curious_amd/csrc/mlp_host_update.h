@@ -103,18 +103,20 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       return n_her + tAll * S_hot + (nsmall + 1) * S_small;
     };
     if (curious_options().lab_dw_stamps) dwAll.stamps = reinterpret_cast<unsigned long long*>(w.part[0]);
+    // The split reduction (mlp_dw.h DwSplit): by default only the SMALL tiles are split (layer-0 segments and output layers:
+    // as many chunks as a hidden tile, and they are what the launch ends with); option "dw_split" = 10 S_hot + S_small
+    // overrides (A/B)
+    int S_hot = 1, S_small = 1;
+    if (w.split && xd.nex == 1 && B % 256 == 0 && tAll + nsmall <= DW_SPLIT_TILES) {
+      const int C = B / 256, opt = curious_options().dw_split;
+      S_small = std::min(4, C / 2);
+      if (opt > 0) { S_hot = opt / 10; S_small = opt % 10; }
+      S_hot = std::max(1, std::min(S_hot, std::min(DW_SPLIT_MAX, C)));
+      S_small = std::max(1, std::min(S_small, std::min(DW_SPLIT_MAX, C)));
+    }
+    dwAll.split.pbuf = w.split; dwAll.split.cnt = w.split_cnt;
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
-      // By default only the SMALL tiles are split (mlp_dw.h DwSplit; layer-0 segments and output layers: as many chunks as
-      // a hidden tile, and they are what the launch ends with); option "dw_split" = 10 S_hot + S_small overrides (A/B)
-      int S_hot = 1, S_small = 1;
-      if (w.split && xd.nex == 1 && B % 256 == 0 && tAll + nsmall <= DW_SPLIT_TILES) {
-        const int C = B / 256, opt = curious_options().dw_split;
-        S_small = std::min(4, C / 2);
-        if (opt > 0) { S_hot = opt / 10; S_small = opt % 10; }
-        S_hot = std::max(1, std::min(S_hot, std::min(DW_SPLIT_MAX, C)));
-        S_small = std::max(1, std::min(S_small, std::min(DW_SPLIT_MAX, C)));
-      }
       const int gx = dw_grid(n_her, S_hot, S_small);
       const int units_s = map.units | (S_hot << 8) | (S_small << 16);
       if (dwAll.stamps && (int64_t)gx * 8 * 2 > 6 * 16 * (int64_t)B) dwAll.stamps = nullptr;   // (room: part[0..5])
@@ -124,8 +126,6 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
         const int32_t* fault0 = af.fault ? af.fault : reinterpret_cast<const int32_t*>(af.theta);
         const int64_t* ctr0 = af.alpha_tab ? af.step_ctr : reinterpret_cast<const int64_t*>(af.theta);
         // batches of several chunks of 256 rows (virtual ranks): the pipelined form of the tiles (mlp_dw.h PIPE)
-        // the split reduction (mlp_dw.h DwSplit): S workgroups per tile, 2 chunks of 256 rows or more each
-        dwAll.split.pbuf = w.split; dwAll.split.cnt = w.split_cnt;
 #define DW_LAUNCH(PIPE)                                                                                        \
   hipLaunchKernelGGL((dw_adam_her_kernel<PIPE>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,          \
                      hwAll.nprob, smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, units_s, fault0, ctr0, \
@@ -141,14 +141,15 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     CURIOUS_CHECK(xd.nex == 1 || !tail, "batched experts need the fused update tail");
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
-      const int gx = dw_grid(0);
+      const int gx = dw_grid(0, S_hot, S_small);
+      const int units_s = map.units | (S_hot << 8) | (S_small << 16);
       if (B <= 256)
         hipLaunchKernelGGL(dw_all_kernel<false>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
-                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
+                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, units_s, (int64_t)xd.stride, dwAll,
                            (int64_t)xd.gstride);
       else
         hipLaunchKernelGGL(dw_all_kernel<true>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
-                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, map.units, (int64_t)xd.stride, dwAll,
+                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, units_s, (int64_t)xd.stride, dwAll,
                            (int64_t)xd.gstride); }
     CURIOUS_LAUNCH_CHECK("dw_all_kernel");
   } else {
