@@ -74,10 +74,10 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((rows_transpose_kernel<false>), dim3(16, n, 1), dim3(256), 0, 0, t, ex);
     CK(hipDeviceSynchronize());
   }
-  const size_t lds = rows_lds_floats(nl) * sizeof(float);
+  const size_t lds = rows_lds_floats(ROWS_R, nl) * sizeof(float);
   // (the kernel also has ~1 KB of static LDS: dynamic + static must stay <= 160 KB)
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_kernel<false>),
-                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows_lds_floats(ROWS_MAXL) * sizeof(float))));
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows_lds_floats(ROWS_R, ROWS_MAXL) * sizeof(float))));
   dim3 grid(4 * (B / ROWS_R), 1, 1);
   printf("B = %d\n", B);
   // the kernel's leading arguments (mlp_rows.h RowsPre), as DdpgPass::launch_rows fills them; argv[2] = 0: flag clear
