@@ -294,6 +294,42 @@ def test_eight_rows_per_workgroup_change_no_bit(V, graph):
     assert np.isfinite(outs[0][3]).all()
 
 
+@pytest.mark.parametrize('V', [3, 5])
+def test_handoff_fault_with_several_ranks_per_launch(V):
+    """The guard of the Q' hand-off on the forms batches of several ranks take (8 rows per workgroup: a main-critic wave
+    waits for TWO words; V = 5: the small weight-gradient tiles are split, the last workgroup of a tile runs -- or skips --
+    the optimiser): a target group that never publishes (fault_inject counts groups of 4 rows) turns the 4 rows' losses
+    NaN, raises the fault word by 4 and leaves theta / m / v alone until the word is cleared; the next update is clean."""
+    from curious_amd import ops
+    from curious_amd.ddpg import HandoffFault
+    agent = make_agent(V, use_graph=False)
+    draw = rank_episodes(V, 12)
+    agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+    agent.train_batches(3)
+    agent.check_faults(wait=True)
+    torch.cuda.synchronize()
+    before = [x.clone() for x in (agent.theta, agent._m, agent._v)]
+    fault = ops.fault_word(agent.net_cfg, agent._Bt, agent._workspace)
+    grp = 64 + 7                                                      # a row group of 4 of the SECOND rank (rows 284..287)
+    with ops.option('fault_inject', grp + 1), ops.option('qt_spins', 20000):
+        agent.train_batches(1)
+        torch.cuda.synchronize()
+    assert int(fault) == 4
+    losses = agent._losses.cpu().numpy().reshape(V, 2)
+    assert not np.isfinite(losses[1, 0]) and np.isfinite(losses[0]).all() and np.isfinite(losses[2:]).all()
+    agent.train_batches(1)                                            # sticky: skipped as well
+    torch.cuda.synchronize()
+    for a, b in zip(before, (agent.theta, agent._m, agent._v)):
+        assert torch.equal(a, b)
+    with pytest.raises(HandoffFault):
+        agent.check_faults(wait=True)
+    assert int(fault) == 0
+    agent.train_batches(2)
+    torch.cuda.synchronize()
+    agent.check_faults(wait=True)
+    assert np.isfinite(agent._losses.cpu().numpy()).all() and not torch.equal(before[0], agent.theta)
+
+
 @pytest.mark.parametrize('graph', [False, True])
 def test_split_reduction_of_the_weight_gradient_tiles(graph):
     """Option dw_split = 10 S_hot + S_small (csrc/mlp_dw.h DwSplit; batches of >= 1 024 rows): S workgroups per
