@@ -840,6 +840,10 @@ def main():
             out['phases'] = phases
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        elif world > 1 or args.gpus > 1:
+            # (rank 0 at N = 1 only, as the contract says: timing the oracle here would hold N - 1 GPUs idle)
+            out['cpu_baseline'] = None
+            out['cpu_baseline_note'] = 'measured on rank 0 of the N = 1 run only (python bench.py)'
         print(json.dumps(out), flush=True)
     teardown(list(bank) if experts else [policy], bank if experts else None)
 
