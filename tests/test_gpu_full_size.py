@@ -285,3 +285,90 @@ def test_full_size_batched_experts_cycles_are_deterministic():
     assert all(torch.equal(x, y) for x, y in zip(a[:8], b[:8])) and a[8:] == b[8:]
     assert all(torch.isfinite(x).all() for x in a[:8])
     assert not torch.equal(a[0], a[1]) and not torch.equal(a[2], a[3])
+
+
+def test_nineteen_virtual_ranks_at_full_buffer_sizes():
+    """The reference's published regime (--num_cpu 19, readme.md:16) at ITS full sizes on one GPU: 19 x 5 private buffers of
+    20 000 episodes (33 GB in one pool: element offsets beyond 2^32), all full.  The joint gather of 19 x 256 transitions:
+    rank v's block holds exact copies of rows of rank v's OWN buffers (its signature names buffer, episode, step AND rank)
+    and of the next row of the same episode, addresses the whole capacity of every rank, meets the replay proportions
+    per rank, relabels with a later achieved goal of the same episode of the same rank."""
+    V = 19
+    params, dims, policy, worker = bench.build_job(use_graph=True, b_r=2, virtual_ranks=V)
+    cap = policy.buffer[1].size
+    assert cap == 20000 and len(policy._rank_buffers) == V and policy._Bt == V * 256
+    lay, dev = policy._layout, policy.device
+    T, O, AG = lay.T, lay.dims['o'], lay.dims['ag']
+    assert policy._pool.storage.numel() > 2 ** 32
+    e = torch.arange(cap, device=dev, dtype=torch.float32)[:, None, None]
+    t = torch.arange(T + 1, device=dev, dtype=torch.float32)[None, :, None]
+    k = torch.arange(O, device=dev, dtype=torch.float32)[None, None, :]
+    ka = torch.arange(AG, device=dev, dtype=torch.float32)[None, None, :]
+    for v, bufs in enumerate(policy._rank_buffers):
+        for i in range(1, 5):
+            buf = bufs[i]
+            assert buf.pool_index == v * 5 + i
+            rec = buf.records
+            rec.zero_()
+            w = lay.record_views(rec)
+            o = 0.001 * torch.remainder(e * 31 + t * 17 + k * 7 + v * 101, 997.)
+            o[:, :, 0] = torch.floor(e[:, :, 0] / 128)
+            o[:, :, 1] = torch.remainder(e[:, :, 0], 128.)
+            o[:, :, 2] = t[:, :, 0]
+            o[:, :, 3] = float(i)
+            o[:, :, 4] = float(v)
+            w['o'].copy_(o)
+            ag = 0.002 * torch.remainder(e * 13 + t * 29 + ka * 3 + v * 37, 499.)
+            w['ag'].copy_(ag)
+            w['g'].copy_(5.0 + 0.5 * ag[:, :T])
+            td = torch.zeros([cap, T, policy.nb_tasks], device=dev)
+            td[:, :, i - 1] = 1.0
+            w['task_descr'].copy_(td)
+            ch = torch.zeros([cap, T, AG], device=dev)
+            ch[:, :, 3 * (i - 1):3 * i] = 1.0
+            w['change'].copy_(ch)
+            buf.current_size = cap
+            buf.n_transitions_stored = cap * T
+            del o, ag, td, ch
+    policy._pool.version += 1
+    policy._tables_dirty = True
+    policy.cp = np.array([0.3, 0.0, 0.2, 0.1])
+    n_draws, B = 8, 256
+    rows = []
+    for _ in range(n_draws):
+        rows.append(policy._sample_packed().clone())
+        policy._step_ctr += 1
+    batch = torch.cat(rows)                                          # [n_draws x V x 256, 152]
+    w = lay.batch_views(batch)
+    o = w['o']
+    e_, t_, b_, r_ = (o[:, 0] * 128 + o[:, 1]).long(), o[:, 2].long(), o[:, 3].long(), o[:, 4].long()
+    want_rank = torch.arange(V, device=dev).repeat_interleave(B).repeat(n_draws)
+    assert torch.equal(r_, want_rank)                                # every row of rank v's block comes from rank v's buffers
+    assert int(e_.max()) > 0.97 * cap and int(e_.min()) < 0.03 * cap and int(t_.max()) == T - 1
+    for v in (0, 7, 18):
+        sel = r_ == v
+        assert int(e_[sel].max()) > 0.9 * cap                        # ... over the whole capacity, rank by rank
+        per_draw = torch.stack([(b_[sel].view(n_draws, B) == i).sum(1) for i in range(5)], 1).cpu().numpy()
+        assert (per_draw == policy.proportions[None, :5]).all()
+    st = policy._pool.storage                                        # [V x 5, cap, T + 1, row]
+    pb = r_ * 5 + b_
+    src, nxt = st[pb, e_, t_], st[pb, e_, t_ + 1]
+    for key, rows_ in (('o', src), ('u', src), ('ag', src), ('o_2', nxt), ('ag_2', nxt)):
+        off, dim = lay.off[key.replace('_2', '')], lay.dims[key.replace('_2', '')]
+        assert torch.equal(w[key], rows_[:, off:off + dim]), key
+    task = b_ - 1
+    g, g_stored = w['g'], src[:, lay.off['g']:lay.off['g'] + lay.dims['g']]
+    her = ~(g == g_stored).all(1)
+    assert 0.77 < float(her.float().mean()) < 0.83
+    slots = (3 * task)[:, None] + torch.arange(3, device=dev)[None, :]
+    on_slots = torch.gather(g, 1, slots)
+    fut = st[pb, e_][:, :, lay.off['ag']:lay.off['ag'] + lay.dims['ag']]
+    fut = torch.gather(fut, 2, slots[:, None, :].expand(-1, T + 1, -1))
+    later = torch.arange(T + 1, device=dev)[None, :] > t_[:, None]
+    assert bool(((fut == on_slots[:, None, :]).all(2) & later).any(1)[her].all())
+    # ... and a whole cycle (38 rollouts, routed store into the ranks' full buffers, 100 updates of 4 864 rows) runs clean
+    for _ in range(2):
+        bench.cycle(policy, worker)
+    torch.cuda.synchronize()
+    policy.check_faults(wait=True)
+    assert np.isfinite(policy._losses.cpu().numpy()).all()
