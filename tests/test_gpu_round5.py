@@ -254,6 +254,34 @@ def test_uneven_layout_of_virtual_ranks_over_two_processes():
     assert (np.abs(rec['theta'] - parts[0]['theta']) > 2e-5).mean() < 1e-2
 
 
+def test_training_job_with_an_uneven_layout_over_two_processes(tmp_path):
+    """`experiment.train --num_cpu 5` under torch.distributed.run with 2 processes (both on this GPU, gloo): process 0 runs
+    global ranks 0..2, process 1 ranks 3..4 -- the whole loop: per-rank draws, competence records of unequal length, the
+    episode count of all FIVE ranks in the log."""
+    import csv
+    import glob
+    import subprocess
+    import sys
+    from test_gpu_round4 import _free_port, _two_rank_env
+    env = _two_rank_env()
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), '-m', 'curious_amd.experiment.train', '--env',
+           'MultiTaskFetchArm4-v5', '--num_cpu', '5', '--rollout_batch_size', '4', '--n_batches', '10', '--n_epochs', '3',
+           '--n_cycles', '6', '--seed', '1']
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)   # (saves under ./save)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    text = out.stdout + out.stderr
+    assert '3 virtual ranks on this GPU, global ranks 0..2 of 5' in text
+    assert '2 virtual ranks on this GPU, global ranks 3..4 of 5' in text
+    files = glob.glob(os.path.join(str(tmp_path), '**', 'progress.csv'), recursive=True)
+    assert len(files) == 1                                           # rank 0 logs
+    rows = list(csv.DictReader(open(files[0])))
+    assert len(rows) == 4                                            # epoch -1 (the initial evaluation) + 3
+    assert float(rows[-1]['train/episode']) == 5 * 4 * 6 * 3          # ranks x rollouts x cycles x epochs
+    assert all(np.isfinite(float(r['test/mean_Q'])) for r in rows)
+
+
 def test_one_virtual_rank_is_the_agent_as_it_was():
     """virtual_ranks = 1 changes nothing: same launches, same bits."""
     from test_gpu_agent import synth_episodes
