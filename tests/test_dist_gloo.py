@@ -343,3 +343,21 @@ def test_captured_allreduce_is_off_without_rccl(monkeypatch):
     monkeypatch.delenv('CURIOUS_GRAPH_ALLREDUCE')
     monkeypatch.setattr(dist, '_CAPTURED_OK', None)
     assert dist.captured_allreduce_ok() is False                   # no process group in this process
+
+
+def test_virtual_layout_covers_exactly_the_ranks_asked_for():
+    """dist.virtual_layout (--num_cpu R on W processes): the processes' rank counts add up to R, their blocks of global
+    ranks are contiguous and in process order, no process stands for more than one rank above another; R <= W: one rank
+    per process (the reference's own layout)."""
+    from curious_amd import dist
+    for R in (2, 3, 5, 8, 19, 24, 64):
+        for W in (1, 2, 3, 4, 8):
+            lay = [dist.virtual_layout(R, W, r) for r in range(W)]
+            if R <= W:
+                assert lay == [(1, r, W) for r in range(W)]
+                continue
+            assert sum(v for v, _, _ in lay) == R and all(t == R for _, _, t in lay)
+            assert [b for _, b, _ in lay] == [sum(v for v, _, _ in lay[:r]) for r in range(W)]
+            assert max(v for v, _, _ in lay) - min(v for v, _, _ in lay) <= 1
+            assert [v for v, _, _ in lay] == sorted((v for v, _, _ in lay), reverse=True)
+    assert [dist.virtual_layout(19, 8, r)[0] for r in range(8)] == [3, 3, 3, 2, 2, 2, 2, 2]
