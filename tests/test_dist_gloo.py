@@ -56,9 +56,11 @@ def _collectives(rank, world):
     dist.broadcast_(theta, 0)                                         # C3
     rec = np.array([[rank, 1.0, 1.0], [rank, 0.0, 1.0]])
     allrec = dist.allgather_numpy(rec)                                # C9
+    # (blocks of unequal length: processes that stand for different numbers of virtual ranks, dist.virtual_layout)
+    urec = dist.allgather_numpy(np.full([3 - rank, 2], float(rank)), uneven=True)
     avg = mpi_average([float(rank), float(rank) + 2.0])              # C11
     obj = dist.broadcast_object({'i_policy': 7 + rank}, 0)            # C12
-    return dict(g=g.numpy().copy(), theta=theta.numpy().copy(), allrec=allrec, avg=avg, obj=obj)
+    return dict(g=g.numpy().copy(), theta=theta.numpy().copy(), allrec=allrec, avg=avg, obj=obj, urec=urec)
 
 
 def test_collectives_world2():
@@ -67,6 +69,7 @@ def test_collectives_world2():
         np.testing.assert_array_equal(out[r]['g'], np.full(1000, 3.0, np.float32))
         np.testing.assert_array_equal(out[r]['theta'], np.arange(10, dtype=np.float32))
         np.testing.assert_array_equal(out[r]['allrec'], np.array([[0, 1, 1], [0, 0, 1], [1, 1, 1], [1, 0, 1]], float))
+        np.testing.assert_array_equal(out[r]['urec'], np.array([[0, 0]] * 3 + [[1, 1]] * 2, float))
         assert out[r]['avg'] == (0 + 2 + 1 + 3) / 4.0
         assert out[r]['obj'] == {'i_policy': 7}
 
