@@ -16,7 +16,7 @@ STAGE_KEYS = ['ag', 'g', 'o', 'task_descr', 'u', 'o_2', 'g_2', 'r']
 NB, DIMO, SEED, B, CAP = 4, 40, 3, 256, 64
 
 
-def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2, **layout):
+def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2, normalize_obs=False, **layout):
     from curious_amd.ddpg import DDPG
     from curious_amd.envs import sparse_reward_fun
     from curious_amd.her import make_sample_multi_task_her_transitions
@@ -35,7 +35,7 @@ def make_agent(V, use_graph=False, cap=CAP, seed=SEED, rollout_batch_size=2, **l
     return DDPG(input_dims=dims, hidden=256, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
                 polyak=0.95, batch_size=B, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1., action_l2=1.,
                 clip_obs=200., scope='ddpg', T=T, rollout_batch_size=rollout_batch_size, subtract_goals=None,
-                relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=normalize_obs,
                 sample_transitions=sampler, gamma=gamma, buffers=buffers, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
                 task_replay='replay_task_cp_buffer', eps_task=0.4, structure='curious', rng_mode='device', seed=seed,
                 use_graph=use_graph, **({} if V is None else dict(virtual_ranks=V)), **layout)
@@ -320,6 +320,39 @@ def test_eight_rows_per_workgroup_change_no_bit(V, graph):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(outs[0][3]).all()
+
+
+@pytest.mark.parametrize('V', [2, 3])
+def test_input_normalisation_with_virtual_ranks_on_both_routes(V):
+    """--normalize_obs with virtual ranks: the statistics are the job's (sums over all ranks / R, normalizer.py:84-94), every
+    rank's rows are normalised with them inside the launches.  The row-local kernels (4 rows per workgroup at V = 2, 8 at
+    V = 3: normalised input rows kept for the layer-0 weight gradients) against the tiled / generic kernels, which normalise
+    in their layer-0 segments -- two implementations, same batches: per-rank losses within 1e-5, gradients within 1e-5 of
+    the max-norm, and the statistics did matter."""
+    from curious_amd import ops
+    res = {}
+    for rows in (1, 0):
+        with ops.option('rows', rows):
+            agent = make_agent(V, use_graph=False, normalize_obs=True)
+            draw = rank_episodes(V, 12)
+            agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+            agent.train_batches(1)
+            torch.cuda.synchronize()
+            agent.check_faults(wait=True)
+            res[rows] = [t.cpu().numpy().copy() for t in (agent._losses, agent.grad, agent.o_stats.state, agent._pp[0])]
+    np.testing.assert_array_equal(res[1][3], res[0][3])              # the same batch
+    np.testing.assert_array_equal(res[1][2], res[0][2])              # the same statistics
+    d = DIMO
+    assert np.abs(res[1][2][2 * d + 1:3 * d + 1]).max() > 0.05       # mean far from 0 / std far from 1: they matter
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5)
+    gmax = np.abs(res[0][1]).max()
+    assert np.abs(res[1][1] - res[0][1]).max() <= 1e-5 * gmax
+    # ... and against the same agent without normalisation the losses differ
+    plain = make_agent(V, use_graph=False, normalize_obs=False)
+    plain.store_episode(rank_episodes(V, 12)(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+    plain.train_batches(1)
+    torch.cuda.synchronize()
+    assert np.abs(plain._losses.cpu().numpy() - res[1][0]).max() > 1e-4
 
 
 @pytest.mark.parametrize('V', [3, 5])
