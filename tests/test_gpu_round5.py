@@ -519,11 +519,13 @@ def test_routed_store_of_several_ranks_equals_one_store_per_rank():
     assert int(tab[1]) == cap and overflowed                         # full buffers, and a contested random slot
 
 
+@pytest.mark.parametrize('relative', [False, True])
 @pytest.mark.parametrize('resident', [0, 1])
-def test_rollout_of_several_ranks_equals_one_rollout_per_rank(resident):
+def test_rollout_of_several_ranks_equals_one_rollout_per_rank(resident, relative):
     """curious_policy_rollout_ranks: the envs of group k act exactly as a launch of their own with the key seed + k *
     seed_stride would make them (same noise, same episodes), and a group whose exploit flag is set acts as a launch with
-    noise_eps = random_eps = 0 (rollout.py:183-189) -- streaming kernel and weights-resident kernel."""
+    noise_eps = random_eps = 0 (rollout.py:183-189) -- streaming kernel and weights-resident kernel, with and without
+    relative goals (ddpg.py:118-127: the policy sees g - ag)."""
     from curious_amd import ops
     from curious_amd.ddpg import RANK_SEED_STRIDE
     from curious_amd.envs import BatchedSyntheticArm, REWARD_EPS
@@ -541,7 +543,7 @@ def test_rollout_of_several_ranks_equals_one_rollout_per_rank(resident):
         u = torch.empty([n_env, 4], device=agent.device)
         ops.policy_rollout(cfg, theta, n_env, 200.0, ws, noise, reps, sd, ctr, u, env._cfg, env.layout, env.env_id0,
                            env.episode, env.tasks, 0, T, env.o, env.ag, env.g, env.td, env.staging, REWARD_EPS,
-                           flags=env.flags, groups=groups)
+                           flags=env.flags, groups=groups, relative_goals=relative)
         torch.cuda.synchronize()
         return env.staging.cpu().numpy().copy()
 
