@@ -1,42 +1,106 @@
 """Training-resumable checkpoints.
 
 The reference can only pickle a policy for acting: Adam moments (mpi_adam.py:14-16), replay buffers and competence
-queues are not saved (docstring at ddpg.py:512), so a run cannot be resumed.  `save_training_state` writes everything a
-bit-exact continuation needs -- parameters, target parameters, Adam m / v / t, the device step counter, normaliser
-state and accumulators, every replay buffer's stored episodes and counters, competence queues / task probabilities
-of the rollout workers, and the NumPy global RNG state -- next to the reference-format `*_weights.pkl`
-(DDPG.save_weights, ddpg.py:481-497), which stays loadable by the reference.
+queues are not saved (docstring at ddpg.py:511-513: "after unpickling you cannot continue training"), so a run cannot be
+resumed.  Here everything a bit-exact continuation needs is written next to the reference-format `policy_*.pkl` /
+`*_weights.pkl` files (DDPG.save_weights, ddpg.py:481-497: those stay loadable by the reference), on the reference's
+own save cadence (train.py:195-205, `policy_save_interval`):
+
+  per policy     parameters, target parameters, Adam m / v / t, the device step counter, normaliser state and
+                 accumulators, competence progress, the counters that key the device RNG streams (noise, statistics
+                 batches, slot draws)
+  per buffer     stored episodes and counters of EVERY replay buffer of EVERY virtual rank of the process (config.py:210-214:
+                 one set per rank), once per pool slot -- the experts of a task_experts job share theirs (train.py:285-291)
+  per worker     competence queues, task probabilities, histories, SAGG-RIAC selectors, the env episode counters, the host
+                 stream of every virtual rank (train.py:242-243)
+  per process    NumPy / Python / torch host RNG states, what the training loop carries (epoch, best success rate, ...)
+
+One file per process and checkpoint (`training_state/rank003_epoch000050.pt`); rank 0 writes `training_state/LATEST.json`
+AFTER every process has finished its file (a barrier), then the files of older checkpoints go: whatever a job dies in the
+middle of, LATEST.json names a complete set.  `experiment.train --resume DIR` continues from it.
 """
+import json
+import os
+import random
+
 import numpy as np
 import torch
 
+from curious_amd import dist
 
+STATE_DIR = 'training_state'
+FORMAT = 2
+
+
+# ---------------------------------------------------------------------------------------------------------- policies
 def _buffers_of(policy):
-    bufs = policy.buffer if isinstance(policy.buffer, list) else [policy.buffer]
+    """[(pool slot, buffer)] of every distinct replay buffer the policy samples from: all virtual ranks' lists
+    (`policy._rank_buffers`; `policy.buffer` is rank 0's alone), aliased logical buffers once."""
+    lists = getattr(policy, '_rank_buffers', None)
+    if lists is None:
+        lists = [policy.buffer]
     seen, out = set(), []
-    for i, b in enumerate(bufs):
-        if b is not None and id(b) not in seen:
-            seen.add(id(b))
-            out.append((i, b))
+    for bl in lists:
+        for b in (bl if isinstance(bl, list) else [bl]):
+            if b is not None and id(b) not in seen:
+                seen.add(id(b))
+                out.append((int(b.pool_index), b))
     return out
 
 
-def policy_state(policy):
+def _pooled(policies):
+    """{(ordinal of the pool among the policies', pool slot): buffer}, in first-seen order."""
+    pools, by_key = [], {}
+    for p in policies:
+        for slot, b in _buffers_of(p):
+            if id(b.pool) not in pools:
+                pools.append(id(b.pool))
+            by_key.setdefault((pools.index(id(b.pool)), slot), b)
+    return by_key
+
+
+def buffers_state(policies):
+    """Every buffer of the pools the policies sample from, once (experts share their buffers)."""
+    return [dict(pool=pool, slot=slot, current_size=int(b.current_size), n_transitions_stored=int(b.n_transitions_stored),
+                 size=int(b.size), records=b.records[:b.current_size].cpu())
+            for (pool, slot), b in _pooled(policies).items()]
+
+
+def load_buffers_state(policies, states):
+    by_key = _pooled(policies)
+    if len(states) != len(by_key):
+        raise ValueError('checkpoint holds %d replay buffers, this job has %d (another --num_cpu / structure / '
+                         'task_replay?)' % (len(states), len(by_key)))
+    for bs in states:
+        b = by_key[(bs['pool'], bs['slot'])]
+        if bs['size'] != b.size:
+            raise ValueError('checkpointed buffer holds %d episodes at most, this job\'s %d' % (bs['size'], b.size))
+        b.current_size, b.n_transitions_stored = bs['current_size'], bs['n_transitions_stored']
+        b.records[:b.current_size].copy_(bs['records'])
+        b.pool.version += 1
+
+
+def policy_state(policy, with_buffers=True):
     st = dict(
         theta=policy.theta.cpu(), theta_target=policy.theta_target.cpu(), m=policy._m.cpu(), v=policy._v.cpu(),
         t_Q=policy.Q_adam.t, t_pi=policy.pi_adam.t, step_ctr=int(policy._step_ctr),
         o_stats=policy.o_stats.state.cpu(), g_stats=policy.g_stats.state.cpu(), stats_acc=policy._stats_acc.cpu(),
         cp=None if policy.cp is None else np.asarray(policy.cp, dtype=np.float64).copy(),
         noise_counter=policy._noise_counter, stats_calls=getattr(policy, '_stats_calls', 0),
-        store_calls=getattr(policy, '_store_calls', 0),
-        buffers=[])
-    for i, b in _buffers_of(policy):
-        st['buffers'].append(dict(index=i, current_size=b.current_size, n_transitions_stored=b.n_transitions_stored,
-                                  records=b.records[:b.current_size].cpu()))
+        store_calls=getattr(policy, '_store_calls', 0), n_episodes=getattr(policy, 'n_episodes', None),
+        fault_tick=getattr(policy, '_fault_tick', 0),
+        shape=(int(policy.P_total), int(policy.V), int(policy.rank_base), int(policy.total_ranks)))
+    if with_buffers:
+        st['buffers'] = buffers_state([policy])
     return st
 
 
 def load_policy_state(policy, st):
+    shape = (int(policy.P_total), int(policy.V), int(policy.rank_base), int(policy.total_ranks))
+    if tuple(st.get('shape', shape)) != shape:
+        raise ValueError('checkpoint of a policy with (parameters, virtual ranks, first rank, ranks) = %s, this one has %s'
+                         % (tuple(st['shape']), shape))
+    policy.settle()
     policy.theta.copy_(st['theta'])
     policy.theta_target.copy_(st['theta_target'])
     policy._m.copy_(st['m'])
@@ -52,32 +116,62 @@ def load_policy_state(policy, st):
         policy._noise_base_val = None
     policy._stats_calls = st['stats_calls']
     policy._store_calls = st.get('store_calls', 0)             # index of the Philox slot draws (device RNG mode)
-    by_index = {i: b for i, b in _buffers_of(policy)}
-    for bs in st['buffers']:
-        b = by_index[bs['index']]
-        b.current_size, b.n_transitions_stored = bs['current_size'], bs['n_transitions_stored']
-        b.records[:b.current_size].copy_(bs['records'])
+    if st.get('n_episodes') is not None:
+        policy.n_episodes = st['n_episodes']
+    policy._fault_tick = st.get('fault_tick', 0)
+    if 'buffers' in st:
+        load_buffers_state([policy], st['buffers'])
     # everything derived from the counters is rebuilt lazily
     policy._tables_dirty = True
     policy._batch_stale = True
     policy._alpha_filled = 0
 
 
+# ----------------------------------------------------------------------------------------------------------- workers
+def _env_state(w):
+    if getattr(w, 'batched', False):
+        return dict(kind='batched', episode=w.benv.episode.cpu(), seed=w.benv._seed)
+    envs = []
+    for e in w.envs:                                                 # host envs: the synthetic arm keeps a counter per env;
+        b = getattr(getattr(e, 'unwrapped', e), '_b', None)          # a real env's state is its own business (the
+        envs.append(None if b is None else (b.episode.cpu(), b._seed))   # reference cannot checkpoint MuJoCo either)
+    return dict(kind='list', envs=envs)
+
+
+def _load_env_state(w, st):
+    if st['kind'] == 'batched':
+        if w.benv._seed != st['seed']:
+            w.benv.seed(st['seed'])
+        w.benv.episode.copy_(st['episode'])
+        return
+    for e, es in zip(w.envs, st['envs']):
+        b = getattr(getattr(e, 'unwrapped', e), '_b', None)
+        if b is not None and es is not None:
+            if b._seed != es[1]:
+                b.seed(es[1])
+            b.episode.copy_(es[0])
+
+
 def worker_state(w):
     st = dict(n_episodes=w.n_episodes, C=np.asarray(w.C).copy(), CP=np.asarray(w.CP).copy(),
               success_history=list(w.success_history), reward_history=list(w.reward_history),
-              Q_history=list(w.Q_history), count=w.count)
+              Q_history=list(w.Q_history), count=w.count, exploit=bool(w.exploit), env=_env_state(w),
+              vrng=None if w._vrng is None else [r.get_state() for r in w._vrng])
     if hasattr(w, 'competence_computers'):
         st['p'] = np.asarray(w.p).copy()
         st['queues'] = [(list(q.successes), q.C, q.CP) for q in w.competence_computers]
         st['task_history'] = list(w.task_history)
-    if getattr(w, 'batched', False):
-        st['env_episode'] = w.benv.episode.cpu()
+        st['n_goal_history'] = len(w.goal_history)
+    if hasattr(w, 'goal_selectors'):                                 # SAGG-RIAC (plain Python objects)
+        st['goal_selectors'] = w.goal_selectors
+        st['split_histories'] = [list(h) for h in w.split_histories]
     return st
 
 
 def load_worker_state(w, st):
+    w.settle()
     w.n_episodes, w.C, w.CP, w.count = st['n_episodes'], st['C'], st['CP'], st['count']
+    w.exploit = st.get('exploit', w.exploit)
     for name in ('success_history', 'reward_history', 'Q_history'):
         h = getattr(w, name)
         h.clear()
@@ -90,17 +184,35 @@ def load_worker_state(w, st):
             q.C, q.CP = C, CP
         w.task_history.clear()
         w.task_history.extend(st['task_history'])
-    if 'env_episode' in st:
+    if 'goal_selectors' in st:
+        w.goal_selectors = st['goal_selectors']
+        for h, saved in zip(w.split_histories, st['split_histories']):
+            h.clear()
+            h.extend(saved)
+    if st.get('vrng') is not None:
+        if w._vrng is None or len(w._vrng) != len(st['vrng']):
+            w._vrng = [np.random.RandomState(0) for _ in st['vrng']]
+        for r, s in zip(w._vrng, st['vrng']):
+            r.set_state(s)
+    if 'env' in st:
+        _load_env_state(w, st['env'])
+    elif 'env_episode' in st:                                        # (format 1)
         w.benv.episode.copy_(st['env_episode'])
 
 
-def save_training_state(path, policy, workers=()):
+# ------------------------------------------------------------------------------------ one policy, in one file (format 1 API)
+def _settle(policies, workers):
     for w in workers:                                                # async_store: flags / routing the host has not
         if hasattr(w, 'settle'):                                     # mirrored yet
             w.settle()
-    if hasattr(policy, 'settle'):
-        policy.settle()
+    for p in policies:
+        if hasattr(p, 'settle'):
+            p.settle()
     torch.cuda.synchronize()
+
+
+def save_training_state(path, policy, workers=()):
+    _settle([policy], workers)
     torch.save(dict(policy=policy_state(policy), workers=[worker_state(w) for w in workers],
                     numpy_rng=np.random.get_state()), path)
 
@@ -112,3 +224,95 @@ def load_training_state(path, policy, workers=()):
         load_worker_state(w, st)
     np.random.set_state(ck['numpy_rng'])
     torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------------- a whole job: every process, every epoch
+def _flat(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _layout_of(policies):
+    p = policies[0]
+    return dict(world=dist.world_size(), rank=dist.rank(), virtual_ranks=int(p.V), rank_base=int(p.rank_base),
+                total_ranks=int(p.total_ranks), n_policies=len(policies))
+
+
+def _file(dirpath, rank, epoch):
+    return os.path.join(dirpath, STATE_DIR, 'rank%03d_epoch%06d.pt' % (rank, epoch))
+
+
+def save_job_state(dirpath, epoch, policy, workers, expert_bank=None, loop=None):
+    """Collective: every process of the job writes its file for `epoch`, then rank 0 publishes LATEST.json and the files of
+    earlier checkpoints are removed.  policy: a DDPG or the list of experts; workers: every RolloutWorker of the process
+    (training workers first, then the evaluator); loop: what the training loop needs to go on (a picklable dict)."""
+    policies = _flat(policy)
+    workers = [w for w in _flat(workers) if w is not None]
+    _settle(policies, workers)
+    os.makedirs(os.path.join(dirpath, STATE_DIR), exist_ok=True)
+    state = dict(format=FORMAT, epoch=int(epoch), layout=_layout_of(policies),
+                 policies=[policy_state(p, with_buffers=False) for p in policies], buffers=buffers_state(policies),
+                 workers=[worker_state(w) for w in workers],
+                 bank=None if expert_bank is None else dict(cur=int(expert_bank._cur), batched=bool(expert_bank.batched)),
+                 loop=dict(loop or {}), numpy_rng=np.random.get_state(), python_rng=random.getstate(),
+                 torch_rng=torch.get_rng_state())
+    path = _file(dirpath, dist.rank(), epoch)
+    torch.save(state, path + '.tmp')
+    os.replace(path + '.tmp', path)
+    dist.barrier()                                                   # every file of this checkpoint is complete
+    latest = os.path.join(dirpath, STATE_DIR, 'LATEST.json')
+    if dist.rank() == 0:
+        with open(latest + '.tmp', 'w') as f:
+            json.dump(dict(format=FORMAT, epoch=int(epoch), world=dist.world_size()), f)
+        os.replace(latest + '.tmp', latest)
+    dist.barrier()                                                   # ... and published: older files may go
+    mine = 'rank%03d_epoch' % dist.rank()
+    for name in os.listdir(os.path.join(dirpath, STATE_DIR)):
+        if name.startswith(mine) and name != os.path.basename(path):
+            try:
+                os.remove(os.path.join(dirpath, STATE_DIR, name))
+            except OSError:
+                pass
+    return path
+
+
+def latest_epoch(dirpath):
+    """Epoch of the last complete checkpoint under `dirpath`, or None."""
+    try:
+        with open(os.path.join(dirpath, STATE_DIR, 'LATEST.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def load_job_state(dirpath, policy, workers, expert_bank=None):
+    """Restore this process's part of the last complete checkpoint under `dirpath`; returns (epoch, loop dict).  The job
+    must be laid out as the one that saved it (same processes, same virtual ranks per process)."""
+    meta = latest_epoch(dirpath)
+    if meta is None:
+        raise FileNotFoundError('no complete checkpoint under %s (no %s/LATEST.json)' % (dirpath, STATE_DIR))
+    if meta['world'] != dist.world_size():
+        raise ValueError('checkpoint of a %d-process job, this job has %d' % (meta['world'], dist.world_size()))
+    policies = _flat(policy)
+    workers = [w for w in _flat(workers) if w is not None]
+    ck = torch.load(_file(dirpath, dist.rank(), meta['epoch']), weights_only=False)
+    if ck['epoch'] != meta['epoch'] or ck['layout'] != _layout_of(policies):
+        raise ValueError('checkpoint file does not belong to this job: saved by %s at epoch %d, this process is %s'
+                         % (ck['layout'], ck['epoch'], _layout_of(policies)))
+    if len(ck['workers']) != len(workers):
+        raise ValueError('checkpoint holds %d rollout workers, this job has %d' % (len(ck['workers']), len(workers)))
+    for p, st in zip(policies, ck['policies']):
+        load_policy_state(p, st)
+    load_buffers_state(policies, ck['buffers'])
+    for w, st in zip(workers, ck['workers']):
+        load_worker_state(w, st)
+    if expert_bank is not None and ck.get('bank') is not None:
+        expert_bank._cur, expert_bank.batched = ck['bank']['cur'], ck['bank']['batched']
+        for x in expert_bank.experts:
+            x._cur = expert_bank._cur
+            x._batch_stale = True
+    np.random.set_state(ck['numpy_rng'])
+    random.setstate(ck['python_rng'])
+    torch.set_rng_state(ck['torch_rng'])
+    torch.cuda.synchronize()
+    dist.barrier()
+    return ck['epoch'], ck['loop']

@@ -99,8 +99,10 @@ CuriousOptions& curious_options() {
     o.dw_xcd = env_int("CURIOUS_DW_XCD", 1) != 0;
     o.rows_pre = env_int("CURIOUS_ROWS_PRE", 1) != 0;
     o.rows8 = env_int("CURIOUS_ROWS8", 1) != 0;
+    o.rows16 = env_int("CURIOUS_ROWS16", ROWS16_DEFAULT_MIN);
     o.dw_split = env_int("CURIOUS_DW_SPLIT", 0);
     o.lab_dw_stamps = 0;
+    o.lab_rows_stamps = 0;
     o.lab_res_stamps = 0;
     o.resident = env_int("CURIOUS_RESIDENT", 1) != 0;
     o.res_spins = 1 << 20;
@@ -120,8 +122,10 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "dw_xcd")) return &o.dw_xcd;
   if (!strcmp(name, "rows_pre")) return &o.rows_pre;
   if (!strcmp(name, "rows8")) return &o.rows8;
+  if (!strcmp(name, "rows16")) return &o.rows16;
   if (!strcmp(name, "dw_split")) return &o.dw_split;
   if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
+  if (!strcmp(name, "lab_rows_stamps")) return &o.lab_rows_stamps;
   if (!strcmp(name, "lab_res_stamps")) return &o.lab_res_stamps;
   if (!strcmp(name, "resident")) return &o.resident;
   if (!strcmp(name, "res_spins")) return &o.res_spins;

@@ -80,6 +80,7 @@ enum {
 extern int g_curious_prof_on;
 
 // ---------------------------------------------------------------- run-time options (curious_set_option)
+#define ROWS16_DEFAULT_MIN 1280      // batch rows from which the 16-row form of the row-local update is taken (option rows16)
 struct CuriousOptions {
   int rows;            // 1: row-local routes (mlp_rows.h, mlp_rows_act.h); 0: tiled multi-launch routes      [CURIOUS_ROWS]
   int rows_xcd;        // 1: kinds of ddpg_rows_kernel placed by XCD; 0: plain block-id order                 [CURIOUS_ROWS_XCD]
@@ -96,8 +97,11 @@ struct CuriousOptions {
                        //    (mlp_rows.h RowsPre; 0 = fetched from the argument segment as before: A/B)  [CURIOUS_ROWS_PRE]
   int rows8;           // 1: the row-local update gives 8 batch rows to a workgroup for batches of >= 768 rows (virtual ranks);
                        //    0: always 4 (A/B)                                                       [CURIOUS_ROWS8]
+  int rows16;          // > 0: from this many batch rows on the row-local update gives 16 rows to a workgroup, the waves
+                       //    splitting the output columns on v_mfma_f32_16x16x4 (mlp_rows16.h); 0: never (A/B)   [CURIOUS_ROWS16]
   int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h
                        //    DwSplit; batches of >= 1 024 rows); 10 S_hot + S_small: fixed (A/B)       [CURIOUS_DW_SPLIT]
+  int lab_rows_stamps; // LAB ONLY (tools/rows_stamps.py): every row group of ddpg_rows_kernel writes its phase stamps into the workspace
   int lab_dw_stamps;   // LAB ONLY (tools/dw_stamps.py): dw_adam_her_kernel writes per-block cycle stamps into the workspace
   int lab_no_target;   // LAB ONLY (tools/update_lab.py): the target groups of ddpg_rows_kernel exit at once and Q' = 0 --
                        // wrong numbers, right timing of an update whose targets were computed elsewhere

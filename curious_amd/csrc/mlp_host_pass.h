@@ -135,6 +135,10 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   a.xmap = (curious_options().rows_xcd && xd.nex == 1) ? 1 : 0;
   a.fault = w.fault; a.inject = curious_options().fault_inject; a.spins = curious_options().qt_spins;
   a.lab_no_target = curious_options().lab_no_target;
+  if (curious_options().lab_rows_stamps && xd.nex == 1 && (int64_t)(B / 4) * 3 * 16 * 2 <= 6 * 16 * (int64_t)B) {
+    a.stamps = reinterpret_cast<unsigned long long*>(w.part[0]);      // (room: part[0..5], as for lab_dw_stamps)
+    a.stamp_all = 1;
+  }
   xn_rows = cfg->normalize_obs != 0;
   if (cfg->normalize_obs) {
     a.o_mean = cur.o_mean; a.o_std = cur.o_std; a.g_mean = cur.g_mean; a.g_std = cur.g_std; a.nclip = cur.nclip;
@@ -148,6 +152,17 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   // (batched experts: the rows of all experts count -- what matters is whether the row groups of 4 outnumber the chip's
   //  workgroup slots; 4 experts x 256 rows: 51.1 -> 49.5 us per launch, 8.12 -> 7.82 ms per cycle)
   ra_R = (curious_options().rows8 && (int64_t)B * xd.nex >= ROWS_R2_MIN && B % (4 * ROWS_R2) == 0) ? ROWS_R2 : ROWS_R;
+  // 16 rows per workgroup, waves splitting the output columns on v_mfma_f32_16x16x4 (mlp_rows16.h), once the chip is full
+  // several times over: the weight stream per row halves again and the matrix unit, not the texture path, bounds a layer.
+  // Another order of summation over k than the 4- / 8-row forms (parity against the oracle, not their bits)
+  if (curious_options().rows16 > 0 && (int64_t)B * xd.nex >= curious_options().rows16 && B % (4 * ROWS_R3) == 0)
+    ra_R = ROWS_R3;
+  // The XCD map gives every actor-side group -- the longest chain -- a CU of XCDs 0-3 for itself; with more row groups than
+  // those 128 CUs some of them hold two and the launch ends with those: in plain order (actor side first, then target, then
+  // main critic) every CU takes the next group as a slot frees up (tools/rows_stamps.py; bench, rows kernel in us, map | plain:
+  // 16 rows: 8 ranks = 128 groups 53 | 68, 10 ranks 86 | 69, 12 ranks 94 | 86, 19 ranks 132 | 113; 8 rows: 4 ranks = 128 groups
+  // 42 | 50, 5 ranks 60 | 51; 4 rows: 2 ranks = 128 groups 30.6 | 36.0)
+  if (B / ra_R > 128) a.xmap = 0;
   const size_t lds = rows_lds_floats(ra_R, nl) * sizeof(float);
   static bool lds_set = false;
   if (!lds_set) {                                            // > 64 KB of dynamic LDS has to be allowed once per kernel
@@ -162,6 +177,15 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows_her_kernel<false, ROWS_R2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    const int max16 = (int)(rows_lds_floats(ROWS_R3, ROWS_MAXL) * sizeof(float));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows16_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows16_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows16_her_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpg_rows16_her_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max16);
     (void)hipGetLastError();                                 // a refusal here must not be mistaken for a failed launch
     lds_set = true;
   }
@@ -199,6 +223,9 @@ int DdpgPass::launch_rows() {
 #define ROWS_LAUNCH(kernel, EXF, RR, ...)                                                                      \
   hipLaunchKernelGGL((kernel<EXF, RR>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch, k0, k1, k2, k3, k4, k5, a, ex, \
                      ##__VA_ARGS__)
+#define ROWS_LAUNCH16(kernel, EXF, ...)                                                                        \
+  hipLaunchKernelGGL((kernel<EXF>), grid, dim3(256), lds, st, pw0a, pw0t, pw0c, a.batch, k0, k1, k2, k3, k4, k5, a, ex, \
+                     ##__VA_ARGS__)
 #define ROWS_LAUNCH_R(kernel, EXF, ...)                                                                         \
   do {                                                                                                          \
     if (ra_R == ROWS_R2) ROWS_LAUNCH(kernel, EXF, ROWS_R2, ##__VA_ARGS__);                                      \
@@ -206,13 +233,20 @@ int DdpgPass::launch_rows() {
   } while (0)
   if (gather_in_rows) {
     ProfScope ps__(CK_ROWS_HER, st);
-    if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_her_kernel, true, her_rows, seed_stride);
+    if (ra_R == ROWS_R3) {
+      if (xd.nex > 1) ROWS_LAUNCH16(ddpg_rows16_her_kernel, true, her_rows, seed_stride);
+      else ROWS_LAUNCH16(ddpg_rows16_her_kernel, false, her_rows, seed_stride);
+    } else if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_her_kernel, true, her_rows, seed_stride);
     else ROWS_LAUNCH_R(ddpg_rows_her_kernel, false, her_rows, seed_stride);
   } else {
     ProfScope ps__(CK_ROWS, st);
-    if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_kernel, true);
+    if (ra_R == ROWS_R3) {
+      if (xd.nex > 1) ROWS_LAUNCH16(ddpg_rows16_kernel, true);
+      else ROWS_LAUNCH16(ddpg_rows16_kernel, false);
+    } else if (xd.nex > 1) ROWS_LAUNCH_R(ddpg_rows_kernel, true);
     else ROWS_LAUNCH_R(ddpg_rows_kernel, false);
   }
+#undef ROWS_LAUNCH16
 #undef ROWS_LAUNCH_R
 #undef ROWS_LAUNCH
   CURIOUS_LAUNCH_CHECK("ddpg_rows_kernel");

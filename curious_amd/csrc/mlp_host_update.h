@@ -237,6 +237,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
     if (her_fill_args(p.her_rows, next->storage, next->buf_stride, next->L, next->tasks, next->P, nullptr, next->rng, B,
                       next->batch, BL)) return -1;
     p.gather_in_rows = p.rows_route() && her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R, cfg->layers) * sizeof(float) &&
+                       her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R3, cfg->layers) * sizeof(float) &&
                        (B % (ROWS_R * 4) == 0) && SPB == ROWS_R;
   }
   if (!rc && p.rows_route()) {

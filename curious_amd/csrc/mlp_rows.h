@@ -40,6 +40,9 @@
                              // one chain's latency: with 8 rows a 16-byte load of W feeds 8 matrix instructions, the stream per
                              // row halves.  (At B = 256 -- one chain per CU -- the 8-row form is the slower one: round 2.)
 #define ROWS_R2_MIN 768
+#ifndef ROWS16_WAVES
+#define ROWS16_WAVES 3       // workgroups per CU the 16-row kernels are compiled for (register budget 512 / 3 -> 168)
+#endif
 #define RLD 264              // LDS row stride of an activation row (8 mod 64: conflict-free b128 broadcast reads)
 #define ROWS_MAXIN 128       // widest layer-0 input [o | td | action | g] the row-local kernels take: two passes of 64 (rows_l0_fwd)
 #define XLD 132              // LDS row stride of that input row: 132 mod 64 = 4 puts the 4 rows a
@@ -70,6 +73,7 @@ struct RowsArgs {
   int32_t inject, spins;          // inject > 0 (tests): the target group of row group inject - 1 never publishes;
                                   // spins: polls before a consumer gives up
   int32_t lab_no_target;          // lab only: no target groups, Q' = 0 (timing of an update with precomputed targets)
+  int32_t stamp_all;              // lab (option lab_rows_stamps): every row group stamps (ROWS_STAMP)
   int32_t n_her;                  // > 0: B / 4 spare workgroups of this launch run the HER gather of the NEXT update's
                                   // batch (her_body.h) -- on CUs the three kinds leave idle, hidden behind the chains.
                                   // The step counter is then NOT incremented here (the gather keys its Philox stream on
@@ -81,9 +85,18 @@ struct RowsArgs {
   float nclip;
   float *xn_c, *xn_a;
 };
+// (stamp_all, option lab_rows_stamps: EVERY row group stamps, 16 words per (row group, kind): [k] cycle counter of stamp k,
+//  [10] / [11] the 100 MHz real-time counter at the first / the latest stamp -- tools/rows_stamps.py)
 #define ROWS_STAMP(k)                                                                                   \
   do {                                                                                                  \
-    if (a.stamps && rgrp == 0 && x.tid == 0) a.stamps[kind * 32 + (k)] = __builtin_readcyclecounter(); \
+    if (a.stamps && x.tid == 0) {                                                                       \
+      if (a.stamp_all) {                                                                                \
+        unsigned long long* sp_ = a.stamps + ((size_t)rgrp * 3 + kind) * 16;                           \
+        sp_[(k)] = __builtin_readcyclecounter();                                                        \
+        if ((k) == 0) sp_[10] = __builtin_amdgcn_s_memrealtime();                                       \
+        sp_[11] = __builtin_amdgcn_s_memrealtime();                                                     \
+      } else if (rgrp == 0) a.stamps[kind * 32 + (k)] = __builtin_readcyclecounter();                  \
+    }                                                                                                   \
   } while (0)
 #define ROWS_QT_TAG 0x51C0FFEEull
 // A consumer that has polled RowsArgs.spins times (default 2^22, ~ seconds) gives up: the loss turns NaN instead of a
@@ -104,9 +117,11 @@ struct RowsArgs {
 #endif
 struct RCtx {
   mutable unsigned long long* dbg;
-  float* hs; mutable float* part; mutable float* part2; float* xin; float* sm;
+  mutable float* hs; mutable float* part; mutable float* part2; float* xin; float* sm;
+  mutable float* hn;              // 16 rows (mlp_rows16.h): the activation buffer the running layer writes; swaps with hs
   float* keep;                    // relu' masks of the kept layers: 4 rows per workgroup -- the kept activations in LDS;
-  mutable uint64_t kb;            // 8 rows -- 8 bits to a layer (rows_keep)
+  mutable uint64_t kb;            // 8 rows -- 8 bits to a layer (rows_keep); 16 rows -- 16 bits to a layer in kb | kb2
+  mutable uint64_t kb2;
   int tid, wave, lane, r0;
 };
 // a result other workgroups read: the weight-gradient launch that follows
@@ -125,6 +140,7 @@ __device__ __forceinline__ void rows_gst(const RCtx& x, float* p, float v) {
 // ================================================================== the kernel
 // grid (4 * B / R, 1, n_experts); B % (4 R) == 0.
 static inline size_t rows_lds_floats(int R, int nl) {
+  if (R == ROWS_R3) return (size_t)2 * R * RLD + R * XLD + 96;   // two activation buffers, no partial tiles: 42 KB
   return (size_t)R * RLD + 2 * 4 * R * 256 + R * XLD + 64 +  // (two buffers of partials: rows_fw_finish)
          (R == ROWS_R ? (size_t)2 * nl * 4 * 256 : 0);       // 4 rows: the kept activations (rows_keep); 64 KB | 77 KB
 }
@@ -143,9 +159,15 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   x.part = x.hs + R * RLD;
   x.part2 = x.part + 4 * R * 256;
   x.xin = x.part2 + 4 * R * 256;
+  x.hn = nullptr;
+  if constexpr (R == ROWS_R3) {                              // two activation buffers instead of the partial tiles
+    x.hn = x.hs + R * RLD;
+    x.part = x.part2 = nullptr;
+    x.xin = x.hn + R * RLD;
+  }
   x.sm = x.xin + R * XLD;
   x.keep = x.sm + 64;                                       // (4 rows) [2 * nl][4 rows][256]: activations kept for relu'
-  x.kb = 0;
+  x.kb = x.kb2 = 0;
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
   // Kind of workgroup and row group from the block id.  Workgroups are dealt round-robin over the 8 XCDs in block-id
   // order (block b lands on XCD b % 8; speed only, nothing depends on it for correctness).  A layer's time is set by
@@ -241,13 +263,22 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     const HeadW4 wpi_t = rows_head4_w(tp + a.tPi.Wout, x.lane);
     const float bpi_t = tp[a.tPi.bout + (x.lane & 3)];
     const float b0_tq = tq[a.tQ.b0 + x.tid];
-    rows_l0_fwd<R>(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, -1, nullptr,
+    rows_l0_fwd<R>(x, wb, tp + a.tPi.W0, Sa, tp + a.tPi.Wg, G, Sc, b0_tp, tp + a.tPi.b0, -1, nullptr,
                    rnext(RN_FWD, tp + a.tPi.W[1]), true);
     ROWS_STAMP(2);
     rows_hidden_fwd<R>(x, wb, a, a.tPi, tp, -1, 0, eo, rnext(RN_L0, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, Sc + G));
     ROWS_STAMP(3);
     const f32x4 wq_t = ldv(tq + a.tQ.Wout + 4 * x.lane);
     const float bq_t = tq[a.tQ.bout];
+    if constexpr (R == ROWS_R3) {                            // (the output layer on the matrix unit: mlp_rows16.h)
+      float bf[16];
+      r16_frag_cols4(bf, tp + a.tPi.Wout, x.wave, x.lane);
+      const float z = r16_thin_sum(x, r16_thin(x, bf));
+      if (x.lane < 16) {
+        const float v = a.max_u * tanhf(z + bpi_t);                                        // actor_critic.py:89
+        x.xin[(4 * x.wave + (x.lane >> 2)) * XLD + Sa + (x.lane & 3)] = fdiv(v, a.max_u);  // actor_critic.py:93
+      }
+    } else {
 #pragma unroll
     for (int hh = 0; hh < R / 4; ++hh) {
       const int row = 4 * hh + x.wave;
@@ -261,12 +292,22 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
         x.xin[row * XLD + Sa + x.lane] = fdiv(v, a.max_u);                                 // actor_critic.py:93
       }
     }
+    }
     __syncthreads();
     ROWS_STAMP(4);
-    rows_l0_fwd<R>(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, -1, nullptr,
+    rows_l0_fwd<R>(x, wb, tq + a.tQ.W0, Sc, tq + a.tQ.Wg, G, Sc, b0_tq, tq + a.tQ.b0, -1, nullptr,
                    rnext(RN_FWD, tq + a.tQ.W[1]), true);
     rows_hidden_fwd<R>(x, wb, a, a.tQ, tq, -1, 0, eo, rnext(RN_NONE, nullptr));
     ROWS_STAMP(5);
+    if constexpr (R == ROWS_R3) {
+      float bf[16];
+      r16_frag_rows(bf, tq + a.tQ.Wout, 1, x.wave, x.lane);
+      const float Qt = r16_thin_sum(x, r16_thin(x, bf)) + bq_t;                            // ddpg.py:427-431
+      const int row = 4 * x.wave + (x.lane >> 2);
+      if (x.lane < 16 && (x.lane & 3) == 0 && !(a.inject > 0 && (x.r0 + row) / ROWS_R == a.inject - 1))
+        __hip_atomic_store(qt + row, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
 #pragma unroll
     for (int hh = 0; hh < R / 4; ++hh) {
       const int row = 4 * hh + x.wave;
@@ -275,6 +316,7 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
       if (x.lane == 0 && !(a.inject > 0 && (x.r0 + row) / ROWS_R == a.inject - 1))
         __hip_atomic_store(qt + row, (ROWS_QT_TAG << 32) | (unsigned long long)__float_as_uint(Qt), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
     ROWS_STAMP(6);
     return nrg + rgrp;
@@ -295,15 +337,48 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
     const float bq_m = mq[a.mQ.bout];
     const float wq_col = mq[a.mQ.Wout + x.tid];
+    const f32x4 wq_c4 = ldv(mq + a.mQ.Wout + 64 * x.wave + 4 * (x.lane & 15));   // (16 rows: the thread's 4 columns)
+    (void)wq_col; (void)wq_c4;
     float rew[R / 4];
 #pragma unroll
     for (int hh = 0; hh < R / 4; ++hh) rew[hh] = batch[(int64_t)(x.r0 + 4 * hh + x.wave) * a.ld + a.off_r];
+    // (16 rows: lane L < 16 of wave w finishes row 4 w + (L >> 2) -- mlp_rows16.h r16_thin_sum)
+    const float rew_l = batch[(int64_t)(x.r0 + 4 * x.wave + ((x.lane & 15) >> 2)) * a.ld + a.off_r];
+    (void)rew; (void)rew_l;
     // relu' masks kept for the backward pass (slots 0 .. nl - 1), layer outputs stored for the weight gradients
-    rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, 0, a.actc[0] + eo,
+    rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, mq + a.mQ.b0, 0, a.actc[0] + eo,
                    rnext(RN_FWD, mq + a.mQ.W[1]), true);
     ROWS_STAMP(2);
     rows_hidden_fwd<R>(x, wb, a, a.mQ, mq, 0, 1, eo, rows_bwd_first(a, false, eo));
     ROWS_STAMP(3);
+    if constexpr (R == ROWS_R3) {
+      float bf[16];
+      r16_frag_rows(bf, mq + a.mQ.Wout, 1, x.wave, x.lane);
+      const float Q = r16_thin_sum(x, r16_thin(x, bf)) + bq_m;
+      const int row = 4 * x.wave + ((x.lane & 15) >> 2), m = x.r0 + row;
+      if (x.lane < 16 && (x.lane & 3) == 0) {               // one lane per row: Q' of its row from the target group
+        unsigned long long word = 0;
+        int spins = 0;
+        const int max_spins = a.spins > 0 ? a.spins : (1 << 22);
+        for (;;) {
+          if (a.lab_no_target) { word = ROWS_QT_TAG << 32; break; }
+          word = __hip_atomic_load(qt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((word >> 32) == ROWS_QT_TAG || ++spins > max_spins) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const bool got = (word >> 32) == ROWS_QT_TAG;
+        const float Qt = got ? __uint_as_float((unsigned)(word & 0xffffffffull)) : NAN;
+        __hip_atomic_store(qt + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // consumed
+        if (!got && a.fault) atomicAdd(reinterpret_cast<int32_t*>(reinterpret_cast<float*>(a.fault) + eo), 1);
+        const float target = got ? fclip(rew_l + a.gamma * Qt, a.clip_lo, a.clip_hi) : NAN;   // ddpg.py:437-438
+        const float diff = target - Q;
+        const float dq = -2.0f * invB * diff;
+        rows_gst(x, a.rows + eo + m, diff * diff);           // ddpg.py:439
+        rows_gst(x, a.dQ + eo + m, dq);
+        sm_s[row] = dq;
+      }
+      ROWS_STAMP(4);
+    } else {
 #pragma unroll
     for (int hh = 0; hh < R / 4; ++hh) {
       const int row = 4 * hh + x.wave, m = x.r0 + row;
@@ -336,9 +411,13 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
         sm_s[row] = dq;
       }
     }
+    }
     __syncthreads();
     // ---- backward through the output layer: dY[i][c] = dQ[i] Wout[c] relu'(h[i][c])
-    {
+    if constexpr (R == ROWS_R3) {
+      const f32x4 w = wq_c4;
+      r16_seed(x, nl - 1, a.dactc[nl - 1] + eo, [&](int row, int e) { return sm_s[row] * w[e]; });
+    } else {
       const int L = nl - 1;
       const float w = wq_col;
       const uint32_t hk = rows_kept<R>(x, L);
@@ -375,12 +454,32 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const HeadW4 wpi = rows_head4_w(mp + a.mPi.Wout, x.lane);
   const f32x4 bpi = ldv(mp + a.mPi.bout);
   const float b0_mq = mq[a.mQ.b0 + x.tid];
-  rows_l0_fwd<R>(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, keepA, a.acta[0] + eo,
+  rows_l0_fwd<R>(x, wb, mp + a.mPi.W0, Sa, mp + a.mPi.Wg, G, Sc, b0_mp, mp + a.mPi.b0, keepA, a.acta[0] + eo,
                  rnext(RN_FWD, mp + a.mPi.W[1]), true);
   ROWS_STAMP(2);
   rows_hidden_fwd<R>(x, wb, a, a.mPi, mp, keepA, 2, eo, rnext(RN_L0, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, Sc + G));
   ROWS_STAMP(3);
   float pi[R / 4][4];
+  float pi_l = 0.f;                                         // (16 rows: pi[row][d] of lane (row, d), mlp_rows16.h r16_thin_sum)
+  if constexpr (R == ROWS_R3) {
+    float bf[16];
+    r16_frag_cols4(bf, mp + a.mPi.Wout, x.wave, x.lane);
+    const float z = r16_thin_sum(x, r16_thin(x, bf));
+    const int row = 4 * x.wave + ((x.lane & 15) >> 2), d = x.lane & 3, m = x.r0 + row;
+    float bd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bd = (d == e) ? bpi[e] : bd;
+    pi_l = a.max_u * tanhf(z + bd);                                                        // actor_critic.py:89
+    float t[4];
+    r16_quad(pi_l / a.max_u, t);
+    float l2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l2 += t[e] * t[e];                                         // ddpg.py:441
+    if (x.lane < 16) {
+      x.xin[row * XLD + Sa + d] = fdiv(pi_l, a.max_u);                                     // actor_critic.py:93
+      if (d == 0) rows_gst(x, a.rows + eo + 2 * a.B + m, l2);
+    }
+  } else {
 #pragma unroll
   for (int hh = 0; hh < R / 4; ++hh) {
     const int row = 4 * hh + x.wave, m = x.r0 + row;
@@ -401,6 +500,8 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     }
     if (x.lane == 0) rows_gst(x, a.rows + eo + 2 * a.B + m, l2);
   }
+  }
+  (void)pi; (void)pi_l;
   __syncthreads();
   ROWS_STAMP(4);
   // operands of the critic's head, of the first backward step, of the action-slot product and of the actor's first
@@ -408,11 +509,23 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
   const f32x4 wq_m = ldv(mq + a.mQ.Wout + 4 * x.lane);
   const float bq_m = mq[a.mQ.bout];
   const float wq_col = mq[a.mQ.Wout + x.tid];
+  const f32x4 wq_c4 = ldv(mq + a.mQ.Wout + 64 * x.wave + 4 * (x.lane & 15));     // (16 rows: the thread's 4 columns)
+  (void)wq_col; (void)wq_c4;
   // ---- main critic on (o, g, pi) -> Q_pi
-  rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, keepD, nullptr,
+  rows_l0_fwd<R>(x, wb, mq + a.mQ.W0, Sc, mq + a.mQ.Wg, G, Sc, b0_mq, mq + a.mQ.b0, keepD, nullptr,
                  rnext(RN_FWD, mq + a.mQ.W[1]), true);
   rows_hidden_fwd<R>(x, wb, a, a.mQ, mq, keepD, 0, eo, rows_bwd_first(a, false, eo));
   ROWS_STAMP(5);
+  if constexpr (R == ROWS_R3) {
+    float bf[16];
+    r16_frag_rows(bf, mq + a.mQ.Wout, 1, x.wave, x.lane);
+    const float Qpi = r16_thin_sum(x, r16_thin(x, bf)) + bq_m;
+    const int m = x.r0 + 4 * x.wave + ((x.lane & 15) >> 2);
+    if (x.lane < 16 && (x.lane & 3) == 0) {
+      rows_gst(x, a.rows + eo + a.B + m, Qpi);               // ddpg.py:440
+      a.out_Qpi[eo + m] = Qpi;
+    }
+  } else {
 #pragma unroll
   for (int hh = 0; hh < R / 4; ++hh) {
     const int row = 4 * hh + x.wave, m = x.r0 + row;
@@ -422,9 +535,13 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
       a.out_Qpi[eo + m] = Qpi;
     }
   }
+  }
   __syncthreads();
   // ---- backward of -mean(Q_pi) through the critic into the action slot
-  {
+  if constexpr (R == ROWS_R3) {
+    const f32x4 w = wq_c4;
+    r16_seed(x, keepD + nl - 1, nullptr, [&](int, int e) { return w[e] * (-invB); });
+  } else {
     const float w = wq_col * (-invB);
     const uint32_t hk = rows_kept<R>(x, keepD + nl - 1);
 #pragma unroll
@@ -439,9 +556,28 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
     for (int d = 0; d < 4; ++d) wu[d] = ldv(Wu + (int64_t)d * 256 + 4 * x.lane);
   }
   const f32x4 wpi_row = ldv(mp + a.mPi.Wout + 4 * x.tid);
+  f32x4 wpi_c4[4];                                          // (16 rows: Wout rows of the thread's 4 columns)
+  if constexpr (R == ROWS_R3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wpi_c4[e] = ldv(mp + a.mPi.Wout + 4 * (64 * x.wave + 4 * (x.lane & 15) + e));
+  }
+  (void)wpi_row; (void)wpi_c4;
   rows_hidden_bwd<R>(x, wb, a, keepD, 0, eo, rows_bwd_first(a, true, eo));
   ROWS_STAMP(7);
   // (every operand that comes from the critic's parameters is in registers or consumed by now: wu, wq_col above)
+  if constexpr (R == ROWS_R3) {
+    float bf[16];
+    r16_frag_rows(bf, mq + a.mQ.W0 + (int64_t)Sa * 256, 4, x.wave, x.lane);
+    const float v = r16_thin_sum(x, r16_thin(x, bf));
+    const int row = 4 * x.wave + ((x.lane & 15) >> 2), d = x.lane & 3, m = x.r0 + row;
+    const float th = pi_l / a.max_u;
+    const float dpi = v / a.max_u + a.l2c * pi_l;
+    const float dzl = dpi * a.max_u * (1.0f - th * th);
+    if (x.lane < 16) {
+      a.dz[eo + (int64_t)m * 4 + d] = dzl;
+      sm_v[4 * row + d] = dzl;
+    }
+  } else {
 #pragma unroll
   for (int hh = 0; hh < R / 4; ++hh) {
     // d / d(action slot): dd0 . Wu^T (Wu = the action rows of the critic's layer-0 kernel), then through
@@ -463,9 +599,16 @@ __device__ __forceinline__ int ddpg_rows_body(const RowsArgs& a, const Ex& ex, c
       *reinterpret_cast<f32x4*>(sm_v + 4 * row) = o;
     }
   }
+  }
   __syncthreads();
   // ---- backward through the actor's output layer: dY[i][c] = (sum_d dz[i][d] Wout[c][d]) relu'(a[i][c])
-  {
+  if constexpr (R == ROWS_R3) {
+    r16_seed(x, keepA + nl - 1, a.dacta[nl - 1] + eo, [&](int row, int e) {
+      const f32x4 dzr = *reinterpret_cast<const f32x4*>(sm_v + 4 * row);
+      const f32x4 w = wpi_c4[e];
+      return dzr[0] * w[0] + dzr[1] * w[1] + dzr[2] * w[2] + dzr[3] * w[3];
+    });
+  } else {
     const int L = nl - 1;
     const f32x4 w = wpi_row;
     const uint32_t hk = rows_kept<R>(x, keepA + L);
@@ -532,6 +675,25 @@ void ddpg_rows_her_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex, HerArgs her, uint6
   ROWS_PRE_MAKE(pre);
   const uint32_t touched = rows_kernarg_touch();
   ddpg_rows_body<EX, true, R>(a, ex, &her, seed_stride, &pre);
+  asm volatile("" :: "s"(touched));
+}
+
+// 16 rows per workgroup (mlp_rows16.h): 42 KB of LDS and <= 168 registers -- THREE workgroups share a CU, so that two
+// keep the matrix unit busy while the third sits in an epilogue, a head or a hand-off
+template <bool EX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROWS16_WAVES, ROWS16_WAVES)))
+void ddpg_rows16_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex) {
+  ROWS_PRE_MAKE(pre);
+  const uint32_t touched = rows_kernarg_touch();
+  ddpg_rows_body<EX, false, ROWS_R3>(a, ex, nullptr, 0, &pre);
+  asm volatile("" :: "s"(touched));
+}
+template <bool EX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROWS16_WAVES, ROWS16_WAVES)))
+void ddpg_rows16_her_kernel(ROWS_PRE_PARAMS, RowsArgs a, Ex ex, HerArgs her, uint64_t seed_stride) {
+  ROWS_PRE_MAKE(pre);
+  const uint32_t touched = rows_kernarg_touch();
+  ddpg_rows_body<EX, true, ROWS_R3>(a, ex, &her, seed_stride, &pre);
   asm volatile("" :: "s"(touched));
 }
 

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
         nd = noise_draw(rn.row * 4 + x.lane, rn.row, rn.random_eps, a.max_u_d, nullptr, nullptr, nullptr, rn.seed,
                         ctr0 + (uint64_t)s);
       __syncthreads();                                       // input rows of all 4 envs are in LDS
-      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr,
+      rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, -1, nullptr,
                   rnext(RN_FWD, pp + a.pi.W[1]));
       const RNext again = (s + 1 < a.nsteps) ? rnext(RN_L0, pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G)
                                              : rnext(RN_NONE, nullptr);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
     return;
   }
   __syncthreads();
-  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr,
+  rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, -1, nullptr,
               rnext(RN_FWD, pp + a.pi.W[1]));
   const float* qp = a.q.th;
   const RNext after = a.out_Q ? rnext(RN_L0, qp + a.q.W0, Sc, qp + a.q.Wg, Sc + G) : rnext(RN_NONE, nullptr);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   const f32x4 wq = ldv(qp + a.q.Wout + 4 * x.lane);
   const float bq = qp[a.q.bout];
   __syncthreads();
-  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp[a.q.b0 + x.tid], -1, nullptr,
+  rows_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp[a.q.b0 + x.tid], nullptr, -1, nullptr,
               rnext(RN_FWD, qp + a.q.W[1]));
   for (int l = 1; l < a.nl; ++l)
     rows_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], -1, nullptr,

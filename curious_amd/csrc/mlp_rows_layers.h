@@ -62,6 +62,7 @@ __device__ __forceinline__ void rows_prefetch(f32x4 (&b)[16], const RNext& n, in
   if (n.kind == RN_FWD) rows_fw_load(b, n.W + n.off, wave, lane, 0);
   else if (n.kind == RN_L0) rows_l0_load(b, n.W, n.S, n.Wg, n.nk, wave, lane, 0);
 }
+#include "mlp_rows16.h"      // 16 rows per workgroup on v_mfma_f32_16x16x4 (the dispatch sits in the routines below)
 // R batch rows per workgroup (4, or 8 for batches of several ranks / experts -- mlp_rows.h): one 16-byte load of W feeds
 // R instructions; acc[h] are rows 4 h .. 4 h + 3
 template <int R>
@@ -196,6 +197,12 @@ template <int R = 4>
 __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W, const float* bias,
                                              const int keep, float* gout, const RNext& next, const bool lean = false,
                                              const int64_t late_off = 0) {
+  if constexpr (R == ROWS_R3) {
+    RNext n = next;
+    if (lean) n.off += late_off;
+    r16_big_fwd(x, wb, W, bias, keep, gout, n);
+    return;
+  }
   f32x4 acc[R / 4][4];
   rows_acc_zero<R>(acc);
   const float bv = bias[x.tid];
@@ -209,6 +216,10 @@ __device__ __forceinline__ void rows_big_fwd(const RCtx& x, f32x4 (&wb)[2][16], 
 template <int R>
 __device__ __forceinline__ void rows_big_bwdT(const RCtx& x, f32x4 (&wb)[2][16], const float* WT, const int mask,
                                               float* gout, const RNext& next, const bool lean = false) {
+  if constexpr (R == ROWS_R3) {
+    r16_big_bwdT(x, wb, WT, mask, gout, next);
+    return;
+  }
   f32x4 acc[R / 4][4];
   rows_acc_zero<R>(acc);
   rows_big_chunks<R>(x, wb, WT, next, false, 0, acc);
@@ -253,8 +264,13 @@ __device__ __forceinline__ void rows_l0_mac(const RCtx& x, const f32x4 (&b)[16],
 // parameters were just rewritten by the optimiser, a load issued here would be a second cold round trip)
 template <int R = 4>
 __device__ __forceinline__ void rows_l0_fwd(const RCtx& x, f32x4 (&wb)[2][16], const float* W0, int S, const float* Wg,
-                                            int G, int gofs, const float bv, const int keep, float* gout,
-                                            const RNext& next, const bool lean = false) {
+                                            int G, int gofs, const float bv, const float* b0p, const int keep,
+                                            float* gout, const RNext& next, const bool lean = false) {
+  // (b0p: the bias vector itself -- the 16-row form's threads own 4 columns each and fetch their own)
+  if constexpr (R == ROWS_R3) {
+    r16_l0_fwd(x, wb, W0, S, Wg, G, gofs, b0p, keep, gout, next);
+    return;
+  }
   f32x4 acc[R / 4][4];
   rows_acc_zero<R>(acc);
   const int nk = S + G;
@@ -442,7 +458,8 @@ __device__ __forceinline__ void rows_first_loads(const RCtx& x, const RowsArgs& 
     foff_g = (kind == 1) ? a.off_g2 : a.off_g;
     asm volatile("" : "+s"(fS), "+s"(foff_o), "+s"(foff_g));   // (no select between the two descriptions: see the caller)
   }
-  rows_l0_load(wb0, fW0, fS, fW0 + fWg_off, fS + fin.dimg, x.wave, x.lane, 0);
+  if constexpr (R == ROWS_R3) r16_l0_load8(wb0, fW0, fS, fW0 + fWg_off, fS + fin.dimg, x.wave, x.lane, 0);
+  else rows_l0_load(wb0, fW0, fS, fW0 + fWg_off, fS + fin.dimg, x.wave, x.lane, 0);
   rows_inputs_issue<R>(x.tid, rgrp * R, fin, fbatch, foff_o, foff_g, kind == 2, xraw);
   __builtin_amdgcn_sched_barrier(0);
 }

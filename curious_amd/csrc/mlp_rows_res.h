@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void policy_resident_kernel(ActRowsArgs a, Res
     }
     __syncthreads();                                         // input rows (and, first step, the slices) are in LDS
     if (rx.stamps && blockIdx.x == 0 && x.tid == 0) last_stamp = __builtin_readcyclecounter();
-    rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, -1, nullptr, rnext(RN_NONE, nullptr));
+    rows_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, b0_pi, nullptr, -1, nullptr, rnext(RN_NONE, nullptr));
     RES_STAMP(0);
     float v1 = res_slice(x, w1s, bias1);
     RES_STAMP(1);

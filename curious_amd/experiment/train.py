@@ -74,10 +74,32 @@ class FaultTolerance:
             return None
 
 
+class Checkpointer:
+    """Resumable training state on the reference's save cadence (train.py:195-205: every `policy_save_interval` epochs;
+    `checkpoint_interval` overrides it, 0 = never) and behind the job's last epoch: curious_amd.checkpoint.save_job_state
+    -- a collective, every process writes its own file into `<logdir>/training_state/`."""
+
+    def __init__(self, dirpath, interval, n_epochs, policy, workers, expert_bank=None):
+        self.dir, self.interval, self.n_epochs = dirpath, int(interval or 0), int(n_epochs)
+        self.policy, self.workers, self.bank = policy, workers, expert_bank
+
+    def due(self, epoch):
+        return self.dir is not None and self.interval > 0 and (epoch % self.interval == 0 or epoch == self.n_epochs - 1)
+
+    def save(self, epoch, best_success_rate, ft, extra=None):
+        from curious_amd.checkpoint import save_job_state
+        loop = dict(best_success_rate=best_success_rate, ft=(ft.cycle, ft.last, ft.count), elapsed=time.time() - t0)
+        loop.update(extra or {})
+        save_job_state(self.dir, epoch, self.policy, self.workers, self.bank, loop)
+
+
 def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
-           save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None, **kwargs):
+           save_policies, structure, task_selection, params, perturbation_study=False, expert_bank=None,
+           checkpointer=None, resumed=None, **kwargs):
     """train.py:49-166.  expert_bank (task_experts only): update ALL experts in one batched launch sequence after
-    every rollout (BASELINE configs[4]) instead of only the expert that collected it."""
+    every rollout (BASELINE configs[4]) instead of only the expert that collected it.
+    checkpointer: writes the resumable state (Checkpointer); resumed = (epoch, loop dict) of the checkpoint this job was
+    restored from (curious_amd.checkpoint.load_job_state): the loop goes on behind that epoch."""
     rank = dist.rank()
     if rank == 0 and logger.get_dir() is not None:
         latest_policy_path = os.path.join(logger.get_dir(), 'policy_latest.pkl')
@@ -89,6 +111,11 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
     best_success_rate = -1
     nb_tasks = params['nb_tasks']
     ft = FaultTolerance()
+    first_epoch = 0
+    if resumed is not None:
+        first_epoch = resumed[0] + 1
+        best_success_rate = resumed[1].get('best_success_rate', -1)
+        ft.cycle, ft.last, ft.count = resumed[1].get('ft', (0, None, 0))
     sync_faults = params.get('fault_check', 'async') == 'sync'
 
     def updates(pol, n):
@@ -99,13 +126,14 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
     if structure == 'task_experts':
         p = 1 / nb_tasks * np.ones([nb_tasks])
         epoch, i_policy = -1, -1
-        evaluator.clear_history()
-        evaluator.clear_competence_queue()
-        evaluator.generate_eval_rollouts(n_test_rollouts)
-        best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate, best_policy_path,
-                                 periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
-                                 policy[i_policy], rank, structure, i_policy=i_policy, task_experts_cp=p)
-        for epoch in range(n_epochs):
+        if resumed is None:
+            evaluator.clear_history()
+            evaluator.clear_competence_queue()
+            evaluator.generate_eval_rollouts(n_test_rollouts)
+            best_success_rate = logs(rollout_worker[i_policy], evaluator, epoch, best_success_rate, best_policy_path,
+                                     periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
+                                     policy[i_policy], rank, structure, i_policy=i_policy, task_experts_cp=p)
+        for epoch in range(first_epoch, n_epochs):
             if task_selection == 'random':
                 i_policy = epoch % nb_tasks                           # train.py:79-81
             else:
@@ -131,18 +159,21 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
                                      best_policy_path, periodic_policy_path, policy_save_interval, save_policies,
                                      latest_policy_path, policy[i_policy], rank, structure, i_policy=i_policy,
                                      task_experts_cp=p)
+            if checkpointer is not None and checkpointer.due(epoch):
+                checkpointer.save(epoch, best_success_rate, ft)
     else:
         epoch = -1
-        evaluator.clear_history()
-        evaluator.generate_eval_rollouts(n_test_rollouts)
-        best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
-                                 periodic_policy_path, policy_save_interval, save_policies, latest_policy_path, policy,
-                                 rank, structure)
-        for epoch in range(n_epochs):
+        if resumed is None:
+            evaluator.clear_history()
+            evaluator.generate_eval_rollouts(n_test_rollouts)
+            best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
+                                     periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
+                                     policy, rank, structure)
+        for epoch in range(first_epoch, n_epochs):
             logger.info('Starting new epoch ', epoch, 'at time', time.time() - t0)
             t_ep = time.time()
             rollout_worker.clear_history()
-            if perturbation_study and epoch == 250:
+            if perturbation_study and (epoch == 250 or (epoch > 250 and epoch == first_epoch)):   # (a job resumed past it)
                 perturb_envs(rollout_worker, evaluator)              # train.py:142-146
             for cyc in range(n_cycles):                               # train.py:148-155 -- the hot loop
                 ft.tick()
@@ -157,6 +188,8 @@ def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycle
             best_success_rate = logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path,
                                      periodic_policy_path, policy_save_interval, save_policies, latest_policy_path,
                                      policy, rank, structure)
+            if checkpointer is not None and checkpointer.due(epoch):
+                checkpointer.save(epoch, best_success_rate, ft)
     return best_success_rate
 
 
@@ -226,17 +259,32 @@ def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, 
 
 def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_return, normalize_obs, structure,
            task_selection, goal_selection, goal_replay, task_replay, perturb=False, save_policies=True,
-           override_params=None, save_root='./save/'):
-    """train.py:217-339."""
+           override_params=None, save_root='./save/', resume=None, checkpoint_interval=None):
+    """train.py:217-339.
+    resume: the log directory of an earlier job of the SAME configuration (its save_root/env/trial directory): the job goes
+    on behind that job's last complete checkpoint (curious_amd.checkpoint) -- same directory, progress.csv continued -- up
+    to epoch n_epochs - 1.  checkpoint_interval: epochs between checkpoints (default: policy_save_interval, the
+    reference's save cadence train.py:195-205; 0: none)."""
+    global t0
     dist.init_from_env()
     rank = dist.rank()
     if torch.cuda.is_available():
         torch.cuda.set_device(dist.local_device_index())
+    resume_meta = None
+    if resume is not None:
+        from curious_amd.checkpoint import latest_epoch
+        resume = os.path.join(os.path.abspath(resume), '')
+        resume_meta = latest_epoch(resume)
+        if resume_meta is None:
+            raise FileNotFoundError('--resume %s: no complete checkpoint there (training_state/LATEST.json)' % resume)
     if rank == 0:
-        save_dir = find_save_path(save_root + env + "/", trial_id)
-        logger.configure(dir=save_dir)
+        save_dir = resume if resume is not None else find_save_path(save_root + env + "/", trial_id)
+        # (a job that went on past its last checkpoint before it died logs those epochs again)
+        logger.configure(dir=save_dir, resume_epoch=None if resume_meta is None else resume_meta['epoch'])
     else:
         save_dir = None
+    # where every process writes its part of a checkpoint: rank 0's log directory
+    state_dir = dist.broadcast_object(os.path.abspath(save_dir) if rank == 0 else None, 0)
     if perturb and structure == 'task_experts':
         raise NotImplementedError('--perturb applies to the curious / flat loop only (train.py:142-146)')
     # Virtual ranks: --num_cpu R with R > WORLD_SIZE runs the reference's R ranks on the WORLD_SIZE processes -- R // W per
@@ -269,8 +317,16 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     if total != world * V or base != rank * V:
         params['rank_base'], params['total_ranks'] = base, total
     if rank == 0:
+        plain = {k: v for k, v in params.items() if isinstance(v, (int, float, str, bool, type(None)))}
+        if resume is not None and os.path.exists(os.path.join(resume, 'params.json')):
+            with open(os.path.join(resume, 'params.json')) as f:
+                was = json.load(f)
+            diff = {k: (was[k], plain.get(k)) for k in was if k not in ('time', 'resumed_at_epoch') and was[k] != plain.get(k)}
+            if diff:
+                raise ValueError('--resume %s: the job there was configured differently (was, now): %s' % (resume, diff))
+            plain['resumed_at_epoch'] = resume_meta['epoch']
         with open(os.path.join(logger.get_dir(), 'params.json'), 'w') as f:
-            json.dump({k: v for k, v in params.items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
+            json.dump(plain, f)
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = normalize_obs
     params['ddpg_params'].setdefault('seed', seed)                    # identical initial weights on every rank
@@ -322,11 +378,21 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         rollout_worker.seed_ranks([seed + 1000000 * (base + v) for v in range(V)])
         evaluator.seed_ranks([seed + 1000000 * (base + v) + 100 for v in range(V)])
 
+    workers = (list(rollout_worker) if isinstance(rollout_worker, list) else [rollout_worker]) + [evaluator]
+    interval = policy_save_interval if checkpoint_interval is None else checkpoint_interval
+    checkpointer = Checkpointer(state_dir, interval if save_policies else 0, n_epochs, policy, workers, expert_bank)
+    resumed = None
+    if resume is not None:
+        from curious_amd.checkpoint import load_job_state
+        resumed = load_job_state(state_dir, policy, workers, expert_bank)
+        t0 = time.time() - resumed[1].get('elapsed', 0.0)             # the 'Time' column goes on where it stopped
+        logger.info('Resumed from %s: epoch %d done, going on to epoch %d' % (state_dir, resumed[0], n_epochs - 1))
+
     best = train(logdir=save_dir, policy=policy, rollout_worker=rollout_worker, evaluator=evaluator,
                  n_epochs=n_epochs, n_test_rollouts=params['n_test_rollouts'], n_cycles=params['n_cycles'],
                  n_batches=params['n_batches'], perturbation_study=perturb, policy_save_interval=policy_save_interval,
                  save_policies=save_policies, structure=structure, task_selection=task_selection, params=params,
-                 expert_bank=expert_bank)
+                 expert_bank=expert_bank, checkpointer=checkpointer, resumed=resumed)
     shutdown(policy if isinstance(policy, list) else [policy], expert_bank)
     return best
 
@@ -370,6 +436,12 @@ def main(argv=None):
     parser.add_argument('--goal_replay', type=str, default=GOAL_REPLAY)
     parser.add_argument('--task_replay', type=str, default=TASK_REPLAY)
     parser.add_argument('--perturb', type=lambda s: s.lower() in ('1', 'true', 'yes'), default=False)
+    parser.add_argument('--resume', type=str, default=None,
+                        help='log directory of an earlier job with the same flags (save/<env>/<trial>/): go on behind its last '
+                             'complete checkpoint, bit for bit what the uninterrupted job would have computed')
+    parser.add_argument('--checkpoint_interval', type=int, default=None,
+                        help='epochs between resumable checkpoints (default: --policy_save_interval, the cadence of '
+                             'train.py:195-205; 0: none); one is always written behind the last epoch')
     # MI355X-side knobs
     parser.add_argument('--rollout_batch_size', type=int, default=None)
     parser.add_argument('--rng_mode', type=str, default='device', choices=['numpy', 'device'])

@@ -9,11 +9,25 @@ import sys
 _state = {'dir': None, 'kv': {}, 'keys': [], 'csv': None}
 
 
-def configure(dir=None):
+def configure(dir=None, resume_epoch=None):
+    """resume_epoch (a job that goes on from a checkpoint, curious_amd.checkpoint): progress.csv of `dir` is continued --
+    its header stays, its rows behind that epoch (logged by the earlier job between its last checkpoint and its end) go."""
     os.makedirs(dir, exist_ok=True)
     _state['dir'] = dir
     _state['csv'] = None
     _state['keys'] = []
+    path = os.path.join(dir, 'progress.csv')
+    if resume_epoch is not None and os.path.exists(path):
+        with open(path, newline='') as f:
+            reader = csv.DictReader(f)
+            keys = list(reader.fieldnames or [])
+            rows = [r for r in reader if int(float(r.get('epoch', -1))) <= resume_epoch]
+        if keys:
+            _state['keys'] = keys
+            with open(path, 'w', newline='') as f:
+                w = csv.DictWriter(f, keys)
+                w.writeheader()
+                w.writerows(rows)
 
 
 def get_dir():

@@ -307,7 +307,7 @@ def test_eight_rows_per_workgroup_change_no_bit(V, graph):
     from curious_amd import ops
     outs = []
     for rows8 in (0, 1):
-        with ops.option('rows8', rows8):
+        with ops.option('rows8', rows8), ops.option('rows16', 0):    # (the 16-row form has its own test: test_gpu_round6)
             agent = make_agent(V, use_graph=graph)
             draw = rank_episodes(V, 12)
             agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
