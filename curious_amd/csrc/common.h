@@ -99,6 +99,9 @@ struct CuriousOptions {
                        //    0: always 4 (A/B)                                                       [CURIOUS_ROWS8]
   int rows16;          // > 0: from this many batch rows on the row-local update gives 16 rows to a workgroup, the waves
                        //    splitting the output columns on v_mfma_f32_16x16x4 (mlp_rows16.h); 0: never (A/B)   [CURIOUS_ROWS16]
+  int dw64;            // > 0 (A/B; default 0 = never): from this many batch rows on the hidden matrices' weight gradients are 64 x 64
+                       //    tiles staged through LDS, 8 workgroups per tile (mlp_dw.h dw_hot_tile64) -- built and measured in round
+                       //    6, no faster than the 16 x 64 tiles (19 ranks: 53.9 against 51.0 us), DESIGN 4.7          [CURIOUS_DW64]
   int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h
                        //    DwSplit; batches of >= 1 024 rows); 10 S_hot + S_small: fixed (A/B)       [CURIOUS_DW_SPLIT]
   int lab_rows_stamps; // LAB ONLY (tools/rows_stamps.py): every row group of ddpg_rows_kernel writes its phase stamps into the workspace

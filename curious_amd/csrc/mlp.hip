@@ -111,6 +111,7 @@ struct Ws {   // workspace carve-up
   float* wT[2][MAX_LAYERS];    // transposed copies of the hidden matrices of main critic / main actor (mlp_rows.h)
   int32_t* fault;              // fault word (mlp_rows.h): consumers of Q' that gave up; sticky until the host clears it.
                                // wT and fault are the ONLY parts of the workspace that carry state between calls
+  float* split64;              // ... of the 64 x 64 tiles (mlp_dw.h dw_hot_tile64)
   float* split;                // batches of >= DW_SPLIT_MIN_B rows: partial tiles of the split weight-gradient reduction
   int32_t* split_cnt;          // (mlp_dw.h DwSplit) and their ticket counters -- zero between launches
   int64_t total;
@@ -144,6 +145,7 @@ static Ws carve(const curious_net_cfg_t* c, int32_t B, float* base) {
   w.fault = reinterpret_cast<int32_t*>(take(64));
   const bool split = B >= DW_SPLIT_MIN_B;
   w.split = split ? take((int64_t)DW_SPLIT_TILES * DW_SPLIT_MAX * DW_PART) : nullptr;
+  w.split64 = split ? take((int64_t)64 * DW_SPLIT_MAX * DW_PART64) : nullptr;     // 4 hidden matrices x 16 tiles of 64 x 64
   w.split_cnt = split ? reinterpret_cast<int32_t*>(take(DW_SPLIT_TILES)) : nullptr;
   w.total = off;
   return w;

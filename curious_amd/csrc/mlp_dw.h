@@ -227,6 +227,217 @@ __device__ DW_INLINE void dw_hot_tile(const GemmHot& P, const AdamFuse& A, const
 }
 
 
+// ---- 64 x 64 tiles of the hidden matrices for batches of many chunks (round 6; option dw64).
+// The 16 x 64 tile above reads, per 4 batch rows and wave, 64 B of X four times (half cache lines) and 256 B of dY four times for
+// 4 matrix instructions; its four waves split the ROWS, so nothing is shared: 12 cache lines through the CU's one texture
+// path per 128 matrix cycles and wave -- the path is busy 75 % of the time with ONE workgroup on the CU (measured: 5.4 k
+// cycles per chunk of 256 rows against 2.0 k of matrix time, 34 % SQ_VALU_MFMA_BUSY), and a second workgroup per CU makes the launch slower, not
+// faster (option dw_split, 51 -> 55 us at 19 ranks).  Here a workgroup owns 64 x 64 of dW = X^T dY for a SEGMENT of the batch
+// rows (DwSplit: S = up to 8 segments per tile, 64 tiles per launch x S = 512 workgroups; the ticket reduction adds the
+// partial tiles in segment order): chunks of 32 rows of X[., 64] and dY[., 64] travel global -> registers -> LDS once per
+// workgroup (two chunks in flight, two LDS stages, one barrier per chunk), wave (wr, wc) multiplies the 32 x 32 quadrant
+// out of LDS: per 4 rows one ds_read_b64 of X and one of dY feed 4 x v_mfma_f32_16x16x4 (rows k' = 2 j + r, columns
+// n = 2 j + c of the quadrant: a lane's operands of both 16-wide halves are neighbours).  Texture traffic per matrix
+// instruction falls by 2.5 (full lines, each fetched once per workgroup), the LDS serves 32 B / clk per workgroup.
+// The finished tile goes through LDS into the layout of four 16 x 64 strips, whose epilogue (store, Adam, transposed copy,
+// bias column) is the one above.
+#define DW64_LD 96                                           // LDS row stride (floats): 96 mod 64 = 32 -> the two 4-row halves of a
+                                                             // ds_read_b64 lane group fall on different banks
+#define DW64_ROWS 32                                         // batch rows per chunk
+#define DW64_STAGE (2 * DW64_ROWS * DW64_LD)                 // floats per stage: X chunk | dY chunk
+#ifndef DW64_PAD
+#define DW64_PAD 0
+#endif
+#define DW64_LDS (2 * DW64_STAGE + DW64_PAD)                 // 48 KB (+ lab padding: workgroups per CU)
+#define DW64_TLD 68                                          // row stride of the finished tile in LDS
+#define DW_PART64 (64 * 64 + 64)                             // floats of a partial 64 x 64 tile + its 64 column sums
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool ADAM>
+__device__ DW_INLINE void dw_hot_tile64(const GemmHot& P, const AdamFuse& A, const int t, float* lds, const int64_t eo,
+                                        const int64_t eg, const AdamEarly* given, float* pbuf64, int32_t* cnt,
+                                        const int gt, const DwSeg sg) {
+  const int S = sg.S, seg = sg.seg;
+  int m_lo = 0, m_hi = P.M;
+  if (S > 1) {
+    // segments in units of 64 rows (two chunks), not of 256 like the 16 x 64 tiles': 19 ranks are 76 units = 9 or 10 per
+    // segment (in units of 256 rows: 2 or 3 -- the segments of 3 took 1.5 x as long as the others and the launch waited)
+    const int U = P.M >> 6;
+    m_lo = ((seg * U) / S) << 6;
+    m_hi = (((seg + 1) * U) / S) << 6;
+  }
+  const int by = t >> 2, bx = t & 3;                          // 4 x 4 tiles of a 256 x 256 matrix
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int k0 = by * 64, n0 = bx * 64;
+  AdamEarly early;
+  if (ADAM) early = given ? *given : adam_early(A, eo);
+  // staging: thread tid carries rows (tid >> 4) and 16 + (tid >> 4) of a chunk, columns 4 (tid & 15) .. + 3
+  // (uniform base + 32-bit lane offset, ld4_su: the row part of an address is scalar work and no vector register is written
+  //  on the way to a load -- with per-lane 64-bit pointers hipcc computed them INTO the destination registers and waited
+  //  vmcnt(0) in front of every fetch for the loads it thought might still be writing them)
+  const float* xu = P.A + eo + k0;
+  const float* yu = P.B + eo + n0;
+  const uint32_t xo = (uint32_t)((tid >> 4) * P.lda + 4 * (tid & 15)) * 4u;
+  const uint32_t yo = (uint32_t)((tid >> 4) * P.ldb + 4 * (tid & 15)) * 4u;
+  const int so = (tid >> 4) * DW64_LD + 4 * (tid & 15);
+  f32x4 sx[2][2], sy[2][2];                                   // [chunk in flight][half]
+  auto fetch = [&](const int m, f32x4 (&x)[2], f32x4 (&y)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#ifdef DW64_NO_LOADS        // (lab: ... without its loads: the same rows again and again)
+      x[h] = ld4_su(xu + (int64_t)(m_lo + 16 * h) * P.lda, xo);
+      y[h] = ld4_su(yu + (int64_t)(m_lo + 16 * h) * P.ldb, yo);
+#else
+      x[h] = ld4_su(xu + (int64_t)(m + 16 * h) * P.lda, xo);
+      y[h] = ld4_su(yu + (int64_t)(m + 16 * h) * P.ldb, yo);
+#endif
+    }
+  };
+  auto stage = [&](float* st, const f32x4 (&x)[2], const f32x4 (&y)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(st + so + 16 * h * DW64_LD) = x[h];
+      *reinterpret_cast<f32x4*>(st + DW64_ROWS * DW64_LD + so + 16 * h * DW64_LD) = y[h];
+    }
+  };
+  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+  float bs = 0.f;                                             // column sums of dY (tiles of the first tile row): column tid & 63,
+  const bool bias = by == 0;                                  // rows 8 (tid >> 6) .. + 7 of every chunk
+  const int ao = q * DW64_LD + 32 * wr + 2 * j, bo = DW64_ROWS * DW64_LD + q * DW64_LD + 32 * wc + 2 * j;
+  auto chunk_mac = [&](const float* st) {
+#pragma unroll
+    for (int s4 = 0; s4 < DW64_ROWS / 4; ++s4) {
+      const f32x2 a2 = *reinterpret_cast<const f32x2*>(st + ao + 4 * s4 * DW64_LD);
+      const f32x2 b2 = *reinterpret_cast<const f32x2*>(st + bo + 4 * s4 * DW64_LD);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#ifdef DW64_NO_MFMA         // (lab: what the tile costs without its matrix instructions)
+        acc[r][c][0] += a2[r] * b2[c];
+#else
+        acc[r][c] = MFMA(a2[r], b2[c], acc[r][c]);
+#endif
+      }
+    }
+    if (bias) {
+      const float* yb = st + DW64_ROWS * DW64_LD + 8 * (tid >> 6) * DW64_LD + (tid & 63);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) bs += yb[r * DW64_LD];
+    }
+  };
+  // pipeline: chunk c is multiplied out of stage c & 1 while chunk c + 1 waits in registers for its turn to be written to
+  // the other stage (behind the products: the barrier at the end of the previous half has freed it) and chunk c + 2 is on
+  // its way from memory.  Branch-free (a segment is a multiple of 256 rows: an even number of chunks; behind the last
+  // chunks the last one is fetched and staged once more, unused): a branch around a fetch makes the number of loads in
+  // flight depend on the path, and the waits in front of the stores to LDS become vmcnt(0) (dw_hot_tile).
+  const int nch = (m_hi - m_lo) / DW64_ROWS;
+  const int last = m_lo + (nch - 1) * DW64_ROWS;
+  fetch(m_lo, sx[0], sy[0]);
+  fetch(min(m_lo + DW64_ROWS, last), sx[1], sy[1]);
+  stage(lds, sx[0], sy[0]);
+  __syncthreads();
+  for (int m = m_lo; m < m_hi; m += 2 * DW64_ROWS) {
+    fetch(min(m + 2 * DW64_ROWS, last), sx[0], sy[0]);         // registers: [1] = chunk c + 1, [0] <- chunk c + 2
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mac(lds);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(lds + DW64_STAGE, sx[1], sy[1]);
+    __syncthreads();
+    fetch(min(m + 3 * DW64_ROWS, last), sx[1], sy[1]);         // registers: [0] = chunk c + 2, [1] <- chunk c + 3
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mac(lds + DW64_STAGE);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(lds, sx[0], sy[0]);
+    __syncthreads();
+  }
+  float aQ = 0.f, aPi = 0.f;
+  bool faulted = false;
+  if (ADAM) {
+    adam_alphas_late(A, early, aQ, aPi, eo);
+    faulted = adam_early_faulted(A, early);
+  }
+  // ---- the quadrants -> LDS tile T[64][DW64_TLD]; thread tid then owns row 16 s + (tid >> 4), columns 4 (tid & 15) .. of
+  // strip s = 0 .. 3 (the ownership of the 16 x 64 tile's epilogue)
+  float* T = lds;
+  float* bred = lds + 64 * DW64_TLD;                          // [4][64] partial column sums
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 v2 = {acc[r][0][i], acc[r][1][i]};
+      *reinterpret_cast<f32x2*>(T + (32 * wr + 2 * (4 * q + i) + r) * DW64_TLD + 32 * wc + 2 * j) = v2;
+    }
+  if (bias) bred[(tid >> 6) * 64 + (tid & 63)] = bs;
+  __syncthreads();
+  f32x4 v[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) v[s4] = *reinterpret_cast<const f32x4*>(T + (16 * s4 + (tid >> 4)) * DW64_TLD + 4 * (tid & 15));
+  float gb = 0.f;
+  if (bias && tid < 64) gb = (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]);
+  if (S > 1) {
+    // split reduction (dw_split_combine for a 64 x 64 partial tile)
+    __syncthreads();                                          // (T is read: `flag` below reuses the LDS)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pbuf64 + (int64_t)gt * S * DW_PART64, 0, 0x7fffffff,
+                                                                        0x00020000);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dw_u32x4, v[s4]), rs, (seg * DW_PART64 + 1024 * s4 + 4 * tid) * 4, 0, DW_SC1);
+    if (tid < 64) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, gb), rs, (seg * DW_PART64 + 4096 + tid) * 4, 0, DW_SC1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(cnt + gt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == S - 1;
+      if (last) __hip_atomic_store(cnt + gt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) v[s4] = zero4();
+    gb = 0.f;
+    for (int k = 0; k < S; ++k) {                             // (segment order: whoever is last adds the same way)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        v[s4] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (k * DW_PART64 + 1024 * s4 + 4 * tid) * 4, 0, DW_SC1));
+      if (tid < 64) gb += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (k * DW_PART64 + 4096 + tid) * 4, 0, DW_SC1));
+    }
+  }
+  // ---- epilogue of the four strips: gradient store, optimiser, transposed copy (dw_hot_tile)
+  AdamPre4 pre[4];
+  int64_t pidx[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int64_t toff = (int64_t)(k0 + 16 * s4 + (tid >> 4)) * P.ldc + n0 + 4 * (tid & 15);
+    pidx[s4] = ADAM ? (int64_t)(P.C - A.grad) + toff : 0;
+    if (ADAM) pre[s4] = adam_prefetch4(A, pidx[s4] + eo);
+    *reinterpret_cast<f32x4*>(P.C + eg + toff) = v[s4];
+  }
+  const int64_t bidx = ADAM ? (int64_t)(P.aux_out + n0 + (tid & 63) - A.grad) : 0;
+  float bm = 0.f, bv = 0.f, bth = 0.f;
+  if (ADAM && bias && tid < 64) { bm = A.m[bidx + eo]; bv = A.v[bidx + eo]; bth = A.theta[bidx + eo]; }
+  if (ADAM && !faulted) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      adam_apply4(A, (pidx[s4] < A.n_Q) ? -aQ : -aPi, pidx[s4] + eo, v[s4], pre[s4]);
+      if (P.dot_out) {                                        // WT[n][k] = W[k][n] (mlp_rows.h)
+        float* tp = P.dot_out + eo + (int64_t)(n0 + 4 * (tid & 15)) * P.K + k0 + 16 * s4 + (tid >> 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tp[(int64_t)e * P.K] = pre[s4].th[e];
+      }
+    }
+  }
+  if (bias && tid < 64) {
+    P.aux_out[eg + n0 + tid] = gb;
+    if (ADAM && !faulted) {
+      const float th = adam_elem(A, (bidx < A.n_Q) ? -aQ : -aPi, gb, bm, bv, bth);
+      A.m[bidx + eo] = bm; A.v[bidx + eo] = bv; A.theta[bidx + eo] = th;
+    }
+  }
+}
+
 // Small weight gradients (layer-0 segments, output layers) on a compact tile list + the loss finalisation.
 //   dW[w,N] = (X[M,w] / div)^T . dY[M,N];  db[N] = colsum(dY)         M % 256 == 0, X and dY plain row matrices
 struct DwSmall {
@@ -471,7 +682,10 @@ __device__ inline void dw_loss_fin(const LossFin& F, float* red, const int64_t e
 // costs a full ~3 k-cycle (1.4 us) round trip (tools/dw_stamps.py: a block that finds it has nothing to do used to need
 // 3 k cycles to find out; a hidden tile issued its operand loads 6 k cycles after its start, a small tile 10-12 k).
 struct DwMap { int32_t r_her, r_hot, units; };                // units == 0: plain block order
-struct DwAllArgs { DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; DwSplit split; };
+struct DwAllArgs {
+  DwHotArgs hot; DwSmallArgs small; int32_t n_hot; unsigned long long* stamps; DwSplit split;
+  float* pbuf64;                  // non-NULL: the hidden matrices as 64 x 64 tiles (dw_hot_tile64; tiles_per = 16), their partial tiles here
+};
 // lab (a build with -DDW_STAMPS, tools/build_variant.py, + option "lab_dw_stamps"): 8 x 64-bit words per block of expert 0 -- [0] entry, [1] operand loads issued /
 // gather: tables in, [2] MFMA loop over / gather: rows in LDS, [3] exit, [4] kind (0 gather, 1 hidden tile, 2 small),
 // [5] s_memrealtime at entry (100 MHz, device-wide)
@@ -556,7 +770,7 @@ __device__ __forceinline__ void pin_adam(const AdamFuse& A) {
 #define DW_ROUTE_PARAMS const int tiles_per, const int hot_nprob, const int slots, const int small_nprob, const int n_her, \
                         const int r_her, const int r_hot, const int units   /* units | S_hot << 8 | S_small << 16: dw_role */
 // the tile work of a block whose role is known: ONE batch of argument loads, then the tile
-template <bool ADAM, bool PIPE>
+template <bool ADAM, bool PIPE, bool T64 = false>
 __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& args, const AdamFuse& A_, const int slots,
                                              const int small_nprob, float* red, const int64_t eo, int64_t grad_stride,
                                              DwStamp* sp, const AdamEarly* early) {
@@ -567,6 +781,13 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
     if (ADAM) pin_adam(A);
     asm volatile("" :: "s"(grad_stride));
     DW_STAMP(sp, 3);
+    if constexpr (T64) {
+      {
+        dw_hot_tile64<ADAM>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, early, args.pbuf64, args.split.cnt,
+                            R.pi * args.hot.tiles_per + R.idx, DwSeg{R.seg, R.S});
+        return;
+      }
+    }
     dw_hot_tile<ADAM, PIPE>(P, A, R.idx, red, eo, (int64_t)blockIdx.y * grad_stride, sp, early, &args.split,
                                 R.pi * args.hot.tiles_per + R.idx, DwSeg{R.seg, R.S});
     return;
@@ -577,6 +798,9 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
     if (pi == small_nprob && t == 0 && R.seg == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
     return;
   }
+#ifdef DW_NO_SMALL            // (lab: the launch without its small tiles)
+  return;
+#endif
   DwSmall P = args.small.p[pi];
   int M = args.small.M;
   pin_small(P);
@@ -591,15 +815,15 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   else dw_small_tile<ADAM, true, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
 }
 
-template <bool PIPE>
+template <bool PIPE, bool T64 = false>
 __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
                                                      int64_t grad_stride) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float red[T64 ? DW64_LDS : 4 * 16 * 64];
   AdamFuse none;
   none.fault = nullptr;
   const int64_t eo = (int64_t)blockIdx.y * ex_stride;
   const DwRole R = dw_role(hot_nprob * tiles_per, tiles_per, hot_nprob, slots, 0, r_her, r_hot, units);
-  if (R.kind > 0) dw_tile_role<false, PIPE>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
+  if (R.kind > 0) dw_tile_role<false, PIPE, T64>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
 }
 
 // The tail of a whole single-rank update in one launch (curious_ddpg_update): every weight/bias gradient with Adam
@@ -608,11 +832,11 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
-template <bool PIPE>
+template <bool PIPE, bool T64 = false>
 __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
                                                           int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
                                                           int64_t grad_stride, uint64_t seed_stride) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float red[T64 ? DW64_LDS : 4 * 16 * 64];
 #ifdef DW_STAMPS
   DwStamp stamp;
   stamp.t[0] = __builtin_readcyclecounter();                 // (before anything of the arguments is read)
@@ -637,7 +861,7 @@ __global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const
       const int64_t c = *ex_i64(ctr0, eo);
       early.lo = (int32_t)c; early.hi = (int32_t)(c >> 32);
     }
-    dw_tile_role<true, PIPE>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
+    dw_tile_role<true, PIPE, T64>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
   }
 #ifdef DW_STAMPS
   unsigned long long* st = dw_stamp_base(args);

@@ -155,7 +155,9 @@ int DdpgPass::rows_pass(bool refresh, bool maintained) {
   // 16 rows per workgroup, waves splitting the output columns on v_mfma_f32_16x16x4 (mlp_rows16.h), once the chip is full
   // several times over: the weight stream per row halves again and the matrix unit, not the texture path, bounds a layer.
   // Another order of summation over k than the 4- / 8-row forms (parity against the oracle, not their bits)
-  if (curious_options().rows16 > 0 && (int64_t)B * xd.nex >= curious_options().rows16 && B % (4 * ROWS_R3) == 0)
+  // (single agent only: a bank of batched experts promises the bits of its experts updated one by one, and those -- 256 rows
+  //  each -- take the 4-row form: test_batched_experts_random_banks)
+  if (curious_options().rows16 > 0 && xd.nex == 1 && B >= curious_options().rows16 && B % (4 * ROWS_R3) == 0)
     ra_R = ROWS_R3;
   // The XCD map gives every actor-side group -- the longest chain -- a CU of XCDs 0-3 for itself; with more row groups than
   // those 128 CUs some of them hold two and the launch ends with those: in plain order (actor side first, then target, then

@@ -16,6 +16,10 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   const bool has_pad = pi_offset(cfg) > offQ.total;
   fin.fault = (tail || !has_pad) ? nullptr : w.fault;
   fin.flag = (tail || !has_pad) ? nullptr : grad + pi_offset(cfg) - 1;
+  // the hidden matrices as 64 x 64 tiles staged through LDS (mlp_dw.h dw_hot_tile64), each reduced by up to 8 workgroups:
+  // batches of >= `dw64` rows of a single agent (the split reduction sums in another order than the 16 x 64 tiles)
+  const bool t64 = dw_hot && curious_options().dw64 > 0 && B >= curious_options().dw64 && xd.nex == 1 && H == 256 &&
+                   w.split64 != nullptr;
   auto build_net = [&](bool critic, DwHotArgs& hw, int& tiles, DwSmallArgs& sm, int& stiles) -> bool {
     int nh = hw.nprob, ns_ = sm.nprob;                              // append to what the other network queued
     bool ok = true;
@@ -37,7 +41,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       p.A = w.act[chain][l - 1]; p.lda = H; p.B = dact[l]; p.ldb = H; p.C = g + off.W[l]; p.ldc = H;
       p.aux_out = g + off.b[l]; p.M = B; p.N = H; p.K = H;
       p.dot_out = copies_kept ? w.wT[critic ? 0 : 1][l] : nullptr;
-      tiles += (H / 16) * (H / 64);
+      tiles += t64 ? (H / 64) * (H / 64) : (H / 16) * (H / 64);
       ++nh;
     }
     hw.nprob = nh;
@@ -82,7 +86,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
   if (lean_dw) {
     smAll.fin = fin;
     dwAll.n_hot = tAll;
-    hwAll.tiles_per = (H / 16) * (H / 64);
+    hwAll.tiles_per = t64 ? (H / 64) * (H / 64) : (H / 16) * (H / 64);
     smAll.slots = stAll > 0 ? stAll : 1;
     const int nsmall = smAll.nprob * smAll.slots;           // + 1 block for the loss finalisation
     // XCD-aware placement of the launch's blocks (mlp_lean_gemm.h DwMap; option "dw_xcd"): applies when the hidden
@@ -91,7 +95,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     memset(&map, 0, sizeof(map));
     auto dw_grid = [&](int n_her, int S_hot = 1, int S_small = 1) -> int {
       const int np = hwAll.nprob;
-      if (curious_options().dw_xcd && (np == 2 || np == 4) && hwAll.tiles_per == 64) {
+      if (curious_options().dw_xcd && (np == 2 || np == 4) && (hwAll.tiles_per == 64 || hwAll.tiles_per == 16)) {
         map.units = 8 / np;
         map.r_hot = hwAll.tiles_per / map.units;
         map.r_her = (n_her + 7) / 8;
@@ -111,10 +115,12 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       const int C = B / 256, opt = curious_options().dw_split;
       S_small = std::min(4, C / 2);
       if (opt > 0) { S_hot = opt / 10; S_small = opt % 10; }
+      if (t64) S_hot = DW_SPLIT_MAX;                          // 64 tiles x 8 = 512 workgroups
       S_hot = std::max(1, std::min(S_hot, std::min(DW_SPLIT_MAX, C)));
       S_small = std::max(1, std::min(S_small, std::min(DW_SPLIT_MAX, C)));
     }
     dwAll.split.pbuf = w.split; dwAll.split.cnt = w.split_cnt;
+    dwAll.pbuf64 = t64 ? w.split64 : nullptr;
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       const int gx = dw_grid(n_her, S_hot, S_small);
@@ -126,11 +132,12 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
         const int32_t* fault0 = af.fault ? af.fault : reinterpret_cast<const int32_t*>(af.theta);
         const int64_t* ctr0 = af.alpha_tab ? af.step_ctr : reinterpret_cast<const int64_t*>(af.theta);
         // batches of several chunks of 256 rows (virtual ranks): the pipelined form of the tiles (mlp_dw.h PIPE)
-#define DW_LAUNCH(PIPE)                                                                                        \
-  hipLaunchKernelGGL((dw_adam_her_kernel<PIPE>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,          \
+#define DW_LAUNCH(...)                                                                                         \
+  hipLaunchKernelGGL((dw_adam_her_kernel<__VA_ARGS__>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,   \
                      hwAll.nprob, smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, units_s, fault0, ctr0, \
                      (int64_t)xd.stride, dwAll, tail->adam, tail->h, (int64_t)xd.gstride, seed_stride)
         if (B <= 256) DW_LAUNCH(false);
+        else if (dwAll.pbuf64) DW_LAUNCH(true, true);
         else DW_LAUNCH(true);
 #undef DW_LAUNCH
       }
@@ -145,6 +152,10 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       const int units_s = map.units | (S_hot << 8) | (S_small << 16);
       if (B <= 256)
         hipLaunchKernelGGL(dw_all_kernel<false>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
+                           smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, units_s, (int64_t)xd.stride, dwAll,
+                           (int64_t)xd.gstride);
+      else if (dwAll.pbuf64)
+        hipLaunchKernelGGL((dw_all_kernel<true, true>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
                            smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, units_s, (int64_t)xd.stride, dwAll,
                            (int64_t)xd.gstride);
       else

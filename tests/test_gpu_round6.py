@@ -56,3 +56,38 @@ def test_sixteen_rows_against_the_eight_row_form(V):
     assert dev.max() <= 5e-4 and (dev > 2e-6).mean() <= 1e-3, (dev.max(), (dev > 2e-6).mean())
     assert np.isfinite(b[5]).all() and np.abs(a[4] - b[4]).max() <= 2e-2   # 16 Adam steps of 1e-3 apart at the very most
     assert (np.abs(a[4] - b[4]) > 1e-4).mean() < 1e-2
+
+
+@pytest.mark.parametrize('V,graph', [(5, 0), (8, 1), (19, 1)])
+def test_weight_gradients_as_64x64_tiles(V, graph):
+    """Option dw64 = N (csrc/mlp_dw.h dw_hot_tile64; off by default -- measured no faster than the 16 x 64 tiles):
+    from N batch rows on the hidden matrices' weight gradients are 64 x 64 tiles staged through LDS, every tile summed by up to 8 workgroups over segments of the rows (ticket reduction: partial
+    tiles added in segment order).  Against the 16 x 64 tiles: same batches, gradients (m after the first Adam step = 0.1 x
+    the summed gradient, util.py:49-53 / mpi_adam.py:31) within 2e-6 of their max-norm -- another order of the sum over the
+    rows and nothing else --, transposed copies of the updated matrices kept current (the next update's backward layers
+    read them); and a run reproduces itself bit for bit whichever workgroup draws a tile's last ticket."""
+    from curious_amd import ops
+    from test_gpu_round5 import make_agent, rank_episodes
+    outs = []
+    for dw64 in (0, 1280, 1280):
+        with ops.option('dw64', dw64):
+            agent = make_agent(V, use_graph=bool(graph))
+            draw = rank_episodes(V, 12)
+            agent.store_episode(draw(), np.array([0.3, 0.0, 0.2, 0.1]), 12 * V)
+            agent.train()
+            torch.cuda.synchronize()
+            first = [t.cpu().numpy().copy() for t in (agent._m, agent._losses, agent.grad)]
+            agent.train_batches(11)
+            agent.update_target_net()
+            agent.train_batches(4)
+            torch.cuda.synchronize()
+            agent.check_faults(wait=True)
+            outs.append(first + [agent.theta.cpu().numpy().copy(), agent._m.cpu().numpy().copy()])
+    a, b, c = outs
+    np.testing.assert_array_equal(a[1], b[1])                        # the losses do not depend on the tiles
+    for x, y in ((a[0], b[0]), (a[2], b[2])):
+        dev = np.abs(x - y) / np.abs(x).max()
+        assert dev.max() <= 2e-6, dev.max()
+    assert (np.abs(a[3] - b[3]) > 1e-4).mean() < 1e-2 and np.abs(a[3] - b[3]).max() <= 2e-2
+    for x, y in zip(b, c):                                           # bit for bit from run to run
+        np.testing.assert_array_equal(x, y)
