@@ -161,7 +161,7 @@ def worker_state(w):
         st['p'] = np.asarray(w.p).copy()
         st['queues'] = [(list(q.successes), q.C, q.CP) for q in w.competence_computers]
         st['task_history'] = list(w.task_history)
-        st['n_goal_history'] = len(w.goal_history)
+        st['goal_history'] = [list(g) if isinstance(g, (list, tuple)) else g for g in w.goal_history]
     if hasattr(w, 'goal_selectors'):                                 # SAGG-RIAC (plain Python objects)
         st['goal_selectors'] = w.goal_selectors
         st['split_histories'] = [list(h) for h in w.split_histories]
@@ -184,6 +184,8 @@ def load_worker_state(w, st):
             q.C, q.CP = C, CP
         w.task_history.clear()
         w.task_history.extend(st['task_history'])
+        w.goal_history.clear()
+        w.goal_history.extend(st.get('goal_history', []))
     if 'goal_selectors' in st:
         w.goal_selectors = st['goal_selectors']
         for h, saved in zip(w.split_histories, st['split_histories']):

@@ -294,10 +294,25 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     world = dist.world_size()
     V, base, total = 1, rank, world
     if num_cpu > world:
+        # what virtual ranks need (DDPG.__init__, RolloutWorker.__init__).  The EFFECTIVE rng mode: DDPG's own default is
+        # 'numpy' -- 'device' is the default of the command line only (main() below), a programmatic launch has to name it.
+        # Not met: an error.  Fewer ranks than asked for is another job (readme.md:16: "fewer cpus for a longer time is NOT
+        # equivalent"), and round 5 ran it behind a warning.
         over = dict(override_params or {})
-        ok = (structure == 'curious' and over.get('rng_mode', 'device') == 'device' and 'buffer' in task_replay)
-        if ok:
-            V, base, total = dist.virtual_layout(num_cpu)
+        missing = []
+        if structure not in ('curious', 'task_experts'):
+            missing.append("structure 'curious' or 'task_experts' (is %r)" % structure)
+        if structure == 'task_experts' and over.get('experts_update', 'sequential') != 'batched':
+            missing.append("experts_update 'batched' for task_experts")
+        if over.get('rng_mode', 'numpy') != 'device':
+            missing.append("override_params['rng_mode'] = 'device' (is %r)" % over.get('rng_mode', 'numpy'))
+        if 'buffer' not in task_replay:
+            missing.append("per-task buffers (task_replay %r)" % task_replay)
+        if missing:
+            raise ValueError('--num_cpu %d on %d process(es) means %d ranks per process (virtual ranks), which need: %s.  '
+                             'Start %d processes (torch.distributed.run) or pass --num_cpu %d'
+                             % (num_cpu, world, -(-num_cpu // world), '; '.join(missing), num_cpu, world))
+        V, base, total = dist.virtual_layout(num_cpu)
     # (a process that stands for ONE rank of an uneven layout runs the single-rank agent: nothing of its own needs V)
     rank_seed = seed + 1000000 * base                                 # train.py:242-243 (of this process's first rank)
     np.random.seed(rank_seed)
@@ -336,8 +351,8 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
         logger.info('--num_cpu %d on %d process(es): %d virtual ranks on this GPU, global ranks %d..%d of %d' %
                     (num_cpu, world, V, base, base + V - 1, total))
     elif num_cpu != world:
-        logger.warn('--num_cpu %d differs from WORLD_SIZE %d; ranks are created by torch.distributed.run (virtual ranks '
-                    "need structure='curious', device RNG and per-task buffers)" % (num_cpu, world))
+        logger.warn('--num_cpu %d differs from WORLD_SIZE %d: the ranks are the %d processes torch.distributed.run created'
+                    % (num_cpu, world, world))
 
     dims = config.configure_dims(params)
     buffers = config.configure_buffer(dims=dims, params=params)
