@@ -51,6 +51,10 @@ def parse():
                     help="diagnostic: V of the reference's MPI ranks per GPU (readme.md:16: the published runs use 19): V "
                          'private buffer sets / seeds / rollout groups, every update = V minibatches of 256 in one launch '
                          'sequence, gradients summed over them (mpi_adam.py:26-28) -- the regime cpu_baseline.ranks times')
+    ap.add_argument('--num-cpu', type=int, default=0,
+                    help="the reference's --num_cpu R laid out over the --gpus processes exactly as experiment.train lays it "
+                         'out (dist.virtual_layout: R // N ranks per process, one more on the first R %% N -- 19 on 8 GPUs = '
+                         '3 3 3 2 2 2 2 2): `--gpus 8 --num-cpu 19` is the published job (readme.md:16) on one node')
     ap.add_argument('--structure', default='curious', choices=['curious', 'task_experts'],
                     help="diagnostic: 'task_experts' = BASELINE configs[4], every expert updated in one batched launch "
                          "sequence per update (curious_ddpg_update_experts)")
@@ -61,8 +65,12 @@ def parse():
     ap.add_argument('--no-ipc-probe', action='store_true',
                     help='several ranks: skip the side measurement of the fused IPC all-reduce + Adam path')
     args = ap.parse_args()
+    if args.num_cpu and args.virtual_ranks > 1:
+        ap.error('--num-cpu R names the ranks of the whole job, --virtual-ranks V the ranks per GPU: give one of them')
+    if args.num_cpu and args.num_cpu < args.gpus:
+        ap.error('--num-cpu %d ranks on --gpus %d processes' % (args.num_cpu, args.gpus))
     if args.rollout_batch_size is None:
-        args.rollout_batch_size = 2 if args.virtual_ranks > 1 else B_R
+        args.rollout_batch_size = 2 if (args.virtual_ranks > 1 or args.num_cpu > args.gpus) else B_R
     return args
 
 
@@ -73,7 +81,7 @@ def maybe_relaunch(args):
         sys.exit(subprocess.call(cmd))
 
 
-def build_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1):
+def build_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1, rank_base=None, total_ranks=None):
     from curious_amd import dist, logger
     from curious_amd.experiment import config
     from curious_amd.rollout import RolloutWorker
@@ -83,6 +91,9 @@ def build_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1):
                   num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed, rollout_batch_size=b_r,
                   n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph,
                   async_store=os.environ.get('CURIOUS_ASYNC_STORE', '1') != '0', virtual_ranks=virtual_ranks)
+    base = dist.rank() * virtual_ranks if rank_base is None else rank_base
+    if rank_base is not None:                                     # an uneven layout (--num-cpu): experiment/train.py:268-270
+        params['rank_base'], params['total_ranks'] = rank_base, total_ranks
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = False
     params['ddpg_params']['seed'] = seed
@@ -94,13 +105,13 @@ def build_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1):
                            random_eps=params['random_eps'], structure='curious',
                            task_selection='active_competence_progress', goal_selection='random',
                            queue_length=params['queue_length'], eval=False)
-    worker.seed(seed + 1000000 * dist.rank() * virtual_ranks)
+    worker.seed(seed + 1000000 * base)
     if virtual_ranks > 1:
-        worker.seed_ranks([seed + 1000000 * (dist.rank() * virtual_ranks + v) for v in range(virtual_ranks)])
+        worker.seed_ranks([seed + 1000000 * (base + v) for v in range(virtual_ranks)])
     return params, dims, policy, worker
 
 
-def build_experts_job(use_graph, seed=0, env=None, b_r=B_R):
+def build_experts_job(use_graph, seed=0, env=None, b_r=B_R, virtual_ranks=1):
     """BASELINE configs[4]: one expert per task on shared per-task buffers (train.py:285-291), all updated together."""
     from curious_amd import dist, logger
     from curious_amd.experiment import config
@@ -110,7 +121,8 @@ def build_experts_job(use_graph, seed=0, env=None, b_r=B_R):
     params.update(env_name=env or ENV, task_selection='random', goal_selection='random',
                   task_replay='replay_current_task_buffer', goal_replay='her', structure='task_experts',
                   normalize_obs=False, num_cpu=dist.world_size(), clip_return=1, trial_id=0, seed=seed,
-                  rollout_batch_size=b_r, n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph)
+                  rollout_batch_size=b_r, n_batches=N_BATCHES, batch_size=BATCH, rng_mode='device', use_graph=use_graph,
+                  virtual_ranks=virtual_ranks)
     params = config.prepare_params(params)
     params['ddpg_params']['normalize_obs'] = False
     params['ddpg_params']['seed'] = seed
@@ -124,7 +136,9 @@ def build_experts_job(use_graph, seed=0, env=None, b_r=B_R):
                              goal_selection='random', queue_length=params['queue_length'], eval=False, unique_task=i)
                for i in range(params['nb_tasks'])]
     for i, w in enumerate(workers):
-        w.seed(seed + 1000000 * dist.rank() + i)
+        w.seed(seed + 1000000 * dist.rank() * virtual_ranks + i)
+        if virtual_ranks > 1:
+            w.seed_ranks([seed + 1000000 * (dist.rank() * virtual_ranks + v) + i for v in range(virtual_ranks)])
     return params, dims, bank, workers
 
 
@@ -698,7 +712,7 @@ def main():
     maybe_relaunch(args)
     # the CPU legs run first, before this process touches the GPU (rank 0 of a one-GPU run only)
     cpu = None
-    V = args.virtual_ranks
+    V = args.virtual_ranks if not (args.num_cpu and args.gpus == 1) else args.num_cpu
     if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
         n_ranks = min(19, os.cpu_count() or 1) if args.cpu_ranks < 0 else args.cpu_ranks
         if V > 1:
@@ -720,8 +734,14 @@ def main():
     np.random.seed(1234 + 1000000 * rank)                        # train.py:242
     b_r = args.rollout_batch_size
     experts = args.structure == 'task_experts'
+    # ranks of the job and of this process: V per process (--virtual-ranks), or --num-cpu R laid out like experiment.train does
+    R_total, layout, base = V * world, [V] * world, None
+    if args.num_cpu:
+        assert not experts, '--num-cpu: the curious structure (task_experts: --virtual-ranks)'
+        V, base, R_total = dist.virtual_layout(args.num_cpu)
+        layout = [int(x) for x in dist.allgather_object(V)]
     if experts:
-        params, dims, bank, workers = build_experts_job(use_graph=not args.no_graph, env=args.env, b_r=b_r)
+        params, dims, bank, workers = build_experts_job(use_graph=not args.no_graph, env=args.env, b_r=b_r, virtual_ranks=V)
         prefill(bank[0], args.prefill, seed=rank)                 # the buffers are shared by the experts
         counter = [0]
 
@@ -730,7 +750,8 @@ def main():
             counter[0] += 1
         policy, worker = bank[0], workers[0]
     else:
-        params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=b_r, virtual_ranks=V)
+        params, dims, policy, worker = build_job(use_graph=not args.no_graph, env=args.env, b_r=b_r, virtual_ranks=V,
+                                                 rank_base=base, total_ranks=R_total if base is not None else None)
         prefill(policy, args.prefill, seed=rank)
 
         def step():
@@ -791,38 +812,49 @@ def main():
 
     if rank == 0:
         T = params['T']
-        n_pol = len(bank) if experts else V                        # minibatches of BATCH rows per update
-        headline = (args.env == ENV and b_r == B_R and not experts and V == 1)
+        # minibatches of BATCH rows one update of the WHOLE job consumes: one per rank (and expert)
+        n_exp = len(bank) if experts else 1
+        mb_job = n_exp * R_total
+        n_pol = mb_job / world                                    # ... per process on average (an uneven --num-cpu layout)
+        Vmax = max(layout)
+        headline = (args.env == ENV and b_r == B_R and not experts and R_total == world)
         workload = ('%s, %d parallel rollouts x T=%d per GPU, HER future k=4, batch %d, %d updates per cycle, %d per-task '
                     'buffers' % (args.env, b_r * V, T, BATCH, N_BATCHES, policy.nb_tasks + 1))
         if headline:
             workload += ' (configs[1])'
-        elif V > 1:
-            workload = ('%s in the reference\'s published regime (readme.md:16, --num_cpu %d) as %d VIRTUAL RANKS per GPU: '
+        elif R_total > world and not experts:
+            per = ('%d VIRTUAL RANKS per GPU' % Vmax) if min(layout) == Vmax else \
+                ('virtual ranks, %s per GPU (dist.virtual_layout)' % ' '.join(str(x) for x in layout))
+            workload = ('%s in the reference\'s published regime (readme.md:16, --num_cpu %d) as %s: '
                         'per rank %d rollouts x T=%d, private per-task buffers and seeds, a minibatch of %d per update; '
-                        'every update consumes the %d minibatches in one launch sequence, gradients summed over them '
-                        '(mpi_adam.py:26-28), normaliser sums averaged (normalizer.py:84-94); %d updates per cycle '
+                        'every update consumes the minibatches of a GPU\'s ranks in one launch sequence, gradients summed '
+                        'over all %d (mpi_adam.py:26-28), normaliser sums averaged (normalizer.py:84-94); %d updates per cycle '
                         '(diagnostic, not the headline configuration)' %
-                        (args.env, V * world, V, b_r, T, BATCH, V, N_BATCHES))
+                        (args.env, R_total, per, b_r, T, BATCH, R_total, N_BATCHES))
         elif experts:
             workload += ('; structure=task_experts: %d experts, every update applies to all of them in one batched launch '
-                         'sequence (configs[4], diagnostic)' % n_pol)
+                         'sequence (configs[4], diagnostic)' % n_exp)
+            if V > 1:
+                workload += ('; %d virtual ranks per GPU: every expert\'s update sums the gradients of %d minibatches, one '
+                             'from each rank\'s buffer of its task (train.py:65-121, mpi_adam.py:26)' % (V, V))
         else:
             workload += ' (diagnostic, not the headline configuration)'
-        bpt = 47213.0 if (experts or V == 1) else 1034.0 + (47213.0 - 1034.0) / V
+        # the parameter side of an update (40 B / param) is spread over the minibatches ONE process puts through it
+        bpt = 47213.0 if Vmax == 1 else 1034.0 + (47213.0 - 1034.0) / (R_total / world)
         out = {
             'metric': 'HER-sampled gradient transitions/sec (+ env_steps_per_sec), %s cycle' % args.env,
-            'value': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed, 1),
+            'value': round(args.steps * N_BATCHES * BATCH * mb_job / elapsed, 1),
             'unit': 'transitions/s',
-            'env_steps_per_sec': round(args.steps * b_r * V * T * world / elapsed, 1),
-            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES * (n_pol if experts else 1) / elapsed, 1),
+            'env_steps_per_sec': round(args.steps * b_r * R_total * T / elapsed, 1),
+            'updates_per_sec_per_gpu': round(args.steps * N_BATCHES * n_exp / elapsed, 1),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'step': 'one cycle: rollout + store_episode + 100 x train() + update_target_net',
-                       'rollout_batch_size': b_r, 'batch_size': BATCH, 'n_batches': N_BATCHES, 'virtual_ranks': V,
+                       'rollout_batch_size': b_r, 'batch_size': BATCH, 'n_batches': N_BATCHES, 'virtual_ranks': Vmax,
+                       'ranks': R_total, 'ranks_per_process': layout,
                        'hipgraph': not args.no_graph, 'rng': 'device (Philox)',
                        'parallelism': 'dp%d' % world},
             'roofline': roof,
@@ -830,7 +862,7 @@ def main():
             # 40 B/param of an update spread over its 256 transitions -- over V x 256 with virtual ranks)
             'step_hbm': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS * world,
                          'bytes_per_transition': round(bpt, 1),
-                         'achieved': round(args.steps * N_BATCHES * BATCH * n_pol * world / elapsed * bpt / 1e9, 2),
+                         'achieved': round(args.steps * N_BATCHES * BATCH * mb_job / elapsed * bpt / 1e9, 2),
                          'frac': round(args.steps * N_BATCHES * BATCH * n_pol / elapsed * bpt / 1e9 / HBM_PEAK_GBS, 5)},
             'kernels': table,
         }

@@ -74,8 +74,8 @@ class DDPG(ActingMixin, StoringMixin, SamplingMixin, UpdateSchedulesMixin, RankS
         # out unevenly (dist.virtual_layout: --num_cpu 19 on 8 processes)
         self.rank_base = int(rank_base) if rank_base is not None else dist.rank() * self.V
         self.total_ranks = int(total_ranks) if total_ranks is not None else dist.world_size() * self.V
-        if self.V > 1 and not (rng_mode == 'device' and structure == 'curious'):
-            raise ValueError("virtual_ranks > 1 needs rng_mode='device' and structure='curious'")
+        if self.V > 1 and not (rng_mode == 'device' and structure in ('curious', 'task_experts')):
+            raise ValueError("virtual_ranks > 1 needs rng_mode='device' and structure 'curious' or 'task_experts'")
         self._Bt = self.V * int(batch_size)                          # rows of one update's joint batch
         # e.g. info, use_mpi: stored by store_args, pickled with the policy; names with a leading underscore are
         # construction hooks of this implementation (_alloc: slab allocator of curious_amd.experts.ExpertBank)

@@ -390,7 +390,11 @@ def launch(env, trial_id, n_epochs, num_cpu, seed, policy_save_interval, clip_re
     evaluator = RolloutWorker(params['make_env'], policy, dims, logger, **eval_params)
     evaluator.seed(rank_seed + 100)
     if V > 1:                                                         # every virtual rank's own host streams
-        rollout_worker.seed_ranks([seed + 1000000 * (base + v) for v in range(V)])
+        if structure == 'task_experts':                               # (+ i: train.py:296-297 seeds worker i with rank_seed + i)
+            for i, w in enumerate(rollout_worker):
+                w.seed_ranks([seed + 1000000 * (base + v) + i for v in range(V)])
+        else:
+            rollout_worker.seed_ranks([seed + 1000000 * (base + v) for v in range(V)])
         evaluator.seed_ranks([seed + 1000000 * (base + v) + 100 for v in range(V)])
 
     workers = (list(rollout_worker) if isinstance(rollout_worker, list) else [rollout_worker]) + [evaluator]

@@ -127,7 +127,7 @@ class ExpertBank:
         x0 = self.experts[0]
         S = x0.sample_transitions
         ops.ddpg_update_experts(x0.net_cfg, self.n, self.stride, self.grad_stride, SEED_STRIDE_SAMPLER, x0.theta,
-                                x0.theta_target, x0._pp[p], x0._layout, x0.batch_size, x0._workspace, x0.grad,
+                                x0.theta_target, x0._pp[p], x0._layout, x0._Bt, x0._workspace, x0.grad,
                                 x0._losses, x0._Q_pi, x0._m, x0._v, x0._step_ctr, x0._alpha_tab, x0._alpha_base,
                                 x0._pp[p ^ 1], x0._pool.storage, x0._pool.buf_stride, S.tasks,
                                 S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, params_unchanged=chained,
@@ -141,7 +141,7 @@ class ExpertBank:
         x0 = self.experts[0]
         S = x0.sample_transitions
         ops.ddpg_grads_experts(x0.net_cfg, self.n, self.stride, self.grad_stride, x0.theta, x0.theta_target, x0._pp[p],
-                               x0._layout, x0.batch_size, x0._workspace, x0.grad, x0._losses, x0._Q_pi, x0._step_ctr,
+                               x0._layout, x0._Bt, x0._workspace, x0.grad, x0._losses, x0._Q_pi, x0._step_ctr,
                                params_unchanged=chained, seed_stride=SEED_STRIDE_SAMPLER, next_batch=x0._pp[p ^ 1],
                                storage=x0._pool.storage, buf_stride=x0._pool.buf_stride, tasks=S.tasks,
                                params=S.params(x0.clip_obs, x0.relative_goals), rng=x0._rng_desc,
@@ -155,7 +155,7 @@ class ExpertBank:
         ops.adam_update_and_sample_experts(self.n, self.stride, self.grad_stride, SEED_STRIDE_SAMPLER, x0.theta, x0._m,
                                            x0._v, x0.grad, x0.off_pi, x0.P_total - x0.off_pi, x0._alpha_tab,
                                            x0._step_ctr, x0._alpha_base, None, 0, x0._layout, S.tasks,
-                                           S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, x0.batch_size, None,
+                                           S.params(x0.clip_obs, x0.relative_goals), x0._rng_desc, x0._Bt, None,
                                            keep=x0._kept_copies())
 
     def _allreduce(self):

@@ -42,16 +42,17 @@ class RolloutWorker:
         self.rank = dist.rank()
         # virtual ranks (DDPG virtual_ranks = V): this worker runs the rollouts of V of the reference's ranks -- V x
         # rollout_batch_size envs in one batched env, env ids, exploit decisions and task / goal draws per rank
-        self.V = int(getattr(policy, 'virtual_ranks', 1) or 1) if not isinstance(policy, (list, tuple)) else 1
+        # (a list of policies -- the task_experts evaluator, rollout.py:212-224 -- stands for the ranks its experts stand for)
+        pol0 = policy[0] if isinstance(policy, (list, tuple)) else policy
+        self.V = int(getattr(pol0, 'virtual_ranks', 1) or 1)
         # global rank of this process's first virtual rank, ranks of the job (uneven layouts: dist.virtual_layout)
-        single = isinstance(policy, (list, tuple))
-        self.rank_base = self.rank * self.V if single else int(getattr(policy, 'rank_base', self.rank * self.V))
-        self.nb_cpu = dist.world_size() * self.V if single else int(getattr(policy, 'total_ranks', dist.world_size() * self.V))
+        self.rank_base = int(getattr(pol0, 'rank_base', self.rank * self.V))
+        self.nb_cpu = int(getattr(pol0, 'total_ranks', dist.world_size() * self.V))
         self._uneven = self.nb_cpu != dist.world_size() * self.V     # (the ranks' record blocks then differ in length)
         self._slot0 = self.rank_base * rollout_batch_size            # this process's first rollout among the job's
         self._nloc = rollout_batch_size * self.V                     # envs of this process
-        if self.V > 1 and not (hasattr(make_env, 'make_batched') and structure == 'curious'):
-            raise ValueError("virtual ranks need the GPU-resident batched env and structure='curious'")
+        if self.V > 1 and not (hasattr(make_env, 'make_batched') and structure in ('curious', 'task_experts')):
+            raise ValueError("virtual ranks need the GPU-resident batched env and structure 'curious' or 'task_experts'")
         self._vrng = None                                            # per-virtual-rank host streams (seed_ranks)
         if self.batched:
             self.benv = (make_env.make_batched(self._nloc, env_id0=self.rank_base * rollout_batch_size, pad_to=4) if self.V > 1
@@ -509,9 +510,9 @@ class RolloutWorker:
     def _expert_steps(self, env, tasks, q_sum):
         """The T acting steps with one expert per task (rollout.py:212-224: policy[task_of_env].get_actions per env):
         expert j acts on the contiguous rows of the envs that drew task j."""
-        B = self.rollout_batch_size
+        B = len(tasks)                                               # (virtual ranks: the envs of all of them)
         bounds = np.searchsorted(tasks, np.arange(self.nb_tasks + 1))
-        u_all = torch.empty([B, self.dims['u']], dtype=torch.float32, device=env.device)
+        u_all = torch.zeros([env.n, self.dims['u']], dtype=torch.float32, device=env.device)   # (idle padding envs: no action)
         noise_eps = self.noise_eps if not self.exploit else 0.
         random_eps = self.random_eps if not self.exploit else 0.
         for t in range(self.T):

@@ -140,7 +140,8 @@ def _launch(tmp, sub, n_epochs, structure='curious', resume=None, **over):
     return os.path.join(root, 'MultiTaskFetchArm4-v5', '0')
 
 
-@pytest.mark.parametrize('case', ['virtual_ranks', 'one_rank', 'task_experts_batched', 'task_experts_sequential'])
+@pytest.mark.parametrize('case', ['virtual_ranks', 'one_rank', 'task_experts_batched', 'task_experts_sequential',
+                                  'task_experts_virtual_ranks'])
 def test_training_job_resumes_bit_for_bit(tmp_path, case):
     """experiment.train --resume (what ddpg.py:511-513 says the reference cannot do): 5 epochs in one go
     against 3 epochs + a new job that goes on from the first one's last checkpoint for 2 more.  Checkpoints fall on the
@@ -153,7 +154,9 @@ def test_training_job_resumes_bit_for_bit(tmp_path, case):
               task_experts_batched=dict(structure='task_experts', experts_update='batched', task_selection='random',
                                         task_replay='replay_current_task_buffer'),
               task_experts_sequential=dict(structure='task_experts', task_selection='active_competence_progress',
-                                           task_replay='replay_current_task_buffer'))[case]
+                                           task_replay='replay_current_task_buffer'),
+              task_experts_virtual_ranks=dict(structure='task_experts', experts_update='batched', task_selection='random',
+                                              task_replay='replay_current_task_buffer', num_cpu=2))[case]
     kw = dict(kw)
     structure = kw.pop('structure', 'curious')
     straight = _launch(tmp_path, 'straight', 5, structure, **kw)
@@ -218,3 +221,145 @@ def test_training_job_resumes_over_two_processes(tmp_path):
         sb = torch.load(os.path.join(first, STATE_DIR, 'rank%03d_epoch000003.pt' % r), weights_only=False)
         assert sa['layout']['virtual_ranks'] == (2 if r == 0 else 1) and sa['layout']['total_ranks'] == 3
         _same_state(sa, sb)
+
+
+# ------------------------------------------------------------------ task experts with virtual ranks
+def _expert_kit_ranks(V, nb=4, dimo=40, batch_size=256, cap_eps=64):
+    """tests/test_gpu_round2._expert_kit with V private buffer sets (config.py:210-214 runs once per MPI rank) on one pool."""
+    from curious_amd.envs import sparse_reward_fun
+    from curious_amd.her import make_sample_multi_task_her_transitions
+    from curious_amd.replay_buffer import make_pooled_buffers
+    from test_gpu_agent import T, tables
+    G = 3 * nb
+    ag_ids, g_ids = tables(nb)
+    dims = dict(o=dimo, u=4, g=G, ag=G, task_descr=nb, info_is_success=1)
+    shapes = dict(o=(T + 1, dimo), u=(T, 4), g=(T, G), ag=(T + 1, G), info_is_success=(T, 1), task_descr=(T, nb),
+                  change=(T, G))
+    tr = 'replay_current_task_buffer'
+    sampler = make_sample_multi_task_her_transitions('her', 4, tr, sparse_reward_fun(dict(kind='sparse_l2', eps=0.05)),
+                                                     tasks_ag_id=ag_ids, tasks_g_id=g_ids)
+    bufs = make_pooled_buffers(shapes, T * cap_eps, T, sampler, nb + 1, alias_from=5, n_ranks=V)
+    gamma = 1. - 1. / T
+
+    def make(t_id, use_graph=False, **hooks):
+        from curious_amd.ddpg import DDPG
+        return DDPG(input_dims=dims, hidden=256, layers=3, network_class='curious_amd.actor_critic:MultiTaskActorCritic',
+                    polyak=0.95, batch_size=batch_size, Q_lr=1e-3, pi_lr=1e-3, norm_eps=0.01, norm_clip=5, max_u=1.,
+                    action_l2=1., clip_obs=200., scope='ddpg', T=T, rollout_batch_size=2, subtract_goals=None,
+                    relative_goals=False, clip_pos_returns=True, clip_return=1. / (1. - gamma), normalize_obs=False,
+                    sample_transitions=sampler, gamma=gamma, buffers=bufs, tasks_ag_id=ag_ids, tasks_g_id=g_ids,
+                    task_replay=tr, eps_task=0.4, structure='task_experts', t_id=t_id, seed=10 + t_id, rng_mode='device',
+                    use_graph=use_graph, virtual_ranks=V, **hooks)
+    return make, bufs
+
+
+@pytest.mark.parametrize('V,graph', [(2, 0), (3, 1)])
+def test_task_experts_with_virtual_ranks(V, graph):
+    """structure='task_experts' on V virtual ranks (train.py:65-121 runs its expert loop on every MPI rank alike; the experts'
+    gradients are summed over the ranks by their MpiAdam, mpi_adam.py:26): every rank owns a buffer set shared by ITS experts,
+    expert t draws 256 transitions per rank from that rank's buffer t + 1 relabelled to its own task (ddpg.py:302-318,335),
+    an update consumes the V minibatches in one launch sequence.  (i) the bank (all experts in one launch sequence) == the
+    experts updated one by one, bit for bit; (ii) every rank's rows come from ITS episodes and carry the expert's task;
+    (iii) per-rank losses and the Adam step from the SUMMED oracle gradients against the float64 oracle, as for the curious
+    agent in test_virtual_ranks_match_the_oracle_rank_model."""
+    from curious_amd import ops
+    from curious_amd.experts import ExpertBank
+    from oracle.optim import adam_update
+    from test_gpu_round4 import _oracle_agent
+    from test_gpu_round5 import B, DIMO, NB, STAGE_KEYS, rank_episodes
+    groups = []
+    for batched in (True, False):
+        make, bufs = _expert_kit_ranks(V)
+        if batched:
+            bank = ExpertBank(lambda t, **h: make(t, use_graph=bool(graph), **h), NB)
+            xs = list(bank)
+        else:
+            bank, xs = None, [make(t, use_graph=bool(graph)) for t in range(NB)]
+        xs[0].store_episode(rank_episodes(V, 24)(), np.zeros(NB), 24 * V)
+        groups.append((bank, xs))
+    (bank, bx), (_, sx) = groups
+    assert all(b.current_size > 0 for bl in bx[0]._rank_buffers for b in bl[1:NB + 1])
+    # ---- one update recorded for the oracle, then a run of updates
+    pre = [[ops.unpad_params(x.net_cfg, t.cpu().numpy()) for t in (x.theta, x._m, x._v)] for x in bx]
+    p = bank._cur
+    bank.train_batches(1)
+    for x in sx:
+        x.train_batches(1)
+    torch.cuda.synchronize()
+    a = _oracle_agent(10)                                            # (network shapes only: the parameters come from the product)
+    PQ = a.math.P_Q
+    for e, x in enumerate(bx):
+        views = x._layout.batch_views(x._pp[p])
+        batch = {k: views[k].cpu().numpy().copy() for k in STAGE_KEYS}
+        # (the HER samples -- future_p = 0.8 of them -- are relabelled to the expert's task, the others keep theirs: her.py:131-155)
+        assert (batch['task_descr'].argmax(axis=1) == e).mean() > 0.7 and np.all(batch['task_descr'].sum(axis=1) == 1)
+        assert all(x.proportions[i] == (B if i == e + 1 else 0) for i in range(NB + 1))
+        assert not np.array_equal(batch['o'][:B], batch['o'][B:2 * B])
+        th, m, v = pre[e]
+        outs = [a.math.losses_and_grads(th, th, {k: batch[k][r * B:(r + 1) * B] for k in STAGE_KEYS}) for r in range(V)]
+        losses = x._losses.cpu().numpy().reshape(V, 2)
+        for r in range(V):
+            assert abs(losses[r, 0] - float(outs[r]['Q_loss'])) <= 1e-5 * abs(float(outs[r]['Q_loss'])), (e, r)
+            assert abs(losses[r, 1] - float(outs[r]['pi_loss'])) <= 1e-5 * abs(float(outs[r]['pi_loss'])) + 1e-7, (e, r)
+        got_m = ops.unpad_params(x.net_cfg, x._m.cpu().numpy())
+        for sl, key, lr in ((slice(0, PQ), 'Q_grad', 1e-3), (slice(PQ, None), 'pi_grad', 1e-3)):
+            g = sum(o[key] for o in outs)                            # mpi_adam.py:26: SUM over ranks
+            want_m = adam_update(th[sl], m[sl], v[sl], 0, g, lr)[1]
+            dev = np.abs(got_m[sl] - want_m) / np.abs(want_m).max()
+            assert dev.max() <= 5e-4 and (dev > 2e-5).mean() <= 2e-3, (e, key, dev.max(), (dev > 2e-5).mean())
+    bank.train_batches(11)
+    for x in sx:
+        x.train_batches(11)
+    bank.update_target_net()
+    for x in sx:
+        x.update_target_net()
+    torch.cuda.synchronize()
+    assert bank.batched
+    for x, y in zip(bx, sx):
+        assert x.Q_adam.t == y.Q_adam.t == 12
+        assert torch.equal(x.theta, y.theta) and torch.equal(x._m, y._m) and torch.equal(x._v, y._v)
+        assert torch.equal(x.theta_target, y.theta_target) and torch.equal(x._staged, y._staged)
+        assert torch.equal(x._losses, y._losses)
+    bank.check_faults()
+
+
+def test_training_job_of_task_experts_with_virtual_ranks(tmp_path):
+    """experiment.train --structure task_experts --experts_update batched --num_cpu 3 on one process: the whole loop (expert of
+    the epoch collects on every rank, every expert is updated from every rank's buffers, the evaluator acts with one expert
+    per task on the envs of all ranks); the episode count is the reference's, and a job that asks for ranks it cannot have
+    is refused instead of running another job."""
+    first = _launch(tmp_path, 'x', 3, 'task_experts', num_cpu=3, experts_update='batched', task_selection='random',
+                    task_replay='replay_current_task_buffer')
+    rows = _rows(os.path.join(first, 'progress.csv'))
+    assert [r['epoch'] for r in rows] == ['-1', '0', '1', '2']
+    assert int(float(rows[-1]['train/episode'])) == 3 * 4 * 3            # cycles x rollouts per rank x ranks, of the LAST expert's worker
+    assert all(np.isfinite(float(r['test/mean_Q'])) for r in rows)
+    with pytest.raises(ValueError, match='virtual ranks'):
+        _launch(tmp_path, 'y', 1, 'task_experts', num_cpu=3, task_selection='random',
+                task_replay='replay_current_task_buffer')               # (sequential experts)
+    with pytest.raises(ValueError, match='virtual ranks'):
+        _launch(tmp_path, 'z', 1, 'curious', num_cpu=3, rng_mode='numpy', use_graph=False, async_store=False)
+
+
+# ------------------------------------------------------------------ bench.py on the published rank layout
+def test_bench_lays_the_published_ranks_out_over_the_processes():
+    """`bench.py --gpus 2 --num-cpu 3` (torch.distributed.run, gloo: both processes share this box's GPU): the reference's
+    --num_cpu R laid out like experiment.train lays it out -- ranks {0, 1} on process 0, {2} on process 1
+    (dist.virtual_layout; `--gpus 8 --num-cpu 19` = 3 3 3 2 2 2 2 2 is the published job, readme.md:16).  `value` counts
+    R x 256 transitions per update -- the accounting of the one-process run `--virtual-ranks 3` --, the line names the
+    layout, the replicas end identical."""
+    import json
+    from test_gpu_round4 import _launch2, _two_rank_env
+    out = _launch2([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--num-cpu', '3', '--steps', '3', '--warmup', '1',
+                    '--prefill', '256', '--no-ipc-probe'], _two_rank_env())
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-1500:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['ranks'] == 3 and rec['config']['ranks_per_process'] == [2, 1]
+    assert rec['config']['rollout_batch_size'] == 2 and '--num_cpu 3' in rec['config']['workload']
+    per_s = 3 / (rec['ms_per_step'] * 3e-3)                          # cycles per second
+    assert abs(rec['value'] - 3 * 100 * 256 * per_s) < 1e-3 * rec['value']          # R x 256 per update, 100 updates per cycle
+    assert abs(rec['env_steps_per_sec'] - 3 * 2 * 50 * per_s) < 1e-3 * rec['env_steps_per_sec']
+    c = rec['collectives']
+    assert c['rccl']['world'] == 2 and c['replicas_identical'] is True
