@@ -5,6 +5,7 @@
 // a flat, fully coalesced 16-byte-per-lane copy; slot selection (replay_buffer.py:90-109, NumPy stream)
 // stays on the host.
 #include "common.h"
+#include <algorithm>
 
 // n_pairs_dev != NULL: the pair list was made on the device (route_episodes_kernel); the grid covers the largest
 // possible list and the blocks beyond the real one leave
@@ -247,6 +248,10 @@ static int route_store_ranks(float* storage, const float* staging, const curious
                 "curious_route_store_episodes: bad task / capacity arguments");
   CURIOUS_CHECK(n_episodes <= ROUTE_MAX_EPISODES, "curious_route_store_episodes: at most %d episodes per call",
                 ROUTE_MAX_EPISODES);
+  // (the copy launch carries one (rank, episode, routed task) pair per grid.y index)
+  CURIOUS_CHECK((int64_t)n_ranks * std::max(n_episodes, 0) * n_route <= 65535,
+                "curious_route_store_episodes: %d ranks x %d episodes x %d routed tasks exceed the 65 535 pairs of one call",
+                n_ranks, n_episodes, n_route);
   if (n_episodes <= 0 || n_route == 0) return 0;
   hipStream_t st = as_stream(stream);
   { ProfScope ps__(CK_ROUTE, st);

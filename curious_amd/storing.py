@@ -172,7 +172,8 @@ class StoringMixin:
             bufs = [bl[j + 1] for j in range(nr)]
             if not (len({id(b) for b in bufs}) == nr and all(b.current_size > 0 for b in bufs)):
                 return False
-        return batch_size <= 2048 and self.dimo + self.dimg <= 256
+        # (the routed copy is one launch with a (rank, episode, routed task) pair per grid.y index: 65 535 of them at most)
+        return batch_size <= 2048 and self.dimo + self.dimg <= 256 and self.V * batch_size * nr <= 65535
 
     def _store_seed(self, v=0):
         return (self.seed * 6700417 + 29 + (self._grank0() + v) * RANK_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF

@@ -65,18 +65,24 @@ def unflatten(flat, shapes):
 
 
 # ------------------------------------------------------------------ forward / backward
-def mlp_forward(params, x_state, x_goal, modular=True):
-    """Returns (out, cache).  Hidden layers ReLU, last layer linear (util.py:76,96)."""
+def mlp_forward(params, x_state, x_goal, modular=True, keep_pre=False):
+    """Returns (out, cache).  Hidden layers ReLU, last layer linear (util.py:76,96).
+    keep_pre (tests: which units sit on the edge of their ReLU): the cache also holds, per hidden layer, the pre-activations
+    `pres` and the sum of the magnitudes of the terms each one is made of, `mags` -- what a float32 evaluation's rounding
+    error scales with."""
     if modular:
         Ws, bs, Wg = params[0], params[1], params[2]
         rest = params[3:]
         pre = x_state @ Ws + bs + x_goal @ Wg                       # util.py:79-91
         x0 = x_state
+        mag = (np.abs(x_state) @ np.abs(Ws) + np.abs(bs) + np.abs(x_goal) @ np.abs(Wg)) if keep_pre else None
     else:
         W0, b0 = params[0], params[1]
         rest = params[2:]
         x0 = x_state                    # flat: caller passes the full concat (actor_critic.py:35,43,46)
         pre = x0 @ W0 + b0
+        mag = (np.abs(x0) @ np.abs(W0) + np.abs(b0)) if keep_pre else None
+    pres, mags = [pre], [mag]
     h = np.maximum(pre, 0)
     acts = [h]
     nl = len(rest) // 2
@@ -84,13 +90,21 @@ def mlp_forward(params, x_state, x_goal, modular=True):
         W, b = rest[2 * i], rest[2 * i + 1]
         pre = h @ W + b
         if i < nl - 1:
+            if keep_pre:
+                pres.append(pre)
+                mags.append(np.abs(h) @ np.abs(W) + np.abs(b))
             h = np.maximum(pre, 0)
             acts.append(h)
-    return pre, dict(x0=x0, x_goal=x_goal, acts=acts, modular=modular)
+    cache = dict(x0=x0, x_goal=x_goal, acts=acts, modular=modular)
+    if keep_pre:
+        cache.update(pres=pres, mags=mags)
+    return pre, cache
 
 
-def mlp_backward(params, cache, dout):
-    """Returns (grads list in param order, d x_state_or_concat).  Goal input grad is not needed."""
+def mlp_backward(params, cache, dout, flip=()):
+    """Returns (grads list in param order, d x_state_or_concat).  Goal input grad is not needed.
+    flip (tests): [(layer, row, unit)] whose relu' is taken on the OTHER side -- what a float32 evaluation does when the
+    unit's pre-activation lies within its rounding error of zero."""
     modular = cache['modular']
     rest = params[3:] if modular else params[2:]
     nl = len(rest) // 2
@@ -102,7 +116,11 @@ def mlp_backward(params, cache, dout):
         h_in = acts[i]
         grest[2 * i] = h_in.T @ d
         grest[2 * i + 1] = d.sum(axis=0)
-        d = (d @ W.T) * (h_in > 0)
+        gate = h_in > 0
+        for (L, r, c) in flip:
+            if L == i:
+                gate[r, c] = not gate[r, c]
+        d = (d @ W.T) * gate
     if modular:
         g = [cache['x0'].T @ d, d.sum(axis=0), cache['x_goal'].T @ d]
         dx = d @ params[0].T
@@ -139,22 +157,26 @@ class DDPGMath:
     def _state(self, o, td):
         return np.concatenate([o, td], axis=1) if self.modular else o
 
-    def actor(self, pi_params, o, td, g):
+    def actor(self, pi_params, o, td, g, keep_pre=False):
         x = self._state(o, td) if self.modular else np.concatenate([o, g], axis=1)
-        z, cache = mlp_forward(pi_params, x, g, self.modular)
+        z, cache = mlp_forward(pi_params, x, g, self.modular, keep_pre)
         pi = self.max_u * np.tanh(z)                                 # actor_critic.py:89
         return pi, z, cache
 
-    def critic(self, Q_params, o, td, g, u_scaled):
+    def critic(self, Q_params, o, td, g, u_scaled, keep_pre=False):
         if self.modular:
             x = np.concatenate([o, td, u_scaled], axis=1)            # actor_critic.py:93,96
         else:
             x = np.concatenate([o, g, u_scaled], axis=1)             # actor_critic.py:43,46
-        return mlp_forward(Q_params, x, g, self.modular)
+        return mlp_forward(Q_params, x, g, self.modular, keep_pre)
 
-    def losses_and_grads(self, theta_main, theta_target, batch):
+    def losses_and_grads(self, theta_main, theta_target, batch, keep_pre=False, flip=None):
         """batch: dict o,g,u,task_descr,o_2,g_2,r (already clipped, ddpg.py:350-353).
-        Returns dict(Q_loss, pi_loss, Q_pi[B,1], Q_grad[P_Q], pi_grad[P_pi], ...)."""
+        Returns dict(Q_loss, pi_loss, Q_pi[B,1], Q_grad[P_Q], pi_grad[P_pi], ...).
+        keep_pre: + `edge` = {'Q': [...], 'pi': [...], 'Q_pi': [...]}: per hidden layer of the passes whose ReLU gates a
+        gradient (critic(u), actor, critic(pi)) the array |pre-activation| / (sum of the magnitudes of its terms), [B, H].
+        flip: (pass name, layer, row, unit), or a list of them: those units' relu' taken on the other side in that backward
+        pass (mlp_backward)."""
         dt = self.dtype
         o, g, u, td = (batch[k].astype(dt) for k in ('o', 'g', 'u', 'task_descr'))
         o2, g2, r = (batch[k].astype(dt) for k in ('o_2', 'g_2', 'r'))
@@ -169,22 +191,30 @@ class DDPGMath:
         hi = dt(0.) if self.clip_pos_returns else dt(np.inf)
         target = np.clip(r + dt(self.gamma) * Q_t_pi, dt(-self.clip_return), hi)   # ddpg.py:437-438
         # main network on (o, g)
-        pi, z, cache_pi = self.actor(pim, o, td, g)
-        Q_pi, cache_Qpi = self.critic(Qm, o, td, g, pi / mu)
-        Q, cache_Q = self.critic(Qm, o, td, g, u / mu)
+        pi, z, cache_pi = self.actor(pim, o, td, g, keep_pre)
+        Q_pi, cache_Qpi = self.critic(Qm, o, td, g, pi / mu, keep_pre)
+        Q, cache_Q = self.critic(Qm, o, td, g, u / mu, keep_pre)
         diff = target - Q
         Q_loss = np.mean(np.square(diff))                            # ddpg.py:439
         pi_loss = -np.mean(Q_pi) + dt(self.action_l2) * np.mean(np.square(pi / mu))  # ddpg.py:440-441
         # critic gradient wrt main/Q (target is stop_gradient)
         dQ = (dt(-2.0) / dt(B)) * diff
-        gQ, _ = mlp_backward(Qm, cache_Q, dQ)
+        fl = {'Q': [], 'pi': [], 'Q_pi': []}
+        if flip is not None:
+            for f in ([flip] if isinstance(flip[0], str) else flip):     # one (pass, layer, row, unit) or a list of them
+                fl[f[0]].append(tuple(f[1:]))
+        gQ, _ = mlp_backward(Qm, cache_Q, dQ, fl['Q'])
         # actor gradient wrt main/pi: through the critic input slot that holds pi/max_u
         dQpi = np.full_like(Q_pi, dt(-1.0) / dt(B))
-        _, dx = mlp_backward(Qm, cache_Qpi, dQpi)
+        _, dx = mlp_backward(Qm, cache_Qpi, dQpi, fl['Q_pi'])
         sd = self.dimo + (self.dimtd if self.modular else self.dimg)
         d_pi_scaled = dx[:, sd:sd + self.dimu]
         dpi = d_pi_scaled / mu + dt(self.action_l2) * dt(2.0) * pi / (mu * mu * dt(B * self.dimu))
         dz = dpi * mu * (dt(1.0) - np.square(np.tanh(z)))
-        gpi, _ = mlp_backward(pim, cache_pi, dz)
-        return dict(Q_loss=Q_loss, pi_loss=pi_loss, Q_pi=Q_pi, Q=Q, pi=pi, target=target,
-                    Q_grad=flatten(gQ).astype(dt), pi_grad=flatten(gpi).astype(dt))
+        gpi, _ = mlp_backward(pim, cache_pi, dz, fl['pi'])
+        out = dict(Q_loss=Q_loss, pi_loss=pi_loss, Q_pi=Q_pi, Q=Q, pi=pi, target=target,
+                   Q_grad=flatten(gQ).astype(dt), pi_grad=flatten(gpi).astype(dt))
+        if keep_pre:
+            out['edge'] = {name: [np.abs(p) / np.maximum(m, 1e-300) for p, m in zip(c['pres'], c['mags'])]
+                           for name, c in (('Q', cache_Q), ('pi', cache_pi), ('Q_pi', cache_Qpi))}
+        return out

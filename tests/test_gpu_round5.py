@@ -116,6 +116,74 @@ def _recompute_ranks(nzs):
         nz.recompute_stats()
 
 
+def _float64_math(m):
+    from oracle.networks import DDPGMath
+    return DDPGMath(m.dimo, m.dimg, m.dimu, m.dimtd, m.hidden, m.layers, m.max_u, m.gamma, m.clip_return,
+                    m.clip_pos_returns, m.action_l2, m.modular, np.float64)
+
+
+TIGHT = 5e-6             # float32 sums over up to 4 864 rows against float64: sqrt(rows) x 2^-24 of the max-norm
+EDGE = 2.0 ** -16        # |pre-activation| / (sum of the magnitudes of its terms) below which float32 may take the other side
+                         # (256 terms x 2^-24: the worst case of a float32 sum; the typical error is 2^-20 of that scale)
+
+
+def _explain_by_relu_flips(m64, th, target0, batches, outs, key, g, m_pre, m_got):
+    """The product's summed gradient differs from the float64 oracle's by float32 rounding -- and by the odd hidden unit
+    whose pre-activation lies within float32 rounding of ZERO on some row and whose relu' the float32 kernels therefore take
+    on the other side: not a rounding error of the gradient but another (equally legitimate) branch, ~1e-4 of the max-norm in
+    that unit's column and less, spread over the layers below.  This makes the statement exact: the candidates are the units
+    with |pre| < EDGE x (sum of the magnitudes of the terms of pre) in the float64 forward pass of the three passes whose
+    ReLUs gate this gradient; for each the oracle is re-run with that ONE relu' flipped; the flips the product took are
+    picked out of those single-flip differences one by one (below) from its deviation (first moment = 0.1 x the gradient,
+    mpi_adam.py:31), the oracle re-run with exactly those flipped.  Returns (the oracle gradient on the product's
+    branch, the flips it took)."""
+    passes = ('Q',) if key == 'Q_grad' else ('pi', 'Q_pi')
+    groups = {}
+    for r, o in enumerate(outs):
+        for name in passes:
+            for L, e in enumerate(o['edge'][name]):
+                for (row, col) in zip(*np.nonzero(e < EDGE)):
+                    # (a minibatch is drawn WITH replacement: copies of one transition are rows with the same pre-activations
+                    #  bit for bit, and whatever one of them does the others do -- one candidate)
+                    groups.setdefault((r, name, L, int(col), float(e[row, col])), []).append(int(row))
+    cands = [(r, name, L, tuple(rows), col) for (r, name, L, col, _), rows in groups.items()]
+    dev = (m_got.astype(np.float64) - (0.9 * m_pre.astype(np.float64) + 0.1 * g)) / 0.1     # in units of the gradient
+    scale = np.abs(g).max()
+    if not cands or np.abs(dev).max() <= TIGHT * scale:              # nothing beyond rounding: no flip happened
+        return g, []
+    assert len(cands) <= 4000, len(cands)
+    cols = []
+    for (r, name, L, rows, col) in cands:
+        alt = m64.losses_and_grads(th.astype(np.float64), target0, batches[r], flip=[(name, L, row, col) for row in rows])[key]
+        cols.append(alt - outs[r][key])
+    A = np.stack(cols, axis=1)
+    n2 = np.maximum((A * A).sum(axis=0), 1e-300)
+    # matching pursuit: the candidate whose single flip, taken whole (coefficient ~ 1), removes most of what is left; then the
+    # oracle is re-run with ALL the flips taken so far (two of them on one row do not add up: the upper one gates what
+    # reaches the lower one) and the search goes on in what remains.  The caller's tight comparison of the moments is the
+    # proof that the branch found is the product's.
+    flipped, g2, resid = [], g, dev
+    for _ in range(8):
+        if np.abs(resid).max() <= TIGHT * scale:
+            break
+        c = (A.T @ resid) / n2
+        gain = np.where((c > 0.7) & (c < 1.3), c * c * n2, 0.0)
+        for i, f in enumerate(cands):
+            if f in flipped:
+                gain[i] = 0.0
+        best = int(np.argmax(gain))
+        if gain[best] < 0.05 * float(resid @ resid):               # nothing among the candidates explains what is left
+            break
+        flipped.append(cands[best])
+        g2 = g.copy()
+        for r in sorted({f[0] for f in flipped}):
+            alt = m64.losses_and_grads(th.astype(np.float64), target0, batches[r],
+                                       flip=[(f[1], f[2], row, f[4]) for f in flipped if f[0] == r for row in f[3]])[key]
+            g2 += alt - outs[r][key]
+        resid = (m_got.astype(np.float64) - (0.9 * m_pre.astype(np.float64) + 0.1 * g2)) / 0.1
+    return g2, flipped
+
+
 @pytest.mark.parametrize('V,graph', [(2, 0), (2, 1), (3, 1), (19, 0), (19, 1)])
 def test_virtual_ranks_match_the_oracle_rank_model(V, graph, route):
     """V virtual ranks of one process against V oracle ranks: per-rank losses 1e-5 relative, one oracle Adam step from the
@@ -127,10 +195,7 @@ def test_virtual_ranks_match_the_oracle_rank_model(V, graph, route):
     from oracle.optim import adam_update, polyak_update
     from test_gpu_round4 import _oracle_agent
     n_per = 24 if V < 19 else 4
-    # (tiled route, 19 ranks: with the episodes of seeds 50.. one pre-activation of rank 13's first batch lies within
-    #  float32 rounding of zero and the tiled kernels' order of summation puts it on the other side of the ReLU than the
-    #  float64 oracle -- 2e-3 in that unit's weight gradients, with or without virtual ranks: another data seed)
-    agent, rec = run_virtual(V, graph, n_per=n_per, first_seed=250 if (V == 19 and route == 'tiled') else 50)
+    agent, rec = run_virtual(V, graph, n_per=n_per)
     n_upd = rec['n_updates']
     # ---- the ranks really saw different data, and every rank's rows come from ITS episodes
     assert not np.array_equal(rec['batch_0_o'][:B], rec['batch_0_o'][B:2 * B])
@@ -153,41 +218,43 @@ def test_virtual_ranks_match_the_oracle_rank_model(V, graph, route):
             np.testing.assert_allclose(st[2 * d + 1:3 * d + 1], nz.mean, rtol=1e-5, atol=1e-6, err_msg=key)
             np.testing.assert_allclose(st[3 * d + 1:], nz.std, rtol=1e-5, atol=1e-6, err_msg=key)
     assert float(o_nz[0].count[0]) == 1.0 + 2 * rows                # two stores of n_per episodes x T on EACH rank
-    # ---- updates, step by step from the product's own state
+    # ---- updates, step by step from the product's own state, against the FLOAT64 oracle
     a = _oracle_agent(SEED)
     np.testing.assert_array_equal(rec['theta_pre_0'], a.theta)
-    target0 = a.theta.copy()
+    target0 = a.theta.copy().astype(np.float64)
+    m64 = _float64_math(a.math)
     PQ = a.math.P_Q
+    n_flips = 0
     for k in range(n_upd):
         th, m, v = (rec['%s_pre_%d' % (name, k)] for name in ('theta', 'm', 'v'))
-        outs = []
+        batches = [{key: rec['batch_%d_%s' % (k, key)][r * B:(r + 1) * B] for key in STAGE_KEYS} for r in range(V)]
+        outs = [m64.losses_and_grads(th.astype(np.float64), target0, bt, keep_pre=True) for bt in batches]
         for r in range(V):
-            batch = {key: rec['batch_%d_%s' % (k, key)][r * B:(r + 1) * B] for key in STAGE_KEYS}
-            outs.append(a.math.losses_and_grads(th, target0, batch))
             want, got = float(outs[r]['Q_loss']), float(rec['loss_%d' % k][r, 0])
             assert abs(got - want) <= 1e-5 * abs(want), (k, r, got, want)
             want, got = float(outs[r]['pi_loss']), float(rec['loss_%d' % k][r, 1])
             assert abs(got - want) <= 1e-5 * abs(want) + 1e-7, (k, r, got, want)
             np.testing.assert_allclose(rec['qpi_%d' % k][r * B:(r + 1) * B], outs[r]['Q_pi'], rtol=1e-4, atol=2e-5)
-        nxt = [np.empty_like(th), np.empty_like(m), np.empty_like(v)]
-        for sl, key, lr in ((slice(0, PQ), 'Q_grad', a.Q_lr), (slice(PQ, None), 'pi_grad', a.pi_lr)):
-            g = sum(o[key] for o in outs)                            # mpi_adam.py:26: SUM over ranks
-            nxt[0][sl], nxt[1][sl], nxt[2][sl], _ = adam_update(th[sl], m[sl], v[sl], k, g, lr)
         suffix = ('_pre_%d' % (k + 1)) if k + 1 < n_upd else ''
         got = [rec[name + suffix] for name in ('theta', 'm', 'v')]
-        # (m, v within 2e-5 / 4e-5 of their max-norm -- but for the odd unit whose pre-activation lies within float32 rounding
-        #  of zero on some row and falls on the other side of the ReLU than in the float64 oracle: that row's term of the
-        #  unit's column, ~1e-4 of the max-norm; with 19 x 256 rows x ~4 000 units per update it happens every few updates.
-        #  At most 0.1 % of the elements, none beyond 5e-4: a lost chunk of rows or a wrong tile would be 100 x that)
-        for gv, nv, tol in ((got[1], nxt[1], 2e-5), (got[2], nxt[2], 4e-5)):
-            dev = np.abs(gv - nv) / np.abs(nv).max()
-            assert dev.max() <= 5e-4 and (dev > tol).mean() <= 1e-3, (k, dev.max(), (dev > tol).mean())
-        assert np.abs(got[0] - nxt[0]).max() <= 1e-4, k              # one Adam step of size 1e-3
-        assert (np.abs(got[0] - nxt[0]) > 2e-6).mean() < 1e-3, k
+        for sl, key, lr in ((slice(0, PQ), 'Q_grad', a.Q_lr), (slice(PQ, None), 'pi_grad', a.pi_lr)):
+            g = sum(o[key] for o in outs)                            # mpi_adam.py:26: SUM over ranks (float64)
+            g, flipped = _explain_by_relu_flips(m64, th, target0, batches, outs, key, g, m[sl], got[1][sl])
+            n_flips += len(flipped)
+            nxt = adam_update(th[sl], m[sl], v[sl], k, g.astype(np.float32), lr)
+            # ZERO exceptions: with the flips accounted for, every element of m, v and theta is the oracle's to float32 rounding
+            for gv, nv, tol, what in ((got[1][sl], nxt[1], TIGHT, 'm'), (got[2][sl], nxt[2], 2 * TIGHT, 'v')):
+                dev = np.abs(gv - nv) / np.abs(nv).max()
+                assert dev.max() <= tol, (k, key, what, float(dev.max()), flipped)
+            # (theta follows from m and v: elements with a vanishing gradient amplify their rounding, m / sqrt(v))
+            assert np.abs(got[0][sl] - nxt[0]).max() <= 1e-4, (k, key)       # one Adam step of size 1e-3
+            assert (np.abs(got[0][sl] - nxt[0]) > 2e-6).mean() < 1e-3, (k, key)
         if k == 0:
             # SUM, not mean, and not one rank alone: the first moments are V times one rank's
-            one = adam_update(th[:PQ], m[:PQ], v[:PQ], 0, outs[0]['Q_grad'], a.Q_lr)[1]
+            one = adam_update(th[:PQ], m[:PQ], v[:PQ], 0, outs[0]['Q_grad'].astype(np.float32), a.Q_lr)[1]
             assert np.abs(got[1][:PQ] - one).max() > 0.2 * np.abs(one).max()
+    assert n_flips <= 2 * n_upd, n_flips                             # (a handful per run at 19 ranks, none at 2 or 3, as a rule)
+    target0 = target0.astype(np.float32)
     np.testing.assert_allclose(rec['target'], polyak_update(target0, rec['theta'], 0.95), rtol=0, atol=1e-6)
 
 

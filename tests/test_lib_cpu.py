@@ -268,3 +268,112 @@ def test_round4_entry_points_host_code_without_gpu():
     h = C.create_string_buffer(64)
     assert L.curious_ipc_export(None, h) != 0 and L.curious_ipc_import(None, C.byref(out)) != 0
     assert L.curious_ipc_close(None) == 0 and L.curious_ipc_free(None) == 0
+
+
+def test_round5_entry_points_host_code_without_gpu():
+    """The entry points of ABI 9 (virtual ranks) and the options of round 6: the several-rank rollout, the routed stores of
+    several ranks (with and without the activity test inside), the counting env reset, the rank fields of the sampler
+    description (64-bit offsets: pools of 33 GB) and `loss_rows` -- argument validation and descriptor arithmetic up to the
+    failing launch (sanitizer coverage of their host side, tools/sanitize_cpu.sh)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('would launch kernels on fake pointers')
+    from curious_amd import _lib
+    L = _lib.lib()
+    fake = [C.c_void_p(0x10000000 + 0x1000000 * i) for i in range(16)]
+    lay = _lib.Layout()
+    lay.T, lay.dimo, lay.dimag, lay.dimg, lay.dimu, lay.dimtd, lay.dimextra = 50, 40, 12, 12, 4, 4, 13
+    lay.off_o, lay.off_ag, lay.off_g, lay.off_u, lay.off_td, lay.off_extra, lay.row_stride = 0, 40, 52, 64, 68, 72, 88
+    tasks = _lib.Tasks()
+    tasks.ntasks = 4
+    for j in range(4):
+        tasks.len[j] = 3
+    # ---- routed store of several ranks
+    def route(n_ranks=3, n_ep=4, ntasks=4, n_route=4, tab_stride=21, capacity=20000, n_pairs=fake[8], storage=fake[0]):
+        return L.curious_route_store_episodes_ranks(storage, fake[1], C.byref(lay), fake[2], ntasks, n_route, n_ep, n_ranks,
+                                                    fake[3], fake[4], tab_stride, capacity, 7, 1000003, 1, None, fake[5],
+                                                    fake[6], n_pairs, None)
+    assert route(n_ranks=0) != 0 and b'bad rank arguments' in L.curious_last_error()
+    assert route(n_ranks=5000) != 0 and b'bad rank arguments' in L.curious_last_error()
+    assert route(tab_stride=-1) != 0 and b'bad rank arguments' in L.curious_last_error()
+    assert route(storage=None) != 0 and b'NULL argument' in L.curious_last_error()
+    assert route(n_route=5) != 0 and b'bad task / capacity' in L.curious_last_error()
+    assert route(capacity=1 << 31) != 0 and b'bad task / capacity' in L.curious_last_error()
+    assert route(n_ep=1 << 20) != 0 and b'episodes per call' in L.curious_last_error()
+    assert route(n_ranks=19, n_ep=1024, n_route=4) != 0 and b'65 535 pairs' in L.curious_last_error()   # ADVICE r5
+    assert route(n_ep=0) == 0                                                                         # nothing to do
+    assert route() != 0 and b'launch failed' in L.curious_last_error()
+    # ... with the activity test inside the routing launch
+    def act_route(tk=tasks, active=fake[2], n_ranks=3):
+        return L.curious_activity_route_store_episodes(fake[0], fake[1], C.byref(lay), C.byref(tk) if tk is not None else None,
+                                                       72, active, 4, 4, n_ranks, fake[3], fake[4], 21, 20000, 7, 1000003, 1,
+                                                       None, fake[5], fake[6], fake[8], None)
+    assert act_route(tk=None) != 0 and b'NULL argument' in L.curious_last_error()
+    assert act_route(active=None) != 0 and b'NULL argument' in L.curious_last_error()
+    assert act_route(n_ranks=0) != 0 and b'bad rank arguments' in L.curious_last_error()
+    assert act_route() != 0 and b'launch failed' in L.curious_last_error()
+    # ---- the counting env reset
+    E = _lib.EnvCfg()
+    E.ntasks, E.dimo, E.T, E.seed = 4, 40, 50, 1
+    def reset(env=E, n=8, counter=fake[14]):
+        return L.curious_env_reset_count(C.byref(env), C.byref(lay), 0, fake[0], fake[1], fake[2], n, fake[3], fake[4],
+                                         fake[5], fake[6], fake[7], None, counter, 50, None)
+    bad = _lib.EnvCfg()
+    bad.ntasks, bad.dimo, bad.T, bad.seed = 4, 200, 50, 1
+    assert reset(env=bad) != 0 and b'at most 128' in L.curious_last_error()
+    bad.dimo, bad.ntasks = 40, 5
+    assert reset(env=bad) != 0                                                              # layout and env disagree
+    assert reset() != 0 and b'launch failed' in L.curious_last_error()
+    assert reset(counter=None) != 0 and b'launch failed' in L.curious_last_error()           # (the counter is optional)
+    # ---- the several-rank rollout
+    cfg = _lib.NetCfg()
+    cfg.dimo, cfg.dimg, cfg.dimtd, cfg.layers, cfg.dimu, cfg.hidden, cfg.modular = 40, 12, 4, 3, 4, 256, 1
+    cfg.max_u, cfg.gamma, cfg.clip_return, cfg.action_l2, cfg.clip_pos_returns = 1.0, 0.98, 50.0, 1.0, 1
+    G = _lib.RankGroups()
+    G.group, G.seed_stride, G.exploit = 2, 1000003, fake[13].value
+    def rollout(groups=G, n=40, nsteps=50, t0=0, theta=fake[0]):
+        return L.curious_policy_rollout_ranks(C.byref(cfg), theta, n, 200.0, fake[1], 0.2, 0.3, 5, 1, fake[14], fake[2], 4,
+                                              C.byref(E), C.byref(lay), 0, fake[3], fake[4], t0, nsteps, fake[5], fake[6],
+                                              fake[7], fake[8], fake[9], 72, 84, 0.05, fake[10], 0, None, None,
+                                              C.byref(groups) if groups is not None else None, None)
+    assert rollout(nsteps=0) != 0 and b'nsteps must be positive' in L.curious_last_error()
+    neg = _lib.RankGroups()
+    neg.group = -1
+    assert rollout(groups=neg) != 0 and b'negative group size' in L.curious_last_error()
+    assert rollout(theta=None) != 0 and b'NULL argument' in L.curious_last_error()
+    assert rollout(t0=10, nsteps=50) != 0 and b't out of range' in L.curious_last_error()
+    assert rollout() != 0 and b'launch failed' in L.curious_last_error()
+    assert rollout(groups=None) != 0 and b'launch failed' in L.curious_last_error()
+    # ---- the sampler description of several ranks: rank_rows must divide the batch; offsets are 64 bit (pools of 33 GB)
+    sp, rng = _lib.SampleParams(), _lib.SampleRng()
+    sp.future_p, sp.reward_eps, sp.clip_obs = 0.8, 0.05, 200.0
+    BL = _lib.BatchLayout()
+    BL.off_o, BL.off_td, BL.off_u, BL.off_g, BL.off_o2, BL.off_g2, BL.off_r = 0, 40, 44, 48, 60, 100, 112
+    BL.off_ag, BL.off_ag2, BL.off_extra, BL.stride = 113, 125, 137, 152
+    rng.prop_prefix, rng.cur_size, rng.buf_alias, rng.buf_task = fake[8].value, fake[9].value, fake[10].value, fake[11].value
+    rng.nbuf, rng.step_ctr, rng.seed = 5, fake[12].value, 3
+    buf_stride = 20000 * 51 * 88                                   # floats per buffer: 19 x 5 of them are 8.5 G floats
+    def sample(n=19 * 256, rank_rows=256, tab_stride=21):
+        rng.rank_rows, rng.rank_tab_stride, rng.rank_seed_stride = rank_rows, tab_stride, 1000003
+        return L.curious_her_sample(fake[0], buf_stride, C.byref(lay), C.byref(tasks), C.byref(sp), None, C.byref(rng), n,
+                                    fake[1], C.byref(BL), None)
+    assert sample(rank_rows=100) != 0 and b'rank' in L.curious_last_error()
+    assert sample(tab_stride=-1) != 0 and b'rank' in L.curious_last_error()
+    assert sample() != 0 and b'launch failed' in L.curious_last_error()
+    # ---- loss_rows: the batch must be a whole number of ranks
+    cfg.loss_rows = 256
+    nb_ = None
+    rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 300, None, None, fake[3], fake[4],
+                              fake[5], fake[6], fake[12], 0, nb_, None)
+    assert rc != 0 and b'whole number of ranks' in L.curious_last_error()
+    ws = L.curious_workspace_floats(C.byref(cfg), 19 * 256)
+    assert ws > L.curious_workspace_floats(C.byref(cfg), 256)
+    rc = L.curious_ddpg_grads(C.byref(cfg), fake[0], fake[1], fake[2], C.byref(BL), 19 * 256, None, None, fake[3], fake[4],
+                              fake[5], fake[6], fake[12], 0, nb_, None)
+    assert rc != 0 and b'launch failed' in L.curious_last_error()                 # (the 16-row form's host code: rows16)
+    # ---- the options of round 6
+    for name, dflt in ((b'rows16', 1280), (b'dw64', 0), (b'lab_rows_stamps', 0)):
+        assert L.curious_get_option(name) == dflt, name
+        assert L.curious_set_option(name, 7) == 0 and L.curious_get_option(name) == 7
+        assert L.curious_set_option(name, dflt) == 0

@@ -15,4 +15,4 @@ wait
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd $ROOT
 CURIOUS_LIB=$OUT/libcurious_hip_asan.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
-  python -m pytest tests/test_lib_cpu.py -q -k "argument_validation or refuses or host_descriptor or store_slots or transposed_copy or round3_entry or round4_entry" "$@"
+  python -m pytest tests/test_lib_cpu.py -q -k "argument_validation or refuses or host_descriptor or store_slots or transposed_copy or round3_entry or round4_entry or round5_entry" "$@"
