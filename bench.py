@@ -303,7 +303,7 @@ def pmc_traffic_file(virtual_ranks=1):
     """The committed PMC passes of this command: per round; a --virtual-ranks V line has passes of its own or none."""
     suffix = '' if virtual_ranks == 1 else '_virtual_ranks_%d' % virtual_ranks
     return next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_hbm_traffic%s.json' % (r, suffix))
-                             for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), '')
+                             for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p)), '')
 
 
 def pmc_traffic(kernel, virtual_ranks=1):
@@ -315,8 +315,10 @@ def pmc_traffic(kernel, virtual_ranks=1):
         with open(path) as f:
             table = json.load(f)
         tot = {'FETCH_SIZE': [0, 0.0], 'WRITE_SIZE': [0, 0.0]}
+        # (batches of >= 1 280 rows run the 16-row form of the row-local kernels under the same profile id: mlp_rows16.h)
+        names = (kernel, kernel.replace('ddpg_rows_', 'ddpg_rows16_'))
         for name, counters in table.items():                      # template instances: fwd_hot_kernel<true>, <false>
-            if name == kernel or name.startswith(kernel + '<'):
+            if any(name == k or name.startswith(k + '<') for k in names):
                 for c in tot:
                     tot[c][0] += counters[c]['launches']
                     tot[c][1] += counters[c]['launches'] * counters[c]['avg_KB']

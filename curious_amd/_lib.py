@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcurious_hip.so')
 
-ABI_VERSION = 9          # CURIOUS_ABI_VERSION of include/curious_hip.h
+ABI_VERSION = 10         # CURIOUS_ABI_VERSION of include/curious_hip.h
 MAX_TASKS = 16
 MAX_TASK_DIMS = 8
 
@@ -91,7 +91,7 @@ class RankGroups(C.Structure):
 
 
 class EnvCfg(C.Structure):
-    _fields_ = [('ntasks', C.c_int32), ('dimo', C.c_int32), ('T', C.c_int32), ('seed', C.c_uint64)]
+    _fields_ = [('ntasks', C.c_int32), ('dimo', C.c_int32), ('T', C.c_int32), ('wrap', C.c_int32), ('seed', C.c_uint64)]
 
 
 _P = C.c_void_p

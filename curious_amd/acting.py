@@ -105,7 +105,7 @@ class ActingMixin:
 
     Q_ROWS = 4096                 # rows per launch of rollout_q_sum (bounds its workspace: ~110 MB)
 
-    def rollout_q_sum(self, env, T, use_target_net=False):
+    def rollout_q_sum(self, env, T, use_target_net=False, rollouts=None):
         """sum over the T steps of the batch-mean Q of the rollout that was just enqueued for `env` (a GPU scalar) -- what
         RolloutWorker accumulates step by step from get_actions(compute_Q=True) (rollout.py:187-189,226-232; ddpg.py:140-146:
         Q_pi_tf = Q(o_t, g, pi(o_t, g))), computed AFTER the fused rollout from its recorded rows: record row t of an episode
@@ -133,6 +133,11 @@ class ActingMixin:
                                o_stats=self.o_stats.state if self.normalize_obs else None,
                                g_stats=self.g_stats.state if self.normalize_obs else None)
         n_used = getattr(env, 'n_used', n)                           # (idle padding envs and the rows t = T do not count)
+        if rollouts is not None:
+            # a batch of slots (envs.BatchedSyntheticArm wrap): R rollouts of nB envs side by side, the first `used` of every
+            # rollout count -- one value per rollout
+            R, nB, used = rollouts
+            return q.view(R, nB, T + 1)[:, :used, :T].mean(dim=(1, 2)) * T
         return q.view(n, T + 1)[:n_used, :T].mean() * T
 
     def act_and_step(self, env, t, noise_eps=0., random_eps=0., use_target_net=False):

@@ -198,6 +198,8 @@ def load_worker_state(w, st):
             r.set_state(s)
     if 'env' in st:
         _load_env_state(w, st['env'])
+        w.__dict__['_ep_host'] = None                                # (the host mirror of benv.episode: re-read on demand)
+        w.__dict__.pop('_eval_env', None)
     elif 'env_episode' in st:                                        # (format 1)
         w.benv.episode.copy_(st['env_episode'])
 

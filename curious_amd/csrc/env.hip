@@ -23,7 +23,7 @@ __global__ void env_reset_kernel(curious_env_cfg_t E, curious_layout_t L, int32_
   const int32_t epi = episode[e];
   episode[e] = epi + 1;                                     // episodes started so far (the env's step stream reads it)
   for (int s = 0; s < (AG + 3) / 4; ++s) {
-    Philox4 r = philox4x32((uint32_t)(env_id0 + e), (uint32_t)epi, (uint32_t)s, STREAM_RESET,
+    Philox4 r = philox4x32((uint32_t)(env_id0 + env_of_slot(E, e)), (uint32_t)epi, (uint32_t)s, STREAM_RESET,
                            (uint32_t)E.seed, (uint32_t)(E.seed >> 32));
     uint32_t w[4] = {r.x, r.y, r.z, r.w};
     for (int k = 0; k < 4; ++k) {

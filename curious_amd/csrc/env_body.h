@@ -22,6 +22,9 @@ struct EnvConsts {
   float v_hi;                         // o[e][lane + 64] (constant during the episode) when lane + 64 < dimo
 };
 
+// slot -> env (curious_env_cfg_t.wrap: a batch of slots that are the SAME envs at different episodes)
+__device__ __forceinline__ int env_of_slot(const curious_env_cfg_t& E, const int e) { return E.wrap > 0 ? e % E.wrap : e; }
+
 __device__ inline EnvConsts env_consts(const curious_env_cfg_t& E, const curious_layout_t& L,
                                        const int32_t* __restrict__ episode, const int32_t* __restrict__ tasks,
                                        const float* __restrict__ o, const float* __restrict__ g,
@@ -92,7 +95,7 @@ __device__ inline float env_step_core(const curious_env_cfg_t& E, const curious_
                         fabsf(__fsub_rn(grip[2], obj2)));
         if (d < 0.1f && uc[3] < 0.0f) nv = fclip(__fadd_rn(v, delta[k]), -1.0f, 1.0f);
       } else {
-        Philox4 r = philox4x32((uint32_t)(env_id0 + e), C.ep_ctr, (uint32_t)(t * E.ntasks + jt), STREAM_DISTRACT,
+        Philox4 r = philox4x32((uint32_t)(env_id0 + env_of_slot(E, e)), C.ep_ctr, (uint32_t)(t * E.ntasks + jt), STREAM_DISTRACT,
                                (uint32_t)E.seed, (uint32_t)(E.seed >> 32));
         uint32_t wv = (k == 0) ? r.x : ((k == 1) ? r.y : r.z);
         float st = __fmul_rn(0.01f, __fsub_rn(__fmul_rn(2.0f, u01_f32(wv)), 1.0f));

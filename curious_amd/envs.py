@@ -116,10 +116,12 @@ class ResidentRolloutVoid(_lib.CuriousHipError):
 
 
 class BatchedSyntheticArm(ArmSpec):
-    def __init__(self, name, n, seed=0, env_id0=0, T=None, pad_to=1):
+    def __init__(self, name, n, seed=0, env_id0=0, T=None, pad_to=1, wrap=0):
         """pad_to: the batch is filled up to a multiple of it with idle envs (they step like any other env, nobody
         reads their episodes): the one-launch rollout kernels take whole groups of 4 envs, and 19 virtual ranks x 2
-        rollouts (the reference's regime, readme.md:16) are 38.  n_used = the envs that count, n = the envs launched."""
+        rollouts (the reference's regime, readme.md:16) are 38.  n_used = the envs that count, n = the envs launched.
+        wrap > 0: a batch of SLOTS (curious_env_cfg_t.wrap) -- slot i is env env_id0 + i % wrap at the episode episode[i]:
+        several rollouts of the same envs side by side (RolloutWorker.generate_eval_rollouts)."""
         super().__init__(name)
         if T is not None:
             self.T = self._max_episode_steps = int(T)
@@ -127,6 +129,7 @@ class BatchedSyntheticArm(ArmSpec):
         n = (int(n) + pad_to - 1) // pad_to * pad_to
         self.n, self.env_id0 = int(n), int(env_id0)
         self._seed = int(seed)
+        self._wrap = int(wrap)
         dev = torch.device('cuda', torch.cuda.current_device())
         self.device = dev
         self.layout = RecordLayout(self.buffer_shapes(), self.T)
@@ -149,7 +152,7 @@ class BatchedSyntheticArm(ArmSpec):
         self._pin_events = [None] * len(self._pins)
         self._pin_k = 0
         self._goals_dev = self._tg_dev[n:].view(n, 3)
-        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
+        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed, self._wrap)
         # rollout flags written by the last env step: is_success per env + one "an observation is NaN" word
         self.flags = torch.zeros(n + 1, dtype=torch.float32, device=dev)
         self._flags_pin = torch.zeros(n + 1, dtype=torch.float32).pin_memory()
@@ -161,7 +164,7 @@ class BatchedSyntheticArm(ArmSpec):
 
     def seed(self, seed):
         self._seed = int(seed)
-        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed)
+        self._cfg = ops.make_env_cfg(self.nb_tasks, self.dimo, self.T, self._seed, self._wrap)
         self.episode.zero_()
 
     def reset_all(self, tasks, goals_raw, launch=True):
@@ -303,5 +306,5 @@ class EnvFactory:
         self._count += 1
         return e
 
-    def make_batched(self, n, env_id0=0, pad_to=1):
-        return BatchedSyntheticArm(self.name, n, env_id0=env_id0, pad_to=pad_to)
+    def make_batched(self, n, env_id0=0, pad_to=1, wrap=0):
+        return BatchedSyntheticArm(self.name, n, env_id0=env_id0, pad_to=pad_to, wrap=wrap)

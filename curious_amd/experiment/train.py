@@ -213,14 +213,16 @@ def perturb_envs(rollout_worker, evaluator, n=2):
 def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, periodic_policy_path,
          policy_save_interval, save_policies, latest_policy_path, policy, rank, structure, i_policy=None,
          task_experts_cp=None):
-    """train.py:170-214: same keys in progress.csv."""
+    """train.py:170-214: same keys in progress.csv.  (Virtual ranks: a process's values are means over ITS ranks and enter
+    the cross-process mean with that many votes -- the mean over the job's ranks whatever the layout.)"""
+    w = int(getattr(policy, 'V', 1) or 1)
     logger.record_tabular('epoch', epoch)
     for key, val in evaluator.logs('test'):
-        logger.record_tabular(key, "%.3g" % mpi_average(val))
+        logger.record_tabular(key, "%.3g" % mpi_average(val, w))
     for key, val in rollout_worker.logs('train'):
-        logger.record_tabular(key, "%.3g" % mpi_average(val))
+        logger.record_tabular(key, "%.3g" % mpi_average(val, w))
     for key, val in policy.logs():
-        logger.record_tabular(key, "%.3g" % mpi_average(val))
+        logger.record_tabular(key, "%.3g" % mpi_average(val, w))
     if rank == 0:
         if i_policy is not None:
             logger.record_tabular('IND_TASK_rollout', i_policy)
@@ -232,7 +234,7 @@ def logs(rollout_worker, evaluator, epoch, best_success_rate, best_policy_path, 
         logger.dump_tabular()
     else:
         logger._state['kv'].clear()
-    success_rate = mpi_average(evaluator.current_success_rate())
+    success_rate = mpi_average(evaluator.current_success_rate(), w)
     snap = []                                                        # one host copy of the policy for all saves below
 
     def snapshot():

@@ -381,9 +381,9 @@ def param_checksum(theta, out):
           'curious_param_checksum')
 
 
-def make_env_cfg(ntasks, dimo, T, seed):
+def make_env_cfg(ntasks, dimo, T, seed, wrap=0):
     e = _lib.EnvCfg()
-    e.ntasks, e.dimo, e.T, e.seed = int(ntasks), int(dimo), int(T), int(seed) & 0xFFFFFFFFFFFFFFFF
+    e.ntasks, e.dimo, e.T, e.seed, e.wrap = int(ntasks), int(dimo), int(T), int(seed) & 0xFFFFFFFFFFFFFFFF, int(wrap)
     return e
 
 

@@ -84,7 +84,9 @@ class RankSchedulesMixin:
         if self._batch_stale:
             self._sample_packed()
             self._batch_stale = False
-        self._ipc_verdict()                                          # of the previous run (its copy arrived long ago)
+        # the verdict of the previous run (its copy arrived long ago), agreed between the ranks: a rank whose wait gave up
+        # skipped an epoch and its peers copied a stale slice -- every rank raises, at the same point of the job
+        self._ipc_verdict(collective=True)
         p = self._cur
         for i in range(n):
             if (self.Q_adam.t + i) % 100 == 0:
@@ -105,18 +107,26 @@ class RankSchedulesMixin:
         self._keep_alpha_ahead()
         return self._losses[0], self._Q_pi
 
-    def _ipc_verdict(self, wait=True):
+    def _ipc_verdict(self, wait=True, collective=False):
+        """collective (every rank calls at the same point: the head of a run of updates): the ranks agree on the verdict
+        over the host-side group -- ADVICE r5: the timed-out rank alone used to raise, its peers went on with a stale slice
+        until the next check_synced."""
         ipc = getattr(self, '_ipc', None)
-        if ipc is None or not ipc['err_pending']:
+        if ipc is None:
             return
-        if wait:
-            ipc['err_ev'].synchronize()
-        elif not ipc['err_ev'].query():
-            return
-        ipc['err_pending'] = False
-        if int(ipc['err_pin'][0]):
-            raise _lib.CuriousHipError('curious_allreduce_adam_ipc: a wait for a peer rank gave up (rank %d): that epoch '
-                                       "was skipped on this rank, the replicas may differ" % dist.rank())
+        mine = False
+        if ipc['err_pending']:
+            if wait:
+                ipc['err_ev'].synchronize()
+            elif not ipc['err_ev'].query():
+                return
+            ipc['err_pending'] = False
+            mine = bool(int(ipc['err_pin'][0]))
+        anyone = dist.host_any(mine) if collective else mine
+        if anyone:
+            who = ('rank %d' % dist.rank()) if mine else 'a peer rank'
+            raise _lib.CuriousHipError('curious_allreduce_adam_ipc: a wait for a peer rank gave up (%s): that epoch was '
+                                       'skipped there, the replicas may differ' % who)
 
     def _rank_graphs(self):
         """The split update graphs of the several-rank path with an eager collective: A[p] = gradients of the batch in

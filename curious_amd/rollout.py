@@ -19,15 +19,12 @@ import torch
 
 from curious_amd import dist
 from curious_amd.queues import CompetenceQueue, task_probabilities
+from curious_amd.rollout_eval import _NOTHING, EvalRolloutsMixin
 from curious_amd.util import convert_episode_to_batch_major, store_args
 
-# What a slot of the per-rollout task / goal lists holds when this rank has nothing for it (rollout.py:149-150: []).  The
-# batched worker fills hundreds of slots per cycle and the histories keep them all (rollout.py:370-371): ONE shared empty
-# list instead of a new one per slot per cycle (nothing ever appends to a slot; slots are assigned).
-_NOTHING = []
 
 
-class RolloutWorker:
+class RolloutWorker(EvalRolloutsMixin):
     @store_args
     def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1, exploit=False, use_target_net=False,
                  compute_Q=False, noise_eps=0, random_eps=0, history_len=100, render=False, structure='curious',
@@ -163,20 +160,6 @@ class RolloutWorker:
         elif self.eval:
             self.exploit = True
             self.p = 1 / self.nb_tasks * np.ones([self.nb_tasks])
-
-    def generate_eval_rollouts(self, n):
-        """`for _ in range(n): evaluator.generate_rollouts()` (train.py:156-158): same draws, same statistics, same
-        order.  On the batched path of an evaluator the n rollouts are ENQUEUED back to back -- each keeps its flags and its
-        Q sum in a pinned slot of its own -- and waited for once: round 3 waited for every rollout's flags before the next
-        one was even enqueued (10 round trips of host latency per epoch).  Nothing an evaluation rollout draws
-        depends on the previous one's outcome (uniform task probabilities, rollout.py:187-189)."""
-        if not (self.batched and self.eval and n > 1):
-            for _ in range(n):
-                self.generate_rollouts()
-            return
-        finish = [self._generate_rollouts_batched(defer=k) for k in range(n)]
-        for fin in finish:
-            fin()
 
     def generate_rollouts(self):
         """Returns (episode batch, CP, n_episodes) (rollout.py:177-406)."""
@@ -349,32 +332,8 @@ class RolloutWorker:
             # ranks' host-side exchanges have to stay paired.)
             self._any_exploit = True if self.eval else dist.host_any(self.exploit)
         B, env = self._nloc, self.benv
-        # task / goal draws for all envs of this rank at once (vectorised form of rollout.py:120,129)
         experts = isinstance(self.policy, (list, tuple))          # task_experts evaluator (rollout.py:212-224)
-        if redo is not None:
-            tasks, goals = redo
-        elif self.V > 1:
-            # every virtual rank draws for its own envs from its own stream; a rank that exploits draws its tasks from
-            # the uniform distribution (rollout.py:184-186)
-            per = self.rollout_batch_size
-            uni = 1 / self.nb_tasks * np.ones([self.nb_tasks])
-            tasks = np.concatenate([self._rng(v).choice(range(self.nb_tasks), size=per,
-                                                        p=uni if (self._exploit_v[v] or self.eval) else self.p)
-                                    for v in range(self.V)])
-            goals = np.concatenate([self._rng(v).uniform(-1, 1, (per, 3)) for v in range(self.V)]).astype(np.float32)
-        else:
-            tasks = np.random.choice(range(self.nb_tasks), p=self.p, size=B)
-        if experts and redo is None:
-            # the draws are i.i.d., so any order of the envs is the same distribution: sorted by task, every expert's
-            # envs are one contiguous row range of the batched env
-            tasks = np.sort(tasks)
-        if redo is not None or self.V > 1:
-            pass
-        elif self.goal_selection == 'active' and not self.eval:
-            # SAGG-RIAC goals live in goal space; reset_task_goal(directly=True) (rollout.py:143) = raw draw x 2 here
-            goals = np.stack([2.0 * self.goal_selectors[int(ta)].sample_goal() for ta in tasks]).astype(np.float32)
-        else:
-            goals = np.random.uniform(-1, 1, (B, 3)).astype(np.float32)
+        tasks, goals = redo if redo is not None else self._draw_tasks_goals(experts)
         fused = not experts and hasattr(self.policy, 'can_act_and_step') and \
             self.policy.can_act_and_step(env, self.compute_Q)
         # (a rollout that is ONE launch: its reset launch heads the captured rollout, where it also advances the noise base)
@@ -382,6 +341,8 @@ class RolloutWorker:
         env.reset_all(tasks, goals, launch=not one_launch)
         env._reset_pending = one_launch
         self.count += B
+        if self.__dict__.get('_ep_host') is not None:
+            self._ep_host += 1                                    # (mirror of env.episode: the reset advances it)
         q_sum = torch.zeros((), device=env.device) if self.compute_Q else None
         if experts:
             q_sum = self._expert_steps(env, tasks, q_sum)
@@ -488,6 +449,8 @@ class RolloutWorker:
             self._resident_off(err)
             self.policy.rewind_rollout(env, self.T, evaluation=self.eval)
             self.count -= B
+            if self.__dict__.get('_ep_host') is not None:
+                self._ep_host -= 1
             return self._generate_rollouts_batched(retry=True, force_sync=force_sync, n_retry=n_retry + 1,
                                                    redo=(tasks, goals))
         if np.isnan(successful).any() or o_has_nan:
@@ -506,31 +469,6 @@ class RolloutWorker:
             goals_now = 0.5 * goals                               # the envs' goals on their task slots (goal space)
         self._finish_rollout(successful, successful - 1.0, mean_Q, task_list, goals_now)
         return env.episode_views(), self.CP, self.n_episodes
-
-    def _expert_steps(self, env, tasks, q_sum):
-        """The T acting steps with one expert per task (rollout.py:212-224: policy[task_of_env].get_actions per env):
-        expert j acts on the contiguous rows of the envs that drew task j."""
-        B = len(tasks)                                               # (virtual ranks: the envs of all of them)
-        bounds = np.searchsorted(tasks, np.arange(self.nb_tasks + 1))
-        u_all = torch.zeros([env.n, self.dims['u']], dtype=torch.float32, device=env.device)   # (idle padding envs: no action)
-        noise_eps = self.noise_eps if not self.exploit else 0.
-        random_eps = self.random_eps if not self.exploit else 0.
-        for t in range(self.T):
-            for j in range(self.nb_tasks):
-                a, b = int(bounds[j]), int(bounds[j + 1])
-                if a == b:
-                    continue
-                out = self.policy[j].get_actions(env.o[a:b], env.ag[a:b], env.g[a:b], task_descr=env.td[a:b],
-                                                 compute_Q=self.compute_Q, noise_eps=noise_eps, random_eps=random_eps,
-                                                 use_target_net=self.use_target_net)
-                if self.compute_Q:
-                    u, Q = out
-                    q_sum += Q.sum() / B
-                else:
-                    u = out
-                u_all[a:b].copy_(u)
-            env.step_all(u_all, t)
-        return q_sum
 
     # ================================================================== statistics, competence, task probabilities
     def _finish_rollout(self, successful, r_competence, mean_Q, tasks_now, goals_now=None):
@@ -676,6 +614,8 @@ class RolloutWorker:
     def seed(self, seed):
         if self.batched:
             self.benv.seed(seed)
+            self._ep_host = 0
+            self.__dict__.pop('_eval_env', None)
         else:
             for idx, env in enumerate(self.envs):
                 env.seed(seed + 1000 * idx)

@@ -69,14 +69,16 @@ def transitions_in_episode_batch(episode_batch):
     return shape[0] * shape[1]
 
 
-def mpi_average(value):
-    """Cross-rank mean of a scalar / list of scalars (util.py:141-146 -> mpi_moments.py:6-31)."""
+def mpi_average(value, weight=1):
+    """Cross-rank mean of a scalar / list of scalars (util.py:141-146 -> mpi_moments.py:6-31).
+    weight: the ranks this process stands for (virtual ranks: its value is already the mean over them) -- with an uneven
+    layout (19 ranks on 8 processes: 3 3 3 2 2 2 2 2) the plain mean over processes is not the mean over ranks."""
     if isinstance(value, list) and len(value) == 0:
         value = [0.]
     if not isinstance(value, list):
         value = [value]
     x = np.asarray(value, dtype=np.float64)
-    packed = np.array([x.sum(), float(x.size)])
+    packed = np.array([x.sum() * weight, float(x.size) * weight])
     packed = dist.allreduce_sum_numpy(packed)
     return packed[0] / packed[1]
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CURIOUS_ABI_VERSION 9      /* bumped whenever a prototype or struct below changes */
+#define CURIOUS_ABI_VERSION 10     /* bumped whenever a prototype or struct below changes */
 #define CURIOUS_MAX_TASKS 16
 #define CURIOUS_MAX_TASK_DIMS 8
 
@@ -509,6 +509,9 @@ int curious_param_checksum(const float* theta, int64_t n, uint64_t* out, curious
  * 256-284).  state/ record layout: see DESIGN.md "Synthetic env". ---------------------------------- */
 typedef struct curious_env_cfg {
   int32_t ntasks, dimo, T;
+  int32_t wrap;   /* 0: env i of a batch is env env_id0 + i.  > 0 (ABI 10; it sits in what was padding): a batch of SLOTS -- slot
+                   * i is env env_id0 + i % wrap at an episode of its own (episode[i]): the n_test_rollouts evaluation rollouts
+                   * of train.py:156-158, rollout k of env e = slot k * wrap + e, stepped by one launch instead of one per rollout */
   uint64_t seed;
 } curious_env_cfg_t;
 

@@ -363,3 +363,50 @@ def test_bench_lays_the_published_ranks_out_over_the_processes():
     assert abs(rec['env_steps_per_sec'] - 3 * 2 * 50 * per_s) < 1e-3 * rec['env_steps_per_sec']
     c = rec['collectives']
     assert c['rccl']['world'] == 2 and c['replicas_identical'] is True
+
+
+# ------------------------------------------------------------------ evaluation rollouts, several to a launch
+@pytest.mark.parametrize('V,B,nb', [(1, 256, 4), (1, 16, 4), (3, 2, 4), (1, 64, 8)])
+def test_evaluation_rollouts_several_to_a_launch(V, B, nb):
+    """RolloutWorker.generate_eval_rollouts: the n_test_rollouts evaluation rollouts of an epoch (train.py:156-158) as a few
+    launches of up to 1 024 env SLOTS (rollout k of env e = slot k' x n_envs + e, the same env id at the episode that env
+    would be at) against one launch per rollout: the same draws, the same episodes (success flags, tasks, competence queues,
+    counters: identical), test/mean_Q equal to 1e-6 (a mean taken in another order); twice in a row (the episodes of the
+    second evaluation follow the first's), and with training rollouts in between (they advance nothing of the evaluator's).
+    Arm8: the distractor tasks' random walk is keyed by (env id, episode) as well (curious_env_cfg_t.wrap)."""
+    from curious_amd import logger
+    from curious_amd.envs import EnvFactory
+    from curious_amd.rollout import RolloutWorker
+    from test_gpu_round5 import make_agent
+    from test_gpu_agent import T
+    name = 'MultiTaskFetchArm%d-v5' % nb
+    outs = []
+    for slots in (0, 1024):
+        if nb == 4:
+            agent = make_agent(V if V > 1 else None, use_graph=True, rollout_batch_size=B)
+            dims = dict(o=40, u=4, g=12, ag=12, task_descr=4, info_is_success=1)
+        else:
+            from test_gpu_agent import build_pair
+            agent, _ = build_pair(8, 52, rng_mode='device', use_graph=True)
+            dims = dict(o=52, u=4, g=24, ag=24, task_descr=8, info_is_success=1)
+        ev = RolloutWorker(EnvFactory(name), agent, dims, logger, T=T, rollout_batch_size=B, exploit=True, compute_Q=True,
+                           structure='curious', task_selection='active_competence_progress', queue_length=20, eval=True)
+        ev.EVAL_SLOTS = slots
+        ev.seed(21)
+        if V > 1:
+            ev.seed_ranks([31 + v for v in range(V)])
+        np.random.seed(5)
+        rec = []
+        for n in (10, 5):
+            ev.generate_eval_rollouts(n)
+            torch.cuda.synchronize()
+            rec.append((list(ev.success_history)[-n:], list(ev.Q_history)[-n:], list(ev.task_history), ev.n_episodes, ev.count,
+                        [(list(q.successes), q.C, q.CP) for q in ev.competence_computers],
+                        ev.benv.episode.cpu().numpy().copy()))
+        assert (slots > 0) == ('_eval_env' in ev.__dict__)
+        outs.append(rec)
+    for a, b in zip(*outs):
+        assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+        np.testing.assert_array_equal(a[6], b[6])
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-7)
+        assert 0.0 <= min(a[0]) and np.isfinite(a[1]).all()
