@@ -95,6 +95,15 @@ class ActingMixin:
             self._host_io[n] = io
         return io
 
+    def _action_block(self, n):
+        """The [n, dimu] block the fused acting launches leave their actions in: one per batch size, for the agent's
+        lifetime -- captured rollout launches hold its address (a block re-allocated when another env's size came along
+        was written to by the graphs of the first)."""
+        blocks = self.__dict__.setdefault('_act_blocks', {})
+        if n not in blocks:
+            blocks[n] = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+        return blocks[n]
+
     def can_act_and_step(self, env, compute_Q):
         """The fused acting step applies to the GPU-resident synthetic env in throughput mode.  compute_Q (the
         evaluator, train.py:308-319): the fused kernels record no Q -- the rollout's Q values are computed afterwards
@@ -149,8 +158,7 @@ class ActingMixin:
         if ws is None:
             ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
             self._act_ws[n] = ws
-        if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
-            self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+        self._act_u = self._action_block(n)
         self._noise_counter += 1
         from curious_amd.envs import REWARD_EPS
         ops.policy_act_env_step(self.net_cfg, theta, n, self.clip_obs, ws, noise_eps * self.max_u, random_eps,
@@ -184,8 +192,7 @@ class ActingMixin:
         if ws is None:
             ws = torch.zeros(ops.workspace_floats(self.net_cfg, n), dtype=torch.float32, device=self.device)
             self._act_ws[ws_key] = ws
-        if getattr(self, '_act_u', None) is None or self._act_u.shape[0] != n:
-            self._act_u = torch.empty([n, self.dimu], dtype=torch.float32, device=self.device)
+        self._act_u = self._action_block(n)
         if getattr(self, '_noise_base', None) is None:
             self._noise_base = torch.zeros(1, dtype=torch.int64, device=self.device)
             self._noise_base_val = 0
@@ -206,17 +213,23 @@ class ActingMixin:
         if self.V > 1:
             group = getattr(env, 'n_used', n) // self.V            # envs per virtual rank (padding envs: groups >= V)
             ng = (n + group - 1) // group
-            if getattr(self, '_exploit_dev', None) is None or self._exploit_dev.numel() != ng:
-                self._exploit_dev = torch.zeros(ng, dtype=torch.int32, device=self.device)
-                self._exploit_pins = [torch.zeros(ng, dtype=torch.int32).pin_memory() for _ in range(4)]
-                self._exploit_k = 0
-            pin = self._exploit_pins[self._exploit_k]               # (a small ring: the copy is asynchronous)
-            self._exploit_k = (self._exploit_k + 1) % len(self._exploit_pins)
+            # one flag vector PER ENV OBJECT, for its lifetime: the captured rollout launches of an env hold its address
+            # (the evaluator's slot env has another number of groups than the training worker's: a vector shared between
+            #  them was re-allocated at every switch, under the graphs that had captured it)
+            bufs = self.__dict__.setdefault('_exploit_bufs', {})
+            eb = bufs.get(id(env))
+            if eb is None or eb['dev'].numel() != ng:
+                eb = dict(dev=torch.zeros(ng, dtype=torch.int32, device=self.device),
+                          pins=[torch.zeros(ng, dtype=torch.int32).pin_memory() for _ in range(4)], k=0, env=env)
+                bufs[id(env)] = eb
+                self._roll_graphs = {k: g for k, g in self._roll_graphs.items() if k[0] != id(env)}
+            pin = eb['pins'][eb['k']]                               # (a small ring: the copy is asynchronous)
+            eb['k'] = (eb['k'] + 1) % len(eb['pins'])
             pin.zero_()
             if exploit is not None:
                 pin[:self.V] = torch.from_numpy(np.asarray(exploit, dtype=np.int32))
-            self._exploit_dev.copy_(pin, non_blocking=True)
-            groups = ops.rank_groups(group, RANK_SEED_STRIDE, self._exploit_dev)
+            eb['dev'].copy_(pin, non_blocking=True)
+            groups = ops.rank_groups(group, RANK_SEED_STRIDE, eb['dev'])
 
         reset_here = bool(getattr(env, '_reset_pending', False))     # the worker only uploaded the draws (reset_all)
         env._reset_pending = False

@@ -523,6 +523,7 @@ def test_evaluation_rollouts_enqueued_together_equal_one_at_a_time():
                            exploit=True, use_target_net=False, compute_Q=True, structure='curious',
                            task_selection='active_competence_progress', queue_length=6, eval=True)
         ev.seed(21)
+        ev.EVAL_SLOTS = 0          # (the one-launch-per-rollout form; several rollouts to a launch: tests/test_gpu_round6.py)
         np.random.seed(17)
         for epoch in range(2):
             ev.clear_history()
