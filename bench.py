@@ -220,6 +220,11 @@ def kernel_flops_bytes(policy, lay, B_R=B_R, n_experts=1):
     w_critic = l0q + hidw + 2 * H + hidw
     # (4 batch rows per workgroup; 8 from 768 rows on -- csrc/mlp_rows.h ROWS_R2: half the stream per row)
     rows_per_wg = 8 if (B * n_experts >= 768 and B % 32 == 0 and os.environ.get('CURIOUS_ROWS8', '1') != '0') else 4
+    # (16 from `rows16` rows on, single agents: csrc/mlp_rows16.h -- the waves split the output columns)
+    from curious_amd import ops as _ops
+    r16 = _ops.get_option('rows16')
+    if n_experts == 1 and r16 > 0 and B >= r16 and B % 64 == 0:
+        rows_per_wg = 16
     rows_l2_bytes = 4 * (w_actor + w_target + w_critic) * (B // rows_per_wg)
     return dict(
         # the row-local routes (one launch per update / per env step; curious_amd/csrc/mlp_rows*.h)
