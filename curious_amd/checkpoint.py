@@ -19,6 +19,7 @@ One file per process and checkpoint (`training_state/rank003_epoch000050.pt`); r
 AFTER every process has finished its file (a barrier), then the files of older checkpoints go: whatever a job dies in the
 middle of, LATEST.json names a complete set.  `experiment.train --resume DIR` continues from it.
 """
+import copy
 import json
 import os
 import random
@@ -163,7 +164,7 @@ def worker_state(w):
         st['task_history'] = list(w.task_history)
         st['goal_history'] = [list(g) if isinstance(g, (list, tuple)) else g for g in w.goal_history]
     if hasattr(w, 'goal_selectors'):                                 # SAGG-RIAC (plain Python objects)
-        st['goal_selectors'] = w.goal_selectors
+        st['goal_selectors'] = copy.deepcopy(w.goal_selectors)      # (a snapshot: the file may be written behind the loop)
         st['split_histories'] = [list(h) for h in w.split_histories]
     return st
 
@@ -245,10 +246,13 @@ def _file(dirpath, rank, epoch):
     return os.path.join(dirpath, STATE_DIR, 'rank%03d_epoch%06d.pt' % (rank, epoch))
 
 
-def save_job_state(dirpath, epoch, policy, workers, expert_bank=None, loop=None):
+def save_job_state(dirpath, epoch, policy, workers, expert_bank=None, loop=None, writer=None):
     """Collective: every process of the job writes its file for `epoch`, then rank 0 publishes LATEST.json and the files of
     earlier checkpoints are removed.  policy: a DDPG or the list of experts; workers: every RolloutWorker of the process
-    (training workers first, then the evaluator); loop: what the training loop needs to go on (a picklable dict)."""
+    (training workers first, then the evaluator); loop: what the training loop needs to go on (a picklable dict).
+    writer (curious_amd.util.BackgroundWriter; one process only): the state is copied to the host here, the file -- up to
+    20 GB with the reference's 19 ranks on full buffers -- and LATEST.json are written behind the training loop (several
+    processes publish behind a barrier, which stays on the training thread)."""
     policies = _flat(policy)
     workers = [w for w in _flat(workers) if w is not None]
     _settle(policies, workers)
@@ -260,22 +264,35 @@ def save_job_state(dirpath, epoch, policy, workers, expert_bank=None, loop=None)
                  loop=dict(loop or {}), numpy_rng=np.random.get_state(), python_rng=random.getstate(),
                  torch_rng=torch.get_rng_state())
     path = _file(dirpath, dist.rank(), epoch)
-    torch.save(state, path + '.tmp')
-    os.replace(path + '.tmp', path)
-    dist.barrier()                                                   # every file of this checkpoint is complete
     latest = os.path.join(dirpath, STATE_DIR, 'LATEST.json')
-    if dist.rank() == 0:
-        with open(latest + '.tmp', 'w') as f:
-            json.dump(dict(format=FORMAT, epoch=int(epoch), world=dist.world_size()), f)
-        os.replace(latest + '.tmp', latest)
+    world, rank = dist.world_size(), dist.rank()
+
+    def write():
+        torch.save(state, path + '.tmp')
+        os.replace(path + '.tmp', path)
+
+    def publish():
+        if rank == 0:
+            with open(latest + '.tmp', 'w') as f:
+                json.dump(dict(format=FORMAT, epoch=int(epoch), world=world), f)
+            os.replace(latest + '.tmp', latest)
+
+    def sweep():
+        mine = 'rank%03d_epoch' % rank
+        for name in os.listdir(os.path.join(dirpath, STATE_DIR)):
+            if name.startswith(mine) and name != os.path.basename(path):
+                try:
+                    os.remove(os.path.join(dirpath, STATE_DIR, name))
+                except OSError:
+                    pass
+    if writer is not None and world == 1:
+        writer.submit(lambda: (write(), publish(), sweep()))          # (in this order, behind earlier jobs of the writer)
+        return path
+    write()
+    dist.barrier()                                                   # every file of this checkpoint is complete
+    publish()
     dist.barrier()                                                   # ... and published: older files may go
-    mine = 'rank%03d_epoch' % dist.rank()
-    for name in os.listdir(os.path.join(dirpath, STATE_DIR)):
-        if name.startswith(mine) and name != os.path.basename(path):
-            try:
-                os.remove(os.path.join(dirpath, STATE_DIR, name))
-            except OSError:
-                pass
+    sweep()
     return path
 
 

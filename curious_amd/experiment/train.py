@@ -90,7 +90,9 @@ class Checkpointer:
         from curious_amd.checkpoint import save_job_state
         loop = dict(best_success_rate=best_success_rate, ft=(ft.cycle, ft.last, ft.count), elapsed=time.time() - t0)
         loop.update(extra or {})
-        save_job_state(self.dir, epoch, self.policy, self.workers, self.bank, loop)
+        # (the evaluator carries the job's BackgroundWriter while train() runs: the file is written behind the loop)
+        save_job_state(self.dir, epoch, self.policy, self.workers, self.bank, loop,
+                       writer=getattr(self.workers[-1], 'writer', None))
 
 
 def _train(policy, rollout_worker, evaluator, n_epochs, n_test_rollouts, n_cycles, n_batches, policy_save_interval,
