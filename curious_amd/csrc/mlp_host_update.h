@@ -59,6 +59,21 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     } else {
       ns = l0_segments(cfg, off, nullptr, cur, critic, cfg->max_u, seg);
     }
+    // Segments that are neighbours in memory AND in W0 become one problem: the staged batch row is [o | td | u | g | ..], so
+    // the critic's o (40) | td (4) | u (4) are one 48-wide operand -- three strips of 16 rows instead of 3 + 1 + 1, every
+    // one of them a tile that costs what a hidden-layer tile costs (Arm4: 76 -> 64 small tiles per launch).  An element's
+    // sum over the batch rows does not depend on the tile it sits in: the same bits.
+    for (int s = 0; s + 1 < ns - (cfg->modular ? 1 : 0);) {
+      Seg& a = seg[s];
+      const Seg& b = seg[s + 1];
+      if (b.x == a.x + a.w && b.ld == a.ld && b.div == a.div && !a.sub && !b.sub && !a.mean && !b.mean && a.clip == b.clip) {
+        a.w += b.w;
+        for (int t = s + 1; t + 1 < ns; ++t) seg[t] = seg[t + 1];
+        --ns;
+      } else {
+        ++s;
+      }
+    }
     int64_t r = 0;
     for (int s = 0; s < ns; ++s) {
       const bool goal_branch = cfg->modular && s == ns - 1;
