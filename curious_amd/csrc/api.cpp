@@ -101,6 +101,7 @@ CuriousOptions& curious_options() {
     o.rows8 = env_int("CURIOUS_ROWS8", 1) != 0;
     o.rows16 = env_int("CURIOUS_ROWS16", ROWS16_DEFAULT_MIN);
     o.dw64 = env_int("CURIOUS_DW64", 0);
+    o.dw_bal = env_int("CURIOUS_DW_BAL", 1);
     o.dw_split = env_int("CURIOUS_DW_SPLIT", 0);
     o.lab_dw_stamps = 0;
     o.lab_rows_stamps = 0;
@@ -125,6 +126,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "rows8")) return &o.rows8;
   if (!strcmp(name, "rows16")) return &o.rows16;
   if (!strcmp(name, "dw64")) return &o.dw64;
+  if (!strcmp(name, "dw_bal")) return &o.dw_bal;
   if (!strcmp(name, "dw_split")) return &o.dw_split;
   if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
   if (!strcmp(name, "lab_rows_stamps")) return &o.lab_rows_stamps;

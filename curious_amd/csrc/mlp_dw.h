@@ -18,6 +18,7 @@ struct DwSplit { float* pbuf; int32_t* cnt; };               // workspace: [tile
 struct DwSeg { int seg, S; };                                // this workgroup's segment of its tile's S (dw_role)
 #define DW_PART 1088                                         // floats of a partial tile: 16 x 64 + 64 column sums
 #define DW_SPLIT_MIN_B 1024                                  // batches from this size on have the workspace for it
+#define DW_BAL_MIN_B 2048                                   // batches from this size on deal their small problems in halves (dw_role)
 #define DW_SPLIT_MAX 8                                       // segments per tile at most
 #define DW_SPLIT_TILES (4 * 64 + 12 * 16)                    // tiles of a launch at most: 4 hidden matrices + MAX_DW_SMALL x 16 slots
 #define DW_SC1 16                                            // aux bit of a raw buffer access: agent scope
@@ -742,6 +743,18 @@ __device__ __forceinline__ DwRole dw_role(const int n_hot, const int tiles_per, 
   } else {
     int j = r - r_hot * S_hot;
     R.S = S_small; R.seg = j % S_small; j /= S_small;
+    if ((units_s >> 24) & 1) {
+      // balanced (several virtual ranks): every small problem is two HALF problems, and the halves -- the host has sorted the
+      // problems by their number of tiles -- are dealt to the XCDs back and forth (0..7, 7..0, ..).  A small tile reads as
+      // many lines per batch row as a hidden tile; with whole problems on XCDs p % 8 three XCDs carried 12-16 of them beside
+      // their 32 hidden tiles and three none, and the launch ended with the hidden tiles of the loaded ones (19 ranks: 101 k
+      // cycles against 74 k).  R.idx = half problem * hs + slot; dw_tile_role turns it into a tile of the problem
+      const int hs = (slots + 1) >> 1;
+      const int round = j / hs, t = j - round * hs;
+      const int vp = round * 8 + ((round & 1) ? 7 - x : x);
+      R.kind = 3; R.idx = vp * hs + t;
+      return R;
+    }
     const int p = x + 8 * (j / slots);
     R.kind = 2; R.idx = p * slots + j % slots;
   }
@@ -792,7 +805,12 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
                                 R.pi * args.hot.tiles_per + R.idx, DwSeg{R.seg, R.S});
     return;
   }
-  const int pi = R.idx / slots, t = R.idx - pi * slots;
+  int pi = R.idx / slots, t = R.idx - pi * slots, half = -1;
+  if (R.kind == 3) {                                          // (dw_role: half problem * hs + slot)
+    const int hs = (slots + 1) >> 1, vp = R.idx / hs;
+    t = R.idx - vp * hs; pi = vp >> 1; half = vp & 1;
+    if (pi == small_nprob && half) return;
+  }
   if (pi >= small_nprob) {
     // the block right behind the last problem finalises the losses (fin.rows != NULL); any other id beyond exits
     if (pi == small_nprob && t == 0 && R.seg == 0) dw_loss_fin(args.small.fin, red, eo, (int64_t)blockIdx.y * grad_stride);
@@ -807,9 +825,20 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   if (ADAM) pin_adam(A);
   asm volatile("" :: "s"(grad_stride), "s"(M));
   DW_STAMP(sp, 3);
+  int gidx = R.idx;
+  if (half >= 0) {
+    // half 0 / 1 of the problem's tiles in COLUMN-panel-major order: the halves of a layer-0 problem split the panels of dY,
+    // those of an output layer the strips of X (neighbouring strips share cache lines) -- neither half reads what the other reads
+    const int nby = (P.w + 15) >> 4, nx = (P.N + 63) >> 6, T = nby * nx, hT = (T + 1) >> 1;
+    const int tb = half * hT + t;
+    if (t >= hT || tb >= T) return;
+    const int bx = tb / nby, by = tb - bx * nby;
+    t = by * nx + bx;
+    gidx = pi * slots + t;
+  }
   if (t >= ((P.w + 15) >> 4) * ((P.N + 63) >> 6)) return;
   const int64_t eg = (int64_t)blockIdx.y * grad_stride;
-  const int gt = args.n_hot + R.idx;
+  const int gt = args.n_hot + gidx;
   if ((P.N & 3) != 0) dw_small_tile<ADAM, false, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
   else if (P.div != 1.0f) dw_small_tile<ADAM, true, PIPE, true>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
   else dw_small_tile<ADAM, true, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
@@ -832,8 +861,12 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
+// (the pipelined form with 4 waves per SIMD: 113 registers instead of 113 + 20 accumulation registers, and a fourth workgroup
+//  per CU -- the small tiles and the gather blocks of a several-rank launch, whose lives are round trips to memory, wait less
+//  for a place: 17.0 -> 16.7 ms per cycle at 19 ranks; the one-chunk kernel keeps the compiler's choice, 3)
+#define DW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 1, PIPE ? 4 : 8)))
 template <bool PIPE, bool T64 = false>
-__global__ __launch_bounds__(256) void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
+__global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
                                                           int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
                                                           int64_t grad_stride, uint64_t seed_stride) {
   __shared__ __attribute__((aligned(16))) float red[T64 ? DW64_LDS : 4 * 16 * 64];

@@ -108,13 +108,23 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     // matrices divide the 8 XCDs evenly (2 or 4 of them: 4 or 2 XCDs each)
     DwMap map;
     memset(&map, 0, sizeof(map));
+    // several virtual ranks: the small problems in halves, dealt evenly over the XCDs (mlp_dw.h dw_role; option "dw_bal")
+    const bool xcd_ok = curious_options().dw_xcd && (hwAll.nprob == 2 || hwAll.nprob == 4) &&
+                        (hwAll.tiles_per == 64 || hwAll.tiles_per == 16);
+    // (measured, us per launch with / without: 19 ranks 45.7 / 47.8, 8 ranks 24.8 / 25.0, 3 ranks 15.6 / 14.8 -- from 8 ranks on)
+    const bool bal = xcd_ok && B >= DW_BAL_MIN_B && xd.nex == 1 && curious_options().dw_bal;
+    if (bal) {
+      auto ntiles = [](const DwSmall& q) { return ((q.w + 15) / 16) * ((q.N + 63) / 64); };
+      std::stable_sort(smAll.p, smAll.p + smAll.nprob, [&](const DwSmall& a, const DwSmall& b) { return ntiles(a) > ntiles(b); });
+    }
     auto dw_grid = [&](int n_her, int S_hot = 1, int S_small = 1) -> int {
       const int np = hwAll.nprob;
-      if (curious_options().dw_xcd && (np == 2 || np == 4) && (hwAll.tiles_per == 64 || hwAll.tiles_per == 16)) {
+      if (xcd_ok) {
         map.units = 8 / np;
         map.r_hot = hwAll.tiles_per / map.units;
         map.r_her = (n_her + 7) / 8;
-        const int r_small = smAll.slots * ((smAll.nprob + 1 + 7) / 8);      // + 1: the loss finalisation
+        const int r_small = bal ? ((smAll.slots + 1) / 2) * ((2 * smAll.nprob + 1 + 7) / 8)
+                                : smAll.slots * ((smAll.nprob + 1 + 7) / 8);      // + 1: the loss finalisation
         const int gx_ = 8 * (map.r_her + map.r_hot * S_hot + r_small * S_small);
         if (B > 256) map.r_her = -map.r_her;                  // several virtual ranks: the gather blocks come last (DwMap)
         return gx_;
@@ -129,6 +139,9 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     if (w.split && xd.nex == 1 && B % 256 == 0 && tAll + nsmall <= DW_SPLIT_TILES) {
       const int C = B / 256, opt = curious_options().dw_split;
       S_small = std::min(4, C / 2);
+      // (dealt in halves, an XCD holds 8 + 2 small tiles: in 3 segments that is 30 workgroups on its 32 CUs, one beside each
+      //  hidden tile -- with 4 segments 8 CUs carried two; 19 ranks 45.9 -> 41.9 us per launch, 8 ranks 24.9 -> 21.8)
+      if (bal) S_small = 3;
       if (opt > 0) { S_hot = opt / 10; S_small = opt % 10; }
       if (t64) S_hot = DW_SPLIT_MAX;                          // 64 tiles x 8 = 512 workgroups
       S_hot = std::max(1, std::min(S_hot, std::min(DW_SPLIT_MAX, C)));
@@ -139,7 +152,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     if (tail && (!tail->her || her_lds_bytes(&tail->h.L) <= sizeof(float) * 4 * 16 * 64)) {
       const int n_her = tail->her ? (tail->h.n + SPB - 1) / SPB : 0;
       const int gx = dw_grid(n_her, S_hot, S_small);
-      const int units_s = map.units | (S_hot << 8) | (S_small << 16);
+      const int units_s = map.units | (S_hot << 8) | (S_small << 16) | ((bal && map.units) ? 1 << 24 : 0);
       if (dwAll.stamps && (int64_t)gx * 8 * 2 > 6 * 16 * (int64_t)B) dwAll.stamps = nullptr;   // (room: part[0..5])
       { ProfScope ps__(CK_DW_ADAM_HER, st);
         const AdamFuse& af = tail->adam;
@@ -164,7 +177,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
     { ProfScope ps__(CK_DW, st);
       const int gx = dw_grid(0, S_hot, S_small);
-      const int units_s = map.units | (S_hot << 8) | (S_small << 16);
+      const int units_s = map.units | (S_hot << 8) | (S_small << 16) | ((bal && map.units) ? 1 << 24 : 0);
       if (B <= 256)
         hipLaunchKernelGGL(dw_all_kernel<false>, dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per, hwAll.nprob,
                            smAll.slots, smAll.nprob, 0, map.r_her, map.r_hot, units_s, (int64_t)xd.stride, dwAll,

@@ -36,6 +36,7 @@ def main():
     nb = 6 * 16 * B // 16
     st = ops.dw_stamps(p.net_cfg, B, p._workspace, nb)
     names = {1: 'gather', 2: 'hidden tile', 3: 'small tile / fin'}
+    a_kind = None
     print('V = %d, %d rows; dw64 = %d, dw_xcd = %d' % (V, B, ops.get_option('dw64'), ops.get_option('dw_xcd')))
     with ops.option('lab_dw_stamps', 1):
         for rep in range(3):
@@ -43,6 +44,7 @@ def main():
             upd()
             torch.cuda.synchronize()
         a = st.cpu().numpy().astype(np.int64)
+    a[a[:, 4] == 4, 4] = 3                                       # (small tiles dealt in halves: dw_role kind 3)
     live = a[:, 4] > 0
     t0 = a[live, 5].min()
     print('%-18s %6s | life k cycles: mean  max | starts (us after the first block): min  mean  max | ends ~ (us): mean  max'
@@ -58,6 +60,37 @@ def main():
         print('%-18s %6d | %19.1f %6.1f | %38.1f %6.1f %6.1f | %18.1f %6.1f' %
               (names[kind], sel.sum(), life.mean() / 1e3, life.max() / 1e3, start.min(), start.mean(), start.max(),
                end.mean(), end.max()))
+    # hidden tiles in detail: by XCD (block id & 7), and the phases of the slowest / fastest tenth
+    sel = live & (a[:, 4] == 2) & (a[:, 3] > a[:, 0])
+    ids = np.nonzero(sel)[0]
+    r = a[sel]
+    life = (r[:, 3] - r[:, 0]) / 1e3
+    head, loop, tail = (r[:, 1] - r[:, 0]) / 1e3, (r[:, 2] - r[:, 1]) / 1e3, (r[:, 3] - r[:, 2]) / 1e3
+    print('hidden tiles by XCD: ' + '  '.join('%d: %.0f/%.0f' % (x, life[(ids & 7) == x].mean(), life[(ids & 7) == x].max())
+                                              for x in range(8) if ((ids & 7) == x).any()) + '   (k cycles mean/max)')
+    order = np.argsort(life)
+    n10 = max(1, len(order) // 10)
+    for name, pick in (('fastest tenth', order[:n10]), ('median tenth', order[len(order) // 2 - n10 // 2:][:n10]), ('slowest tenth', order[-n10:])):
+        print('%-14s life %6.1f = head %5.1f + loop %6.1f + tail %5.1f k cycles; start %5.2f us; ids e.g. %s' %
+              (name, life[pick].mean(), head[pick].mean(), loop[pick].mean(), tail[pick].mean(),
+               ((r[pick, 5] - t0) / 100.0).mean(), ids[pick][:8].tolist()))
+    # the same split by the row (block id >> 3) within the hidden rows: which (tile, segment) rows are slow
+    rows = ids >> 3
+    ur = np.unique(rows)
+    print('by block row (mean life k cycles): ' + ' '.join('%d:%.0f' % (q, life[rows == q].mean()) for q in ur[:80]))
+    # the slowest small tiles: block id, tile index (problem * slots + tile), life, start
+    sel = live & (a[:, 4] == 3) & (a[:, 3] > a[:, 0])
+    ids = np.nonzero(sel)[0]
+    r = a[sel]
+    life = (r[:, 3] - r[:, 0]) / 1e3
+    order = np.argsort(-life)[:24]
+    print('slowest small tiles (block id, index, life k cycles = head + loop + tail, start us):')
+    for i in order:
+        print('   %5d %4d  %6.1f = %5.1f + %5.1f + %5.1f   %5.1f' % (ids[i], r[i, 7], life[i], (r[i, 1] - r[i, 0]) / 1e3,
+              (r[i, 2] - r[i, 1]) / 1e3, (r[i, 3] - r[i, 2]) / 1e3, (r[i, 5] - t0) / 100.0))
+    idx = r[:, 7]
+    print('small tiles by index (mean life k cycles over the segments): ' +
+          ' '.join('%d:%.0f' % (q, life[idx == q].mean()) for q in np.unique(idx)))
     ops.prof_collect()
     ops.prof_enable(True)
     for _ in range(100):
