@@ -844,8 +844,12 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
   else dw_small_tile<ADAM, true, PIPE, false>(P, M, A, t, red, eo, eg, sp, early, &args.split, gt, DwSeg{R.seg, R.S});
 }
 
+// (the pipelined form with 4 waves per SIMD: 113 registers instead of 113 + 20 accumulation registers, and a fourth workgroup
+//  per CU -- the small tiles and the gather blocks of a several-rank launch, whose lives are round trips to memory, wait less
+//  for a place: 17.0 -> 16.7 ms per cycle at 19 ranks; the one-chunk kernel keeps the compiler's choice, 3)
+#define DW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 1, PIPE ? 4 : 8)))
 template <bool PIPE, bool T64 = false>
-__global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
+__global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
                                                      int64_t grad_stride) {
   __shared__ __attribute__((aligned(16))) float red[T64 ? DW64_LDS : 4 * 16 * 64];
   AdamFuse none;
@@ -861,10 +865,6 @@ __global__ __launch_bounds__(256) void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
-// (the pipelined form with 4 waves per SIMD: 113 registers instead of 113 + 20 accumulation registers, and a fourth workgroup
-//  per CU -- the small tiles and the gather blocks of a several-rank launch, whose lives are round trips to memory, wait less
-//  for a place: 17.0 -> 16.7 ms per cycle at 19 ranks; the one-chunk kernel keeps the compiler's choice, 3)
-#define DW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 1, PIPE ? 4 : 8)))
 template <bool PIPE, bool T64 = false>
 __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
                                                           int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
