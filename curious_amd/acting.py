@@ -112,7 +112,8 @@ class ActingMixin:
                 and self.dimu == 4 and hasattr(env, 'step_all')
                 and getattr(env, 'dimo', None) == self.dimo and getattr(env, 'nb_tasks', None) == self.dimtd)
 
-    Q_ROWS = 4096                 # rows per launch of rollout_q_sum (bounds its workspace: ~110 MB)
+    Q_ROWS = 13056                # rows per launch of rollout_q_sum: one rollout of 256 envs x (T + 1 = 51) rows -- 816
+                                  # workgroups of 16 rows, three to a CU (policy_fwd16_kernel); bounds the workspace
 
     def rollout_q_sum(self, env, T, use_target_net=False, rollouts=None):
         """sum over the T steps of the batch-mean Q of the rollout that was just enqueued for `env` (a GPU scalar) -- what
@@ -132,8 +133,10 @@ class ActingMixin:
                             torch.zeros(ops.workspace_floats(self.net_cfg, chunk), dtype=torch.float32, device=self.device))
         q, u, ws = self._q_rows
         o_, g_, ag_, td_ = lay.off['o'], lay.off['g'], lay.off['ag'], lay.off['task_descr']
-        for r0 in range(0, rows.shape[0], u.shape[0]):
-            blk = rows[r0:r0 + u.shape[0]]
+        # (a batch of slots whose last rollouts are idle: only the rows of the first `live` rollouts are evaluated)
+        n_rows = rows.shape[0] if rollouts is None or len(rollouts) < 4 else rollouts[3] * rollouts[1] * (T + 1)
+        for r0 in range(0, n_rows, u.shape[0]):
+            blk = rows[r0:min(r0 + u.shape[0], n_rows)]
             m = blk.shape[0]
             ops.policy_forward(self.net_cfg, theta, blk[:, o_:o_ + self.dimo], blk[:, g_:g_ + self.dimg],
                                blk[:, td_:td_ + self.dimtd] if self.dimtd > 0 else None, m, self.clip_obs, ws, u[:m],
@@ -144,8 +147,9 @@ class ActingMixin:
         n_used = getattr(env, 'n_used', n)                           # (idle padding envs and the rows t = T do not count)
         if rollouts is not None:
             # a batch of slots (envs.BatchedSyntheticArm wrap): R rollouts of nB envs side by side, the first `used` of every
-            # rollout count -- one value per rollout
-            R, nB, used = rollouts
+            # rollout count -- one value per rollout (a fourth entry: only that many rollouts are live, the values of the
+            # rest are stale)
+            R, nB, used = rollouts[:3]
             return q.view(R, nB, T + 1)[:, :used, :T].mean(dim=(1, 2)) * T
         return q.view(n, T + 1)[:n_used, :T].mean() * T
 

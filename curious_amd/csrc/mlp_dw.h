@@ -847,7 +847,7 @@ __device__ __forceinline__ void dw_tile_role(const DwRole& R, const DwAllArgs& a
 // (the pipelined form with 4 waves per SIMD: 113 registers instead of 113 + 20 accumulation registers, and a fourth workgroup
 //  per CU -- the small tiles and the gather blocks of a several-rank launch, whose lives are round trips to memory, wait less
 //  for a place: 17.0 -> 16.7 ms per cycle at 19 ranks; the one-chunk kernel keeps the compiler's choice, 3)
-#define DW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PIPE ? 4 : 1, PIPE ? 4 : 8)))
+#define DW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((PIPE && !T64) ? 4 : 1, (PIPE && !T64) ? 4 : 8)))
 template <bool PIPE, bool T64 = false>
 __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_all_kernel(DW_ROUTE_PARAMS, int64_t ex_stride, DwAllArgs args,
                                                      int64_t grad_stride) {

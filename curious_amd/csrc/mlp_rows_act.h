@@ -180,3 +180,84 @@ __global__ __launch_bounds__(256) void policy_rows_kernel(ActRowsArgs a) {
   const float Q = rows_head1(x, wq) + bq;
   if (x.lane == 0) a.out_Q[m] = Q;
 }
+
+// ---- the plain forward (no env step) for SIXTEEN rows per workgroup (mlp_rows16.h): batches of >= FWD16_MIN rows -- the
+// evaluator's Q values, one actor + critic forward over the [n x (T + 1)] recorded rows of its rollouts
+// (DDPG.rollout_q_sum: 13 056 rows per rollout of 256 envs).  The 4-row form above pulls every layer's 256 KB for 4 rows
+// (4 096 rows: 62 us); here the waves split the output columns of 16 rows on v_mfma_f32_16x16x4 and the output layers run
+// on the matrix unit too -- the target group of ddpg_rows16_kernel with the main networks and two outputs.  The hidden
+// layers sum over k in the order of mlp_rows16.h: the oracle's values at 1e-5, not the bits of the 4-row form.
+#define FWD16_MIN 1024
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROWS16_WAVES, ROWS16_WAVES)))
+void policy_fwd16_kernel(ActRowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+  constexpr int R = ROWS_R3;
+  RCtx x;
+  x.dbg = nullptr;
+  x.hs = rows_lds;
+  x.hn = x.hs + R * RLD;
+  x.part = x.part2 = nullptr;
+  x.xin = x.hn + R * RLD;
+  x.sm = x.xin + R * XLD;
+  x.keep = nullptr; x.kb = x.kb2 = 0;
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63;
+  x.r0 = blockIdx.x * R;
+  const int Sa = a.dimo + a.dimtd, Sc = Sa + 4, G = a.dimg;
+  const float* pp = a.pi.th;
+  const float* qp = a.q.th;
+  f32x4 wb[2][16];
+  r16_l0_load8(wb[0], pp + a.pi.W0, Sa, pp + a.pi.Wg, Sa + G, x.wave, x.lane, 0);
+  const float bpi = pp[a.pi.bout + (x.lane & 3)];
+  {
+    const int tot = Sc + G;
+    const float c = (a.clip > 0.f) ? a.clip : INFINITY;
+    for (int idx = x.tid; idx < R * tot; idx += 256) {
+      const int i = idx / tot, k = idx - i * tot;
+      const int64_t r = x.r0 + i;
+      float v;
+      if (k < a.dimo) {
+        v = fclip(a.o[r * a.ldo + k], -c, c);
+        if (a.o_mean) v = fclip(fdiv(__fsub_rn(v, a.o_mean[k]), a.o_std[k]), -a.nclip, a.nclip);     // actor_critic.py:76-83
+      } else if (k < Sa) {
+        v = a.td[r * a.ldtd + (k - a.dimo)];
+      } else if (k < Sc) {
+        v = 0.f;
+      } else {
+        v = a.g[r * a.ldg + (k - Sc)];
+        if (a.ag) v = __fsub_rn(v, a.ag[r * a.ldag + (k - Sc)]);
+        v = fclip(v, -c, c);
+        if (a.g_mean) v = fclip(fdiv(__fsub_rn(v, a.g_mean[k - Sc]), a.g_std[k - Sc]), -a.nclip, a.nclip);
+      }
+      x.xin[i * XLD + k] = v;
+    }
+  }
+  __syncthreads();
+  r16_l0_fwd(x, wb, pp + a.pi.W0, Sa, pp + a.pi.Wg, G, Sc, pp + a.pi.b0, -1, nullptr, rnext(RN_FWD, pp + a.pi.W[1]));
+  const RNext after = a.out_Q ? rnext(RN_L0, qp + a.q.W0, Sc, qp + a.q.Wg, Sc + G) : rnext(RN_NONE, nullptr);
+  for (int l = 1; l < a.nl; ++l)
+    r16_big_fwd(x, wb, pp + a.pi.W[l], pp + a.pi.b[l], -1, nullptr,
+                (l + 1 < a.nl) ? rnext(RN_FWD, pp + a.pi.W[l + 1]) : after);
+  const int row = 4 * x.wave + ((x.lane & 15) >> 2);          // lane L < 16 of wave w finishes row 4 w + (L >> 2) (r16_thin_sum)
+  {
+    float bf[16];
+    r16_frag_cols4(bf, pp + a.pi.Wout, x.wave, x.lane);
+    const float z = r16_thin_sum(x, r16_thin(x, bf));
+    if (x.lane < 16) {
+      const float v = a.max_u * tanhf(z + bpi);                                              // actor_critic.py:89
+      a.out_pi[(int64_t)(x.r0 + row) * a.ldpi + (x.lane & 3)] = v;
+      x.xin[row * XLD + Sa + (x.lane & 3)] = fdiv(v, a.max_u);                               // actor_critic.py:93
+    }
+  }
+  if (!a.out_Q) return;
+  const float bq = qp[a.q.bout];
+  __syncthreads();
+  r16_l0_fwd(x, wb, qp + a.q.W0, Sc, qp + a.q.Wg, G, Sc, qp + a.q.b0, -1, nullptr, rnext(RN_FWD, qp + a.q.W[1]));
+  for (int l = 1; l < a.nl; ++l)
+    r16_big_fwd(x, wb, qp + a.q.W[l], qp + a.q.b[l], -1, nullptr,
+                (l + 1 < a.nl) ? rnext(RN_FWD, qp + a.q.W[l + 1]) : rnext(RN_NONE, nullptr));
+  float bf[16];
+  r16_frag_rows(bf, qp + a.q.Wout, 1, x.wave, x.lane);
+  const float Q = r16_thin_sum(x, r16_thin(x, bf)) + bq;
+  if (x.lane < 16 && (x.lane & 3) == 0) a.out_Q[x.r0 + row] = Q;
+}
+

@@ -84,7 +84,7 @@ class EvalRolloutsMixin:
                                         evaluation=True)
             q_pin = None
             if self.compute_Q:
-                q = self.policy.rollout_q_sum(big, T, use_target_net=self.use_target_net, rollouts=(per, nB, used))
+                q = self.policy.rollout_q_sum(big, T, use_target_net=self.use_target_net, rollouts=(per, nB, used, R))
                 while len(self._eval_q_pins) <= j:
                     self._eval_q_pins.append(torch.zeros(per, dtype=torch.float32).pin_memory())
                 q_pin = self._eval_q_pins[j]

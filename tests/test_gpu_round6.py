@@ -410,3 +410,71 @@ def test_evaluation_rollouts_several_to_a_launch(V, B, nb):
         np.testing.assert_array_equal(a[6], b[6])
         np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-7)
         assert 0.0 <= min(a[0]) and np.isfinite(a[1]).all()
+
+
+@pytest.mark.parametrize('case', range(6))
+def test_big_policy_forward_sixteen_rows_vs_oracle(case):
+    """curious_policy_forward on >= 1 024 rows takes 16 rows per workgroup (mlp_rows_act.h policy_fwd16_kernel: the
+    evaluator's Q pass over the recorded rows of its rollouts, DDPG.rollout_q_sum; ddpg.py:129-147): pi and Q(pi) within
+    1e-5 of the float64 oracle -- 2-3 hidden layers, 1-8 tasks, normalised inputs, relative goals, with and without Q --
+    and within 1e-5 of the 4-row form (another order of the sums over k, not another result)."""
+    from curious_amd import ops
+    from oracle.ddpg import preprocess_og
+    from oracle.networks import DDPGMath
+    from test_gpu_kernels import dev
+    rs = np.random.RandomState(4100 + case)
+    nb, dimo = int(rs.randint(1, 9)), int(rs.randint(5, 60))
+    G = 3 * nb
+    n = int(rs.choice([1024, 2048, 13056, 4096 + 16]))
+    layers = int(rs.randint(2, 4))
+    max_u = float(rs.choice([1.0, 2.0]))
+    clip = float(rs.choice([200.0, 2.0]))
+    m64 = DDPGMath(dimo, G, 4, nb, 256, layers, max_u, 0.98, 50., True, 1.0, True, np.float64)
+    m32 = DDPGMath(dimo, G, 4, nb, 256, layers, max_u, 0.98, 50., True, 1.0, True, np.float32)
+    theta = m32.init(rs)
+    norm, relative, with_q = case % 3 == 1, case % 3 == 2, case != 4
+    ncfg = ops.make_net_cfg(dimo, G, 4, nb, 256, layers, True, max_u, 0.98, 50., 1.0, normalize_obs=norm, norm_clip=5.0)
+    o = (rs.randn(n, dimo) * 3).astype(np.float32)
+    g = rs.randn(n, G).astype(np.float32)
+    ag = rs.randn(n, G).astype(np.float32)
+    td = np.eye(nb, dtype=np.float32)[rs.randint(nb, size=n)]
+    stats = {}
+    if norm:
+        for key, d in (('o', dimo), ('g', G)):
+            mean, std = (rs.randn(d) * 0.3).astype(np.float32), (0.5 + rs.rand(d)).astype(np.float32)
+            st = np.zeros(4 * d + 1, np.float32)
+            st[2 * d] = 1
+            st[2 * d + 1:3 * d + 1] = mean
+            st[3 * d + 1:] = std
+            stats[key] = (mean, std, dev(st))
+    ws = torch.zeros(ops.workspace_floats(ncfg, n), device='cuda')
+    th, do, dg, dtd, dag = dev(ops.pad_params(ncfg, theta)), dev(o), dev(g), dev(td), dev(ag)
+
+    def run():
+        pi = torch.full([n, 4], float('nan'), device='cuda')
+        Q = torch.full([n, 1], float('nan'), device='cuda') if with_q else None
+        ops.policy_forward(ncfg, th, do, dg, dtd, n, clip, ws, pi, Q, ag=dag, relative_goals=relative,
+                           o_stats=stats['o'][2] if norm else None, g_stats=stats['g'][2] if norm else None)
+        torch.cuda.synchronize()
+        return pi.cpu().numpy(), (Q.cpu().numpy() if with_q else None)
+    ops.prof_collect()
+    ops.prof_enable(True)
+    pi16, q16 = run()
+    ops.prof_enable(False)
+    assert ops.prof_collect().get('policy_rows_kernel', (0, 0))[0] == 1          # (one launch: both forms report under this name)
+    with ops.option('rows16', 0):
+        pi4, q4 = run()
+    oc, gc = preprocess_og(o, ag, g, clip, relative)
+    if norm:
+        oc = np.clip((oc.astype(np.float32) - stats['o'][0]) / stats['o'][1], -5, 5)
+        gc = np.clip((gc.astype(np.float32) - stats['g'][0]) / stats['g'][1], -5, 5)
+    Qp, pip = m64.split(theta.astype(np.float64))
+    want_pi, _, _ = m64.actor(pip, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64))
+    tag = 'case %d: n %d nb %d dimo %d layers %d' % (case, n, nb, dimo, layers)
+    np.testing.assert_allclose(pi16, want_pi, rtol=1e-5, atol=2e-6 * max_u, err_msg=tag)
+    np.testing.assert_allclose(pi16, pi4, rtol=1e-5, atol=2e-6 * max_u, err_msg=tag)
+    assert not np.array_equal(pi16, pi4) or layers < 2, 'the 16-row form did not run'
+    if with_q:
+        want_Q, _ = m64.critic(Qp, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64), want_pi / max_u)
+        np.testing.assert_allclose(q16, want_Q, rtol=1e-5, atol=4e-6, err_msg=tag)
+        np.testing.assert_allclose(q16, q4, rtol=1e-5, atol=4e-6, err_msg=tag)
