@@ -478,3 +478,34 @@ def test_big_policy_forward_sixteen_rows_vs_oracle(case):
         want_Q, _ = m64.critic(Qp, oc.astype(np.float64), td.astype(np.float64), gc.astype(np.float64), want_pi / max_u)
         np.testing.assert_allclose(q16, want_Q, rtol=1e-5, atol=4e-6, err_msg=tag)
         np.testing.assert_allclose(q16, q4, rtol=1e-5, atol=4e-6, err_msg=tag)
+
+
+def test_several_rank_paths_of_eight_virtual_ranks_leave_the_same_bits():
+    """Eight virtual ranks (2 048 rows: the 16-row kernels, the small weight-gradient problems dealt to the XCDs in halves
+    and reduced in 3 segments, mlp_dw.h dw_role) through the fused update (gradients + Adam + gather in dw_adam_her_kernel)
+    and through the several-process path on a one-rank RCCL communicator (dw_all_kernel, all-reduce, adam_her_kernel; eager
+    and captured): the same parameters bit for bit after 35 updates -- and other bits than with the problems kept whole
+    (the balanced map did apply), within the rounding of another order of the partial sums."""
+    import socket
+    import subprocess
+    import sys
+    digests = {}
+    for name, extra in (('fused', {}), ('eager', {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '0'}),
+                        ('captured', {'CURIOUS_FORCE_DIST': '1', 'CURIOUS_GRAPH_ALLREDUCE': '1'}),
+                        ('whole', {'CURIOUS_DW_BAL': '0'})):
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   CURIOUS_RANK_CHECK_V='8')
+        env.pop('CURIOUS_GRAPH_ALLREDUCE', None)
+        env.update(extra)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rank_path_check.py')], env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1].split()
+        assert line[2] == '35'
+        digests[name] = (line[1], float(line[3]))
+    assert digests['fused'][0] == digests['eager'][0] == digests['captured'][0], digests
+    assert digests['whole'][0] != digests['fused'][0]
+    assert abs(digests['whole'][1] - digests['fused'][1]) <= 1e-3 * abs(digests['fused'][1]), digests

@@ -18,8 +18,10 @@ def main():
     np.random.seed(1234 + 1000000 * dist.rank())                # train.py:242 (the rollouts' task / goal draws)
     if os.environ.get('CURIOUS_RANK_CHECK_STRUCTURE') == 'task_experts':
         return experts_main()
-    params, dims, policy, worker = bench.build_job(use_graph=os.environ.get('CURIOUS_RANK_CHECK_NOGRAPH', '0') != '1')
-    bench.prefill(policy, 256, seed=dist.rank())
+    V = int(os.environ.get('CURIOUS_RANK_CHECK_V', '1'))        # virtual ranks per process (DDPG virtual_ranks)
+    params, dims, policy, worker = bench.build_job(use_graph=os.environ.get('CURIOUS_RANK_CHECK_NOGRAPH', '0') != '1',
+                                                   b_r=2 if V > 1 else 256, virtual_ranks=V)
+    bench.prefill(policy, 256 if V == 1 else 2048, seed=dist.rank())
     for _ in range(5):
         policy.train()
     policy.train_batches(30)
