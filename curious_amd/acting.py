@@ -135,15 +135,17 @@ class ActingMixin:
         o_, g_, ag_, td_ = lay.off['o'], lay.off['g'], lay.off['ag'], lay.off['task_descr']
         # (a batch of slots whose last rollouts are idle: only the rows of the first `live` rollouts are evaluated)
         n_rows = rows.shape[0] if rollouts is None or len(rollouts) < 4 else rollouts[3] * rollouts[1] * (T + 1)
-        for r0 in range(0, n_rows, u.shape[0]):
-            blk = rows[r0:min(r0 + u.shape[0], n_rows)]
-            m = blk.shape[0]
-            ops.policy_forward(self.net_cfg, theta, blk[:, o_:o_ + self.dimo], blk[:, g_:g_ + self.dimg],
-                               blk[:, td_:td_ + self.dimtd] if self.dimtd > 0 else None, m, self.clip_obs, ws, u[:m],
-                               q[r0:r0 + m].view(m, 1), ag=blk[:, ag_:ag_ + self.dimag],
-                               relative_goals=self.relative_goals,
-                               o_stats=self.o_stats.state if self.normalize_obs else None,
-                               g_stats=self.g_stats.state if self.normalize_obs else None)
+        # (option fwd16: these forwards may take the 16-row form -- the values to 1e-6, not the bits of get_actions)
+        with ops.option('fwd16', 1):
+            for r0 in range(0, n_rows, u.shape[0]):
+                blk = rows[r0:min(r0 + u.shape[0], n_rows)]
+                m = blk.shape[0]
+                ops.policy_forward(self.net_cfg, theta, blk[:, o_:o_ + self.dimo], blk[:, g_:g_ + self.dimg],
+                                   blk[:, td_:td_ + self.dimtd] if self.dimtd > 0 else None, m, self.clip_obs, ws, u[:m],
+                                   q[r0:r0 + m].view(m, 1), ag=blk[:, ag_:ag_ + self.dimag],
+                                   relative_goals=self.relative_goals,
+                                   o_stats=self.o_stats.state if self.normalize_obs else None,
+                                   g_stats=self.g_stats.state if self.normalize_obs else None)
         n_used = getattr(env, 'n_used', n)                           # (idle padding envs and the rows t = T do not count)
         if rollouts is not None:
             # a batch of slots (envs.BatchedSyntheticArm wrap): R rollouts of nB envs side by side, the first `used` of every

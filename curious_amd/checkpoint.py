@@ -23,11 +23,14 @@ import copy
 import json
 import os
 import random
+from itertools import islice, repeat
 
 import numpy as np
 import torch
 
 from curious_amd import dist
+
+HISTORY_TAIL = 100             # entries of a worker's task / goal history a checkpoint keeps (worker_state)
 
 STATE_DIR = 'training_state'
 FORMAT = 2
@@ -161,8 +164,14 @@ def worker_state(w):
     if hasattr(w, 'competence_computers'):
         st['p'] = np.asarray(w.p).copy()
         st['queues'] = [(list(q.successes), q.C, q.CP) for q in w.competence_computers]
-        st['task_history'] = list(w.task_history)
-        st['goal_history'] = [list(g) if isinstance(g, (list, tuple)) else g for g in w.goal_history]
+        # The histories grow by a rollout's worth of entries per cycle for the whole job (rollout.py:392-393: unbounded upstream
+        # too) and only the last 100 tasks are ever read (the '%_task' columns, rollout.py:475): their length and their last
+        # HISTORY_TAIL entries are the state -- pickling two million entries took the writer thread, and the epoch beside it,
+        # up to 0.7 s per checkpoint 250 epochs into a job
+        for name in ('task_history', 'goal_history'):
+            h = getattr(w, name)
+            tail = list(islice(reversed(h), HISTORY_TAIL))[::-1]
+            st[name] = dict(n=len(h), tail=[list(g) if isinstance(g, (list, tuple, np.ndarray)) else g for g in tail])
     if hasattr(w, 'goal_selectors'):                                 # SAGG-RIAC (plain Python objects)
         st['goal_selectors'] = copy.deepcopy(w.goal_selectors)      # (a snapshot: the file may be written behind the loop)
         st['split_histories'] = [list(h) for h in w.split_histories]
@@ -183,10 +192,15 @@ def load_worker_state(w, st):
             q.successes.clear()
             q.successes.extend(succ)
             q.C, q.CP = C, CP
-        w.task_history.clear()
-        w.task_history.extend(st['task_history'])
-        w.goal_history.clear()
-        w.goal_history.extend(st.get('goal_history', []))
+        for name in ('task_history', 'goal_history'):
+            h, saved = getattr(w, name), st.get(name, [])
+            h.clear()
+            if isinstance(saved, dict):                              # length + tail; the entries in front are placeholders
+                from curious_amd.rollout_eval import _NOTHING
+                h.extend(repeat(_NOTHING, saved['n'] - len(saved['tail'])))
+                h.extend(saved['tail'])
+            else:                                                    # (files written before the histories were cut)
+                h.extend(saved)
     if 'goal_selectors' in st:
         w.goal_selectors = st['goal_selectors']
         for h, saved in zip(w.split_histories, st['split_histories']):

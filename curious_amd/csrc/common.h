@@ -102,6 +102,9 @@ struct CuriousOptions {
   int dw64;            // > 0 (A/B; default 0 = never): from this many batch rows on the hidden matrices' weight gradients are 64 x 64
                        //    tiles staged through LDS, 8 workgroups per tile (mlp_dw.h dw_hot_tile64) -- built and measured in round
                        //    6, no faster than the 16 x 64 tiles (19 ranks: 53.9 against 51.0 us), DESIGN 4.7          [CURIOUS_DW64]
+  int fwd16;           // 1: curious_policy_forward on >= 1 024 rows (a multiple of 16) takes 16 rows per workgroup (mlp_rows_act.h
+                       //    policy_fwd16_kernel) -- another order of the sums over k than the 4-row form the fused acting kernels share:
+                       //    off by default, DDPG.rollout_q_sum (the evaluator's Q pass) switches it on around its calls
   int dw_bal;          // 1: batches of several chunks deal the small weight-gradient problems over the XCDs in halves   [CURIOUS_DW_BAL]
   int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h
                        //    DwSplit; batches of >= 1 024 rows); 10 S_hot + S_small: fixed (A/B)       [CURIOUS_DW_SPLIT]

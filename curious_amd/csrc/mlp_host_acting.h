@@ -91,8 +91,9 @@ static int launch_policy_rows(ActRowsArgs& a, int n, hipStream_t st) {
     lds = act_rows_lds_floats(1) * sizeof(float);
   }
   CURIOUS_CHECK(lds_big || lds <= 64 * 1024, "policy_rows_kernel: the device refused %zu bytes of dynamic LDS", lds);
-  if (!a.fused && n >= FWD16_MIN && n % ROWS_R3 == 0 && curious_options().rows16 > 0 && a.nl >= 2) {
-    // big plain forwards (the evaluator's Q pass): 16 rows per workgroup (mlp_rows_act.h policy_fwd16_kernel)
+  if (!a.fused && n >= FWD16_MIN && n % ROWS_R3 == 0 && curious_options().fwd16 && curious_options().rows16 > 0 && a.nl >= 2) {
+    // big plain forwards on request (option fwd16: the evaluator's Q pass): 16 rows per workgroup (mlp_rows_act.h
+    // policy_fwd16_kernel); without the option every forward keeps the bits of the fused acting kernels
     ProfScope ps__(CK_ACT_ROWS, st);
     hipLaunchKernelGGL(policy_fwd16_kernel, dim3(n / ROWS_R3), dim3(256), rows_lds_floats(ROWS_R3, a.nl) * sizeof(float), st, a);
     CURIOUS_LAUNCH_CHECK("policy_fwd16_kernel");

@@ -414,7 +414,7 @@ def test_evaluation_rollouts_several_to_a_launch(V, B, nb):
 
 @pytest.mark.parametrize('case', range(6))
 def test_big_policy_forward_sixteen_rows_vs_oracle(case):
-    """curious_policy_forward on >= 1 024 rows takes 16 rows per workgroup (mlp_rows_act.h policy_fwd16_kernel: the
+    """curious_policy_forward on >= 1 024 rows with option fwd16 takes 16 rows per workgroup (mlp_rows_act.h policy_fwd16_kernel: the
     evaluator's Q pass over the recorded rows of its rollouts, DDPG.rollout_q_sum; ddpg.py:129-147): pi and Q(pi) within
     1e-5 of the float64 oracle -- 2-3 hidden layers, 1-8 tasks, normalised inputs, relative goals, with and without Q --
     and within 1e-5 of the 4-row form (another order of the sums over k, not another result)."""
@@ -459,11 +459,14 @@ def test_big_policy_forward_sixteen_rows_vs_oracle(case):
         return pi.cpu().numpy(), (Q.cpu().numpy() if with_q else None)
     ops.prof_collect()
     ops.prof_enable(True)
-    pi16, q16 = run()
+    with ops.option('fwd16', 1):
+        pi16, q16 = run()
     ops.prof_enable(False)
     assert ops.prof_collect().get('policy_rows_kernel', (0, 0))[0] == 1          # (one launch: both forms report under this name)
-    with ops.option('rows16', 0):
-        pi4, q4 = run()
+    pi4, q4 = run()                                                  # (the default: the 4-row form of the fused acting kernels)
+    with ops.option('fwd16', 1), ops.option('rows16', 0):
+        pi4b, _ = run()
+    np.testing.assert_array_equal(pi4, pi4b)
     oc, gc = preprocess_og(o, ag, g, clip, relative)
     if norm:
         oc = np.clip((oc.astype(np.float32) - stats['o'][0]) / stats['o'][1], -5, 5)

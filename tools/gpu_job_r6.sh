@@ -54,6 +54,8 @@ timeout 200 python bench.py --structure task_experts --virtual-ranks 3 --steps 2
 timeout 200 python bench.py --env MultiTaskFetchArm8-v5 --rollout-batch-size 1024 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_arm8_1024env.json 2> $O/bench_arm8_1024env.err
 head -c 600 $O/bench_kernel_stats.csv; cat $O/pmc_hbm.txt | tail -20; tail -n 2 $O/*.err
 timeout 200 python tools/cycle_timeline.py 2>&1 | grep -v amdgpu.ids > $O/cycle_timeline.txt
+# (block stamps of the weight-gradient launch: a build with -DDW_STAMPS, python tools/build_variant.py dwst -DDW_STAMPS)
+[ -f abtest/dwst.so ] && CURIOUS_LIB=abtest/dwst.so timeout 200 python tools/dw_timeline.py 19 2>&1 | grep -v amdgpu.ids | cut -c1-400 > $O/dw_timeline_v19.txt
 for V in 19 8 3; do timeout 200 python tools/rows_stamps.py $V 2>&1 | grep -v amdgpu.ids > $O/rows_stamps_v$V.txt; done
 CURIOUS_ROWS16=0 timeout 200 python tools/rows_stamps.py 19 2>&1 | grep -v amdgpu.ids > $O/rows_stamps_v19_eight_rows.txt
 cd $O && export PYTHONPATH=$R
