@@ -60,6 +60,14 @@ def main():
         print('%-18s %6d | %19.1f %6.1f | %38.1f %6.1f %6.1f | %18.1f %6.1f' %
               (names[kind], sel.sum(), life.mean() / 1e3, life.max() / 1e3, start.min(), start.mean(), start.max(),
                end.mean(), end.max()))
+    # when the arguments of a tile had arrived (stamp 3, dw_tile_role) and when its operand loads were out (stamp 1)
+    for kind in (2, 3):
+        sel = live & (a[:, 4] == kind) & (a[:, 3] > a[:, 0]) & (a[:, 1] > a[:, 0]) & (a[:, 6] > a[:, 0])
+        if sel.any():
+            r = a[sel]
+            print('%-18s entry -> arguments in %5.1f k cycles -> operand loads out %5.1f k -> products done %5.1f k -> exit %5.1f k  (means over %d blocks that did a tile)'
+                  % (names[kind], (r[:, 6] - r[:, 0]).mean() / 1e3, (r[:, 1] - r[:, 6]).mean() / 1e3,
+                     (r[:, 2] - r[:, 1]).mean() / 1e3, (r[:, 3] - r[:, 2]).mean() / 1e3, sel.sum()))
     # hidden tiles in detail: by XCD (block id & 7), and the phases of the slowest / fastest tenth
     sel = live & (a[:, 4] == 2) & (a[:, 3] > a[:, 0])
     ids = np.nonzero(sel)[0]
