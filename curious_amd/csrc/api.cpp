@@ -101,7 +101,7 @@ CuriousOptions& curious_options() {
     o.rows8 = env_int("CURIOUS_ROWS8", 1) != 0;
     o.rows16 = env_int("CURIOUS_ROWS16", ROWS16_DEFAULT_MIN);
     o.dw64 = env_int("CURIOUS_DW64", 0);
-    o.dw_bal = env_int("CURIOUS_DW_BAL", 1);
+    o.dw_bal = env_int("CURIOUS_DW_BAL", DW_BAL_MIN_B);
     o.fwd16 = 0;
     o.dw_split = env_int("CURIOUS_DW_SPLIT", 0);
     o.lab_dw_stamps = 0;

@@ -80,6 +80,7 @@ enum {
 extern int g_curious_prof_on;
 
 // ---------------------------------------------------------------- run-time options (curious_set_option)
+#define DW_BAL_MIN_B 1280       // batches from this size on deal their small weight-gradient problems in halves (mlp_dw.h dw_role)
 #define ROWS16_DEFAULT_MIN 1280      // batch rows from which the 16-row form of the row-local update is taken (option rows16)
 struct CuriousOptions {
   int rows;            // 1: row-local routes (mlp_rows.h, mlp_rows_act.h); 0: tiled multi-launch routes      [CURIOUS_ROWS]
@@ -105,7 +106,8 @@ struct CuriousOptions {
   int fwd16;           // 1: curious_policy_forward on >= 1 024 rows (a multiple of 16) takes 16 rows per workgroup (mlp_rows_act.h
                        //    policy_fwd16_kernel) -- another order of the sums over k than the 4-row form the fused acting kernels share:
                        //    off by default, DDPG.rollout_q_sum (the evaluator's Q pass) switches it on around its calls
-  int dw_bal;          // 1: batches of several chunks deal the small weight-gradient problems over the XCDs in halves   [CURIOUS_DW_BAL]
+  int dw_bal;          // = N: batches of >= N rows deal their small weight-gradient problems over the XCDs in halves, 3 segments each
+                       //    (mlp_dw.h dw_role); default DW_BAL_MIN_B = 1 280, 0 = never                                  [CURIOUS_DW_BAL]
   int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h
                        //    DwSplit; batches of >= 1 024 rows); 10 S_hot + S_small: fixed (A/B)       [CURIOUS_DW_SPLIT]
   int lab_rows_stamps; // LAB ONLY (tools/rows_stamps.py): every row group of ddpg_rows_kernel writes its phase stamps into the workspace

@@ -18,7 +18,6 @@ struct DwSplit { float* pbuf; int32_t* cnt; };               // workspace: [tile
 struct DwSeg { int seg, S; };                                // this workgroup's segment of its tile's S (dw_role)
 #define DW_PART 1088                                         // floats of a partial tile: 16 x 64 + 64 column sums
 #define DW_SPLIT_MIN_B 1024                                  // batches from this size on have the workspace for it
-#define DW_BAL_MIN_B 2048                                   // batches from this size on deal their small problems in halves (dw_role)
 #define DW_SPLIT_MAX 8                                       // segments per tile at most
 #define DW_SPLIT_TILES (4 * 64 + 12 * 16)                    // tiles of a launch at most: 4 hidden matrices + MAX_DW_SMALL x 16 slots
 #define DW_SC1 16                                            // aux bit of a raw buffer access: agent scope

@@ -111,8 +111,9 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     // several virtual ranks: the small problems in halves, dealt evenly over the XCDs (mlp_dw.h dw_role; option "dw_bal")
     const bool xcd_ok = curious_options().dw_xcd && (hwAll.nprob == 2 || hwAll.nprob == 4) &&
                         (hwAll.tiles_per == 64 || hwAll.tiles_per == 16);
-    // (measured, us per launch with / without: 19 ranks 45.7 / 47.8, 8 ranks 24.8 / 25.0, 3 ranks 15.6 / 14.8 -- from 8 ranks on)
-    const bool bal = xcd_ok && B >= DW_BAL_MIN_B && xd.nex == 1 && curious_options().dw_bal;
+    // (measured, us per launch with -- in 3 segments -- / without: 19 ranks 41.9 / 47.8, 8 ranks 21.8 / 25.0, 7 ranks 20.7 / 24.9,
+    //  6 ranks 18.5 / 22.4, 5 ranks 17.8 / 19.3, 4 ranks 17.1 / 16.3, 3 ranks 15.6 / 14.8: from 5 ranks = 1 280 rows on)
+    const bool bal = xcd_ok && curious_options().dw_bal > 0 && B >= curious_options().dw_bal && xd.nex == 1;
     if (bal) {
       auto ntiles = [](const DwSmall& q) { return ((q.w + 15) / 16) * ((q.N + 63) / 64); };
       std::stable_sort(smAll.p, smAll.p + smAll.nprob, [&](const DwSmall& a, const DwSmall& b) { return ntiles(a) > ntiles(b); });

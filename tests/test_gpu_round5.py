@@ -468,7 +468,7 @@ def test_split_reduction_of_the_weight_gradient_tiles(graph):
     from curious_amd import ops
     V = 5                                                             # 1 280 rows: 5 chunks of 256
     outs = {}
-    for S, rep in ((11, 0), (12, 0), (12, 1), (33, 0), (25, 0), (81, 0), (0, 0)):
+    for S, rep in ((11, 0), (12, 0), (12, 1), (13, 0), (33, 0), (25, 0), (81, 0), (0, 0)):
         with ops.option('dw_split', S):
             agent = make_agent(V, use_graph=graph)
             draw = rank_episodes(V, 12)
@@ -491,7 +491,7 @@ def test_split_reduction_of_the_weight_gradient_tiles(graph):
         assert np.isfinite(o[3]).all() and np.abs(o[3] - ref[3]).max() < 5e-3, key
     for a, b in zip(outs[(12, 0)], outs[(12, 1)]):                    # the same run twice
         np.testing.assert_array_equal(a, b)
-    for a, b in zip(outs[(0, 0)], outs[(12, 0)]):                     # 0 = by batch size: 5 chunks -> small tiles in 2 segments
+    for a, b in zip(outs[(0, 0)], outs[(13, 0)]):                     # 0 = by batch size: from 1 280 rows on, small tiles in 3 segments
         np.testing.assert_array_equal(a, b)
     assert np.abs(outs[(33, 0)][0] - ref[0]).max() > 0                # (the split did happen)
 

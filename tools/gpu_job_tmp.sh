@@ -1,4 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/$1; O=$PWD/gpurun_out/$1
-CURIOUS_LIB=abtest/dwst.so timeout 300 python tools/dw_timeline.py 1 2>&1 | grep -v amdgpu.ids | cut -c1-900 > $O/tl_v1.txt
-cat $O/tl_v1.txt
+mkdir -p gpurun_out/$1; O=gpurun_out/$1
+timeout 2400 python -m pytest tests -q -x -m gpu 2>&1 | tail -6 > $O/tests.txt
+cat $O/tests.txt
