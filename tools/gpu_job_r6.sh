@@ -36,7 +36,7 @@ find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.c
 cp $O/pmc_hbm_traffic.json profiles/r06_pmc_hbm_traffic.json; cp $O/pmc_hbm_traffic_virtual_ranks_19.json profiles/r06_pmc_hbm_traffic_virtual_ranks_19.json
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?" >> $O/bench_default.err
 timeout 400 python bench.py --virtual-ranks 19 > $O/bench_virtual_ranks_19.json 2> $O/bench_virtual_ranks_19.err
-for V in 2 3 5 8 12 16; do timeout 200 python bench.py --virtual-ranks $V --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_virtual_ranks_$V.json 2> $O/bench_virtual_ranks_$V.err; done
+for V in 2 3 4 5 6 7 8 12 16; do timeout 200 python bench.py --virtual-ranks $V --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_virtual_ranks_$V.json 2> $O/bench_virtual_ranks_$V.err; done
 timeout 200 python bench.py --num-cpu 19 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_num_cpu_19_one_gpu.json 2> $O/bench_num_cpu_19_one_gpu.err
 CURIOUS_ROWS16=0 timeout 200 python bench.py --virtual-ranks 19 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_virtual_ranks_19_eight_rows.json 2> /dev/null
 CURIOUS_DW64=1280 timeout 200 python bench.py --virtual-ranks 19 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_virtual_ranks_19_dw64.json 2> /dev/null
@@ -83,5 +83,5 @@ a=list(csv.DictReader(open('learn_num_cpu19_16_progress.csv'))); b=list(csv.Dict
 for r in a + b: r.pop('Time', None)
 print('resumed job == uninterrupted job, cell for cell:', a == b, len(a), len(b))
 t=np.array([float(m.group(1)) for m in re.finditer(r"over in\s+([0-9.]+)\s+s", open("soak.log").read())])
-print(len(t), "epochs of the soak; ms per epoch: first 100 %.1f, last 100 %.1f, median %.1f" % (1e3*t[:100].mean(), 1e3*t[-100:].mean(), 1e3*np.median(t)))
+print(len(t), "epochs of the soak; ms per epoch: first 100 %.1f, last 100 %.1f, median %.1f; epochs over 150 ms: %d" % (1e3*t[:100].mean(), 1e3*t[-100:].mean(), 1e3*np.median(t), int((t > 0.15).sum())))
 PY
