@@ -900,7 +900,10 @@ __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE
   if (st && threadIdx.x == 0) {
     st[0] = stamp.t[0]; st[1] = stamp.t[1]; st[2] = stamp.t[2]; st[3] = __builtin_readcyclecounter();
     st[4] = (unsigned long long)(R.kind + 1); st[5] = rt0;
-    st[6] = stamp.t[3]; st[7] = (unsigned long long)R.idx;
+    // (+ where the block ran: HW_ID (wave / SIMD / CU / SH / SE) in bits 32-47 of word 7, XCC_ID in bits 48-51)
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    st[6] = stamp.t[3];
+    st[7] = (unsigned long long)(unsigned)R.idx | ((unsigned long long)(hw & 0xffffu) << 32) | ((unsigned long long)(xcc & 0xfu) << 48);
   }
 #endif
 }

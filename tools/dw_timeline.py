@@ -46,6 +46,18 @@ def main():
         a = st.cpu().numpy().astype(np.int64)
     a[a[:, 4] == 4, 4] = 3                                       # (small tiles dealt in halves: dw_role kind 3)
     live = a[:, 4] > 0
+    # where every block ran (a[:, 7] bits 32..: HW_ID, XCC_ID): CU key = (xcc, se, sh, cu)
+    hw = (a[:, 7] >> 32) & 0xffff
+    cu_key = (((a[:, 7] >> 48) & 0xf) << 12) | (((hw >> 13) & 0x7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+    a[:, 7] &= 0xffffffff
+    if live.any():
+        kinds = {}
+        busy = live & (a[:, 3] - a[:, 0] > 4000)                    # (blocks that found a tile / transitions to do)
+        for k, c in zip(a[busy, 4], cu_key[busy]):
+            kinds.setdefault(int(c), []).append(int(k))
+        from collections import Counter
+        mix = Counter(''.join(sorted('gHs'[k - 1] if 1 <= k <= 3 else '?' for k in v)) for v in kinds.values())
+        print('%d CUs seen; blocks per CU by kind (g gather, H hidden tile, s small tile): %s' % (len(kinds), dict(mix)))
     t0 = a[live, 5].min()
     print('%-18s %6s | life k cycles: mean  max | starts (us after the first block): min  mean  max | ends ~ (us): mean  max'
           % ('kind', 'blocks'))
