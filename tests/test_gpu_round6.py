@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('V,graph', [(2, 0), (2, 1), (3, 0), (8, 1)])
 def test_sixteen_rows_per_workgroup_match_the_oracle(V, graph):
-    """Option rows16 = N: batches of >= N rows take the 16-row form (default 2 048 rows = 8 ranks; here forced from 1 row
+    """Option rows16 = N: batches of >= N rows take the 16-row form (default 1 280 rows = 5 ranks; here forced from 1 row
     on).  Another order of summation over k than the 4- / 8-row forms, so the check is the oracle's: the V-rank test of
     round 5 (per-rank losses 1e-5, one oracle Adam step from the summed oracle gradients, normalisers, Polyak) run through
     the 16-row kernels -- ddpg.py:419-449, actor_critic.py:51-98, util.py:73-107, mpi_adam.py:26-35."""
