@@ -198,3 +198,37 @@ def test_adam_step_size_table_equals_the_scalar_formula():
             want = np.array([ops.adam_alpha(lr, int(t), b1, b2) for t in ts])
             got = ops.adam_alpha_table(lr, ts, b1, b2)
             assert got.dtype == np.float32 and np.array_equal(got, want)
+
+
+def test_checkpointed_worker_histories_are_length_and_tail():
+    """curious_amd.checkpoint.worker_state keeps, of the ever-growing task / goal histories (rollout.py:392-393), their
+    length and their last HISTORY_TAIL entries -- all the '%_task' columns ever read (rollout.py:475); load_worker_state
+    restores a history of that length with that tail, and a second checkpoint of the restored worker equals the first."""
+    from collections import deque
+    from curious_amd import checkpoint as ck
+    from curious_amd.queues import CompetenceQueue
+
+    def worker(n):
+        w = types.SimpleNamespace(n_episodes=7, C=np.zeros(2), CP=np.ones(2), success_history=deque([1.0, 0.0]),
+                                  reward_history=deque([-1.0]), Q_history=deque(), count=3, exploit=False, envs=[],
+                                  _vrng=[np.random.RandomState(5)], p=np.array([0.5, 0.5]),
+                                  competence_computers=[CompetenceQueue(window=4), CompetenceQueue(window=4)],
+                                  task_history=deque(int(i % 2) for i in range(n)),
+                                  goal_history=deque([float(i), 0.0, 1.0] if i % 3 else [] for i in range(n)))
+        w.settle = lambda: None
+        return w
+    src = worker(250)
+    st = ck.worker_state(src)
+    assert st['task_history']['n'] == 250 and st['task_history']['tail'] == [int(i % 2) for i in range(150, 250)]
+    assert st['goal_history']['n'] == 250 and len(st['goal_history']['tail']) == ck.HISTORY_TAIL
+    dst = worker(3)
+    ck.load_worker_state(dst, st)
+    assert len(dst.task_history) == 250 and list(dst.task_history)[-100:] == list(src.task_history)[-100:]
+    assert len(dst.goal_history) == 250 and list(dst.goal_history)[-1] == list(src.goal_history)[-1]
+    again = ck.worker_state(dst)
+    assert again['task_history'] == st['task_history'] and again['goal_history'] == st['goal_history']
+    short = ck.worker_state(worker(30))                                # shorter than the tail: everything is kept
+    assert short['task_history']['n'] == 30 and len(short['task_history']['tail']) == 30
+    old = dict(st, task_history=[0, 1, 1], goal_history=[[1.0], [2.0]])   # a file written before the histories were cut
+    ck.load_worker_state(dst, old)
+    assert list(dst.task_history) == [0, 1, 1] and len(dst.goal_history) == 2
