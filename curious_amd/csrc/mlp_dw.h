@@ -864,7 +864,10 @@ __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_all_kernel(DW_ROUTE_PARA
 // the layer-0 gradient tiles of this launch still read).
 // Batched experts: blockIdx.y = expert; its slab offset shifts every pointer except the (shared) replay storage, its
 // sampler seed is h.rng.seed + expert * seed_stride.
-template <bool PIPE, bool T64 = false>
+// ADAM = false (curious_ddpg_grads with `next` on batches of >= 1 280 rows: several processes, several virtual ranks each): the
+// gradients only, as dw_all_kernel, WITH the gather blocks -- ridden in the row-local launch instead, as smaller batches have
+// it, the gather of 4 864 transitions ends that launch 11 us late (19 ranks: 120.7 us against 109.4)
+template <bool PIPE, bool T64 = false, bool ADAM = true>
 __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE_PARAMS, const int32_t* fault0, const int64_t* ctr0,
                                                           int64_t ex_stride, DwAllArgs args, AdamFuse A, HerArgs h,
                                                           int64_t grad_stride, uint64_t seed_stride) {
@@ -885,6 +888,11 @@ __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE
     her_sample_body(h, R.idx, red, eo, (uint64_t)blockIdx.y * seed_stride, 0, sp);
 #endif
   } else if (R.kind > 0) {
+    if constexpr (!ADAM) {
+      AdamFuse none;
+      none.fault = nullptr;
+      dw_tile_role<false, PIPE, T64>(R, args, none, slots, small_nprob, red, eo, grad_stride, nullptr, nullptr);
+    } else {
     // the optimiser's two scalar inputs (fault word, step counter): their pointers came with the wave, so the loads go
     // out before the first argument is fetched from memory (fault0 / ctr0 == A.fault / A.step_ctr or a valid dummy)
     AdamEarly early;
@@ -894,6 +902,7 @@ __global__ __launch_bounds__(256) DW_WAVES_ATTR void dw_adam_her_kernel(DW_ROUTE
       early.lo = (int32_t)c; early.hi = (int32_t)(c >> 32);
     }
     dw_tile_role<true, PIPE, T64>(R, args, A, slots, small_nprob, red, eo, grad_stride, sp, &early);
+    }
   }
 #ifdef DW_STAMPS
   unsigned long long* st = dw_stamp_base(args);

@@ -41,6 +41,8 @@ struct DdpgPass {
   // counter's increment moves to the weight-gradient launch (mlp_rows.h RowsArgs.n_her)
   bool gather_in_rows = false;
   HerArgs her_rows;
+  bool gather_in_dw = false;      // (gradients only, big batches: the gather rides in the weight-gradient launch; her_rows holds it)
+  bool gather_done = false;       // ... and that launch took it
   bool xn_rows = false;       // the row-local launch of this pass keeps the NORMALISED layer-0 input rows in w.xn
   RowsArgs ra;
   size_t ra_lds = 0;

@@ -305,8 +305,9 @@ typedef struct curious_next_batch {
  * next (may be NULL; multi-rank training, where the optimiser is a launch of its own behind the all-reduce): the gather
  * of the NEXT update's batch (ddpg.py:251-360, device-drawn plan keyed by THIS call's step_ctr: next->rng->step_ctr ==
  * step_ctr) is part of this call -- on the row-local route it runs in spare workgroups of the gradient launch, hidden
- * behind the layer chains (elsewhere: a launch behind the gradients).  Same batch as curious_her_sample called right
- * after this call; next->batch must not alias `batch`. */
+ * behind the layer chains; batches of the 16-row form (>= 1 280 rows: several virtual ranks) have it in extra blocks of
+ * the weight-gradient launch instead (elsewhere: a launch behind the gradients).  Same batch as curious_her_sample called
+ * right after this call; next->batch must not alias `batch`. */
 int curious_ddpg_grads(const curious_net_cfg_t* cfg, const float* theta_main, const float* theta_target,
                        const float* batch, const curious_batch_layout_t* BL, int32_t B,
                        const float* o_stats, const float* g_stats, float* workspace, float* grad,
