@@ -103,6 +103,7 @@ CuriousOptions& curious_options() {
     o.dw64 = env_int("CURIOUS_DW64", 0);
     o.dw_bal = env_int("CURIOUS_DW_BAL", DW_BAL_MIN_B);
     o.fwd16 = 0;
+    o.gather_dw = env_int("CURIOUS_GATHER_DW", ROWS16_DEFAULT_MIN);
     o.dw_split = env_int("CURIOUS_DW_SPLIT", 0);
     o.lab_dw_stamps = 0;
     o.lab_rows_stamps = 0;
@@ -129,6 +130,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "dw64")) return &o.dw64;
   if (!strcmp(name, "dw_bal")) return &o.dw_bal;
   if (!strcmp(name, "fwd16")) return &o.fwd16;
+  if (!strcmp(name, "gather_dw")) return &o.gather_dw;
   if (!strcmp(name, "dw_split")) return &o.dw_split;
   if (!strcmp(name, "lab_dw_stamps")) return &o.lab_dw_stamps;
   if (!strcmp(name, "lab_rows_stamps")) return &o.lab_rows_stamps;

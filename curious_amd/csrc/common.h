@@ -106,6 +106,8 @@ struct CuriousOptions {
   int fwd16;           // 1: curious_policy_forward on >= 1 024 rows (a multiple of 16) takes 16 rows per workgroup (mlp_rows_act.h
                        //    policy_fwd16_kernel) -- another order of the sums over k than the 4-row form the fused acting kernels share:
                        //    off by default, DDPG.rollout_q_sum (the evaluator's Q pass) switches it on around its calls
+  int gather_dw;       // = N: curious_ddpg_grads with `next` on >= N rows puts the gather into the weight-gradient launch instead of the
+                       //    row-local one (mlp_host_update.h); default ROWS16_DEFAULT_MIN, 0 = never                      [CURIOUS_GATHER_DW]
   int dw_bal;          // = N: batches of >= N rows deal their small weight-gradient problems over the XCDs in halves, 3 segments each
                        //    (mlp_dw.h dw_role); default DW_BAL_MIN_B = 1 280, 0 = never                                  [CURIOUS_DW_BAL]
   int dw_split;        // 0: segments per tile of the weight-gradient launch's split reduction chosen by batch size (mlp_dw.h

@@ -175,7 +175,7 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
     }
     dwAll.stamps = nullptr;
     CURIOUS_CHECK(xd.nex == 1 || !tail, "batched experts need the fused update tail");
-    if (!tail && gather_in_dw && B > 256 && !dwAll.pbuf64 && her_lds_bytes(&her_rows.L) <= sizeof(float) * 4 * 16 * 64) {
+    if (!tail && gather_in_dw && !dwAll.pbuf64 && her_lds_bytes(&her_rows.L) <= sizeof(float) * 4 * 16 * 64) {
       // gradients only + the gather of the next batch (dw_adam_her_kernel<true, false, false>, mlp_dw.h)
       CURIOUS_CHECK(!copies_kept, "internal: the transposed copies are not maintained on this route");
       const int n_her = (her_rows.n + SPB - 1) / SPB;
@@ -184,10 +184,15 @@ int DdpgPass::weight_grads(const UpdateTail* tail) {
       AdamFuse none;
       memset(&none, 0, sizeof(none));
       { ProfScope ps__(CK_DW, st);
-        hipLaunchKernelGGL((dw_adam_her_kernel<true, false, false>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,
-                           hwAll.nprob, smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, units_s,
-                           reinterpret_cast<const int32_t*>(theta_main), reinterpret_cast<const int64_t*>(theta_main),
-                           (int64_t)xd.stride, dwAll, none, her_rows, (int64_t)xd.gstride, seed_stride); }
+#define DW_GRADS_HER(PIPE_)                                                                                      \
+  hipLaunchKernelGGL((dw_adam_her_kernel<PIPE_, false, false>), dim3(gx, xd.nex), dim3(256), 0, st, hwAll.tiles_per,  \
+                     hwAll.nprob, smAll.slots, smAll.nprob, n_her, map.r_her, map.r_hot, units_s,                 \
+                     reinterpret_cast<const int32_t*>(theta_main), reinterpret_cast<const int64_t*>(theta_main),  \
+                     (int64_t)xd.stride, dwAll, none, her_rows, (int64_t)xd.gstride, seed_stride)
+        if (B <= 256) DW_GRADS_HER(false);
+        else DW_GRADS_HER(true);
+#undef DW_GRADS_HER
+      }
       CURIOUS_LAUNCH_CHECK("dw_adam_her_kernel (gradients + gather)");
       gather_done = true;
       return 0;
@@ -297,7 +302,7 @@ static int ddpg_grads_impl(const curious_net_cfg_t* cfg, const float* theta_main
                        her_lds_bytes(next->L) <= rows_lds_floats(ROWS_R3, cfg->layers) * sizeof(float) &&
                        (B % (ROWS_R * 4) == 0) && SPB == ROWS_R;
     // batches of the 16-row form (several virtual ranks): the gather rides in the weight-gradient launch (mlp_dw.h)
-    if (p.gather_in_rows && xd.nex == 1 && curious_options().rows16 > 0 && B >= curious_options().rows16 && B % 256 == 0) {
+    if (p.gather_in_rows && xd.nex == 1 && curious_options().gather_dw > 0 && B >= curious_options().gather_dw && B % 256 == 0) {
       p.gather_in_rows = false;
       p.gather_in_dw = true;
     }
