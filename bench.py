@@ -39,6 +39,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-regime-line', action='store_true',
+                    help="the default run (N = 1, headline configuration, with the CPU baseline) also measures the reference's "
+                         "published --num_cpu 19 regime as 19 virtual ranks in a child process: skip that")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--prefill', type=int, default=2048, help='synthetic episodes pre-loaded per buffer')
     ap.add_argument('--env', default=ENV, help='diagnostic: another synthetic env (the headline is %s)' % ENV)
@@ -701,6 +704,41 @@ def ipc_probe(args, steps=10, timeout=100.0):
         return dict(error='%s: %s' % (type(err).__name__, err))
 
 
+def regime_line(args, ranks=19, steps=10, timeout=150.0):
+    """The default run's diagnostic: the reference's PUBLISHED regime (readme.md:16, `--num_cpu 19`) as 19 virtual ranks on
+    this GPU -- the one configuration in which the chip is loaded -- measured in a child process behind the timed region
+    (`bench.py --virtual-ranks 19`, a few cycles), so that the driver's own record carries it next to the headline.  A
+    failure there is reported, it does not take the line with it."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--virtual-ranks', str(ranks), '--steps', str(steps), '--warmup', '3',
+           '--no-cpu-baseline', '--no-regime-line']
+    if args.no_graph:
+        cmd.append('--no-graph')
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC_')}
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        try:
+            out, errtxt = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return dict(error='timed out after %.0f s' % timeout)
+        if p.returncode != 0:
+            return dict(error='child exited with %d: %s' % (p.returncode, errtxt.decode(errors='replace')[-300:]))
+        d = json.loads([ln for ln in out.decode().splitlines() if ln.startswith('{')][-1])
+        k = d.get('kernels', {})
+        return {'command': 'python bench.py --virtual-ranks %d --steps %d --warmup 3 --no-cpu-baseline' % (ranks, steps),
+                'what': "the reference's --num_cpu %d job on ONE GPU: %d private buffer sets / seeds / rollout groups, every "
+                        "update = %d minibatches of 256 in one launch sequence, gradients summed (diagnostic, not the headline)"
+                        % (ranks, ranks, ranks),
+                'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'ranks': ranks,
+                'roofline': {key: d['roofline'].get(key) for key in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                     'avg_launch_us')},
+                'kernels_avg_us': {name: round(v['avg_us'], 2) for name, v in k.items()
+                                   if name in ('ddpg_rows_kernel', 'dw_adam_her_kernel', 'policy_resident_kernel')}}
+    except Exception as err:                                       # a side measurement must never sink the bench line
+        return dict(error='%s: %s' % (type(err).__name__, err))
+
+
 def teardown(policies, bank=None):
     """Captured graphs hold the communicator's streams: drop them before the process group goes, then leave through the
     normal interpreter exit (curious_amd.experiment.train.shutdown)."""
@@ -877,6 +915,8 @@ def main():
             out['collectives'] = coll
         if phases:
             out['phases'] = phases
+        if headline and world == 1 and cpu is not None and not args.no_regime_line:
+            out['reference_regime'] = regime_line(args)
         if cpu is not None:
             out['cpu_baseline'] = cpu
         elif world > 1 or args.gpus > 1:
