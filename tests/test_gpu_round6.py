@@ -512,3 +512,17 @@ def test_several_rank_paths_of_eight_virtual_ranks_leave_the_same_bits():
     assert digests['fused'][0] == digests['eager'][0] == digests['captured'][0], digests
     assert digests['whole'][0] != digests['fused'][0]
     assert abs(digests['whole'][1] - digests['fused'][1]) <= 1e-3 * abs(digests['fused'][1]), digests
+
+
+def test_bench_default_line_carries_the_reference_regime():
+    """bench.regime_line: the diagnostic the default `python bench.py` adds to its JSON line -- the reference's published
+    `--num_cpu 19` job (readme.md:16) as 19 virtual ranks on this GPU, measured by a child process (here: 2 cycles)."""
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.regime_line(types.SimpleNamespace(no_graph=False), steps=2)
+    assert 'error' not in r, r
+    assert r['ranks'] == 19 and r['unit'] == 'transitions/s' and r['value'] > 1e7 and r['ms_per_step'] > 0
+    assert r['roofline']['bound'] == 'mfma' and 0.3 < r['roofline']['frac'] < 1.0
+    assert set(r['kernels_avg_us']) >= {'ddpg_rows_kernel', 'dw_adam_her_kernel'}
