@@ -1,4 +1,5 @@
-"""Build libcurious_hip.so (gfx950) in-tree with hipcc.  `python -m curious_amd.build [--force]`."""
+"""Build libcurious_hip.so (gfx950, hipcc) and libcurious_torch.so (the TORCH_LIBRARY face, g++) in-tree.
+`python -m curious_amd.build [--force]`."""
 import hashlib
 import os
 import subprocess
@@ -64,5 +65,44 @@ def build(force=False, verbose=True):
     return LIB
 
 
+TORCH_LIB = os.path.join(LIBDIR, 'libcurious_torch.so')
+TORCH_SRC = os.path.join(CSRC, 'torch_library.cpp')
+
+
+def _torch_digest():
+    import torch
+    h = hashlib.sha256()
+    for p in (TORCH_SRC, os.path.join(os.path.dirname(HERE), 'include', 'curious_hip.h')):
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()
+
+
+def build_torch_library(force=False, verbose=True):
+    """libcurious_torch.so: TORCH_LIBRARY(curious_hip, ...) over the C ABI (csrc/torch_library.cpp; host-only C++, g++ against
+    the headers of the installed torch; linked to libcurious_hip.so next to it).  Loaded by curious_amd/torch_ops.py."""
+    import torch
+    from torch.utils import cpp_extension
+    build(force=False, verbose=verbose)                           # (what it links to)
+    stamp = os.path.join(LIBDIR, 'build_torch.sha256')
+    dig = _torch_digest()
+    if not force and os.path.exists(TORCH_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return TORCH_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    cmd = [os.environ.get('CXX', 'g++'), '-shared', '-fPIC', '-std=c++17', '-O2', '-Wall', '-Wno-unused-function',
+           '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1', '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ['-I' + p for p in cpp_extension.include_paths()] + ['-I/opt/rocm/include']
+    cmd += [TORCH_SRC, '-o', TORCH_LIB, '-L' + tlib, '-lc10', '-ltorch_cpu', '-ltorch', '-lc10_hip', '-ltorch_hip',
+            '-L' + LIBDIR, '-lcurious_hip', '-Wl,-rpath,$ORIGIN', '-Wl,-rpath,' + tlib]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    return TORCH_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_torch_library(force='--force' in sys.argv))

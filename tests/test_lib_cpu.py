@@ -377,3 +377,24 @@ def test_round5_entry_points_host_code_without_gpu():
         assert L.curious_get_option(name) == dflt, name
         assert L.curious_set_option(name, 7) == 0 and L.curious_get_option(name) == 7
         assert L.curious_set_option(name, dflt) == 0
+
+
+def test_torch_library_loads_and_registers_every_op_without_a_gpu():
+    """curious_amd/lib/libcurious_torch.so (csrc/torch_library.cpp: TORCH_LIBRARY_FRAGMENT(curious_hip, ...) in C++ over the
+    C ABI) loads next to libcurious_hip.so and registers the tensor / scalar ops with aliasing schemas; the
+    descriptor ops join the same namespace from Python; there is no CPU implementation to fall back to."""
+    import torch
+    from curious_amd.build import build_torch_library
+    build_torch_library(verbose=False)
+    import curious_amd.torch_ops  # noqa: F401
+    native = ('polyak_update', 'adam_update', 'param_checksum', 'norm_update', 'norm_recompute', 'policy_forward', 'ddpg_grads')
+    for name in native + ('her_sample', 'ddpg_update', 'policy_rollout'):
+        assert hasattr(torch.ops.curious_hip, name), name
+    schema = str(torch.ops.curious_hip.polyak_update.default._schema)
+    assert 'Tensor(a!) target' in schema and 'float polyak' in schema, schema
+    assert '-> (Tensor, Tensor)' in str(torch.ops.curious_hip.ddpg_grads.default._schema)
+    # implemented in C++ (no Python kernel behind the CUDA key), nothing behind the CPU key
+    assert torch._C._dispatch_has_kernel_for_dispatch_key('curious_hip::polyak_update', 'CUDA')
+    assert not torch._C._dispatch_has_kernel_for_dispatch_key('curious_hip::polyak_update', 'CPU')
+    with pytest.raises(NotImplementedError):
+        torch.ops.curious_hip.polyak_update(torch.zeros(4), torch.zeros(4), 0.95)
