@@ -14,14 +14,24 @@
 //   torch.ops.curious_hip.policy_forward(cfg_i, cfg_f, theta, o, g, td, clip_obs, compute_Q) -> (pi, Q)      ddpg.py:129-146
 //   torch.ops.curious_hip.ddpg_grads(cfg_i, cfg_f, theta, theta_target, batch, batch_layout, grad) -> (losses, Q_pi)
 //                                                                                               ddpg.py:235-243, 419-449
-// The three hot entry points whose arguments are tables (her_sample, ddpg_update, policy_rollout) take a descriptor the
-// Python side files (torch_ops.desc_create) and are registered there, in the same namespace.
+// The three hot entry points take the reference's table-shaped arguments (record / batch layouts, task tables, sampler and
+// env descriptions), for which the dispatcher's schema language has no type: the caller files them ONCE as a descriptor --
+// a curious_torch_desc_t of pointers to the C ABI's own structs, registered here under an int64 handle
+// (desc_register / desc_release; curious_amd/torch_ops.py desc_create builds it and keeps what it points to alive) --
+// and the ops take the handle + tensors:
+//   torch.ops.curious_hip.her_sample(desc, storage, batch)                                      her.py:99-183, ddpg.py:326-353
+//   torch.ops.curious_hip.ddpg_update(desc, theta, theta_target, batch, workspace, grad, losses, Q_pi, m, v, step_ctr,
+//                                     alpha_tab, next_batch, storage, params_unchanged)         ddpg.py:235-248, mpi_adam.py:29-35
+//   torch.ops.curious_hip.policy_rollout(desc, theta, workspace, u_out, counter_base, episode, tasks, o, ag, g, td, staging,
+//                                        flags)                                                 rollout.py:226-303 x T
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "../../include/curious_hip.h"
 
@@ -148,9 +158,117 @@ std::tuple<at::Tensor, at::Tensor> ddpg_grads(at::IntArrayRef cfg_i, at::ArrayRe
   return std::make_tuple(losses, Q_pi);
 }
 
+// ------------------------------------------------------------------ descriptors of the three hot entry points
+// (mirrored field by field by curious_amd/torch_ops.py TorchDesc; pointers a given op does not need stay NULL)
+struct curious_torch_desc_t {
+  const curious_net_cfg_t* cfg; const curious_layout_t* L; const curious_batch_layout_t* BL;
+  const curious_tasks_t* tasks; const curious_sample_params_t* P; const curious_sample_rng_t* rng;
+  const curious_sample_plan_t* plan; const curious_env_cfg_t* E;
+  const float* o_stats; const float* g_stats;
+  int64_t buf_stride, tab_base;
+  uint64_t seed, counter;
+  double noise_scale, random_eps, reward_eps;
+  float clip_obs;
+  int32_t n, B, env_id0, t0, nsteps, off_change, off_success, relative_goals;
+};
+std::mutex g_desc_mutex;
+std::unordered_map<int64_t, const curious_torch_desc_t*> g_desc;
+int64_t g_desc_next = 1;
+
+int64_t desc_register(int64_t address) {
+  TORCH_CHECK(address != 0, "curious_hip::desc_register: NULL descriptor");
+  std::lock_guard<std::mutex> lock(g_desc_mutex);
+  g_desc[g_desc_next] = reinterpret_cast<const curious_torch_desc_t*>(address);
+  return g_desc_next++;
+}
+void desc_release(int64_t handle) {
+  std::lock_guard<std::mutex> lock(g_desc_mutex);
+  g_desc.erase(handle);
+}
+const curious_torch_desc_t& desc(int64_t handle) {
+  std::lock_guard<std::mutex> lock(g_desc_mutex);
+  auto it = g_desc.find(handle);
+  TORCH_CHECK(it != g_desc.end(), "curious_hip: unknown descriptor handle ", handle, " (torch_ops.desc_create)");
+  return *it->second;
+}
+
+void her_sample(int64_t handle, const at::Tensor& storage, at::Tensor batch) {
+  const curious_torch_desc_t& d = desc(handle);
+  TORCH_CHECK(d.L && d.BL && d.tasks && d.P && (d.rng || d.plan), "curious_hip::her_sample: the descriptor needs layout, tasks, "
+              "params and rng or plan");
+  dev(storage, "storage"); rows(batch, "batch");
+  TORCH_CHECK(batch.stride(0) == d.BL->stride && batch.size(0) >= d.n, "curious_hip::her_sample: batch is [>= n, batch stride]");
+  check(curious_her_sample(f32(storage), d.buf_stride, d.L, d.tasks, d.P, d.plan, d.plan ? nullptr : d.rng, d.n, f32(batch), d.BL,
+                           current_stream()), "curious_her_sample");
+}
+
+void ddpg_update(int64_t handle, at::Tensor theta, const at::Tensor& theta_target, const at::Tensor& batch, at::Tensor workspace,
+                 at::Tensor grad, at::Tensor losses, at::Tensor Q_pi, at::Tensor m, at::Tensor v, at::Tensor step_ctr,
+                 const at::Tensor& alpha_tab, at::Tensor next_batch, const at::Tensor& storage, bool params_unchanged) {
+  const curious_torch_desc_t& d = desc(handle);
+  TORCH_CHECK(d.cfg && d.L && d.BL && d.tasks && d.P && d.rng, "curious_hip::ddpg_update: the descriptor needs cfg, layout, tasks, "
+              "params and rng");
+  dev(theta, "theta"); dev(theta_target, "theta_target"); rows(batch, "batch"); dev(workspace, "workspace"); dev(grad, "grad");
+  dev(losses, "losses"); dev(Q_pi, "Q_pi"); dev(m, "m"); dev(v, "v"); dev(step_ctr, "step_ctr", at::kLong);
+  dev(alpha_tab, "alpha_tab"); rows(next_batch, "next_batch"); dev(storage, "storage");
+  const int64_t total = curious_param_total(d.cfg);
+  TORCH_CHECK(theta.numel() >= total && theta_target.numel() >= total && grad.numel() >= total && m.numel() >= total &&
+                  v.numel() >= total, "curious_hip::ddpg_update: parameter vectors shorter than the networks");
+  TORCH_CHECK(batch.size(0) >= d.B && batch.stride(0) == d.BL->stride && next_batch.size(0) >= d.B &&
+                  next_batch.stride(0) == d.BL->stride && next_batch.data_ptr() != batch.data_ptr(),
+              "curious_hip::ddpg_update: batch / next_batch are two staging tensors [B, batch stride]");
+  TORCH_CHECK(workspace.numel() >= curious_workspace_floats(d.cfg, d.B) && Q_pi.numel() >= d.B && alpha_tab.dim() == 2 &&
+                  alpha_tab.size(1) == 2, "curious_hip::ddpg_update: workspace / Q_pi / alpha_tab [len, 2] too small");
+  curious_adam_state_t A;
+  std::memset(&A, 0, sizeof(A));
+  A.m = f32(m); A.v = f32(v); A.alpha_tab = f32(alpha_tab); A.tab_base = d.tab_base; A.tab_len = (int32_t)alpha_tab.size(0);
+  A.beta1 = 0.9f; A.one_minus_beta1 = (float)(1 - 0.9); A.beta2 = 0.999f; A.one_minus_beta2 = (float)(1 - 0.999);
+  A.epsilon = 1e-08f; A.params_unchanged = params_unchanged ? 1 : 0;
+  curious_next_batch_t N;
+  N.storage = f32(storage); N.buf_stride = d.buf_stride; N.L = d.L; N.tasks = d.tasks; N.P = d.P; N.rng = d.rng;
+  N.batch = f32(next_batch);
+  check(curious_ddpg_update(d.cfg, f32(theta), f32(theta_target), f32(batch), d.BL, d.B, d.o_stats, d.g_stats, f32(workspace),
+                            f32(grad), f32(losses), f32(Q_pi), step_ctr.data_ptr<int64_t>(), &A, &N, current_stream()),
+        "curious_ddpg_update");
+}
+
+void policy_rollout(int64_t handle, const at::Tensor& theta, at::Tensor workspace, at::Tensor u_out, const at::Tensor& counter_base,
+                    at::Tensor episode, const at::Tensor& tasks, at::Tensor o, at::Tensor ag, const at::Tensor& g,
+                    const at::Tensor& td, at::Tensor staging, at::Tensor flags) {
+  const curious_torch_desc_t& d = desc(handle);
+  TORCH_CHECK(d.cfg && d.E && d.L && d.n > 0 && d.nsteps > 0, "curious_hip::policy_rollout: the descriptor needs cfg, ecfg, layout, n, "
+              "nsteps");
+  dev(theta, "theta"); dev(workspace, "workspace"); rows(u_out, "u_out"); dev(counter_base, "counter_base", at::kLong);
+  dev(episode, "episode", at::kInt); dev(tasks, "tasks", at::kInt); dev(o, "o"); dev(ag, "ag"); dev(g, "g"); dev(td, "td");
+  dev(staging, "staging"); dev(flags, "flags");
+  TORCH_CHECK(u_out.size(0) >= d.n && episode.numel() >= d.n && tasks.numel() >= d.n && flags.numel() > d.n,
+              "curious_hip::policy_rollout: per-env tensors shorter than n");
+  if (d.o_stats || d.g_stats || d.relative_goals)
+    check(curious_policy_rollout_stats(d.cfg, f32(theta), d.n, d.clip_obs, f32(workspace), d.noise_scale, d.random_eps, d.seed,
+                                       d.counter, counter_base.data_ptr<int64_t>(), f32(u_out), (int32_t)u_out.stride(0), d.E,
+                                       d.L, d.env_id0, episode.data_ptr<int32_t>(), tasks.data_ptr<int32_t>(), d.t0, d.nsteps,
+                                       f32(o), f32(ag), f32(g), f32(td), f32(staging), d.off_change, d.off_success,
+                                       d.reward_eps, f32(flags), d.relative_goals, d.o_stats, d.g_stats, current_stream()),
+          "curious_policy_rollout_stats");
+  else
+    check(curious_policy_rollout(d.cfg, f32(theta), d.n, d.clip_obs, f32(workspace), d.noise_scale, d.random_eps, d.seed,
+                                 d.counter, counter_base.data_ptr<int64_t>(), f32(u_out), (int32_t)u_out.stride(0), d.E, d.L,
+                                 d.env_id0, episode.data_ptr<int32_t>(), tasks.data_ptr<int32_t>(), d.t0, d.nsteps, f32(o),
+                                 f32(ag), f32(g), f32(td), f32(staging), d.off_change, d.off_success, d.reward_eps, f32(flags),
+                                 current_stream()), "curious_policy_rollout");
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(curious_hip, m) {
+  m.def("desc_register(int address) -> int", &desc_register);
+  m.def("desc_release(int handle) -> ()", &desc_release);
+  m.def("her_sample(int desc, Tensor storage, Tensor(a!) batch) -> ()");
+  m.def("ddpg_update(int desc, Tensor(a!) theta, Tensor theta_target, Tensor batch, Tensor(b!) workspace, Tensor(c!) grad, "
+        "Tensor(d!) losses, Tensor(e!) Q_pi, Tensor(f!) m, Tensor(g!) v, Tensor(h!) step_ctr, Tensor alpha_tab, "
+        "Tensor(i!) next_batch, Tensor storage, bool params_unchanged) -> ()");
+  m.def("policy_rollout(int desc, Tensor theta, Tensor(a!) workspace, Tensor(b!) u_out, Tensor counter_base, Tensor(c!) episode, "
+        "Tensor tasks, Tensor(d!) o, Tensor(e!) ag, Tensor g, Tensor td, Tensor(f!) staging, Tensor(g!) flags) -> ()");
   m.def("polyak_update(Tensor(a!) target, Tensor main, float polyak) -> ()");
   m.def("adam_update(Tensor(a!) theta, Tensor(b!) m, Tensor(c!) v, Tensor grad, int n_Q, int n_pi, float alpha_Q, "
         "float alpha_pi) -> ()");
@@ -171,4 +289,7 @@ TORCH_LIBRARY_IMPL(curious_hip, CUDA, m) {
   m.impl("norm_recompute", &norm_recompute);
   m.impl("policy_forward", &policy_forward);
   m.impl("ddpg_grads", &ddpg_grads);
+  m.impl("her_sample", &her_sample);
+  m.impl("ddpg_update", &ddpg_update);
+  m.impl("policy_rollout", &policy_rollout);
 }

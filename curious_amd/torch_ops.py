@@ -19,8 +19,8 @@ context, schema aliasing (`Tensor(a!)`), and a call into the same `libcurious_hi
 
 The three HOT entry points take the reference's table-shaped arguments (record / batch layouts, task tables, sampler
 descriptions) -- the dispatcher's schema language has no struct type.  They get an opaque DESCRIPTOR instead (round 4):
-`desc_create(...)` files the structs once and returns an int64 handle, the ops (registered here, in the same namespace, with
-`torch.library.custom_op`) then take the handle + tensors:
+`desc_create(...)` files the structs once (a `curious_torch_desc_t` of pointers to them, registered with the C++ library) and
+returns an int64 handle; the ops -- native as well -- then take the handle + tensors:
 
     d = torch_ops.desc_create(layout=..., tasks=..., params=..., rng=..., buf_stride=..., n=...)
     torch.ops.curious_hip.her_sample(d, storage, batch)                                   # her.py:99-183, ddpg.py:326-353
@@ -35,11 +35,12 @@ descriptions) -- the dispatcher's schema language has no struct type.  They get 
 The remaining struct-carrying entry points (`curious_store_episodes`, the env reset / step kernels, the batched experts)
 stay on the ctypes binding (curious_amd/ops.py).  Every face calls the same symbols; there is no second implementation.
 """
+import ctypes as C
 import os
 
 import torch
 
-from curious_amd import _lib, ops
+from curious_amd import _lib
 from curious_amd._lib import lib
 
 _NS = 'curious_hip'
@@ -76,59 +77,55 @@ def _(cfg_i, cfg_f, theta, theta_target, batch, batch_layout, grad):
     return batch.new_empty(2), batch.new_empty([batch.shape[0], 1])
 
 
-# ------------------------------------------------------------------ descriptor-carrying ops (the three hot entry points)
+# ------------------------------------------------------------------ descriptors of the three hot entry points
+class TorchDesc(C.Structure):
+    """curious_torch_desc_t of csrc/torch_library.cpp, field by field: pointers to the C ABI's own structs + the scalars of
+    the hot entry points.  Pointers an op does not need stay NULL."""
+    _fields_ = [('cfg', C.c_void_p), ('L', C.c_void_p), ('BL', C.c_void_p), ('tasks', C.c_void_p), ('P', C.c_void_p),
+                ('rng', C.c_void_p), ('plan', C.c_void_p), ('E', C.c_void_p), ('o_stats', C.c_void_p),
+                ('g_stats', C.c_void_p), ('buf_stride', C.c_int64), ('tab_base', C.c_int64), ('seed', C.c_uint64),
+                ('counter', C.c_uint64), ('noise_scale', C.c_double), ('random_eps', C.c_double),
+                ('reward_eps', C.c_double), ('clip_obs', C.c_float), ('n', C.c_int32), ('B', C.c_int32),
+                ('env_id0', C.c_int32), ('t0', C.c_int32), ('nsteps', C.c_int32), ('off_change', C.c_int32),
+                ('off_success', C.c_int32), ('relative_goals', C.c_int32)]
+
+
 _DESCS = {}
 
 
-def desc_create(**fields):
+def desc_create(layout=None, tasks=None, params=None, rng=None, plan=None, cfg=None, ecfg=None, o_stats=None, g_stats=None,
+                buf_stride=0, tab_base=0, n=0, B=0, clip_obs=0.0, noise_scale=0.0, random_eps=0.0, seed=0, counter=0,
+                env_id0=0, t0=0, nsteps=0, reward_eps=0.0, relative_goals=False, keep=None):
     """File the struct-shaped arguments of a hot entry point (layouts, task tables, sampler / env descriptions, scalars)
-    and return an int64 handle for the ops below.  The descriptor keeps what it is given alive (e.g. the device tables a
-    SampleRng points into, through `keep=`)."""
-    h = (max(_DESCS) + 1) if _DESCS else 1
-    _DESCS[h] = dict(fields)
+    ONCE and return an int64 handle for torch.ops.curious_hip.{her_sample, ddpg_update, policy_rollout}.  The descriptor
+    keeps what it is given alive (e.g. the device tables a SampleRng points into, through `keep=`) until desc_free."""
+    d = TorchDesc()
+    held = [layout, tasks, params, rng, plan, cfg, ecfg, o_stats, g_stats, keep]
+    if layout is not None:
+        L = layout.c_layout()
+        d.L = C.addressof(L)
+        held.append(L)
+        if getattr(layout, 'batch_cols', None) is not None:
+            BL = layout.c_batch_layout()
+            d.BL = C.addressof(BL)
+            held.append(BL)
+        d.off_change = int(layout.off.get('change', 0))
+        d.off_success = int(layout.off.get('info_is_success', 0))
+    for name, obj in (('tasks', tasks), ('P', params), ('rng', rng), ('plan', plan), ('cfg', cfg), ('E', ecfg)):
+        if obj is not None:
+            setattr(d, name, C.addressof(obj))
+    d.o_stats = o_stats.data_ptr() if o_stats is not None else None
+    d.g_stats = g_stats.data_ptr() if g_stats is not None else None
+    d.buf_stride, d.tab_base = int(buf_stride), int(tab_base)
+    d.seed, d.counter = int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter) & 0xFFFFFFFFFFFFFFFF
+    d.noise_scale, d.random_eps, d.reward_eps, d.clip_obs = float(noise_scale), float(random_eps), float(reward_eps), float(clip_obs)
+    d.n, d.B, d.env_id0, d.t0, d.nsteps = int(n), int(B), int(env_id0), int(t0), int(nsteps)
+    d.relative_goals = int(bool(relative_goals))
+    h = int(torch.ops.curious_hip.desc_register(C.addressof(d)))
+    _DESCS[h] = (d, held)
     return h
 
 
 def desc_free(handle):
-    _DESCS.pop(int(handle), None)
-
-
-def _desc(handle):
-    try:
-        return _DESCS[int(handle)]
-    except KeyError:
-        raise _lib.CuriousHipError('unknown descriptor handle %r (torch_ops.desc_create)' % (handle,))
-
-
-@torch.library.custom_op(_NS + '::her_sample', mutates_args=('batch',), device_types='cuda')
-def her_sample(desc: int, storage: torch.Tensor, batch: torch.Tensor) -> None:
-    d = _desc(desc)                                                                  # her.py:99-183, ddpg.py:326-353
-    ops.her_sample(storage, d['buf_stride'], d['layout'], d['tasks'], d['params'], d['n'], batch, plan=d.get('plan'),
-                   rng=d.get('rng'))
-
-
-@torch.library.custom_op(_NS + '::ddpg_update',
-                         mutates_args=('theta', 'workspace', 'grad', 'losses', 'Q_pi', 'm', 'v', 'step_ctr', 'next_batch'),
-                         device_types='cuda')
-def ddpg_update(desc: int, theta: torch.Tensor, theta_target: torch.Tensor, batch: torch.Tensor, workspace: torch.Tensor,
-                grad: torch.Tensor, losses: torch.Tensor, Q_pi: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
-                step_ctr: torch.Tensor, alpha_tab: torch.Tensor, next_batch: torch.Tensor, storage: torch.Tensor,
-                params_unchanged: bool) -> None:
-    d = _desc(desc)                                                                  # ddpg.py:235-248, mpi_adam.py:29-35
-    ops.ddpg_update(d['cfg'], theta, theta_target, batch, d['layout'], d['B'], workspace, grad, losses, Q_pi, m, v,
-                    step_ctr=step_ctr, alpha_tab=alpha_tab, tab_base=d.get('tab_base', 0), o_stats=d.get('o_stats'),
-                    g_stats=d.get('g_stats'), next_batch=next_batch, storage=storage, buf_stride=d['buf_stride'],
-                    tasks=d['tasks'], params=d['params'], rng=d['rng'], params_unchanged=params_unchanged)
-
-
-@torch.library.custom_op(_NS + '::policy_rollout',
-                         mutates_args=('workspace', 'u_out', 'episode', 'o', 'ag', 'staging', 'flags'), device_types='cuda')
-def policy_rollout(desc: int, theta: torch.Tensor, workspace: torch.Tensor, u_out: torch.Tensor,
-                   counter_base: torch.Tensor, episode: torch.Tensor, tasks: torch.Tensor, o: torch.Tensor,
-                   ag: torch.Tensor, g: torch.Tensor, td: torch.Tensor, staging: torch.Tensor, flags: torch.Tensor) -> None:
-    d = _desc(desc)                                                                  # rollout.py:226-303 for every env
-    ops.policy_rollout(d['cfg'], theta, d['n'], d['clip_obs'], workspace, d['noise_scale'], d['random_eps'], d['seed'],
-                       d['counter'], u_out, d['ecfg'], d['layout'], d['env_id0'], episode, tasks, d['t0'], d['nsteps'],
-                       o, ag, g, td, staging, d['reward_eps'], counter_base=counter_base, flags=flags,
-                       o_stats=d.get('o_stats'), g_stats=d.get('g_stats'),
-                       relative_goals=bool(d.get('relative_goals', False)))
+    if _DESCS.pop(int(handle), None) is not None:
+        torch.ops.curious_hip.desc_release(int(handle))

@@ -1,4 +1,5 @@
 """CPU-side checks of the C-ABI library: it builds, loads, and exports every declared symbol."""
+import ctypes as C
 import os
 import re
 
@@ -381,14 +382,15 @@ def test_round5_entry_points_host_code_without_gpu():
 
 def test_torch_library_loads_and_registers_every_op_without_a_gpu():
     """curious_amd/lib/libcurious_torch.so (csrc/torch_library.cpp: TORCH_LIBRARY_FRAGMENT(curious_hip, ...) in C++ over the
-    C ABI) loads next to libcurious_hip.so and registers the tensor / scalar ops with aliasing schemas; the
-    descriptor ops join the same namespace from Python; there is no CPU implementation to fall back to."""
+    C ABI) loads next to libcurious_hip.so and registers every op with its aliasing schema -- the tensor / scalar
+    ops and the three hot entry points behind a registered descriptor; there is no CPU implementation to fall back to; an
+    unknown descriptor handle is an error, not a wild pointer."""
     import torch
     from curious_amd.build import build_torch_library
     build_torch_library(verbose=False)
     import curious_amd.torch_ops  # noqa: F401
     native = ('polyak_update', 'adam_update', 'param_checksum', 'norm_update', 'norm_recompute', 'policy_forward', 'ddpg_grads')
-    for name in native + ('her_sample', 'ddpg_update', 'policy_rollout'):
+    for name in native + ('her_sample', 'ddpg_update', 'policy_rollout', 'desc_register', 'desc_release'):
         assert hasattr(torch.ops.curious_hip, name), name
     schema = str(torch.ops.curious_hip.polyak_update.default._schema)
     assert 'Tensor(a!) target' in schema and 'float polyak' in schema, schema
@@ -398,3 +400,9 @@ def test_torch_library_loads_and_registers_every_op_without_a_gpu():
     assert not torch._C._dispatch_has_kernel_for_dispatch_key('curious_hip::polyak_update', 'CPU')
     with pytest.raises(NotImplementedError):
         torch.ops.curious_hip.polyak_update(torch.zeros(4), torch.zeros(4), 0.95)
+    import curious_amd.torch_ops as T
+    h = T.desc_create(n=3, B=5, seed=2 ** 63 + 1)
+    assert h in T._DESCS and T._DESCS[h][0].n == 3 and T._DESCS[h][0].seed == 2 ** 63 + 1
+    T.desc_free(h)
+    assert h not in T._DESCS
+    assert C.sizeof(T.TorchDesc) == 176                                 # (curious_torch_desc_t: 10 pointers, 4 x 8, 3 doubles, float, 8 x int32)
